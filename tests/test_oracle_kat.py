@@ -1,0 +1,194 @@
+"""Known-answer tests that pin the oracle.  The reference has no fixtures for
+this path (parity unpinned), so these analytic cases are what anchors both oracle restatements."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from oracle import gdkvm_oracle as O
+from tests.util import make_kpff_inputs, make_scan_inputs
+
+RULES = [O.RULE_GATED_LINEAR, O.RULE_DELTA_PARALLEL, O.RULE_DELTA_SEQUENTIAL]
+
+
+def _unit(d, i):
+    e = np.zeros(d); e[i] = 1.0
+    return e
+
+
+def _one(q, k, v, a, b, **kw):
+    """Single clip/head convenience: q,k [T,N,Dk] v [T,N,Dv] a [T] b [T,N]."""
+    R, S = O.scan(q[None, :, :, None], k[None, :, :, None], v[None, :, :, None], a[None, :, None],
+                  b[None, :, :, None], **kw)
+    return R[0, :, :, 0], S[0, 0]
+
+
+def test_k1_recall():
+    Dk, Dv = 8, 5
+    k = _unit(Dk, 3)[None, None].repeat(2, 0)            # T=2, N=1
+    v = np.arange(1, Dv + 1, dtype=float)[None, None].repeat(2, 0)
+    R, S = _one(k, k, v, np.ones(2), np.ones((2, 1)))
+    assert np.array_equal(R[0, 0], np.zeros(Dv))         # frame 0 reads the empty state
+    assert np.array_equal(R[1, 0], v[0, 0])              # frame 1 recalls exactly what frame 0 wrote
+
+
+def test_k2_overwrite_vs_accumulate():
+    Dk, Dv = 4, 3
+    k = _unit(Dk, 1)[None, None].repeat(3, 0)
+    v = np.stack([np.full(Dv, 1.0), np.full(Dv, 5.0), np.zeros(Dv)])[:, None]
+    a, b = np.ones(3), np.ones((3, 1))
+    R, _ = _one(k, k, v, a, b, rule=O.RULE_DELTA_SEQUENTIAL)
+    assert np.array_equal(R[2, 0], v[1, 0])              # delta rule: second write replaces the first
+    R, _ = _one(k, k, v, a, b, rule=O.RULE_GATED_LINEAR)
+    assert np.array_equal(R[2, 0], v[0, 0] + v[1, 0])    # purely additive rule accumulates
+
+
+def test_k3_orthonormal_keys():
+    rng = np.random.default_rng(0)
+    Dk, Dv, n = 16, 7, 16
+    Qm, _ = np.linalg.qr(rng.standard_normal((Dk, Dk)))
+    k = Qm[:n][None]                                      # T=1 frame of n orthonormal keys
+    v = rng.standard_normal((1, n, Dv))
+    k2 = np.concatenate([k, k]); v2 = np.concatenate([v, v])
+    for rule in RULES:
+        R, _ = _one(k2, k2, v2, np.ones(2), np.ones((2, n)), rule=rule)
+        np.testing.assert_allclose(R[1], v[0], atol=1e-12)
+
+
+def test_k4_alpha_zero_resets():
+    q, k, v, a, b = make_scan_inputs(1, 3, 6, 1, 8, 4, seed=1)
+    a = a.copy(); a[0, 2, 0] = 0.0
+    _, S = O.scan(q, k, v, a, b)
+    _, S_last = O.scan(q[:, 2:], k[:, 2:], v[:, 2:], a[:, 2:], b[:, 2:])
+    np.testing.assert_allclose(S, S_last, atol=1e-14)
+
+
+def test_k5_beta_zero_is_pure_decay():
+    q, k, v, a, b = make_scan_inputs(2, 2, 5, 2, 8, 4, seed=2)
+    s0 = np.random.default_rng(3).standard_normal((2, 2, 8, 4))
+    for rule in RULES:
+        _, S = O.scan(q, k, v, a, np.zeros_like(b), s0=s0, rule=rule)
+        a64 = a.astype(np.float64)
+        np.testing.assert_allclose(S, s0 * a64[:, 0, :, None, None] * a64[:, 1, :, None, None], rtol=1e-14)
+
+
+@pytest.mark.parametrize("rule", RULES)
+def test_k6_chunk_carry_bit_identity(rule):
+    q, k, v, a, b = make_scan_inputs(2, 6, 7, 2, 8, 5, seed=4)
+    R, S = O.scan(q, k, v, a, b, rule=rule, dtype=np.float32)
+    R1, S1 = O.scan(q[:, :2], k[:, :2], v[:, :2], a[:, :2], b[:, :2], rule=rule, dtype=np.float32)
+    R2, S2 = O.scan(q[:, 2:], k[:, 2:], v[:, 2:], a[:, 2:], b[:, 2:], s0=S1, rule=rule, dtype=np.float32)
+    assert np.array_equal(np.concatenate([R1, R2], 1), R) and np.array_equal(S2, S)
+
+
+@pytest.mark.parametrize("rule", RULES)
+@pytest.mark.parametrize("corr", [0.0, 0.8])
+def test_k7_wy_equals_sequential(rule, corr):
+    q, k, v, a, b = make_scan_inputs(2, 4, 49, 1, 64, 32, seed=5, corr=corr)
+    k = O.l2_normalize(k)
+    Rs, Ss = O.scan(q, k, v, a, b, rule=rule, form="sequential")
+    Rc, Sc = O.scan(q, k, v, a, b, rule=rule, form="chunk")
+    np.testing.assert_allclose(Rc, Rs, atol=1e-9); np.testing.assert_allclose(Sc, Ss, atol=1e-9)
+    Rc32, Sc32 = O.scan(q, k, v, a, b, rule=rule, form="chunk", dtype=np.float32)
+    np.testing.assert_allclose(Rc32, Rs, atol=1e-4); np.testing.assert_allclose(Sc32, Ss, atol=1e-4)
+
+
+def test_k8_dv_slice_independence_and_batch_equivariance():
+    q, k, v, a, b = make_scan_inputs(3, 3, 9, 2, 8, 12, seed=6)
+    R, S = O.scan(q, k, v, a, b)
+    Rh, Sh = O.scan(q, k, v[..., 4:8], a, b)
+    assert np.array_equal(Rh, R[..., 4:8]) and np.array_equal(Sh, S[..., 4:8])
+    perm = [2, 0, 1]
+    Rp, Sp = O.scan(q[perm], k[perm], v[perm], a[perm], b[perm])
+    assert np.array_equal(Rp, R[perm]) and np.array_equal(Sp, S[perm])
+
+
+def test_k9_argmax_ties_lowest_index():
+    logits = np.zeros((1, 4, 2, 3), dtype=np.float32)
+    logits[0, 2, 0, 0] = 1.0; logits[0, 3, 0, 0] = 1.0      # tie between 2 and 3 -> 2
+    logits[0, 1, 1, 1] = -0.0                                # -0.0 == 0.0 -> still class 0
+    m = O.argmax_mask(logits)
+    assert m[0, 0, 0] == 2 and m[0, 1, 1] == 0 and m.sum() == 2
+    mc, _ = c_oracle.argmax_dice(logits)
+    assert np.array_equal(mc, m)
+
+
+def test_k10_dice_edge_cases():
+    z = np.zeros((1, 4, 4), dtype=np.uint8)
+    one = np.ones((1, 4, 4), dtype=np.uint8)
+    d = O.dice_from_counts(*O.dice_counts(z, z, 2))
+    assert d[0, 0] == pytest.approx(1.0) and d[0, 1] == 1.0           # class 1: both empty -> 1
+    d = O.dice_from_counts(*O.dice_counts(z, one, 2))
+    assert d[0, 0] < 1e-6 and d[0, 1] < 1e-6                          # disjoint -> 0
+    half = z.copy(); half[0, :2] = 1
+    d = O.dice_from_counts(*O.dice_counts(half, half, 2))
+    np.testing.assert_allclose(d, 1.0)
+
+
+def test_k11_fp64_vs_fp32_cfg1():
+    q, k, v, a, b = make_scan_inputs(1, 8, 49, 1, 64, 256, seed=0)
+    R64, S64 = O.scan(q, k, v, a, b)
+    R32, S32 = O.scan(q, k, v, a, b, dtype=np.float32)
+    assert np.abs(R32 - R64).max() <= 1e-5 and np.abs(S32 - S64).max() <= 1e-5
+
+
+# ------------------------------------------------------------- C restatement vs numpy restatement
+@pytest.mark.parametrize("rule", RULES)
+@pytest.mark.parametrize("flags", [0, 3])
+def test_c_oracle_matches_numpy_scan(rule, flags):
+    q, k, v, a, b = make_scan_inputs(2, 3, 10, 2, 16, 8, seed=7, normalized=not flags, logits=bool(flags))
+    s0 = np.random.default_rng(8).standard_normal((2, 2, 16, 8)).astype(np.float32)
+    R, S = O.scan(q, k, v, a, b, s0=s0, rule=rule, flags=flags)
+    Rc, Sc = c_oracle.scan(q, k, v, a, b, s0=s0, rule=rule, flags=flags, math="f64")
+    np.testing.assert_allclose(Rc, R, atol=2e-6); np.testing.assert_allclose(Sc, S, atol=2e-6)
+    Rc, Sc = c_oracle.scan(q, k, v, a, b, s0=s0, rule=rule, flags=flags, math="f32")
+    np.testing.assert_allclose(Rc, R, atol=1e-4); np.testing.assert_allclose(Sc, S, atol=1e-4)
+
+
+def test_c_oracle_empty_inputs():
+    for shape in [(0, 2, 4), (2, 0, 4), (2, 2, 0)]:
+        B, T, N = shape
+        q, k, v, a, b = make_scan_inputs(B, T, N, 1, 8, 4)
+        s0 = np.ones((B, 1, 8, 4), dtype=np.float32)
+        R, S = c_oracle.scan(q, k, v, a, b, s0=s0)
+        assert R.shape == (B, T, N, 1, 4)
+        Rn, Sn = O.scan(q, k, v, a, b, s0=s0)
+        np.testing.assert_allclose(S, Sn, atol=1e-6)
+
+
+@pytest.mark.parametrize("hw", [(7, 7), (4, 4), (5, 3), (1, 1)])
+def test_c_oracle_matches_numpy_kpff(hw):
+    h, w = hw
+    L, G, P, Wa, ba, Wl, Wg = make_kpff_inputs(3, h, w, 8, 12, 16, seed=9)
+    F = O.kpff(L, G, P, Wa, ba, Wl, Wg, h, w)
+    Fc = c_oracle.kpff(L, G, P, Wa, ba, Wl, Wg, h, w)
+    np.testing.assert_allclose(Fc, F, atol=2e-6)
+
+
+def test_kpff_known_answers():
+    # zero mixing weights -> F == P ; constant G -> multi-scale pooling is the identity
+    L, G, P, Wa, ba, Wl, Wg = make_kpff_inputs(2, 7, 7, 8, 12, 16, seed=10)
+    F = O.kpff(L, G, P, Wa, ba, 0 * Wl, 0 * Wg, 7, 7)
+    assert np.array_equal(F, P.astype(np.float64))
+    Gc = np.broadcast_to(G[:, :1], G.shape)
+    np.testing.assert_allclose(O.multiscale_pool(Gc.astype(np.float64), 7, 7), Gc, atol=1e-12)
+    # pooling preserves the frame mean only when cells tile the grid exactly (4x4 with s in {1,2,4})
+    G4 = np.random.default_rng(0).standard_normal((1, 16, 3))
+    np.testing.assert_allclose(O.multiscale_pool(G4, 4, 4).mean(1), G4.mean(1), atol=1e-12)
+
+
+def test_argmax_dice_c_matches_numpy():
+    rng = np.random.default_rng(11)
+    logits = rng.standard_normal((5, 4, 9, 11)).astype(np.float32)
+    logits[:, :, ::3] = np.round(logits[:, :, ::3])          # provoke exact ties
+    target = rng.integers(0, 4, (5, 9, 11)).astype(np.uint8)
+    m, counts = c_oracle.argmax_dice(logits, target)
+    assert np.array_equal(m, O.argmax_mask(logits))
+    i, p, t = O.dice_counts(m, target, 4)
+    assert np.array_equal(counts[..., 0], i) and np.array_equal(counts[..., 1], p) and np.array_equal(counts[..., 2], t)
+
+
+def test_bf16_rounding_helper():
+    import torch
+    x = np.random.default_rng(12).standard_normal(4096).astype(np.float32) * 100
+    ref = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
+    assert np.array_equal(O.to_bf16_f32(x), ref)
