@@ -1,0 +1,127 @@
+// argmax_dice.hip -- SURVEY.md §8 row a6: mask = argmax_c logits (ties -> lowest class index) and exact
+// integer Dice counts.  HBM-bound: every logit is read once with 8/16-byte loads, the mask is written
+// once; counts are reduced wave-wide with ballots, per block in LDS, then one integer atomic per
+// (block, class, kind) -- integer adds commute, so the result is bit-reproducible.
+#include "gdkvm_common.hpp"
+
+namespace {
+
+struct AdArgs {
+    const void* logits; const uint8_t* target; uint8_t* mask; int32_t* counts;
+    int ncls, HW;
+};
+
+template <int IO, int VEC>
+__global__ __launch_bounds__(256) void argmax_dice_kernel(AdArgs a)
+{
+    extern __shared__ int s_cnt[];                       // [ncls][3]
+    const int f = blockIdx.y, ncls = a.ncls, HW = a.HW;
+    const bool dice = a.target != nullptr;
+    if (dice) {
+        for (int i = threadIdx.x; i < ncls * 3; i += 256) s_cnt[i] = 0;
+        __syncthreads();
+    }
+    const size_t base = (size_t)f * ncls * HW;
+    const int nvec = (HW + VEC - 1) / VEC;
+    for (int pv = blockIdx.x * 256 + threadIdx.x; pv < ((nvec + 255) / 256) * 256; pv += gridDim.x * 256) {
+        const int p = pv * VEC;
+        const bool act = pv < nvec;
+        float best[VEC];
+        int arg[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { best[e] = 0.f; arg[e] = 0; }
+        if (act) {
+            for (int c = 0; c < ncls; ++c) {
+                float x[VEC];
+                if constexpr (VEC == 4) {
+                    const f32x4 v = load4<IO>(a.logits, base + (size_t)c * HW + p);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[e] = v[e];
+                } else {
+                    x[0] = load1<IO>(a.logits, base + (size_t)c * HW + p);
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    if (c == 0 || x[e] > best[e]) { best[e] = x[e]; arg[e] = c; }   // strict > keeps the lowest index
+            }
+            if constexpr (VEC == 4) {
+                *reinterpret_cast<uchar4*>(a.mask + (size_t)f * HW + p) =
+                    make_uchar4((unsigned char)arg[0], (unsigned char)arg[1], (unsigned char)arg[2], (unsigned char)arg[3]);
+            } else {
+                a.mask[(size_t)f * HW + p] = (uint8_t)arg[0];
+            }
+        }
+        if (dice) {
+            int tc[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) tc[e] = -1;
+            if (act) {
+                if constexpr (VEC == 4) {
+                    const uchar4 t4 = *reinterpret_cast<const uchar4*>(a.target + (size_t)f * HW + p);
+                    tc[0] = t4.x; tc[1] = t4.y; tc[2] = t4.z; tc[3] = t4.w;
+                } else {
+                    tc[0] = a.target[(size_t)f * HW + p];
+                }
+            }
+            for (int c = 0; c < ncls; ++c) {
+                int ni = 0, np = 0, nt = 0;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const unsigned long long mp = __ballot(act && arg[e] == c);
+                    const unsigned long long mt = __ballot(tc[e] == c);
+                    np += __popcll(mp); nt += __popcll(mt); ni += __popcll(mp & mt);
+                }
+                if ((threadIdx.x & 63) == 0 && (np | nt)) {
+                    if (ni) atomicAdd(&s_cnt[c * 3 + 0], ni);
+                    if (np) atomicAdd(&s_cnt[c * 3 + 1], np);
+                    if (nt) atomicAdd(&s_cnt[c * 3 + 2], nt);
+                }
+            }
+        }
+    }
+    if (dice) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < ncls * 3; i += 256)
+            if (s_cnt[i]) atomicAdd(&a.counts[(size_t)f * ncls * 3 + i], s_cnt[i]);
+    }
+}
+
+}  // namespace
+
+extern "C" int gdkvm_argmax_dice(const void* logits, const uint8_t* target, uint8_t* mask, int32_t* counts,
+                                 int BT, int ncls, int H, int W, int io_dtype, void* stream)
+{
+    if (BT < 0 || ncls <= 0 || ncls > 255 || H <= 0 || W <= 0)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "argmax_dice: bad shape BT=%d ncls=%d H=%d W=%d", BT, ncls, H, W);
+    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "argmax_dice: io_dtype=%d", io_dtype);
+    if (BT == 0) return GDKVM_OK;
+    if (!logits || !mask) return gdkvm_fail(GDKVM_ERR_ARG, "argmax_dice: null pointer");
+    if (target && !counts) return gdkvm_fail(GDKVM_ERR_ARG, "argmax_dice: counts required with a target");
+    if (!gdkvm_aligned16(logits) || !gdkvm_aligned16(mask) || (target && !gdkvm_aligned16(target)) ||
+        (counts && !gdkvm_aligned16(counts)))
+        return gdkvm_fail(GDKVM_ERR_ARG, "argmax_dice: pointers must be 16-byte aligned");
+    if ((size_t)H * W > 0x7fffffffu / 2) return gdkvm_fail(GDKVM_ERR_SHAPE, "argmax_dice: image too large");
+    if (int rc = gdkvm_check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int HW = H * W;
+    if (target) {
+        hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)BT * ncls * 3, st);
+        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "argmax_dice: memset: %s", hipGetErrorString(e));
+    }
+    AdArgs a{logits, target, mask, counts, ncls, HW};
+    const bool vec = (HW % 4) == 0;
+    const int nvec = vec ? HW / 4 : HW;
+    int gx = (nvec + 255) / 256;
+    if (gx > 64) gx = 64;
+    const dim3 grid((unsigned)gx, (unsigned)BT);
+    const size_t lds = sizeof(int) * (size_t)ncls * 3;
+    if (io_dtype == GDKVM_F32) {
+        if (vec) hipLaunchKernelGGL((argmax_dice_kernel<GDKVM_F32, 4>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((argmax_dice_kernel<GDKVM_F32, 1>), grid, dim3(256), lds, st, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((argmax_dice_kernel<GDKVM_BF16, 4>), grid, dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((argmax_dice_kernel<GDKVM_BF16, 1>), grid, dim3(256), lds, st, a);
+    }
+    GDKVM_LAUNCH_CHECK("argmax_dice_kernel");
+    return GDKVM_OK;
+}

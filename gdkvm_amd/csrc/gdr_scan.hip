@@ -1,0 +1,386 @@
+// gdr_scan.hip -- LKVA read + gated-delta-rule write for gfx950.
+//
+// Two kernels per call, both exact fp32 on v_mfma_f32_16x16x4_f32:
+//
+//  gdr_prep_kernel   one workgroup per (clip, frame, head); fully parallel over frames.  Computes the
+//                    state-INDEPENDENT WY factors of SURVEY.md A.3
+//                        Wt = T diag(b) Kn,  Ut = T diag(b) V,  T = (I + tril(diag(b) Kn Kn^T, -1))^-1
+//                    by a blocked forward substitution that lives entirely in MFMA accumulators: the Gram
+//                    blocks are produced TRANSPOSED so their C/D registers are directly the A operand of the
+//                    next product, and each solved 16-token block Y_J stays in registers as a B operand
+//                    (k order permuted consistently on both operands).  Also applies the a5 prologue
+//                    (L2-normalise k, sigmoid gates) and emits Kn^T.
+//  gdr_scan_kernel   one workgroup per (clip, head, 16-column slice of Dv) -- the delta rule never mixes
+//                    columns of S, so Dv is the parallel axis.  Serial over frames with the 64x16 state
+//                    slice held in MFMA accumulators; per frame only two dependent products remain:
+//                        [R ; X] = [Qn ; Wt] S          U = Ut - a X          S <- a S + Kn^T U
+//
+// Workspace (fp32), per frame-head fh, NP = 16*NB padded tokens:
+//   wt  [FH][NP][64]                natural rows  -> A operand of X = Wt S by 16-byte loads
+//   knT [FH][64][NP]                transposed    -> A operand of Kn^T U by 16-byte loads
+//   ut  [FH][Dv/16][NB][64 lanes][4] accumulator images -> one 16-byte load per lane per tile
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gdkvm_common.hpp"
+
+namespace {
+
+struct PrepArgs {
+    const void* k; const void* v; const float* beta;
+    float* wt; float* knT; float* ut;
+    int T, Hh, N, Dv, rule, flags;
+};
+
+__device__ __forceinline__ int pair_slot(int I, int J) { return I * (I - 1) / 2 + J; }   // J < I
+
+// LDS carve for NB token tiles (floats): kinv[NP] beta[NP] | negA[NB(NB-1)/2][64][4] | Ld[NB][64][4] | Tm[NB][64][4]
+__host__ __device__ constexpr size_t prep_lds_bytes(int NB)
+{
+    return (size_t)(2 * 16 * NB + (NB * (NB - 1) / 2 + 2 * NB) * 256) * sizeof(float);
+}
+
+template <int NB, int IO>
+__global__ __launch_bounds__(256) void gdr_prep_kernel(PrepArgs a)
+{
+    constexpr int NP = 16 * NB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_kinv = smem;
+    float* s_beta = smem + NP;
+    f32x4* s_negA = reinterpret_cast<f32x4*>(smem + 2 * NP);
+    f32x4* s_Ld = s_negA + (NB * (NB - 1) / 2) * 64;
+    f32x4* s_Tm = s_Ld + NB * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fh = blockIdx.x;                       // (b*T + t)*Hh + h
+    const int h = fh % a.Hh;
+    const size_t bt = fh / a.Hh;
+    const int N = a.N, Hh = a.Hh, Dv = a.Dv;
+    const bool seq = a.rule == GDKVM_RULE_DELTA_SEQUENTIAL;
+
+    // ---- phase 0 (a5 prologue): inverse key norms and gates -> LDS -------------------------------
+    for (int n = tid; n < NP; n += 256) {
+        float kinv = 0.f, bta = 0.f;
+        if (n < N) {
+            kinv = 1.f;
+            if (a.flags & GDKVM_FLAG_NORMALIZE_QK) {
+                float ss = 0.f;
+#pragma unroll
+                for (int c = 0; c < GDKVM_DK; c += 4) {
+                    const f32x4 x = load4<IO>(a.k, ((bt * N + n) * Hh + h) * GDKVM_DK + c);
+                    ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+                }
+                kinv = 1.0f / sqrtf(ss + GDKVM_EPS_NORM);
+            }
+            bta = a.beta[(bt * N + n) * Hh + h];
+            if (a.flags & GDKVM_FLAG_GATE_LOGITS) bta = 1.0f / (1.0f + expf(-bta));
+        }
+        s_kinv[n] = kinv;
+        s_beta[n] = bta;
+    }
+    __syncthreads();
+
+    if (seq) {
+        // ---- phase 1: Gram blocks, transposed:  C = K_J K_I^T, lane (i,g) reg r = k_{J,4g+r} . k_{I,i}
+        //      = the A-operand image of A_IJ[i][4g+r];  stored negated and scaled by b_i (row gate).
+        for (int p = w; p < NB * (NB + 1) / 2; p += 4) {
+            int I = 0;
+            while ((I + 1) * (I + 2) / 2 <= p) ++I;
+            const int J = p - I * (I + 1) / 2;
+            const int nI = 16 * I + li, nJ = 16 * J + li;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 kI = {0.f, 0.f, 0.f, 0.f}, kJ = {0.f, 0.f, 0.f, 0.f};
+                if (nI < N) kI = load4<IO>(a.k, ((bt * N + nI) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
+                if (nJ < N) kJ = load4<IO>(a.k, ((bt * N + nJ) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = mfma4(kJ[r], kI[r], acc);
+            }
+            const float rowscale = s_kinv[nI] * s_beta[nI];
+            const f32x4 kinvJ = *reinterpret_cast<const f32x4*>(s_kinv + 16 * J + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] *= rowscale * kinvJ[r];
+            if (J < I) {
+                s_negA[pair_slot(I, J) * 64 + lane] = -acc;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (4 * g + r >= li) acc[r] = 0.f;   // strictly lower: col < row
+                s_Ld[I * 64 + lane] = acc;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: T_II = (I + L_II)^-1 by forward substitution; 16 threads per block, one column each
+        {
+            const int I = tid >> 4, j = tid & 15;
+            if (I < NB) {
+                float t[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t[i] = (i == j) ? 1.f : 0.f;
+#pragma unroll
+                for (int i = 1; i < 16; ++i) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int gg = 0; gg * 4 < i; ++gg) {
+                        const f32x4 Lr = s_Ld[I * 64 + gg * 16 + i];        // L[i][4gg .. 4gg+3]
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (4 * gg + r < i) s += Lr[r] * t[4 * gg + r];
+                    }
+                    t[i] = (i > j) ? -s : t[i];
+                }
+                float* Tm = reinterpret_cast<float*>(s_Tm + I * 64);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) Tm[((j >> 2) * 16 + i) * 4 + (j & 3)] = t[i];   // image of T[i][j]
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 3: per 16-column tile, blocked forward substitution entirely in accumulators -----------
+    const int ntile = GDKVM_DK / 16 + Dv / 16;
+    float* wt = a.wt + (size_t)fh * NP * GDKVM_DK;
+    float* knT = a.knT + (size_t)fh * GDKVM_DK * NP;
+    f32x4* ut = reinterpret_cast<f32x4*>(a.ut + (size_t)fh * NP * Dv);
+    for (int c = w; c < ntile; c += 4) {
+        const bool isK = c < GDKVM_DK / 16;
+        f32x4 Y[NB];
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            const int n0 = 16 * I + 4 * g;
+            const f32x4 bt4 = *reinterpret_cast<const f32x4*>(s_beta + n0);
+            f32x4 acc;
+            if (isK) {
+                const f32x4 ki4 = *reinterpret_cast<const f32x4*>(s_kinv + n0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = 0.f;
+                    if (n0 + r < N) x = load1<IO>(a.k, ((bt * N + n0 + r) * Hh + h) * GDKVM_DK + 16 * c + li);
+                    acc[r] = x * ki4[r];
+                }
+                *reinterpret_cast<f32x4*>(knT + (size_t)(16 * c + li) * NP + n0) = acc;   // Kn^T, 4 tokens
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = 0.f;
+                    if (n0 + r < N) x = load1<IO>(a.v, ((bt * N + n0 + r) * Hh + h) * Dv + 16 * (c - 4) + li);
+                    acc[r] = x;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] *= bt4[r];
+            if (seq) {
+#pragma unroll
+                for (int J = 0; J < I; ++J) {
+                    const f32x4 na = s_negA[pair_slot(I, J) * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = mfma4(na[r], Y[J][r], acc);
+                }
+                const f32x4 t4 = s_Tm[I * 64 + lane];
+                f32x4 y = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y = mfma4(t4[r], acc[r], y);
+                acc = y;
+            }
+            if (isK && a.rule == GDKVM_RULE_GATED_LINEAR) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            Y[I] = acc;
+            if (isK) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wt[(size_t)(n0 + r) * GDKVM_DK + 16 * c + li] = acc[r];
+            } else {
+                ut[((size_t)(c - 4) * NB + I) * 64 + lane] = acc;
+            }
+        }
+    }
+}
+
+struct ScanArgs {
+    const void* q; const float* alpha; const float* s_in;
+    const float* wt; const float* knT; const float* ut;
+    void* r_out; float* s_out;
+    int T, Hh, N, Dv, nb, flags, BH;
+};
+
+template <int IO>
+__global__ __launch_bounds__(256) void gdr_scan_kernel(ScanArgs a)
+{
+    __shared__ __attribute__((aligned(16))) f32x4 s_S[4 * 64];
+    __shared__ __attribute__((aligned(16))) f32x4 s_U[(GDKVM_MAX_N / 16) * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nsl = a.Dv / 16, N = a.N, Hh = a.Hh, Dv = a.Dv, nb = a.nb, NP = 16 * a.nb, T = a.T;
+    // XCD-aware mapping: blocks x and x+8 share an XCD (L2); keep the slices of one (clip, head) -- which
+    // re-read the same q / wt / knT -- on one XCD when the grid allows it (speed only, never correctness).
+    int bh, sl;
+    {
+        const int x = blockIdx.x;
+        if (a.BH % 8 == 0) { bh = (x & 7) + 8 * ((x >> 3) / nsl); sl = (x >> 3) % nsl; }
+        else { bh = x / nsl; sl = x % nsl; }
+    }
+    const int b = bh / Hh, h = bh % Hh;
+    const int col = h * Dv + 16 * sl + li;               // this lane's column inside a [.., Hh*Dv] row
+
+    // state tile of this wave: rows 16w + 4g + r of S, column `col`
+    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+    if (a.s_in) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[r] = a.s_in[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li];
+    }
+    s_S[w * 64 + lane] = sacc;
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        const size_t bt = (size_t)b * T + t;
+        const size_t fh = bt * Hh + h;
+        float alpha = a.alpha[fh];
+        if (a.flags & GDKVM_FLAG_GATE_LOGITS) alpha = 1.0f / (1.0f + expf(-alpha));
+        const float* wt = a.wt + fh * NP * GDKVM_DK;
+        const float* knT = a.knT + fh * GDKVM_DK * NP;
+        const f32x4* ut = reinterpret_cast<const f32x4*>(a.ut + fh * NP * Dv) + (size_t)sl * nb * 64;
+
+        f32x4 sreg[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) sreg[m] = s_S[m * 64 + lane];
+
+        for (int tt = w; tt < nb; tt += 4) {
+            const int n = 16 * tt + li;
+            f32x4 qa[4], wa[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                qa[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (n < N) qa[m] = load4<IO>(a.q, ((bt * N + n) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
+                wa[m] = *reinterpret_cast<const f32x4*>(wt + (size_t)n * GDKVM_DK + 16 * m + 4 * g);
+            }
+            const f32x4 ut4 = ut[tt * 64 + lane];
+            if (a.flags & GDKVM_FLAG_NORMALIZE_QK) {
+                float ss = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ss += qa[m][r] * qa[m][r];
+                ss += __shfl_xor(ss, 16);
+                ss += __shfl_xor(ss, 32);
+                const float inv = 1.0f / sqrtf(ss + GDKVM_EPS_NORM);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) qa[m] *= inv;
+            }
+            f32x4 accR = {0.f, 0.f, 0.f, 0.f}, accX = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    accR = mfma4(qa[m][r], sreg[m][r], accR);
+                    accX = mfma4(wa[m][r], sreg[m][r], accX);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nr = 16 * tt + 4 * g + r;
+                if (nr < N) store1<IO>(a.r_out, (bt * N + nr) * Hh * Dv + col, accR[r]);
+            }
+            f32x4 u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] = ut4[r] - alpha * accX[r];
+            s_U[tt * 64 + lane] = u;
+        }
+        __syncthreads();
+
+        f32x4 acc = sacc * alpha;
+        for (int tt = 0; tt < nb; ++tt) {
+            const f32x4 ub = s_U[tt * 64 + lane];
+            const f32x4 ka = *reinterpret_cast<const f32x4*>(knT + (size_t)(16 * w + li) * NP + 16 * tt + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = mfma4(ka[r], ub[r], acc);
+        }
+        sacc = acc;
+        s_S[w * 64 + lane] = sacc;
+        __syncthreads();
+    }
+    if (a.s_out) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.s_out[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li] = sacc[r];
+    }
+}
+
+int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
+
+template <int NB, int IO>
+int launch_prep(const PrepArgs& pa, int FH, hipStream_t st)
+{
+    const size_t lds = prep_lds_bytes(NB);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_prep_kernel<NB, IO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_prep: LDS attribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL((gdr_prep_kernel<NB, IO>), dim3(FH), dim3(256), lds, st, pa);
+    GDKVM_LAUNCH_CHECK("gdr_prep_kernel");
+    return GDKVM_OK;
+}
+
+template <int IO>
+int launch_prep_nb(int nb, const PrepArgs& pa, int FH, hipStream_t st)
+{
+    switch (nb) {
+        case 4: return launch_prep<4, IO>(pa, FH, st);
+        case 8: return launch_prep<8, IO>(pa, FH, st);
+        default: return launch_prep<16, IO>(pa, FH, st);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
+{
+    if (B <= 0 || T <= 0 || Hh <= 0 || N <= 0 || Dk <= 0 || Dv <= 0 || N > GDKVM_MAX_N) return 16;
+    const size_t NP = 16 * (size_t)tiles_for(N);
+    return (size_t)B * T * Hh * NP * (2 * (size_t)Dk + Dv) * sizeof(float) + 16;
+}
+
+extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
+                              const float* s_in, void* r_out, float* s_out, void* workspace, size_t workspace_bytes,
+                              int B, int T, int Hh, int N, int Dk, int Dv,
+                              int io_dtype, int rule, int flags, void* stream)
+{
+    if (B < 0 || T < 0 || Hh <= 0 || N < 0 || Dv <= 0)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: negative or zero dimension (B=%d T=%d Hh=%d N=%d Dv=%d)", B, T, Hh, N, Dv);
+    if (Dk != GDKVM_DK) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: Dk=%d unsupported (kernels are built for Dk=%d)", Dk, GDKVM_DK);
+    if (Dv % 16 != 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: Dv=%d must be a multiple of 16", Dv);
+    if (N > GDKVM_MAX_N) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: N=%d exceeds %d tokens per frame", N, GDKVM_MAX_N);
+    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "scan_fwd: io_dtype=%d", io_dtype);
+    if (rule < 0 || rule > 2) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: rule=%d", rule);
+    if (flags & ~3) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: unknown flags 0x%x", flags);
+    if (B == 0) return GDKVM_OK;
+    const bool have_tokens = T > 0 && N > 0;
+    if (have_tokens && (!q || !k || !v || !alpha || !beta || !r_out || !workspace))
+        return gdkvm_fail(GDKVM_ERR_ARG, "scan_fwd: null pointer");
+    if (T > 0 && !alpha) return gdkvm_fail(GDKVM_ERR_ARG, "scan_fwd: null alpha");
+    const void* ptrs[] = {q, k, v, alpha, beta, s_in, r_out, s_out, workspace};
+    for (const void* p : ptrs)
+        if (p && !gdkvm_aligned16(p)) return gdkvm_fail(GDKVM_ERR_ARG, "scan_fwd: pointer %p is not 16-byte aligned", p);
+    if (workspace_bytes < gdkvm_scan_workspace_bytes(B, T, Hh, N, Dk, Dv) - 16 && have_tokens)
+        return gdkvm_fail(GDKVM_ERR_WORKSPACE, "scan_fwd: workspace %zu < %zu bytes", workspace_bytes,
+                          gdkvm_scan_workspace_bytes(B, T, Hh, N, Dk, Dv));
+    if (int rc = gdkvm_check_device()) return rc;
+
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nb = have_tokens ? tiles_for(N) : 0;
+    const size_t NP = 16 * (size_t)nb, FH = (size_t)B * T * Hh;
+    float* wt = static_cast<float*>(workspace);
+    float* knT = wt + FH * NP * GDKVM_DK;
+    float* ut = knT + FH * NP * GDKVM_DK;
+
+    if (have_tokens) {
+        PrepArgs pa{k, v, beta, wt, knT, ut, T, Hh, N, Dv, rule, flags};
+        const int rc = io_dtype == GDKVM_F32 ? launch_prep_nb<GDKVM_F32>(nb, pa, (int)FH, st)
+                                             : launch_prep_nb<GDKVM_BF16>(nb, pa, (int)FH, st);
+        if (rc) return rc;
+    }
+    ScanArgs sa{q, alpha, s_in, wt, knT, ut, r_out, s_out, T, Hh, N, Dv, nb, flags, B * Hh};
+    const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
+    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_scan_kernel<GDKVM_F32>), grid, dim3(256), 0, st, sa);
+    else hipLaunchKernelGGL((gdr_scan_kernel<GDKVM_BF16>), grid, dim3(256), 0, st, sa);
+    GDKVM_LAUNCH_CHECK("gdr_scan_kernel");
+    return GDKVM_OK;
+}

@@ -1,0 +1,174 @@
+// kpff.hip -- SURVEY.md §8 row a4 / Appendix A.5: Key-Pixel Feature Fusion, one fused kernel.
+//
+//   Gms = mean_{s in 1,2,4} cellmean_s(G)            (multi-scale "global key feature")
+//   g   = sigmoid([P ; L ; Gms] Wa^T + ba) = (g_l | g_g)
+//   F   = P + g_l * (L Wl^T) + g_g * (Gms Wg^T)
+//
+// One workgroup owns a tile of <= 64 tokens made of whole 4-row bands of the h x w grid (or the whole
+// frame when it has <= 64 tokens), so every 2x2 and 4x4 pooling cell is tile-local.  The tile's [P;L;G]
+// rows are staged once in LDS (fp32, padded rows -> conflict-free 16-byte operand reads), G is pooled in
+// place, and the four channel mixes run as ONE pass of exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) over the
+// concatenated input: each wave owns 16 output channels x 64 tokens x {g_l, g_g, L Wl, Gms Wg} = 16
+// accumulator tiles, reads its weight rows straight from L2 with 16-byte loads (each weight element is
+// fetched once per workgroup), and fuses bias, sigmoid, gating and the residual into the epilogue.
+#include "gdkvm_common.hpp"
+
+namespace {
+
+struct KpffArgs {
+    const void* L; const void* G; const void* P;
+    const float* wa; const float* ba; const float* wl; const float* wg;
+    void* out;
+    int Ck, Cv, Cp, h, w, rows_per_tile, tiles_per_frame;
+};
+
+constexpr int KPFF_TM = 64;       // tokens per workgroup tile
+constexpr int KPFF_PAD = 4;       // row padding in floats: stride % 64 == 4 -> 16 rows cover all 64 banks
+
+template <int IO>
+__global__ __launch_bounds__(256) void kpff_kernel(KpffArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_x[];   // [KPFF_TM][Cin + PAD]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ck = a.Ck, Cv = a.Cv, Cp = a.Cp, Cin = Cp + Ck + Cv, ld = Cin + KPFF_PAD;
+    const int f = blockIdx.x / a.tiles_per_frame, rt = blockIdx.x % a.tiles_per_frame;
+    const int N = a.h * a.w, W = a.w;
+    const int row0 = rt * a.rows_per_tile;
+    const int nrows = min(a.rows_per_tile, a.h - row0);
+    const int n0 = row0 * W, ntok = nrows * W;
+
+    // ---- stage [P ; L ; G] rows (4 channels per thread, 16-byte LDS stores) -------------------------
+    {
+        const int q4 = Cin / 4;
+        for (int idx = tid; idx < KPFF_TM * q4; idx += 256) {
+            const int tok = idx / q4, c = (idx - tok * q4) * 4;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (tok < ntok) {
+                const size_t row = (size_t)f * N + n0 + tok;
+                if (c < Cp) x = load4<IO>(a.P, row * Cp + c);
+                else if (c < Cp + Ck) x = load4<IO>(a.L, row * Ck + (c - Cp));
+                else x = load4<IO>(a.G, row * Cv + (c - Cp - Ck));
+            }
+            *reinterpret_cast<f32x4*>(s_x + (size_t)tok * ld + c) = x;
+        }
+    }
+    __syncthreads();
+    // ---- multi-scale pooling of G in place: one thread per (4x4 cell, channel) -----------------------
+    {
+        const int cw = (W + 3) / 4, chh = (nrows + 3) / 4;
+        float* gx = s_x + Cp + Ck;
+        for (int idx = tid; idx < cw * chh * Cv; idx += 256) {
+            const int c = idx % Cv, cell = idx / Cv;
+            const int y0 = (cell / cw) * 4, x0 = (cell % cw) * 4;
+            const int y1 = min(y0 + 4, nrows), x1 = min(x0 + 4, W);
+            float s4 = 0.f, s2[4] = {0.f, 0.f, 0.f, 0.f};
+            int n2[4] = {0, 0, 0, 0};
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) {
+                    const float v = gx[(size_t)(y * W + x) * ld + c];
+                    const int q = ((y - y0) >> 1) * 2 + ((x - x0) >> 1);
+                    s2[q] += v; n2[q] += 1; s4 += v;
+                }
+            const float m4 = s4 / (float)((y1 - y0) * (x1 - x0));
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) {
+                    const int q = ((y - y0) >> 1) * 2 + ((x - x0) >> 1);
+                    float* p = gx + (size_t)(y * W + x) * ld + c;
+                    *p = (*p + s2[q] / (float)n2[q] + m4) * (1.0f / 3.0f);
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- fused channel mixes: wave owns output channels o = 64*chunk + 16*wave + li -----------------
+    const int kbP = Cp / 16, kbL = Ck / 16, kbG = Cv / 16;
+    for (int chunk = 0; chunk * 64 < Cp; ++chunk) {
+        const int ob = chunk * 64 + 16 * w_id;            // wave-uniform
+        if (ob >= Cp) break;
+        const int o = ob + li;
+        f32x4 gl[4], gg[4], lp[4], gp[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) gl[mt] = gg[mt] = lp[mt] = gp[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float* wal = a.wa + (size_t)o * Cin + 4 * g;
+        const float* wag = a.wa + (size_t)(Cp + o) * Cin + 4 * g;
+        const float* xa = s_x + (size_t)li * ld + 4 * g;
+
+        auto step = [&](int kb, const float* wmix, f32x4* mix) {
+            const f32x4 bl = *reinterpret_cast<const f32x4*>(wal + 16 * kb);
+            const f32x4 bg = *reinterpret_cast<const f32x4*>(wag + 16 * kb);
+            f32x4 bm = {0.f, 0.f, 0.f, 0.f};
+            if (wmix) bm = *reinterpret_cast<const f32x4*>(wmix);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(xa + (size_t)mt * 16 * ld + 16 * kb);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    gl[mt] = mfma4(av[r], bl[r], gl[mt]);
+                    gg[mt] = mfma4(av[r], bg[r], gg[mt]);
+                    if (wmix) mix[mt] = mfma4(av[r], bm[r], mix[mt]);
+                }
+            }
+        };
+        for (int kb = 0; kb < kbP; ++kb) step(kb, nullptr, nullptr);
+        for (int kb = 0; kb < kbL; ++kb) step(kbP + kb, a.wl + (size_t)o * Ck + 16 * kb + 4 * g, lp);
+        for (int kb = 0; kb < kbG; ++kb) step(kbP + kbL + kb, a.wg + (size_t)o * Cv + 16 * kb + 4 * g, gp);
+
+        const float bl = a.ba[o], bg = a.ba[Cp + o];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tok = 16 * mt + 4 * g + r;
+                if (tok < ntok) {
+                    const float sl = 1.0f / (1.0f + expf(-(gl[mt][r] + bl)));
+                    const float sg = 1.0f / (1.0f + expf(-(gg[mt][r] + bg)));
+                    const float y = s_x[(size_t)tok * ld + o] + sl * lp[mt][r] + sg * gp[mt][r];
+                    store1<IO>(a.out, ((size_t)f * N + n0 + tok) * Cp + o, y);
+                }
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int gdkvm_kpff_fwd(const void* local, const void* global, const void* pixel,
+                              const float* wa, const float* ba, const float* wl, const float* wg, void* out,
+                              int BT, int Ck, int Cv, int Cp, int h, int w, int io_dtype, void* stream)
+{
+    if (BT < 0 || Ck <= 0 || Cv <= 0 || Cp <= 0 || h <= 0 || w <= 0)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: bad shape BT=%d Ck=%d Cv=%d Cp=%d h=%d w=%d", BT, Ck, Cv, Cp, h, w);
+    if (Ck % 16 || Cv % 16 || Cp % 16) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: channels must be multiples of 16");
+    if ((long)h * w > GDKVM_MAX_N || w > 64) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: grid %dx%d unsupported", h, w);
+    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "kpff_fwd: io_dtype=%d", io_dtype);
+    if (BT == 0) return GDKVM_OK;
+    const void* ptrs[] = {local, global, pixel, wa, ba, wl, wg, out};
+    for (const void* p : ptrs) {
+        if (!p) return gdkvm_fail(GDKVM_ERR_ARG, "kpff_fwd: null pointer");
+        if (!gdkvm_aligned16(p)) return gdkvm_fail(GDKVM_ERR_ARG, "kpff_fwd: pointer %p is not 16-byte aligned", p);
+    }
+    // tile = whole frame if it fits 64 tokens, else the largest multiple of 4 grid rows that does
+    int rows;
+    if (h * w <= KPFF_TM) rows = h;
+    else {
+        rows = (KPFF_TM / w) & ~3;
+        if (rows < 4) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: grid width %d too large for a 4-row tile", w);
+    }
+    const int tiles = (h + rows - 1) / rows;
+    const size_t lds = (size_t)KPFF_TM * (Cp + Ck + Cv + KPFF_PAD) * sizeof(float);
+    if (lds > 160 * 1024) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: Cp+Ck+Cv=%d exceeds the LDS tile", Cp + Ck + Cv);
+    if (int rc = gdkvm_check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    KpffArgs a{local, global, pixel, wa, ba, wl, wg, out, Ck, Cv, Cp, h, w, rows, tiles};
+    const void* fn = io_dtype == GDKVM_F32 ? reinterpret_cast<const void*>(kpff_kernel<GDKVM_F32>)
+                                           : reinterpret_cast<const void*>(kpff_kernel<GDKVM_BF16>);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "kpff_fwd: LDS attribute: %s", hipGetErrorString(e));
+    }
+    const dim3 grid((unsigned)(BT * tiles));
+    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((kpff_kernel<GDKVM_F32>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((kpff_kernel<GDKVM_BF16>), grid, dim3(256), lds, st, a);
+    GDKVM_LAUNCH_CHECK("kpff_kernel");
+    return GDKVM_OK;
+}

@@ -1,0 +1,190 @@
+"""Host-side bindings of the C ABI (include/gdkvm.h) for torch tensors.
+
+Every function checks shapes on the host, hands raw device pointers + the current HIP stream to
+libgdkvm_hip.so and returns torch tensors.  No fallback path exists: a missing library or a CPU tensor
+raises (the product must never silently run anything but the HIP kernels).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import torch
+
+RULE_GATED_LINEAR, RULE_DELTA_PARALLEL, RULE_DELTA_SEQUENTIAL = 0, 1, 2
+FLAG_NORMALIZE_QK, FLAG_GATE_LOGITS = 1, 2
+F32, BF16 = 0, 1
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_PKG, "libgdkvm_hip.so")
+_lib = None
+_vp, _sz, _i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+
+# symbol -> (restype, argtypes): must list every entry point include/gdkvm.h declares
+SIGNATURES = {
+    "gdkvm_abi_version": (_i, []),
+    "gdkvm_last_error": (ctypes.c_char_p, []),
+    "gdkvm_scan_workspace_bytes": (_sz, [_i] * 6),
+    "gdkvm_scan_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
+    "gdkvm_kpff_fwd": (_i, [_vp] * 8 + [_i] * 7 + [_vp]),
+    "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
+}
+
+
+class GdkvmError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _SO
+
+
+def load():
+    """dlopen libgdkvm_hip.so and bind every ABI symbol.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise GdkvmError(f"{_SO} not found: build it with `python -m gdkvm_amd.build` "
+                             "(there is no fallback path)")
+        lib = ctypes.CDLL(_SO)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.gdkvm_abi_version() != 1:
+            raise GdkvmError(f"ABI version mismatch: {lib.gdkvm_abi_version()}")
+        _lib = lib
+    return _lib
+
+
+def require_native():
+    """Fail loudly unless the HIP library is loaded and a GPU is present."""
+    load()
+    if not torch.cuda.is_available():
+        raise GdkvmError("no HIP device visible: the GDKVM ops have no CPU path")
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise GdkvmError(f"{what} failed ({rc}): {load().gdkvm_last_error().decode()}")
+
+
+def _io_dtype(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise GdkvmError(f"unsupported io dtype {t.dtype} (float32 or bfloat16)")
+
+
+def _dev(*ts):
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise GdkvmError("GDKVM ops need device tensors (no CPU path)")
+        if not t.is_contiguous():
+            raise GdkvmError("GDKVM ops need contiguous tensors")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise GdkvmError("tensors on different devices")
+    return dev
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def _stream(dev) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def scan_workspace_bytes(B, T, Hh, N, Dk, Dv) -> int:
+    return int(load().gdkvm_scan_workspace_bytes(B, T, Hh, N, Dk, Dv))
+
+
+def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor,
+             state: Optional[torch.Tensor] = None, rule: int = RULE_DELTA_SEQUENTIAL, flags: int = 0,
+             workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+             state_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Fused LKVA read + GDR write over T frames (gdkvm_scan_fwd).
+
+    q,k [B,T,N,Hh,Dk]  v [B,T,N,Hh,Dv]  (f32|bf16)   alpha [B,T,Hh]  beta [B,T,N,Hh]  state [B,Hh,Dk,Dv] (f32)
+    returns (R [B,T,N,Hh,Dv] in the io dtype, S_T [B,Hh,Dk,Dv] f32)."""
+    lib = load()
+    if q.dim() != 5 or k.shape != q.shape or v.dim() != 5 or v.shape[:4] != q.shape[:4]:
+        raise GdkvmError(f"bad shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
+    B, T, N, Hh, Dk = q.shape
+    Dv = v.shape[-1]
+    if tuple(alpha.shape) != (B, T, Hh) or tuple(beta.shape) != (B, T, N, Hh):
+        raise GdkvmError(f"bad gate shapes alpha{tuple(alpha.shape)} beta{tuple(beta.shape)}")
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        raise GdkvmError("q, k, v must share one dtype")
+    if alpha.dtype != torch.float32 or beta.dtype != torch.float32:
+        raise GdkvmError("alpha / beta must be float32")
+    if state is not None and (tuple(state.shape) != (B, Hh, Dk, Dv) or state.dtype != torch.float32):
+        raise GdkvmError("state must be float32 [B,Hh,Dk,Dv]")
+    dev = _dev(q, k, v, alpha, beta, state, workspace, out, state_out)
+    io = _io_dtype(q)
+    need = scan_workspace_bytes(B, T, Hh, N, Dk, Dv)
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+    r = out if out is not None else torch.empty((B, T, N, Hh, Dv), dtype=q.dtype, device=dev)
+    s = state_out if state_out is not None else torch.empty((B, Hh, Dk, Dv), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gdkvm_scan_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(alpha), _ptr(beta), _ptr(state), _ptr(r), _ptr(s),
+                                workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                B, T, Hh, N, Dk, Dv, io, rule, flags, _stream(dev))
+    _check(rc, "gdkvm_scan_fwd")
+    return r, s
+
+
+def kpff_fwd(local: torch.Tensor, glob: torch.Tensor, pixel: torch.Tensor, wa: torch.Tensor, ba: torch.Tensor,
+             wl: torch.Tensor, wg: torch.Tensor, h: int, w: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Key-Pixel Feature Fusion (gdkvm_kpff_fwd).  local [BT,N,Ck] glob [BT,N,Cv] pixel [BT,N,Cp], N=h*w;
+    wa [2Cp,Cp+Ck+Cv] ba [2Cp] wl [Cp,Ck] wg [Cp,Cv] float32.  Returns F [BT,N,Cp] in the io dtype."""
+    lib = load()
+    BT, N, Ck = local.shape
+    Cv, Cp = glob.shape[-1], pixel.shape[-1]
+    if N != h * w or glob.shape[:2] != (BT, N) or pixel.shape[:2] != (BT, N):
+        raise GdkvmError("bad KPFF feature shapes")
+    if tuple(wa.shape) != (2 * Cp, Cp + Ck + Cv) or tuple(ba.shape) != (2 * Cp,) or \
+            tuple(wl.shape) != (Cp, Ck) or tuple(wg.shape) != (Cp, Cv):
+        raise GdkvmError("bad KPFF weight shapes")
+    for t in (wa, ba, wl, wg):
+        if t.dtype != torch.float32:
+            raise GdkvmError("KPFF weights must be float32")
+    if glob.dtype != local.dtype or pixel.dtype != local.dtype:
+        raise GdkvmError("KPFF features must share one dtype")
+    dev = _dev(local, glob, pixel, wa, ba, wl, wg, out)
+    f = out if out is not None else torch.empty((BT, N, Cp), dtype=local.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gdkvm_kpff_fwd(_ptr(local), _ptr(glob), _ptr(pixel), _ptr(wa), _ptr(ba), _ptr(wl), _ptr(wg), _ptr(f),
+                                BT, Ck, Cv, Cp, h, w, _io_dtype(local), _stream(dev))
+    _check(rc, "gdkvm_kpff_fwd")
+    return f
+
+
+def argmax_dice(logits: torch.Tensor, target: Optional[torch.Tensor] = None):
+    """mask = argmax over classes (ties -> lowest index) and, with a target, integer Dice counts
+    (gdkvm_argmax_dice).  logits [BT,ncls,H,W]; target [BT,H,W] uint8.  Returns (mask u8, counts i32|None)."""
+    lib = load()
+    BT, ncls, H, W = logits.shape
+    dev = _dev(logits, target)
+    if target is not None and (target.dtype != torch.uint8 or tuple(target.shape) != (BT, H, W)):
+        raise GdkvmError("target must be uint8 [BT,H,W]")
+    mask = torch.empty((BT, H, W), dtype=torch.uint8, device=dev)
+    counts = torch.empty((BT, ncls, 3), dtype=torch.int32, device=dev) if target is not None else None
+    with torch.cuda.device(dev):
+        rc = lib.gdkvm_argmax_dice(_ptr(logits), _ptr(target), _ptr(mask), _ptr(counts), BT, ncls, H, W,
+                                   _io_dtype(logits), _stream(dev))
+    _check(rc, "gdkvm_argmax_dice")
+    return mask, counts
+
+
+def dice_from_counts(counts: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """Dice_c = (2|AnB| + eps) / (|A| + |B| + eps) from the integer counts of argmax_dice."""
+    c = counts.to(torch.float64)
+    return (2.0 * c[..., 0] + eps) / (c[..., 1] + c[..., 2] + eps)

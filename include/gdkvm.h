@@ -1,0 +1,93 @@
+/* gdkvm.h -- C ABI of the MI355X-native GDKVM memory path (libgdkvm_hip.so, gfx950 only).
+ *
+ * The reference snapshot exposes NO plugin / operator / FFI interface for this path: /root/reference is the
+ * project website and holds no model code (the code lives in the repo named at
+ * /root/reference/README.md:1 and is excluded at /root/reference/.gitignore:73-76).  There is therefore no
+ * reference interface file:line for these entry points to replace; each one is instead tied to the
+ * operation the reference *names* (/root/reference/README.md:20, .../website/src/content/homepage/en.json:20)
+ * and to the row of SURVEY.md §8(a) that specifies it.  INTEGRATION.md shows the binding a maintainer of the
+ * real model code would add (ctypes stub + nn.Module seam).
+ *
+ * Conventions (all entry points)
+ *   - every pointer is a DEVICE pointer owned by the caller (hipMalloc / torch CUDA tensor); nothing is
+ *     allocated, retained or freed by the callee; 16-byte alignment is required for every buffer;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); calls are asynchronous with
+ *     respect to the host and stream-ordered; no host synchronisation happens inside (graph-capturable);
+ *   - return value: 0 on success, <0 on error; never throws, never exits:
+ *       GDKVM_ERR_SHAPE (-1) bad / unsupported shape    GDKVM_ERR_DTYPE (-2) unsupported io_dtype
+ *       GDKVM_ERR_ARCH  (-3) device is not gfx950       GDKVM_ERR_LAUNCH(-4) HIP launch failure
+ *       GDKVM_ERR_WORKSPACE (-5) workspace too small    GDKVM_ERR_ARG (-6) null / misaligned pointer
+ *     gdkvm_last_error() returns a thread-local message for the most recent failure on this thread;
+ *   - re-entrant; concurrent calls are safe iff their output / workspace buffers are distinct.
+ *
+ * Tensor layouts are token-major with the channel innermost (what an NHWC 1x1 convolution emits):
+ *   q, k   [B, T, N, Hh, Dk]     v, r   [B, T, N, Hh, Dv]     (io_dtype: f32 or bf16)
+ *   alpha  [B, T, Hh]  fp32      beta   [B, T, N, Hh]  fp32
+ *   state  [B, Hh, Dk, Dv] fp32  (always fp32: the recurrent memory is never stored narrow)
+ */
+#ifndef GDKVM_H
+#define GDKVM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDKVM_ABI_VERSION 1
+
+enum { GDKVM_OK = 0, GDKVM_ERR_SHAPE = -1, GDKVM_ERR_DTYPE = -2, GDKVM_ERR_ARCH = -3,
+       GDKVM_ERR_LAUNCH = -4, GDKVM_ERR_WORKSPACE = -5, GDKVM_ERR_ARG = -6 };
+
+enum { GDKVM_F32 = 0, GDKVM_BF16 = 1 };                       /* io_dtype */
+
+/* GDR write rule */
+enum { GDKVM_RULE_GATED_LINEAR = 0,      /* S <- a S + sum_i b_i k_i v_i^T  (literal BASELINE.json formula) */
+       GDKVM_RULE_DELTA_PARALLEL = 1,    /* all tokens of a frame erase against the decayed state          */
+       GDKVM_RULE_DELTA_SEQUENTIAL = 2   /* token-sequential gated delta rule (default)                    */ };
+
+/* prologue flags */
+enum { GDKVM_FLAG_NORMALIZE_QK = 1,      /* q,k <- x * rsqrt(sum x^2 + 1e-12)   */
+       GDKVM_FLAG_GATE_LOGITS = 2        /* alpha, beta are logits -> sigmoid   */ };
+
+int gdkvm_abi_version(void);
+const char* gdkvm_last_error(void);
+
+/* Bytes of scratch gdkvm_scan_fwd needs for this shape (per-frame WY factors). */
+size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv);
+
+/* Rows a1+a2+a3+a5: fused LKVA read + GDR write over T frames with state carry.
+ *   for t in 0..T-1:  R_t = Q_t S_{t-1};   S_t = GDR(S_{t-1}, K_t, V_t, alpha_t, beta_t)
+ * s_in may be NULL (zero state); s_out may be NULL.  T == 1 is the per-frame `step` entry point.  A clip
+ * processed as consecutive calls with the state carried is bit-identical to one call.
+ * Names: LKVA / GDR at /root/reference/README.md:20; "state transition matrix" at
+ * /root/reference/website/src/content/homepage/en.json:20.
+ * Supported: Dk == 64, Dv % 16 == 0, 0 <= N <= 256. */
+int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
+                   const float* s_in, void* r_out, float* s_out, void* workspace, size_t workspace_bytes,
+                   int B, int T, int Hh, int N, int Dk, int Dv,
+                   int io_dtype, int rule, int flags, void* stream);
+
+/* Row a4: Key-Pixel Feature Fusion ("fuses the local key feature, the global key feature with the pixel
+ * feature", /root/reference/website/src/content/homepage/en.json:20; "multiple scales", README.md:20).
+ *   local [BT,N,Ck]  global [BT,N,Cv]  pixel [BT,N,Cp]  out [BT,N,Cp]   (io_dtype), N = h*w
+ *   wa [2Cp, Cp+Ck+Cv]  ba [2Cp]  wl [Cp,Ck]  wg [Cp,Cv]                 (fp32)
+ *   Gms = mean_{s in 1,2,4} cellmean_s(global);  g = sigmoid([P;L;Gms] wa^T + ba) = (g_l | g_g)
+ *   out = P + g_l * (L wl^T) + g_g * (Gms wg^T)
+ * Supported: Ck, Cv, Cp multiples of 16; h*w <= 256. */
+int gdkvm_kpff_fwd(const void* local, const void* global, const void* pixel,
+                   const float* wa, const float* ba, const float* wl, const float* wg, void* out,
+                   int BT, int Ck, int Cv, int Cp, int h, int w, int io_dtype, void* stream);
+
+/* Row a6: mask = argmax_c logits (ties -> lowest class index); optional integer Dice counts.
+ *   logits [BT, ncls, H, W] (io_dtype)   target [BT,H,W] u8 or NULL   mask [BT,H,W] u8
+ *   counts [BT, ncls, 3] int32 = { |mask==c & target==c|, |mask==c|, |target==c| }  (zeroed by the callee;
+ *   required iff target != NULL). */
+int gdkvm_argmax_dice(const void* logits, const uint8_t* target, uint8_t* mask, int32_t* counts,
+                      int BT, int ncls, int H, int W, int io_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDKVM_H */

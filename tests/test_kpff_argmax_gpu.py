@@ -1,0 +1,59 @@
+"""GPU parity: gdkvm_kpff_fwd and gdkvm_argmax_dice vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import gdkvm_oracle as O
+from tests.util import make_kpff_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+@pytest.mark.parametrize("case", [(3, 7, 7, 64, 256, 256), (2, 16, 16, 64, 256, 256), (2, 4, 4, 16, 32, 64),
+                                  (1, 5, 3, 32, 16, 16), (2, 14, 14, 64, 64, 128), (1, 1, 1, 16, 16, 16),
+                                  (1, 6, 16, 16, 48, 80)])
+def test_kpff_fp32(hip, case):
+    BT, h, w, Ck, Cv, Cp = case
+    L, G, P, Wa, ba, Wl, Wg = make_kpff_inputs(BT, h, w, Ck, Cv, Cp, seed=sum(case))
+    F = hip.kpff_fwd(_dev(L), _dev(G), _dev(P), _dev(Wa), _dev(ba), _dev(Wl), _dev(Wg), h, w).cpu().numpy()
+    Fo = c_oracle.kpff(L, G, P, Wa, ba, Wl, Wg, h, w)
+    assert np.abs(F - Fo).max() <= 1e-4
+
+
+def test_kpff_bf16_io(hip):
+    BT, h, w, Ck, Cv, Cp = 4, 7, 7, 64, 256, 256
+    L, G, P, Wa, ba, Wl, Wg = make_kpff_inputs(BT, h, w, Ck, Cv, Cp, seed=3)
+    F = hip.kpff_fwd(_dev(L, torch.bfloat16), _dev(G, torch.bfloat16), _dev(P, torch.bfloat16),
+                     _dev(Wa), _dev(ba), _dev(Wl), _dev(Wg), h, w).float().cpu().numpy()
+    Fo = c_oracle.kpff(O.to_bf16_f32(L), O.to_bf16_f32(G), O.to_bf16_f32(P), Wa, ba, Wl, Wg, h, w)
+    assert np.all(np.abs(F - Fo) <= 1e-4 + np.abs(Fo) * 2.0 ** -8)
+
+
+def test_kpff_known_answers(hip):
+    L, G, P, Wa, ba, Wl, Wg = make_kpff_inputs(2, 7, 7, 16, 32, 32, seed=4)
+    F = hip.kpff_fwd(_dev(L), _dev(G), _dev(P), _dev(Wa), _dev(ba), _dev(0 * Wl), _dev(0 * Wg), 7, 7).cpu().numpy()
+    assert np.array_equal(F, P)                                   # zero mixes -> identity on the pixel feature
+
+
+@pytest.mark.parametrize("case", [(5, 4, 9, 11), (3, 2, 112, 112), (2, 4, 256, 256), (1, 1, 8, 8), (2, 7, 5, 4)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_argmax_dice_bit_exact(hip, case, dtype):
+    BT, ncls, H, W = case
+    rng = np.random.default_rng(sum(case))
+    logits = rng.standard_normal(case).astype(np.float32)
+    logits[:, :, ::3] = np.round(logits[:, :, ::3])              # exact ties -> lowest index must win
+    logits = O.to_bf16_f32(logits)                               # representable in both io dtypes
+    target = rng.integers(0, ncls + 1, (BT, H, W)).astype(np.uint8)   # includes an out-of-range label
+    m, c = hip.argmax_dice(_dev(logits, dtype), _dev(target))
+    mo, co = c_oracle.argmax_dice(logits, target)
+    assert np.array_equal(m.cpu().numpy(), mo) and np.array_equal(c.cpu().numpy(), co)
+    m2, c2 = hip.argmax_dice(_dev(logits, dtype))
+    assert c2 is None and np.array_equal(m2.cpu().numpy(), mo)
+    d = hip.dice_from_counts(c).cpu().numpy()
+    np.testing.assert_allclose(d, O.dice_from_counts(co[..., 0], co[..., 1], co[..., 2]), rtol=1e-12)

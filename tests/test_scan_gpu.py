@@ -1,0 +1,148 @@
+"""GPU parity: gdkvm_scan_fwd (HIP, through the C ABI) vs the CPU oracle on the same seeded inputs.
+Tolerance: 1e-4 absolute on fp32 (BASELINE.json north_star); bf16 I/O is compared against the oracle fed
+the same bf16-rounded inputs, with the bf16 output quantisation (2^-8 relative) added."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import gdkvm_oracle as O
+from tests.util import make_scan_inputs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _dev(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def _run(hip, q, k, v, a, b, s0=None, rule=2, flags=0, dtype=torch.float32):
+    r, s = hip.scan_fwd(_dev(q, dtype), _dev(k, dtype), _dev(v, dtype), _dev(a), _dev(b),
+                        None if s0 is None else _dev(s0), rule=rule, flags=flags)
+    torch.cuda.synchronize()
+    return r.float().cpu().numpy(), s.cpu().numpy()
+
+
+@pytest.mark.parametrize("rule", [0, 1, 2])
+@pytest.mark.parametrize("flags", [0, 3])
+def test_scan_fp32_cfg1_shape(hip, rule, flags):
+    """cfg1 shape (B=1,T=8,N=49,Dk=64,Dv=256) for every rule, with and without the a5 prologue."""
+    q, k, v, a, b = make_scan_inputs(1, 8, 49, 1, 64, 256, seed=rule * 7 + flags, normalized=not flags,
+                                     logits=bool(flags), corr=0.5)
+    s0 = np.random.default_rng(1).standard_normal((1, 1, 64, 256)).astype(np.float32) * 0.1
+    Rg, Sg = _run(hip, q, k, v, a, b, s0, rule, flags)
+    Ro, So = c_oracle.scan(q, k, v, a, b, s0, rule, flags, math="f64")
+    assert np.abs(Rg - Ro).max() <= TOL and np.abs(Sg - So).max() <= TOL
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 3, 1, 1, 16), (2, 3, 16, 2, 32), (3, 2, 64, 1, 48), (2, 2, 65, 2, 16), (1, 2, 100, 1, 64),
+    (1, 2, 128, 1, 32), (1, 2, 129, 1, 16), (1, 3, 256, 1, 64), (8, 2, 49, 1, 32), (16, 2, 7, 1, 16)])
+def test_scan_fp32_ragged_shapes(hip, shape):
+    """token counts on and off the 16-token tile edges, several heads, max N, B%8==0 (XCD mapping)."""
+    B, T, N, Hh, Dv = shape
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, 64, Dv, seed=sum(shape), corr=0.7)
+    Rg, Sg = _run(hip, q, k, v, a, b)
+    Ro, So = c_oracle.scan(q, k, v, a, b, None, 2, 0, math="f64")
+    assert Rg.shape == Ro.shape
+    assert np.abs(Rg - Ro).max() <= TOL and np.abs(Sg - So).max() <= TOL
+
+
+def test_scan_matches_numpy_oracle_too(hip):
+    q, k, v, a, b = make_scan_inputs(1, 3, 20, 2, 64, 16, seed=5)
+    Rg, Sg = _run(hip, q, k, v, a, b)
+    Ro, So = O.scan(q, k, v, a, b)
+    assert np.abs(Rg - Ro).max() <= TOL and np.abs(Sg - So).max() <= TOL
+
+
+def test_scan_known_answers_on_gpu(hip):
+    """K1/K2/K3 of SURVEY.md A.6 straight on the kernel."""
+    Dk, Dv = 64, 16
+    k = np.zeros((1, 3, 1, 1, Dk), np.float32); k[..., 5] = 1
+    v = np.stack([np.full(Dv, 1.0), np.full(Dv, 5.0), np.zeros(Dv)]).astype(np.float32)[None, :, None, None]
+    a = np.ones((1, 3, 1), np.float32); b = np.ones((1, 3, 1, 1), np.float32)
+    R, _ = _run(hip, k, k, v, a, b, rule=2)
+    assert np.array_equal(R[0, 0, 0, 0], np.zeros(Dv)) and np.array_equal(R[0, 1, 0, 0], v[0, 0, 0, 0])
+    assert np.array_equal(R[0, 2, 0, 0], v[0, 1, 0, 0])                   # overwrite
+    R, _ = _run(hip, k, k, v, a, b, rule=0)
+    assert np.array_equal(R[0, 2, 0, 0], v[0, 0, 0, 0] + v[0, 1, 0, 0])  # accumulate
+    Qm, _ = np.linalg.qr(np.random.default_rng(0).standard_normal((Dk, Dk)))
+    kk = np.repeat(Qm[None, None, :49, None, :].astype(np.float32), 2, 1)
+    vv = np.repeat(np.random.default_rng(1).standard_normal((1, 1, 49, 1, Dv)).astype(np.float32), 2, 1)
+    R, _ = _run(hip, kk, kk, vv, np.ones((1, 2, 1), np.float32), np.ones((1, 2, 49, 1), np.float32))
+    np.testing.assert_allclose(R[0, 1], vv[0, 0], atol=2e-5)              # orthonormal recall
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_chunk_carry_bit_identity(hip, dtype):
+    """K6 / cfg5 property: chunked calls with the state carried == one call, bit for bit."""
+    q, k, v, a, b = make_scan_inputs(2, 12, 49, 1, 64, 64, seed=11)
+    tq, tk, tv = (_dev(x, dtype) for x in (q, k, v)); ta, tb = _dev(a), _dev(b)
+    R, S = hip.scan_fwd(tq, tk, tv, ta, tb)
+    s = None; parts = []
+    for lo, hi in [(0, 1), (1, 5), (5, 12)]:
+        r, s = hip.scan_fwd(tq[:, lo:hi].contiguous(), tk[:, lo:hi].contiguous(), tv[:, lo:hi].contiguous(),
+                            ta[:, lo:hi].contiguous(), tb[:, lo:hi].contiguous(), s)
+        parts.append(r)
+    assert torch.equal(torch.cat(parts, 1), R) and torch.equal(s, S)
+
+
+def test_scan_deterministic_and_slice_independent(hip):
+    q, k, v, a, b = make_scan_inputs(2, 4, 49, 1, 64, 64, seed=12)
+    R1, S1 = _run(hip, q, k, v, a, b); R2, S2 = _run(hip, q, k, v, a, b)
+    assert np.array_equal(R1, R2) and np.array_equal(S1, S2)
+    Rh, Sh = _run(hip, q, k, np.ascontiguousarray(v[..., 16:48]), a, b)      # K8: Dv columns never interact
+    assert np.array_equal(Rh, R1[..., 16:48]) and np.array_equal(Sh, S1[..., 16:48])
+
+
+@pytest.mark.parametrize("rule", [0, 2])
+def test_scan_bf16_io(hip, rule):
+    q, k, v, a, b = make_scan_inputs(2, 6, 49, 1, 64, 64, seed=13, normalized=False, logits=True)
+    qb, kb, vb = (O.to_bf16_f32(x) for x in (q, k, v))
+    Rg, Sg = _run(hip, q, k, v, a, b, None, rule, 3, dtype=torch.bfloat16)
+    Ro, So = c_oracle.scan(qb, kb, vb, a, b, None, rule, 3, math="f64")
+    assert np.abs(Sg - So).max() <= TOL                        # the state is fp32 end to end
+    assert np.all(np.abs(Rg - Ro) <= TOL + np.abs(Ro) * 2.0 ** -8)
+
+
+def test_scan_empty_and_degenerate(hip):
+    for B, T, N in [(0, 2, 4), (2, 0, 4), (2, 2, 0)]:
+        q, k, v, a, b = make_scan_inputs(B, T, N, 1, 64, 16)
+        s0 = np.full((B, 1, 64, 16), 0.5, np.float32)
+        R, S = _run(hip, q, k, v, a, b, s0)
+        assert R.shape == (B, T, N, 1, 16)
+        _, So = c_oracle.scan(q, k, v, a, b, s0)
+        if B:
+            np.testing.assert_allclose(S, So, atol=1e-6)       # N=0 / T=0: pure decay / identity
+
+
+def test_scan_error_codes(hip):
+    q, k, v, a, b = make_scan_inputs(1, 1, 4, 1, 32, 16)
+    with pytest.raises(hip.GdkvmError, match="Dk"):
+        _run(hip, q, k, v, a, b)
+    q, k, v, a, b = make_scan_inputs(1, 1, 4, 1, 64, 24)
+    with pytest.raises(hip.GdkvmError, match="Dv"):
+        _run(hip, q, k, v, a, b)
+    q, k, v, a, b = make_scan_inputs(1, 1, 4, 1, 64, 16)
+    with pytest.raises(hip.GdkvmError, match="device"):
+        hip.scan_fwd(*(torch.from_numpy(x) for x in (q, k, v, a, b)))
+    with pytest.raises(hip.GdkvmError, match="workspace"):
+        hip.scan_fwd(_dev(q), _dev(k), _dev(v), _dev(a), _dev(b), workspace=torch.empty(64, dtype=torch.uint8, device="cuda"))
+
+
+def test_scan_cfg2_full_size_properties(hip):
+    """BASELINE cfg2 size (B=16,T=32,N=49,Dv=256, bf16): too big for the scalar oracle to be quick on every
+    clip, so check size-independent properties: clips are independent (a sub-batch reproduces its rows bit for
+    bit), and two clips are checked against the oracle outright."""
+    q, k, v, a, b = make_scan_inputs(16, 32, 49, 1, 64, 256, seed=1, normalized=False, logits=True)
+    t = [_dev(x, torch.bfloat16) for x in (q, k, v)] + [_dev(a), _dev(b)]
+    R, S = hip.scan_fwd(*t, flags=3)
+    Rs, Ss = hip.scan_fwd(*(x[8:16].contiguous() for x in t), flags=3)
+    assert torch.equal(Rs, R[8:16]) and torch.equal(Ss, S[8:16])
+    for c in (0, 15):
+        Ro, So = c_oracle.scan(*(O.to_bf16_f32(x[c:c + 1]) for x in (q, k, v)), a[c:c + 1], b[c:c + 1], None, 2, 3)
+        assert np.abs(S[c:c + 1].cpu().numpy() - So).max() <= TOL
+        Rg = R[c:c + 1].float().cpu().numpy()
+        assert np.all(np.abs(Rg - Ro) <= TOL + np.abs(Ro) * 2.0 ** -8)
