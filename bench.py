@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the GDKVM forward (encoder -> HIP memory path -> decoder -> HIP argmax mask) on
+BASELINE.json configs[1]: EchoNet-Dynamic 112x112x32 clips, bf16 inference, batch 16 per MI355X, synthetic data.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Prints ONE JSON line on rank 0 (contract in the task prompt) with two extra objects:
+  roofline      the hot path's dominant kernels (gdr_prep_kernel + gdr_scan_kernel = one gdkvm_scan_fwd), timed
+                live with HIP events on the launch stream; achieved = SURVEY.md §8(d) algorithmic bytes / time
+  cpu_baseline  the CPU oracle module (oracle/model_ref.py: PyTorch CPU convs + scalar C memory path) on a
+                bounded sample of the same workload, rank 0, N=1 only
+Clips shard over GPUs with no data-path collective (inference): scaling is weak, per-GPU batch fixed.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def scan_algorithmic_bytes(B, T, N, Hh, Dk, Dv, s):
+    """per frame s*N*(2Ck+2Cv) + 4*Hh*(1+N); per clip per call 2*4*Hh*Dk*Dv (state in/out)."""
+    ck, cv = Hh * Dk, Hh * Dv
+    return B * T * (s * N * (2 * ck + 2 * cv) + 4 * Hh * (1 + N)) + B * 2 * 4 * Hh * Dk * Dv
+
+
+def time_events(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    return sum(ms) / len(ms), ms[len(ms) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
+    ap.add_argument("--frames", type=int, default=32)
+    ap.add_argument("--size", type=int, default=112)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-iters", type=int, default=50)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gdkvm_amd import ops
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    ops.require_native()
+
+    cfg = GDKVMConfig()
+    torch.manual_seed(1)                                    # SURVEY.md §8(d) cfg2 seed; same weights on every rank
+    model = GDKVM(cfg).eval().to(dev).to(memory_format=torch.channels_last)
+    B, T, S = args.batch, args.frames, args.size
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    u = torch.rand(B, T, 3, S, S, generator=g)
+    speckle = torch.sqrt(-2.0 * torch.log(torch.rand(B, T, 1, S, S, generator=g).clamp_min(1e-7))) * 0.25
+    frames = (u * speckle).clamp_(0, 1).to(dev)             # resident in HBM before the timed region
+
+    def step():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            return model.segment(frames)[0]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    value = world * B * T * args.steps / dt
+
+    out = {"metric": "frames/sec (GDKVM forward + argmax mask), EchoNet 112x112x32 clips", "value": round(value, 1),
+           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "BASELINE.json configs[1]: EchoNet-Dynamic 112x112x32 bf16 inference, batch=16 per GPU",
+                      "clips_per_gpu": B, "frames_per_clip": T, "image": f"{S}x{S}", "tokens_per_frame": (S // 16) ** 2,
+                      "heads": cfg.heads, "key_dim": cfg.key_dim, "value_dim": cfg.value_dim, "rule": cfg.rule,
+                      "sharding": f"clips over {world} GPU(s), no data-path collective"}}
+
+    if rank == 0:
+        # ---- roofline of the hot path's dominant kernels, live HIP-event timing on the launch stream -------
+        N, Hh, Dk, Dv = (S // 16) ** 2, cfg.heads, cfg.key_dim, cfg.value_dim
+        gq = torch.Generator(device=dev).manual_seed(1)
+        q, k = (torch.randn(B, T, N, Hh, Dk, device=dev, generator=gq).bfloat16() for _ in range(2))
+        v = torch.randn(B, T, N, Hh, Dv, device=dev, generator=gq).bfloat16()
+        al = 2 + torch.randn(B, T, Hh, device=dev, generator=gq)
+        be = torch.randn(B, T, N, Hh, device=dev, generator=gq)
+        ws = torch.empty(ops.scan_workspace_bytes(B, T, Hh, N, Dk, Dv), dtype=torch.uint8, device=dev)
+        r = torch.empty(B, T, N, Hh, Dv, device=dev, dtype=torch.bfloat16)
+        s = torch.empty(B, Hh, Dk, Dv, device=dev)
+        prep_ms, _ = time_events(lambda: ops.scan_prep(k, v, be, ws, flags=3), args.kernel_iters)
+        scan_ms, _ = time_events(lambda: ops.scan_apply(q, al, ws, Dv, flags=3, out=r, state_out=s), args.kernel_iters)
+        both_ms, _ = time_events(lambda: ops.scan_fwd(q, k, v, al, be, flags=3, workspace=ws, out=r, state_out=s),
+                                 args.kernel_iters)
+        alg = scan_algorithmic_bytes(B, T, N, Hh, Dk, Dv, 2)
+        achieved = alg / (both_ms * 1e-3) / 1e9
+        out["roofline"] = {"kernel": "gdr_prep_kernel+gdr_scan_kernel (one gdkvm_scan_fwd)", "bound": "hbm",
+                           "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                           "algorithmic_bytes": alg, "avg_ms": {"gdr_prep_kernel": round(prep_ms, 4),
+                                                                "gdr_scan_kernel": round(scan_ms, 4),
+                                                                "scan_fwd_total": round(both_ms, 4)}}
+        # ---- CPU baseline: the oracle module on a bounded sample of the same workload (N=1 only) -----------
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.model_ref import GDKVMRef
+            torch.set_num_threads(os.cpu_count() or 1)
+            ref = GDKVMRef(cfg).eval()
+            ref.load_state_dict({k_: v_.cpu() for k_, v_ in model.state_dict().items()})
+            cb = min(B, 2)
+            sample = frames[:cb].cpu()
+            with torch.no_grad():
+                ref.segment(sample[:, :4])                       # warm-up
+                ts = []
+                for _ in range(3):
+                    c0 = time.perf_counter(); cpu_mask, _ = ref.segment(sample); ts.append(time.perf_counter() - c0)
+                cpu_fps = cb * T / sorted(ts)[1]
+                # Dice of the GPU masks (bf16 run) against the CPU reference's masks on the same clips
+                gmask = step()[:cb].cpu()
+            _, cnt = ops.argmax_dice(torch.nn.functional.one_hot(gmask.reshape(-1, S, S).long(), cfg.num_classes)
+                                     .permute(0, 3, 1, 2).float().contiguous().to(dev), cpu_mask.reshape(-1, S, S).to(dev))
+            dice = ops.dice_from_counts(cnt.sum(0)).tolist()
+            out["cpu_baseline"] = {"value": round(cpu_fps, 1), "unit": "frames/s", "cores": torch.get_num_threads(),
+                                   "kind": "port", "sample": f"{cb} clips x {T} frames {S}x{S}, fp32, median of 3",
+                                   "gpu_over_cpu": round(value / world / cpu_fps, 1)}
+            out["dice_vs_cpu"] = {"per_class": [round(d, 5) for d in dice],
+                                  "mask_agreement": round((gmask == cpu_mask).float().mean().item(), 6)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

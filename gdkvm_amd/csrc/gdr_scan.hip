@@ -23,6 +23,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <initializer_list>
+
 #include "gdkvm_common.hpp"
 
 namespace {
@@ -338,49 +340,94 @@ extern "C" size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk
     return (size_t)B * T * Hh * NP * (2 * (size_t)Dk + Dv) * sizeof(float) + 16;
 }
 
-extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
-                              const float* s_in, void* r_out, float* s_out, void* workspace, size_t workspace_bytes,
-                              int B, int T, int Hh, int N, int Dk, int Dv,
-                              int io_dtype, int rule, int flags, void* stream)
+namespace {
+
+int check_common(const char* fn, int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int flags)
 {
     if (B < 0 || T < 0 || Hh <= 0 || N < 0 || Dv <= 0)
-        return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: negative or zero dimension (B=%d T=%d Hh=%d N=%d Dv=%d)", B, T, Hh, N, Dv);
-    if (Dk != GDKVM_DK) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: Dk=%d unsupported (kernels are built for Dk=%d)", Dk, GDKVM_DK);
-    if (Dv % 16 != 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: Dv=%d must be a multiple of 16", Dv);
-    if (N > GDKVM_MAX_N) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: N=%d exceeds %d tokens per frame", N, GDKVM_MAX_N);
-    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "scan_fwd: io_dtype=%d", io_dtype);
-    if (rule < 0 || rule > 2) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: rule=%d", rule);
-    if (flags & ~3) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: unknown flags 0x%x", flags);
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: negative or zero dimension (B=%d T=%d Hh=%d N=%d Dv=%d)", fn, B, T, Hh, N, Dv);
+    if (Dk != GDKVM_DK) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: Dk=%d unsupported (kernels are built for Dk=%d)", fn, Dk, GDKVM_DK);
+    if (Dv % 16 != 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: Dv=%d must be a multiple of 16", fn, Dv);
+    if (N > GDKVM_MAX_N) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: N=%d exceeds %d tokens per frame", fn, N, GDKVM_MAX_N);
+    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "%s: io_dtype=%d", fn, io_dtype);
+    if (flags & ~3) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: unknown flags 0x%x", fn, flags);
+    return GDKVM_OK;
+}
+
+int check_ptrs(const char* fn, std::initializer_list<const void*> required, std::initializer_list<const void*> optional)
+{
+    for (const void* p : required) {
+        if (!p) return gdkvm_fail(GDKVM_ERR_ARG, "%s: null pointer", fn);
+        if (!gdkvm_aligned16(p)) return gdkvm_fail(GDKVM_ERR_ARG, "%s: pointer %p is not 16-byte aligned", fn, p);
+    }
+    for (const void* p : optional)
+        if (p && !gdkvm_aligned16(p)) return gdkvm_fail(GDKVM_ERR_ARG, "%s: pointer %p is not 16-byte aligned", fn, p);
+    return GDKVM_OK;
+}
+
+struct WsView { float* wt; float* knT; float* ut; int nb; };
+
+int carve(const char* fn, void* workspace, size_t workspace_bytes, int B, int T, int Hh, int N, int Dk, int Dv, WsView* v)
+{
+    const size_t need = gdkvm_scan_workspace_bytes(B, T, Hh, N, Dk, Dv) - 16;
+    if (workspace_bytes < need)
+        return gdkvm_fail(GDKVM_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, workspace_bytes, need + 16);
+    v->nb = tiles_for(N);
+    const size_t NP = 16 * (size_t)v->nb, FH = (size_t)B * T * Hh;
+    v->wt = static_cast<float*>(workspace);
+    v->knT = v->wt + FH * NP * GDKVM_DK;
+    v->ut = v->knT + FH * NP * GDKVM_DK;
+    return GDKVM_OK;
+}
+
+}  // namespace
+
+extern "C" int gdkvm_scan_prep(const void* k, const void* v, const float* beta, void* workspace, size_t workspace_bytes,
+                               int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
+{
+    if (int rc = check_common("scan_prep", B, T, Hh, N, Dk, Dv, io_dtype, flags)) return rc;
+    if (rule < 0 || rule > 2) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_prep: rule=%d", rule);
+    if (B == 0 || T == 0 || N == 0) return GDKVM_OK;
+    if (int rc = check_ptrs("scan_prep", {k, v, beta, workspace}, {})) return rc;
+    WsView ws;
+    if (int rc = carve("scan_prep", workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
+    if (int rc = gdkvm_check_device()) return rc;
+    PrepArgs pa{k, v, beta, ws.wt, ws.knT, ws.ut, T, Hh, N, Dv, rule, flags};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return io_dtype == GDKVM_F32 ? launch_prep_nb<GDKVM_F32>(ws.nb, pa, B * T * Hh, st)
+                                 : launch_prep_nb<GDKVM_BF16>(ws.nb, pa, B * T * Hh, st);
+}
+
+extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* s_in, void* r_out, float* s_out,
+                                const void* workspace, size_t workspace_bytes,
+                                int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int flags, void* stream)
+{
+    if (int rc = check_common("scan_apply", B, T, Hh, N, Dk, Dv, io_dtype, flags)) return rc;
     if (B == 0) return GDKVM_OK;
     const bool have_tokens = T > 0 && N > 0;
-    if (have_tokens && (!q || !k || !v || !alpha || !beta || !r_out || !workspace))
-        return gdkvm_fail(GDKVM_ERR_ARG, "scan_fwd: null pointer");
-    if (T > 0 && !alpha) return gdkvm_fail(GDKVM_ERR_ARG, "scan_fwd: null alpha");
-    const void* ptrs[] = {q, k, v, alpha, beta, s_in, r_out, s_out, workspace};
-    for (const void* p : ptrs)
-        if (p && !gdkvm_aligned16(p)) return gdkvm_fail(GDKVM_ERR_ARG, "scan_fwd: pointer %p is not 16-byte aligned", p);
-    if (workspace_bytes < gdkvm_scan_workspace_bytes(B, T, Hh, N, Dk, Dv) - 16 && have_tokens)
-        return gdkvm_fail(GDKVM_ERR_WORKSPACE, "scan_fwd: workspace %zu < %zu bytes", workspace_bytes,
-                          gdkvm_scan_workspace_bytes(B, T, Hh, N, Dk, Dv));
-    if (int rc = gdkvm_check_device()) return rc;
-
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const int nb = have_tokens ? tiles_for(N) : 0;
-    const size_t NP = 16 * (size_t)nb, FH = (size_t)B * T * Hh;
-    float* wt = static_cast<float*>(workspace);
-    float* knT = wt + FH * NP * GDKVM_DK;
-    float* ut = knT + FH * NP * GDKVM_DK;
-
+    WsView ws{nullptr, nullptr, nullptr, 0};
     if (have_tokens) {
-        PrepArgs pa{k, v, beta, wt, knT, ut, T, Hh, N, Dv, rule, flags};
-        const int rc = io_dtype == GDKVM_F32 ? launch_prep_nb<GDKVM_F32>(nb, pa, (int)FH, st)
-                                             : launch_prep_nb<GDKVM_BF16>(nb, pa, (int)FH, st);
-        if (rc) return rc;
+        if (int rc = check_ptrs("scan_apply", {q, alpha, r_out, workspace}, {s_in, s_out})) return rc;
+        if (int rc = carve("scan_apply", const_cast<void*>(workspace), workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
+    } else {
+        if (T > 0 && !alpha) return gdkvm_fail(GDKVM_ERR_ARG, "scan_apply: null alpha");
+        if (int rc = check_ptrs("scan_apply", {}, {alpha, s_in, s_out})) return rc;
     }
-    ScanArgs sa{q, alpha, s_in, wt, knT, ut, r_out, s_out, T, Hh, N, Dv, nb, flags, B * Hh};
+    if (int rc = gdkvm_check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ScanArgs sa{q, alpha, s_in, ws.wt, ws.knT, ws.ut, r_out, s_out, T, Hh, N, Dv, ws.nb, flags, B * Hh};
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
     if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_scan_kernel<GDKVM_F32>), grid, dim3(256), 0, st, sa);
     else hipLaunchKernelGGL((gdr_scan_kernel<GDKVM_BF16>), grid, dim3(256), 0, st, sa);
     GDKVM_LAUNCH_CHECK("gdr_scan_kernel");
     return GDKVM_OK;
+}
+
+extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
+                              const float* s_in, void* r_out, float* s_out, void* workspace, size_t workspace_bytes,
+                              int B, int T, int Hh, int N, int Dk, int Dv,
+                              int io_dtype, int rule, int flags, void* stream)
+{
+    if (int rc = gdkvm_scan_prep(k, v, beta, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream)) return rc;
+    return gdkvm_scan_apply(q, alpha, s_in, r_out, s_out, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, flags, stream);
 }

@@ -1,0 +1,208 @@
+"""GDKVM nn.Module -- the Python seam of the drop-in boundary.
+
+The reference's own module is not in the snapshot (/root/reference/README.md:1 points at an un-vendored
+repo), so the surface below is the builder's SPEC-v0: ``forward(frames[B,T,C,H,W], mask0=None, state=None,
+return_state=False) -> logits[B,T,ncls,H,W] (, state)`` with parameters grouped ``encoder.* / key_proj.* /
+query_proj.* / value_proj.* / gate_proj.* / kpff.* / decoder.*`` and one ``_KEY_REMAP`` table applied in
+``load_state_dict`` for the day real checkpoints are visible.
+
+Only the CNN encoder / decoder (unchanged PyTorch-ROCm convolutions, BASELINE.json north_star) run in
+torch.  The memory path between them -- LKVA read, GDR write, KPFF -- is ``ops.scan_fwd`` /
+``ops.kpff_fwd`` (hand-written HIP behind include/gdkvm.h).  There is no eager fallback: on a CPU tensor
+or without libgdkvm_hip.so the forward raises.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+_RULES = {"gated_linear": ops.RULE_GATED_LINEAR, "delta_parallel": ops.RULE_DELTA_PARALLEL,
+          "delta_sequential": ops.RULE_DELTA_SEQUENTIAL}
+
+# checkpoint-key prefixes of the real model code -> ours; empty until that code is visible
+_KEY_REMAP: dict = {}
+
+
+@dataclass
+class GDKVMConfig:
+    in_channels: int = 3
+    num_classes: int = 2            # EchoNet-Dynamic: background / LV.  CAMUS: 4.
+    heads: int = 1                  # Hh
+    key_dim: int = 64               # Dk per head (the HIP kernels are specialised for 64)
+    value_dim: int = 256            # Dv per head
+    pixel_dim: int = 256            # Cp, stride-16 encoder feature
+    widths: Tuple[int, int, int] = (64, 128, 256)
+    rule: str = "delta_sequential"
+    stride: int = 16
+
+
+def _bn(c):
+    return nn.BatchNorm2d(c)
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = _bn(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = _bn(cout)
+        self.down = None
+        if stride != 1 or cin != cout:
+            self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), _bn(cout))
+
+    def forward(self, x):
+        y = F.relu(self.bn1(self.conv1(x)), inplace=True)
+        y = self.bn2(self.conv2(y))
+        return F.relu(y + (x if self.down is None else self.down(x)), inplace=True)
+
+
+class Encoder(nn.Module):
+    """ResNet-18-style trunk to stride 16; returns (f4, f8, f16)."""
+
+    def __init__(self, cin, widths):
+        super().__init__()
+        w4, w8, w16 = widths
+        self.stem = nn.Sequential(nn.Conv2d(cin, w4, 7, 2, 3, bias=False), _bn(w4), nn.ReLU(inplace=True),
+                                  nn.MaxPool2d(3, 2, 1))
+        self.layer1 = nn.Sequential(BasicBlock(w4, w4, 1), BasicBlock(w4, w4, 1))
+        self.layer2 = nn.Sequential(BasicBlock(w4, w8, 2), BasicBlock(w8, w8, 1))
+        self.layer3 = nn.Sequential(BasicBlock(w8, w16, 2), BasicBlock(w16, w16, 1))
+
+    def forward(self, x):
+        f4 = self.layer1(self.stem(x))
+        f8 = self.layer2(f4)
+        return f4, f8, self.layer3(f8)
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cin, cskip, cout):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(cin + cskip, cout, 3, 1, 1, bias=False), _bn(cout), nn.ReLU(inplace=True),
+                                  nn.Conv2d(cout, cout, 3, 1, 1, bias=False), _bn(cout), nn.ReLU(inplace=True))
+
+    def forward(self, x, skip):
+        x = F.interpolate(x, size=skip.shape[-2:], mode="bilinear", align_corners=False)
+        return self.conv(torch.cat([x, skip], 1))
+
+
+class Decoder(nn.Module):
+    def __init__(self, cp, widths, ncls):
+        super().__init__()
+        w4, w8, _ = widths
+        self.up8 = UpBlock(cp, w8, w8)
+        self.up4 = UpBlock(w8, w4, w4)
+        self.head = nn.Conv2d(w4, ncls, 1)
+
+    def forward(self, f, f8, f4, size):
+        x = self.head(self.up4(self.up8(f, f8), f4))
+        return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+
+
+class KPFFParams(nn.Module):
+    """Weights of Key-Pixel Feature Fusion; always fp32 (the kernel reads fp32 weights)."""
+
+    def __init__(self, ck, cv, cp):
+        super().__init__()
+        cin = cp + ck + cv
+        self.wa = nn.Parameter(torch.empty(2 * cp, cin))
+        self.ba = nn.Parameter(torch.zeros(2 * cp))
+        self.wl = nn.Parameter(torch.empty(cp, ck))
+        self.wg = nn.Parameter(torch.empty(cp, cv))
+        for p in (self.wa, self.wl, self.wg):
+            nn.init.kaiming_uniform_(p, a=5 ** 0.5)
+
+
+class GDKVM(nn.Module):
+    def __init__(self, cfg: Optional[GDKVMConfig] = None):
+        super().__init__()
+        self.cfg = cfg = cfg or GDKVMConfig()
+        if cfg.rule not in _RULES:
+            raise ValueError(f"unknown rule {cfg.rule!r}")
+        Hh, Dk, Dv, Cp = cfg.heads, cfg.key_dim, cfg.value_dim, cfg.pixel_dim
+        if cfg.widths[2] != Cp:
+            raise ValueError("pixel_dim must equal the stride-16 encoder width")
+        self.encoder = Encoder(cfg.in_channels, cfg.widths)
+        self.key_proj = nn.Conv2d(Cp, Hh * Dk, 1)
+        self.query_proj = nn.Conv2d(Cp, Hh * Dk, 1)
+        self.value_proj = nn.Conv2d(Cp, Hh * Dv, 1)
+        self.mask_embed = nn.Conv2d(1, Hh * Dv, 1, bias=False)          # first-frame mask -> value (optional input)
+        self.gate_proj = nn.Conv2d(Cp, Hh, 1)                            # beta logits, per token and head
+        self.decay_proj = nn.Linear(Cp, Hh)                              # alpha logits, per frame and head
+        nn.init.constant_(self.decay_proj.bias, 2.0)                     # sigmoid(2) ~ 0.88: remember by default
+        self.kpff = KPFFParams(Hh * Dk, Hh * Dv, Cp)
+        self.decoder = Decoder(Cp, cfg.widths, cfg.num_classes)
+
+    # ------------------------------------------------------------------ memory path (HIP; overridable hooks)
+    def _memory_scan(self, q, k, v, alpha_logit, beta_logit, state):
+        """q,k [B,T,N,Hh,Dk] v [B,T,N,Hh,Dv] alpha [B,T,Hh] beta [B,T,N,Hh] -> (R [B,T,N,Hh,Dv], S_T)."""
+        return ops.scan_fwd(q, k, v, alpha_logit, beta_logit, state, rule=_RULES[self.cfg.rule],
+                            flags=ops.FLAG_NORMALIZE_QK | ops.FLAG_GATE_LOGITS)
+
+    def _fuse(self, local, glob, pixel, h, w):
+        p = self.kpff
+        return ops.kpff_fwd(local, glob, pixel, p.wa.float(), p.ba.float(), p.wl.float(), p.wg.float(), h, w)
+
+    # ------------------------------------------------------------------------------------------ forward
+    @staticmethod
+    def _tokens(x):
+        """[BT,C,h,w] conv output -> [BT, h*w, C] token-major view (free when x is channels_last)."""
+        return x.permute(0, 2, 3, 1).reshape(x.shape[0], x.shape[2] * x.shape[3], x.shape[1]).contiguous()
+
+    def forward(self, frames: torch.Tensor, mask0: Optional[torch.Tensor] = None,
+                state: Optional[torch.Tensor] = None, return_state: bool = False):
+        if frames.dim() != 5:
+            raise ValueError("frames must be [B,T,C,H,W]")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("GDKVM.forward: the memory path has no backward kernel yet "
+                                      "(SURVEY.md §8 row a7); call under torch.no_grad()")
+        cfg = self.cfg
+        B, T, C, H, W = frames.shape
+        Hh, Dk, Dv = cfg.heads, cfg.key_dim, cfg.value_dim
+        x = frames.reshape(B * T, C, H, W).contiguous(memory_format=torch.channels_last)
+        f4, f8, f16 = self.encoder(x)
+        h, w = f16.shape[-2:]
+        N = h * w
+        key = self.key_proj(f16)
+        val = self.value_proj(f16)
+        if mask0 is not None:
+            m = F.adaptive_avg_pool2d(mask0.to(val.dtype), (h, w))
+            val = val.reshape(B, T, *val.shape[1:])
+            val = torch.cat([val[:, :1] + self.mask_embed(m).unsqueeze(1), val[:, 1:]], 1).reshape(B * T, Hh * Dv, h, w)
+        k_tok = self._tokens(key)                                                # [BT,N,Hh*Dk] local key feature
+        q = self._tokens(self.query_proj(f16)).reshape(B, T, N, Hh, Dk)
+        v = self._tokens(val).reshape(B, T, N, Hh, Dv)
+        beta = self._tokens(self.gate_proj(f16)).float().reshape(B, T, N, Hh)
+        alpha = self.decay_proj(f16.mean((2, 3))).float().reshape(B, T, Hh)
+        r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state)
+        p_tok = self._tokens(f16)
+        fused = self._fuse(k_tok, r.reshape(B * T, N, Hh * Dv), p_tok, h, w)       # [BT,N,Cp]
+        fmap = fused.reshape(B * T, h, w, -1).permute(0, 3, 1, 2)                  # channels_last view, no copy
+        logits = self.decoder(fmap, f8, f4, (H, W)).reshape(B, T, cfg.num_classes, H, W)
+        return (logits, s_out) if return_state else logits
+
+    @torch.no_grad()
+    def segment(self, frames, target=None, **kw):
+        """logits -> (mask uint8 [B,T,H,W], Dice counts int32 [B,T,ncls,3] | None) with the HIP argmax kernel."""
+        logits = self.forward(frames, **kw)
+        B, T, ncls, H, W = logits.shape
+        tgt = None if target is None else target.reshape(B * T, H, W).contiguous()
+        mask, counts = ops.argmax_dice(logits.reshape(B * T, ncls, H, W).contiguous(), tgt)
+        return mask.reshape(B, T, H, W), (None if counts is None else counts.reshape(B, T, ncls, 3))
+
+    # -------------------------------------------------------------------------------------- checkpoints
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        remapped = {}
+        for key, val in state_dict.items():
+            for old, new in _KEY_REMAP.items():
+                if key.startswith(old):
+                    key = new + key[len(old):]
+                    break
+            remapped[key] = val
+        return super().load_state_dict(remapped, strict=strict, **kw)

@@ -27,6 +27,8 @@ SIGNATURES = {
     "gdkvm_last_error": (ctypes.c_char_p, []),
     "gdkvm_scan_workspace_bytes": (_sz, [_i] * 6),
     "gdkvm_scan_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
+    "gdkvm_scan_prep": (_i, [_vp] * 4 + [_sz] + [_i] * 9 + [_vp]),
+    "gdkvm_scan_apply": (_i, [_vp] * 6 + [_sz] + [_i] * 8 + [_vp]),
     "gdkvm_kpff_fwd": (_i, [_vp] * 8 + [_i] * 7 + [_vp]),
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
 }
@@ -138,6 +140,31 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
                                 workspace.data_ptr(), workspace.numel() * workspace.element_size(),
                                 B, T, Hh, N, Dk, Dv, io, rule, flags, _stream(dev))
     _check(rc, "gdkvm_scan_fwd")
+    return r, s
+
+
+def scan_prep(k, v, beta, workspace, rule=RULE_DELTA_SEQUENTIAL, flags=0):
+    """Stage 1 of scan_fwd alone (gdkvm_scan_prep): fills ``workspace`` with the per-frame WY factors."""
+    B, T, N, Hh, Dk = k.shape
+    Dv = v.shape[-1]
+    dev = _dev(k, v, beta, workspace)
+    with torch.cuda.device(dev):
+        rc = load().gdkvm_scan_prep(_ptr(k), _ptr(v), _ptr(beta), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                    B, T, Hh, N, Dk, Dv, _io_dtype(k), rule, flags, _stream(dev))
+    _check(rc, "gdkvm_scan_prep")
+
+
+def scan_apply(q, alpha, workspace, Dv, state=None, flags=0, out=None, state_out=None):
+    """Stage 2 of scan_fwd alone (gdkvm_scan_apply): the serial read/write recurrence over a prepared workspace."""
+    B, T, N, Hh, Dk = q.shape
+    dev = _dev(q, alpha, workspace, state, out, state_out)
+    r = out if out is not None else torch.empty((B, T, N, Hh, Dv), dtype=q.dtype, device=dev)
+    s = state_out if state_out is not None else torch.empty((B, Hh, Dk, Dv), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().gdkvm_scan_apply(_ptr(q), _ptr(alpha), _ptr(state), _ptr(r), _ptr(s), workspace.data_ptr(),
+                                     workspace.numel() * workspace.element_size(), B, T, Hh, N, Dk, Dv, _io_dtype(q), flags,
+                                     _stream(dev))
+    _check(rc, "gdkvm_scan_apply")
     return r, s
 
 

@@ -1,0 +1,37 @@
+"""GDKVMRef -- the CPU reference of the whole module: the SAME encoder/decoder definitions and state_dict as
+gdkvm_amd.model.GDKVM (PyTorch CPU convolutions), with the memory path replaced by the CPU oracle
+(oracle/gdkvm_oracle.c through ctypes).  TEST INFRASTRUCTURE ONLY: used by tests/, smoke() and bench.py's
+cpu_baseline leg; the product never imports this (the dependency points from the oracle to the product's
+layer definitions, never the other way)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from gdkvm_amd.model import GDKVM, _RULES
+from oracle import c_oracle
+
+
+class GDKVMRef(GDKVM):
+    math = "f32"          # arithmetic of the C oracle: "f32" (CPU-baseline speed) or "f64" (parity checks)
+
+    def _memory_scan(self, q, k, v, alpha_logit, beta_logit, state):
+        args = [t.detach().float().cpu().numpy() for t in (q, k, v, alpha_logit, beta_logit)]
+        s0 = None if state is None else state.detach().float().cpu().numpy()
+        r, s = c_oracle.scan(*args, s0, _RULES[self.cfg.rule], 3, math=self.math)
+        return torch.from_numpy(r).to(q.dtype), torch.from_numpy(s)
+
+    def _fuse(self, local, glob, pixel, h, w):
+        p = self.kpff
+        f = c_oracle.kpff(*(t.detach().float().cpu().numpy() for t in (local, glob, pixel, p.wa, p.ba, p.wl, p.wg)),
+                          h, w, math=self.math)
+        return torch.from_numpy(f).to(pixel.dtype)
+
+    @torch.no_grad()
+    def segment(self, frames, target=None, **kw):
+        logits = self.forward(frames, **kw)
+        B, T, ncls, H, W = logits.shape
+        tgt = None if target is None else target.reshape(B * T, H, W).numpy()
+        mask, counts = c_oracle.argmax_dice(logits.reshape(B * T, ncls, H, W).float().numpy(), tgt)
+        return (torch.from_numpy(mask).reshape(B, T, H, W),
+                None if counts is None else torch.from_numpy(counts).reshape(B, T, ncls, 3))
