@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Shorten a rocprofv3 *_kernel_stats.csv into a readable, committed summary.
+usage: python profiles/summarize.py <kernel_stats.csv> <out.csv> "<command line that was profiled>" """
+import csv
+import re
+import sys
+
+
+def short(name: str) -> str:
+    name = re.sub(r"^void\s+", "", name)
+    name = name.replace("(anonymous namespace)::", "").replace("at::native::", "")
+    m = re.match(r"([A-Za-z_0-9:]+)(<[^(]{0,40})?", name)
+    s = (m.group(1) + (m.group(2) or "")) if m else name
+    if "elementwise_kernel" in s or "distribution" in s:
+        inner = re.search(r"(bfloat16_copy|bfloat16tofloat32_copy|direct_copy|launch_clamp|CUDAFunctor_add|CUDAFunctorOnSelf_add|normal_kernel)", name)
+        if inner:
+            s = s.split("<")[0] + "[" + inner.group(1) + "]"
+    return s[:100].replace(",", ";")
+
+
+def main():
+    src, dst, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
+    rows = list(csv.DictReader(open(src)))
+    with open(dst, "w") as f:
+        f.write(f"# {cmd}\n")
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+        for r in rows:
+            f.write(f"{short(r['Name'])},{r['Calls']},{r['TotalDurationNs']},{float(r['AverageNs']):.0f},"
+                    f"{r['Percentage']},{r['MinNs']},{r['MaxNs']}\n")
+
+
+if __name__ == "__main__":
+    main()
