@@ -24,6 +24,7 @@
 #include <string.h>
 
 #include <initializer_list>
+#include <type_traits>
 
 #include "gdkvm_common.hpp"
 
@@ -197,22 +198,82 @@ __global__ __launch_bounds__(256) void gdr_prep_kernel(PrepArgs a)
     }
 }
 
+#ifdef GDKVM_DIAG
+// Diagnostic build only (libgdkvm_hip_diag.so, built by tools/diag_scan.py): wave 0 of block 0 stamps s_memtime at
+// five points per frame into a buffer of its own.  Never compiled into the product library.
+static unsigned long long* g_diag_buf = nullptr;
+extern "C" void gdkvm_diag_set_buffer(unsigned long long* p) { g_diag_buf = p; }
+#define DIAG_STAMP(slot)                                                                      \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t__;                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");            \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (a.diag && blockIdx.x == 0 && tid == 0) a.diag[(size_t)t * 8 + (slot)] = t__;      \
+    } while (0)
+#else
+#define DIAG_STAMP(slot) do {} while (0)
+#endif
+
 struct ScanArgs {
     const void* q; const float* alpha; const float* s_in;
     const float* wt; const float* knT; const float* ut;
     void* r_out; float* s_out;
-    int T, Hh, N, Dv, nb, flags, BH;
+    int T, Hh, N, Dv, flags, BH;
+#ifdef GDKVM_DIAG
+    unsigned long long* diag;
+#endif
 };
 
-template <int IO>
+// 4 consecutive channels as fetched (bf16 stays packed until use, so a prefetched tile costs half the VGPRs)
+template <int IO> struct Raw4;
+template <> struct Raw4<GDKVM_F32> { f32x4 v; };
+template <> struct Raw4<GDKVM_BF16> { uint2 v; };
+template <int IO> __device__ __forceinline__ Raw4<IO> raw_load4(const void* base, size_t off)
+{
+    Raw4<IO> r;
+    if constexpr (IO == GDKVM_F32) r.v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + off);
+    else r.v = *reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(base) + off);
+    return r;
+}
+template <int IO> __device__ __forceinline__ f32x4 widen(const Raw4<IO>& r)
+{
+    if constexpr (IO == GDKVM_F32) return r.v;
+    else {
+        f32x4 x;
+        x[0] = __uint_as_float(r.v.x << 16); x[1] = __uint_as_float(r.v.x & 0xffff0000u);
+        x[2] = __uint_as_float(r.v.y << 16); x[3] = __uint_as_float(r.v.y & 0xffff0000u);
+        return x;
+    }
+}
+
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+
+// Operands of one read/erase item (one 16-token tile of one frame) and of one write item (4 token tiles).
+template <int IO> struct ReadItem { Raw4<IO> q[4]; f32x4 w[4]; f32x4 u; float alpha; };
+struct WriteItem { f32x4 k[4]; };
+
+// Software-pipelined recurrence.  Per frame each wave runs JT = NB/4 read items ([R;X] = [Qn;Wt] S, U = Ut - aX)
+// then NB/4 write items (S <- aS + Kn^T U).  The global loads of item i+1 are issued before item i is computed
+// and stay in flight across the workgroup barriers (plain loads survive s_barrier), so the serial chain per
+// frame is LDS + MFMA only.
+template <int IO, int NB>
 __global__ __launch_bounds__(256) void gdr_scan_kernel(ScanArgs a)
 {
+    constexpr int NP = 16 * NB, JT = NB / 4, NG = NB / 4;
     __shared__ __attribute__((aligned(16))) f32x4 s_S[4 * 64];
-    __shared__ __attribute__((aligned(16))) f32x4 s_U[(GDKVM_MAX_N / 16) * 64];
+    __shared__ __attribute__((aligned(16))) f32x4 s_U[NB * 64];
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nsl = a.Dv / 16, N = a.N, Hh = a.Hh, Dv = a.Dv, nb = a.nb, NP = 16 * a.nb, T = a.T;
+    const int nsl = a.Dv / 16, N = a.N, Hh = a.Hh, Dv = a.Dv, T = a.T;
     // XCD-aware mapping: blocks x and x+8 share an XCD (L2); keep the slices of one (clip, head) -- which
     // re-read the same q / wt / knT -- on one XCD when the grid allows it (speed only, never correctness).
     int bh, sl;
@@ -223,6 +284,40 @@ __global__ __launch_bounds__(256) void gdr_scan_kernel(ScanArgs a)
     }
     const int b = bh / Hh, h = bh % Hh;
     const int col = h * Dv + 16 * sl + li;               // this lane's column inside a [.., Hh*Dv] row
+    const size_t fh0 = (size_t)b * T * Hh + h;           // frame-head index of frame 0; +Hh per frame
+
+    auto load_read = [&](int item, ReadItem<IO>& d) {    // item = t*JT + j  -> token tile tt = w + 4j of frame t
+        const int t = item / JT, tt = w + 4 * (item - t * JT);
+        if (t < T) {
+            const size_t bt = (size_t)b * T + t, fh = fh0 + (size_t)t * Hh;
+            const int n = 16 * tt + li;
+            const float* wt = a.wt + fh * NP * GDKVM_DK + (size_t)n * GDKVM_DK + 4 * g;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (n < N) d.q[m] = raw_load4<IO>(a.q, ((bt * N + n) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
+                else d.q[m] = Raw4<IO>{};
+                d.w[m] = *reinterpret_cast<const f32x4*>(wt + 16 * m);
+            }
+            d.u = reinterpret_cast<const f32x4*>(a.ut + fh * NP * Dv)[((size_t)sl * NB + tt) * 64 + lane];
+            d.alpha = a.alpha[fh];
+        }
+    };
+    auto load_write = [&](int item, WriteItem& d) {      // item = t*NG + gi -> token tiles 4gi..4gi+3 of frame t
+        const int t = item / NG, gi = item - t * NG;
+        if (t < T) {
+            const float* knT = a.knT + (fh0 + (size_t)t * Hh) * GDKVM_DK * NP + (size_t)(16 * w + li) * NP + 64 * gi + 4 * g;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d.k[j] = *reinterpret_cast<const f32x4*>(knT + 16 * j);
+        }
+    };
+
+    // ping-pong operand buffers: item i computes from buffer (i & 1) and prefetches item i+1 into the other
+    // one.  The parity is a compile-time constant (frames are unrolled by two), so no register copies exist
+    // for the compiler to hoist in front of a barrier -- which would turn into an early vmcnt wait.
+    ReadItem<IO> rd0, rd1;
+    WriteItem wr0, wr1;
+    load_read(0, rd0);
+    load_write(0, wr0);
 
     // state tile of this wave: rows 16w + 4g + r of S, column `col`
     f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
@@ -233,76 +328,108 @@ __global__ __launch_bounds__(256) void gdr_scan_kernel(ScanArgs a)
     s_S[w * 64 + lane] = sacc;
     __syncthreads();
 
-    for (int t = 0; t < T; ++t) {
-        const size_t bt = (size_t)b * T + t;
-        const size_t fh = bt * Hh + h;
-        float alpha = a.alpha[fh];
-        if (a.flags & GDKVM_FLAG_GATE_LOGITS) alpha = 1.0f / (1.0f + expf(-alpha));
-        const float* wt = a.wt + fh * NP * GDKVM_DK;
-        const float* knT = a.knT + fh * GDKVM_DK * NP;
-        const f32x4* ut = reinterpret_cast<const f32x4*>(a.ut + fh * NP * Dv) + (size_t)sl * nb * 64;
+    const bool gate_logits = a.flags & GDKVM_FLAG_GATE_LOGITS, normalize = a.flags & GDKVM_FLAG_NORMALIZE_QK;
 
-        f32x4 sreg[4];
+    auto read_item = [&](int t, int j, const ReadItem<IO>& cur, ReadItem<IO>& nxt, const f32x4 (&sreg)[4], float& alpha) {
+        load_read(t * JT + j + 1, nxt);
+        const int tt = w + 4 * j;
+        alpha = cur.alpha;
+        if (gate_logits) alpha = 1.0f / (1.0f + expf(-alpha));
+        f32x4 qa[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) sreg[m] = s_S[m * 64 + lane];
-
-        for (int tt = w; tt < nb; tt += 4) {
-            const int n = 16 * tt + li;
-            f32x4 qa[4], wa[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                qa[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (n < N) qa[m] = load4<IO>(a.q, ((bt * N + n) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
-                wa[m] = *reinterpret_cast<const f32x4*>(wt + (size_t)n * GDKVM_DK + 16 * m + 4 * g);
-            }
-            const f32x4 ut4 = ut[tt * 64 + lane];
-            if (a.flags & GDKVM_FLAG_NORMALIZE_QK) {
-                float ss = 0.f;
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ss += qa[m][r] * qa[m][r];
-                ss += __shfl_xor(ss, 16);
-                ss += __shfl_xor(ss, 32);
-                const float inv = 1.0f / sqrtf(ss + GDKVM_EPS_NORM);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) qa[m] *= inv;
-            }
-            f32x4 accR = {0.f, 0.f, 0.f, 0.f}, accX = {0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < 4; ++m) qa[m] = widen<IO>(cur.q[m]);
+        if (normalize) {
+            float ss = 0.f;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    accR = mfma4(qa[m][r], sreg[m][r], accR);
-                    accX = mfma4(wa[m][r], sreg[m][r], accX);
-                }
+                for (int r = 0; r < 4; ++r) ss += qa[m][r] * qa[m][r];
+            ss += __shfl_xor(ss, 16);
+            ss += __shfl_xor(ss, 32);
+            const float inv = 1.0f / sqrtf(ss + GDKVM_EPS_NORM);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) qa[m] *= inv;
+        }
+        f32x4 accR = {0.f, 0.f, 0.f, 0.f}, accX = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int nr = 16 * tt + 4 * g + r;
-                if (nr < N) store1<IO>(a.r_out, (bt * N + nr) * Hh * Dv + col, accR[r]);
+                accX = mfma4(cur.w[m][r], sreg[m][r], accX);
+                accR = mfma4(qa[m][r], sreg[m][r], accR);
             }
-            f32x4 u;
+        f32x4 u;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) u[r] = ut4[r] - alpha * accX[r];
-            s_U[tt * 64 + lane] = u;
+        for (int r = 0; r < 4; ++r) u[r] = cur.u[r] - alpha * accX[r];
+        s_U[tt * 64 + lane] = u;
+        const size_t bt = (size_t)b * T + t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nr = 16 * tt + 4 * g + r;
+            if (nr < N) store1<IO>(a.r_out, (bt * N + nr) * Hh * Dv + col, accR[r]);
         }
+    };
+    auto write_item = [&](int t, int gi, const WriteItem& cur, WriteItem& nxt, f32x4& acc0, f32x4& acc1) {
+        load_write(t * NG + gi + 1, nxt);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 ub = s_U[(4 * gi + j) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (j & 1) acc1 = mfma4(cur.k[j][r], ub[r], acc1);
+                else acc0 = mfma4(cur.k[j][r], ub[r], acc0);
+            }
+        }
+    };
+    auto frame = [&](int t, auto parity) {
+        constexpr int P = decltype(parity)::value;
+        DIAG_STAMP(0);
+        f32x4 sreg[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) sreg[m] = s_S[m * 64 + lane];
+        float alpha = 0.f;
+        static_for<0, JT>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (((P * JT + j) & 1) == 0) read_item(t, j, rd0, rd1, sreg, alpha);
+            else read_item(t, j, rd1, rd0, sreg, alpha);
+        });
+        DIAG_STAMP(1);
         __syncthreads();
-
-        f32x4 acc = sacc * alpha;
-        for (int tt = 0; tt < nb; ++tt) {
-            const f32x4 ub = s_U[tt * 64 + lane];
-            const f32x4 ka = *reinterpret_cast<const f32x4*>(knT + (size_t)(16 * w + li) * NP + 16 * tt + 4 * g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc = mfma4(ka[r], ub[r], acc);
-        }
-        sacc = acc;
+        DIAG_STAMP(2);
+        f32x4 acc0 = sacc * alpha, acc1 = {0.f, 0.f, 0.f, 0.f};      // two chains: hide the 40-cycle MFMA latency
+        static_for<0, NG>([&](auto gc) {
+            constexpr int gi = decltype(gc)::value;
+            if constexpr (((P * NG + gi) & 1) == 0) write_item(t, gi, wr0, wr1, acc0, acc1);
+            else write_item(t, gi, wr1, wr0, acc0, acc1);
+        });
+        sacc = acc0 + acc1;
+        DIAG_STAMP(3);
         s_S[w * 64 + lane] = sacc;
         __syncthreads();
+        DIAG_STAMP(4);
+    };
+    for (int t = 0; t < T; t += 2) {
+        frame(t, std::integral_constant<int, 0>{});
+        if (t + 1 < T) frame(t + 1, std::integral_constant<int, 1>{});
     }
     if (a.s_out) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) a.s_out[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li] = sacc[r];
     }
+}
+
+// N == 0: no tokens -> the state only decays, S_T = S_0 * prod_t alpha_t (no read-out rows exist)
+__global__ void gdr_decay_kernel(const float* alpha, const float* s_in, float* s_out, int T, int Hh, int per_bh, int flags)
+{
+    const int bh = blockIdx.y, b = bh / Hh, h = bh % Hh;
+    float f = 1.f;
+    for (int t = 0; t < T; ++t) {
+        float al = alpha[((size_t)b * T + t) * Hh + h];
+        if (flags & GDKVM_FLAG_GATE_LOGITS) al = 1.0f / (1.0f + expf(-al));
+        f *= al;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < per_bh; i += gridDim.x * blockDim.x)
+        s_out[(size_t)bh * per_bh + i] = s_in ? s_in[(size_t)bh * per_bh + i] * f : 0.f;
 }
 
 int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
@@ -415,10 +542,27 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
     }
     if (int rc = gdkvm_check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    ScanArgs sa{q, alpha, s_in, ws.wt, ws.knT, ws.ut, r_out, s_out, T, Hh, N, Dv, ws.nb, flags, B * Hh};
+    if (!have_tokens) {
+        if (s_out) {
+            hipLaunchKernelGGL(gdr_decay_kernel, dim3(4, (unsigned)(B * Hh)), dim3(256), 0, st, alpha, s_in, s_out, T, Hh,
+                               GDKVM_DK * Dv, flags);
+            GDKVM_LAUNCH_CHECK("gdr_decay_kernel");
+        }
+        return GDKVM_OK;
+    }
+    ScanArgs sa{q, alpha, s_in, ws.wt, ws.knT, ws.ut, r_out, s_out, T, Hh, N, Dv, flags, B * Hh};
+#ifdef GDKVM_DIAG
+    sa.diag = g_diag_buf;
+#endif
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
-    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_scan_kernel<GDKVM_F32>), grid, dim3(256), 0, st, sa);
-    else hipLaunchKernelGGL((gdr_scan_kernel<GDKVM_BF16>), grid, dim3(256), 0, st, sa);
+#define GDKVM_SCAN_LAUNCH(IO)                                                                         \
+    switch (ws.nb) {                                                                                  \
+        case 4: hipLaunchKernelGGL((gdr_scan_kernel<IO, 4>), grid, dim3(256), 0, st, sa); break;      \
+        case 8: hipLaunchKernelGGL((gdr_scan_kernel<IO, 8>), grid, dim3(256), 0, st, sa); break;      \
+        default: hipLaunchKernelGGL((gdr_scan_kernel<IO, 16>), grid, dim3(256), 0, st, sa); break;    \
+    }
+    if (io_dtype == GDKVM_F32) { GDKVM_SCAN_LAUNCH(GDKVM_F32) } else { GDKVM_SCAN_LAUNCH(GDKVM_BF16) }
+#undef GDKVM_SCAN_LAUNCH
     GDKVM_LAUNCH_CHECK("gdr_scan_kernel");
     return GDKVM_OK;
 }

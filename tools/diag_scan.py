@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Diagnostic only: builds libgdkvm_hip_diag.so (-DGDKVM_DIAG: s_memtime stamps in gdr_scan_kernel) and prints where
+one workgroup's cycles go per frame.  Shares of a diagnostic build, never a quoted run time
+(cdna_hip_programming.md §7 'In-kernel stamps')."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "gdkvm_amd", "csrc")
+SO = os.path.join(ROOT, "gpurun_out", "libgdkvm_hip_diag.so")
+
+
+def main():
+    os.makedirs(os.path.dirname(SO), exist_ok=True)
+    srcs = [os.path.join(CSRC, f) for f in ("gdr_scan.hip", "gdkvm_api.hip")]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGDKVM_DIAG",
+                           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", SO] + srcs)
+    lib = ctypes.CDLL(SO)
+    B, T, N, Hh, Dk, Dv = 16, 32, 49, 1, 64, 256
+    dev = torch.device("cuda")
+    q, k = (torch.randn(B, T, N, Hh, Dk, device=dev).bfloat16() for _ in range(2))
+    v = torch.randn(B, T, N, Hh, Dv, device=dev).bfloat16()
+    al = 2 + torch.randn(B, T, Hh, device=dev); be = torch.randn(B, T, N, Hh, device=dev)
+    lib.gdkvm_scan_workspace_bytes.restype = ctypes.c_size_t
+    wsb = lib.gdkvm_scan_workspace_bytes(B, T, Hh, N, Dk, Dv)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    r = torch.empty(B, T, N, Hh, Dv, device=dev, dtype=torch.bfloat16); s = torch.empty(B, Hh, Dk, Dv, device=dev)
+    diag = torch.zeros(T * 8, dtype=torch.int64, device=dev)
+    lib.gdkvm_diag_set_buffer(ctypes.c_void_p(diag.data_ptr()))
+    vp = ctypes.c_void_p
+    lib.gdkvm_scan_fwd.argtypes = [vp] * 9 + [ctypes.c_size_t] + [ctypes.c_int] * 9 + [vp]
+    for _ in range(3):
+        rc = lib.gdkvm_scan_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), al.data_ptr(), be.data_ptr(), None, r.data_ptr(),
+                                s.data_ptr(), ws.data_ptr(), wsb, B, T, Hh, N, Dk, Dv, 1, 2, 3, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+    d = diag.cpu().reshape(T, 8)[:, :5]
+    seg = torch.stack([d[:, 1] - d[:, 0], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2], d[:, 4] - d[:, 3]], 1).float()
+    names = ["read items (S lds read + 32 MFMA + U/R out)", "barrier 1", "write items (U lds read + 16 MFMA)", "S lds write + barrier 2"]
+    print("s_memtime ticks per frame (median over frames 2..T-1), block 0 wave 0; 1 tick = 1 shader cycle")
+    for i, n in enumerate(names):
+        print(f"  {n:48s} {seg[2:, i].median().item():8.0f}")
+    print(f"  frame total {(d[2:, 4] - d[2:, 0]).float().median().item():.0f}; whole scan {(d[-1, 4] - d[0, 0]).item()} ticks")
+
+
+if __name__ == "__main__":
+    main()
