@@ -218,7 +218,7 @@ extern "C" void gdkvm_diag_set_buffer(unsigned long long* p) { g_diag_buf = p; }
 struct ScanArgs {
     const void* q; const float* alpha; const float* s_in;
     const float* wt; const float* knT; const float* ut;
-    void* r_out; float* s_out;
+    void* r_out; float* s_out; char* trash;
     int T, Hh, N, Dv, flags, BH;
 #ifdef GDKVM_DIAG
     unsigned long long* diag;
@@ -256,23 +256,40 @@ __device__ __forceinline__ void static_for(F&& f)
     }
 }
 
-// Operands of one read/erase item (one 16-token tile of one frame) and of one write item (4 token tiles).
-template <int IO> struct ReadItem { Raw4<IO> q[4]; f32x4 w[4]; f32x4 u; float alpha; };
-struct WriteItem { f32x4 k[4]; };
+// Operands of one item (one 16-token tile of one frame) per role, as prefetched into registers.
+template <int IO> struct QItem { Raw4<IO> q[4]; };                    // read-out waves:  R = Qn S
+struct XItem { f32x4 w[4]; f32x4 u; float alpha; };                    // state waves:     X = Wt S, U = Ut - aX
+struct KItem { f32x4 k[4]; };                                          // state waves:     S <- aS + Kn^T U (4 token tiles)
 
-// Software-pipelined recurrence.  Per frame each wave runs JT = NB/4 read items ([R;X] = [Qn;Wt] S, U = Ut - aX)
-// then NB/4 write items (S <- aS + Kn^T U).  The global loads of item i+1 are issued before item i is computed
-// and stay in flight across the workgroup barriers (plain loads survive s_barrier), so the serial chain per
-// frame is LDS + MFMA only.
+__device__ __forceinline__ float fast_sigmoid(float x)
+{   // v_exp_f32 + v_rcp_f32 (1 ulp each): relative error < 1e-6 for |x| < 16, far inside the 1e-4 budget
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+
+// Serial-in-time recurrence, 8 waves per workgroup in two roles (wave-specialised):
+//   state waves 0-3   the critical path.  Per frame: X = Wt S (16 MFMA per tile), U = Ut - aX -> LDS, barrier,
+//                     S <- aS + Kn^T U (this wave owns S rows 16w..16w+15; 4*NB MFMA), S -> LDS, barrier.
+//   read waves  4-7   the LKVA read-out R = Qn S_{t-1} (16 MFMA per tile) with its loads, L2 normalisation and
+//                     stores -- everything that is NOT on the S -> S dependency chain.  They share the two barriers
+//                     per frame and the S image in LDS; their VALU/memory work overlaps the state waves' MFMA chain
+//                     on the same SIMD (one wave of each role per SIMD).
+// Operands live in 4 rotating register buffers per role; item i computes from buffer i%4 and, when done, prefetches
+// item i+3 into the buffer item i-1 freed (>= 3000 cycles ahead; the measured latency of these MALL/HBM-resident
+// operands under load is ~2500 cycles).  The loops are branch-free (clamped indices, read-out rows of padding tokens
+// go to a trash slot): a CFG merge makes hipcc's vmcnt bookkeeping conservative, and a conservative wait lands on
+// the freshly issued loads and exposes the full latency every frame.
 template <int IO, int NB>
-__global__ __launch_bounds__(256) void gdr_scan_kernel(ScanArgs a)
+__global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
 {
-    constexpr int NP = 16 * NB, JT = NB / 4, NG = NB / 4;
+    constexpr int NP = 16 * NB, JT = NB / 4, NG = NB / 4, NBUF = 4, DEPTH = 3, UF = NBUF / JT;
+    static_assert(JT == 1 || JT == 2 || JT == 4, "token tiles per wave");
     __shared__ __attribute__((aligned(16))) f32x4 s_S[4 * 64];
     __shared__ __attribute__((aligned(16))) f32x4 s_U[NB * 64];
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wave & 3;
+    const bool read_role = wave >= 4;
     const int nsl = a.Dv / 16, N = a.N, Hh = a.Hh, Dv = a.Dv, T = a.T;
     // XCD-aware mapping: blocks x and x+8 share an XCD (L2); keep the slices of one (clip, head) -- which
     // re-read the same q / wt / knT -- on one XCD when the grid allows it (speed only, never correctness).
@@ -283,94 +300,154 @@ __global__ __launch_bounds__(256) void gdr_scan_kernel(ScanArgs a)
         else { bh = x / nsl; sl = x % nsl; }
     }
     const int b = bh / Hh, h = bh % Hh;
-    const int col = h * Dv + 16 * sl + li;               // this lane's column inside a [.., Hh*Dv] row
     const size_t fh0 = (size_t)b * T * Hh + h;           // frame-head index of frame 0; +Hh per frame
+    const int last_item = T * JT - 1;
+    constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
 
-    auto load_read = [&](int item, ReadItem<IO>& d) {    // item = t*JT + j  -> token tile tt = w + 4j of frame t
-        const int t = item / JT, tt = w + 4 * (item - t * JT);
-        if (t < T) {
-            const size_t bt = (size_t)b * T + t, fh = fh0 + (size_t)t * Hh;
-            const int n = 16 * tt + li;
-            const float* wt = a.wt + fh * NP * GDKVM_DK + (size_t)n * GDKVM_DK + 4 * g;
+    // state tile of wave w: rows 16w + 4g + r of S, column 16*sl + li.  Both roles start from the LDS image.
+    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+    if (!read_role) {
+        if (a.s_in) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[r] = a.s_in[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li];
+        }
+        s_S[w * 64 + lane] = sacc;
+    }
+
+    if (read_role) {
+        // ------------------------------------------------------------------------------ read-out waves
+        const bool normalize = a.flags & GDKVM_FLAG_NORMALIZE_QK;
+        const char* qbase = static_cast<const char*>(a.q) + (((size_t)b * T * N * Hh + h) * GDKVM_DK + 4 * g) * ESZ;
+        const size_t q_fstride = (size_t)N * Hh * GDKVM_DK * ESZ;               // bytes per frame
+        char* rbase = static_cast<char*>(a.r_out) + ((size_t)b * T * N * Hh * Dv + h * Dv + 16 * sl + li) * ESZ;
+        const size_t r_fstride = (size_t)N * Hh * Dv * ESZ;
+        auto load_q = [&](int item, QItem<IO>& d) {
+            item = min(item, last_item);                  // past the end: re-fetch the last item (never used)
+            const int t = item / JT, tt = w + 4 * (item - t * JT);
+            const int nq = min(16 * tt + li, N - 1);      // padding tokens fetch a real row; zeroed at use
+            const char* p = qbase + t * q_fstride + (size_t)nq * (Hh * GDKVM_DK * ESZ);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                if (n < N) d.q[m] = raw_load4<IO>(a.q, ((bt * N + n) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
-                else d.q[m] = Raw4<IO>{};
-                d.w[m] = *reinterpret_cast<const f32x4*>(wt + 16 * m);
+                if constexpr (IO == GDKVM_F32) d.q[m].v = *reinterpret_cast<const f32x4*>(p + 64 * m);
+                else d.q[m].v = *reinterpret_cast<const uint2*>(p + 32 * m);
             }
-            d.u = reinterpret_cast<const f32x4*>(a.ut + fh * NP * Dv)[((size_t)sl * NB + tt) * 64 + lane];
-            d.alpha = a.alpha[fh];
-        }
-    };
-    auto load_write = [&](int item, WriteItem& d) {      // item = t*NG + gi -> token tiles 4gi..4gi+3 of frame t
-        const int t = item / NG, gi = item - t * NG;
-        if (t < T) {
-            const float* knT = a.knT + (fh0 + (size_t)t * Hh) * GDKVM_DK * NP + (size_t)(16 * w + li) * NP + 64 * gi + 4 * g;
+        };
+        QItem<IO> qb[NBUF];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d.k[j] = *reinterpret_cast<const f32x4*>(knT + 16 * j);
-        }
-    };
+        for (int i = 0; i < DEPTH; ++i) load_q(i, qb[i]);
+        __syncthreads();
 
-    // ping-pong operand buffers: item i computes from buffer (i & 1) and prefetches item i+1 into the other
-    // one.  The parity is a compile-time constant (frames are unrolled by two), so no register copies exist
-    // for the compiler to hoist in front of a barrier -- which would turn into an early vmcnt wait.
-    ReadItem<IO> rd0, rd1;
-    WriteItem wr0, wr1;
-    load_read(0, rd0);
-    load_write(0, wr0);
-
-    // state tile of this wave: rows 16w + 4g + r of S, column `col`
-    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
-    if (a.s_in) {
+        auto read_item = [&](int t, int j, const QItem<IO>& cur, QItem<IO>& nxt, const f32x4 (&sreg)[4]) {
+            const int tt = w + 4 * j;
+            const float qmask = (16 * tt + li < N) ? 1.f : 0.f;
+            f32x4 qa[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[r] = a.s_in[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li];
-    }
-    s_S[w * 64 + lane] = sacc;
-    __syncthreads();
-
-    const bool gate_logits = a.flags & GDKVM_FLAG_GATE_LOGITS, normalize = a.flags & GDKVM_FLAG_NORMALIZE_QK;
-
-    auto read_item = [&](int t, int j, const ReadItem<IO>& cur, ReadItem<IO>& nxt, const f32x4 (&sreg)[4], float& alpha) {
-        load_read(t * JT + j + 1, nxt);
-        const int tt = w + 4 * j;
-        alpha = cur.alpha;
-        if (gate_logits) alpha = 1.0f / (1.0f + expf(-alpha));
-        f32x4 qa[4];
+            for (int m = 0; m < 4; ++m) qa[m] = widen<IO>(cur.q[m]) * qmask;
+            if (normalize) {
+                float ss = 0.f;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) qa[m] = widen<IO>(cur.q[m]);
-        if (normalize) {
-            float ss = 0.f;
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ss += qa[m][r] * qa[m][r];
+                ss += __shfl_xor(ss, 16);
+                ss += __shfl_xor(ss, 32);
+                const float inv = 1.0f / sqrtf(ss + GDKVM_EPS_NORM);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) qa[m] *= inv;
+            }
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ss += qa[m][r] * qa[m][r];
-            ss += __shfl_xor(ss, 16);
-            ss += __shfl_xor(ss, 32);
-            const float inv = 1.0f / sqrtf(ss + GDKVM_EPS_NORM);
+                for (int r = 0; r < 4; ++r) {
+                    if (m & 1) acc1 = mfma4(qa[m][r], sreg[m][r], acc1);
+                    else acc0 = mfma4(qa[m][r], sreg[m][r], acc0);
+                }
+            const f32x4 accR = acc0 + acc1;
+            char* rp = rbase + t * r_fstride;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) qa[m] *= inv;
+            for (int r = 0; r < 4; ++r) {
+                const int nr = 16 * tt + 4 * g + r;
+                char* p = nr < N ? rp + (size_t)nr * (Hh * Dv * ESZ) : a.trash;
+                if constexpr (IO == GDKVM_F32) *reinterpret_cast<float*>(p) = accR[r];
+                else *reinterpret_cast<bf16_t*>(p) = f32_to_bf16(accR[r]);
+            }
+            load_q(t * JT + j + DEPTH, nxt);               // after every use of `cur`: waits above never see these
+        };
+        auto frame = [&](int t, auto fc) {
+            constexpr int F = decltype(fc)::value;         // frame index inside the unrolled group: buffer ids static
+            f32x4 sreg[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) sreg[m] = s_S[m * 64 + lane];
+            static_for<0, JT>([&](auto jc) {
+                constexpr int i = F * JT + decltype(jc)::value;
+                read_item(t, decltype(jc)::value, qb[i % NBUF], qb[(i + DEPTH) % NBUF], sreg);
+            });
+            __syncthreads();                               // (1) U complete / this wave is done reading S_{t-1}
+            __syncthreads();                               // (2) S_t published
+        };
+        for (int t0 = 0; t0 < T; t0 += UF) {
+            bool done = false;
+            static_for<0, UF>([&](auto fc) {
+                if (!done) {
+                    if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, fc);
+                    else done = true;
+                }
+            });
         }
-        f32x4 accR = {0.f, 0.f, 0.f, 0.f}, accX = {0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------- state waves
+    const bool gate_logits = a.flags & GDKVM_FLAG_GATE_LOGITS;
+    const float* wt_lane = a.wt + fh0 * NP * GDKVM_DK + (size_t)li * GDKVM_DK + 4 * g;
+    const size_t wt_fstride = (size_t)Hh * NP * GDKVM_DK;
+    const f32x4* ut_lane = reinterpret_cast<const f32x4*>(a.ut + fh0 * NP * Dv) + (size_t)sl * NB * 64 + lane;
+    const size_t ut_fstride = (size_t)Hh * NP * Dv / 4;
+    const float* kn_lane = a.knT + fh0 * GDKVM_DK * NP + (size_t)(16 * w + li) * NP + 4 * g;
+    const size_t kn_fstride = (size_t)Hh * GDKVM_DK * NP;
+    const float* al_ptr = a.alpha + fh0;
+
+    auto load_x = [&](int item, XItem& d) {              // item = t*JT + j  -> token tile tt = w + 4j of frame t
+        item = min(item, last_item);
+        const int t = item / JT, tt = w + 4 * (item - t * JT);
+        const float* wt = wt_lane + t * wt_fstride + tt * (16 * GDKVM_DK);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) d.w[m] = *reinterpret_cast<const f32x4*>(wt + 16 * m);
+        d.u = ut_lane[t * ut_fstride + tt * 64];
+        d.alpha = al_ptr[(size_t)t * Hh];
+    };
+    auto load_k = [&](int item, KItem& d) {              // item = t*NG + gi -> token tiles 4gi..4gi+3 of frame t
+        item = min(item, last_item);
+        const int t = item / NG, gi = item - t * NG;
+        const float* kp = kn_lane + t * kn_fstride + 64 * gi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d.k[j] = *reinterpret_cast<const f32x4*>(kp + 16 * j);
+    };
+    XItem xb[NBUF];
+    KItem kb[NBUF];
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) { load_x(i, xb[i]); load_k(i, kb[i]); }
+    __syncthreads();
+
+    auto x_item = [&](int t, int j, const XItem& cur, XItem& nxt, const f32x4 (&sreg)[4], float& alpha) {
+        const int tt = w + 4 * j;
+        alpha = gate_logits ? fast_sigmoid(cur.alpha) : cur.alpha;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                accX = mfma4(cur.w[m][r], sreg[m][r], accX);
-                accR = mfma4(qa[m][r], sreg[m][r], accR);
+                if (m & 1) acc1 = mfma4(cur.w[m][r], sreg[m][r], acc1);
+                else acc0 = mfma4(cur.w[m][r], sreg[m][r], acc0);
             }
         f32x4 u;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) u[r] = cur.u[r] - alpha * accX[r];
+        for (int r = 0; r < 4; ++r) u[r] = cur.u[r] - alpha * (acc0[r] + acc1[r]);
         s_U[tt * 64 + lane] = u;
-        const size_t bt = (size_t)b * T + t;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int nr = 16 * tt + 4 * g + r;
-            if (nr < N) store1<IO>(a.r_out, (bt * N + nr) * Hh * Dv + col, accR[r]);
-        }
+        load_x(t * JT + j + DEPTH, nxt);
     };
-    auto write_item = [&](int t, int gi, const WriteItem& cur, WriteItem& nxt, f32x4& acc0, f32x4& acc1) {
-        load_write(t * NG + gi + 1, nxt);
+    auto k_item = [&](int t, int gi, const KItem& cur, KItem& nxt, f32x4& acc0, f32x4& acc1) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x4 ub = s_U[(4 * gi + j) * 64 + lane];
@@ -380,27 +457,26 @@ __global__ __launch_bounds__(256) void gdr_scan_kernel(ScanArgs a)
                 else acc0 = mfma4(cur.k[j][r], ub[r], acc0);
             }
         }
+        load_k(t * NG + gi + DEPTH, nxt);
     };
-    auto frame = [&](int t, auto parity) {
-        constexpr int P = decltype(parity)::value;
+    auto frame = [&](int t, auto fc) {
+        constexpr int F = decltype(fc)::value;
         DIAG_STAMP(0);
         f32x4 sreg[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) sreg[m] = s_S[m * 64 + lane];
         float alpha = 0.f;
         static_for<0, JT>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            if constexpr (((P * JT + j) & 1) == 0) read_item(t, j, rd0, rd1, sreg, alpha);
-            else read_item(t, j, rd1, rd0, sreg, alpha);
+            constexpr int i = F * JT + decltype(jc)::value;
+            x_item(t, decltype(jc)::value, xb[i % NBUF], xb[(i + DEPTH) % NBUF], sreg, alpha);
         });
         DIAG_STAMP(1);
         __syncthreads();
         DIAG_STAMP(2);
         f32x4 acc0 = sacc * alpha, acc1 = {0.f, 0.f, 0.f, 0.f};      // two chains: hide the 40-cycle MFMA latency
         static_for<0, NG>([&](auto gc) {
-            constexpr int gi = decltype(gc)::value;
-            if constexpr (((P * NG + gi) & 1) == 0) write_item(t, gi, wr0, wr1, acc0, acc1);
-            else write_item(t, gi, wr1, wr0, acc0, acc1);
+            constexpr int i = F * NG + decltype(gc)::value;
+            k_item(t, decltype(gc)::value, kb[i % NBUF], kb[(i + DEPTH) % NBUF], acc0, acc1);
         });
         sacc = acc0 + acc1;
         DIAG_STAMP(3);
@@ -408,9 +484,14 @@ __global__ __launch_bounds__(256) void gdr_scan_kernel(ScanArgs a)
         __syncthreads();
         DIAG_STAMP(4);
     };
-    for (int t = 0; t < T; t += 2) {
-        frame(t, std::integral_constant<int, 0>{});
-        if (t + 1 < T) frame(t + 1, std::integral_constant<int, 1>{});
+    for (int t0 = 0; t0 < T; t0 += UF) {
+        bool done = false;
+        static_for<0, UF>([&](auto fc) {
+            if (!done) {
+                if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, fc);
+                else done = true;
+            }
+        });
     }
     if (a.s_out) {
 #pragma unroll
@@ -432,6 +513,7 @@ __global__ void gdr_decay_kernel(const float* alpha, const float* s_in, float* s
         s_out[(size_t)bh * per_bh + i] = s_in ? s_in[(size_t)bh * per_bh + i] * f : 0.f;
 }
 
+constexpr size_t GDKVM_WS_TAIL = 256;   // trash slot for padded read-out rows
 int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
 
 template <int NB, int IO>
@@ -462,9 +544,9 @@ int launch_prep_nb(int nb, const PrepArgs& pa, int FH, hipStream_t st)
 
 extern "C" size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
 {
-    if (B <= 0 || T <= 0 || Hh <= 0 || N <= 0 || Dk <= 0 || Dv <= 0 || N > GDKVM_MAX_N) return 16;
+    if (B <= 0 || T <= 0 || Hh <= 0 || N <= 0 || Dk <= 0 || Dv <= 0 || N > GDKVM_MAX_N) return GDKVM_WS_TAIL;
     const size_t NP = 16 * (size_t)tiles_for(N);
-    return (size_t)B * T * Hh * NP * (2 * (size_t)Dk + Dv) * sizeof(float) + 16;
+    return (size_t)B * T * Hh * NP * (2 * (size_t)Dk + Dv) * sizeof(float) + GDKVM_WS_TAIL;
 }
 
 namespace {
@@ -492,18 +574,19 @@ int check_ptrs(const char* fn, std::initializer_list<const void*> required, std:
     return GDKVM_OK;
 }
 
-struct WsView { float* wt; float* knT; float* ut; int nb; };
+struct WsView { float* wt; float* knT; float* ut; char* trash; int nb; };
 
 int carve(const char* fn, void* workspace, size_t workspace_bytes, int B, int T, int Hh, int N, int Dk, int Dv, WsView* v)
 {
-    const size_t need = gdkvm_scan_workspace_bytes(B, T, Hh, N, Dk, Dv) - 16;
+    const size_t need = gdkvm_scan_workspace_bytes(B, T, Hh, N, Dk, Dv);
     if (workspace_bytes < need)
-        return gdkvm_fail(GDKVM_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, workspace_bytes, need + 16);
+        return gdkvm_fail(GDKVM_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, workspace_bytes, need);
     v->nb = tiles_for(N);
     const size_t NP = 16 * (size_t)v->nb, FH = (size_t)B * T * Hh;
     v->wt = static_cast<float*>(workspace);
     v->knT = v->wt + FH * NP * GDKVM_DK;
     v->ut = v->knT + FH * NP * GDKVM_DK;
+    v->trash = reinterpret_cast<char*>(v->ut + FH * NP * Dv);       // write-only slot for read-out rows of padding tokens
     return GDKVM_OK;
 }
 
@@ -532,7 +615,7 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
     if (int rc = check_common("scan_apply", B, T, Hh, N, Dk, Dv, io_dtype, flags)) return rc;
     if (B == 0) return GDKVM_OK;
     const bool have_tokens = T > 0 && N > 0;
-    WsView ws{nullptr, nullptr, nullptr, 0};
+    WsView ws{nullptr, nullptr, nullptr, nullptr, 0};
     if (have_tokens) {
         if (int rc = check_ptrs("scan_apply", {q, alpha, r_out, workspace}, {s_in, s_out})) return rc;
         if (int rc = carve("scan_apply", const_cast<void*>(workspace), workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
@@ -550,16 +633,16 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
         }
         return GDKVM_OK;
     }
-    ScanArgs sa{q, alpha, s_in, ws.wt, ws.knT, ws.ut, r_out, s_out, T, Hh, N, Dv, flags, B * Hh};
+    ScanArgs sa{q, alpha, s_in, ws.wt, ws.knT, ws.ut, r_out, s_out, ws.trash, T, Hh, N, Dv, flags, B * Hh};
 #ifdef GDKVM_DIAG
     sa.diag = g_diag_buf;
 #endif
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
 #define GDKVM_SCAN_LAUNCH(IO)                                                                         \
     switch (ws.nb) {                                                                                  \
-        case 4: hipLaunchKernelGGL((gdr_scan_kernel<IO, 4>), grid, dim3(256), 0, st, sa); break;      \
-        case 8: hipLaunchKernelGGL((gdr_scan_kernel<IO, 8>), grid, dim3(256), 0, st, sa); break;      \
-        default: hipLaunchKernelGGL((gdr_scan_kernel<IO, 16>), grid, dim3(256), 0, st, sa); break;    \
+        case 4: hipLaunchKernelGGL((gdr_scan_kernel<IO, 4>), grid, dim3(512), 0, st, sa); break;      \
+        case 8: hipLaunchKernelGGL((gdr_scan_kernel<IO, 8>), grid, dim3(512), 0, st, sa); break;      \
+        default: hipLaunchKernelGGL((gdr_scan_kernel<IO, 16>), grid, dim3(512), 0, st, sa); break;    \
     }
     if (io_dtype == GDKVM_F32) { GDKVM_SCAN_LAUNCH(GDKVM_F32) } else { GDKVM_SCAN_LAUNCH(GDKVM_BF16) }
 #undef GDKVM_SCAN_LAUNCH
