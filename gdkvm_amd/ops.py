@@ -29,7 +29,8 @@ SIGNATURES = {
     "gdkvm_scan_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_prep": (_i, [_vp] * 4 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_apply": (_i, [_vp] * 6 + [_sz] + [_i] * 8 + [_vp]),
-    "gdkvm_kpff_fwd": (_i, [_vp] * 8 + [_i] * 7 + [_vp]),
+    "gdkvm_kpff_workspace_bytes": (_sz, [_i] * 4),
+    "gdkvm_kpff_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 7 + [_vp]),
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
 }
 
@@ -169,7 +170,8 @@ def scan_apply(q, alpha, workspace, Dv, state=None, flags=0, out=None, state_out
 
 
 def kpff_fwd(local: torch.Tensor, glob: torch.Tensor, pixel: torch.Tensor, wa: torch.Tensor, ba: torch.Tensor,
-             wl: torch.Tensor, wg: torch.Tensor, h: int, w: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+             wl: torch.Tensor, wg: torch.Tensor, h: int, w: int, out: Optional[torch.Tensor] = None,
+             workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Key-Pixel Feature Fusion (gdkvm_kpff_fwd).  local [BT,N,Ck] glob [BT,N,Cv] pixel [BT,N,Cp], N=h*w;
     wa [2Cp,Cp+Ck+Cv] ba [2Cp] wl [Cp,Ck] wg [Cp,Cv] float32.  Returns F [BT,N,Cp] in the io dtype."""
     lib = load()
@@ -185,11 +187,14 @@ def kpff_fwd(local: torch.Tensor, glob: torch.Tensor, pixel: torch.Tensor, wa: t
             raise GdkvmError("KPFF weights must be float32")
     if glob.dtype != local.dtype or pixel.dtype != local.dtype:
         raise GdkvmError("KPFF features must share one dtype")
-    dev = _dev(local, glob, pixel, wa, ba, wl, wg, out)
+    dev = _dev(local, glob, pixel, wa, ba, wl, wg, out, workspace)
+    io = _io_dtype(local)
     f = out if out is not None else torch.empty((BT, N, Cp), dtype=local.dtype, device=dev)
+    if workspace is None:
+        workspace = torch.empty(int(lib.gdkvm_kpff_workspace_bytes(Ck, Cv, Cp, io)), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = lib.gdkvm_kpff_fwd(_ptr(local), _ptr(glob), _ptr(pixel), _ptr(wa), _ptr(ba), _ptr(wl), _ptr(wg), _ptr(f),
-                                BT, Ck, Cv, Cp, h, w, _io_dtype(local), _stream(dev))
+                                workspace.data_ptr(), workspace.numel(), BT, Ck, Cv, Cp, h, w, io, _stream(dev))
     _check(rc, "gdkvm_kpff_fwd")
     return f
 

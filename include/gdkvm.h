@@ -85,9 +85,15 @@ int gdkvm_scan_apply(const void* q, const float* alpha, const float* s_in, void*
  *   wa [2Cp, Cp+Ck+Cv]  ba [2Cp]  wl [Cp,Ck]  wg [Cp,Cv]                 (fp32)
  *   Gms = mean_{s in 1,2,4} cellmean_s(global);  g = sigmoid([P;L;Gms] wa^T + ba) = (g_l | g_g)
  *   out = P + g_l * (L wl^T) + g_g * (Gms wg^T)
- * Supported: Ck, Cv, Cp multiples of 16; h*w <= 256. */
+ * Arithmetic: io_dtype f32 -> exact fp32 MFMA.  io_dtype bf16 with channel counts that are multiples of 32 ->
+ * bf16 MFMA with fp32 accumulation (weights and the pooled feature are rounded to bf16, i.e. bf16-autocast
+ * accuracy); other bf16 shapes use the exact fp32 arm.  `workspace` (gdkvm_kpff_workspace_bytes) holds the bf16
+ * copy of the weights, rebuilt on every call; it may be NULL for io_dtype f32.
+ * Supported: Ck, Cv, Cp multiples of 16; h*w <= 256, w <= 16 when h*w > 64. */
+size_t gdkvm_kpff_workspace_bytes(int Ck, int Cv, int Cp, int io_dtype);
 int gdkvm_kpff_fwd(const void* local, const void* global, const void* pixel,
                    const float* wa, const float* ba, const float* wl, const float* wg, void* out,
+                   void* workspace, size_t workspace_bytes,
                    int BT, int Ck, int Cv, int Cp, int h, int w, int io_dtype, void* stream);
 
 /* Row a6: mask = argmax_c logits (ties -> lowest class index); optional integer Dice counts.

@@ -26,8 +26,25 @@ def test_kpff_fp32(hip, case):
     assert np.abs(F - Fo).max() <= 1e-4
 
 
-def test_kpff_bf16_io(hip):
-    BT, h, w, Ck, Cv, Cp = 4, 7, 7, 64, 256, 256
+@pytest.mark.parametrize("case", [(4, 7, 7, 64, 256, 256), (2, 16, 16, 64, 256, 256), (3, 4, 4, 32, 32, 64), (2, 14, 14, 64, 64, 128)])
+def test_kpff_bf16_mfma_arm(hip, case):
+    """bf16 I/O, channels % 32 == 0 -> bf16 MFMA arm: weights and the pooled feature are rounded to bf16 (bf16
+    autocast accuracy).  Checked against the oracle fed the same bf16-rounded inputs AND weights; what is left is
+    the bf16 rounding of the pooled feature and of the output: 1e-2 absolute + 2^-7 relative."""
+    BT, h, w, Ck, Cv, Cp = case
+    L, G, P, Wa, ba, Wl, Wg = make_kpff_inputs(BT, h, w, Ck, Cv, Cp, seed=sum(case))
+    F = hip.kpff_fwd(_dev(L, torch.bfloat16), _dev(G, torch.bfloat16), _dev(P, torch.bfloat16),
+                     _dev(Wa), _dev(ba), _dev(Wl), _dev(Wg), h, w).float().cpu().numpy()
+    Fo = c_oracle.kpff(O.to_bf16_f32(L), O.to_bf16_f32(G), O.to_bf16_f32(P), O.to_bf16_f32(Wa), ba, O.to_bf16_f32(Wl),
+                       O.to_bf16_f32(Wg), h, w)
+    err = np.abs(F - Fo)
+    assert np.all(err <= 1e-2 + np.abs(Fo) * 2.0 ** -7), err.max()
+    assert err.mean() <= 2e-3
+
+
+def test_kpff_bf16_io_exact_arm(hip):
+    """bf16 I/O with channel counts that are not multiples of 32 keeps the exact fp32-MFMA arm."""
+    BT, h, w, Ck, Cv, Cp = 4, 7, 7, 16, 48, 80
     L, G, P, Wa, ba, Wl, Wg = make_kpff_inputs(BT, h, w, Ck, Cv, Cp, seed=3)
     F = hip.kpff_fwd(_dev(L, torch.bfloat16), _dev(G, torch.bfloat16), _dev(P, torch.bfloat16),
                      _dev(Wa), _dev(ba), _dev(Wl), _dev(Wg), h, w).float().cpu().numpy()
