@@ -105,8 +105,36 @@ class Decoder(nn.Module):
         return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
 
 
+def _fold_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d) -> nn.Conv2d:
+    """conv -> BN(eval) == one conv with W' = W * g/sqrt(var+eps), b' = beta + (b - mean) * g/sqrt(var+eps)."""
+    fused = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
+                      conv.dilation, conv.groups, bias=True).to(conv.weight.device, conv.weight.dtype)
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    fused.weight.data = conv.weight * scale.reshape(-1, 1, 1, 1)
+    b0 = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
+    fused.bias.data = bn.bias + (b0 - bn.running_mean) * scale
+    return fused
+
+
+def _fold_sequential(seq: nn.Sequential) -> nn.Sequential:
+    mods, out, i = list(seq), [], 0
+    while i < len(mods):
+        if isinstance(mods[i], nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
+            out.append(_fold_bn(mods[i], mods[i + 1])); i += 2
+        else:
+            out.append(mods[i]); i += 1
+    return nn.Sequential(*out)
+
+
 class KPFFParams(nn.Module):
     """Weights of Key-Pixel Feature Fusion; always fp32 (the kernel reads fp32 weights)."""
+
+    def _apply(self, fn, recurse=True):
+        # .to(bfloat16) / .half() on the parent must not narrow these: device moves only
+        def keep_fp32(t):
+            r = fn(t)
+            return r.float() if r.is_floating_point() else r
+        return super()._apply(keep_fp32, recurse)
 
     def __init__(self, ck, cv, cp):
         super().__init__()
@@ -163,6 +191,7 @@ class GDKVM(nn.Module):
             raise NotImplementedError("GDKVM.forward: the memory path has no backward kernel yet "
                                       "(SURVEY.md §8 row a7); call under torch.no_grad()")
         cfg = self.cfg
+        frames = frames.to(self.key_proj.weight.dtype)
         B, T, C, H, W = frames.shape
         Hh, Dk, Dv = cfg.heads, cfg.key_dim, cfg.value_dim
         x = frames.reshape(B * T, C, H, W).contiguous(memory_format=torch.channels_last)
@@ -186,6 +215,24 @@ class GDKVM(nn.Module):
         fmap = fused.reshape(B * T, h, w, -1).permute(0, 3, 1, 2)                  # channels_last view, no copy
         logits = self.decoder(fmap, f8, f4, (H, W)).reshape(B, T, cfg.num_classes, H, W)
         return (logits, s_out) if return_state else logits
+
+    @torch.no_grad()
+    def fuse_for_inference(self):
+        """Fold every eval-mode BatchNorm into the convolution in front of it (in place; inference only).
+        The folded module computes the same function; BatchNorm kernels were 46 % of a cfg2 forward
+        (profiles/r01_a_bench_cfg2_kernel_stats.csv)."""
+        if self.training:
+            raise RuntimeError("fuse_for_inference() needs eval() mode")
+        for m in list(self.modules()):
+            if isinstance(m, BasicBlock) and isinstance(m.bn1, nn.BatchNorm2d):
+                m.conv1, m.bn1 = _fold_bn(m.conv1, m.bn1), nn.Identity()
+                m.conv2, m.bn2 = _fold_bn(m.conv2, m.bn2), nn.Identity()
+                if m.down is not None:
+                    m.down = _fold_sequential(m.down)
+            elif isinstance(m, UpBlock):
+                m.conv = _fold_sequential(m.conv)
+        self.encoder.stem = _fold_sequential(self.encoder.stem)
+        return self
 
     @torch.no_grad()
     def segment(self, frames, target=None, **kw):

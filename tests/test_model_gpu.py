@@ -1,0 +1,85 @@
+"""Whole-module parity on the GPU: GDKVM (torch convs + HIP memory path) vs GDKVMRef (torch CPU convs + oracle)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(cfg=None, seed=0):
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    from oracle.model_ref import GDKVMRef
+    torch.manual_seed(seed)
+    cfg = cfg or GDKVMConfig()
+    ref = GDKVMRef(cfg).eval()
+    ref.math = "f64"
+    for m in ref.modules():                      # non-trivial BatchNorm statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.8, 1.25)
+    model = GDKVM(cfg).eval()
+    model.load_state_dict(ref.state_dict())
+    return ref, model.cuda().to(memory_format=torch.channels_last)
+
+
+def _balance(ref, model, frames):
+    """Random init puts one class everywhere; shift the head bias by the median logit gap so masks are mixed."""
+    with torch.no_grad():
+        lg = ref(frames)
+        for c in range(1, lg.shape[2]):
+            gap = (lg[:, :, 0] - lg[:, :, c]).median()
+            ref.decoder.head.bias[c] += gap
+            model.decoder.head.bias[c] += gap.to(model.decoder.head.bias.device)
+
+
+def test_module_fp32_matches_cpu_reference(hip):
+    ref, model = _pair()
+    frames = torch.rand(2, 4, 3, 112, 112)
+    _balance(ref, model, frames)
+    with torch.no_grad():
+        lr, sr = ref(frames, return_state=True)
+        lg, sg = model(frames.cuda(), return_state=True)
+    lg = lg.cpu(); sg = sg.cpu()
+    assert (lg - lr).abs().max() <= 1e-3 and (sg - sr).abs().max() <= 1e-3
+    mr, mg = lr.argmax(2), lg.argmax(2)
+    frac = mr.float().mean().item()
+    assert 0.2 < frac < 0.8, f"degenerate mask ({frac})"
+    disagree = (mr != mg)
+    # every disagreeing pixel must be a near-tie of the reference logits (MIOpen vs MKLDNN summation order)
+    margin = (lr[:, :, 0] - lr[:, :, 1]).abs()
+    assert disagree.float().mean() <= 1e-3 and (margin[disagree] <= 1e-3).all()
+
+
+def test_module_state_carry_and_mask0(hip):
+    ref, model = _pair(seed=1)
+    frames = torch.rand(1, 6, 3, 112, 112).cuda()
+    mask0 = (torch.rand(1, 1, 112, 112) > 0.5).float().cuda()
+    with torch.no_grad():
+        full, s_full = model(frames, mask0=mask0, return_state=True)
+        a, s = model(frames[:, :2], mask0=mask0, return_state=True)
+        b, s2 = model(frames[:, 2:], state=s, return_state=True)
+    assert torch.equal(torch.cat([a, b], 1), full) and torch.equal(s2, s_full)
+    with torch.no_grad():
+        other = model(frames, mask0=1 - mask0)
+    assert not torch.equal(other, full)           # the first-frame mask does reach the memory
+
+
+def test_module_bf16_fused_dice_parity(hip):
+    """bf16 inference build (BatchNorm folded, bf16 conv weights) vs the fp32 CPU reference: Dice of the masks."""
+    from gdkvm_amd import ops
+    ref, model = _pair(seed=2)
+    frames = torch.rand(2, 8, 3, 112, 112)
+    _balance(ref, model, frames)
+    with torch.no_grad():
+        mr, _ = ref.segment(frames)
+        model = model.fuse_for_inference().to(torch.bfloat16)
+        assert model.kpff.wa.dtype == torch.float32          # KPFF weights stay fp32 under .to(bfloat16)
+        mg, counts = model.segment(frames.cuda(), target=mr.cuda())
+    dice = ops.dice_from_counts(counts.sum((0, 1))).cpu().numpy()
+    assert (dice >= 0.97).all(), dice
+    assert 0.2 < mr.float().mean() < 0.8
+
+
+def test_module_refuses_training_until_backward_exists(hip):
+    _, model = _pair(seed=3)
+    with pytest.raises(NotImplementedError):
+        model(torch.rand(1, 2, 3, 112, 112).cuda())
