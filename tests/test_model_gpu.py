@@ -57,7 +57,9 @@ def test_module_state_carry_and_mask0(hip):
         full, s_full = model(frames, mask0=mask0, return_state=True)
         a, s = model(frames[:, :2], mask0=mask0, return_state=True)
         b, s2 = model(frames[:, 2:], state=s, return_state=True)
-    assert torch.equal(torch.cat([a, b], 1), full) and torch.equal(s2, s_full)
+    # the memory path is bit-identical under chunking (tests/test_scan_gpu.py); the MIOpen convs around it may pick
+    # another algorithm for another batch size, so the module as a whole is compared with a tolerance
+    assert (torch.cat([a, b], 1) - full).abs().max() <= 1e-4 and (s2 - s_full).abs().max() <= 1e-4
     with torch.no_grad():
         other = model(frames, mask0=1 - mask0)
     assert not torch.equal(other, full)           # the first-frame mask does reach the memory
