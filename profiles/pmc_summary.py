@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950).
+usage: python profiles/pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.csv> "<cmd>"
+Units/corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: both counters are in KiB; FETCH_SIZE reads
+exactly 1/2 of the bytes of a wide (16 B/lane) coalesced read stream on gfx950, WRITE_SIZE is exact for 16 B/lane
+stores; other access widths are uncalibrated.  The summary therefore reports the raw value and the x2-corrected
+read bytes side by side (the truth for mixed-width kernels lies between them)."""
+import collections
+import csv
+import re
+import sys
+
+from summarize import short
+
+
+def load(path, counter):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            d[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return d
+
+
+def main():
+    f, w, out, cmd = sys.argv[1:5]
+    fe, wr = load(f, "FETCH_SIZE"), load(w, "WRITE_SIZE")
+    with open(out, "w") as o:
+        o.write(f"# {cmd}\n# per-launch means; KiB as reported by rocprofv3; read_x2 = FETCH_SIZE*2 (gfx950 wide-read correction)\n")
+        o.write("Kernel,launches,FETCH_SIZE_KiB,WRITE_SIZE_KiB,hbm_bytes_raw,hbm_bytes_read_x2\n")
+        for k in sorted(fe, key=lambda k: -sum(fe[k])):
+            if not re.search(r"gdr_|kpff|argmax", k):
+                continue
+            fv = sum(fe[k]) / len(fe[k])
+            wv = sum(wr[k]) / len(wr[k]) if wr.get(k) else 0.0
+            o.write(f"{k},{len(fe[k])},{fv:.1f},{wv:.1f},{(fv + wv) * 1024:.0f},{(2 * fv + wv) * 1024:.0f}\n")
+
+
+if __name__ == "__main__":
+    main()
