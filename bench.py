@@ -143,7 +143,7 @@ def main():
         ws = torch.empty(ops.scan_workspace_bytes(B, T, Hh, N, Dk, Dv), dtype=torch.uint8, device=dev)
         r = torch.empty(B, T, N, Hh, Dv, device=dev, dtype=torch.bfloat16)
         s = torch.empty(B, Hh, Dk, Dv, device=dev)
-        prep_ms, _ = time_events(lambda: ops.scan_prep(k, v, be, ws, flags=3), args.kernel_iters)
+        prep_ms, _ = time_events(lambda: ops.scan_prep(q, k, v, be, ws, flags=3), args.kernel_iters)
         scan_ms, _ = time_events(lambda: ops.scan_apply(q, al, ws, Dv, flags=3, out=r, state_out=s), args.kernel_iters)
         both_ms, _ = time_events(lambda: ops.scan_fwd(q, k, v, al, be, flags=3, workspace=ws, out=r, state_out=s),
                                  args.kernel_iters)

@@ -7,6 +7,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define GDKVM_DK 64             // per-head key dim the kernels are specialised for (SURVEY.md §8 defaults)
 #define GDKVM_MAX_N 256

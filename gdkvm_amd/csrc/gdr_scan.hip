@@ -31,8 +31,8 @@
 namespace {
 
 struct PrepArgs {
-    const void* k; const void* v; const float* beta;
-    float* wt; float* knT; float* ut;
+    const void* q; const void* k; const void* v; const float* beta;
+    float* wt; float* knT; float* ut; float* qinv;
     int T, Hh, N, Dv, rule, flags;
 };
 
@@ -44,8 +44,10 @@ __host__ __device__ constexpr size_t prep_lds_bytes(int NB)
     return (size_t)(2 * 16 * NB + (NB * (NB - 1) / 2 + 2 * NB) * 256) * sizeof(float);
 }
 
-template <int NB, int IO>
-__global__ __launch_bounds__(256) void gdr_prep_kernel(PrepArgs a)
+// TPR = column tiles a wave solves at once.  Their operands are fetched at kernel entry (latency hidden behind
+// the norm / Gram / T_II phases) and their substitution chains are interleaved (TPR independent MFMA chains).
+template <int NB, int IO, int TPR>
+__global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prep_kernel(PrepArgs a)
 {
     constexpr int NP = 16 * NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -62,26 +64,51 @@ __global__ __launch_bounds__(256) void gdr_prep_kernel(PrepArgs a)
     const size_t bt = fh / a.Hh;
     const int N = a.N, Hh = a.Hh, Dv = a.Dv;
     const bool seq = a.rule == GDKVM_RULE_DELTA_SEQUENTIAL;
+    const int ntile = GDKVM_DK / 16 + Dv / 16;       // column tiles: 4 of K (-> Wt, Kn^T) then Dv/16 of V (-> Ut)
+    const int nround = (ntile + 4 * TPR - 1) / (4 * TPR);
 
-    // ---- phase 0 (a5 prologue): inverse key norms and gates -> LDS -------------------------------
+    // raw operands of this wave's column tiles for one round: x[i][I][r] = X[token 16I+4g+r][col 16c+li]
+    float xr[TPR][NB][4];
+    auto fetch_round = [&](int rd) {
+#pragma unroll
+        for (int i = 0; i < TPR; ++i) {
+            const int c = min((rd * TPR + i) * 4 + w, ntile - 1);          // clamp: surplus slots refetch a real tile
+            const bool isK = c < GDKVM_DK / 16;
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = min(16 * I + 4 * g + r, N - 1);          // padding tokens: real row, zeroed by beta = 0
+                    xr[i][I][r] = isK ? load1<IO>(a.k, ((bt * N + n) * Hh + h) * GDKVM_DK + 16 * c + li)
+                                      : load1<IO>(a.v, ((bt * N + n) * Hh + h) * Dv + 16 * (c - 4) + li);
+                }
+        }
+    };
+    fetch_round(0);
+
+    // ---- phase 0 (a5 prologue): inverse key / query norms and gates ----------------------------------
     for (int n = tid; n < NP; n += 256) {
-        float kinv = 0.f, bta = 0.f;
+        float kinv = 0.f, qinv = 0.f, bta = 0.f;
         if (n < N) {
-            kinv = 1.f;
+            kinv = qinv = 1.f;
             if (a.flags & GDKVM_FLAG_NORMALIZE_QK) {
-                float ss = 0.f;
+                float sk = 0.f, sq = 0.f;
 #pragma unroll
                 for (int c = 0; c < GDKVM_DK; c += 4) {
                     const f32x4 x = load4<IO>(a.k, ((bt * N + n) * Hh + h) * GDKVM_DK + c);
-                    ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+                    const f32x4 y = load4<IO>(a.q, ((bt * N + n) * Hh + h) * GDKVM_DK + c);
+                    sk += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+                    sq += y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
                 }
-                kinv = 1.0f / sqrtf(ss + GDKVM_EPS_NORM);
+                kinv = 1.0f / sqrtf(sk + GDKVM_EPS_NORM);
+                qinv = 1.0f / sqrtf(sq + GDKVM_EPS_NORM);
             }
             bta = a.beta[(bt * N + n) * Hh + h];
             if (a.flags & GDKVM_FLAG_GATE_LOGITS) bta = 1.0f / (1.0f + expf(-bta));
         }
         s_kinv[n] = kinv;
         s_beta[n] = bta;
+        a.qinv[(size_t)fh * NP + n] = qinv;
     }
     __syncthreads();
 
@@ -93,16 +120,22 @@ __global__ __launch_bounds__(256) void gdr_prep_kernel(PrepArgs a)
             while ((I + 1) * (I + 2) / 2 <= p) ++I;
             const int J = p - I * (I + 1) / 2;
             const int nI = 16 * I + li, nJ = 16 * J + li;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            f32x4 kI[4], kJ[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                f32x4 kI = {0.f, 0.f, 0.f, 0.f}, kJ = {0.f, 0.f, 0.f, 0.f};
-                if (nI < N) kI = load4<IO>(a.k, ((bt * N + nI) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
-                if (nJ < N) kJ = load4<IO>(a.k, ((bt * N + nJ) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc = mfma4(kJ[r], kI[r], acc);
+                kI[m] = load4<IO>(a.k, ((bt * N + min(nI, N - 1)) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
+                kJ[m] = load4<IO>(a.k, ((bt * N + min(nJ, N - 1)) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
             }
-            const float rowscale = s_kinv[nI] * s_beta[nI];
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (m & 1) acc1 = mfma4(kJ[m][r], kI[m][r], acc1);
+                    else acc0 = mfma4(kJ[m][r], kI[m][r], acc0);
+                }
+            f32x4 acc = acc0 + acc1;
+            const float rowscale = s_kinv[nI] * s_beta[nI];                 // 0 for padding rows (kinv = beta = 0)
             const f32x4 kinvJ = *reinterpret_cast<const f32x4*>(s_kinv + 16 * J + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[r] *= rowscale * kinvJ[r];
@@ -124,14 +157,14 @@ __global__ __launch_bounds__(256) void gdr_prep_kernel(PrepArgs a)
                 for (int i = 0; i < 16; ++i) t[i] = (i == j) ? 1.f : 0.f;
 #pragma unroll
                 for (int i = 1; i < 16; ++i) {
-                    float s = 0.f;
+                    float sm = 0.f;
 #pragma unroll
                     for (int gg = 0; gg * 4 < i; ++gg) {
                         const f32x4 Lr = s_Ld[I * 64 + gg * 16 + i];        // L[i][4gg .. 4gg+3]
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) if (4 * gg + r < i) s += Lr[r] * t[4 * gg + r];
+                        for (int r = 0; r < 4; ++r) if (4 * gg + r < i) sm += Lr[r] * t[4 * gg + r];
                     }
-                    t[i] = (i > j) ? -s : t[i];
+                    t[i] = (i > j) ? -sm : t[i];
                 }
                 float* Tm = reinterpret_cast<float*>(s_Tm + I * 64);
 #pragma unroll
@@ -141,58 +174,63 @@ __global__ __launch_bounds__(256) void gdr_prep_kernel(PrepArgs a)
         __syncthreads();
     }
 
-    // ---- phase 3: per 16-column tile, blocked forward substitution entirely in accumulators -----------
-    const int ntile = GDKVM_DK / 16 + Dv / 16;
+    // ---- phase 3: blocked forward substitution entirely in accumulators, TPR column tiles interleaved ----
     float* wt = a.wt + (size_t)fh * NP * GDKVM_DK;
     float* knT = a.knT + (size_t)fh * GDKVM_DK * NP;
     f32x4* ut = reinterpret_cast<f32x4*>(a.ut + (size_t)fh * NP * Dv);
-    for (int c = w; c < ntile; c += 4) {
-        const bool isK = c < GDKVM_DK / 16;
-        f32x4 Y[NB];
+    for (int rd = 0; rd < nround; ++rd) {
+        if (rd > 0) fetch_round(rd);
+        f32x4 Y[TPR][NB];
 #pragma unroll
         for (int I = 0; I < NB; ++I) {
             const int n0 = 16 * I + 4 * g;
             const f32x4 bt4 = *reinterpret_cast<const f32x4*>(s_beta + n0);
-            f32x4 acc;
-            if (isK) {
-                const f32x4 ki4 = *reinterpret_cast<const f32x4*>(s_kinv + n0);
+            const f32x4 ki4 = *reinterpret_cast<const f32x4*>(s_kinv + n0);
+            f32x4 acc[TPR];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = 0.f;
-                    if (n0 + r < N) x = load1<IO>(a.k, ((bt * N + n0 + r) * Hh + h) * GDKVM_DK + 16 * c + li);
-                    acc[r] = x * ki4[r];
-                }
-                *reinterpret_cast<f32x4*>(knT + (size_t)(16 * c + li) * NP + n0) = acc;   // Kn^T, 4 tokens
-            } else {
+            for (int i = 0; i < TPR; ++i) {
+                const int c = (rd * TPR + i) * 4 + w;
+                const bool isK = c < GDKVM_DK / 16;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = 0.f;
-                    if (n0 + r < N) x = load1<IO>(a.v, ((bt * N + n0 + r) * Hh + h) * Dv + 16 * (c - 4) + li);
-                    acc[r] = x;
-                }
+                for (int r = 0; r < 4; ++r) acc[i][r] = isK ? xr[i][I][r] * ki4[r] : xr[i][I][r];
+                if (isK) *reinterpret_cast<f32x4*>(knT + (size_t)(16 * c + li) * NP + n0) = acc[i];   // Kn^T, 4 tokens
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][r] *= bt4[r];
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] *= bt4[r];
             if (seq) {
 #pragma unroll
                 for (int J = 0; J < I; ++J) {
                     const f32x4 na = s_negA[pair_slot(I, J) * 64 + lane];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = mfma4(na[r], Y[J][r], acc);
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int i = 0; i < TPR; ++i) acc[i] = mfma4(na[r], Y[i][J][r], acc[i]);
                 }
                 const f32x4 t4 = s_Tm[I * 64 + lane];
-                f32x4 y = {0.f, 0.f, 0.f, 0.f};
+                f32x4 y[TPR];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) y = mfma4(t4[r], acc[r], y);
-                acc = y;
+                for (int i = 0; i < TPR; ++i) y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < TPR; ++i) y[i] = mfma4(t4[r], acc[i][r], y[i]);
+#pragma unroll
+                for (int i = 0; i < TPR; ++i) acc[i] = y[i];
             }
-            if (isK && a.rule == GDKVM_RULE_GATED_LINEAR) acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            Y[I] = acc;
-            if (isK) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) wt[(size_t)(n0 + r) * GDKVM_DK + 16 * c + li] = acc[r];
-            } else {
-                ut[((size_t)(c - 4) * NB + I) * 64 + lane] = acc;
+            for (int i = 0; i < TPR; ++i) {
+                const int c = (rd * TPR + i) * 4 + w;
+                const bool isK = c < GDKVM_DK / 16;
+                if (isK && a.rule == GDKVM_RULE_GATED_LINEAR) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                Y[i][I] = acc[i];
+                if (c < ntile) {
+                    if (isK) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) wt[(size_t)(n0 + r) * GDKVM_DK + 16 * c + li] = acc[i][r];
+                    } else {
+                        ut[((size_t)(c - 4) * NB + I) * 64 + lane] = acc[i];
+                    }
+                }
             }
         }
     }
@@ -217,7 +255,7 @@ extern "C" void gdkvm_diag_set_buffer(unsigned long long* p) { g_diag_buf = p; }
 
 struct ScanArgs {
     const void* q; const float* alpha; const float* s_in;
-    const float* wt; const float* knT; const float* ut;
+    const float* wt; const float* knT; const float* ut; const float* qinv;
     void* r_out; float* s_out; char* trash;
     int T, Hh, N, Dv, flags, BH;
 #ifdef GDKVM_DIAG
@@ -257,7 +295,9 @@ __device__ __forceinline__ void static_for(F&& f)
 }
 
 // Operands of one item (one 16-token tile of one frame) per role, as prefetched into registers.
-template <int IO> struct QItem { Raw4<IO> q[4]; };                    // read-out waves:  R = Qn S
+template <int IO> struct QItem;                                        // read-out waves:  R = (Q S) * qinv
+template <> struct QItem<GDKVM_F32> { f32x4 q[4]; f32x4 qinv; };       //   fp32 I/O: exact fp32 MFMA, k = 16m + 4g + r
+template <> struct QItem<GDKVM_BF16> { bf16x8 q[2]; f32x4 qinv; };     //   bf16 I/O: bf16 MFMA on S = S_hi + S_lo, k = 32s + 8g + j
 struct XItem { f32x4 w[4]; f32x4 u; float alpha; };                    // state waves:     X = Wt S, U = Ut - aX
 struct KItem { f32x4 k[4]; };                                          // state waves:     S <- aS + Kn^T U (4 token tiles)
 
@@ -285,6 +325,7 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
     static_assert(JT == 1 || JT == 2 || JT == 4, "token tiles per wave");
     __shared__ __attribute__((aligned(16))) f32x4 s_S[4 * 64];
     __shared__ __attribute__((aligned(16))) f32x4 s_U[NB * 64];
+    __shared__ __attribute__((aligned(16))) uint2 s_Sh[2 * 64 * 2], s_Sl[2 * 64 * 2];   // bf16 hi / lo B-operand images of S
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -304,66 +345,80 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
     const int last_item = T * JT - 1;
     constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
 
-    // state tile of wave w: rows 16w + 4g + r of S, column 16*sl + li.  Both roles start from the LDS image.
+    // Publishing S for the next frame: the fp32 accumulator image (B operand of the state waves' exact products) and,
+    // for the bf16 arm, S = S_hi + S_lo in bf16 as the B operand of the read-out's 16x16x32 MFMA.  This wave's rows
+    // 16w+4g+r are k = 32s + 8g' + j with s = w>>1, g' = 2(w&1) + (g>>1), j = 4(g&1) + r  ->  half a fragment lane.
+    auto publish_state = [&](const f32x4& sv) {
+        s_S[w * 64 + lane] = sv;
+        if constexpr (IO == GDKVM_BF16) {
+            unsigned h0 = f32_to_bf16(sv[0]), h1 = f32_to_bf16(sv[1]), h2 = f32_to_bf16(sv[2]), h3 = f32_to_bf16(sv[3]);
+            const float l0 = sv[0] - __uint_as_float(h0 << 16), l1 = sv[1] - __uint_as_float(h1 << 16);
+            const float l2 = sv[2] - __uint_as_float(h2 << 16), l3 = sv[3] - __uint_as_float(h3 << 16);
+            const int slot = (((w >> 1) * 64 + (2 * (w & 1) + (g >> 1)) * 16 + li) << 1) + (g & 1);
+            s_Sh[slot] = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+            s_Sl[slot] = make_uint2((unsigned)f32_to_bf16(l0) | ((unsigned)f32_to_bf16(l1) << 16),
+                                    (unsigned)f32_to_bf16(l2) | ((unsigned)f32_to_bf16(l3) << 16));
+        }
+    };
+    // state tile of wave w: rows 16w + 4g + r of S, column 16*sl + li.  Both roles start from the LDS images.
     f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
     if (!read_role) {
         if (a.s_in) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) sacc[r] = a.s_in[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li];
         }
-        s_S[w * 64 + lane] = sacc;
+        publish_state(sacc);
     }
 
     if (read_role) {
         // ------------------------------------------------------------------------------ read-out waves
-        const bool normalize = a.flags & GDKVM_FLAG_NORMALIZE_QK;
-        const char* qbase = static_cast<const char*>(a.q) + (((size_t)b * T * N * Hh + h) * GDKVM_DK + 4 * g) * ESZ;
+        const char* qbase = static_cast<const char*>(a.q) + (((size_t)b * T * N * Hh + h) * GDKVM_DK) * ESZ;
         const size_t q_fstride = (size_t)N * Hh * GDKVM_DK * ESZ;               // bytes per frame
+        const float* qinv_lane = a.qinv + fh0 * NP + 4 * g;
         char* rbase = static_cast<char*>(a.r_out) + ((size_t)b * T * N * Hh * Dv + h * Dv + 16 * sl + li) * ESZ;
         const size_t r_fstride = (size_t)N * Hh * Dv * ESZ;
         auto load_q = [&](int item, QItem<IO>& d) {
             item = min(item, last_item);                  // past the end: re-fetch the last item (never used)
             const int t = item / JT, tt = w + 4 * (item - t * JT);
-            const int nq = min(16 * tt + li, N - 1);      // padding tokens fetch a real row; zeroed at use
+            const int nq = min(16 * tt + li, N - 1);      // padding tokens fetch a real row; their qinv is 0
             const char* p = qbase + t * q_fstride + (size_t)nq * (Hh * GDKVM_DK * ESZ);
+            if constexpr (IO == GDKVM_F32) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if constexpr (IO == GDKVM_F32) d.q[m].v = *reinterpret_cast<const f32x4*>(p + 64 * m);
-                else d.q[m].v = *reinterpret_cast<const uint2*>(p + 32 * m);
+                for (int m = 0; m < 4; ++m) d.q[m] = *reinterpret_cast<const f32x4*>(p + 64 * m + 16 * g);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) d.q[ks] = *reinterpret_cast<const bf16x8*>(p + 64 * ks + 16 * g);
             }
+            d.qinv = *reinterpret_cast<const f32x4*>(qinv_lane + (size_t)t * Hh * NP + 16 * tt);
         };
         QItem<IO> qb[NBUF];
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) load_q(i, qb[i]);
         __syncthreads();
 
-        auto read_item = [&](int t, int j, const QItem<IO>& cur, QItem<IO>& nxt, const f32x4 (&sreg)[4]) {
+        auto read_item = [&](int t, int j, const QItem<IO>& cur, QItem<IO>& nxt) {
             const int tt = w + 4 * j;
-            const float qmask = (16 * tt + li < N) ? 1.f : 0.f;
-            f32x4 qa[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) qa[m] = widen<IO>(cur.q[m]) * qmask;
-            if (normalize) {
-                float ss = 0.f;
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ss += qa[m][r] * qa[m][r];
-                ss += __shfl_xor(ss, 16);
-                ss += __shfl_xor(ss, 32);
-                const float inv = 1.0f / sqrtf(ss + GDKVM_EPS_NORM);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) qa[m] *= inv;
-            }
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (IO == GDKVM_F32) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m) {
+                    const f32x4 sm = s_S[m * 64 + lane];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (m & 1) acc1 = mfma4(qa[m][r], sreg[m][r], acc1);
-                    else acc0 = mfma4(qa[m][r], sreg[m][r], acc0);
+                    for (int r = 0; r < 4; ++r) {
+                        if (m & 1) acc1 = mfma4(cur.q[m][r], sm[r], acc1);
+                        else acc0 = mfma4(cur.q[m][r], sm[r], acc0);
+                    }
                 }
-            const f32x4 accR = acc0 + acc1;
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&s_Sh[(ks * 64 + lane) * 2]);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&s_Sl[(ks * 64 + lane) * 2]);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.q[ks], bh, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.q[ks], bl, acc1, 0, 0, 0);
+                }
+            }
+            const f32x4 accR = (acc0 + acc1) * cur.qinv;        // rows 4g+r of the tile: L2 normalisation folded here
             char* rp = rbase + t * r_fstride;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -376,12 +431,9 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
         };
         auto frame = [&](int t, auto fc) {
             constexpr int F = decltype(fc)::value;         // frame index inside the unrolled group: buffer ids static
-            f32x4 sreg[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) sreg[m] = s_S[m * 64 + lane];
             static_for<0, JT>([&](auto jc) {
                 constexpr int i = F * JT + decltype(jc)::value;
-                read_item(t, decltype(jc)::value, qb[i % NBUF], qb[(i + DEPTH) % NBUF], sreg);
+                read_item(t, decltype(jc)::value, qb[i % NBUF], qb[(i + DEPTH) % NBUF]);
             });
             __syncthreads();                               // (1) U complete / this wave is done reading S_{t-1}
             __syncthreads();                               // (2) S_t published
@@ -480,7 +532,7 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
         });
         sacc = acc0 + acc1;
         DIAG_STAMP(3);
-        s_S[w * 64 + lane] = sacc;
+        publish_state(sacc);
         __syncthreads();
         DIAG_STAMP(4);
     };
@@ -516,16 +568,16 @@ __global__ void gdr_decay_kernel(const float* alpha, const float* s_in, float* s
 constexpr size_t GDKVM_WS_TAIL = 256;   // trash slot for padded read-out rows
 int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
 
-template <int NB, int IO>
+template <int NB, int IO, int TPR>
 int launch_prep(const PrepArgs& pa, int FH, hipStream_t st)
 {
     const size_t lds = prep_lds_bytes(NB);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_prep_kernel<NB, IO>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_prep_kernel<NB, IO, TPR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_prep: LDS attribute: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL((gdr_prep_kernel<NB, IO>), dim3(FH), dim3(256), lds, st, pa);
+    hipLaunchKernelGGL((gdr_prep_kernel<NB, IO, TPR>), dim3(FH), dim3(256), lds, st, pa);
     GDKVM_LAUNCH_CHECK("gdr_prep_kernel");
     return GDKVM_OK;
 }
@@ -534,9 +586,9 @@ template <int IO>
 int launch_prep_nb(int nb, const PrepArgs& pa, int FH, hipStream_t st)
 {
     switch (nb) {
-        case 4: return launch_prep<4, IO>(pa, FH, st);
-        case 8: return launch_prep<8, IO>(pa, FH, st);
-        default: return launch_prep<16, IO>(pa, FH, st);
+        case 4: return launch_prep<4, IO, 5>(pa, FH, st);
+        case 8: return launch_prep<8, IO, 2>(pa, FH, st);
+        default: return launch_prep<16, IO, 1>(pa, FH, st);
     }
 }
 
@@ -546,7 +598,7 @@ extern "C" size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk
 {
     if (B <= 0 || T <= 0 || Hh <= 0 || N <= 0 || Dk <= 0 || Dv <= 0 || N > GDKVM_MAX_N) return GDKVM_WS_TAIL;
     const size_t NP = 16 * (size_t)tiles_for(N);
-    return (size_t)B * T * Hh * NP * (2 * (size_t)Dk + Dv) * sizeof(float) + GDKVM_WS_TAIL;
+    return (size_t)B * T * Hh * NP * (2 * (size_t)Dk + Dv + 1) * sizeof(float) + GDKVM_WS_TAIL;
 }
 
 namespace {
@@ -574,7 +626,7 @@ int check_ptrs(const char* fn, std::initializer_list<const void*> required, std:
     return GDKVM_OK;
 }
 
-struct WsView { float* wt; float* knT; float* ut; char* trash; int nb; };
+struct WsView { float* wt; float* knT; float* ut; float* qinv; char* trash; int nb; };
 
 int carve(const char* fn, void* workspace, size_t workspace_bytes, int B, int T, int Hh, int N, int Dk, int Dv, WsView* v)
 {
@@ -586,23 +638,24 @@ int carve(const char* fn, void* workspace, size_t workspace_bytes, int B, int T,
     v->wt = static_cast<float*>(workspace);
     v->knT = v->wt + FH * NP * GDKVM_DK;
     v->ut = v->knT + FH * NP * GDKVM_DK;
-    v->trash = reinterpret_cast<char*>(v->ut + FH * NP * Dv);       // write-only slot for read-out rows of padding tokens
+    v->qinv = v->ut + FH * NP * Dv;
+    v->trash = reinterpret_cast<char*>(v->qinv + FH * NP);          // write-only slot for read-out rows of padding tokens
     return GDKVM_OK;
 }
 
 }  // namespace
 
-extern "C" int gdkvm_scan_prep(const void* k, const void* v, const float* beta, void* workspace, size_t workspace_bytes,
+extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, const float* beta, void* workspace, size_t workspace_bytes,
                                int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
 {
     if (int rc = check_common("scan_prep", B, T, Hh, N, Dk, Dv, io_dtype, flags)) return rc;
     if (rule < 0 || rule > 2) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_prep: rule=%d", rule);
     if (B == 0 || T == 0 || N == 0) return GDKVM_OK;
-    if (int rc = check_ptrs("scan_prep", {k, v, beta, workspace}, {})) return rc;
+    if (int rc = check_ptrs("scan_prep", {q, k, v, beta, workspace}, {})) return rc;
     WsView ws;
     if (int rc = carve("scan_prep", workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
     if (int rc = gdkvm_check_device()) return rc;
-    PrepArgs pa{k, v, beta, ws.wt, ws.knT, ws.ut, T, Hh, N, Dv, rule, flags};
+    PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, T, Hh, N, Dv, rule, flags};
     hipStream_t st = static_cast<hipStream_t>(stream);
     return io_dtype == GDKVM_F32 ? launch_prep_nb<GDKVM_F32>(ws.nb, pa, B * T * Hh, st)
                                  : launch_prep_nb<GDKVM_BF16>(ws.nb, pa, B * T * Hh, st);
@@ -615,7 +668,7 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
     if (int rc = check_common("scan_apply", B, T, Hh, N, Dk, Dv, io_dtype, flags)) return rc;
     if (B == 0) return GDKVM_OK;
     const bool have_tokens = T > 0 && N > 0;
-    WsView ws{nullptr, nullptr, nullptr, nullptr, 0};
+    WsView ws{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (have_tokens) {
         if (int rc = check_ptrs("scan_apply", {q, alpha, r_out, workspace}, {s_in, s_out})) return rc;
         if (int rc = carve("scan_apply", const_cast<void*>(workspace), workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
@@ -633,7 +686,7 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
         }
         return GDKVM_OK;
     }
-    ScanArgs sa{q, alpha, s_in, ws.wt, ws.knT, ws.ut, r_out, s_out, ws.trash, T, Hh, N, Dv, flags, B * Hh};
+    ScanArgs sa{q, alpha, s_in, ws.wt, ws.knT, ws.ut, ws.qinv, r_out, s_out, ws.trash, T, Hh, N, Dv, flags, B * Hh};
 #ifdef GDKVM_DIAG
     sa.diag = g_diag_buf;
 #endif
@@ -655,6 +708,6 @@ extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const
                               int B, int T, int Hh, int N, int Dk, int Dv,
                               int io_dtype, int rule, int flags, void* stream)
 {
-    if (int rc = gdkvm_scan_prep(k, v, beta, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream)) return rc;
+    if (int rc = gdkvm_scan_prep(q, k, v, beta, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream)) return rc;
     return gdkvm_scan_apply(q, alpha, s_in, r_out, s_out, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, flags, stream);
 }

@@ -137,7 +137,6 @@ __global__ __launch_bounds__(256) void kpff_kernel(KpffArgs a)
 // weights are read as bf16 from a workspace copy made by kpff_pack_weights_kernel (rows [out][in], so a B
 // fragment = 8 consecutive k of one output channel = one 16-byte load).  Lane l = 16g + i:
 //   A = X[row i][k 8g..8g+7],  B = W[col i][k 8g..8g+7],  C/D reg r = D[row 4g + r][col i].
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct KpffBf16Args {
     const bf16_t* L; const bf16_t* G; const bf16_t* P;

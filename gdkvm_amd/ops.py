@@ -27,7 +27,7 @@ SIGNATURES = {
     "gdkvm_last_error": (ctypes.c_char_p, []),
     "gdkvm_scan_workspace_bytes": (_sz, [_i] * 6),
     "gdkvm_scan_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
-    "gdkvm_scan_prep": (_i, [_vp] * 4 + [_sz] + [_i] * 9 + [_vp]),
+    "gdkvm_scan_prep": (_i, [_vp] * 5 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_apply": (_i, [_vp] * 6 + [_sz] + [_i] * 8 + [_vp]),
     "gdkvm_kpff_workspace_bytes": (_sz, [_i] * 4),
     "gdkvm_kpff_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 7 + [_vp]),
@@ -144,13 +144,13 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
     return r, s
 
 
-def scan_prep(k, v, beta, workspace, rule=RULE_DELTA_SEQUENTIAL, flags=0):
+def scan_prep(q, k, v, beta, workspace, rule=RULE_DELTA_SEQUENTIAL, flags=0):
     """Stage 1 of scan_fwd alone (gdkvm_scan_prep): fills ``workspace`` with the per-frame WY factors."""
     B, T, N, Hh, Dk = k.shape
     Dv = v.shape[-1]
-    dev = _dev(k, v, beta, workspace)
+    dev = _dev(q, k, v, beta, workspace)
     with torch.cuda.device(dev):
-        rc = load().gdkvm_scan_prep(_ptr(k), _ptr(v), _ptr(beta), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+        rc = load().gdkvm_scan_prep(_ptr(q), _ptr(k), _ptr(v), _ptr(beta), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
                                     B, T, Hh, N, Dk, Dv, _io_dtype(k), rule, flags, _stream(dev))
     _check(rc, "gdkvm_scan_prep")
 
