@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "gdkvm_common.hpp"
+#include "gdr_ws.hpp"
 
 namespace {
 
@@ -256,7 +257,7 @@ extern "C" void gdkvm_diag_set_buffer(unsigned long long* p) { g_diag_buf = p; }
 struct ScanArgs {
     const void* q; const float* alpha; const float* s_in;
     const float* wt; const float* knT; const float* ut; const float* qinv;
-    void* r_out; float* s_out; char* trash;
+    void* r_out; float* s_out; float* s_hist; char* trash;
     int T, Hh, N, Dv, flags, BH;
 #ifdef GDKVM_DIAG
     unsigned long long* diag;
@@ -318,7 +319,8 @@ __device__ __forceinline__ float fast_sigmoid(float x)
 // operands under load is ~2500 cycles).  The loops are branch-free (clamped indices, read-out rows of padding tokens
 // go to a trash slot): a CFG merge makes hipcc's vmcnt bookkeeping conservative, and a conservative wait lands on
 // the freshly issued loads and exposes the full latency every frame.
-template <int IO, int NB>
+// SAVE: training mode -- also write the state BEFORE every frame (s_hist [B,T,Hh,Dk,Dv]) for the backward pass.
+template <int IO, int NB, bool SAVE>
 __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
 {
     constexpr int NP = 16 * NB, JT = NB / 4, NG = NB / 4, NBUF = 4, DEPTH = 3, UF = NBUF / JT;
@@ -514,6 +516,11 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
     auto frame = [&](int t, auto fc) {
         constexpr int F = decltype(fc)::value;
         DIAG_STAMP(0);
+        if constexpr (SAVE) {
+            float* hp = a.s_hist + ((fh0 + (size_t)t * Hh) * GDKVM_DK + 16 * w + 4 * g) * Dv + 16 * sl + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hp[(size_t)r * Dv] = sacc[r];
+        }
         f32x4 sreg[4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) sreg[m] = s_S[m * 64 + lane];
@@ -565,9 +572,6 @@ __global__ void gdr_decay_kernel(const float* alpha, const float* s_in, float* s
         s_out[(size_t)bh * per_bh + i] = s_in ? s_in[(size_t)bh * per_bh + i] * f : 0.f;
 }
 
-constexpr size_t GDKVM_WS_TAIL = 256;   // trash slot for padded read-out rows
-int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
-
 template <int NB, int IO, int TPR>
 int launch_prep(const PrepArgs& pa, int FH, hipStream_t st)
 {
@@ -596,54 +600,8 @@ int launch_prep_nb(int nb, const PrepArgs& pa, int FH, hipStream_t st)
 
 extern "C" size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
 {
-    if (B <= 0 || T <= 0 || Hh <= 0 || N <= 0 || Dk <= 0 || Dv <= 0 || N > GDKVM_MAX_N) return GDKVM_WS_TAIL;
-    const size_t NP = 16 * (size_t)tiles_for(N);
-    return (size_t)B * T * Hh * NP * (2 * (size_t)Dk + Dv + 1) * sizeof(float) + GDKVM_WS_TAIL;
+    return gdr_workspace_bytes(B, T, Hh, N, Dk, Dv);
 }
-
-namespace {
-
-int check_common(const char* fn, int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int flags)
-{
-    if (B < 0 || T < 0 || Hh <= 0 || N < 0 || Dv <= 0)
-        return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: negative or zero dimension (B=%d T=%d Hh=%d N=%d Dv=%d)", fn, B, T, Hh, N, Dv);
-    if (Dk != GDKVM_DK) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: Dk=%d unsupported (kernels are built for Dk=%d)", fn, Dk, GDKVM_DK);
-    if (Dv % 16 != 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: Dv=%d must be a multiple of 16", fn, Dv);
-    if (N > GDKVM_MAX_N) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: N=%d exceeds %d tokens per frame", fn, N, GDKVM_MAX_N);
-    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "%s: io_dtype=%d", fn, io_dtype);
-    if (flags & ~3) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: unknown flags 0x%x", fn, flags);
-    return GDKVM_OK;
-}
-
-int check_ptrs(const char* fn, std::initializer_list<const void*> required, std::initializer_list<const void*> optional)
-{
-    for (const void* p : required) {
-        if (!p) return gdkvm_fail(GDKVM_ERR_ARG, "%s: null pointer", fn);
-        if (!gdkvm_aligned16(p)) return gdkvm_fail(GDKVM_ERR_ARG, "%s: pointer %p is not 16-byte aligned", fn, p);
-    }
-    for (const void* p : optional)
-        if (p && !gdkvm_aligned16(p)) return gdkvm_fail(GDKVM_ERR_ARG, "%s: pointer %p is not 16-byte aligned", fn, p);
-    return GDKVM_OK;
-}
-
-struct WsView { float* wt; float* knT; float* ut; float* qinv; char* trash; int nb; };
-
-int carve(const char* fn, void* workspace, size_t workspace_bytes, int B, int T, int Hh, int N, int Dk, int Dv, WsView* v)
-{
-    const size_t need = gdkvm_scan_workspace_bytes(B, T, Hh, N, Dk, Dv);
-    if (workspace_bytes < need)
-        return gdkvm_fail(GDKVM_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, workspace_bytes, need);
-    v->nb = tiles_for(N);
-    const size_t NP = 16 * (size_t)v->nb, FH = (size_t)B * T * Hh;
-    v->wt = static_cast<float*>(workspace);
-    v->knT = v->wt + FH * NP * GDKVM_DK;
-    v->ut = v->knT + FH * NP * GDKVM_DK;
-    v->qinv = v->ut + FH * NP * Dv;
-    v->trash = reinterpret_cast<char*>(v->qinv + FH * NP);          // write-only slot for read-out rows of padding tokens
-    return GDKVM_OK;
-}
-
-}  // namespace
 
 extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, const float* beta, void* workspace, size_t workspace_bytes,
                                int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
@@ -662,7 +620,7 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
 }
 
 extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* s_in, void* r_out, float* s_out,
-                                const void* workspace, size_t workspace_bytes,
+                                float* s_hist, const void* workspace, size_t workspace_bytes,
                                 int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int flags, void* stream)
 {
     if (int rc = check_common("scan_apply", B, T, Hh, N, Dk, Dv, io_dtype, flags)) return rc;
@@ -670,7 +628,7 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
     const bool have_tokens = T > 0 && N > 0;
     WsView ws{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (have_tokens) {
-        if (int rc = check_ptrs("scan_apply", {q, alpha, r_out, workspace}, {s_in, s_out})) return rc;
+        if (int rc = check_ptrs("scan_apply", {q, alpha, r_out, workspace}, {s_in, s_out, s_hist})) return rc;
         if (int rc = carve("scan_apply", const_cast<void*>(workspace), workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
     } else {
         if (T > 0 && !alpha) return gdkvm_fail(GDKVM_ERR_ARG, "scan_apply: null alpha");
@@ -679,6 +637,7 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
     if (int rc = gdkvm_check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!have_tokens) {
+        if (s_hist && T > 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_apply: s_hist needs N > 0");
         if (s_out) {
             hipLaunchKernelGGL(gdr_decay_kernel, dim3(4, (unsigned)(B * Hh)), dim3(256), 0, st, alpha, s_in, s_out, T, Hh,
                                GDKVM_DK * Dv, flags);
@@ -686,28 +645,29 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
         }
         return GDKVM_OK;
     }
-    ScanArgs sa{q, alpha, s_in, ws.wt, ws.knT, ws.ut, ws.qinv, r_out, s_out, ws.trash, T, Hh, N, Dv, flags, B * Hh};
+    ScanArgs sa{q, alpha, s_in, ws.wt, ws.knT, ws.ut, ws.qinv, r_out, s_out, s_hist, ws.trash, T, Hh, N, Dv, flags, B * Hh};
 #ifdef GDKVM_DIAG
     sa.diag = g_diag_buf;
 #endif
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
-#define GDKVM_SCAN_LAUNCH(IO)                                                                         \
-    switch (ws.nb) {                                                                                  \
-        case 4: hipLaunchKernelGGL((gdr_scan_kernel<IO, 4>), grid, dim3(512), 0, st, sa); break;      \
-        case 8: hipLaunchKernelGGL((gdr_scan_kernel<IO, 8>), grid, dim3(512), 0, st, sa); break;      \
-        default: hipLaunchKernelGGL((gdr_scan_kernel<IO, 16>), grid, dim3(512), 0, st, sa); break;    \
+#define GDKVM_SCAN_LAUNCH(IO, SV)                                                                         \
+    switch (ws.nb) {                                                                                      \
+        case 4: hipLaunchKernelGGL((gdr_scan_kernel<IO, 4, SV>), grid, dim3(512), 0, st, sa); break;      \
+        case 8: hipLaunchKernelGGL((gdr_scan_kernel<IO, 8, SV>), grid, dim3(512), 0, st, sa); break;      \
+        default: hipLaunchKernelGGL((gdr_scan_kernel<IO, 16, SV>), grid, dim3(512), 0, st, sa); break;    \
     }
-    if (io_dtype == GDKVM_F32) { GDKVM_SCAN_LAUNCH(GDKVM_F32) } else { GDKVM_SCAN_LAUNCH(GDKVM_BF16) }
+    if (io_dtype == GDKVM_F32) { if (s_hist) { GDKVM_SCAN_LAUNCH(GDKVM_F32, true) } else { GDKVM_SCAN_LAUNCH(GDKVM_F32, false) } }
+    else { if (s_hist) { GDKVM_SCAN_LAUNCH(GDKVM_BF16, true) } else { GDKVM_SCAN_LAUNCH(GDKVM_BF16, false) } }
 #undef GDKVM_SCAN_LAUNCH
     GDKVM_LAUNCH_CHECK("gdr_scan_kernel");
     return GDKVM_OK;
 }
 
 extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
-                              const float* s_in, void* r_out, float* s_out, void* workspace, size_t workspace_bytes,
+                              const float* s_in, void* r_out, float* s_out, float* s_hist, void* workspace, size_t workspace_bytes,
                               int B, int T, int Hh, int N, int Dk, int Dv,
                               int io_dtype, int rule, int flags, void* stream)
 {
     if (int rc = gdkvm_scan_prep(q, k, v, beta, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream)) return rc;
-    return gdkvm_scan_apply(q, alpha, s_in, r_out, s_out, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, flags, stream);
+    return gdkvm_scan_apply(q, alpha, s_in, r_out, s_out, s_hist, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, flags, stream);
 }

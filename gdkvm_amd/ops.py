@@ -26,9 +26,11 @@ SIGNATURES = {
     "gdkvm_abi_version": (_i, []),
     "gdkvm_last_error": (ctypes.c_char_p, []),
     "gdkvm_scan_workspace_bytes": (_sz, [_i] * 6),
-    "gdkvm_scan_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
+    "gdkvm_scan_fwd": (_i, [_vp] * 10 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_prep": (_i, [_vp] * 5 + [_sz] + [_i] * 9 + [_vp]),
-    "gdkvm_scan_apply": (_i, [_vp] * 6 + [_sz] + [_i] * 8 + [_vp]),
+    "gdkvm_scan_apply": (_i, [_vp] * 7 + [_sz] + [_i] * 8 + [_vp]),
+    "gdkvm_scan_bwd_workspace_bytes": (_sz, [_i] * 6),
+    "gdkvm_scan_bwd": (_i, [_vp] * 7 + [_sz] + [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_kpff_workspace_bytes": (_sz, [_i] * 4),
     "gdkvm_kpff_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 7 + [_vp]),
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
@@ -111,7 +113,8 @@ def scan_workspace_bytes(B, T, Hh, N, Dk, Dv) -> int:
 def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor,
              state: Optional[torch.Tensor] = None, rule: int = RULE_DELTA_SEQUENTIAL, flags: int = 0,
              workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-             state_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+             state_out: Optional[torch.Tensor] = None, state_hist: Optional[torch.Tensor] = None
+             ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Fused LKVA read + GDR write over T frames (gdkvm_scan_fwd).
 
     q,k [B,T,N,Hh,Dk]  v [B,T,N,Hh,Dv]  (f32|bf16)   alpha [B,T,Hh]  beta [B,T,N,Hh]  state [B,Hh,Dk,Dv] (f32)
@@ -129,7 +132,7 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
         raise GdkvmError("alpha / beta must be float32")
     if state is not None and (tuple(state.shape) != (B, Hh, Dk, Dv) or state.dtype != torch.float32):
         raise GdkvmError("state must be float32 [B,Hh,Dk,Dv]")
-    dev = _dev(q, k, v, alpha, beta, state, workspace, out, state_out)
+    dev = _dev(q, k, v, alpha, beta, state, workspace, out, state_out, state_hist)
     io = _io_dtype(q)
     need = scan_workspace_bytes(B, T, Hh, N, Dk, Dv)
     if workspace is None:
@@ -138,10 +141,63 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
     s = state_out if state_out is not None else torch.empty((B, Hh, Dk, Dv), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = lib.gdkvm_scan_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(alpha), _ptr(beta), _ptr(state), _ptr(r), _ptr(s),
-                                workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                _ptr(state_hist), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
                                 B, T, Hh, N, Dk, Dv, io, rule, flags, _stream(dev))
     _check(rc, "gdkvm_scan_fwd")
     return r, s
+
+
+def scan_bwd(q, k, v, alpha, beta, state_hist, workspace, d_r, d_state_out=None, rule=RULE_DELTA_SEQUENTIAL, flags=0,
+             need_d_state_in=True):
+    """Backward of scan_fwd (gdkvm_scan_bwd).  ``state_hist`` and ``workspace`` are the ones the forward call filled.
+    Returns (d_q, d_k, d_v, d_alpha, d_beta, d_state_in | None)."""
+    lib = load()
+    B, T, N, Hh, Dk = q.shape
+    Dv = v.shape[-1]
+    dev = _dev(q, k, v, alpha, beta, state_hist, workspace, d_r, d_state_out)
+    if d_r.dtype != q.dtype or tuple(d_r.shape) != (B, T, N, Hh, Dv):
+        raise GdkvmError("d_r must match the read-out's shape and dtype")
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    da = torch.empty((B, T, Hh), dtype=torch.float32, device=dev)
+    db = torch.empty((B, T, N, Hh), dtype=torch.float32, device=dev)
+    ds = torch.empty((B, Hh, Dk, Dv), dtype=torch.float32, device=dev) if need_d_state_in else None
+    bws = torch.empty(int(lib.gdkvm_scan_bwd_workspace_bytes(B, T, Hh, N, Dk, Dv)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gdkvm_scan_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(alpha), _ptr(beta), _ptr(state_hist), workspace.data_ptr(),
+                                workspace.numel(), _ptr(d_r), _ptr(d_state_out), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(da),
+                                _ptr(db), _ptr(ds), bws.data_ptr(), bws.numel(), B, T, Hh, N, Dk, Dv, _io_dtype(q), rule,
+                                flags, _stream(dev))
+    _check(rc, "gdkvm_scan_bwd")
+    return dq, dk, dv, da, db, ds
+
+
+class _ScanFunction(torch.autograd.Function):
+    """Differentiable gdkvm_scan_fwd: forward saves the state history and the WY workspace, backward is gdkvm_scan_bwd."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, alpha, beta, state, rule, flags):
+        B, T, N, Hh, Dk = q.shape
+        Dv = v.shape[-1]
+        ws = torch.empty(scan_workspace_bytes(B, T, Hh, N, Dk, Dv), dtype=torch.uint8, device=q.device)
+        hist = torch.empty((B, T, Hh, Dk, Dv), dtype=torch.float32, device=q.device)
+        r, s = scan_fwd(q, k, v, alpha, beta, state, rule=rule, flags=flags, workspace=ws, state_hist=hist)
+        ctx.save_for_backward(q, k, v, alpha, beta, hist, ws)
+        ctx.rule, ctx.flags, ctx.has_state = rule, flags, state is not None
+        return r, s
+
+    @staticmethod
+    def backward(ctx, d_r, d_s):
+        q, k, v, alpha, beta, hist, ws = ctx.saved_tensors
+        d_r = d_r.contiguous()
+        d_s = None if d_s is None else d_s.contiguous().float()
+        dq, dk, dv, da, db, ds = scan_bwd(q, k, v, alpha, beta, hist, ws, d_r, d_s, ctx.rule, ctx.flags,
+                                          need_d_state_in=ctx.has_state)
+        return dq, dk, dv, da, db, ds, None, None
+
+
+def scan(q, k, v, alpha, beta, state=None, rule: int = RULE_DELTA_SEQUENTIAL, flags: int = 0):
+    """scan_fwd with autograd support (training).  Inference callers should use scan_fwd directly (no history)."""
+    return _ScanFunction.apply(q, k, v, alpha, beta, state, rule, flags)
 
 
 def scan_prep(q, k, v, beta, workspace, rule=RULE_DELTA_SEQUENTIAL, flags=0):
@@ -162,7 +218,7 @@ def scan_apply(q, alpha, workspace, Dv, state=None, flags=0, out=None, state_out
     r = out if out is not None else torch.empty((B, T, N, Hh, Dv), dtype=q.dtype, device=dev)
     s = state_out if state_out is not None else torch.empty((B, Hh, Dk, Dv), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        rc = load().gdkvm_scan_apply(_ptr(q), _ptr(alpha), _ptr(state), _ptr(r), _ptr(s), workspace.data_ptr(),
+        rc = load().gdkvm_scan_apply(_ptr(q), _ptr(alpha), _ptr(state), _ptr(r), _ptr(s), None, workspace.data_ptr(),
                                      workspace.numel() * workspace.element_size(), B, T, Hh, N, Dk, Dv, _io_dtype(q), flags,
                                      _stream(dev))
     _check(rc, "gdkvm_scan_apply")

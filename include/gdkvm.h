@@ -63,9 +63,11 @@ size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv);
  * processed as consecutive calls with the state carried is bit-identical to one call.
  * Names: LKVA / GDR at /root/reference/README.md:20; "state transition matrix" at
  * /root/reference/website/src/content/homepage/en.json:20.
- * Supported: Dk == 64, Dv % 16 == 0, 0 <= N <= 256. */
+ * Supported: Dk == 64, Dv % 16 == 0, 0 <= N <= 256.
+ * s_hist (training): if non-NULL, [B,T,Hh,Dk,Dv] fp32 receives the state BEFORE every frame; gdkvm_scan_bwd needs
+ * it together with the untouched workspace of this call. */
 int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
-                   const float* s_in, void* r_out, float* s_out, void* workspace, size_t workspace_bytes,
+                   const float* s_in, void* r_out, float* s_out, float* s_hist, void* workspace, size_t workspace_bytes,
                    int B, int T, int Hh, int N, int Dk, int Dv,
                    int io_dtype, int rule, int flags, void* stream);
 
@@ -76,8 +78,21 @@ int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const float* alp
 int gdkvm_scan_prep(const void* q, const void* k, const void* v, const float* beta, void* workspace, size_t workspace_bytes,
                     int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream);
 int gdkvm_scan_apply(const void* q, const float* alpha, const float* s_in, void* r_out, float* s_out,
-                     const void* workspace, size_t workspace_bytes,
+                     float* s_hist, const void* workspace, size_t workspace_bytes,
                      int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int flags, void* stream);
+
+/* Row a7: backward of gdkvm_scan_fwd.  Inputs: the forward's inputs, its s_hist, its workspace exactly as the
+ * forward left it, the gradients d_r [B,T,N,Hh,Dv] (io_dtype) and d_s_out [B,Hh,Dk,Dv] (fp32, may be NULL = 0).
+ * Outputs: d_q, d_k [B,T,N,Hh,Dk], d_v [B,T,N,Hh,Dv] (io_dtype), d_alpha [B,T,Hh], d_beta [B,T,N,Hh] (fp32; with
+ * GDKVM_FLAG_GATE_LOGITS they are gradients w.r.t. the logits), d_s_in [B,Hh,Dk,Dv] (fp32, may be NULL).
+ * bwd_workspace (gdkvm_scan_bwd_workspace_bytes) holds the per-frame state gradients.  Supported: N <= 64. */
+size_t gdkvm_scan_bwd_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv);
+int gdkvm_scan_bwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
+                   const float* s_hist, const void* fwd_workspace, size_t fwd_workspace_bytes,
+                   const void* d_r, const float* d_s_out,
+                   void* d_q, void* d_k, void* d_v, float* d_alpha, float* d_beta, float* d_s_in,
+                   void* bwd_workspace, size_t bwd_workspace_bytes,
+                   int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream);
 
 /* Row a4: Key-Pixel Feature Fusion ("fuses the local key feature, the global key feature with the pixel
  * feature", /root/reference/website/src/content/homepage/en.json:20; "multiple scales", README.md:20).

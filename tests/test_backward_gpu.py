@@ -1,0 +1,83 @@
+"""GPU parity of the backward kernels: HIP gradients vs CPU autograd through the fp64 torch
+restatement (oracle/torch_ref.py) on the same seeded inputs.  Tolerance 1e-4 absolute, scaled by the gradient's
+magnitude for the larger shapes (fp32 accumulation over T frames and N tokens)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as TR
+from tests.util import make_scan_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_grads(q, k, v, a, b, s0, dR, dS, rule, flags):
+    ts = [torch.from_numpy(np.asarray(x, np.float64)).requires_grad_() for x in (q, k, v, a, b, s0)]
+    R, S = TR.scan(*ts, rule, flags)
+    ((R * torch.from_numpy(dR).double()).sum() + (S * torch.from_numpy(dS).double()).sum()).backward()
+    return [t.grad.numpy() for t in ts]
+
+
+def _hip_grads(hip, q, k, v, a, b, s0, dR, dS, rule, flags, dtype=torch.float32):
+    dev = lambda x, dt=None: (torch.from_numpy(np.ascontiguousarray(x)).cuda().to(dt) if dt else torch.from_numpy(np.ascontiguousarray(x)).cuda())
+    tq, tk, tv = (dev(x, dtype).requires_grad_() for x in (q, k, v))
+    ta, tb, ts0 = (dev(x).requires_grad_() for x in (a, b, s0))
+    R, S = hip.scan(tq, tk, tv, ta, tb, ts0, rule, flags)
+    torch.autograd.backward([R, S], [dev(dR, dtype), dev(dS)])
+    return [t.grad.float().cpu().numpy() for t in (tq, tk, tv, ta, tb, ts0)]
+
+
+@pytest.mark.parametrize("rule", [0, 1, 2])
+@pytest.mark.parametrize("flags", [0, 3])
+def test_scan_backward_fp32(hip, rule, flags):
+    B, T, N, Hh, Dk, Dv = 2, 4, 49, 1, 64, 80
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=40 + rule, normalized=not flags, logits=bool(flags), corr=0.5)
+    rng = np.random.default_rng(41)
+    s0 = (0.3 * rng.standard_normal((B, Hh, Dk, Dv))).astype(np.float32)
+    dR = rng.standard_normal((B, T, N, Hh, Dv)).astype(np.float32)
+    dS = rng.standard_normal((B, Hh, Dk, Dv)).astype(np.float32)
+    ref = _ref_grads(q, k, v, a, b, s0, dR, dS, rule, flags)
+    got = _hip_grads(hip, q, k, v, a, b, s0, dR, dS, rule, flags)
+    for name, g, r in zip("q k v alpha beta s0".split(), got, ref):
+        tol = 1e-4 * max(1.0, np.abs(r).max())
+        assert np.abs(g - r).max() <= tol, (name, np.abs(g - r).max(), np.abs(r).max())
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 1, 1, 16), (2, 3, 17, 2, 32), (1, 2, 64, 1, 48), (3, 5, 7, 1, 256)])
+def test_scan_backward_shapes(hip, shape):
+    B, T, N, Hh, Dv = shape
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, 64, Dv, seed=sum(shape), normalized=False, logits=True, corr=0.7)
+    rng = np.random.default_rng(43)
+    s0 = (0.3 * rng.standard_normal((B, Hh, 64, Dv))).astype(np.float32)
+    dR = rng.standard_normal((B, T, N, Hh, Dv)).astype(np.float32)
+    dS = rng.standard_normal((B, Hh, 64, Dv)).astype(np.float32)
+    ref = _ref_grads(q, k, v, a, b, s0, dR, dS, 2, 3)
+    got = _hip_grads(hip, q, k, v, a, b, s0, dR, dS, 2, 3)
+    for name, g, r in zip("q k v alpha beta s0".split(), got, ref):
+        assert np.abs(g - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), (name, np.abs(g - r).max())
+
+
+def test_scan_backward_bf16_io(hip):
+    """bf16 tensors: the kernels differentiate the exact-fp32 function of the bf16-rounded inputs; the returned
+    gradients are rounded to bf16 (2^-8 relative)."""
+    from oracle import gdkvm_oracle as O
+    B, T, N, Hh, Dk, Dv = 2, 3, 49, 1, 64, 64
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=44, normalized=False, logits=True)
+    rng = np.random.default_rng(45)
+    s0 = np.zeros((B, Hh, Dk, Dv), np.float32)
+    dR = O.to_bf16_f32(rng.standard_normal((B, T, N, Hh, Dv)).astype(np.float32))
+    dS = rng.standard_normal((B, Hh, Dk, Dv)).astype(np.float32)
+    ref = _ref_grads(*(O.to_bf16_f32(x) for x in (q, k, v)), a, b, s0, dR, dS, 2, 3)
+    got = _hip_grads(hip, q, k, v, a, b, s0, dR, dS, 2, 3, dtype=torch.bfloat16)
+    for name, g, r in zip("q k v alpha beta s0".split(), got, ref):
+        lim = 1e-4 * max(1.0, np.abs(r).max()) + (np.abs(r) * 2.0 ** -7 if name in "qkv" else 0)
+        assert np.all(np.abs(g - r) <= lim), (name, np.abs(g - r).max())
+
+
+def test_scan_backward_no_state_input(hip):
+    q, k, v, a, b = make_scan_inputs(1, 2, 9, 1, 64, 16, seed=46)
+    dev = lambda x: torch.from_numpy(x).cuda()
+    tq = dev(q).requires_grad_()
+    R, S = hip.scan(tq, dev(k), dev(v), dev(a), dev(b))
+    R.sum().backward()
+    assert tq.grad is not None and torch.isfinite(tq.grad).all()

@@ -192,3 +192,38 @@ def test_bf16_rounding_helper():
     x = np.random.default_rng(12).standard_normal(4096).astype(np.float32) * 100
     ref = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
     assert np.array_equal(O.to_bf16_f32(x), ref)
+
+
+# ------------------------------------------------ the differentiable torch restatement (gradient oracle)
+@pytest.mark.parametrize("rule", RULES)
+def test_torch_ref_matches_numpy_oracle(rule):
+    import torch
+    from oracle import torch_ref as TR
+    q, k, v, a, b = make_scan_inputs(2, 3, 9, 2, 16, 8, seed=21, normalized=False, logits=True)
+    s0 = np.random.default_rng(22).standard_normal((2, 2, 16, 8))
+    R, S = O.scan(q, k, v, a, b, s0=s0, rule=rule, flags=3)
+    Rt, St = TR.scan(*(torch.from_numpy(x).double() for x in (q, k, v, a, b)), torch.from_numpy(s0), rule, 3)
+    np.testing.assert_allclose(Rt.numpy(), R, atol=1e-12); np.testing.assert_allclose(St.numpy(), S, atol=1e-12)
+    L, G, P, Wa, ba, Wl, Wg = make_kpff_inputs(2, 5, 6, 8, 12, 16, seed=23)
+    F = O.kpff(L, G, P, Wa, ba, Wl, Wg, 5, 6)
+    Ft = TR.kpff(*(torch.from_numpy(x).double() for x in (L, G, P, Wa, ba, Wl, Wg)), 5, 6)
+    np.testing.assert_allclose(Ft.numpy(), F, atol=1e-12)
+
+
+@pytest.mark.parametrize("rule", RULES)
+@pytest.mark.parametrize("flags", [0, 3])
+def test_backward_algorithm_matches_autograd(rule, flags):
+    """The reverse recurrence + per-frame assembly (oracle/bwd_ref.py, the algorithm of the HIP backward) against
+    autograd through the token-sequential definition."""
+    import torch
+    from oracle import bwd_ref
+    from oracle import torch_ref as TR
+    q, k, v, a, b = make_scan_inputs(2, 3, 7, 2, 8, 6, seed=31 + rule, normalized=not flags, logits=bool(flags), corr=0.5)
+    rng = np.random.default_rng(32)
+    s0 = rng.standard_normal((2, 2, 8, 6)); dR = rng.standard_normal((2, 3, 7, 2, 6)); dST = rng.standard_normal((2, 2, 8, 6))
+    ts = [torch.from_numpy(np.asarray(x, np.float64)).requires_grad_() for x in (q, k, v, a, b, s0)]
+    R, S = TR.scan(*ts, rule, flags)
+    (R * torch.from_numpy(dR)).sum().add((S * torch.from_numpy(dST)).sum()).backward()
+    got = bwd_ref.scan_backward(q, k, v, a, b, s0, dR, dST, rule, flags)
+    for g, t in zip(got, ts):
+        np.testing.assert_allclose(g, t.grad.numpy(), atol=1e-9)

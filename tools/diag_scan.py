@@ -34,10 +34,10 @@ def main():
     diag = torch.zeros(T * 8, dtype=torch.int64, device=dev)
     lib.gdkvm_diag_set_buffer(ctypes.c_void_p(diag.data_ptr()))
     vp = ctypes.c_void_p
-    lib.gdkvm_scan_fwd.argtypes = [vp] * 9 + [ctypes.c_size_t] + [ctypes.c_int] * 9 + [vp]
+    lib.gdkvm_scan_fwd.argtypes = [vp] * 10 + [ctypes.c_size_t] + [ctypes.c_int] * 9 + [vp]
     for _ in range(3):
         rc = lib.gdkvm_scan_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), al.data_ptr(), be.data_ptr(), None, r.data_ptr(),
-                                s.data_ptr(), ws.data_ptr(), wsb, B, T, Hh, N, Dk, Dv, 1, 2, 3, None)
+                                s.data_ptr(), None, ws.data_ptr(), wsb, B, T, Hh, N, Dk, Dv, 1, 2, 3, None)
         assert rc == 0
         torch.cuda.synchronize()
     d = diag.cpu().reshape(T, 8)[:, :5]
