@@ -15,11 +15,14 @@
 
 namespace {
 
+struct KpffSave { void* gates; void* lp; void* gp; void* gms; };   // training: [M,2Cp] [M,Cp] [M,Cp] [M,Cv] (io dtype) or NULL
+
 struct KpffArgs {
     const void* L; const void* G; const void* P;
     const float* wa; const float* ba; const float* wl; const float* wg;
     void* out;
     int Ck, Cv, Cp, h, w, rows_per_tile, tiles_per_frame;
+    KpffSave sv;
 };
 
 constexpr int KPFF_TM = 64;       // tokens per workgroup tile
@@ -80,6 +83,12 @@ __global__ __launch_bounds__(256) void kpff_kernel(KpffArgs a)
         }
     }
     __syncthreads();
+    if (a.sv.gms) {                                            // training: keep the pooled feature for the backward
+        for (int idx = tid; idx < ntok * Cv; idx += 256) {
+            const int tok = idx / Cv, c = idx - tok * Cv;
+            store1<IO>(a.sv.gms, ((size_t)f * N + n0 + tok) * Cv + c, s_x[(size_t)tok * ld + Cp + Ck + c]);
+        }
+    }
 
     // ---- fused channel mixes: wave owns output channels o = 64*chunk + 16*wave + li -----------------
     const int kbP = Cp / 16, kbL = Ck / 16, kbG = Cv / 16;
@@ -124,7 +133,14 @@ __global__ __launch_bounds__(256) void kpff_kernel(KpffArgs a)
                     const float sl = 1.0f / (1.0f + expf(-(gl[mt][r] + bl)));
                     const float sg = 1.0f / (1.0f + expf(-(gg[mt][r] + bg)));
                     const float y = s_x[(size_t)tok * ld + o] + sl * lp[mt][r] + sg * gp[mt][r];
-                    store1<IO>(a.out, ((size_t)f * N + n0 + tok) * Cp + o, y);
+                    const size_t grow = (size_t)f * N + n0 + tok;
+                    store1<IO>(a.out, grow * Cp + o, y);
+                    if (a.sv.gates) {
+                        store1<IO>(a.sv.gates, grow * 2 * Cp + o, sl);
+                        store1<IO>(a.sv.gates, grow * 2 * Cp + Cp + o, sg);
+                        store1<IO>(a.sv.lp, grow * Cp + o, lp[mt][r]);
+                        store1<IO>(a.sv.gp, grow * Cp + o, gp[mt][r]);
+                    }
                 }
             }
     }
@@ -143,6 +159,7 @@ struct KpffBf16Args {
     const bf16_t* wa; const float* ba; const bf16_t* wl; const bf16_t* wg;
     bf16_t* out;
     int Ck, Cv, Cp, h, w, rows_per_tile, tiles_per_frame;
+    KpffSave sv;
 };
 
 constexpr int KPFF_PAD16 = 8;     // bf16 elements (16 B) of row padding
@@ -221,6 +238,13 @@ __global__ __launch_bounds__(256, 2) void kpff_bf16_kernel(KpffBf16Args a)
         }
     }
     __syncthreads();
+    if (a.sv.gms) {                                            // training: keep the pooled feature for the backward
+        bf16_t* gms = static_cast<bf16_t*>(a.sv.gms);
+        for (int idx = tid; idx < ntok * Cv; idx += 256) {
+            const int tok = idx / Cv, c = idx - tok * Cv;
+            gms[((size_t)f * N + n0 + tok) * Cv + c] = s_xb[(size_t)tok * ld + Cp + Ck + c];
+        }
+    }
 
     // ---- fused channel mixes: wave owns output channels o = 64*chunk + 16*wave + li -----------------
     const int ksP = Cp / 32, ksL = Ck / 32, ksG = Cv / 32;
@@ -264,8 +288,79 @@ __global__ __launch_bounds__(256, 2) void kpff_bf16_kernel(KpffBf16Args a)
                     const float sl = 1.0f / (1.0f + __expf(-(gl[mt][r] + bl)));
                     const float sg = 1.0f / (1.0f + __expf(-(gg[mt][r] + bg)));
                     const float y = bf16_to_f32(s_xb[(size_t)tok * ld + o]) + sl * lp[mt][r] + sg * gp[mt][r];
-                    a.out[((size_t)f * N + n0 + tok) * Cp + o] = f32_to_bf16(y);
+                    const size_t grow = (size_t)f * N + n0 + tok;
+                    a.out[grow * Cp + o] = f32_to_bf16(y);
+                    if (a.sv.gates) {
+                        bf16_t* sg_ = static_cast<bf16_t*>(a.sv.gates);
+                        sg_[grow * 2 * Cp + o] = f32_to_bf16(sl);
+                        sg_[grow * 2 * Cp + Cp + o] = f32_to_bf16(sg);
+                        static_cast<bf16_t*>(a.sv.lp)[grow * Cp + o] = f32_to_bf16(lp[mt][r]);
+                        static_cast<bf16_t*>(a.sv.gp)[grow * Cp + o] = f32_to_bf16(gp[mt][r]);
+                    }
                 }
+            }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward (row a7) pieces that are not plain GEMMs.  With g = (g_l | g_g), Lp = L Wl^T, Gp = Gms Wg^T:
+//   pre :  dz = (dF * Lp * g_l (1-g_l) | dF * Gp * g_g (1-g_g)),  dLp = dF * g_l,  dGp = dF * g_g     (elementwise)
+//   ...    dX = dz Wa,  dL += dLp Wl,  dGms += dGp Wg,  dWa = dz^T [P;L;Gms], dWl = dLp^T L, dWg = dGp^T Gms   (library GEMMs)
+//   post:  dP = dF + dX_P,  dL = dX_L + dLp Wl,  dG = pool(dX_G + dGp Wg)   (the multi-scale pooling is symmetric)
+template <int IO>
+__global__ void kpff_bwd_pre_kernel(const void* dF, const void* gates, const void* lp, const void* gp,
+                                    void* dz, void* dlp, void* dgp, size_t M, int Cp)
+{
+    const size_t n = M * Cp;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / Cp;
+        const int o = (int)(i - row * Cp);
+        const float d = load1<IO>(dF, i), gl = load1<IO>(gates, row * 2 * Cp + o), gg = load1<IO>(gates, row * 2 * Cp + Cp + o);
+        store1<IO>(dz, row * 2 * Cp + o, d * load1<IO>(lp, i) * gl * (1.f - gl));
+        store1<IO>(dz, row * 2 * Cp + Cp + o, d * load1<IO>(gp, i) * gg * (1.f - gg));
+        store1<IO>(dlp, i, d * gl);
+        store1<IO>(dgp, i, d * gg);
+    }
+}
+
+// one workgroup per frame: dP, dL (elementwise sums) and dG = pool(dGms) over the h x w grid
+template <int IO>
+__global__ __launch_bounds__(256) void kpff_bwd_post_kernel(const void* dF, const void* dX, const void* dL_add, const void* dG_add,
+                                                            void* dP, void* dL, void* dG, int Ck, int Cv, int Cp, int h, int w)
+{
+    const int f = blockIdx.x, N = h * w, Cin = Cp + Ck + Cv, tid = threadIdx.x;
+    for (int idx = tid; idx < N * Cp; idx += 256) {
+        const int tok = idx / Cp, c = idx - tok * Cp;
+        const size_t row = (size_t)f * N + tok;
+        store1<IO>(dP, row * Cp + c, load1<IO>(dF, row * Cp + c) + load1<IO>(dX, row * Cin + c));
+    }
+    for (int idx = tid; idx < N * Ck; idx += 256) {
+        const int tok = idx / Ck, c = idx - tok * Ck;
+        const size_t row = (size_t)f * N + tok;
+        store1<IO>(dL, row * Ck + c, load1<IO>(dX, row * Cin + Cp + c) + load1<IO>(dL_add, row * Ck + c));
+    }
+    const int cw = (w + 3) / 4, chh = (h + 3) / 4;
+    for (int idx = tid; idx < cw * chh * Cv; idx += 256) {
+        const int c = idx % Cv, cell = idx / Cv;
+        const int y0 = (cell / cw) * 4, x0 = (cell % cw) * 4;
+        const int y1 = min(y0 + 4, h), x1 = min(x0 + 4, w);
+        float s4 = 0.f, s2[4] = {0.f, 0.f, 0.f, 0.f}, v[16];
+        int n2[4] = {0, 0, 0, 0};
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                const size_t row = (size_t)f * N + y * w + x;
+                const float val = load1<IO>(dX, row * Cin + Cp + Ck + c) + load1<IO>(dG_add, row * Cv + c);
+                const int q = ((y - y0) >> 1) * 2 + ((x - x0) >> 1);
+                v[(y - y0) * 4 + (x - x0)] = val;
+                s2[q] += val; n2[q] += 1; s4 += val;
+            }
+        const float m4 = s4 / (float)((y1 - y0) * (x1 - x0));
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                const int q = ((y - y0) >> 1) * 2 + ((x - x0) >> 1);
+                const size_t row = (size_t)f * N + y * w + x;
+                store1<IO>(dG, row * Cv + c, (v[(y - y0) * 4 + (x - x0)] + s2[q] / (float)n2[q] + m4) * (1.0f / 3.0f));
             }
     }
 }
@@ -278,11 +373,15 @@ extern "C" size_t gdkvm_kpff_workspace_bytes(int Ck, int Cv, int Cp, int io_dtyp
     return ((size_t)2 * Cp * (Cp + Ck + Cv) + (size_t)Cp * Ck + (size_t)Cp * Cv) * sizeof(bf16_t) + 16;
 }
 
-extern "C" int gdkvm_kpff_fwd(const void* local, const void* global, const void* pixel,
-                              const float* wa, const float* ba, const float* wl, const float* wg, void* out,
-                              void* workspace, size_t workspace_bytes,
-                              int BT, int Ck, int Cv, int Cp, int h, int w, int io_dtype, void* stream)
+extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const void* pixel,
+                                    const float* wa, const float* ba, const float* wl, const float* wg, void* out,
+                                    void* save_gates, void* save_lp, void* save_gp, void* save_gms,
+                                    void* workspace, size_t workspace_bytes,
+                                    int BT, int Ck, int Cv, int Cp, int h, int w, int io_dtype, void* stream)
 {
+    const bool any = save_gates || save_lp || save_gp || save_gms, all = save_gates && save_lp && save_gp && save_gms;
+    if (any && !all) return gdkvm_fail(GDKVM_ERR_ARG, "kpff_fwd: the four save buffers go together");
+    const KpffSave sv{save_gates, save_lp, save_gp, save_gms};
     if (BT < 0 || Ck <= 0 || Cv <= 0 || Cp <= 0 || h <= 0 || w <= 0)
         return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: bad shape BT=%d Ck=%d Cv=%d Cp=%d h=%d w=%d", BT, Ck, Cv, Cp, h, w);
     if (Ck % 16 || Cv % 16 || Cp % 16) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: channels must be multiples of 16");
@@ -319,7 +418,7 @@ extern "C" int gdkvm_kpff_fwd(const void* local, const void* global, const void*
         hipLaunchKernelGGL(kpff_pack_weights_kernel, dim3(256), dim3(256), 0, st, wa, wl, wg, wab, na, nl, ng);
         GDKVM_LAUNCH_CHECK("kpff_pack_weights_kernel");
         KpffBf16Args b{static_cast<const bf16_t*>(local), static_cast<const bf16_t*>(global), static_cast<const bf16_t*>(pixel),
-                       wab, ba, wab + na, wab + na + nl, static_cast<bf16_t*>(out), Ck, Cv, Cp, h, w, rows, tiles};
+                       wab, ba, wab + na, wab + na + nl, static_cast<bf16_t*>(out), Ck, Cv, Cp, h, w, rows, tiles, sv};
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kpff_bf16_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -332,7 +431,7 @@ extern "C" int gdkvm_kpff_fwd(const void* local, const void* global, const void*
 
     const size_t lds = (size_t)KPFF_TM * (Cin + KPFF_PAD) * sizeof(float);
     if (lds > 160 * 1024) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: Cp+Ck+Cv=%d exceeds the LDS tile", Cin);
-    KpffArgs a{local, global, pixel, wa, ba, wl, wg, out, Ck, Cv, Cp, h, w, rows, tiles};
+    KpffArgs a{local, global, pixel, wa, ba, wl, wg, out, Ck, Cv, Cp, h, w, rows, tiles, sv};
     const void* fn = io_dtype == GDKVM_F32 ? reinterpret_cast<const void*>(kpff_kernel<GDKVM_F32>)
                                            : reinterpret_cast<const void*>(kpff_kernel<GDKVM_BF16>);
     if (lds > 64 * 1024) {
@@ -342,5 +441,48 @@ extern "C" int gdkvm_kpff_fwd(const void* local, const void* global, const void*
     if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((kpff_kernel<GDKVM_F32>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((kpff_kernel<GDKVM_BF16>), grid, dim3(256), lds, st, a);
     GDKVM_LAUNCH_CHECK("kpff_kernel");
+    return GDKVM_OK;
+}
+
+extern "C" int gdkvm_kpff_fwd(const void* local, const void* global, const void* pixel,
+                              const float* wa, const float* ba, const float* wl, const float* wg, void* out,
+                              void* workspace, size_t workspace_bytes,
+                              int BT, int Ck, int Cv, int Cp, int h, int w, int io_dtype, void* stream)
+{
+    return gdkvm_kpff_fwd_train(local, global, pixel, wa, ba, wl, wg, out, nullptr, nullptr, nullptr, nullptr,
+                                workspace, workspace_bytes, BT, Ck, Cv, Cp, h, w, io_dtype, stream);
+}
+
+extern "C" int gdkvm_kpff_bwd_pre(const void* d_out, const void* gates, const void* lp, const void* gp,
+                                  void* d_z, void* d_lp, void* d_gp, int BT, int N, int Cp, int io_dtype, void* stream)
+{
+    if (BT < 0 || N <= 0 || Cp <= 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_bwd_pre: bad shape");
+    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "kpff_bwd_pre: io_dtype=%d", io_dtype);
+    if (BT == 0) return GDKVM_OK;
+    const void* ptrs[] = {d_out, gates, lp, gp, d_z, d_lp, d_gp};
+    for (const void* p : ptrs) if (!p || !gdkvm_aligned16(p)) return gdkvm_fail(GDKVM_ERR_ARG, "kpff_bwd_pre: null or misaligned pointer");
+    if (int rc = gdkvm_check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t M = (size_t)BT * N;
+    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((kpff_bwd_pre_kernel<GDKVM_F32>), dim3(2048), dim3(256), 0, st, d_out, gates, lp, gp, d_z, d_lp, d_gp, M, Cp);
+    else hipLaunchKernelGGL((kpff_bwd_pre_kernel<GDKVM_BF16>), dim3(2048), dim3(256), 0, st, d_out, gates, lp, gp, d_z, d_lp, d_gp, M, Cp);
+    GDKVM_LAUNCH_CHECK("kpff_bwd_pre_kernel");
+    return GDKVM_OK;
+}
+
+extern "C" int gdkvm_kpff_bwd_post(const void* d_out, const void* d_x, const void* d_l_add, const void* d_g_add,
+                                   void* d_pixel, void* d_local, void* d_global,
+                                   int BT, int Ck, int Cv, int Cp, int h, int w, int io_dtype, void* stream)
+{
+    if (BT < 0 || Ck <= 0 || Cv <= 0 || Cp <= 0 || h <= 0 || w <= 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_bwd_post: bad shape");
+    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "kpff_bwd_post: io_dtype=%d", io_dtype);
+    if (BT == 0) return GDKVM_OK;
+    const void* ptrs[] = {d_out, d_x, d_l_add, d_g_add, d_pixel, d_local, d_global};
+    for (const void* p : ptrs) if (!p || !gdkvm_aligned16(p)) return gdkvm_fail(GDKVM_ERR_ARG, "kpff_bwd_post: null or misaligned pointer");
+    if (int rc = gdkvm_check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((kpff_bwd_post_kernel<GDKVM_F32>), dim3(BT), dim3(256), 0, st, d_out, d_x, d_l_add, d_g_add, d_pixel, d_local, d_global, Ck, Cv, Cp, h, w);
+    else hipLaunchKernelGGL((kpff_bwd_post_kernel<GDKVM_BF16>), dim3(BT), dim3(256), 0, st, d_out, d_x, d_l_add, d_g_add, d_pixel, d_local, d_global, Ck, Cv, Cp, h, w);
+    GDKVM_LAUNCH_CHECK("kpff_bwd_post_kernel");
     return GDKVM_OK;
 }

@@ -33,6 +33,9 @@ SIGNATURES = {
     "gdkvm_scan_bwd": (_i, [_vp] * 7 + [_sz] + [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_kpff_workspace_bytes": (_sz, [_i] * 4),
     "gdkvm_kpff_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 7 + [_vp]),
+    "gdkvm_kpff_fwd_train": (_i, [_vp] * 13 + [_sz] + [_i] * 7 + [_vp]),
+    "gdkvm_kpff_bwd_pre": (_i, [_vp] * 7 + [_i] * 4 + [_vp]),
+    "gdkvm_kpff_bwd_post": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
 }
 
@@ -253,6 +256,67 @@ def kpff_fwd(local: torch.Tensor, glob: torch.Tensor, pixel: torch.Tensor, wa: t
                                 workspace.data_ptr(), workspace.numel(), BT, Ck, Cv, Cp, h, w, io, _stream(dev))
     _check(rc, "gdkvm_kpff_fwd")
     return f
+
+
+class _KpffFunction(torch.autograd.Function):
+    """Differentiable KPFF: HIP forward (saving gates / mixes / pooled feature), HIP elementwise + pooling backward;
+    the six plain GEMMs of the backward are library GEMMs (torch.mm -> hipBLASLt/rocBLAS)."""
+
+    @staticmethod
+    def forward(ctx, local, glob, pixel, wa, ba, wl, wg, h, w):
+        lib = load()
+        BT, N, Ck = local.shape
+        Cv, Cp = glob.shape[-1], pixel.shape[-1]
+        dev = _dev(local, glob, pixel, wa, ba, wl, wg)
+        io = _io_dtype(local)
+        f = torch.empty((BT, N, Cp), dtype=local.dtype, device=dev)
+        gates = torch.empty((BT * N, 2 * Cp), dtype=local.dtype, device=dev)
+        lp, gp = (torch.empty((BT * N, Cp), dtype=local.dtype, device=dev) for _ in range(2))
+        gms = torch.empty((BT * N, Cv), dtype=local.dtype, device=dev)
+        ws = torch.empty(int(lib.gdkvm_kpff_workspace_bytes(Ck, Cv, Cp, io)), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.gdkvm_kpff_fwd_train(_ptr(local), _ptr(glob), _ptr(pixel), _ptr(wa), _ptr(ba), _ptr(wl), _ptr(wg), _ptr(f),
+                                          _ptr(gates), _ptr(lp), _ptr(gp), _ptr(gms), ws.data_ptr(), ws.numel(),
+                                          BT, Ck, Cv, Cp, h, w, io, _stream(dev))
+        _check(rc, "gdkvm_kpff_fwd_train")
+        ctx.save_for_backward(local, pixel, wa, wl, wg, gates, lp, gp, gms)
+        ctx.hw = (h, w)
+        return f
+
+    @staticmethod
+    def backward(ctx, d_f):
+        lib = load()
+        local, pixel, wa, wl, wg, gates, lp, gp, gms = ctx.saved_tensors
+        h, w = ctx.hw
+        BT, N, Ck = local.shape
+        Cp, Cv = pixel.shape[-1], gms.shape[-1]
+        M, dt, dev = BT * N, local.dtype, local.device
+        io = _io_dtype(local)
+        d_f = d_f.contiguous()
+        dz = torch.empty((M, 2 * Cp), dtype=dt, device=dev)
+        dlp, dgp = (torch.empty((M, Cp), dtype=dt, device=dev) for _ in range(2))
+        with torch.cuda.device(dev):
+            _check(lib.gdkvm_kpff_bwd_pre(_ptr(d_f), _ptr(gates), _ptr(lp), _ptr(gp), _ptr(dz), _ptr(dlp), _ptr(dgp),
+                                          BT, N, Cp, io, _stream(dev)), "gdkvm_kpff_bwd_pre")
+        L2, P2 = local.reshape(M, Ck), pixel.reshape(M, Cp)
+        wa_c, wl_c, wg_c = wa.to(dt), wl.to(dt), wg.to(dt)
+        dx = dz @ wa_c                                   # [M, Cin]      plain library GEMMs from here ...
+        dl_add = dlp @ wl_c                              # [M, Ck]
+        dg_add = dgp @ wg_c                              # [M, Cv]
+        d_wa = torch.cat([dz.t() @ P2, dz.t() @ L2, dz.t() @ gms], 1).float()
+        d_wl = (dlp.t() @ L2).float()
+        d_wg = (dgp.t() @ gms).float()                   # ... to here
+        d_ba = dz.float().sum(0)
+        d_p, d_l, d_g = torch.empty_like(pixel), torch.empty_like(local), torch.empty((BT, N, Cv), dtype=dt, device=dev)
+        with torch.cuda.device(dev):
+            _check(lib.gdkvm_kpff_bwd_post(_ptr(d_f), _ptr(dx), _ptr(dl_add), _ptr(dg_add), _ptr(d_p), _ptr(d_l), _ptr(d_g),
+                                           BT, Ck, Cv, Cp, h, w, io, _stream(dev)), "gdkvm_kpff_bwd_post")
+        return d_l, d_g, d_p, d_wa, d_ba, d_wl, d_wg, None, None
+
+
+def kpff(local, glob, pixel, wa, ba, wl, wg, h: int, w: int):
+    """kpff_fwd with autograd support (training)."""
+    return _KpffFunction.apply(local, glob, pixel, wa, ba, wl, wg, h, w)
 
 
 def argmax_dice(logits: torch.Tensor, target: Optional[torch.Tensor] = None):

@@ -111,6 +111,24 @@ int gdkvm_kpff_fwd(const void* local, const void* global, const void* pixel,
                    void* workspace, size_t workspace_bytes,
                    int BT, int Ck, int Cv, int Cp, int h, int w, int io_dtype, void* stream);
 
+/* Row a7 for KPFF.  The training forward also stores what the backward needs (all [M = BT*N, .] in io_dtype): the
+ * gates after the sigmoid [M,2Cp], L wl^T [M,Cp], Gms wg^T [M,Cp] and the pooled feature Gms [M,Cv].  The backward is
+ *   gdkvm_kpff_bwd_pre   d_z = (d_out*Lp*g_l(1-g_l) | d_out*Gp*g_g(1-g_g)), d_lp = d_out*g_l, d_gp = d_out*g_g
+ *   six plain GEMMs      d_x = d_z wa, d_l_add = d_lp wl, d_g_add = d_gp wg, d_wa = d_z^T [P;L;Gms], d_wl = d_lp^T L,
+ *                        d_wg = d_gp^T Gms  (and d_ba = column sums of d_z) -- library GEMMs on the caller's side
+ *   gdkvm_kpff_bwd_post  d_pixel = d_out + d_x[:, :Cp], d_local = d_x[:, Cp:Cp+Ck] + d_l_add,
+ *                        d_global = pool(d_x[:, Cp+Ck:] + d_g_add)   (the multi-scale pooling operator is symmetric) */
+int gdkvm_kpff_fwd_train(const void* local, const void* global, const void* pixel,
+                         const float* wa, const float* ba, const float* wl, const float* wg, void* out,
+                         void* save_gates, void* save_lp, void* save_gp, void* save_gms,
+                         void* workspace, size_t workspace_bytes,
+                         int BT, int Ck, int Cv, int Cp, int h, int w, int io_dtype, void* stream);
+int gdkvm_kpff_bwd_pre(const void* d_out, const void* gates, const void* lp, const void* gp,
+                       void* d_z, void* d_lp, void* d_gp, int BT, int N, int Cp, int io_dtype, void* stream);
+int gdkvm_kpff_bwd_post(const void* d_out, const void* d_x, const void* d_l_add, const void* d_g_add,
+                        void* d_pixel, void* d_local, void* d_global,
+                        int BT, int Ck, int Cv, int Cp, int h, int w, int io_dtype, void* stream);
+
 /* Row a6: mask = argmax_c logits (ties -> lowest class index); optional integer Dice counts.
  *   logits [BT, ncls, H, W] (io_dtype)   target [BT,H,W] u8 or NULL   mask [BT,H,W] u8
  *   counts [BT, ncls, 3] int32 = { |mask==c & target==c|, |mask==c|, |target==c| }  (zeroed by the callee;

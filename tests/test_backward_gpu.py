@@ -81,3 +81,38 @@ def test_scan_backward_no_state_input(hip):
     R, S = hip.scan(tq, dev(k), dev(v), dev(a), dev(b))
     R.sum().backward()
     assert tq.grad is not None and torch.isfinite(tq.grad).all()
+
+
+@pytest.mark.parametrize("case", [(3, 7, 7, 64, 256, 256), (2, 16, 16, 32, 64, 64), (2, 5, 3, 16, 16, 32)])
+def test_kpff_backward_fp32(hip, case):
+    from tests.util import make_kpff_inputs
+    BT, h, w, Ck, Cv, Cp = case
+    arrs = make_kpff_inputs(BT, h, w, Ck, Cv, Cp, seed=sum(case))
+    dF = np.random.default_rng(50).standard_normal((BT, h * w, Cp)).astype(np.float32)
+    ts = [torch.from_numpy(x).double().requires_grad_() for x in arrs]
+    (TR.kpff(*ts, h, w) * torch.from_numpy(dF).double()).sum().backward()
+    ref = [t.grad.numpy() for t in ts]
+    gs = [torch.from_numpy(x).cuda().requires_grad_() for x in arrs]
+    F = hip.kpff(*gs, h, w)
+    F.backward(torch.from_numpy(dF).cuda())
+    for name, g, r in zip("L G P Wa ba Wl Wg".split(), gs, ref):
+        err = np.abs(g.grad.cpu().numpy() - r).max()
+        assert err <= 2e-4 * max(1.0, np.abs(r).max()), (name, err, np.abs(r).max())
+
+
+def test_kpff_backward_bf16(hip):
+    from oracle import gdkvm_oracle as O
+    from tests.util import make_kpff_inputs
+    BT, h, w, Ck, Cv, Cp = 3, 7, 7, 64, 256, 256
+    arrs = make_kpff_inputs(BT, h, w, Ck, Cv, Cp, seed=51)
+    dF = O.to_bf16_f32(np.random.default_rng(52).standard_normal((BT, h * w, Cp)).astype(np.float32))
+    rnd = [O.to_bf16_f32(x) if i != 4 else x for i, x in enumerate(arrs)]      # features and weights as the bf16 arm sees them
+    ts = [torch.from_numpy(x).double().requires_grad_() for x in rnd]
+    (TR.kpff(*ts, h, w) * torch.from_numpy(dF).double()).sum().backward()
+    ref = [t.grad.numpy() for t in ts]
+    gs = [torch.from_numpy(x).cuda().to(torch.bfloat16 if i < 3 else torch.float32).requires_grad_() for i, x in enumerate(arrs)]
+    hip.kpff(*gs, h, w).backward(torch.from_numpy(dF).cuda().bfloat16())
+    for name, g, r in zip("L G P Wa ba Wl Wg".split(), gs, ref):
+        err = np.abs(g.grad.float().cpu().numpy() - r)
+        scale = np.abs(r).max()
+        assert err.max() <= 0.03 * scale + 1e-2 and err.mean() <= 4e-3 * scale + 1e-3, (name, err.max(), err.mean(), scale)
