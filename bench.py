@@ -57,6 +57,57 @@ def time_events(fn, iters, warmup=3):
     return sum(ms) / len(ms), ms[len(ms) // 2]
 
 
+def bench_train(args, world, rank, dev):
+    """BASELINE configs[3]: EchoNet-Dynamic training, DDP over the GPUs of one node, 16 clips x 32 frames per GPU,
+    bf16 autocast with fp32 master weights, AdamW lr 1e-4 (the reference guide's learning rate).  A step = forward,
+    loss, backward (HIP backward kernels + RCCL gradient all-reduce), optimiser update."""
+    import torch.distributed as dist
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    from gdkvm_amd.train import train_step, wrap_ddp
+    cfg = GDKVMConfig()
+    torch.manual_seed(3)
+    model = GDKVM(cfg).train().to(dev).to(memory_format=torch.channels_last)
+    ddp = wrap_ddp(model, dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=1.0e-4)
+    B, T, S = args.batch, args.frames, args.size
+    g = torch.Generator(device="cpu").manual_seed(3000 + rank)
+    frames = torch.rand(B, T, 3, S, S, generator=g).to(dev)
+    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    target = ((((yy - S / 2) / (S * 0.3)) ** 2 + ((xx - S / 2) / (S * 0.2)) ** 2) < 1).long().expand(B, T, S, S).contiguous().to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = train_step(ddp, opt, frames, target, torch.bfloat16)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(ddp, opt, frames, target, torch.bfloat16)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    if rank == 0:
+        print(json.dumps({"metric": "training frames/sec (GDKVM forward+backward+AdamW), EchoNet 112x112x32 clips",
+                          "value": round(world * B * T * args.steps / dt, 1), "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": "BASELINE.json configs[3]: EchoNet-Dynamic training, DDP, 16 clips/GPU "
+                                                 "(global batch 128 at 8 GPUs), bf16 autocast, AdamW lr 1e-4",
+                                     "clips_per_gpu": B, "frames_per_clip": T, "image": f"{S}x{S}",
+                                     "sharding": f"DDP over {world} GPU(s): one gradient all-reduce per step (RCCL)"},
+                          "final_loss": round(float(loss), 5)}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +117,8 @@ def main():
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--size", type=int, default=112)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer = BASELINE configs[1] (the headline metric); train = configs[3]: DDP training step")
     ap.add_argument("--kernel-iters", type=int, default=50)
     args = ap.parse_args()
 
@@ -83,6 +136,8 @@ def main():
     from gdkvm_amd import ops
     from gdkvm_amd.model import GDKVM, GDKVMConfig
     ops.require_native()
+    if args.mode == "train":
+        return bench_train(args, world, rank, dev)
 
     cfg = GDKVMConfig()
     torch.manual_seed(1)                                    # SURVEY.md §8(d) cfg2 seed; same weights on every rank

@@ -170,11 +170,15 @@ class GDKVM(nn.Module):
     # ------------------------------------------------------------------ memory path (HIP; overridable hooks)
     def _memory_scan(self, q, k, v, alpha_logit, beta_logit, state):
         """q,k [B,T,N,Hh,Dk] v [B,T,N,Hh,Dv] alpha [B,T,Hh] beta [B,T,N,Hh] -> (R [B,T,N,Hh,Dv], S_T)."""
-        return ops.scan_fwd(q, k, v, alpha_logit, beta_logit, state, rule=_RULES[self.cfg.rule],
-                            flags=ops.FLAG_NORMALIZE_QK | ops.FLAG_GATE_LOGITS)
+        flags = ops.FLAG_NORMALIZE_QK | ops.FLAG_GATE_LOGITS
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v, alpha_logit, beta_logit)):
+            return ops.scan(q, k, v, alpha_logit, beta_logit, state, _RULES[self.cfg.rule], flags)   # saves history
+        return ops.scan_fwd(q, k, v, alpha_logit, beta_logit, state, rule=_RULES[self.cfg.rule], flags=flags)
 
     def _fuse(self, local, glob, pixel, h, w):
         p = self.kpff
+        if torch.is_grad_enabled() and (pixel.requires_grad or p.wa.requires_grad):
+            return ops.kpff(local, glob, pixel, p.wa, p.ba, p.wl, p.wg, h, w)
         return ops.kpff_fwd(local, glob, pixel, p.wa.float(), p.ba.float(), p.wl.float(), p.wg.float(), h, w)
 
     # ------------------------------------------------------------------------------------------ forward
@@ -187,11 +191,9 @@ class GDKVM(nn.Module):
                 state: Optional[torch.Tensor] = None, return_state: bool = False):
         if frames.dim() != 5:
             raise ValueError("frames must be [B,T,C,H,W]")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("GDKVM.forward: the memory path has no backward kernel yet "
-                                      "(SURVEY.md §8 row a7); call under torch.no_grad()")
         cfg = self.cfg
-        frames = frames.to(self.key_proj.weight.dtype)
+        if not torch.is_autocast_enabled():
+            frames = frames.to(self.key_proj.weight.dtype)
         B, T, C, H, W = frames.shape
         Hh, Dk, Dv = cfg.heads, cfg.key_dim, cfg.value_dim
         x = frames.reshape(B * T, C, H, W).contiguous(memory_format=torch.channels_last)
@@ -204,11 +206,13 @@ class GDKVM(nn.Module):
             m = F.adaptive_avg_pool2d(mask0.to(val.dtype), (h, w))
             val = val.reshape(B, T, *val.shape[1:])
             val = torch.cat([val[:, :1] + self.mask_embed(m).unsqueeze(1), val[:, 1:]], 1).reshape(B * T, Hh * Dv, h, w)
+        elif torch.is_grad_enabled() and self.mask_embed.weight.requires_grad:
+            val = val + 0.0 * self.mask_embed.weight.sum()        # keep every parameter in the graph (DDP: no unused params)
         k_tok = self._tokens(key)                                                # [BT,N,Hh*Dk] local key feature
         q = self._tokens(self.query_proj(f16)).reshape(B, T, N, Hh, Dk)
         v = self._tokens(val).reshape(B, T, N, Hh, Dv)
-        beta = self._tokens(self.gate_proj(f16)).float().reshape(B, T, N, Hh)
-        alpha = self.decay_proj(f16.mean((2, 3))).float().reshape(B, T, Hh)
+        beta = self._tokens(self.gate_proj(f16)).float().reshape(B, T, N, Hh).contiguous()
+        alpha = self.decay_proj(f16.mean((2, 3))).float().reshape(B, T, Hh).contiguous()
         r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state)
         p_tok = self._tokens(f16)
         fused = self._fuse(k_tok, r.reshape(B * T, N, Hh * Dv), p_tok, h, w)       # [BT,N,Cp]

@@ -1,0 +1,54 @@
+"""Training-side host code for the GDKVM module: loss, one optimisation step, DDP wrapping.
+
+The reference's harness is not in the snapshot; its guide names the recipe this mirrors: batch_size 8,
+learning_rate 1.0e-4, num_iterations 3000, two GPUs under a torch.distributed launcher
+(/root/reference/website/src/pages/[lang]/reprod/index.astro:238-252).  One process per GPU; the only exchange per
+step is the DDP gradient all-reduce (RCCL over xGMI on the GPU box, gloo in CPU tests) -- the memory path itself shards
+over clips with no collective."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def segmentation_loss(logits: torch.Tensor, target: torch.Tensor, dice_weight: float = 1.0, eps: float = 1.0) -> torch.Tensor:
+    """Cross-entropy + soft Dice over [B,T,ncls,H,W] logits and [B,T,H,W] integer labels (fp32 math)."""
+    B, T, C, H, W = logits.shape
+    lg = logits.reshape(B * T, C, H, W).float()
+    tg = target.reshape(B * T, H, W).long()
+    ce = F.cross_entropy(lg, tg)
+    p = lg.softmax(1)
+    oh = F.one_hot(tg, C).permute(0, 3, 1, 2).float()
+    inter = (p * oh).sum((0, 2, 3))
+    dice = 1.0 - ((2 * inter + eps) / (p.sum((0, 2, 3)) + oh.sum((0, 2, 3)) + eps)).mean()
+    return ce + dice_weight * dice
+
+
+def wrap_ddp(model: nn.Module, device: Optional[torch.device] = None, bucket_cap_mb: int = 25) -> nn.Module:
+    """DistributedDataParallel over the default process group (gradient all-reduce bucketed and overlapped with the
+    backward).  xGMI is point-to-point, so buckets are kept large enough to amortise ring latency: the whole model is
+    ~16 MB of fp32 gradients, i.e. one or two buckets."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return model
+    ids = None if device is None or device.type != "cuda" else [device.index]
+    return nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb,
+                                               gradient_as_bucket_view=True)
+
+
+def train_step(model: nn.Module, opt: torch.optim.Optimizer, frames: torch.Tensor, target: torch.Tensor,
+               autocast_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """forward -> loss -> backward (HIP backward kernels; DDP all-reduce if wrapped) -> optimiser step."""
+    opt.zero_grad(set_to_none=True)
+    if autocast_dtype is not None:
+        with torch.autocast(frames.device.type, dtype=autocast_dtype):
+            logits = model(frames)
+    else:
+        logits = model(frames)
+    loss = segmentation_loss(logits, target)
+    loss.backward()
+    opt.step()
+    return loss.detach()

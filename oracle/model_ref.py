@@ -16,6 +16,11 @@ class GDKVMRef(GDKVM):
     math = "f32"          # arithmetic of the C oracle: "f32" (CPU-baseline speed) or "f64" (parity checks)
 
     def _memory_scan(self, q, k, v, alpha_logit, beta_logit, state):
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v, alpha_logit, beta_logit)):
+            from oracle import torch_ref                      # differentiable restatement: the gradient oracle
+            r, s = torch_ref.scan(q.double(), k.double(), v.double(), alpha_logit.double(), beta_logit.double(),
+                                  None if state is None else state.double(), _RULES[self.cfg.rule], 3)
+            return r.to(q.dtype), s.float()
         args = [t.detach().float().cpu().numpy() for t in (q, k, v, alpha_logit, beta_logit)]
         s0 = None if state is None else state.detach().float().cpu().numpy()
         r, s = c_oracle.scan(*args, s0, _RULES[self.cfg.rule], 3, math=self.math)
@@ -23,6 +28,9 @@ class GDKVMRef(GDKVM):
 
     def _fuse(self, local, glob, pixel, h, w):
         p = self.kpff
+        if torch.is_grad_enabled() and (pixel.requires_grad or p.wa.requires_grad):
+            from oracle import torch_ref
+            return torch_ref.kpff(*(t.double() for t in (local, glob, pixel, p.wa, p.ba, p.wl, p.wg)), h, w).to(pixel.dtype)
         f = c_oracle.kpff(*(t.detach().float().cpu().numpy() for t in (local, glob, pixel, p.wa, p.ba, p.wl, p.wg)),
                           h, w, math=self.math)
         return torch.from_numpy(f).to(pixel.dtype)

@@ -64,3 +64,65 @@ def test_two_rank_gloo_matches_single_process():
         p.join(60)
         assert p.exitcode == 0
     assert (got == want.numpy()).all()
+
+
+def test_two_rank_ddp_gradients_match_full_batch():
+    """Training shards clips too; the only exchange is DDP's gradient all-reduce.  With equal shards the averaged
+    gradients must equal the single-process gradients of the mean loss over the whole batch (BatchNorm in eval-style
+    statistics would differ per shard, so the tiny model is built without running-stat dependence: momentum-free check
+    is done on all non-BatchNorm-sensitive parameters via frozen BN)."""
+    from gdkvm_amd.model import GDKVMConfig
+    from gdkvm_amd.train import segmentation_loss
+    from oracle.model_ref import GDKVMRef
+    torch.manual_seed(1)
+    cfg = GDKVMConfig(widths=(16, 32, 64), pixel_dim=64, value_dim=32)
+    model = GDKVMRef(cfg).train()
+    for m in model.modules():                       # batch statistics depend on the shard: freeze BN for this identity
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    frames = torch.rand(2, 2, 3, 32, 32)
+    target = (torch.rand(2, 2, 32, 32) > 0.5).long()
+    # per-shard mean losses averaged == DDP semantics
+    g_sum = None
+    for lo in (0, 1):
+        model.zero_grad()
+        segmentation_loss(model(frames[lo:lo + 1]), target[lo:lo + 1]).backward()
+        g = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        g_sum = g if g_sum is None else {n: g_sum[n] + g[n] for n in g}
+    want = {n: v / 2 for n, v in g_sum.items()}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    state = model.state_dict()
+    procs = [ctx.Process(target=_ddp_worker_frozen, args=(r, 2, port, frames, target, state, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = out.get(timeout=300)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for n in want:
+        assert torch.allclose(torch.from_numpy(got[n]), want[n], atol=1e-6, rtol=1e-4), n
+
+
+def _ddp_worker_frozen(rank, world, port, frames, target, state, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from gdkvm_amd.distributed import init_from_env
+    from gdkvm_amd.model import GDKVMConfig
+    from gdkvm_amd.train import segmentation_loss, wrap_ddp
+    from oracle.model_ref import GDKVMRef
+    init_from_env("gloo")
+    model = GDKVMRef(GDKVMConfig(widths=(16, 32, 64), pixel_dim=64, value_dim=32)).train()
+    model.load_state_dict(state)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    ddp = wrap_ddp(model)
+    lo, hi = shard_range(frames.shape[0], world, rank)
+    segmentation_loss(ddp(frames[lo:hi]), target[lo:hi]).backward()
+    if rank == 0:
+        out.put({n: p.grad.numpy().copy() for n, p in model.named_parameters() if p.grad is not None})
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
