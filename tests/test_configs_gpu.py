@@ -1,0 +1,69 @@
+"""BASELINE.json configs[2] and configs[4] as parity cases (configs[1] is the bench workload, configs[3] the training
+bench; tests/test_scan_gpu.py covers configs[0]/[1] shapes)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import gdkvm_oracle as O
+from tests.util import make_scan_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def test_cfg3_camus_shape_scan_fp32_and_bf16(hip):
+    """configs[2]: 256x256 frames -> N = 256 tokens (the 16-tile kernels), T = 20.  fp32 against the oracle at 1e-4;
+    bf16 I/O against the oracle on the rounded inputs."""
+    B, T, N, Hh, Dk, Dv = 2, 20, 256, 1, 64, 64
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=2, normalized=False, logits=True, corr=0.6)
+    Ro, So = c_oracle.scan(q, k, v, a, b, None, 2, 3, math="f64")
+    R, S = hip.scan_fwd(_dev(q), _dev(k), _dev(v), _dev(a), _dev(b), flags=3)
+    assert np.abs(R.cpu().numpy() - Ro).max() <= 1e-4 and np.abs(S.cpu().numpy() - So).max() <= 1e-4
+    qb, kb, vb = (O.to_bf16_f32(x) for x in (q, k, v))
+    Rb, Sb = c_oracle.scan(qb, kb, vb, a, b, None, 2, 3, math="f64")
+    R16, S16 = hip.scan_fwd(_dev(q, torch.bfloat16), _dev(k, torch.bfloat16), _dev(v, torch.bfloat16), _dev(a), _dev(b), flags=3)
+    assert np.abs(S16.cpu().numpy() - Sb).max() <= 1e-4
+    assert np.all(np.abs(R16.float().cpu().numpy() - Rb) <= 1e-4 + np.abs(Rb) * 2.0 ** -8)
+
+
+def test_cfg3_camus_module_fp32_vs_bf16_dice(hip):
+    """configs[2] end to end: 4-class CAMUS-style head, 256x256, fp32 run vs bf16 run of the SAME GPU module -> Dice of
+    the two masks (the fp32 run itself is tied to the CPU reference in tests/test_model_gpu.py)."""
+    from gdkvm_amd import ops
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    torch.manual_seed(2)
+    model = GDKVM(GDKVMConfig(num_classes=4)).eval().cuda().to(memory_format=torch.channels_last)
+    frames = torch.rand(2, 5, 3, 256, 256, device="cuda")
+    with torch.no_grad():
+        lg = model(frames)
+        med = lg.float().flatten(3).median(-1).values.mean((0, 1))            # balance the random-init head
+        model.decoder.head.bias -= med
+        m32, _ = model.segment(frames)
+        m16, counts = model.fuse_for_inference().to(torch.bfloat16).segment(frames, target=m32)
+    assert len(torch.unique(m32)) >= 3, "degenerate mask"
+    dice = ops.dice_from_counts(counts.sum((0, 1))).cpu().numpy()
+    present = counts.sum((0, 1))[:, 2].cpu().numpy() > 500
+    assert (dice[present] >= 0.9).all(), dice
+
+
+def test_cfg5_long_clip_chunked_state_carry(hip):
+    """configs[4]: long clip at N = 256 processed as chunks of 32 frames with S carried as a tensor: bit-identical to
+    one call (T shortened to 128 frames to keep the GPU suite quick; the property is independent of T)."""
+    B, T, N, Hh, Dk, Dv = 2, 128, 256, 1, 64, 32
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=4, normalized=False, logits=True)
+    tq, tk, tv = (_dev(x, torch.bfloat16) for x in (q, k, v)); ta, tb = _dev(a), _dev(b)
+    R, S = hip.scan_fwd(tq, tk, tv, ta, tb, flags=3)
+    s, parts = None, []
+    for lo in range(0, T, 32):
+        r, s = hip.scan_fwd(*(x[:, lo:lo + 32].contiguous() for x in (tq, tk, tv, ta, tb)), s, flags=3)
+        parts.append(r)
+    assert torch.equal(torch.cat(parts, 1), R) and torch.equal(s, S)
+    # and the first chunk against the oracle outright
+    Ro, So = c_oracle.scan(*(O.to_bf16_f32(x[:, :8]) for x in (q, k, v)), a[:, :8], b[:, :8], None, 2, 3)
+    r8, s8 = hip.scan_fwd(*(x[:, :8].contiguous() for x in (tq, tk, tv, ta, tb)), flags=3)
+    assert np.abs(s8.cpu().numpy() - So).max() <= 1e-4
