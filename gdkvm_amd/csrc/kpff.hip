@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void kpff_kernel(KpffArgs a)
 // ---------------------------------------------------------------------------------------------------------
 // bf16 arm: same tiling, operands in bf16 on v_mfma_f32_16x16x32_bf16 (fp32 accumulate), 16x the fp32 MFMA rate.
 // The tile is staged as bf16 (72 KB -> two workgroups per CU), pooled in place (fp32 math, bf16 store), and the
-// weights are read as bf16 from a workspace copy made by kpff_pack_weights_kernel (rows [out][in], so a B
-// fragment = 8 consecutive k of one output channel = one 16-byte load).  Lane l = 16g + i:
+// weights are read as bf16 from a workspace copy made by kpff_pack_weights_kernel in MFMA-fragment order (a B
+// fragment = 8 consecutive k of one output channel = one 16-byte load, a wave's 64 fragments contiguous).  Lane l = 16g + i:
 //   A = X[row i][k 8g..8g+7],  B = W[col i][k 8g..8g+7],  C/D reg r = D[row 4g + r][col i].
 
 struct KpffBf16Args {
@@ -164,13 +164,23 @@ struct KpffBf16Args {
 
 constexpr int KPFF_PAD16 = 8;     // bf16 elements (16 B) of row padding
 
+// Weights are re-packed to bf16 in MFMA-fragment order: for output tile ot (16 channels) and k-step ks (32 inputs) the
+// 64 lanes' B fragments (lane 16g+i = W[16ot+i][32ks+8g .. +7]) are contiguous, so a wave's B load is one 1 KiB access.
+// (Reading the row-major matrix directly makes each wave-instruction touch 16 rows x 64 B: measured 9 B/clk/CU.)
 __global__ void kpff_pack_weights_kernel(const float* wa, const float* wl, const float* wg, bf16_t* dst,
-                                         size_t na, size_t nl, size_t ng)
+                                         int Cp, int Ck, int Cv)
 {
-    const size_t n = na + nl + ng;
+    const int Cin = Cp + Ck + Cv;
+    const size_t na = (size_t)2 * Cp * Cin, nl = (size_t)Cp * Ck, ng = (size_t)Cp * Cv, n = na + nl + ng;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float x = i < na ? wa[i] : (i < na + nl ? wl[i - na] : wg[i - na - nl]);
-        dst[i] = f32_to_bf16(x);
+        const float* src; int K; size_t e;
+        if (i < na) { src = wa; K = Cin; e = i; }
+        else if (i < na + nl) { src = wl; K = Ck; e = i - na; }
+        else { src = wg; K = Cv; e = i - na - nl; }
+        const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+        const size_t blk = e >> 9;                          // = ot * (K/32) + ks
+        const int KS = K / 32, ks = (int)(blk % KS), ot = (int)(blk / KS);
+        dst[i] = f32_to_bf16(src[(size_t)(16 * ot + (lane & 15)) * K + 32 * ks + 8 * (lane >> 4) + j]);
     }
 }
 
@@ -179,126 +189,191 @@ __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void kpff_bf16_kernel(KpffBf16Args a)
+// One software-pipelined pass of `n` k-steps (32 inputs each, starting at k-step ks0 of the LDS tile) against NS weight
+// streams in fragment order, for MT token tiles.  The WEIGHTS are the A operand and the tokens the B operand, so an
+// accumulator register holds D[channel 4g+r][token i]: a lane ends up with 4 consecutive channels of one token (8-byte
+// stores, one 8-byte LDS read for the residual) instead of one channel of 4 tokens (four 2-byte stores).  Weight
+// fragments are prefetched three k-steps ahead (L2 latency ~600-800 cycles vs ~130-400 cycles of MFMA per step); the
+// rotation is done with register copies, which only ever wait on the OLDEST fetch.
+template <int NS, int MT>
+__device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, int n, const bf16_t* w0, const bf16_t* w1,
+                                            f32x4 (&acc0)[MT], f32x4 (&acc1)[MT])
 {
-    extern __shared__ __attribute__((aligned(16))) bf16_t s_xb[];   // [KPFF_TM][Cin + PAD16]
+    if (n <= 0) return;
+    bf16x8 b0[4], b1[4];                                   // [0] = current, [1..3] = the next three k-steps
+#pragma unroll
+    for (int d = 1; d < 4; ++d) {
+        const size_t off = (size_t)min(d - 1, n - 1) * 512;
+        b0[d] = *reinterpret_cast<const bf16x8*>(w0 + off);
+        if constexpr (NS == 2) b1[d] = *reinterpret_cast<const bf16x8*>(w1 + off);
+    }
+    for (int i = 0; i < n; ++i) {
+        b0[0] = b0[1]; b0[1] = b0[2]; b0[2] = b0[3];
+        if constexpr (NS == 2) { b1[0] = b1[1]; b1[1] = b1[2]; b1[2] = b1[3]; }
+        const size_t off = (size_t)min(i + 3, n - 1) * 512;
+        b0[3] = *reinterpret_cast<const bf16x8*>(w0 + off);
+        if constexpr (NS == 2) b1[3] = *reinterpret_cast<const bf16x8*>(w1 + off);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xb + (size_t)mt * 16 * ld + 32 * (ks0 + i));
+            acc0[mt] = mfma_bf16(b0[0], xv, acc0[mt]);
+            if constexpr (NS == 2) acc1[mt] = mfma_bf16(b1[0], xv, acc1[mt]);
+        }
+    }
+}
+
+// NT = 64-token tiles per workgroup (4*NT waves).  NT = 2 halves the weight traffic per token: at 64 tokens per
+// workgroup the kernel sits at the L2 balance point (0.75 MB of weights per 64 tokens ~ 64 flop per L2 byte).
+template <int NT>
+__global__ __launch_bounds__(256 * NT, (NT == 1 ? 2 : 1)) void kpff_bf16_kernel(KpffBf16Args a, int total_tiles)
+{
+    constexpr int NTHR = 256 * NT, MT = 4 * NT, TMW = KPFF_TM * NT;
+    extern __shared__ __attribute__((aligned(16))) bf16_t s_xb[];   // [TMW][Cin + PAD16]
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Ck = a.Ck, Cv = a.Cv, Cp = a.Cp, Cin = Cp + Ck + Cv, ld = Cin + KPFF_PAD16;
-    const int f = blockIdx.x / a.tiles_per_frame, rt = blockIdx.x % a.tiles_per_frame;
     const int N = a.h * a.w, W = a.w;
-    const int row0 = rt * a.rows_per_tile;
-    const int nrows = min(a.rows_per_tile, a.h - row0);
-    const int n0 = row0 * W, ntok = nrows * W;
+    // sub-tile s of this workgroup = global tile NT*blockIdx.x + s  ->  (frame, row band)
+    int t_f[NT], t_n0[NT], t_ntok[NT], t_nrows[NT];
+#pragma unroll
+    for (int sb = 0; sb < NT; ++sb) {
+        const int tile = NT * blockIdx.x + sb;
+        const bool valid = tile < total_tiles;
+        const int f = valid ? tile / a.tiles_per_frame : 0, rt = valid ? tile % a.tiles_per_frame : 0;
+        const int row0 = rt * a.rows_per_tile;
+        t_nrows[sb] = valid ? min(a.rows_per_tile, a.h - row0) : 0;
+        t_f[sb] = f; t_n0[sb] = row0 * W; t_ntok[sb] = t_nrows[sb] * W;
+    }
 
-    // ---- stage [P ; L ; G] rows as they are (8 channels = 16 bytes per thread) ------------------------
+    // ---- stage [P ; L ; G] rows as they are (8 channels = 16 bytes per thread, 4 loads in flight) -----------
     {
-        const int q8 = Cin / 8;
-        for (int idx = tid; idx < KPFF_TM * q8; idx += 256) {
-            const int tok = idx / q8, c = (idx - tok * q8) * 8;
-            uint4 x = make_uint4(0u, 0u, 0u, 0u);
-            if (tok < ntok) {
-                const size_t row = (size_t)f * N + n0 + tok;
-                if (c < Cp) x = *reinterpret_cast<const uint4*>(a.P + row * Cp + c);
-                else if (c < Cp + Ck) x = *reinterpret_cast<const uint4*>(a.L + row * Ck + (c - Cp));
-                else x = *reinterpret_cast<const uint4*>(a.G + row * Cv + (c - Cp - Ck));
+        const int q8 = Cin / 8, total = TMW * q8;
+        for (int base = tid; base < total; base += 4 * NTHR) {
+            uint4 x[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * NTHR;
+                const int trow = idx / q8, c = (idx - trow * q8) * 8;
+                const int sb = trow >> 6, tok = trow & 63;
+                dst[u] = idx < total ? trow * ld + c : -1;
+                x[u] = make_uint4(0u, 0u, 0u, 0u);
+                if (idx < total && tok < t_ntok[sb < NT ? sb : 0]) {
+                    const size_t row = (size_t)t_f[sb] * N + t_n0[sb] + tok;
+                    const bf16_t* src = c < Cp ? a.P + row * Cp + c : (c < Cp + Ck ? a.L + row * Ck + (c - Cp) : a.G + row * Cv + (c - Cp - Ck));
+                    x[u] = *reinterpret_cast<const uint4*>(src);
+                }
             }
-            *reinterpret_cast<uint4*>(s_xb + (size_t)tok * ld + c) = x;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u] >= 0) *reinterpret_cast<uint4*>(s_xb + dst[u]) = x[u];
         }
     }
     __syncthreads();
-    // ---- multi-scale pooling of G in place: one thread per (4x4 cell, channel pair) -------------------
-    {
+#ifndef KPFF_SKIP_POOL
+    // ---- multi-scale pooling of G in place: one thread per (4x4 cell, channel pair); the cell is read with 16
+    //      independent predicated LDS loads (a runtime-bounded loop serialises on the ~100-cycle LDS latency)
+#pragma unroll
+    for (int sb = 0; sb < NT; ++sb) {
+        const int nrows = t_nrows[sb];
         const int cw = (W + 3) / 4, chh = (nrows + 3) / 4, cv2 = Cv / 2;
-        bf16_t* gx = s_xb + Cp + Ck;
-        for (int idx = tid; idx < cw * chh * cv2; idx += 256) {
-            const int c = (idx % cv2) * 2, cell = idx / cv2;
-            const int y0 = (cell / cw) * 4, x0 = (cell % cw) * 4;
-            const int y1 = min(y0 + 4, nrows), x1 = min(x0 + 4, W);
-            float s4[2] = {0.f, 0.f}, s2[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-            int n2[4] = {0, 0, 0, 0};
-            for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) {
-                    const unsigned u = *reinterpret_cast<const unsigned*>(gx + (size_t)(y * W + x) * ld + c);
-                    const float v0 = __uint_as_float(u << 16), v1 = __uint_as_float(u & 0xffff0000u);
-                    const int q = ((y - y0) >> 1) * 2 + ((x - x0) >> 1);
-                    s2[q][0] += v0; s2[q][1] += v1; n2[q] += 1; s4[0] += v0; s4[1] += v1;
-                }
-            const float i4 = 1.0f / (float)((y1 - y0) * (x1 - x0));
-            for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) {
-                    const int q = ((y - y0) >> 1) * 2 + ((x - x0) >> 1);
-                    unsigned* p = reinterpret_cast<unsigned*>(gx + (size_t)(y * W + x) * ld + c);
-                    const unsigned u = *p;
-                    const float i2 = 1.0f / (float)n2[q];
-                    const float r0 = (__uint_as_float(u << 16) + s2[q][0] * i2 + s4[0] * i4) * (1.0f / 3.0f);
-                    const float r1 = (__uint_as_float(u & 0xffff0000u) + s2[q][1] * i2 + s4[1] * i4) * (1.0f / 3.0f);
-                    *p = (unsigned)f32_to_bf16(r0) | ((unsigned)f32_to_bf16(r1) << 16);
-                }
+        bf16_t* gx = s_xb + (size_t)sb * 64 * ld + Cp + Ck;
+        for (int idx = tid; idx < cw * chh * cv2; idx += NTHR) {
+            const int cell = idx / cv2, c = (idx - cell * cv2) * 2;
+            const int cy = cell / cw, y0 = cy * 4, x0 = (cell - cy * cw) * 4;
+            unsigned u[16];
+            bool ok[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int y = y0 + (p >> 2), x = x0 + (p & 3);
+                ok[p] = y < nrows && x < W;
+                u[p] = ok[p] ? *reinterpret_cast<const unsigned*>(gx + (size_t)(y * W + x) * ld + c) : 0u;
+            }
+            float s2[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, s4[2] = {0.f, 0.f};
+            float n2[4] = {0.f, 0.f, 0.f, 0.f}, n4 = 0.f;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int q = ((p >> 3) << 1) | ((p >> 1) & 1);
+                const float v0 = __uint_as_float(u[p] << 16), v1 = __uint_as_float(u[p] & 0xffff0000u), m = ok[p] ? 1.f : 0.f;
+                s2[q][0] += v0; s2[q][1] += v1; n2[q] += m; s4[0] += v0; s4[1] += v1; n4 += m;
+            }
+            const float i4 = 1.0f / n4;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int q = ((p >> 3) << 1) | ((p >> 1) & 1);
+                const float i2 = 1.0f / fmaxf(n2[q], 1.f);
+                const float r0 = (__uint_as_float(u[p] << 16) + s2[q][0] * i2 + s4[0] * i4) * (1.0f / 3.0f);
+                const float r1 = (__uint_as_float(u[p] & 0xffff0000u) + s2[q][1] * i2 + s4[1] * i4) * (1.0f / 3.0f);
+                const int y = y0 + (p >> 2), x = x0 + (p & 3);
+                if (ok[p]) *reinterpret_cast<unsigned*>(gx + (size_t)(y * W + x) * ld + c) = (unsigned)f32_to_bf16(r0) | ((unsigned)f32_to_bf16(r1) << 16);
+            }
         }
     }
+#endif
     __syncthreads();
     if (a.sv.gms) {                                            // training: keep the pooled feature for the backward
         bf16_t* gms = static_cast<bf16_t*>(a.sv.gms);
-        for (int idx = tid; idx < ntok * Cv; idx += 256) {
-            const int tok = idx / Cv, c = idx - tok * Cv;
-            gms[((size_t)f * N + n0 + tok) * Cv + c] = s_xb[(size_t)tok * ld + Cp + Ck + c];
-        }
+#pragma unroll
+        for (int sb = 0; sb < NT; ++sb)
+            for (int idx = tid; idx < t_ntok[sb] * Cv; idx += NTHR) {
+                const int tok = idx / Cv, c = idx - tok * Cv;
+                gms[((size_t)t_f[sb] * N + t_n0[sb] + tok) * Cv + c] = s_xb[(size_t)(sb * 64 + tok) * ld + Cp + Ck + c];
+            }
     }
 
-    // ---- fused channel mixes: wave owns output channels o = 64*chunk + 16*wave + li -----------------
-    const int ksP = Cp / 32, ksL = Ck / 32, ksG = Cv / 32;
-    for (int chunk = 0; chunk * 64 < Cp; ++chunk) {
-        const int ob = chunk * 64 + 16 * w_id;            // wave-uniform
-        if (ob >= Cp) break;
-        const int o = ob + li;
-        f32x4 gl[4], gg[4], lp[4], gp[4];
+    // ---- fused channel mixes: wave owns output channels 16*(4*NT*chunk + wave) .. +15 for all TMW tokens ------
+    const int ksP = Cp / 32, ksL = Ck / 32, KSa = Cin / 32;
+    for (int ob = 16 * w_id; ob < Cp; ob += 64 * NT) {
+        f32x4 gl[MT], gg[MT], lp[MT], gp[MT];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) gl[mt] = gg[mt] = lp[mt] = gp[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bf16_t* wal = a.wa + (size_t)o * Cin + 8 * g;
-        const bf16_t* wag = a.wa + (size_t)(Cp + o) * Cin + 8 * g;
-        const bf16_t* xa = s_xb + (size_t)li * ld + 8 * g;
-
-        auto step = [&](int ks, const bf16_t* wmix, f32x4* mix) {
-            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wal + 32 * ks);
-            const bf16x8 bg = *reinterpret_cast<const bf16x8*>(wag + 32 * ks);
-            bf16x8 bm = {};
-            if (wmix) bm = *reinterpret_cast<const bf16x8*>(wmix);
+        for (int mt = 0; mt < MT; ++mt) gl[mt] = gg[mt] = lp[mt] = gp[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bf16_t* xb = s_xb + (size_t)li * ld + 8 * g;             // B fragment: token 16mt+li, k 8g..8g+7
+#ifndef KPFF_SKIP_GEMM
+        // fragment-order packs: k-step ks of output tile ot lives at ((ot*KS + ks)*64 + lane)*8
+        kpff_stream<2, MT>(xb, ld, 0, KSa, a.wa + ((size_t)(ob / 16) * KSa * 64 + lane) * 8,
+                           a.wa + ((size_t)((Cp + ob) / 16) * KSa * 64 + lane) * 8, gl, gg);                        // gates
+        kpff_stream<1, MT>(xb, ld, ksP, ksL, a.wl + ((size_t)(ob / 16) * ksL * 64 + lane) * 8, nullptr, lp, lp);    // L Wl^T
+        kpff_stream<1, MT>(xb, ld, ksP + ksL, Cv / 32, a.wg + ((size_t)(ob / 16) * (Cv / 32) * 64 + lane) * 8, nullptr, gp, gp);
+#else
+        gl[0][0] = xb[0]; (void)ksP; (void)ksL; (void)KSa;
+#endif
+        // epilogue: this lane holds channels oc..oc+3 of token 16mt+li for every token tile mt
+        const int oc = ob + 4 * g;
+        const f32x4 bl4 = *reinterpret_cast<const f32x4*>(a.ba + oc), bg4 = *reinterpret_cast<const f32x4*>(a.ba + Cp + oc);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const bf16x8 av = *reinterpret_cast<const bf16x8*>(xa + (size_t)mt * 16 * ld + 32 * ks);
-                gl[mt] = mfma_bf16(av, bl, gl[mt]);
-                gg[mt] = mfma_bf16(av, bg, gg[mt]);
-                if (wmix) mix[mt] = mfma_bf16(av, bm, mix[mt]);
-            }
-        };
-#pragma unroll 2
-        for (int ks = 0; ks < ksP; ++ks) step(ks, nullptr, nullptr);
-        for (int ks = 0; ks < ksL; ++ks) step(ksP + ks, a.wl + (size_t)o * Ck + 32 * ks + 8 * g, lp);
-#pragma unroll 2
-        for (int ks = 0; ks < ksG; ++ks) step(ksP + ksL + ks, a.wg + (size_t)o * Cv + 32 * ks + 8 * g, gp);
-
-        const float bl = a.ba[o], bg = a.ba[Cp + o];
+        for (int mt = 0; mt < MT; ++mt) {
+            const int trow = 16 * mt + li, sb = trow >> 6, tok = trow & 63;
+#ifdef KPFF_SKIP_EPI
+            if (tok < t_ntok[sb] && gl[mt][0] == 123.f) {
+#else
+            if (tok < t_ntok[sb]) {
+#endif
+                const uint2 pu = *reinterpret_cast<const uint2*>(s_xb + (size_t)trow * ld + oc);
+                const float pv[4] = {__uint_as_float(pu.x << 16), __uint_as_float(pu.x & 0xffff0000u),
+                                     __uint_as_float(pu.y << 16), __uint_as_float(pu.y & 0xffff0000u)};
+                float y[4], sl[4], sg[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int tok = 16 * mt + 4 * g + r;
-                if (tok < ntok) {
-                    const float sl = 1.0f / (1.0f + __expf(-(gl[mt][r] + bl)));
-                    const float sg = 1.0f / (1.0f + __expf(-(gg[mt][r] + bg)));
-                    const float y = bf16_to_f32(s_xb[(size_t)tok * ld + o]) + sl * lp[mt][r] + sg * gp[mt][r];
-                    const size_t grow = (size_t)f * N + n0 + tok;
-                    a.out[grow * Cp + o] = f32_to_bf16(y);
-                    if (a.sv.gates) {
-                        bf16_t* sg_ = static_cast<bf16_t*>(a.sv.gates);
-                        sg_[grow * 2 * Cp + o] = f32_to_bf16(sl);
-                        sg_[grow * 2 * Cp + Cp + o] = f32_to_bf16(sg);
-                        static_cast<bf16_t*>(a.sv.lp)[grow * Cp + o] = f32_to_bf16(lp[mt][r]);
-                        static_cast<bf16_t*>(a.sv.gp)[grow * Cp + o] = f32_to_bf16(gp[mt][r]);
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    sl[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (gl[mt][r] + bl4[r])));
+                    sg[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (gg[mt][r] + bg4[r])));
+                    y[r] = pv[r] + sl[r] * lp[mt][r] + sg[r] * gp[mt][r];
+                }
+                auto pack4 = [](const float (&v)[4]) {
+                    return make_uint2((unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16),
+                                      (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16));
+                };
+                const size_t grow = (size_t)t_f[sb] * N + t_n0[sb] + tok;
+                *reinterpret_cast<uint2*>(a.out + grow * Cp + oc) = pack4(y);
+                if (a.sv.gates) {
+                    bf16_t* sg_ = static_cast<bf16_t*>(a.sv.gates);
+                    const float lpv[4] = {lp[mt][0], lp[mt][1], lp[mt][2], lp[mt][3]}, gpv[4] = {gp[mt][0], gp[mt][1], gp[mt][2], gp[mt][3]};
+                    *reinterpret_cast<uint2*>(sg_ + grow * 2 * Cp + oc) = pack4(sl);
+                    *reinterpret_cast<uint2*>(sg_ + grow * 2 * Cp + Cp + oc) = pack4(sg);
+                    *reinterpret_cast<uint2*>(static_cast<bf16_t*>(a.sv.lp) + grow * Cp + oc) = pack4(lpv);
+                    *reinterpret_cast<uint2*>(static_cast<bf16_t*>(a.sv.gp) + grow * Cp + oc) = pack4(gpv);
                 }
             }
+        }
     }
 }
 
@@ -411,20 +486,24 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
         const size_t need = gdkvm_kpff_workspace_bytes(Ck, Cv, Cp, io_dtype) - 16;
         if (!workspace || !gdkvm_aligned16(workspace)) return gdkvm_fail(GDKVM_ERR_ARG, "kpff_fwd: workspace null or misaligned");
         if (workspace_bytes < need) return gdkvm_fail(GDKVM_ERR_WORKSPACE, "kpff_fwd: workspace %zu < %zu bytes", workspace_bytes, need + 16);
-        const size_t lds = (size_t)KPFF_TM * (Cin + KPFF_PAD16) * sizeof(bf16_t);
-        if (lds > 160 * 1024) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: Cp+Ck+Cv=%d exceeds the LDS tile", Cin);
+        const size_t lds1 = (size_t)KPFF_TM * (Cin + KPFF_PAD16) * sizeof(bf16_t);
+        if (lds1 > 160 * 1024) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: Cp+Ck+Cv=%d exceeds the LDS tile", Cin);
+        const int total_tiles = BT * tiles;
+        const bool pair = 2 * lds1 <= 160 * 1024 && total_tiles >= 2;     // two 64-token tiles per 8-wave workgroup
         bf16_t* wab = static_cast<bf16_t*>(workspace);
         const size_t na = (size_t)2 * Cp * Cin, nl = (size_t)Cp * Ck, ng = (size_t)Cp * Cv;
-        hipLaunchKernelGGL(kpff_pack_weights_kernel, dim3(256), dim3(256), 0, st, wa, wl, wg, wab, na, nl, ng);
+        hipLaunchKernelGGL(kpff_pack_weights_kernel, dim3(256), dim3(256), 0, st, wa, wl, wg, wab, Cp, Ck, Cv);
         GDKVM_LAUNCH_CHECK("kpff_pack_weights_kernel");
         KpffBf16Args b{static_cast<const bf16_t*>(local), static_cast<const bf16_t*>(global), static_cast<const bf16_t*>(pixel),
                        wab, ba, wab + na, wab + na + nl, static_cast<bf16_t*>(out), Ck, Cv, Cp, h, w, rows, tiles, sv};
+        const size_t lds = pair ? 2 * lds1 : lds1;
+        const void* fn = pair ? reinterpret_cast<const void*>(kpff_bf16_kernel<2>) : reinterpret_cast<const void*>(kpff_bf16_kernel<1>);
         if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kpff_bf16_kernel),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "kpff_fwd: LDS attribute: %s", hipGetErrorString(e));
         }
-        hipLaunchKernelGGL(kpff_bf16_kernel, grid, dim3(256), lds, st, b);
+        if (pair) hipLaunchKernelGGL(kpff_bf16_kernel<2>, dim3((unsigned)((total_tiles + 1) / 2)), dim3(512), lds, st, b, total_tiles);
+        else hipLaunchKernelGGL(kpff_bf16_kernel<1>, dim3((unsigned)total_tiles), dim3(256), lds, st, b, total_tiles);
         GDKVM_LAUNCH_CHECK("kpff_bf16_kernel");
         return GDKVM_OK;
     }
