@@ -440,15 +440,12 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
             __syncthreads();                               // (1) U complete / this wave is done reading S_{t-1}
             __syncthreads();                               // (2) S_t published
         };
-        for (int t0 = 0; t0 < T; t0 += UF) {
-            bool done = false;
-            static_for<0, UF>([&](auto fc) {
-                if (!done) {
-                    if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, fc);
-                    else done = true;
-                }
-            });
-        }
+        int t0 = 0;
+        for (; t0 + UF <= T; t0 += UF)                     // full groups: a straight-line body, no CFG merge inside
+            static_for<0, UF>([&](auto fc) { frame(t0 + decltype(fc)::value, fc); });
+        static_for<0, UF - 1>([&](auto fc) {               // tail: the last T % UF frames
+            if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, fc);
+        });
         return;
     }
 
@@ -461,6 +458,8 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
     const float* kn_lane = a.knT + fh0 * GDKVM_DK * NP + (size_t)(16 * w + li) * NP + 4 * g;
     const size_t kn_fstride = (size_t)Hh * GDKVM_DK * NP;
     const float* al_ptr = a.alpha + fh0;
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));       // opaque per-lane zero: keeps the alpha prefetch off the SMEM path
 
     auto load_x = [&](int item, XItem& d) {              // item = t*JT + j  -> token tile tt = w + 4j of frame t
         item = min(item, last_item);
@@ -469,8 +468,8 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
 #pragma unroll
         for (int m = 0; m < 4; ++m) d.w[m] = *reinterpret_cast<const f32x4*>(wt + 16 * m);
         d.u = ut_lane[t * ut_fstride + tt * 64];
-        d.alpha = al_ptr[(size_t)t * Hh];
-    };
+        d.alpha = al_ptr[(size_t)t * Hh + vzero];       // VECTOR load on purpose: a scalar load shares lgkmcnt with the
+    };                                                   // LDS reads, whose lgkmcnt(0) would then wait ~1 us for it
     auto load_k = [&](int item, KItem& d) {              // item = t*NG + gi -> token tiles 4gi..4gi+3 of frame t
         item = min(item, last_item);
         const int t = item / NG, gi = item - t * NG;
@@ -486,32 +485,52 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
 
     auto x_item = [&](int t, int j, const XItem& cur, XItem& nxt, const f32x4 (&sreg)[4], float& alpha) {
         const int tt = w + 4 * j;
+        load_x(t * JT + j + DEPTH, nxt);                 // issued first so its address math and loads can sit in MFMA gaps
         alpha = gate_logits ? fast_sigmoid(cur.alpha) : cur.alpha;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        // alternate the two accumulation chains on every instruction: a dependent 16x16x4 MFMA needs 40 cycles,
+        // an independent one issues after 32
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int m = 0; m < 4; ++m) {
                 if (m & 1) acc1 = mfma4(cur.w[m][r], sreg[m][r], acc1);
                 else acc0 = mfma4(cur.w[m][r], sreg[m][r], acc0);
             }
+#ifdef GDKVM_SCHED
+        // an MFMA holds the issue port for 8 of its 32 cycles: put the independent prefetch work into the gaps
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);     // up to 3 VALU/SALU
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // up to 1 VMEM read
+        }
+#endif
         f32x4 u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) u[r] = cur.u[r] - alpha * (acc0[r] + acc1[r]);
         s_U[tt * 64 + lane] = u;
-        load_x(t * JT + j + DEPTH, nxt);
     };
     auto k_item = [&](int t, int gi, const KItem& cur, KItem& nxt, f32x4& acc0, f32x4& acc1) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 ub = s_U[(4 * gi + j) * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (j & 1) acc1 = mfma4(cur.k[j][r], ub[r], acc1);
-                else acc0 = mfma4(cur.k[j][r], ub[r], acc0);
-            }
-        }
         load_k(t * NG + gi + DEPTH, nxt);
+        f32x4 ub[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ub[j] = s_U[(4 * gi + j) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j & 1) acc1 = mfma4(cur.k[j][r], ub[j][r], acc1);
+                else acc0 = mfma4(cur.k[j][r], ub[j][r], acc0);
+            }
+#ifdef GDKVM_SCHED
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+#endif
     };
     auto frame = [&](int t, auto fc) {
         constexpr int F = decltype(fc)::value;
@@ -543,15 +562,12 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
         __syncthreads();
         DIAG_STAMP(4);
     };
-    for (int t0 = 0; t0 < T; t0 += UF) {
-        bool done = false;
-        static_for<0, UF>([&](auto fc) {
-            if (!done) {
-                if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, fc);
-                else done = true;
-            }
-        });
-    }
+    int t0 = 0;
+    for (; t0 + UF <= T; t0 += UF)                         // full groups: a straight-line body, no CFG merge inside
+        static_for<0, UF>([&](auto fc) { frame(t0 + decltype(fc)::value, fc); });
+    static_for<0, UF - 1>([&](auto fc) {                   // tail: the last T % UF frames
+        if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, fc);
+    });
     if (a.s_out) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) a.s_out[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li] = sacc[r];

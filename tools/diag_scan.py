@@ -46,6 +46,8 @@ def main():
     print("s_memtime ticks per frame (median over frames 2..T-1), block 0 wave 0; 1 tick = 1 shader cycle")
     for i, n in enumerate(names):
         print(f"  {n:48s} {seg[2:, i].median().item():8.0f}")
+    print("  per-frame totals:", [int(x) for x in (d[:, 4] - d[:, 0]).tolist()])
+    print("  gaps between frames:", [int(x) for x in (d[1:, 0] - d[:-1, 4]).tolist()])
     print(f"  frame total {(d[2:, 4] - d[2:, 0]).float().median().item():.0f}; whole scan {(d[-1, 4] - d[0, 0]).item()} ticks")
 
 
