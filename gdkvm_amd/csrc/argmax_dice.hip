@@ -86,6 +86,75 @@ __global__ __launch_bounds__(256) void argmax_dice_kernel(AdArgs a)
     }
 }
 
+
+// Fused form: bilinear upsampling (align_corners = false, PyTorch's formula) of low-resolution logits + argmax + Dice.
+// The full-resolution logits are never written: per frame 2*hl*wl*ncls bytes are read (L2-resident, re-read per
+// output row) and H*W mask bytes written.  Arithmetic is fp32 with explicitly un-fused multiplies and adds
+// (__fmul_rn/__fadd_rn), so the result is bit-identical to the scalar oracle and near-ties resolve the same way.
+struct UpArgs {
+    const void* logits; const uint8_t* target; uint8_t* mask; int32_t* counts;
+    int ncls, hl, wl, H, W;
+    float sy, sx;
+};
+
+__device__ __forceinline__ float up_src(float scale, int dst)
+{
+    const float s = __fsub_rn(__fmul_rn(scale, __fadd_rn((float)dst, 0.5f)), 0.5f);
+    return s < 0.f ? 0.f : s;
+}
+
+template <int IO>
+__global__ __launch_bounds__(256) void upsample_argmax_dice_kernel(UpArgs a)
+{
+    extern __shared__ int s_cnt[];                       // [ncls][3]
+    const int f = blockIdx.y, ncls = a.ncls, HW = a.H * a.W, hw = a.hl * a.wl;
+    const bool dice = a.target != nullptr;
+    if (dice) {
+        for (int i = threadIdx.x; i < ncls * 3; i += 256) s_cnt[i] = 0;
+        __syncthreads();
+    }
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < ((HW + 255) / 256) * 256; p += gridDim.x * 256) {
+        const bool act = p < HW;
+        int arg = 0;
+        if (act) {
+            const int y = p / a.W, x = p - y * a.W;
+            const float fy = up_src(a.sy, y), fx = up_src(a.sx, x);
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = min(y0 + 1, a.hl - 1), x1 = min(x0 + 1, a.wl - 1);
+            const float ly = __fsub_rn(fy, (float)y0), lx = __fsub_rn(fx, (float)x0);
+            const float hy = __fsub_rn(1.0f, ly), hx = __fsub_rn(1.0f, lx);
+            float best = 0.f;
+            for (int c = 0; c < ncls; ++c) {
+                const size_t base = ((size_t)f * ncls + c) * hw;
+                const float v00 = load1<IO>(a.logits, base + y0 * a.wl + x0), v01 = load1<IO>(a.logits, base + y0 * a.wl + x1);
+                const float v10 = load1<IO>(a.logits, base + y1 * a.wl + x0), v11 = load1<IO>(a.logits, base + y1 * a.wl + x1);
+                const float top = __fadd_rn(__fmul_rn(hx, v00), __fmul_rn(lx, v01));
+                const float bot = __fadd_rn(__fmul_rn(hx, v10), __fmul_rn(lx, v11));
+                const float v = __fadd_rn(__fmul_rn(hy, top), __fmul_rn(ly, bot));
+                if (c == 0 || v > best) { best = v; arg = c; }
+            }
+            a.mask[(size_t)f * HW + p] = (uint8_t)arg;
+        }
+        if (dice) {
+            const int tc = act ? a.target[(size_t)f * HW + p] : -1;
+            for (int c = 0; c < ncls; ++c) {
+                const unsigned long long mp = __ballot(act && arg == c), mt = __ballot(tc == c);
+                if ((threadIdx.x & 63) == 0 && (mp | mt)) {
+                    const int ni = __popcll(mp & mt), np = __popcll(mp), nt = __popcll(mt);
+                    if (ni) atomicAdd(&s_cnt[c * 3 + 0], ni);
+                    if (np) atomicAdd(&s_cnt[c * 3 + 1], np);
+                    if (nt) atomicAdd(&s_cnt[c * 3 + 2], nt);
+                }
+            }
+        }
+    }
+    if (dice) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < ncls * 3; i += 256)
+            if (s_cnt[i]) atomicAdd(&a.counts[(size_t)f * ncls * 3 + i], s_cnt[i]);
+    }
+}
+
 }  // namespace
 
 extern "C" int gdkvm_argmax_dice(const void* logits, const uint8_t* target, uint8_t* mask, int32_t* counts,
@@ -123,5 +192,34 @@ extern "C" int gdkvm_argmax_dice(const void* logits, const uint8_t* target, uint
         else hipLaunchKernelGGL((argmax_dice_kernel<GDKVM_BF16, 1>), grid, dim3(256), lds, st, a);
     }
     GDKVM_LAUNCH_CHECK("argmax_dice_kernel");
+    return GDKVM_OK;
+}
+
+extern "C" int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* target, uint8_t* mask, int32_t* counts,
+                                          int BT, int ncls, int hl, int wl, int H, int W, int io_dtype, void* stream)
+{
+    if (BT < 0 || ncls <= 0 || ncls > 255 || hl <= 0 || wl <= 0 || H <= 0 || W <= 0)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_argmax_dice: bad shape BT=%d ncls=%d %dx%d -> %dx%d", BT, ncls, hl, wl, H, W);
+    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "upsample_argmax_dice: io_dtype=%d", io_dtype);
+    if (BT == 0) return GDKVM_OK;
+    if (!logits || !mask) return gdkvm_fail(GDKVM_ERR_ARG, "upsample_argmax_dice: null pointer");
+    if (target && !counts) return gdkvm_fail(GDKVM_ERR_ARG, "upsample_argmax_dice: counts required with a target");
+    if (!gdkvm_aligned16(logits) || !gdkvm_aligned16(mask) || (target && !gdkvm_aligned16(target)) || (counts && !gdkvm_aligned16(counts)))
+        return gdkvm_fail(GDKVM_ERR_ARG, "upsample_argmax_dice: pointers must be 16-byte aligned");
+    if ((size_t)H * W > 0x7fffffffu / 2) return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_argmax_dice: image too large");
+    if (int rc = gdkvm_check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (target) {
+        hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)BT * ncls * 3, st);
+        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "upsample_argmax_dice: memset: %s", hipGetErrorString(e));
+    }
+    UpArgs a{logits, target, mask, counts, ncls, hl, wl, H, W, (float)hl / (float)H, (float)wl / (float)W};
+    int gx = (H * W + 255) / 256;
+    if (gx > 64) gx = 64;
+    const dim3 grid((unsigned)gx, (unsigned)BT);
+    const size_t lds = sizeof(int) * (size_t)ncls * 3;
+    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((upsample_argmax_dice_kernel<GDKVM_F32>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((upsample_argmax_dice_kernel<GDKVM_BF16>), grid, dim3(256), lds, st, a);
+    GDKVM_LAUNCH_CHECK("upsample_argmax_dice_kernel");
     return GDKVM_OK;
 }

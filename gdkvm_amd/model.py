@@ -101,8 +101,10 @@ class Decoder(nn.Module):
         self.head = nn.Conv2d(w4, ncls, 1)
 
     def forward(self, f, f8, f4, size):
+        """size = (H, W): full-resolution logits; size = None: the stride-4 logits (segment() upsamples them inside
+        the fused argmax kernel instead of materialising them)."""
         x = self.head(self.up4(self.up8(f, f8), f4))
-        return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+        return x if size is None else F.interpolate(x, size=size, mode="bilinear", align_corners=False)
 
 
 def _fold_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d) -> nn.Conv2d:
@@ -188,7 +190,7 @@ class GDKVM(nn.Module):
         return x.permute(0, 2, 3, 1).reshape(x.shape[0], x.shape[2] * x.shape[3], x.shape[1]).contiguous()
 
     def forward(self, frames: torch.Tensor, mask0: Optional[torch.Tensor] = None,
-                state: Optional[torch.Tensor] = None, return_state: bool = False):
+                state: Optional[torch.Tensor] = None, return_state: bool = False, _lowres: bool = False):
         if frames.dim() != 5:
             raise ValueError("frames must be [B,T,C,H,W]")
         cfg = self.cfg
@@ -217,7 +219,8 @@ class GDKVM(nn.Module):
         p_tok = self._tokens(f16)
         fused = self._fuse(k_tok, r.reshape(B * T, N, Hh * Dv), p_tok, h, w)       # [BT,N,Cp]
         fmap = fused.reshape(B * T, h, w, -1).permute(0, 3, 1, 2)                  # channels_last view, no copy
-        logits = self.decoder(fmap, f8, f4, (H, W)).reshape(B, T, cfg.num_classes, H, W)
+        logits = self.decoder(fmap, f8, f4, None if _lowres else (H, W))
+        logits = logits.reshape(B, T, cfg.num_classes, *logits.shape[-2:])
         return (logits, s_out) if return_state else logits
 
     @torch.no_grad()
@@ -241,10 +244,11 @@ class GDKVM(nn.Module):
     @torch.no_grad()
     def segment(self, frames, target=None, **kw):
         """logits -> (mask uint8 [B,T,H,W], Dice counts int32 [B,T,ncls,3] | None) with the HIP argmax kernel."""
-        logits = self.forward(frames, **kw)
-        B, T, ncls, H, W = logits.shape
+        B, T, _, H, W = frames.shape
+        lowres = self.forward(frames, _lowres=True, **kw)                     # [B,T,ncls,H/4,W/4]
+        ncls, hl, wl = lowres.shape[2:]
         tgt = None if target is None else target.reshape(B * T, H, W).contiguous()
-        mask, counts = ops.argmax_dice(logits.reshape(B * T, ncls, H, W).contiguous(), tgt)
+        mask, counts = ops.upsample_argmax_dice(lowres.reshape(B * T, ncls, hl, wl).contiguous(), H, W, tgt)
         return mask.reshape(B, T, H, W), (None if counts is None else counts.reshape(B, T, ncls, 3))
 
     # -------------------------------------------------------------------------------------- checkpoints

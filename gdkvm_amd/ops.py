@@ -37,6 +37,7 @@ SIGNATURES = {
     "gdkvm_kpff_bwd_pre": (_i, [_vp] * 7 + [_i] * 4 + [_vp]),
     "gdkvm_kpff_bwd_post": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
+    "gdkvm_upsample_argmax_dice": (_i, [_vp] * 4 + [_i] * 7 + [_vp]),
 }
 
 
@@ -333,6 +334,23 @@ def argmax_dice(logits: torch.Tensor, target: Optional[torch.Tensor] = None):
         rc = lib.gdkvm_argmax_dice(_ptr(logits), _ptr(target), _ptr(mask), _ptr(counts), BT, ncls, H, W,
                                    _io_dtype(logits), _stream(dev))
     _check(rc, "gdkvm_argmax_dice")
+    return mask, counts
+
+
+def upsample_argmax_dice(logits: torch.Tensor, H: int, W: int, target: Optional[torch.Tensor] = None):
+    """Fused bilinear upsample (align_corners=False) + argmax + Dice counts (gdkvm_upsample_argmax_dice).
+    logits [BT,ncls,hl,wl] low-resolution; returns (mask u8 [BT,H,W], counts i32 [BT,ncls,3] | None)."""
+    lib = load()
+    BT, ncls, hl, wl = logits.shape
+    dev = _dev(logits, target)
+    if target is not None and (target.dtype != torch.uint8 or tuple(target.shape) != (BT, H, W)):
+        raise GdkvmError("target must be uint8 [BT,H,W]")
+    mask = torch.empty((BT, H, W), dtype=torch.uint8, device=dev)
+    counts = torch.empty((BT, ncls, 3), dtype=torch.int32, device=dev) if target is not None else None
+    with torch.cuda.device(dev):
+        rc = lib.gdkvm_upsample_argmax_dice(_ptr(logits), _ptr(target), _ptr(mask), _ptr(counts), BT, ncls, hl, wl, H, W,
+                                            _io_dtype(logits), _stream(dev))
+    _check(rc, "gdkvm_upsample_argmax_dice")
     return mask, counts
 
 

@@ -136,6 +136,12 @@ int gdkvm_kpff_bwd_post(const void* d_out, const void* d_x, const void* d_l_add,
 int gdkvm_argmax_dice(const void* logits, const uint8_t* target, uint8_t* mask, int32_t* counts,
                       int BT, int ncls, int H, int W, int io_dtype, void* stream);
 
+/* Row a6, fused with the decoder's last step: logits [BT, ncls, hl, wl] at low resolution are upsampled bilinearly
+ * (align_corners = false, PyTorch's formula, fp32 without fused multiply-add) to H x W inside the kernel and reduced to
+ * the argmax mask / Dice counts directly; the full-resolution logits are never materialised. */
+int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* target, uint8_t* mask, int32_t* counts,
+                               int BT, int ncls, int hl, int wl, int H, int W, int io_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,8 @@ def lib():
             fn.argtypes = [_f] * 7 + [_f] + [ctypes.c_int] * 6
         _lib.gdkvm_oracle_argmax_dice.restype = ctypes.c_int
         _lib.gdkvm_oracle_argmax_dice.argtypes = [_f, _u8, _u8, _i32] + [ctypes.c_int] * 4
+        _lib.gdkvm_oracle_upsample_argmax_dice.restype = ctypes.c_int
+        _lib.gdkvm_oracle_upsample_argmax_dice.argtypes = [_f, _u8, _u8, _i32] + [ctypes.c_int] * 6
         _lib.gdkvm_oracle_num_threads.restype = ctypes.c_int
     return _lib
 
@@ -93,6 +95,24 @@ def argmax_dice(logits, target=None):
                                         BT, ncls, H, W)
     if rc != 0:
         raise RuntimeError(f"gdkvm_oracle_argmax_dice failed: {rc}")
+    return mask, counts
+
+
+def upsample_argmax_dice(logits, H, W, target=None):
+    """low-res logits [BT,ncls,hl,wl] -> bilinear (align_corners=False) to HxW -> (mask u8 [BT,H,W], counts | None)."""
+    logits = _c32(logits)
+    BT, ncls, hl, wl = logits.shape
+    mask = np.empty((BT, H, W), dtype=np.uint8)
+    counts, tp = None, None
+    if target is not None:
+        target = np.ascontiguousarray(target, dtype=np.uint8)
+        counts = np.zeros((BT, ncls, 3), dtype=np.int32)
+        tp = target.ctypes.data_as(_u8)
+    rc = lib().gdkvm_oracle_upsample_argmax_dice(_fp(logits), tp, mask.ctypes.data_as(_u8),
+                                                 counts.ctypes.data_as(_i32) if counts is not None else None,
+                                                 BT, ncls, hl, wl, H, W)
+    if rc != 0:
+        raise RuntimeError(f"gdkvm_oracle_upsample_argmax_dice failed: {rc}")
     return mask, counts
 
 

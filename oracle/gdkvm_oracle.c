@@ -61,6 +61,50 @@ int gdkvm_oracle_argmax_dice(const float* logits, const uint8_t* target, uint8_t
     return 0;
 }
 
+/* Row a6, fused form: bilinear upsampling (align_corners = false, the PyTorch formula, all in fp32 and WITHOUT fused
+ * multiply-add -- this file is built with -ffp-contract=off) of low-resolution logits [BT, ncls, hl, wl] to H x W, then
+ * argmax over classes (ties -> lowest index) and the integer Dice counts.  The full-resolution logits never exist. */
+static float up_src(float scale, int dst) { const float s = scale * ((float)dst + 0.5f) - 0.5f; return s < 0.f ? 0.f : s; }
+
+int gdkvm_oracle_upsample_argmax_dice(const float* logits, const uint8_t* target, uint8_t* mask, int32_t* counts,
+                                      int BT, int ncls, int hl, int wl, int H, int W)
+{
+    if (BT < 0 || ncls <= 0 || ncls > 255 || hl <= 0 || wl <= 0 || H <= 0 || W <= 0) return -1;
+    const float sy = (float)hl / (float)H, sx = (float)wl / (float)W;
+    if (counts && target) memset(counts, 0, sizeof(int32_t) * (size_t)BT * ncls * 3);
+    for (int f = 0; f < BT; ++f)
+        for (int y = 0; y < H; ++y) {
+            const float fy = up_src(sy, y);
+            const int y0 = (int)fy, y1 = y0 + 1 < hl ? y0 + 1 : hl - 1;
+            const float ly = fy - (float)y0, hy = 1.0f - ly;
+            for (int x = 0; x < W; ++x) {
+                const float fx = up_src(sx, x);
+                const int x0 = (int)fx, x1 = x0 + 1 < wl ? x0 + 1 : wl - 1;
+                const float lx = fx - (float)x0, hx = 1.0f - lx;
+                int best = 0;
+                float bv = 0.f;
+                for (int c = 0; c < ncls; ++c) {
+                    const float* L = logits + ((size_t)f * ncls + c) * hl * wl;
+                    const float top = hx * L[y0 * wl + x0] + lx * L[y0 * wl + x1];
+                    const float bot = hx * L[y1 * wl + x0] + lx * L[y1 * wl + x1];
+                    const float v = hy * top + ly * bot;
+                    if (c == 0 || v > bv) { bv = v; best = c; }
+                }
+                const size_t p = ((size_t)f * H + y) * W + x;
+                mask[p] = (uint8_t)best;
+                if (counts && target) {
+                    const int tc = target[p];
+                    counts[((size_t)f * ncls + best) * 3 + 1] += 1;
+                    if (tc < ncls) {
+                        counts[((size_t)f * ncls + tc) * 3 + 2] += 1;
+                        if (tc == best) counts[((size_t)f * ncls + best) * 3 + 0] += 1;
+                    }
+                }
+            }
+        }
+    return 0;
+}
+
 int gdkvm_oracle_num_threads(void)
 {
 #ifdef _OPENMP

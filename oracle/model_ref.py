@@ -37,9 +37,10 @@ class GDKVMRef(GDKVM):
 
     @torch.no_grad()
     def segment(self, frames, target=None, **kw):
-        logits = self.forward(frames, **kw)
-        B, T, ncls, H, W = logits.shape
+        B, T, _, H, W = frames.shape
+        lowres = self.forward(frames, _lowres=True, **kw)
+        ncls, hl, wl = lowres.shape[2:]
         tgt = None if target is None else target.reshape(B * T, H, W).numpy()
-        mask, counts = c_oracle.argmax_dice(logits.reshape(B * T, ncls, H, W).float().numpy(), tgt)
+        mask, counts = c_oracle.upsample_argmax_dice(lowres.reshape(B * T, ncls, hl, wl).float().numpy(), H, W, tgt)
         return (torch.from_numpy(mask).reshape(B, T, H, W),
                 None if counts is None else torch.from_numpy(counts).reshape(B, T, ncls, 3))

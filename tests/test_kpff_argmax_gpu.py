@@ -74,3 +74,20 @@ def test_argmax_dice_bit_exact(hip, case, dtype):
     assert c2 is None and np.array_equal(m2.cpu().numpy(), mo)
     d = hip.dice_from_counts(c).cpu().numpy()
     np.testing.assert_allclose(d, O.dice_from_counts(co[..., 0], co[..., 1], co[..., 2]), rtol=1e-12)
+
+
+@pytest.mark.parametrize("case", [(3, 2, 28, 28, 112, 112), (2, 4, 64, 64, 256, 256), (2, 3, 7, 5, 30, 17), (1, 2, 28, 28, 28, 28)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_upsample_argmax_dice_bit_exact(hip, case, dtype):
+    """Fused bilinear upsample + argmax + Dice against the scalar oracle (same un-fused fp32 formula): bit-exact."""
+    BT, ncls, hl, wl, H, W = case
+    rng = np.random.default_rng(sum(case))
+    logits = O.to_bf16_f32(rng.standard_normal((BT, ncls, hl, wl)).astype(np.float32))
+    logits[:, :, ::4] = np.round(logits[:, :, ::4])
+    target = rng.integers(0, ncls + 1, (BT, H, W)).astype(np.uint8)
+    m, c = hip.upsample_argmax_dice(_dev(logits, dtype), H, W, _dev(target))
+    mo, co = c_oracle.upsample_argmax_dice(logits, H, W, target)
+    assert np.array_equal(m.cpu().numpy(), mo) and np.array_equal(c.cpu().numpy(), co)
+    # and against torch's own upsample + argmax: identical up to fused-multiply-add rounding at near-ties
+    ref = torch.nn.functional.interpolate(torch.from_numpy(logits), size=(H, W), mode="bilinear", align_corners=False).argmax(1)
+    assert (ref.numpy() != mo).mean() <= 2e-3

@@ -227,3 +227,14 @@ def test_backward_algorithm_matches_autograd(rule, flags):
     got = bwd_ref.scan_backward(q, k, v, a, b, s0, dR, dST, rule, flags)
     for g, t in zip(got, ts):
         np.testing.assert_allclose(g, t.grad.numpy(), atol=1e-9)
+
+
+def test_upsample_argmax_oracle_matches_torch_interpolate():
+    import torch
+    rng = np.random.default_rng(61)
+    logits = rng.standard_normal((2, 3, 28, 28)).astype(np.float32)
+    m, _ = c_oracle.upsample_argmax_dice(logits, 112, 112)
+    up = torch.nn.functional.interpolate(torch.from_numpy(logits), size=(112, 112), mode="bilinear", align_corners=False)
+    assert (up.argmax(1).numpy() != m).mean() <= 1e-4          # same formula; only FMA-contraction-level near-ties may differ
+    same, _ = c_oracle.upsample_argmax_dice(logits, 28, 28)     # identity scale == plain argmax
+    assert np.array_equal(same, O.argmax_mask(logits))
