@@ -448,6 +448,8 @@ extern "C" size_t gdkvm_kpff_workspace_bytes(int Ck, int Cv, int Cp, int io_dtyp
     return ((size_t)2 * Cp * (Cp + Ck + Cv) + (size_t)Cp * Ck + (size_t)Cp * Cv) * sizeof(bf16_t) + 16;
 }
 
+static thread_local int g_kpff_skip_pack = 0;            // set by gdkvm_kpff_fwd_packed around its call
+
 extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const void* pixel,
                                     const float* wa, const float* ba, const float* wl, const float* wg, void* out,
                                     void* save_gates, void* save_lp, void* save_gp, void* save_gms,
@@ -492,8 +494,10 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
         const bool pair = 2 * lds1 <= 160 * 1024 && total_tiles >= 2;     // two 64-token tiles per 8-wave workgroup
         bf16_t* wab = static_cast<bf16_t*>(workspace);
         const size_t na = (size_t)2 * Cp * Cin, nl = (size_t)Cp * Ck, ng = (size_t)Cp * Cv;
-        hipLaunchKernelGGL(kpff_pack_weights_kernel, dim3(256), dim3(256), 0, st, wa, wl, wg, wab, Cp, Ck, Cv);
-        GDKVM_LAUNCH_CHECK("kpff_pack_weights_kernel");
+        if (!g_kpff_skip_pack) {
+            hipLaunchKernelGGL(kpff_pack_weights_kernel, dim3(256), dim3(256), 0, st, wa, wl, wg, wab, Cp, Ck, Cv);
+            GDKVM_LAUNCH_CHECK("kpff_pack_weights_kernel");
+        }
         KpffBf16Args b{static_cast<const bf16_t*>(local), static_cast<const bf16_t*>(global), static_cast<const bf16_t*>(pixel),
                        wab, ba, wab + na, wab + na + nl, static_cast<bf16_t*>(out), Ck, Cv, Cp, h, w, rows, tiles, sv};
         const size_t lds = pair ? 2 * lds1 : lds1;
@@ -564,4 +568,19 @@ extern "C" int gdkvm_kpff_bwd_post(const void* d_out, const void* d_x, const voi
     else hipLaunchKernelGGL((kpff_bwd_post_kernel<GDKVM_BF16>), dim3(BT), dim3(256), 0, st, d_out, d_x, d_l_add, d_g_add, d_pixel, d_local, d_global, Ck, Cv, Cp, h, w);
     GDKVM_LAUNCH_CHECK("kpff_bwd_post_kernel");
     return GDKVM_OK;
+}
+
+// Inference with constant weights: the caller keeps the workspace of an earlier gdkvm_kpff_fwd call with the SAME weight
+// tensors alive and skips the re-pack (about 5 us per call at Cp = Cv = 256).  wa / wl / wg are still required for the
+// fp32 arm and for argument checking.
+extern "C" int gdkvm_kpff_fwd_packed(const void* local, const void* global, const void* pixel,
+                                     const float* wa, const float* ba, const float* wl, const float* wg, void* out,
+                                     void* packed_workspace, size_t workspace_bytes,
+                                     int BT, int Ck, int Cv, int Cp, int h, int w, int io_dtype, void* stream)
+{
+    g_kpff_skip_pack = 1;
+    const int rc = gdkvm_kpff_fwd_train(local, global, pixel, wa, ba, wl, wg, out, nullptr, nullptr, nullptr, nullptr,
+                                        packed_workspace, workspace_bytes, BT, Ck, Cv, Cp, h, w, io_dtype, stream);
+    g_kpff_skip_pack = 0;
+    return rc;
 }

@@ -33,6 +33,7 @@ SIGNATURES = {
     "gdkvm_scan_bwd": (_i, [_vp] * 7 + [_sz] + [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_kpff_workspace_bytes": (_sz, [_i] * 4),
     "gdkvm_kpff_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 7 + [_vp]),
+    "gdkvm_kpff_fwd_packed": (_i, [_vp] * 9 + [_sz] + [_i] * 7 + [_vp]),
     "gdkvm_kpff_fwd_train": (_i, [_vp] * 13 + [_sz] + [_i] * 7 + [_vp]),
     "gdkvm_kpff_bwd_pre": (_i, [_vp] * 7 + [_i] * 4 + [_vp]),
     "gdkvm_kpff_bwd_post": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
@@ -231,7 +232,7 @@ def scan_apply(q, alpha, workspace, Dv, state=None, flags=0, out=None, state_out
 
 def kpff_fwd(local: torch.Tensor, glob: torch.Tensor, pixel: torch.Tensor, wa: torch.Tensor, ba: torch.Tensor,
              wl: torch.Tensor, wg: torch.Tensor, h: int, w: int, out: Optional[torch.Tensor] = None,
-             workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+             workspace: Optional[torch.Tensor] = None, packed: bool = False) -> torch.Tensor:
     """Key-Pixel Feature Fusion (gdkvm_kpff_fwd).  local [BT,N,Ck] glob [BT,N,Cv] pixel [BT,N,Cp], N=h*w;
     wa [2Cp,Cp+Ck+Cv] ba [2Cp] wl [Cp,Ck] wg [Cp,Cv] float32.  Returns F [BT,N,Cp] in the io dtype."""
     lib = load()
@@ -252,9 +253,10 @@ def kpff_fwd(local: torch.Tensor, glob: torch.Tensor, pixel: torch.Tensor, wa: t
     f = out if out is not None else torch.empty((BT, N, Cp), dtype=local.dtype, device=dev)
     if workspace is None:
         workspace = torch.empty(int(lib.gdkvm_kpff_workspace_bytes(Ck, Cv, Cp, io)), dtype=torch.uint8, device=dev)
+    fn = lib.gdkvm_kpff_fwd_packed if packed else lib.gdkvm_kpff_fwd     # packed: `workspace` already holds these weights
     with torch.cuda.device(dev):
-        rc = lib.gdkvm_kpff_fwd(_ptr(local), _ptr(glob), _ptr(pixel), _ptr(wa), _ptr(ba), _ptr(wl), _ptr(wg), _ptr(f),
-                                workspace.data_ptr(), workspace.numel(), BT, Ck, Cv, Cp, h, w, io, _stream(dev))
+        rc = fn(_ptr(local), _ptr(glob), _ptr(pixel), _ptr(wa), _ptr(ba), _ptr(wl), _ptr(wg), _ptr(f),
+                workspace.data_ptr(), workspace.numel(), BT, Ck, Cv, Cp, h, w, io, _stream(dev))
     _check(rc, "gdkvm_kpff_fwd")
     return f
 

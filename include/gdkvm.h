@@ -111,6 +111,13 @@ int gdkvm_kpff_fwd(const void* local, const void* global, const void* pixel,
                    void* workspace, size_t workspace_bytes,
                    int BT, int Ck, int Cv, int Cp, int h, int w, int io_dtype, void* stream);
 
+/* gdkvm_kpff_fwd with the weight re-pack skipped: `packed_workspace` must be the workspace a previous gdkvm_kpff_fwd
+ * call filled from the SAME (unchanged) wa / wl / wg -- the inference case. */
+int gdkvm_kpff_fwd_packed(const void* local, const void* global, const void* pixel,
+                          const float* wa, const float* ba, const float* wl, const float* wg, void* out,
+                          void* packed_workspace, size_t workspace_bytes,
+                          int BT, int Ck, int Cv, int Cp, int h, int w, int io_dtype, void* stream);
+
 /* Row a7 for KPFF.  The training forward also stores what the backward needs (all [M = BT*N, .] in io_dtype): the
  * gates after the sigmoid [M,2Cp], L wl^T [M,Cp], Gms wg^T [M,Cp] and the pooled feature Gms [M,Cv].  The backward is
  *   gdkvm_kpff_bwd_pre   d_z = (d_out*Lp*g_l(1-g_l) | d_out*Gp*g_g(1-g_g)), d_lp = d_out*g_l, d_gp = d_out*g_g
