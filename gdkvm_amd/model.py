@@ -58,6 +58,9 @@ class BasicBlock(nn.Module):
             self.down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), _bn(cout))
 
     def forward(self, x):
+        if isinstance(self.conv1, FusedConv):              # inference build: conv -> one fused epilogue pass
+            skip = x if self.down is None else self.down(x)
+            return self.conv2(self.conv1(x), skip.contiguous(memory_format=torch.channels_last) if skip.is_cuda else skip)
         y = F.relu(self.bn1(self.conv1(x)), inplace=True)
         y = self.bn2(self.conv2(y))
         return F.relu(y + (x if self.down is None else self.down(x)), inplace=True)
@@ -116,6 +119,42 @@ def _fold_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d) -> nn.Conv2d:
     b0 = conv.bias if conv.bias is not None else torch.zeros_like(bn.running_mean)
     fused.bias.data = bn.bias + (b0 - bn.running_mean) * scale
     return fused
+
+
+class FusedConv(nn.Module):
+    """Inference-only: a bias-free MIOpen convolution followed by ONE fused HIP epilogue pass (bias + optional residual +
+    optional ReLU, in place) instead of PyTorch's separate bias-add / add / clamp kernels.  The bias is kept in fp32."""
+
+    def __init__(self, conv: nn.Conv2d, relu: bool):
+        super().__init__()
+        self.conv = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding,
+                              conv.dilation, conv.groups, bias=False).to(conv.weight.device, conv.weight.dtype)
+        self.conv.weight.data = conv.weight.data
+        self.epi = _EpilogueBias(conv.bias.data.float() if conv.bias is not None else torch.zeros(conv.out_channels, device=conv.weight.device))
+        self.relu = relu
+
+    def forward(self, x, residual=None):
+        y = self.conv(x)
+        if not y.is_cuda:                                  # CPU reference module (oracle/model_ref.py): plain torch
+            y = y + self.epi.bias.to(y.dtype).reshape(1, -1, 1, 1)
+            y = y if residual is None else y + residual
+            return F.relu(y) if self.relu else y
+        y = y.contiguous(memory_format=torch.channels_last)
+        return ops.bias_act_(y, self.epi.bias, residual, self.relu)
+
+
+class _EpilogueBias(nn.Module):
+    """fp32 bias that survives .to(bfloat16) on the parent."""
+
+    def __init__(self, bias):
+        super().__init__()
+        self.bias = nn.Parameter(bias, requires_grad=False)
+
+    def _apply(self, fn, recurse=True):
+        def keep_fp32(t):
+            r = fn(t)
+            return r.float() if r.is_floating_point() else r
+        return super()._apply(keep_fp32, recurse)
 
 
 def _fold_sequential(seq: nn.Sequential) -> nn.Sequential:
@@ -238,15 +277,26 @@ class GDKVM(nn.Module):
         (profiles/r01_a_bench_cfg2_kernel_stats.csv)."""
         if self.training:
             raise RuntimeError("fuse_for_inference() needs eval() mode")
+        def fuse_seq(seq):
+            """conv, bn, relu -> FusedConv(relu) ; conv, bn -> FusedConv(no relu)"""
+            mods, out, i = list(_fold_sequential(seq)), [], 0
+            while i < len(mods):
+                if isinstance(mods[i], nn.Conv2d):
+                    relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                    out.append(FusedConv(mods[i], relu)); i += 2 if relu else 1
+                else:
+                    out.append(mods[i]); i += 1
+            return nn.Sequential(*out)
+
         for m in list(self.modules()):
             if isinstance(m, BasicBlock) and isinstance(m.bn1, nn.BatchNorm2d):
-                m.conv1, m.bn1 = _fold_bn(m.conv1, m.bn1), nn.Identity()
-                m.conv2, m.bn2 = _fold_bn(m.conv2, m.bn2), nn.Identity()
+                m.conv1, m.bn1 = FusedConv(_fold_bn(m.conv1, m.bn1), True), nn.Identity()
+                m.conv2, m.bn2 = FusedConv(_fold_bn(m.conv2, m.bn2), True), nn.Identity()   # + residual, then ReLU
                 if m.down is not None:
-                    m.down = _fold_sequential(m.down)
+                    m.down = fuse_seq(m.down)
             elif isinstance(m, UpBlock):
-                m.conv = _fold_sequential(m.conv)
-        self.encoder.stem = _fold_sequential(self.encoder.stem)
+                m.conv = fuse_seq(m.conv)
+        self.encoder.stem = fuse_seq(self.encoder.stem)
         return self
 
     @torch.no_grad()

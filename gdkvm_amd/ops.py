@@ -38,6 +38,7 @@ SIGNATURES = {
     "gdkvm_kpff_bwd_pre": (_i, [_vp] * 7 + [_i] * 4 + [_vp]),
     "gdkvm_kpff_bwd_post": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
+    "gdkvm_bias_act": (_i, [_vp] * 4 + [_sz] + [_i] * 3 + [_vp]),
     "gdkvm_upsample_argmax_dice": (_i, [_vp] * 4 + [_i] * 7 + [_vp]),
 }
 
@@ -354,6 +355,26 @@ def upsample_argmax_dice(logits: torch.Tensor, H: int, W: int, target: Optional[
                                             _io_dtype(logits), _stream(dev))
     _check(rc, "gdkvm_upsample_argmax_dice")
     return mask, counts
+
+
+def bias_act_(x: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tensor] = None, relu: bool = True) -> torch.Tensor:
+    """In-place fused epilogue on an NHWC (channels_last) conv output: x <- act(x + bias[c] (+ residual))  (gdkvm_bias_act)."""
+    lib = load()
+    if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("bias_act_ needs a channels_last [N,C,H,W] tensor")
+    if residual is not None and (residual.shape != x.shape or residual.dtype != x.dtype or
+                                 not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise GdkvmError("residual must match x (shape, dtype, channels_last)")
+    if bias.dtype != torch.float32 or bias.numel() != x.shape[1]:
+        raise GdkvmError("bias must be float32 [C]")
+    if not x.is_cuda:
+        raise GdkvmError("GDKVM ops need device tensors (no CPU path)")
+    n, c, hh, ww = x.shape
+    with torch.cuda.device(x.device):
+        rc = lib.gdkvm_bias_act(x.data_ptr(), bias.data_ptr(), None if residual is None else residual.data_ptr(), x.data_ptr(),
+                                n * hh * ww, c, int(relu), _io_dtype(x), _stream(x.device))
+    _check(rc, "gdkvm_bias_act")
+    return x
 
 
 def dice_from_counts(counts: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:

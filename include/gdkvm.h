@@ -149,6 +149,12 @@ int gdkvm_argmax_dice(const void* logits, const uint8_t* target, uint8_t* mask, 
 int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* target, uint8_t* mask, int32_t* counts,
                                int BT, int ncls, int hl, int wl, int H, int W, int io_dtype, void* stream);
 
+/* SURVEY.md §8(f) row n1 (inference build only): fused pointwise epilogue for the unchanged MIOpen convolutions,
+ * y[r, c] = act(x[r, c] + bias[c] (+ residual[r, c])) over an NHWC tensor viewed as [rows, C]; relu != 0 applies ReLU.
+ * x, residual, y in io_dtype (y may alias x), bias fp32.  C must be a multiple of 4 (f32) / 8 (bf16). */
+int gdkvm_bias_act(const void* x, const float* bias, const void* residual, void* y,
+                   size_t rows, int C, int relu, int io_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

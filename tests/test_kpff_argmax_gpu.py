@@ -91,3 +91,18 @@ def test_upsample_argmax_dice_bit_exact(hip, case, dtype):
     # and against torch's own upsample + argmax: identical up to fused-multiply-add rounding at near-ties
     ref = torch.nn.functional.interpolate(torch.from_numpy(logits), size=(H, W), mode="bilinear", align_corners=False).argmax(1)
     assert (ref.numpy() != mo).mean() <= 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 64, 28, 28), (2, 8, 5, 7), (1, 256, 7, 7)])
+def test_bias_act_epilogue(hip, dtype, shape):
+    """Fused bias + residual + ReLU over NHWC against the same arithmetic in torch (fp32 math, one rounding)."""
+    torch.manual_seed(sum(shape))
+    x = torch.randn(shape, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(shape, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(shape[1], device="cuda")
+    for res, relu in ((None, True), (r, True), (r, False), (None, False)):
+        want = (x.float() if res is None else x.float() + res.float()) + b.reshape(1, -1, 1, 1)     # the kernel's order
+        want = (want.clamp_min(0) if relu else want).to(dtype)
+        got = hip.bias_act_(x.clone(memory_format=torch.channels_last), b, res, relu)
+        assert torch.equal(got, want)
