@@ -78,3 +78,76 @@ extern "C" int gdkvm_bias_act(const void* x, const float* bias, const void* resi
     GDKVM_LAUNCH_CHECK("bias_act_kernel");
     return GDKVM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Decoder glue of the inference build: out[n, y, x, :] = [ bilinear(lo)[n, y, x, :C1] ; skip[n, y, x, :C2] ]  (NHWC).
+// PyTorch runs this as an upsample kernel that writes the enlarged map plus a concat kernel that re-reads and re-writes
+// everything; here the enlarged map is never written on its own.  align_corners = false, PyTorch's source-index formula,
+// blend in fp32.  One thread = 8 channels (16 bytes) of one output pixel.
+namespace {
+
+__device__ __forceinline__ void unpack8(const uint4& a, float (&v)[8])
+{
+    const unsigned w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+}
+
+__global__ __launch_bounds__(256) void upsample_cat_bf16_kernel(const bf16_t* lo, const bf16_t* skip, bf16_t* out,
+                                                                int Nimg, int hl, int wl, int H, int W, int C1, int C2,
+                                                                float sy, float sx)
+{
+    const int C = C1 + C2, c8n = C / 8;
+    const size_t total = (size_t)Nimg * H * W * c8n;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % c8n) * 8;
+        const size_t pix = i / c8n;
+        const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
+        uint4 o;
+        if (c >= C1) {
+            o = *reinterpret_cast<const uint4*>(skip + (((size_t)n * H + y) * W + x) * C2 + (c - C1));
+        } else {
+            const float fy = fmaxf(sy * ((float)y + 0.5f) - 0.5f, 0.f), fx = fmaxf(sx * ((float)x + 0.5f) - 0.5f, 0.f);
+            const int y0 = (int)fy, x0 = (int)fx, y1 = min(y0 + 1, hl - 1), x1 = min(x0 + 1, wl - 1);
+            const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+            const bf16_t* base = lo + (size_t)n * hl * wl * C1 + c;
+            float a[8], b[8], cc[8], d[8];
+            unpack8(*reinterpret_cast<const uint4*>(base + ((size_t)y0 * wl + x0) * C1), a);
+            unpack8(*reinterpret_cast<const uint4*>(base + ((size_t)y0 * wl + x1) * C1), b);
+            unpack8(*reinterpret_cast<const uint4*>(base + ((size_t)y1 * wl + x0) * C1), cc);
+            unpack8(*reinterpret_cast<const uint4*>(base + ((size_t)y1 * wl + x1) * C1), d);
+            unsigned r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v0 = hy * (hx * a[2 * j] + lx * b[2 * j]) + ly * (hx * cc[2 * j] + lx * d[2 * j]);
+                const float v1 = hy * (hx * a[2 * j + 1] + lx * b[2 * j + 1]) + ly * (hx * cc[2 * j + 1] + lx * d[2 * j + 1]);
+                r[j] = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
+            }
+            o = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+        *reinterpret_cast<uint4*>(out + pix * C + c) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int gdkvm_upsample_cat(const void* lo, const void* skip, void* out,
+                                  int Nimg, int hl, int wl, int H, int W, int C1, int C2, int io_dtype, void* stream)
+{
+    if (Nimg < 0 || hl <= 0 || wl <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 <= 0)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_cat: bad shape");
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "upsample_cat: only bf16 (inference build) is implemented");
+    if (C1 % 8 || C2 % 8) return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_cat: channel counts must be multiples of 8");
+    if (Nimg == 0) return GDKVM_OK;
+    if (!lo || !skip || !out || !gdkvm_aligned16(lo) || !gdkvm_aligned16(skip) || !gdkvm_aligned16(out))
+        return gdkvm_fail(GDKVM_ERR_ARG, "upsample_cat: null or misaligned pointer");
+    if (int rc = gdkvm_check_device()) return rc;
+    const size_t total = (size_t)Nimg * H * W * ((C1 + C2) / 8);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(upsample_cat_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(lo), static_cast<const bf16_t*>(skip), static_cast<bf16_t*>(out),
+                       Nimg, hl, wl, H, W, C1, C2, (float)hl / (float)H, (float)wl / (float)W);
+    GDKVM_LAUNCH_CHECK("upsample_cat_bf16_kernel");
+    return GDKVM_OK;
+}

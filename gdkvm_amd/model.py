@@ -91,6 +91,10 @@ class UpBlock(nn.Module):
                                   nn.Conv2d(cout, cout, 3, 1, 1, bias=False), _bn(cout), nn.ReLU(inplace=True))
 
     def forward(self, x, skip):
+        if (isinstance(self.conv[0], FusedConv) and x.is_cuda and x.dtype == torch.bfloat16
+                and x.shape[1] % 8 == 0 and skip.shape[1] % 8 == 0):            # inference build: one fused HIP pass
+            return self.conv(ops.upsample_cat(x.contiguous(memory_format=torch.channels_last),
+                                              skip.contiguous(memory_format=torch.channels_last)))
         x = F.interpolate(x, size=skip.shape[-2:], mode="bilinear", align_corners=False)
         return self.conv(torch.cat([x, skip], 1))
 

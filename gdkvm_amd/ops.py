@@ -39,6 +39,7 @@ SIGNATURES = {
     "gdkvm_kpff_bwd_post": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "gdkvm_bias_act": (_i, [_vp] * 4 + [_sz] + [_i] * 3 + [_vp]),
+    "gdkvm_upsample_cat": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_upsample_argmax_dice": (_i, [_vp] * 4 + [_i] * 7 + [_vp]),
 }
 
@@ -375,6 +376,24 @@ def bias_act_(x: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tens
                                 n * hh * ww, c, int(relu), _io_dtype(x), _stream(x.device))
     _check(rc, "gdkvm_bias_act")
     return x
+
+
+def upsample_cat(lo: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:
+    """concat(bilinear_upsample(lo -> skip's H x W, align_corners=False), skip) along channels, both channels_last
+    bf16 [N,C,h,w]; returns a channels_last [N,C1+C2,H,W] tensor (gdkvm_upsample_cat)."""
+    lib = load()
+    for t in (lo, skip):
+        if t.dim() != 4 or not t.is_cuda or not t.is_contiguous(memory_format=torch.channels_last):
+            raise GdkvmError("upsample_cat needs channels_last device tensors")
+    if lo.dtype != torch.bfloat16 or skip.dtype != torch.bfloat16 or lo.shape[0] != skip.shape[0]:
+        raise GdkvmError("upsample_cat: bf16 tensors with equal batch")
+    n, c1, hl, wl = lo.shape
+    _, c2, H, W = skip.shape
+    out = torch.empty((n, c1 + c2, H, W), dtype=lo.dtype, device=lo.device, memory_format=torch.channels_last)
+    with torch.cuda.device(lo.device):
+        rc = lib.gdkvm_upsample_cat(lo.data_ptr(), skip.data_ptr(), out.data_ptr(), n, hl, wl, H, W, c1, c2, BF16, _stream(lo.device))
+    _check(rc, "gdkvm_upsample_cat")
+    return out
 
 
 def dice_from_counts(counts: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:

@@ -155,6 +155,11 @@ int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* target, uint8_
 int gdkvm_bias_act(const void* x, const float* bias, const void* residual, void* y,
                    size_t rows, int C, int relu, int io_dtype, void* stream);
 
+/* SURVEY.md §8(f) row n1 (inference build only): decoder glue, out = concat(bilinear_upsample(lo -> H x W), skip) over
+ * NHWC tensors  lo [N,hl,wl,C1], skip [N,H,W,C2], out [N,H,W,C1+C2]; align_corners = false; bf16 only. */
+int gdkvm_upsample_cat(const void* lo, const void* skip, void* out,
+                       int Nimg, int hl, int wl, int H, int W, int C1, int C2, int io_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,3 +106,17 @@ def test_bias_act_epilogue(hip, dtype, shape):
         want = (want.clamp_min(0) if relu else want).to(dtype)
         got = hip.bias_act_(x.clone(memory_format=torch.channels_last), b, res, relu)
         assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("case", [(4, 256, 7, 7, 128, 14, 14), (2, 128, 14, 14, 64, 28, 28), (1, 16, 5, 3, 8, 9, 7)])
+def test_upsample_cat(hip, case):
+    n, c1, hl, wl, c2, H, W = case
+    torch.manual_seed(sum(case))
+    lo = torch.randn(n, c1, hl, wl, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    sk = torch.randn(n, c2, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    got = hip.upsample_cat(lo, sk)
+    up = torch.nn.functional.interpolate(lo.float(), size=(H, W), mode="bilinear", align_corners=False)
+    want = torch.cat([up, sk.float()], 1)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got[:, c1:], sk)
+    assert (got[:, :c1].float() - up).abs().max() <= 2.0 ** -7 * up.abs().max()     # one bf16 rounding of an fp32 blend
