@@ -34,15 +34,16 @@ namespace {
 struct PrepArgs {
     const void* q; const void* k; const void* v; const float* beta;
     float* wt; float* knT; float* ut; float* qinv;
+    float* kn; float* wtT; float* qnT;                  // training mode only (GDKVM_FLAG_TRAIN)
     int T, Hh, N, Dv, rule, flags;
 };
 
 __device__ __forceinline__ int pair_slot(int I, int J) { return I * (I - 1) / 2 + J; }   // J < I
 
-// LDS carve for NB token tiles (floats): kinv[NP] beta[NP] | negA[NB(NB-1)/2][64][4] | Ld[NB][64][4] | Tm[NB][64][4]
+// LDS carve for NB token tiles (floats): kinv[NP] beta[NP] qinv[NP] pad[NP] | negA[NB(NB-1)/2][64][4] | Ld[NB][64][4] | Tm[NB][64][4]
 __host__ __device__ constexpr size_t prep_lds_bytes(int NB)
 {
-    return (size_t)(2 * 16 * NB + (NB * (NB - 1) / 2 + 2 * NB) * 256) * sizeof(float);
+    return (size_t)(4 * 16 * NB + (NB * (NB - 1) / 2 + 2 * NB) * 256) * sizeof(float);
 }
 
 // TPR = column tiles a wave solves at once.  Their operands are fetched at kernel entry (latency hidden behind
@@ -54,7 +55,8 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prep_kernel(PrepAr
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_kinv = smem;
     float* s_beta = smem + NP;
-    f32x4* s_negA = reinterpret_cast<f32x4*>(smem + 2 * NP);
+    float* s_qinv = smem + 2 * NP;                        // (+ NP floats of padding keeps the images 16-byte aligned)
+    f32x4* s_negA = reinterpret_cast<f32x4*>(smem + 4 * NP);
     f32x4* s_Ld = s_negA + (NB * (NB - 1) / 2) * 64;
     f32x4* s_Tm = s_Ld + NB * 64;
 
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prep_kernel(PrepAr
         }
         s_kinv[n] = kinv;
         s_beta[n] = bta;
+        s_qinv[n] = qinv;
         a.qinv[(size_t)fh * NP + n] = qinv;
     }
     __syncthreads();
@@ -179,6 +182,20 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prep_kernel(PrepAr
     float* wt = a.wt + (size_t)fh * NP * GDKVM_DK;
     float* knT = a.knT + (size_t)fh * GDKVM_DK * NP;
     f32x4* ut = reinterpret_cast<f32x4*>(a.ut + (size_t)fh * NP * Dv);
+    const bool train = a.flags & GDKVM_FLAG_TRAIN;
+    float* kn_nat = a.kn + (size_t)fh * NP * GDKVM_DK;
+    float* wtT = a.wtT + (size_t)fh * GDKVM_DK * NP;
+    if (train) {                                          // Qn^T for the backward's Qn^T dR: 4 tokens per 16-byte store
+        float* qnT = a.qnT + (size_t)fh * GDKVM_DK * NP;
+        for (int idx = tid; idx < GDKVM_DK * (NP / 4); idx += 256) {
+            const int d = idx / (NP / 4), n0 = (idx - d * (NP / 4)) * 4;
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                o[r] = n0 + r < N ? load1<IO>(a.q, ((bt * N + n0 + r) * Hh + h) * GDKVM_DK + d) * s_qinv[n0 + r] : 0.f;
+            *reinterpret_cast<f32x4*>(qnT + (size_t)d * NP + n0) = o;
+        }
+    }
     for (int rd = 0; rd < nround; ++rd) {
         if (rd > 0) fetch_round(rd);
         f32x4 Y[TPR][NB];
@@ -194,7 +211,13 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prep_kernel(PrepAr
                 const bool isK = c < GDKVM_DK / 16;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][r] = isK ? xr[i][I][r] * ki4[r] : xr[i][I][r];
-                if (isK) *reinterpret_cast<f32x4*>(knT + (size_t)(16 * c + li) * NP + n0) = acc[i];   // Kn^T, 4 tokens
+                if (isK) {
+                    *reinterpret_cast<f32x4*>(knT + (size_t)(16 * c + li) * NP + n0) = acc[i];   // Kn^T, 4 tokens
+                    if (train) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) kn_nat[(size_t)(n0 + r) * GDKVM_DK + 16 * c + li] = acc[i][r];
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][r] *= bt4[r];
             }
@@ -228,6 +251,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prep_kernel(PrepAr
                     if (isK) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) wt[(size_t)(n0 + r) * GDKVM_DK + 16 * c + li] = acc[i][r];
+                        if (train) *reinterpret_cast<f32x4*>(wtT + (size_t)(16 * c + li) * NP + n0) = acc[i];
                     } else {
                         ut[((size_t)(c - 4) * NB + I) * 64 + lane] = acc[i];
                     }
@@ -258,6 +282,7 @@ struct ScanArgs {
     const void* q; const float* alpha; const float* s_in;
     const float* wt; const float* knT; const float* ut; const float* qinv;
     void* r_out; float* s_out; float* s_hist; char* trash;
+    const float* qnT; const void* d_r;                    // BWD mode: read waves form Qn^T dR
     int T, Hh, N, Dv, flags, BH;
 #ifdef GDKVM_DIAG
     unsigned long long* diag;
@@ -299,6 +324,7 @@ __device__ __forceinline__ void static_for(F&& f)
 template <int IO> struct QItem;                                        // read-out waves:  R = (Q S) * qinv
 template <> struct QItem<GDKVM_F32> { f32x4 q[4]; f32x4 qinv; };       //   fp32 I/O: exact fp32 MFMA, k = 16m + 4g + r
 template <> struct QItem<GDKVM_BF16> { bf16x8 q[2]; f32x4 qinv; };     //   bf16 I/O: bf16 MFMA on S = S_hi + S_lo, k = 32s + 8g + j
+struct GItem { f32x4 a[4]; float b[4][4]; };                           // BWD read waves: Qn^T rows 16w.. and dR rows, 4 token tiles
 struct XItem { f32x4 w[4]; f32x4 u; float alpha; };                    // state waves:     X = Wt S, U = Ut - aX
 struct KItem { f32x4 k[4]; };                                          // state waves:     S <- aS + Kn^T U (4 token tiles)
 
@@ -320,14 +346,21 @@ __device__ __forceinline__ float fast_sigmoid(float x)
 // go to a trash slot): a CFG merge makes hipcc's vmcnt bookkeeping conservative, and a conservative wait lands on
 // the freshly issued loads and exposes the full latency every frame.
 // SAVE: training mode -- also write the state BEFORE every frame (s_hist [B,T,Hh,Dk,Dv]) for the backward pass.
-template <int IO, int NB, bool SAVE>
+// BWD:  the reverse-time recurrence of the backward pass has the same shape,
+//           dS = a (dS' - Wt^T (Kn dS')) + Qn^T dR ,
+//       so the same kernel runs it with the operand roles swapped (Wt -> Kn, Kn^T -> Wt^T, no Ut term), frames visited
+//       last to first, the read waves producing the state-independent term Qn^T dR, and "s_hist" receiving dS' of every
+//       frame.  (NB = 4 only: the per-frame assembly kernel is limited to 64 tokens.)
+template <int IO, int NB, bool SAVE, bool BWD>
 __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
 {
+    static_assert(!BWD || NB == 4, "backward: N <= 64");
     constexpr int NP = 16 * NB, JT = NB / 4, NG = NB / 4, NBUF = 4, DEPTH = 3, UF = NBUF / JT;
     static_assert(JT == 1 || JT == 2 || JT == 4, "token tiles per wave");
     __shared__ __attribute__((aligned(16))) f32x4 s_S[4 * 64];
     __shared__ __attribute__((aligned(16))) f32x4 s_U[NB * 64];
     __shared__ __attribute__((aligned(16))) uint2 s_Sh[2 * 64 * 2], s_Sl[2 * 64 * 2];   // bf16 hi / lo B-operand images of S
+    __shared__ __attribute__((aligned(16))) f32x4 s_G[4 * 64];                           // BWD: Qn^T dR tiles from the read waves
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -346,13 +379,14 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
     const size_t fh0 = (size_t)b * T * Hh + h;           // frame-head index of frame 0; +Hh per frame
     const int last_item = T * JT - 1;
     constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
+    auto tmap = [&](int t) { return BWD ? T - 1 - t : t; };   // frame visited at step t
 
     // Publishing S for the next frame: the fp32 accumulator image (B operand of the state waves' exact products) and,
     // for the bf16 arm, S = S_hi + S_lo in bf16 as the B operand of the read-out's 16x16x32 MFMA.  This wave's rows
     // 16w+4g+r are k = 32s + 8g' + j with s = w>>1, g' = 2(w&1) + (g>>1), j = 4(g&1) + r  ->  half a fragment lane.
     auto publish_state = [&](const f32x4& sv) {
         s_S[w * 64 + lane] = sv;
-        if constexpr (IO == GDKVM_BF16) {
+        if constexpr (IO == GDKVM_BF16 && !BWD) {
             unsigned h0 = f32_to_bf16(sv[0]), h1 = f32_to_bf16(sv[1]), h2 = f32_to_bf16(sv[2]), h3 = f32_to_bf16(sv[3]);
             const float l0 = sv[0] - __uint_as_float(h0 << 16), l1 = sv[1] - __uint_as_float(h1 << 16);
             const float l2 = sv[2] - __uint_as_float(h2 << 16), l3 = sv[3] - __uint_as_float(h3 << 16);
@@ -372,6 +406,55 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
         publish_state(sacc);
     }
 
+    if constexpr (BWD) if (read_role) {
+        // ------------------------------------------------------------------ BWD read waves: G_t = Qn_t^T dR_t
+        const float* qn_lane = a.qnT + fh0 * GDKVM_DK * NP + (size_t)(16 * w + li) * NP + 4 * g;
+        const size_t qn_fstride = (size_t)Hh * GDKVM_DK * NP;
+        const char* drbase = static_cast<const char*>(a.d_r) + ((size_t)b * T * N * Hh * Dv + h * Dv + 16 * sl + li) * ESZ;
+        const size_t dr_fstride = (size_t)N * Hh * Dv * ESZ;
+        auto load_g = [&](int item, GItem& d) {
+            const int t = tmap(min(item, last_item));
+            const float* qp = qn_lane + t * qn_fstride;
+            const char* rp = drbase + t * dr_fstride;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                d.a[j] = *reinterpret_cast<const f32x4*>(qp + 16 * j);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = min(16 * j + 4 * g + r, N - 1);       // padding tokens: Qn^T column is zero
+                    if constexpr (IO == GDKVM_F32) d.b[j][r] = *reinterpret_cast<const float*>(rp + (size_t)n * (Hh * Dv * ESZ));
+                    else d.b[j][r] = bf16_to_f32(*reinterpret_cast<const bf16_t*>(rp + (size_t)n * (Hh * Dv * ESZ)));
+                }
+            }
+        };
+        GItem gb[NBUF];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) load_g(i, gb[i]);
+        __syncthreads();
+        auto frame = [&](int t, auto fc) {
+            constexpr int F = decltype(fc)::value;
+            const GItem& cur = gb[F % NBUF];
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j & 1) acc1 = mfma4(cur.a[j][r], cur.b[j][r], acc1);
+                    else acc0 = mfma4(cur.a[j][r], cur.b[j][r], acc0);
+                }
+            s_G[w * 64 + lane] = acc0 + acc1;
+            load_g(t + DEPTH, gb[(F + DEPTH) % NBUF]);
+            __syncthreads();                               // (1) G_t and V' complete
+            __syncthreads();                               // (2) dS published
+        };
+        int t0 = 0;
+        for (; t0 + UF <= T; t0 += UF)
+            static_for<0, UF>([&](auto fc) { frame(t0 + decltype(fc)::value, fc); });
+        static_for<0, UF - 1>([&](auto fc) {
+            if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, fc);
+        });
+        return;
+    }
     if (read_role) {
         // ------------------------------------------------------------------------------ read-out waves
         const char* qbase = static_cast<const char*>(a.q) + (((size_t)b * T * N * Hh + h) * GDKVM_DK) * ESZ;
@@ -463,16 +546,16 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
 
     auto load_x = [&](int item, XItem& d) {              // item = t*JT + j  -> token tile tt = w + 4j of frame t
         item = min(item, last_item);
-        const int t = item / JT, tt = w + 4 * (item - t * JT);
+        const int ts = item / JT, tt = w + 4 * (item - ts * JT), t = tmap(ts);
         const float* wt = wt_lane + t * wt_fstride + tt * (16 * GDKVM_DK);
 #pragma unroll
         for (int m = 0; m < 4; ++m) d.w[m] = *reinterpret_cast<const f32x4*>(wt + 16 * m);
-        d.u = ut_lane[t * ut_fstride + tt * 64];
+        if constexpr (!BWD) d.u = ut_lane[t * ut_fstride + tt * 64];
         d.alpha = al_ptr[(size_t)t * Hh + vzero];       // VECTOR load on purpose: a scalar load shares lgkmcnt with the
     };                                                   // LDS reads, whose lgkmcnt(0) would then wait ~1 us for it
     auto load_k = [&](int item, KItem& d) {              // item = t*NG + gi -> token tiles 4gi..4gi+3 of frame t
         item = min(item, last_item);
-        const int t = item / NG, gi = item - t * NG;
+        const int ts = item / NG, gi = item - ts * NG, t = tmap(ts);
         const float* kp = kn_lane + t * kn_fstride + 64 * gi;
 #pragma unroll
         for (int j = 0; j < 4; ++j) d.k[j] = *reinterpret_cast<const f32x4*>(kp + 16 * j);
@@ -508,7 +591,7 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
 #endif
         f32x4 u;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) u[r] = cur.u[r] - alpha * (acc0[r] + acc1[r]);
+        for (int r = 0; r < 4; ++r) u[r] = (BWD ? 0.f : cur.u[r]) - alpha * (acc0[r] + acc1[r]);
         s_U[tt * 64 + lane] = u;
     };
     auto k_item = [&](int t, int gi, const KItem& cur, KItem& nxt, f32x4& acc0, f32x4& acc1) {
@@ -536,7 +619,7 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
         constexpr int F = decltype(fc)::value;
         DIAG_STAMP(0);
         if constexpr (SAVE) {
-            float* hp = a.s_hist + ((fh0 + (size_t)t * Hh) * GDKVM_DK + 16 * w + 4 * g) * Dv + 16 * sl + li;
+            float* hp = a.s_hist + ((fh0 + (size_t)tmap(t) * Hh) * GDKVM_DK + 16 * w + 4 * g) * Dv + 16 * sl + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) hp[(size_t)r * Dv] = sacc[r];
         }
@@ -557,6 +640,7 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
             k_item(t, decltype(gc)::value, kb[i % NBUF], kb[(i + DEPTH) % NBUF], acc0, acc1);
         });
         sacc = acc0 + acc1;
+        if constexpr (BWD) sacc += s_G[w * 64 + lane];    // + Qn^T dR of this frame (written before barrier 1)
         DIAG_STAMP(3);
         publish_state(sacc);
         __syncthreads();
@@ -629,7 +713,7 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
     WsView ws;
     if (int rc = carve("scan_prep", workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
     if (int rc = gdkvm_check_device()) return rc;
-    PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, T, Hh, N, Dv, rule, flags};
+    PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, ws.kn, ws.wtT, ws.qnT, T, Hh, N, Dv, rule, flags};
     hipStream_t st = static_cast<hipStream_t>(stream);
     return io_dtype == GDKVM_F32 ? launch_prep_nb<GDKVM_F32>(ws.nb, pa, B * T * Hh, st)
                                  : launch_prep_nb<GDKVM_BF16>(ws.nb, pa, B * T * Hh, st);
@@ -642,7 +726,7 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
     if (int rc = check_common("scan_apply", B, T, Hh, N, Dk, Dv, io_dtype, flags)) return rc;
     if (B == 0) return GDKVM_OK;
     const bool have_tokens = T > 0 && N > 0;
-    WsView ws{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    WsView ws{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (have_tokens) {
         if (int rc = check_ptrs("scan_apply", {q, alpha, r_out, workspace}, {s_in, s_out, s_hist})) return rc;
         if (int rc = carve("scan_apply", const_cast<void*>(workspace), workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
@@ -661,16 +745,16 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
         }
         return GDKVM_OK;
     }
-    ScanArgs sa{q, alpha, s_in, ws.wt, ws.knT, ws.ut, ws.qinv, r_out, s_out, s_hist, ws.trash, T, Hh, N, Dv, flags, B * Hh};
+    ScanArgs sa{q, alpha, s_in, ws.wt, ws.knT, ws.ut, ws.qinv, r_out, s_out, s_hist, ws.trash, nullptr, nullptr, T, Hh, N, Dv, flags, B * Hh};
 #ifdef GDKVM_DIAG
     sa.diag = g_diag_buf;
 #endif
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
 #define GDKVM_SCAN_LAUNCH(IO, SV)                                                                         \
     switch (ws.nb) {                                                                                      \
-        case 4: hipLaunchKernelGGL((gdr_scan_kernel<IO, 4, SV>), grid, dim3(512), 0, st, sa); break;      \
-        case 8: hipLaunchKernelGGL((gdr_scan_kernel<IO, 8, SV>), grid, dim3(512), 0, st, sa); break;      \
-        default: hipLaunchKernelGGL((gdr_scan_kernel<IO, 16, SV>), grid, dim3(512), 0, st, sa); break;    \
+        case 4: hipLaunchKernelGGL((gdr_scan_kernel<IO, 4, SV, false>), grid, dim3(512), 0, st, sa); break;      \
+        case 8: hipLaunchKernelGGL((gdr_scan_kernel<IO, 8, SV, false>), grid, dim3(512), 0, st, sa); break;      \
+        default: hipLaunchKernelGGL((gdr_scan_kernel<IO, 16, SV, false>), grid, dim3(512), 0, st, sa); break;    \
     }
     if (io_dtype == GDKVM_F32) { if (s_hist) { GDKVM_SCAN_LAUNCH(GDKVM_F32, true) } else { GDKVM_SCAN_LAUNCH(GDKVM_F32, false) } }
     else { if (s_hist) { GDKVM_SCAN_LAUNCH(GDKVM_BF16, true) } else { GDKVM_SCAN_LAUNCH(GDKVM_BF16, false) } }
@@ -684,6 +768,23 @@ extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const
                               int B, int T, int Hh, int N, int Dk, int Dv,
                               int io_dtype, int rule, int flags, void* stream)
 {
+    if (s_hist) flags |= GDKVM_FLAG_TRAIN;              // the backward reads extra operand layouts from the workspace
     if (int rc = gdkvm_scan_prep(q, k, v, beta, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream)) return rc;
     return gdkvm_scan_apply(q, alpha, s_in, r_out, s_out, s_hist, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, flags, stream);
+}
+
+// Reverse-time recurrence of the backward pass on the forward kernel (BWD mode); called by gdkvm_scan_bwd.
+int gdr_launch_reverse_scan(const WsView& ws, const float* alpha, const void* d_r, const float* ds_out, float* ds_hist,
+                            float* ds_in, int B, int T, int Hh, int N, int Dv, int io_dtype, int flags, hipStream_t st)
+{
+    ScanArgs sa{nullptr, alpha, ds_out, ws.kn, ws.wtT, nullptr, nullptr, nullptr, ds_in, ds_hist, ws.trash, ws.qnT, d_r,
+                T, Hh, N, Dv, flags, B * Hh};
+#ifdef GDKVM_DIAG
+    sa.diag = nullptr;
+#endif
+    const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
+    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_scan_kernel<GDKVM_F32, 4, true, true>), grid, dim3(512), 0, st, sa);
+    else hipLaunchKernelGGL((gdr_scan_kernel<GDKVM_BF16, 4, true, true>), grid, dim3(512), 0, st, sa);
+    GDKVM_LAUNCH_CHECK("gdr_scan_kernel<BWD>");
+    return GDKVM_OK;
 }

@@ -2,103 +2,26 @@
 //
 // With the forward per frame   R = Qn S,  X = Wt S,  U = Ut - a X,  S' = a S + Kn^T U   (Wt = T b Kn, Ut = T b V):
 //
-//  gdr_bwd_scan_kernel   reverse-time recurrence on dS, one workgroup per (clip, head, 16-column slice) like the
-//                        forward scan -- it has the same shape:
-//                            dS = a (dS' - Wt^T (Kn dS')) + Qn^T dR
-//                        (two dependent products per frame + a state-independent term), exact fp32 MFMA, with the
-//                        accumulator-as-operand trick of the forward kernel.  Writes dS' of every frame (ds_hist).
+//  reverse scan          the reverse-time recurrence on dS has the shape of the forward one,
+//                            dS = a (dS' - Wt^T (Kn dS')) + Qn^T dR ,
+//                        and runs on the forward kernel itself in BWD mode (gdr_scan.hip: operand roles swapped, frames
+//                        visited last to first, read waves forming Qn^T dR).  Writes dS' of every frame (ds_hist).
 //  gdr_bwd_frame_kernel  everything else is frame-local given S (s_hist, saved by the forward) and dS' (ds_hist):
 //                            dU = Kn dS'   dKn = U dS'^T   dWt = -a dU S^T   dQn = dR S^T   da = <S,dS'> - <X,dU>
 //                            Z = T^T [dWt | dU]  (back substitution)   db, dV, dKn through diag(b) and A = tril(b Kn Kn^T)
 //                        then the L2-normalisation and sigmoid derivatives.  One workgroup per (clip, frame, head),
-//                        fully parallel over frames; fp32 VALU over LDS tiles (first version: written for clarity and
-//                        exactness, not yet for MFMA throughput -- the backward is ~17 MFLOP per frame).
+//                        fully parallel over frames; the eight 64x64x64 contractions run on exact-fp32 MFMA with both
+//                        operands read straight from padded LDS tiles, the back substitution on VALU.
 //
 // Derivation and its numpy restatement: oracle/bwd_ref.py (checked against autograd in tests/test_oracle_kat.py).
 #include "gdkvm_common.hpp"
 #include "gdr_ws.hpp"
 
+int gdr_launch_reverse_scan(const WsView& ws, const float* alpha, const void* d_r, const float* ds_out, float* ds_hist,
+                            float* ds_in, int B, int T, int Hh, int N, int Dv, int io_dtype, int flags, hipStream_t st);
+
 namespace {
 
-struct BwdScanArgs {
-    const void* q; const float* qinv; const float* knT; const float* wt; const float* alpha;
-    const void* d_r; const float* ds_out; float* ds_hist; float* ds_in;
-    int T, Hh, N, Dv, flags, nb;
-};
-
-template <int IO>
-__global__ __launch_bounds__(256) void gdr_bwd_scan_kernel(BwdScanArgs a)
-{
-    __shared__ __attribute__((aligned(16))) f32x4 s_D[4 * 64];                       // dS image (B operand)
-    __shared__ __attribute__((aligned(16))) f32x4 s_V[(GDKVM_MAX_N / 16) * 64];      // V' = -a Kn dS tiles
-
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nsl = a.Dv / 16, N = a.N, Hh = a.Hh, Dv = a.Dv, T = a.T, nb = a.nb, NP = 16 * a.nb;
-    const int bh = blockIdx.x / nsl, sl = blockIdx.x % nsl;
-    const int b = bh / Hh, h = bh % Hh;
-
-    f32x4 dacc = {0.f, 0.f, 0.f, 0.f};                    // rows 16w+4g+r of dS, column 16*sl + li
-    if (a.ds_out) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dacc[r] = a.ds_out[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li];
-    }
-    s_D[w * 64 + lane] = dacc;
-    __syncthreads();
-
-    for (int t = T - 1; t >= 0; --t) {
-        const size_t bt = (size_t)b * T + t, fh = bt * Hh + h;
-        float alpha = a.alpha[fh];
-        if (a.flags & GDKVM_FLAG_GATE_LOGITS) alpha = 1.0f / (1.0f + expf(-alpha));
-        const float* knT = a.knT + fh * GDKVM_DK * NP;
-        const float* wt = a.wt + fh * NP * GDKVM_DK;
-        const float* qinv = a.qinv + fh * NP;
-        {   // dS' of this frame (gradient w.r.t. the state after frame t)
-            float* hp = a.ds_hist + (fh * GDKVM_DK + 16 * w + 4 * g) * Dv + 16 * sl + li;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hp[(size_t)r * Dv] = dacc[r];
-        }
-        f32x4 dreg[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) dreg[m] = s_D[m * 64 + lane];
-        for (int tt = w; tt < nb; tt += 4) {              // Y = Kn dS' for token tile tt;  V' = -a Y
-            f32x4 y = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    y = mfma4(knT[(size_t)(16 * m + 4 * g + r) * NP + 16 * tt + li], dreg[m][r], y);
-            s_V[tt * 64 + lane] = y * (-alpha);
-        }
-        __syncthreads();
-        f32x4 acc = dacc * alpha;
-        for (int tt = 0; tt < nb; ++tt) {
-            const f32x4 vb = s_V[tt * 64 + lane];
-            f32x4 rb;                                      // dR[token 16tt+4g+r][col]  (B operand of Qn^T dR)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = 16 * tt + 4 * g + r;
-                rb[r] = n < N ? load1<IO>(a.d_r, ((bt * N + n) * Hh + h) * Dv + 16 * sl + li) : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = 16 * tt + 4 * g + r;         // A operands: column 16w+li of Wt / Qn, token n
-                acc = mfma4(wt[(size_t)n * GDKVM_DK + 16 * w + li], vb[r], acc);
-                const float qn = n < N ? load1<IO>(a.q, ((bt * N + n) * Hh + h) * GDKVM_DK + 16 * w + li) * qinv[n] : 0.f;
-                acc = mfma4(qn, rb[r], acc);
-            }
-        }
-        dacc = acc;
-        s_D[w * 64 + lane] = dacc;
-        __syncthreads();
-    }
-    if (a.ds_in) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a.ds_in[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li] = dacc[r];
-    }
-}
-
-// -------------------------------------------------------------------------------------------------------------
 struct BwdFrameArgs {
     const void* q; const void* k; const void* v; const float* alpha; const float* beta;
     const float* qinv; const float* knT; const float* wt; const float* ut;
@@ -107,28 +30,58 @@ struct BwdFrameArgs {
     int T, Hh, N, Dv, rule, flags;
 };
 
-constexpr int BF_LD = 65;                                  // padded leading dimension of the 64x64 LDS tiles
-constexpr int BF_TILE = 64 * BF_LD;
+constexpr int BF_LD = 68;                                  // leading dimension of the 64 x 64 LDS tiles: rows stay 16-byte
+constexpr int BF_TILE = 64 * BF_LD;                        // aligned (b128 operand reads) and shift by 4 banks per row
 
-__device__ __forceinline__ float quad_sum(float x)         // sum over the 4 adjacent lanes that share a row
+// acc[nt] += A[16mt .. +15, 0..63] * B over one 64-deep contraction, A row-major with k contiguous.
+//   BT = false:  B given as [k][col]   (one ds_read_b32 per MFMA)
+//   BT = true :  B given as [col][k]   (ds_read_b128, like A)
+// k is visited in the order 16kb + 4g + r on BOTH operands (the accumulator-as-operand permutation of the forward).
+template <bool BT>
+__device__ __forceinline__ void tile_gemm(f32x4 (&acc)[4], const float* A, const float* B, int mt, int li, int g)
 {
-    x += __shfl_xor(x, 1);
-    x += __shfl_xor(x, 2);
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(A + (16 * mt + li) * BF_LD + 16 * kb + 4 * g);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if constexpr (BT) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(B + (16 * nt + li) * BF_LD + 16 * kb + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[nt] = mfma4(a4[r], b4[r], acc[nt]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[nt] = mfma4(a4[r], B[(16 * kb + 4 * g + r) * BF_LD + 16 * nt + li], acc[nt]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float row16_sum(float x)        // sum over the 16 lanes (li) that hold one accumulator row
+{
+    x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
+    return x;
+}
+__device__ __forceinline__ float quad_sum(float x)         // sum over 4 adjacent lanes
+{
+    x += __shfl_xor(x, 1); x += __shfl_xor(x, 2);
     return x;
 }
 
+// One workgroup (4 waves) per (clip, frame, head).  Wave w owns the 16 x 64 row band w of every 64 x 64 result as four
+// accumulator tiles: element (reg r of tile nt, lane (li, g)) = [row 16w + 4g + r][col 16nt + li].
 template <int IO>
 __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* Kn = sm;                  float* Wt = sm + BF_TILE;        float* Qn = sm + 2 * BF_TILE;
-    float* bA = sm + 3 * BF_TILE;    float* bB = sm + 4 * BF_TILE;    float* bC = sm + 5 * BF_TILE;
-    float* bD = sm + 6 * BF_TILE;    float* bE = sm + 7 * BF_TILE;    float* bF = sm + 8 * BF_TILE;
-    float* s_beta = sm + 9 * BF_TILE; float* s_kinv = s_beta + 64;    float* s_qinv = s_kinv + 64;
+    float* Kn = sm;                  float* Wt = sm + BF_TILE;
+    float* b0 = sm + 2 * BF_TILE;    float* b1 = sm + 3 * BF_TILE;    float* b2 = sm + 4 * BF_TILE;
+    float* b3 = sm + 5 * BF_TILE;    float* b4 = sm + 6 * BF_TILE;    float* b5 = sm + 7 * BF_TILE;
+    float* s_beta = sm + 8 * BF_TILE; float* s_kinv = s_beta + 64;    float* s_qinv = s_kinv + 64;
     float* s_red = s_qinv + 64;                                       // 8 floats
 
-    const int tid = threadIdx.x;
-    const int row = tid >> 2, c0 = (tid & 3) * 16;         // this thread's 1 x 16 strip of every 64 x 64 result
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fh = blockIdx.x, h = fh % a.Hh;
     const size_t bt = fh / a.Hh;
     const int N = a.N, Hh = a.Hh, Dv = a.Dv, NP = 64, NB = 4;
@@ -136,8 +89,9 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
     const bool normalize = a.flags & GDKVM_FLAG_NORMALIZE_QK, logits = a.flags & GDKVM_FLAG_GATE_LOGITS;
     float alpha = a.alpha[fh];
     if (logits) alpha = 1.0f / (1.0f + expf(-alpha));
+    auto at = [&](int nt, int r) { return (16 * w + 4 * g + r) * BF_LD + 16 * nt + li; };   // LDS offset of an accumulator element
 
-    // ---- stage the frame's factors:  Kn (from Kn^T), Wt, Qn = q * qinv, gates, key norms ---------------------
+    // ---- stage the frame's factors:  Kn (from Kn^T), Wt, gates, key norms ---------------------------------
     if (tid < 64) {
         float bta = 0.f, kinv = 0.f;
         if (tid < N) {
@@ -155,59 +109,52 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
         }
         s_beta[tid] = bta; s_kinv[tid] = kinv; s_qinv[tid] = a.qinv[(size_t)fh * NP + tid];
     }
-    __syncthreads();
     for (int idx = tid; idx < 64 * 64; idx += 256) {
-        const int i = idx >> 6, d = idx & 63;              // token i, channel d
-        Wt[i * BF_LD + d] = a.wt[((size_t)fh * NP + i) * GDKVM_DK + d];
-        Kn[d * BF_LD + i] = a.knT[((size_t)fh * GDKVM_DK + i) * NP + d];       // idx = (channel i, token d) here
-        Qn[i * BF_LD + d] = i < N ? load1<IO>(a.q, ((bt * N + i) * Hh + h) * GDKVM_DK + d) * s_qinv[i] : 0.f;
+        const int i = idx >> 6, d = idx & 63;
+        Wt[i * BF_LD + d] = a.wt[((size_t)fh * NP + i) * GDKVM_DK + d];                 // token i, channel d
+        Kn[d * BF_LD + i] = a.knT[((size_t)fh * GDKVM_DK + i) * NP + d];               // (channel i, token d) here
     }
     __syncthreads();
 
-    float dKn[16], dWt[16], dQn[16];
+    f32x4 dKn[4], dWt[4], dQn[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dKn[j] = dWt[j] = dQn[j] = 0.f;
+    for (int nt = 0; nt < 4; ++nt) dKn[nt] = dWt[nt] = dQn[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float da = 0.f;
     const float* s_prev = a.s_hist + (size_t)fh * GDKVM_DK * Dv;
     const float* ds_now = a.ds_hist + (size_t)fh * GDKVM_DK * Dv;
     const f32x4* ut_img = reinterpret_cast<const f32x4*>(a.ut + (size_t)fh * NP * Dv);
     const int nchunk = (Dv + 63) / 64;
 
-    // load a 64 x CW chunk of [S ; dS' ; dR ; Ut] into bA / bB / bC / bD  (rows: channel d or token i; cols: chunk)
+    auto ut_at = [&](int i, int col) {                      // de-image: token i = 16I + 4g + r, column = 16ct + li
+        return ut_img[((size_t)(col >> 4) * NB + (i >> 4)) * 64 + ((i >> 2) & 3) * 16 + (col & 15)][i & 3];
+    };
+    // 64 x CW chunk of S -> b0, dS' -> b1, (dR -> b2), Ut -> b3   (rows: channel d or token i)
     auto load_chunk = [&](int cb, int CW, bool want_dr) {
         for (int idx = tid; idx < 64 * 64; idx += 256) {
             const int i = idx >> 6, c = idx & 63;
             const bool in = c < CW;
-            bA[i * BF_LD + c] = in ? s_prev[(size_t)i * Dv + cb + c] : 0.f;
-            bB[i * BF_LD + c] = in ? ds_now[(size_t)i * Dv + cb + c] : 0.f;
-            if (want_dr) bC[i * BF_LD + c] = (in && i < N) ? load1<IO>(a.d_r, ((bt * N + i) * Hh + h) * Dv + cb + c) : 0.f;
-            float u = 0.f;
-            if (in) {                                       // de-image: token i = 16I + 4g + r, column = 16ct + li
-                const int ct = (cb + c) >> 4, lane = ((i >> 2) & 3) * 16 + ((cb + c) & 15);
-                u = ut_img[((size_t)ct * NB + (i >> 4)) * 64 + lane][i & 3];
-            }
-            bD[i * BF_LD + c] = u;
+            b0[i * BF_LD + c] = in ? s_prev[(size_t)i * Dv + cb + c] : 0.f;
+            b1[i * BF_LD + c] = in ? ds_now[(size_t)i * Dv + cb + c] : 0.f;
+            if (want_dr) b2[i * BF_LD + c] = (in && i < N) ? load1<IO>(a.d_r, ((bt * N + i) * Hh + h) * Dv + cb + c) : 0.f;
+            b3[i * BF_LD + c] = in ? ut_at(i, cb + c) : 0.f;
         }
     };
-    // X = Wt S, U = Ut - a X (-> bD in place), dU = Kn dS' (-> bE); also the da partial of this thread's strip
+    // X = Wt S (registers), dU = Kn dS' -> b4, U = Ut - a X -> b3 in place; optionally the da partial
     auto xu_du = [&](bool want_da) {
-        float x[16], du[16];
+        f32x4 x[4], du[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) x[j] = du[j] = 0.f;
-        for (int d = 0; d < 64; ++d) {
-            const float wv = Wt[row * BF_LD + d], kv = Kn[row * BF_LD + d];
+        for (int nt = 0; nt < 4; ++nt) x[nt] = du[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        tile_gemm<false>(x, Wt, b0, w, li, g);
+        tile_gemm<false>(du, Kn, b1, w, li, g);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                x[j] += wv * bA[d * BF_LD + c0 + j];
-                du[j] += kv * bB[d * BF_LD + c0 + j];
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = at(nt, r);
+                if (want_da) da += b0[o] * b1[o] - x[nt][r] * du[nt][r];
+                b3[o] -= alpha * x[nt][r];
+                b4[o] = du[nt][r];
             }
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (want_da) da += bA[row * BF_LD + c0 + j] * bB[row * BF_LD + c0 + j] - x[j] * du[j];
-            bD[row * BF_LD + c0 + j] -= alpha * x[j];
-            bE[row * BF_LD + c0 + j] = du[j];
-        }
     };
 
     // ---- phase 1: contractions over Dv, 64 columns at a time --------------------------------------------------
@@ -217,22 +164,16 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
         __syncthreads();
         xu_du(true);
         __syncthreads();
-        for (int c = 0; c < CW; ++c) {
-            const float u = bD[row * BF_LD + c], du = bE[row * BF_LD + c], dr = bC[row * BF_LD + c];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float sp = bA[(c0 + j) * BF_LD + c];
-                dKn[j] += u * bB[(c0 + j) * BF_LD + c];
-                dWt[j] -= alpha * du * sp;
-                dQn[j] += dr * sp;
-            }
-        }
+        tile_gemm<true>(dKn, b3, b1, w, li, g);             // dKn += U dS'^T
+        tile_gemm<true>(dWt, b4, b0, w, li, g);             // dWt += dU S^T      (scaled by -a below)
+        tile_gemm<true>(dQn, b2, b0, w, li, g);             // dQn += dR S^T
         __syncthreads();
     }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) dWt[nt] *= -alpha;
     {   // d alpha
-        da = quad_sum(da);
-        for (int o = 4; o < 64; o <<= 1) da += __shfl_xor(da, o);
-        if ((tid & 63) == 0) s_red[tid >> 6] = da;
+        for (int o = 1; o < 64; o <<= 1) da += __shfl_xor(da, o);
+        if (lane == 0) s_red[w] = da;
         __syncthreads();
         if (tid == 0) {
             const float d = s_red[0] + s_red[1] + s_red[2] + s_red[3];
@@ -241,20 +182,19 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
     }
 
     // ---- phase 2: through T = (I + tril(b Kn Kn^T, -1))^-1 ---------------------------------------------------
-    float dA[16], dbeta = 0.f;
+    f32x4 dA[4];
+    float dbeta[4] = {0.f, 0.f, 0.f, 0.f};                  // per accumulator row r (token 16w + 4g + r), partial over li
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dA[j] = 0.f;
-    if (seq) {                                              // Gram matrix -> bF
-        float gm[16];
+    for (int nt = 0; nt < 4; ++nt) dA[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (seq) {                                              // Gram matrix -> b5
+        f32x4 gm[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) gm[j] = 0.f;
-        for (int d = 0; d < 64; ++d) {
-            const float kv = Kn[row * BF_LD + d];
+        for (int nt = 0; nt < 4; ++nt) gm[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        tile_gemm<true>(gm, Kn, Kn, w, li, g);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) gm[j] += kv * Kn[(c0 + j) * BF_LD + d];
-        }
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) bF[row * BF_LD + c0 + j] = gm[j];
+            for (int r = 0; r < 4; ++r) b5[at(nt, r)] = gm[nt][r];
     }
     __syncthreads();
     // column chunks of dY = [dWt | dU]:  cc = 0 is the key block (Y = Wt, X0 = Kn), cc >= 1 the value chunks
@@ -262,22 +202,18 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
         const int cb = 64 * (cc - 1), CW = cc == 0 ? 64 : min(64, Dv - cb);
         if (cc == 0) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) bE[row * BF_LD + c0 + j] = dWt[j];          // dY chunk -> bE
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b4[at(nt, r)] = dWt[nt][r];                  // dY chunk -> b4
         } else {
             load_chunk(cb, CW, false);
             __syncthreads();
-            xu_du(false);                                   // bE = dU chunk; bD = U chunk (need Ut: rebuilt below)
+            xu_du(false);                                   // b4 = dU chunk (b3 = U is rebuilt as Ut below)
             __syncthreads();
-            for (int idx = tid; idx < 64 * 64; idx += 256) {                          // Y chunk = Ut -> bD, X0 chunk = V -> bC
+            for (int idx = tid; idx < 64 * 64; idx += 256) {                             // Y chunk = Ut -> b3, X0 chunk = V -> b2
                 const int i = idx >> 6, c = idx & 63;
-                float u = 0.f, vv = 0.f;
-                if (c < CW) {
-                    const int ct = (cb + c) >> 4, lane = ((i >> 2) & 3) * 16 + ((cb + c) & 15);
-                    u = ut_img[((size_t)ct * NB + (i >> 4)) * 64 + lane][i & 3];
-                    if (i < N) vv = load1<IO>(a.v, ((bt * N + i) * Hh + h) * Dv + cb + c);
-                }
-                bD[i * BF_LD + c] = u;
-                bC[i * BF_LD + c] = vv;
+                b3[i * BF_LD + c] = c < CW ? ut_at(i, cb + c) : 0.f;
+                b2[i * BF_LD + c] = (c < CW && i < N) ? load1<IO>(a.v, ((bt * N + i) * Hh + h) * Dv + cb + c) : 0.f;
             }
         }
         __syncthreads();
@@ -286,9 +222,9 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
             const int c = tid >> 2, part = tid & 3;
             for (int i = 62; i >= 0; --i) {
                 float sacc = 0.f;
-                for (int j = i + 1 + part; j < 64; j += 4) sacc += s_beta[j] * bF[j * BF_LD + i] * bE[j * BF_LD + c];
+                for (int j = i + 1 + part; j < 64; j += 4) sacc += s_beta[j] * b5[j * BF_LD + i] * b4[j * BF_LD + c];
                 sacc = quad_sum(sacc);
-                if (part == 0) bE[i * BF_LD + c] -= sacc;
+                if (part == 0) b4[i * BF_LD + c] -= sacc;
                 // only the 4 adjacent lanes of this column read the row just written: order it inside the wave
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
@@ -296,69 +232,74 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
             }
             __syncthreads();                                // other waves own the other columns of Z
         }
-        // now bE = Z chunk.  d beta, d(X0) and dA
+        // now b4 = Z chunk.  d beta, d(X0) and dA
         {
-            const float bi = s_beta[row];
-            const float* X0 = cc == 0 ? Kn : bC;
-            const float* Y = cc == 0 ? Wt : bD;
+            const float* X0 = cc == 0 ? Kn : b2;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const float z = bE[row * BF_LD + c0 + j];
-                dbeta += z * X0[row * BF_LD + c0 + j];
-                if (cc == 0) dKn[j] += bi * z;
-                else if (c0 + j < CW && row < N) store1<IO>(a.d_v, ((bt * N + row) * Hh + h) * Dv + cb + c0 + j, bi * z);
-            }
-            if (seq)
-                for (int c = 0; c < CW; ++c) {
-                    const float z = bE[row * BF_LD + c];
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * w + 4 * g + r;
+                const float bi = s_beta[row];
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) dA[j] -= z * Y[(c0 + j) * BF_LD + c];
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int o = at(nt, r), col = 16 * nt + li;
+                    const float z = b4[o];
+                    dbeta[r] += z * X0[o];
+                    if (cc == 0) dKn[nt][r] += bi * z;
+                    else if (col < CW && row < N) store1<IO>(a.d_v, ((bt * N + row) * Hh + h) * Dv + cb + col, bi * z);
                 }
+            }
+            if (seq) tile_gemm<true>(dA, b4, cc == 0 ? Wt : b3, w, li, g);              // accumulates +Z Y^T; negated below
         }
         __syncthreads();
-    }
-    if (lin) {                                              // Wt == 0: the key block contributes nothing through T
-        // (dKn keeps only U dS'^T)
     }
     if (seq) {
-        const float bi = s_beta[row];
+        // M = diag(b) * tril(-Z Y^T, -1);  d beta += rowsum(tril(dA) * G);  dKn += (M + M^T) Kn
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const float m = (c0 + j < row) ? dA[j] : 0.f;   // strictly lower: column < row
-            dbeta += m * bF[row * BF_LD + c0 + j];
-            bE[row * BF_LD + c0 + j] = bi * m;              // M = diag(b) dA
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * w + 4 * g + r;
+            const float bi = s_beta[row];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float m = (16 * nt + li < row) ? -dA[nt][r] : 0.f;                  // strictly lower: column < row
+                dbeta[r] += m * b5[at(nt, r)];
+                b0[at(nt, r)] = bi * m;
+            }
         }
         __syncthreads();
-        for (int j2 = 0; j2 < 64; ++j2) {
-            const float m1 = bE[row * BF_LD + j2], m2 = bE[j2 * BF_LD + row];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) dKn[j] += (m1 + m2) * Kn[j2 * BF_LD + c0 + j];
-        }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) b1[at(nt, r)] = b0[at(nt, r)] + b0[(16 * nt + li) * BF_LD + 16 * w + 4 * g + r];
+        __syncthreads();
+        tile_gemm<false>(dKn, b1, Kn, w, li, g);
     }
     // ---- gates, L2 normalisation, stores ---------------------------------------------------------------------
-    dbeta = quad_sum(dbeta);
-    if ((tid & 3) == 0 && row < N) {
-        const float bi = s_beta[row];
-        a.d_beta[(bt * N + row) * Hh + h] = logits ? dbeta * bi * (1.f - bi) : dbeta;
+    for (int idx = tid; idx < 64 * 64; idx += 256) {                                     // Qn = q * qinv -> b2
+        const int i = idx >> 6, d = idx & 63;
+        b2[i * BF_LD + d] = i < N ? load1<IO>(a.q, ((bt * N + i) * Hh + h) * GDKVM_DK + d) * s_qinv[i] : 0.f;
     }
-    float dotk = 0.f, dotq = 0.f;
+    __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        dotk += Kn[row * BF_LD + c0 + j] * dKn[j];
-        dotq += Qn[row * BF_LD + c0 + j] * dQn[j];
-    }
-    dotk = quad_sum(dotk); dotq = quad_sum(dotq);
-    if (row < N) {
-        const float ki = s_kinv[row], qi = s_qinv[row];
+    for (int r = 0; r < 4; ++r) {
+        const int row = 16 * w + 4 * g + r;
+        const float db = row16_sum(dbeta[r]);
+        float dotk = 0.f, dotq = 0.f;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            float gk = dKn[j], gq = dQn[j];
-            if (normalize) {
-                gk = ki * (gk - Kn[row * BF_LD + c0 + j] * dotk);
-                gq = qi * (gq - Qn[row * BF_LD + c0 + j] * dotq);
+        for (int nt = 0; nt < 4; ++nt) { dotk += Kn[at(nt, r)] * dKn[nt][r]; dotq += b2[at(nt, r)] * dQn[nt][r]; }
+        dotk = row16_sum(dotk); dotq = row16_sum(dotq);
+        if (row < N) {
+            const float bi = s_beta[row], ki = s_kinv[row], qi = s_qinv[row];
+            if (li == 0) a.d_beta[(bt * N + row) * Hh + h] = logits ? db * bi * (1.f - bi) : db;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                float gk = dKn[nt][r], gq = dQn[nt][r];
+                if (normalize) {
+                    gk = ki * (gk - Kn[at(nt, r)] * dotk);
+                    gq = qi * (gq - b2[at(nt, r)] * dotq);
+                }
+                store1<IO>(a.d_k, ((bt * N + row) * Hh + h) * GDKVM_DK + 16 * nt + li, gk);
+                store1<IO>(a.d_q, ((bt * N + row) * Hh + h) * GDKVM_DK + 16 * nt + li, gq);
             }
-            store1<IO>(a.d_k, ((bt * N + row) * Hh + h) * GDKVM_DK + c0 + j, gk);
-            store1<IO>(a.d_q, ((bt * N + row) * Hh + h) * GDKVM_DK + c0 + j, gq);
         }
     }
 }
@@ -394,15 +335,12 @@ extern "C" int gdkvm_scan_bwd(const void* q, const void* k, const void* v, const
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* ds_hist = static_cast<float*>(bwd_workspace);
 
-    BwdScanArgs sa{q, ws.qinv, ws.knT, ws.wt, alpha, d_r, d_s_out, ds_hist, d_s_in, T, Hh, N, Dv, flags, ws.nb};
-    const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
-    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_bwd_scan_kernel<GDKVM_F32>), grid, dim3(256), 0, st, sa);
-    else hipLaunchKernelGGL((gdr_bwd_scan_kernel<GDKVM_BF16>), grid, dim3(256), 0, st, sa);
-    GDKVM_LAUNCH_CHECK("gdr_bwd_scan_kernel");
+    // reverse recurrence: the tuned forward kernel in BWD mode (operands from the training-mode workspace)
+    if (int rc = gdr_launch_reverse_scan(ws, alpha, d_r, d_s_out, ds_hist, d_s_in, B, T, Hh, N, Dv, io_dtype, flags, st)) return rc;
 
     BwdFrameArgs fa{q, k, v, alpha, beta, ws.qinv, ws.knT, ws.wt, ws.ut, s_hist, ds_hist, d_r,
                     d_q, d_k, d_v, d_alpha, d_beta, T, Hh, N, Dv, rule, flags};
-    const size_t lds = (size_t)(9 * BF_TILE + 3 * 64 + 8) * sizeof(float);
+    const size_t lds = (size_t)(8 * BF_TILE + 3 * 64 + 8) * sizeof(float);
     const void* fn = io_dtype == GDKVM_F32 ? reinterpret_cast<const void*>(gdr_bwd_frame_kernel<GDKVM_F32>)
                                            : reinterpret_cast<const void*>(gdr_bwd_frame_kernel<GDKVM_BF16>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -8,13 +8,14 @@ constexpr size_t GDKVM_WS_TAIL = 256;   // trash slot for padded read-out rows
 static inline int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
 
 // fp32 workspace per frame-head, NP = 16*nb padded tokens:  wt [NP][64] | knT [64][NP] | ut [Dv/16][nb][64][4] | qinv [NP]
-struct WsView { float* wt; float* knT; float* ut; float* qinv; char* trash; int nb; };
+// and, filled only by a training-mode prep (GDKVM_FLAG_TRAIN) for the backward:  kn [NP][64] | wtT [64][NP] | qnT [64][NP]
+struct WsView { float* wt; float* knT; float* ut; float* qinv; float* kn; float* wtT; float* qnT; char* trash; int nb; };
 
 static inline size_t gdr_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
 {
     if (B <= 0 || T <= 0 || Hh <= 0 || N <= 0 || Dk <= 0 || Dv <= 0 || N > GDKVM_MAX_N) return GDKVM_WS_TAIL;
     const size_t NP = 16 * (size_t)tiles_for(N);
-    return (size_t)B * T * Hh * NP * (2 * (size_t)Dk + Dv + 1) * sizeof(float) + GDKVM_WS_TAIL;
+    return (size_t)B * T * Hh * NP * (5 * (size_t)Dk + Dv + 1) * sizeof(float) + GDKVM_WS_TAIL;
 }
 
 static inline int carve(const char* fn, void* workspace, size_t workspace_bytes, int B, int T, int Hh, int N, int Dk, int Dv, WsView* v)
@@ -28,7 +29,10 @@ static inline int carve(const char* fn, void* workspace, size_t workspace_bytes,
     v->knT = v->wt + FH * NP * GDKVM_DK;
     v->ut = v->knT + FH * NP * GDKVM_DK;
     v->qinv = v->ut + FH * NP * Dv;
-    v->trash = reinterpret_cast<char*>(v->qinv + FH * NP);          // write-only slot for read-out rows of padding tokens
+    v->kn = v->qinv + FH * NP;
+    v->wtT = v->kn + FH * NP * GDKVM_DK;
+    v->qnT = v->wtT + FH * NP * GDKVM_DK;
+    v->trash = reinterpret_cast<char*>(v->qnT + FH * NP * GDKVM_DK);   // write-only slot for read-out rows of padding tokens
     return GDKVM_OK;
 }
 
@@ -40,7 +44,7 @@ static inline int check_common(const char* fn, int B, int T, int Hh, int N, int 
     if (Dv % 16 != 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: Dv=%d must be a multiple of 16", fn, Dv);
     if (N > GDKVM_MAX_N) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: N=%d exceeds %d tokens per frame", fn, N, GDKVM_MAX_N);
     if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "%s: io_dtype=%d", fn, io_dtype);
-    if (flags & ~3) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: unknown flags 0x%x", fn, flags);
+    if (flags & ~7) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: unknown flags 0x%x", fn, flags);
     return GDKVM_OK;
 }
 
