@@ -34,7 +34,7 @@ namespace {
 struct PrepArgs {
     const void* q; const void* k; const void* v; const float* beta;
     float* wt; float* knT; float* ut; float* qinv;
-    float* kn; float* wtT; float* qnT;                  // training mode only (GDKVM_FLAG_TRAIN)
+    float* kn; float* wtT; float* qnT; float* tii;      // training mode only (GDKVM_FLAG_TRAIN)
     int T, Hh, N, Dv, rule, flags;
 };
 
@@ -173,6 +173,11 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prep_kernel(PrepAr
                 float* Tm = reinterpret_cast<float*>(s_Tm + I * 64);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) Tm[((j >> 2) * 16 + i) * 4 + (j & 3)] = t[i];   // image of T[i][j]
+                if (a.flags & GDKVM_FLAG_TRAIN) {                                        // T_II row-major for the backward
+                    float* tg = a.tii + ((size_t)fh * NB + I) * 256;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) tg[i * 16 + j] = t[i];
+                }
             }
         }
         __syncthreads();
@@ -713,7 +718,7 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
     WsView ws;
     if (int rc = carve("scan_prep", workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
     if (int rc = gdkvm_check_device()) return rc;
-    PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, ws.kn, ws.wtT, ws.qnT, T, Hh, N, Dv, rule, flags};
+    PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, ws.kn, ws.wtT, ws.qnT, ws.tii, T, Hh, N, Dv, rule, flags};
     hipStream_t st = static_cast<hipStream_t>(stream);
     return io_dtype == GDKVM_F32 ? launch_prep_nb<GDKVM_F32>(ws.nb, pa, B * T * Hh, st)
                                  : launch_prep_nb<GDKVM_BF16>(ws.nb, pa, B * T * Hh, st);
@@ -726,7 +731,7 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
     if (int rc = check_common("scan_apply", B, T, Hh, N, Dk, Dv, io_dtype, flags)) return rc;
     if (B == 0) return GDKVM_OK;
     const bool have_tokens = T > 0 && N > 0;
-    WsView ws{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    WsView ws{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (have_tokens) {
         if (int rc = check_ptrs("scan_apply", {q, alpha, r_out, workspace}, {s_in, s_out, s_hist})) return rc;
         if (int rc = carve("scan_apply", const_cast<void*>(workspace), workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;

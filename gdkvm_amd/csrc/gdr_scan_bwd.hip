@@ -14,6 +14,8 @@
 //                        operands read straight from padded LDS tiles, the back substitution on VALU.
 //
 // Derivation and its numpy restatement: oracle/bwd_ref.py (checked against autograd in tests/test_oracle_kat.py).
+#include <type_traits>
+
 #include "gdkvm_common.hpp"
 #include "gdr_ws.hpp"
 
@@ -24,7 +26,7 @@ namespace {
 
 struct BwdFrameArgs {
     const void* q; const void* k; const void* v; const float* alpha; const float* beta;
-    const float* qinv; const float* knT; const float* wt; const float* ut;
+    const float* qinv; const float* knT; const float* wt; const float* ut; const float* tii;
     const float* s_hist; const float* ds_hist; const void* d_r;
     void* d_q; void* d_k; void* d_v; float* d_alpha; float* d_beta;
     int T, Hh, N, Dv, rule, flags;
@@ -57,6 +59,13 @@ __device__ __forceinline__ void tile_gemm(f32x4 (&acc)[4], const float* A, const
     }
 }
 
+template <int I, class F>
+__device__ __forceinline__ void static_for_desc(F&& f)     // f(I), f(I-1), ..., f(0) with compile-time indices
+{
+    f(std::integral_constant<int, I>{});
+    if constexpr (I > 0) static_for_desc<I - 1>(f);
+}
+
 __device__ __forceinline__ float row16_sum(float x)        // sum over the 16 lanes (li) that hold one accumulator row
 {
     x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
@@ -79,6 +88,7 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
     float* b3 = sm + 5 * BF_TILE;    float* b4 = sm + 6 * BF_TILE;    float* b5 = sm + 7 * BF_TILE;
     float* s_beta = sm + 8 * BF_TILE; float* s_kinv = s_beta + 64;    float* s_qinv = s_kinv + 64;
     float* s_red = s_qinv + 64;                                       // 8 floats
+    float* s_tii = s_red + 8;                                         // [4][16][16] diagonal-block inverses T_II
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,6 +119,7 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
         }
         s_beta[tid] = bta; s_kinv[tid] = kinv; s_qinv[tid] = a.qinv[(size_t)fh * NP + tid];
     }
+    for (int idx = tid; idx < NB * 256; idx += 256) s_tii[idx] = a.tii[(size_t)fh * NB * 256 + idx];
     for (int idx = tid; idx < 64 * 64; idx += 256) {
         const int i = idx >> 6, d = idx & 63;
         Wt[i * BF_LD + d] = a.wt[((size_t)fh * NP + i) * GDKVM_DK + d];                 // token i, channel d
@@ -218,18 +229,29 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
         }
         __syncthreads();
         if (seq) {
-            // Z = T^T dY:  z_i = dy_i - sum_{j>i} A_ji z_j, i descending; column = tid>>2, the j range split over 4 lanes
-            const int c = tid >> 2, part = tid & 3;
-            for (int i = 62; i >= 0; --i) {
-                float sacc = 0.f;
-                for (int j = i + 1 + part; j < 64; j += 4) sacc += s_beta[j] * b5[j * BF_LD + i] * b4[j * BF_LD + c];
-                sacc = quad_sum(sacc);
-                if (part == 0) b4[i * BF_LD + c] -= sacc;
-                // only the 4 adjacent lanes of this column read the row just written: order it inside the wave
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
+            // Z = T^T dY by blocked BACK substitution, the mirror image of the forward prep: wave w owns columns
+            // 16w..16w+15 (columns never interact); for I = 3..0:  Z_I = T_II^T (dY_I - sum_{J>I} A_JI^T Z_J), every
+            // solved Z_J staying in accumulator registers as the B operand of the next product (k = 4g + r).
+            f32x4 Z[4];
+            static_for_desc<3>([&](auto Ic) {
+                constexpr int I = decltype(Ic)::value;
+                f32x4 acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = b4[(16 * I + 4 * g + r) * BF_LD + 16 * w + li];
+#pragma unroll
+                for (int J = I + 1; J < 4; ++J)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = 16 * J + 4 * g + r;                               // A = -A_JI^T[i = li][j]
+                        acc = mfma4(-s_beta[j] * b5[j * BF_LD + 16 * I + li], Z[J][r], acc);
+                    }
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z = mfma4(s_tii[I * 256 + (4 * g + r) * 16 + li], acc[r], z);   // T_II^T[li][4g+r]
+                Z[I] = z;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b4[(16 * I + 4 * g + r) * BF_LD + 16 * w + li] = z[r];
+            });
             __syncthreads();                                // other waves own the other columns of Z
         }
         // now b4 = Z chunk.  d beta, d(X0) and dA
@@ -338,9 +360,9 @@ extern "C" int gdkvm_scan_bwd(const void* q, const void* k, const void* v, const
     // reverse recurrence: the tuned forward kernel in BWD mode (operands from the training-mode workspace)
     if (int rc = gdr_launch_reverse_scan(ws, alpha, d_r, d_s_out, ds_hist, d_s_in, B, T, Hh, N, Dv, io_dtype, flags, st)) return rc;
 
-    BwdFrameArgs fa{q, k, v, alpha, beta, ws.qinv, ws.knT, ws.wt, ws.ut, s_hist, ds_hist, d_r,
+    BwdFrameArgs fa{q, k, v, alpha, beta, ws.qinv, ws.knT, ws.wt, ws.ut, ws.tii, s_hist, ds_hist, d_r,
                     d_q, d_k, d_v, d_alpha, d_beta, T, Hh, N, Dv, rule, flags};
-    const size_t lds = (size_t)(8 * BF_TILE + 3 * 64 + 8) * sizeof(float);
+    const size_t lds = (size_t)(8 * BF_TILE + 3 * 64 + 8 + 4 * 256) * sizeof(float);
     const void* fn = io_dtype == GDKVM_F32 ? reinterpret_cast<const void*>(gdr_bwd_frame_kernel<GDKVM_F32>)
                                            : reinterpret_cast<const void*>(gdr_bwd_frame_kernel<GDKVM_BF16>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

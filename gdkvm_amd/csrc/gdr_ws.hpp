@@ -9,13 +9,14 @@ static inline int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
 
 // fp32 workspace per frame-head, NP = 16*nb padded tokens:  wt [NP][64] | knT [64][NP] | ut [Dv/16][nb][64][4] | qinv [NP]
 // and, filled only by a training-mode prep (GDKVM_FLAG_TRAIN) for the backward:  kn [NP][64] | wtT [64][NP] | qnT [64][NP]
-struct WsView { float* wt; float* knT; float* ut; float* qinv; float* kn; float* wtT; float* qnT; char* trash; int nb; };
+// | tii [nb][16][16] (the diagonal-block inverses T_II)
+struct WsView { float* wt; float* knT; float* ut; float* qinv; float* kn; float* wtT; float* qnT; float* tii; char* trash; int nb; };
 
 static inline size_t gdr_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
 {
     if (B <= 0 || T <= 0 || Hh <= 0 || N <= 0 || Dk <= 0 || Dv <= 0 || N > GDKVM_MAX_N) return GDKVM_WS_TAIL;
     const size_t NP = 16 * (size_t)tiles_for(N);
-    return (size_t)B * T * Hh * NP * (5 * (size_t)Dk + Dv + 1) * sizeof(float) + GDKVM_WS_TAIL;
+    return (size_t)B * T * Hh * NP * (5 * (size_t)Dk + Dv + 1 + 16) * sizeof(float) + GDKVM_WS_TAIL;
 }
 
 static inline int carve(const char* fn, void* workspace, size_t workspace_bytes, int B, int T, int Hh, int N, int Dk, int Dv, WsView* v)
@@ -32,7 +33,8 @@ static inline int carve(const char* fn, void* workspace, size_t workspace_bytes,
     v->kn = v->qinv + FH * NP;
     v->wtT = v->kn + FH * NP * GDKVM_DK;
     v->qnT = v->wtT + FH * NP * GDKVM_DK;
-    v->trash = reinterpret_cast<char*>(v->qnT + FH * NP * GDKVM_DK);   // write-only slot for read-out rows of padding tokens
+    v->tii = v->qnT + FH * NP * GDKVM_DK;
+    v->trash = reinterpret_cast<char*>(v->tii + FH * NP * 16);   // write-only slot for read-out rows of padding tokens
     return GDKVM_OK;
 }
 
