@@ -26,7 +26,7 @@ namespace {
 
 struct BwdFrameArgs {
     const void* q; const void* k; const void* v; const float* alpha; const float* beta;
-    const float* qinv; const float* knT; const float* wt; const float* ut; const float* tii;
+    const float* qinv; const float* kn; const float* wt; const float* ut; const float* tii;
     const float* s_hist; const float* ds_hist; const void* d_r;
     void* d_q; void* d_k; void* d_v; float* d_alpha; float* d_beta;
     int T, Hh, N, Dv, rule, flags;
@@ -120,10 +120,11 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
         s_beta[tid] = bta; s_kinv[tid] = kinv; s_qinv[tid] = a.qinv[(size_t)fh * NP + tid];
     }
     for (int idx = tid; idx < NB * 256; idx += 256) s_tii[idx] = a.tii[(size_t)fh * NB * 256 + idx];
-    for (int idx = tid; idx < 64 * 64; idx += 256) {
-        const int i = idx >> 6, d = idx & 63;
-        Wt[i * BF_LD + d] = a.wt[((size_t)fh * NP + i) * GDKVM_DK + d];                 // token i, channel d
-        Kn[d * BF_LD + i] = a.knT[((size_t)fh * GDKVM_DK + i) * NP + d];               // (channel i, token d) here
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                           // Wt and Kn (the training prep's natural-layout copy) rows
+        const int e = tid + 256 * u, i = e >> 4, d = (e & 15) * 4;
+        *reinterpret_cast<f32x4*>(Wt + i * BF_LD + d) = *reinterpret_cast<const f32x4*>(a.wt + ((size_t)fh * NP + i) * GDKVM_DK + d);
+        *reinterpret_cast<f32x4*>(Kn + i * BF_LD + d) = *reinterpret_cast<const f32x4*>(a.kn + ((size_t)fh * NP + i) * GDKVM_DK + d);
     }
     __syncthreads();
 
@@ -136,19 +137,49 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
     const f32x4* ut_img = reinterpret_cast<const f32x4*>(a.ut + (size_t)fh * NP * Dv);
     const int nchunk = (Dv + 63) / 64;
 
-    auto ut_at = [&](int i, int col) {                      // de-image: token i = 16I + 4g + r, column = 16ct + li
-        return ut_img[((size_t)(col >> 4) * NB + (i >> 4)) * 64 + ((i >> 2) & 3) * 16 + (col & 15)][i & 3];
+    // Staging helpers: every thread issues all of its 16-byte loads back to back (a `for idx += 256` loop of scalar loads
+    // serialises on memory latency: 16 round trips per call).
+    auto load4io = [&](const void* base, size_t off) { return load4<IO>(base, off); };
+    // Ut chunk (column tiles cb/16 .. ) -> dst, read in image order: one float4 = 4 tokens (r) of one column
+    auto load_ut = [&](float* dst, int cb, int CW) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u;                      // (ct_local, I, lane)
+            const int ln = e & 63, I = (e >> 6) & 3, ctl = e >> 8;
+            const bool in = 16 * ctl < CW;
+            const f32x4 v4 = ut_img[((size_t)((cb >> 4) + (in ? ctl : 0)) * NB + I) * 64 + ln];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(16 * I + 4 * (ln >> 4) + r) * BF_LD + 16 * ctl + (ln & 15)] = in ? v4[r] : 0.f;
+        }
+    };
+    // rows x 64-column chunk of a row-major fp32 matrix [64][Dv] -> dst
+    auto load_rows_f32 = [&](float* dst, const float* src, int cb, int CW) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u, i = e >> 4, c = (e & 15) * 4;
+            const bool in = c < CW;
+            f32x4 v4 = *reinterpret_cast<const f32x4*>(src + (size_t)i * Dv + cb + (in ? c : 0));
+            if (!in) v4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(dst + i * BF_LD + c) = v4;
+        }
+    };
+    // token rows x 64-column chunk of an I/O tensor [N][Hh][C] (C = Dv or Dk) -> dst, optionally scaled per row
+    auto load_rows_io = [&](float* dst, const void* src, int C, int cb, int CW, const float* rowscale) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + 256 * u, i = e >> 4, c = (e & 15) * 4;
+            const bool in = c < CW && i < N;
+            f32x4 v4 = load4io(src, ((bt * N + min(i, N - 1)) * Hh + h) * C + cb + (c < CW ? c : 0));
+            const float sc = in ? (rowscale ? rowscale[i] : 1.f) : 0.f;
+            *reinterpret_cast<f32x4*>(dst + i * BF_LD + c) = v4 * sc;
+        }
     };
     // 64 x CW chunk of S -> b0, dS' -> b1, (dR -> b2), Ut -> b3   (rows: channel d or token i)
     auto load_chunk = [&](int cb, int CW, bool want_dr) {
-        for (int idx = tid; idx < 64 * 64; idx += 256) {
-            const int i = idx >> 6, c = idx & 63;
-            const bool in = c < CW;
-            b0[i * BF_LD + c] = in ? s_prev[(size_t)i * Dv + cb + c] : 0.f;
-            b1[i * BF_LD + c] = in ? ds_now[(size_t)i * Dv + cb + c] : 0.f;
-            if (want_dr) b2[i * BF_LD + c] = (in && i < N) ? load1<IO>(a.d_r, ((bt * N + i) * Hh + h) * Dv + cb + c) : 0.f;
-            b3[i * BF_LD + c] = in ? ut_at(i, cb + c) : 0.f;
-        }
+        load_rows_f32(b0, s_prev, cb, CW);
+        load_rows_f32(b1, ds_now, cb, CW);
+        if (want_dr) load_rows_io(b2, a.d_r, Dv, cb, CW, nullptr);
+        load_ut(b3, cb, CW);
     };
     // X = Wt S (registers), dU = Kn dS' -> b4, U = Ut - a X -> b3 in place; optionally the da partial
     auto xu_du = [&](bool want_da) {
@@ -221,11 +252,8 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
             __syncthreads();
             xu_du(false);                                   // b4 = dU chunk (b3 = U is rebuilt as Ut below)
             __syncthreads();
-            for (int idx = tid; idx < 64 * 64; idx += 256) {                             // Y chunk = Ut -> b3, X0 chunk = V -> b2
-                const int i = idx >> 6, c = idx & 63;
-                b3[i * BF_LD + c] = c < CW ? ut_at(i, cb + c) : 0.f;
-                b2[i * BF_LD + c] = (c < CW && i < N) ? load1<IO>(a.v, ((bt * N + i) * Hh + h) * Dv + cb + c) : 0.f;
-            }
+            load_ut(b3, cb, CW);                             // Y chunk = Ut -> b3
+            load_rows_io(b2, a.v, Dv, cb, CW, nullptr);      // X0 chunk = V -> b2
         }
         __syncthreads();
         if (seq) {
@@ -296,10 +324,7 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
         tile_gemm<false>(dKn, b1, Kn, w, li, g);
     }
     // ---- gates, L2 normalisation, stores ---------------------------------------------------------------------
-    for (int idx = tid; idx < 64 * 64; idx += 256) {                                     // Qn = q * qinv -> b2
-        const int i = idx >> 6, d = idx & 63;
-        b2[i * BF_LD + d] = i < N ? load1<IO>(a.q, ((bt * N + i) * Hh + h) * GDKVM_DK + d) * s_qinv[i] : 0.f;
-    }
+    load_rows_io(b2, a.q, GDKVM_DK, 0, 64, s_qinv);                                     // Qn = q * qinv -> b2
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -360,7 +385,7 @@ extern "C" int gdkvm_scan_bwd(const void* q, const void* k, const void* v, const
     // reverse recurrence: the tuned forward kernel in BWD mode (operands from the training-mode workspace)
     if (int rc = gdr_launch_reverse_scan(ws, alpha, d_r, d_s_out, ds_hist, d_s_in, B, T, Hh, N, Dv, io_dtype, flags, st)) return rc;
 
-    BwdFrameArgs fa{q, k, v, alpha, beta, ws.qinv, ws.knT, ws.wt, ws.ut, ws.tii, s_hist, ds_hist, d_r,
+    BwdFrameArgs fa{q, k, v, alpha, beta, ws.qinv, ws.kn, ws.wt, ws.ut, ws.tii, s_hist, ds_hist, d_r,
                     d_q, d_k, d_v, d_alpha, d_beta, T, Hh, N, Dv, rule, flags};
     const size_t lds = (size_t)(8 * BF_TILE + 3 * 64 + 8 + 4 * 256) * sizeof(float);
     const void* fn = io_dtype == GDKVM_F32 ? reinterpret_cast<const void*>(gdr_bwd_frame_kernel<GDKVM_F32>)
