@@ -46,6 +46,22 @@ def scan_algorithmic_bytes(B, T, N, Hh, Dk, Dv, s):
     return B * T * (s * N * (2 * ck + 2 * cv) + 4 * Hh * (1 + N)) + B * 2 * 4 * Hh * Dk * Dv
 
 
+def committed_traffic():
+    """HBM bytes per gdkvm_scan_fwd launch pair from the newest committed PMC summary (profiles/*_pmc_hbm.csv: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  PMC counters
+    cannot be collected from inside this process, so the bench line quotes the committed measurement and names it."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")))
+    if not files:
+        return None, None
+    total = 0.0
+    for row in csv.DictReader(l for l in open(files[-1]) if not l.startswith("#")):
+        if row["Kernel"].startswith(("gdr_prep_kernel", "gdr_scan_kernel")):
+            total += float(row["hbm_bytes_read_x2"])
+    return (int(total) if total else None), os.path.relpath(files[-1], ROOT)
+
+
 def time_events(fn, iters, warmup=3):
     for _ in range(warmup):
         fn()
@@ -204,9 +220,10 @@ def main():
                                  args.kernel_iters)
         alg = scan_algorithmic_bytes(B, T, N, Hh, Dk, Dv, 2)
         achieved = alg / (both_ms * 1e-3) / 1e9
+        traffic, traffic_src = committed_traffic() if (B, T, S) == (16, 32, 112) else (None, None)
         out["roofline"] = {"kernel": "gdr_prep_kernel+gdr_scan_kernel (one gdkvm_scan_fwd)", "bound": "hbm",
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                            "algorithmic_bytes": alg, "avg_ms": {"gdr_prep_kernel": round(prep_ms, 4),
                                                                 "gdr_scan_kernel": round(scan_ms, 4),
                                                                 "scan_fwd_total": round(both_ms, 4)}}
