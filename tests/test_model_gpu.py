@@ -103,3 +103,28 @@ def test_module_gradients_match_cpu_reference(hip):
         worst = max(worst, err)
         assert err <= 2e-3, (n, err, scale)
     assert worst > 0
+
+
+def test_train_and_eval_entry_points(hip, tmp_path):
+    """Row n2 smoke: a few optimisation steps through train.py (HIP forward + backward kernels), a checkpoint, then eval.py
+    on it; the loss must drop and the evaluation must print per-class Dice."""
+    import json
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["data.size=64", "data.frames=4", "data.num_classes=2", "batch_size=4", f"run_dir={tmp_path}", "log_every=5",
+              "model.value_dim=64"]
+    out = subprocess.run([sys.executable, os.path.join(root, "train.py"), "num_iterations=30", "save_every=30", "learning_rate=1e-3"] + common,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    losses = [float(l.split("loss")[1].split()[0]) for l in out.stdout.splitlines() if l.startswith("step")]
+    assert len(losses) == 6 and losses[-1] < losses[0], losses
+    ck = os.path.join(tmp_path, "gdkvm_step30.pth")
+    assert os.path.exists(ck)
+    ev = subprocess.run([sys.executable, os.path.join(root, "eval.py"), "--weights", ck, "eval_stage.num_vis=1"] + common,
+                        capture_output=True, text=True, timeout=600)
+    assert ev.returncode == 0, ev.stderr[-2000:]
+    res = json.loads(ev.stdout.strip().splitlines()[-1])
+    assert len(res["dice_per_class"]) == 2 and 0.0 <= res["mean_foreground_dice"] <= 1.0
+    assert os.listdir(os.path.join(tmp_path, "vis"))

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Training entry point: one process per GPU under torchrun, DDP gradient all-reduce over RCCL.
+
+    python train.py --config config/config_gdkvm_01.yaml [key=value ...]                       # one GPU
+    torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 train.py --config ... # one node
+
+Mirrors the recipe the reference's guide shows (batch_size 8, learning_rate 1e-4, num_iterations 3000, offline metrics,
+weights under outputs/): /root/reference/website/src/pages/[lang]/reprod/index.astro:238-269."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default=os.path.join(ROOT, "config", "config_gdkvm_01.yaml"))
+    ap.add_argument("--resume", default="")
+    ap.add_argument("overrides", nargs="*")
+    args = ap.parse_args(argv)
+
+    from gdkvm_amd import ops
+    from gdkvm_amd.config import load_config
+    from gdkvm_amd.data import build_dataset
+    from gdkvm_amd.distributed import init_from_env
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    from gdkvm_amd.runlog import OfflineRun
+    from gdkvm_amd.train import train_step, wrap_ddp
+
+    cfg = load_config(args.config, args.overrides)
+    ops.require_native()
+    rank, world, local = init_from_env()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(cfg.seed)                                   # identical initial weights on every rank
+
+    mcfg = GDKVMConfig(num_classes=cfg.data.num_classes, heads=cfg.model.heads, value_dim=cfg.model.value_dim, rule=cfg.model.rule)
+    model = GDKVM(mcfg).train().to(dev).to(memory_format=torch.channels_last)
+    opt = torch.optim.AdamW(model.parameters(), lr=cfg.learning_rate)
+    step0 = 0
+    if args.resume:
+        ck = torch.load(args.resume, map_location=dev)
+        model.load_state_dict(ck["model"]); opt.load_state_dict(ck["optimizer"]); step0 = ck["step"]
+    ddp = wrap_ddp(model, dev)
+
+    ds = build_dataset(cfg, "train")
+    sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=True, seed=cfg.seed) if world > 1 else None
+    dl = torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, sampler=sampler, shuffle=sampler is None, drop_last=True,
+                                     num_workers=2, persistent_workers=True)
+    run = OfflineRun(cfg.run_dir, cfg.to_dict(), cfg.eval_stage.wandb_mode, enabled=rank == 0)
+    amp = torch.bfloat16 if cfg.precision == "bf16" else None
+
+    step, epoch, t_log = step0, 0, time.perf_counter()
+    while step < cfg.num_iterations:
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        for frames, target in dl:
+            loss = train_step(ddp, opt, frames.to(dev, non_blocking=True), target.to(dev, non_blocking=True), amp)
+            step += 1
+            if step % cfg.log_every == 0 and rank == 0:
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t_log; t_log = time.perf_counter()
+                fps = world * cfg.batch_size * cfg.data.frames * cfg.log_every / dt
+                run.log(step, loss=float(loss), frames_per_s=fps)
+                print(f"step {step:6d}  loss {float(loss):.4f}  {fps:9.0f} frames/s", flush=True)
+            if (step % cfg.save_every == 0 or step == cfg.num_iterations) and rank == 0:
+                os.makedirs(cfg.run_dir, exist_ok=True)
+                torch.save({"model": model.state_dict(), "optimizer": opt.state_dict(), "step": step, "config": cfg.to_dict()},
+                           os.path.join(cfg.run_dir, f"gdkvm_step{step}.pth"))
+            if step >= cfg.num_iterations:
+                break
+        epoch += 1
+    run.close()
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
