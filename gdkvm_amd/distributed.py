@@ -51,3 +51,38 @@ def gather_clips(local: torch.Tensor, n_total: int) -> torch.Tensor:
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], 0)
+
+
+def context_parallel_scan(q, k, v, alpha, beta, state=None, rule: int = 2, flags: int = 0, backend=None):
+    """Sequence-parallel scan of clips whose TIME axis is sharded over the ranks of the default process group (rank r holds
+    frames [r*T_local, (r+1)*T_local) of every clip) -- SURVEY.md §8f row n3.
+
+    Each rank computes, for its frames only, the state-transition matrix Phi_r and the zero-start end state S_loc_r
+    (gdkvm_scan_prep + gdkvm_scan_transition + gdkvm_scan_apply without read-out), ONE all-gather exchanges them
+    ([B,Hh,Dk,Dk+Dv] fp32 per rank: 80 KB per clip-head at Dk=64, Dv=256), every rank folds the maps of the ranks before it
+    into its true start state, S_start_r = Phi_{r-1}(...Phi_0 S_0 + S_loc_0...) + S_loc_{r-1}, and scans its frames from
+    there, reusing its prepared workspace.  Returns (R_local, S_final) with S_final identical on every rank.
+    ``backend`` defaults to gdkvm_amd.ops (HIP); tests inject a CPU implementation of the same three calls."""
+    if backend is None:
+        from . import ops as backend
+    B, T, N, Hh, Dk = q.shape
+    Dv = v.shape[-1]
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    ws = backend.new_workspace(B, T, Hh, N, Dk, Dv, q.device)
+    backend.scan_prep(q, k, v, beta, ws, rule=rule, flags=flags)
+    cur = state if state is not None else torch.zeros((B, Hh, Dk, Dv), dtype=torch.float32, device=q.device)
+    if world > 1:
+        phi = backend.scan_transition(q, alpha, ws, Dv, flags=flags)
+        _, s_loc = backend.scan_apply(q, alpha, ws, Dv, flags=flags, want_readout=False)
+        mine = torch.cat([phi, s_loc], -1).contiguous()                      # [B,Hh,Dk,Dk+Dv]
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                                         # the only exchange of the whole scan
+        start = None
+        for r in range(world):
+            if r == rank:
+                start = cur
+            cur = torch.matmul(every[r][..., :Dk], cur) + every[r][..., Dk:]
+        r_local, _ = backend.scan_apply(q, alpha, ws, Dv, state=start.contiguous(), flags=flags)
+        return r_local, cur
+    return backend.scan_apply(q, alpha, ws, Dv, state=cur if state is not None else None, flags=flags)

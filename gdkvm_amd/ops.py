@@ -219,6 +219,10 @@ def scan_prep(q, k, v, beta, workspace, rule=RULE_DELTA_SEQUENTIAL, flags=0):
     _check(rc, "gdkvm_scan_prep")
 
 
+def new_workspace(B, T, Hh, N, Dk, Dv, device) -> torch.Tensor:
+    return torch.empty(scan_workspace_bytes(B, T, Hh, N, Dk, Dv), dtype=torch.uint8, device=device)
+
+
 def scan_transition(q, alpha, workspace, Dv, flags=0):
     """State-transition matrix Phi [B,Hh,Dk,Dk] of the frames prepared in ``workspace`` (gdkvm_scan_transition):
     S_out = Phi @ S_in + S_loc for these frames."""

@@ -98,3 +98,13 @@ def test_segmented_scan_cfg5_shape_bf16(hip):
     R2, S2 = hip.scan_fwd_segmented(*t, segments=8, flags=3)
     assert (S - S2).abs().max() <= 1e-4
     assert ((R.float() - R2.float()).abs() <= 1e-4 + R.float().abs() * 2.0 ** -7).all()
+
+
+def test_context_parallel_scan_single_rank_hip_backend(hip):
+    """The cross-GPU stitch with the HIP backend and a world of one degenerates to a plain scan (bit for bit)."""
+    from gdkvm_amd.distributed import context_parallel_scan
+    q, k, v, a, b = make_scan_inputs(2, 5, 49, 1, 64, 32, seed=12, normalized=False, logits=True)
+    t = [_dev(x) for x in (q, k, v, a, b)]
+    R, S = hip.scan_fwd(*t, flags=3)
+    R2, S2 = context_parallel_scan(*t, flags=3)
+    assert torch.equal(R, R2) and torch.equal(S, S2)

@@ -4,6 +4,7 @@ may use the oracle) and gather; the result must equal the single-process run bit
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.multiprocessing as mp
@@ -126,3 +127,67 @@ def _ddp_worker_frozen(rank, world, port, frames, target, state, out):
         out.put({n: p.grad.numpy().copy() for n, p in model.named_parameters() if p.grad is not None})
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
+
+
+class _OracleBackend:
+    """CPU stand-in for gdkvm_amd.ops in context_parallel_scan: the same three calls, computed with the numpy oracle
+    (the transition matrix as the scan of an identity state with zero values)."""
+
+    @staticmethod
+    def new_workspace(B, T, Hh, N, Dk, Dv, device):
+        return {}
+
+    @staticmethod
+    def scan_prep(q, k, v, beta, ws, rule=2, flags=0):
+        ws.update(k=k.numpy(), v=v.numpy(), beta=beta.numpy(), rule=rule)
+
+    @staticmethod
+    def scan_transition(q, alpha, ws, Dv, flags=0):
+        from oracle import gdkvm_oracle as O
+        Dk = q.shape[-1]
+        eye = np.broadcast_to(np.eye(Dk), (q.shape[0], q.shape[3], Dk, Dk)).copy()
+        _, phi = O.scan(q.numpy(), ws["k"], np.zeros(ws["v"].shape[:-1] + (Dk,)), alpha.numpy(), ws["beta"], s0=eye, rule=ws["rule"], flags=flags)
+        return torch.from_numpy(phi).float()
+
+    @staticmethod
+    def scan_apply(q, alpha, ws, Dv, state=None, flags=0, want_readout=True):
+        from oracle import gdkvm_oracle as O
+        R, S = O.scan(q.numpy(), ws["k"], ws["v"], alpha.numpy(), ws["beta"], s0=None if state is None else state.numpy(),
+                      rule=ws["rule"], flags=flags)
+        return (torch.from_numpy(R).float() if want_readout else None), torch.from_numpy(S).float()
+
+
+def _cp_worker(rank, world, port, arrs, s0, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from gdkvm_amd.distributed import context_parallel_scan, init_from_env
+    init_from_env("gloo")
+    T = arrs[0].shape[1]
+    lo, hi = shard_range(T, world, rank)
+    q, k, v, a, b = (torch.from_numpy(np.ascontiguousarray(x[:, lo:hi])) for x in arrs)
+    r, s = context_parallel_scan(q, k, v, a, b, torch.from_numpy(s0), rule=2, flags=3, backend=_OracleBackend)
+    out.put((rank, r.numpy(), s.numpy()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_context_parallel_scan_two_ranks():
+    """Time-sharded clips over 2 gloo ranks: read-outs of both halves and the final state equal the single-process scan."""
+    from oracle import gdkvm_oracle as O
+    from tests.util import make_scan_inputs
+    arrs = make_scan_inputs(2, 6, 9, 2, 8, 5, seed=70, normalized=False, logits=True)
+    s0 = np.random.default_rng(71).standard_normal((2, 2, 8, 5)).astype(np.float32)
+    R, S = O.scan(*arrs, s0=s0, rule=2, flags=3)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_cp_worker, args=(r, 2, port, arrs, s0, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((rk, (r, s)) for rk, r, s in (out.get(timeout=240) for _ in range(2)))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    np.testing.assert_allclose(np.concatenate([got[0][0], got[1][0]], 1), R, atol=1e-5)
+    np.testing.assert_allclose(got[0][1], S, atol=1e-5); np.testing.assert_allclose(got[1][1], S, atol=1e-5)
