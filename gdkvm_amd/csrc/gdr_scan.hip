@@ -34,7 +34,8 @@ namespace {
 struct PrepArgs {
     const void* q; const void* k; const void* v; const float* beta;
     float* wt; float* knT; float* ut; float* qinv;
-    float* kn; float* wtT; float* qnT; float* tii;      // training mode only (GDKVM_FLAG_TRAIN)
+    float* kn; float* wtT; float* qnT; float* tii;      // training mode only (GDKVM_FLAG_TRAIN); so is wt
+    float* wti;                                         // Wt as accumulator images, for the fold kernel
     int T, Hh, N, Dv, rule, flags;
 };
 
@@ -185,6 +186,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prep_kernel(PrepAr
 
     // ---- phase 3: blocked forward substitution entirely in accumulators, TPR column tiles interleaved ----
     float* wt = a.wt + (size_t)fh * NP * GDKVM_DK;
+    f32x4* wti = reinterpret_cast<f32x4*>(a.wti) + (size_t)fh * NP * GDKVM_DK / 4;
     float* knT = a.knT + (size_t)fh * GDKVM_DK * NP;
     f32x4* ut = reinterpret_cast<f32x4*>(a.ut + (size_t)fh * NP * Dv);
     const bool train = a.flags & GDKVM_FLAG_TRAIN;
@@ -254,9 +256,12 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prep_kernel(PrepAr
                 Y[i][I] = acc[i];
                 if (c < ntile) {
                     if (isK) {
+                        wti[((size_t)c * NB + I) * 64 + lane] = acc[i];
+                        if (train) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) wt[(size_t)(n0 + r) * GDKVM_DK + 16 * c + li] = acc[i][r];
-                        if (train) *reinterpret_cast<f32x4*>(wtT + (size_t)(16 * c + li) * NP + n0) = acc[i];
+                            for (int r = 0; r < 4; ++r) wt[(size_t)(n0 + r) * GDKVM_DK + 16 * c + li] = acc[i][r];
+                            *reinterpret_cast<f32x4*>(wtT + (size_t)(16 * c + li) * NP + n0) = acc[i];
+                        }
                     } else {
                         ut[((size_t)(c - 4) * NB + I) * 64 + lane] = acc[i];
                     }
@@ -668,6 +673,312 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The frame as ONE affine map of the state.  Substituting U = Ut - a Wt S into S' = a S + Kn^T U gives
+//        S' = a (I - Kn^T Wt) S + Kn^T Ut  =  a P S + G ,
+// and neither P [Dk,Dk] nor G [Dk,Dv] depends on S: they belong to the state-independent (frame-parallel) side.  The
+// serial chain per frame drops from two dependent GEMMs with an LDS exchange between them (and a cost that grows with the
+// token count) to one [Dk,Dk]x[Dk,16] product per slice -- 16 fp32 MFMA per state wave, one barrier, independent of N.
+//
+// gdr_fold_kernel: P = I - Kn^T Wt and G = Kn^T Ut for one frame-head; wave w owns row tile w (Dk rows 16w..16w+15), the
+// 4 + Dv/16 column tiles are split over gridDim.y workgroups.  A operands are rows of knT (k = 16I + 4g + r, the
+// permutation under which the Ut images -- prep's accumulator layout -- are B operands as stored).
+struct FoldArgs { const float* wti; const float* knT; const float* ut; float* pp; float* gg; int Dv; };
+
+// grid (FH, 1 + ceil(Dv/64)): block y = 0 folds the four Wt tiles into P, block y > 0 four Ut tiles into G.  Every operand
+// of the block's four tiles is requested up front (20 16-byte loads per lane), then 4 x 4NB MFMA run back to back.
+template <int NB>
+__global__ __launch_bounds__(256) void gdr_fold_kernel(FoldArgs a)
+{
+    constexpr int NP = 16 * NB;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t fh = blockIdx.x;
+    const int nsl = a.Dv / 16;
+    const bool isP = blockIdx.y == 0;
+    const int c0 = isP ? 0 : 4 * ((int)blockIdx.y - 1);               // first of this block's column tiles
+    const int nlim = isP ? GDKVM_DK / 16 : nsl;
+    const f32x4* img = isP ? reinterpret_cast<const f32x4*>(a.wti) + fh * (NP * (size_t)GDKVM_DK / 4)
+                           : reinterpret_cast<const f32x4*>(a.ut) + fh * (NP * (size_t)a.Dv / 4);
+    f32x4 ka[NB];
+    {
+        const float* kp = a.knT + (fh * GDKVM_DK + 16 * w + li) * NP + 4 * g;
+#pragma unroll
+        for (int I = 0; I < NB; ++I) ka[I] = *reinterpret_cast<const f32x4*>(kp + 16 * I);
+    }
+    constexpr int TB = NB <= 8 ? 4 : 2;                                // tiles whose operands are in registers together
+#pragma unroll
+    for (int j0 = 0; j0 < 4; j0 += TB) {
+        f32x4 y[TB][NB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int c = min(c0 + j0 + j, nlim - 1);
+#pragma unroll
+            for (int I = 0; I < NB; ++I) y[j][I] = img[((size_t)c * NB + I) * 64 + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int c = c0 + j0 + j;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int I = 0; I < NB; ++I) {
+                    if (I & 1) acc1 = mfma4(ka[I][r], y[j][I][r], acc1);
+                    else acc0 = mfma4(ka[I][r], y[j][I][r], acc0);
+                }
+            const f32x4 o = acc0 + acc1;
+            if (c < nlim) {
+                if (isP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * w + 4 * g + r, col = 16 * c + li;
+                        a.pp[(fh * GDKVM_DK + row) * GDKVM_DK + col] = (row == col ? 1.f : 0.f) - o[r];
+                    }
+                } else {
+                    reinterpret_cast<f32x4*>(a.gg)[((fh * nsl + c) * 4 + w) * 64 + lane] = o;
+                }
+            }
+        }
+    }
+}
+
+template <int NB>
+void launch_fold(const FoldArgs& fa, int FH, hipStream_t st)
+{
+    hipLaunchKernelGGL((gdr_fold_kernel<NB>), dim3((unsigned)FH, (unsigned)(1 + (fa.Dv / 16 + 3) / 4)), dim3(256), 0, st, fa);
+}
+
+// gdr_affine_scan_kernel: the serial recurrence on the folded operands.  Same workgroup shape and roles as above:
+//   state waves 0-3   S_t tile (rows 16w.., this slice's 16 columns) = a_t * (P_t[rows 16w..] S_{t-1}) + G_t tile; the B
+//                     operand is the four waves' accumulator tiles as published in LDS.  One barrier per frame: the
+//                     images are double-buffered by frame parity.
+//   read waves  4-7   R_t = (Qn_t S_{t-1}) from the same images (bf16 arm: S = S_hi + S_lo on the bf16 MFMA), unchanged.
+// A frame is now ~1/3 us, so the operand prefetch runs 6 frames ahead (8 rotating register buffers per role).
+struct AffArgs {
+    const void* q; const float* alpha; const float* s_in;
+    const float* pp; const float* gg; const float* qinv;
+    void* r_out; float* s_out; float* s_hist; char* trash;
+    int init_identity, zero_g;                       // transition mode: S_0 = I, and gg is ONE zero tile (all strides 0)
+    int T, Hh, N, Dv, flags, BH;
+#ifdef GDKVM_DIAG
+    unsigned long long* diag;
+#endif
+};
+struct PItem { f32x4 p[4]; f32x4 gt; float alpha; };
+
+template <int IO, int NB, bool SAVE>
+__global__ __launch_bounds__(512) void gdr_affine_scan_kernel(AffArgs a)
+{
+    constexpr int NP = 16 * NB, JT = NB / 4, NBUF = 8, DEPTH = 6, UFR = NBUF / JT;
+    __shared__ __attribute__((aligned(16))) f32x4 s_S[2][4 * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = wave & 3;
+    const bool read_role = wave >= 4;
+    const int nsl = a.Dv / 16, N = a.N, Hh = a.Hh, Dv = a.Dv, T = a.T;
+    int bh, sl;
+    {
+        const int x = blockIdx.x;                         // XCD-aware: the slices of one (clip, head) share an L2
+        if (a.BH % 8 == 0) { bh = (x & 7) + 8 * ((x >> 3) / nsl); sl = (x >> 3) % nsl; }
+        else { bh = x / nsl; sl = x % nsl; }
+    }
+    const int b = bh / Hh, h = bh % Hh;
+    const size_t fh0 = (size_t)b * T * Hh + h;
+    constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
+
+    // Only the fp32 accumulator image is published: the bf16 arm's S = S_hi + S_lo split is the read waves' own work, off
+    // the S -> S chain.
+    auto publish_state = [&](int par, const f32x4& sv) { s_S[par][w * 64 + lane] = sv; };
+    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+    if (!read_role) {
+        if (a.s_in) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[r] = a.s_in[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li];
+        } else if (a.init_identity) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[r] = (16 * w + 4 * g + r == 16 * sl + li) ? 1.f : 0.f;
+        }
+        publish_state(0, sacc);
+    }
+
+    if (read_role) {
+        // ------------------------------------------------------------------------------ read-out waves
+        const int last_item = T * JT - 1;
+        const char* qbase = static_cast<const char*>(a.q) + (((size_t)b * T * N * Hh + h) * GDKVM_DK) * ESZ;
+        const size_t q_fstride = (size_t)N * Hh * GDKVM_DK * ESZ;
+        const float* qinv_lane = a.qinv + fh0 * NP + 4 * g;
+        char* rbase = static_cast<char*>(a.r_out) + ((size_t)b * T * N * Hh * Dv + h * Dv + 16 * sl + li) * ESZ;
+        const size_t r_fstride = (size_t)N * Hh * Dv * ESZ;
+        auto load_q = [&](int item, QItem<IO>& d) {
+#ifdef GDKVM_ABL_NOQ
+            item = 0;
+#endif
+            item = min(item, last_item);
+            const int t = item / JT, tt = w + 4 * (item - t * JT);
+            const int nq = min(16 * tt + li, N - 1);
+            const char* p = qbase + t * q_fstride + (size_t)nq * (Hh * GDKVM_DK * ESZ);
+            if constexpr (IO == GDKVM_F32) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) d.q[m] = *reinterpret_cast<const f32x4*>(p + 64 * m + 16 * g);
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) d.q[ks] = *reinterpret_cast<const bf16x8*>(p + 64 * ks + 16 * g);
+            }
+            d.qinv = *reinterpret_cast<const f32x4*>(qinv_lane + (size_t)t * Hh * NP + 16 * tt);
+        };
+        QItem<IO> qb[NBUF];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) load_q(i, qb[i]);
+        __syncthreads();
+        // B operand of the frame's read-out, fetched once per frame.  fp32 arm: the four accumulator images (k = 16m + 4g + r).
+        // bf16 arm: k = 32ks + 8g + j is row 16m + 4g' + r with m = 2ks + (g>>1), g' = 2(g&1) + (j>>2), r = j&3 -- two 16-byte
+        // reads per ks -- split into bf16 S_hi + S_lo here.
+        struct SB { f32x4 f[4]; bf16x8 h[2], l[2]; };
+        auto load_sb = [&](int par, SB& sb) {
+            if constexpr (IO == GDKVM_F32) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) sb.f[m] = s_S[par][m * 64 + lane];
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int src = (2 * ks + (g >> 1)) * 64 + 32 * (g & 1) + li;
+                    const f32x4 x0 = s_S[par][src], x1 = s_S[par][src + 16];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = j < 4 ? x0[j & 3] : x1[j & 3];
+                        const __bf16 hi = static_cast<__bf16>(x);
+                        sb.h[ks][j] = hi;
+                        sb.l[ks][j] = static_cast<__bf16>(x - static_cast<float>(hi));
+                    }
+                }
+            }
+        };
+        auto read_item = [&](int t, int j, const SB& sb, const QItem<IO>& cur, QItem<IO>& nxt) {
+            const int tt = w + 4 * j;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (IO == GDKVM_F32) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (m & 1) acc1 = mfma4(cur.q[m][r], sb.f[m][r], acc1);
+                        else acc0 = mfma4(cur.q[m][r], sb.f[m][r], acc0);
+                    }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.q[ks], sb.h[ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.q[ks], sb.l[ks], acc1, 0, 0, 0);
+                }
+            }
+            const f32x4 accR = (acc0 + acc1) * cur.qinv;
+            char* rp = rbase + t * r_fstride;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nr = 16 * tt + 4 * g + r;
+                char* p = (nr < N && a.r_out) ? rp + (size_t)nr * (Hh * Dv * ESZ) : a.trash;
+#ifdef GDKVM_ABL_NOR
+                p = a.trash;
+#endif
+                if constexpr (IO == GDKVM_F32) *reinterpret_cast<float*>(p) = accR[r];
+                else *reinterpret_cast<bf16_t*>(p) = f32_to_bf16(accR[r]);
+            }
+            load_q(t * JT + j + DEPTH, nxt);
+        };
+        auto frame = [&](int t, auto fc) {
+            constexpr int F = decltype(fc)::value;
+            SB sb;
+            load_sb(t & 1, sb);
+            static_for<0, JT>([&](auto jc) {
+                constexpr int i = F * JT + decltype(jc)::value;
+                read_item(t, decltype(jc)::value, sb, qb[i % NBUF], qb[(i + DEPTH) % NBUF]);
+            });
+            __syncthreads();                               // S_{t-1} consumed / S_t published
+        };
+        int t0 = 0;
+        for (; t0 + UFR <= T; t0 += UFR)
+            static_for<0, UFR>([&](auto fc) { frame(t0 + decltype(fc)::value, fc); });
+        static_for<0, UFR - 1>([&](auto fc) {
+            if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, fc);
+        });
+        return;
+    }
+
+    // ---------------------------------------------------------------------------------- state waves
+    __builtin_amdgcn_s_setprio(2);                        // the S -> S chain goes first at the SIMD's issue port and the LDS
+    const bool gate_logits = a.flags & GDKVM_FLAG_GATE_LOGITS;
+    const float* pp_lane = a.pp + (fh0 * GDKVM_DK + 16 * w + li) * GDKVM_DK + 4 * g;
+    const size_t pp_fstride = (size_t)Hh * GDKVM_DK * GDKVM_DK;
+    // (a select "zero_g ? 0 : gt" would be hoisted onto the freshly issued prefetch and wait for it: strides instead)
+    const f32x4* gg_lane = reinterpret_cast<const f32x4*>(a.gg) + (a.zero_g ? 0 : ((fh0 * nsl + sl) * 4 + w) * 64) + lane;
+    const size_t gg_fstride = a.zero_g ? 0 : (size_t)Hh * nsl * 4 * 64;
+    const float* al_ptr = a.alpha + fh0;
+    int vzero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));       // opaque per-lane zero: keeps the alpha prefetch off the SMEM path
+    auto load_p = [&](int t, PItem& d) {
+#ifdef GDKVM_ABL_NOP
+        t = 0;
+#endif
+        t = min(t, T - 1);
+        const float* pr = pp_lane + t * pp_fstride;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) d.p[m] = *reinterpret_cast<const f32x4*>(pr + 16 * m);
+        d.gt = gg_lane[t * gg_fstride];
+        d.alpha = al_ptr[(size_t)t * Hh + vzero];
+    };
+    PItem pb[NBUF];
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) load_p(i, pb[i]);
+    __syncthreads();
+    auto frame = [&](int t, auto fc) {
+        constexpr int F = decltype(fc)::value;
+        const PItem& cur = pb[F % NBUF];
+        const int par = t & 1;
+        DIAG_STAMP(0);
+        if constexpr (SAVE) {
+            float* hp = a.s_hist + ((fh0 + (size_t)t * Hh) * GDKVM_DK + 16 * w + 4 * g) * Dv + 16 * sl + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hp[(size_t)r * Dv] = sacc[r];
+        }
+        f32x4 sreg[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) sreg[m] = s_S[par][m * 64 + lane];
+        DIAG_STAMP(4);
+        load_p(t + DEPTH, pb[(F + DEPTH) % NBUF]);
+        DIAG_STAMP(5);
+        const float alpha = gate_logits ? fast_sigmoid(cur.alpha) : cur.alpha;
+        DIAG_STAMP(6);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (m & 1) acc1 = mfma4(cur.p[m][r], sreg[m][r], acc1);
+                else acc0 = mfma4(cur.p[m][r], sreg[m][r], acc0);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[r] = alpha * (acc0[r] + acc1[r]) + cur.gt[r];
+        DIAG_STAMP(1);
+        publish_state(par ^ 1, sacc);
+        DIAG_STAMP(2);
+        __syncthreads();
+        DIAG_STAMP(3);
+    };
+    int t0 = 0;
+    for (; t0 + NBUF <= T; t0 += NBUF)
+        static_for<0, NBUF>([&](auto fc) { frame(t0 + decltype(fc)::value, fc); });
+    static_for<0, NBUF - 1>([&](auto fc) {
+        if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, fc);
+    });
+    if (a.s_out) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.s_out[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li] = sacc[r];
+    }
+}
+
 // N == 0: no tokens -> the state only decays, S_T = S_0 * prod_t alpha_t (no read-out rows exist)
 __global__ void gdr_decay_kernel(const float* alpha, const float* s_in, float* s_out, int T, int Hh, int per_bh, int flags)
 {
@@ -723,10 +1034,18 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
     WsView ws;
     if (int rc = carve("scan_prep", workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
     if (int rc = gdkvm_check_device()) return rc;
-    PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, ws.kn, ws.wtT, ws.qnT, ws.tii, T, Hh, N, Dv, rule, flags};
+    PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, ws.kn, ws.wtT, ws.qnT, ws.tii, ws.wti, T, Hh, N, Dv, rule, flags};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    return io_dtype == GDKVM_F32 ? launch_prep_nb<GDKVM_F32>(ws.nb, pa, B * T * Hh, st)
-                                 : launch_prep_nb<GDKVM_BF16>(ws.nb, pa, B * T * Hh, st);
+    if (int rc = io_dtype == GDKVM_F32 ? launch_prep_nb<GDKVM_F32>(ws.nb, pa, B * T * Hh, st)
+                                       : launch_prep_nb<GDKVM_BF16>(ws.nb, pa, B * T * Hh, st)) return rc;
+    FoldArgs fa{ws.wti, ws.knT, ws.ut, ws.pp, ws.gg, Dv};
+    switch (ws.nb) {
+        case 4: launch_fold<4>(fa, B * T * Hh, st); break;
+        case 8: launch_fold<8>(fa, B * T * Hh, st); break;
+        default: launch_fold<16>(fa, B * T * Hh, st); break;
+    }
+    GDKVM_LAUNCH_CHECK("gdr_fold_kernel");
+    return GDKVM_OK;
 }
 
 extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* s_in, void* r_out, float* s_out,
@@ -736,7 +1055,7 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
     if (int rc = check_common("scan_apply", B, T, Hh, N, Dk, Dv, io_dtype, flags)) return rc;
     if (B == 0) return GDKVM_OK;
     const bool have_tokens = T > 0 && N > 0;
-    WsView ws{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    WsView ws{};
     if (have_tokens) {
         if (int rc = check_ptrs("scan_apply", {q, alpha, workspace}, {r_out, s_in, s_out, s_hist})) return rc;
         if (int rc = carve("scan_apply", const_cast<void*>(workspace), workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
@@ -755,22 +1074,21 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
         }
         return GDKVM_OK;
     }
-    ScanArgs sa{q, alpha, s_in, ws.wt, ws.knT, ws.ut, ws.qinv, r_out, s_out, s_hist, ws.trash, nullptr, nullptr,
-                (size_t)16 * ws.nb * Dv / 4, (size_t)ws.nb * 64, 0, T, Hh, N, Dv, flags, B * Hh};
+    AffArgs sa{q, alpha, s_in, ws.pp, ws.gg, ws.qinv, r_out, s_out, s_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh};
 #ifdef GDKVM_DIAG
     sa.diag = g_diag_buf;
 #endif
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
 #define GDKVM_SCAN_LAUNCH(IO, SV)                                                                         \
     switch (ws.nb) {                                                                                      \
-        case 4: hipLaunchKernelGGL((gdr_scan_kernel<IO, 4, SV, false>), grid, dim3(512), 0, st, sa); break;      \
-        case 8: hipLaunchKernelGGL((gdr_scan_kernel<IO, 8, SV, false>), grid, dim3(512), 0, st, sa); break;      \
-        default: hipLaunchKernelGGL((gdr_scan_kernel<IO, 16, SV, false>), grid, dim3(512), 0, st, sa); break;    \
+        case 4: hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, 4, SV>), grid, dim3(512), 0, st, sa); break;      \
+        case 8: hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, 8, SV>), grid, dim3(512), 0, st, sa); break;      \
+        default: hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, 16, SV>), grid, dim3(512), 0, st, sa); break;    \
     }
     if (io_dtype == GDKVM_F32) { if (s_hist) { GDKVM_SCAN_LAUNCH(GDKVM_F32, true) } else { GDKVM_SCAN_LAUNCH(GDKVM_F32, false) } }
     else { if (s_hist) { GDKVM_SCAN_LAUNCH(GDKVM_BF16, true) } else { GDKVM_SCAN_LAUNCH(GDKVM_BF16, false) } }
 #undef GDKVM_SCAN_LAUNCH
-    GDKVM_LAUNCH_CHECK("gdr_scan_kernel");
+    GDKVM_LAUNCH_CHECK("gdr_affine_scan_kernel");
     return GDKVM_OK;
 }
 
@@ -785,26 +1103,23 @@ extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* p
     if (int rc = carve("scan_transition", const_cast<void*>(workspace), workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
     if (int rc = gdkvm_check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // a zero Ut tile for every (frame, slice, tile): borrow the trash slot's neighbourhood -- one 1 KiB tile of zeros
-    float* zero_tile = ws.zero;
-    hipError_t e = hipMemsetAsync(zero_tile, 0, 64 * 4 * sizeof(float), st);
+    // the recurrence on Dk columns from S = I with G = 0 and no read-out:  Phi = prod_t a_t P_t
+    hipError_t e = hipMemsetAsync(ws.zero, 0, 64 * 4 * sizeof(float), st);       // the one G tile every frame and slice reads
     if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_transition: memset: %s", hipGetErrorString(e));
-    // the recurrence on Dk columns from S = I with Ut = 0 and no read-out:  Phi = prod_t a_t (I - Kn_t^T Wt_t)
-    ScanArgs sa{q, alpha, nullptr, ws.wt, ws.knT, zero_tile, ws.qinv, nullptr, phi_out, nullptr, ws.trash, nullptr, nullptr,
-                0, 0, 1, T, Hh, N, GDKVM_DK, flags, B * Hh};
+    AffArgs sa{q, alpha, nullptr, ws.pp, ws.zero, ws.qinv, nullptr, phi_out, nullptr, ws.trash, 1, 1, T, Hh, N, GDKVM_DK, flags, B * Hh};
 #ifdef GDKVM_DIAG
     sa.diag = nullptr;
 #endif
     const dim3 grid((unsigned)(B * Hh * (GDKVM_DK / 16)));
 #define GDKVM_TR_LAUNCH(IO)                                                                              \
     switch (ws.nb) {                                                                                     \
-        case 4: hipLaunchKernelGGL((gdr_scan_kernel<IO, 4, false, false>), grid, dim3(512), 0, st, sa); break;   \
-        case 8: hipLaunchKernelGGL((gdr_scan_kernel<IO, 8, false, false>), grid, dim3(512), 0, st, sa); break;   \
-        default: hipLaunchKernelGGL((gdr_scan_kernel<IO, 16, false, false>), grid, dim3(512), 0, st, sa); break; \
+        case 4: hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, 4, false>), grid, dim3(512), 0, st, sa); break;   \
+        case 8: hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, 8, false>), grid, dim3(512), 0, st, sa); break;   \
+        default: hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, 16, false>), grid, dim3(512), 0, st, sa); break; \
     }
     if (io_dtype == GDKVM_F32) { GDKVM_TR_LAUNCH(GDKVM_F32) } else { GDKVM_TR_LAUNCH(GDKVM_BF16) }
 #undef GDKVM_TR_LAUNCH
-    GDKVM_LAUNCH_CHECK("gdr_scan_kernel<transition>");
+    GDKVM_LAUNCH_CHECK("gdr_affine_scan_kernel<transition>");
     return GDKVM_OK;
 }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic only: builds libgdkvm_hip_diag.so (-DGDKVM_DIAG: s_memtime stamps in gdr_scan_kernel) and prints where
+"""Diagnostic only: builds libgdkvm_hip_diag.so (-DGDKVM_DIAG: s_memtime stamps in gdr_affine_scan_kernel) and prints where
 one workgroup's cycles go per frame.  Shares of a diagnostic build, never a quoted run time
 (cdna_hip_programming.md §7 'In-kernel stamps')."""
 import ctypes
@@ -40,15 +40,17 @@ def main():
                                 s.data_ptr(), None, ws.data_ptr(), wsb, B, T, Hh, N, Dk, Dv, 1, 2, 3, None)
         assert rc == 0
         torch.cuda.synchronize()
-    d = diag.cpu().reshape(T, 8)[:, :5]
-    seg = torch.stack([d[:, 1] - d[:, 0], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2], d[:, 4] - d[:, 3]], 1).float()
-    names = ["read items (S lds read + 32 MFMA + U/R out)", "barrier 1", "write items (U lds read + 16 MFMA)", "S lds write + barrier 2"]
-    print("s_memtime ticks per frame (median over frames 2..T-1), block 0 wave 0; 1 tick = 1 shader cycle")
+    d8 = diag.cpu().reshape(T, 8)
+    d = d8[:, :4]
+    seg = torch.stack([d8[:, 4] - d8[:, 0], d8[:, 5] - d8[:, 4], d8[:, 6] - d8[:, 5], d8[:, 1] - d8[:, 6], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2]], 1).float()
+    names = ["S images: 4 ds_read_b128 (waited)", "issue prefetch of frame t+6 (6 loads)", "gate (sigmoid of alpha_t; waits its load)",
+             "16 MFMA + a*acc + G", "publish S (1 ds_write_b128, waited)", "barrier"]
+    print("s_memtime ticks per frame (median over frames 2..T-1), block 0 wave 0 (a state wave)")
     for i, n in enumerate(names):
-        print(f"  {n:48s} {seg[2:, i].median().item():8.0f}")
-    print("  per-frame totals:", [int(x) for x in (d[:, 4] - d[:, 0]).tolist()])
-    print("  gaps between frames:", [int(x) for x in (d[1:, 0] - d[:-1, 4]).tolist()])
-    print(f"  frame total {(d[2:, 4] - d[2:, 0]).float().median().item():.0f}; whole scan {(d[-1, 4] - d[0, 0]).item()} ticks")
+        print(f"  {n:48s} {seg[2:, i].median().item():8.0f}  (min {seg[2:, i].min().item():.0f} max {seg[2:, i].max().item():.0f})")
+    print("  per-frame totals:", [int(x) for x in (d[:, 3] - d[:, 0]).tolist()])
+    print("  gaps between frames:", [int(x) for x in (d[1:, 0] - d[:-1, 3]).tolist()])
+    print(f"  frame total {(d[2:, 3] - d[2:, 0]).float().median().item():.0f}; whole scan {(d[-1, 3] - d[0, 0]).item()} ticks")
 
 
 if __name__ == "__main__":
