@@ -732,9 +732,9 @@ __global__ __launch_bounds__(256) void gdr_fold_kernel(FoldArgs a)
             if (c < nlim) {
                 if (isP) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < 4; ++r) {                  // P[16w + 4g + r][16c + li] -> image (w, m = c), lane (li>>2, 4g+r), reg li&3
                         const int row = 16 * w + 4 * g + r, col = 16 * c + li;
-                        a.pp[(fh * GDKVM_DK + row) * GDKVM_DK + col] = (row == col ? 1.f : 0.f) - o[r];
+                        a.pp[(((fh * 4 + w) * 4 + c) * 64 + (li >> 2) * 16 + 4 * g + r) * 4 + (li & 3)] = (row == col ? 1.f : 0.f) - o[r];
                     }
                 } else {
                     reinterpret_cast<f32x4*>(a.gg)[((fh * nsl + c) * 4 + w) * 64 + lane] = o;
@@ -750,12 +750,281 @@ void launch_fold(const FoldArgs& fa, int FH, hipStream_t st)
     hipLaunchKernelGGL((gdr_fold_kernel<NB>), dim3((unsigned)FH, (unsigned)(1 + (fa.Dv / 16 + 3) / 4)), dim3(256), 0, st, fa);
 }
 
-// gdr_affine_scan_kernel: the serial recurrence on the folded operands.  Same workgroup shape and roles as above:
-//   state waves 0-3   S_t tile (rows 16w.., this slice's 16 columns) = a_t * (P_t[rows 16w..] S_{t-1}) + G_t tile; the B
-//                     operand is the four waves' accumulator tiles as published in LDS.  One barrier per frame: the
-//                     images are double-buffered by frame parity.
-//   read waves  4-7   R_t = (Qn_t S_{t-1}) from the same images (bf16 arm: S = S_hi + S_lo on the bf16 MFMA), unchanged.
-// A frame is now ~1/3 us, so the operand prefetch runs 6 frames ahead (8 rotating register buffers per role).
+// ------------------------------------------------------------------------------------------------------------------
+// gdr_prepm_kernel -- the frame-parallel side for INFERENCE (N <= 128), producing the affine map of the frame directly:
+//        M = Kn^T T diag(b)  [Dk, N]          P = I - M Kn          G = M V
+// (P = I - Kn^T Wt and G = Kn^T Ut with Wt = T b Kn, Ut = T b V substituted).  Only the FOUR column tiles of Kn go through
+// the triangular solve -- M^T = diag(b) T^T Kn is a BACK substitution with the transposed Gram blocks -- and V is used
+// raw: its tiles, fetched in the accumulator layout, are B operands as loaded.  Wt and Ut never exist, nothing but P, G
+// and qinv is written.  (Training keeps gdr_prep_kernel + gdr_fold_kernel: the backward consumes Wt, Ut, T_II.)
+//   phase 0   norms and gates (as gdr_prep_kernel)
+//   phase 1   Gram blocks: L_II (row gate, strictly lower) and, for J > I, -L_JI as the A image of (L_JI)^T
+//   phase 2   T_II = (I + L_II)^-1 by forward substitution, stored as the A image of T_II^T
+//   phase 3   wave w: Kn column tile w;  Z_I = T_II^T (Kn_I - sum_{J>I} L_JI^T Z_J), I = NB-1 .. 0;  M^T_I = b_I Z_I;
+//             Kn and M^T tiles -> LDS as accumulator images
+//   phase 4   wave w: P^T tiles (w, m) = delta - Kn_w^T-image x M^T_m  (the C layout of P^T IS the state waves' A layout
+//             of P), then G tiles (m, cV) = M_m x V_cV for cV = w, w+4, ...
+struct PrepMArgs {
+    const void* q; const void* k; const void* v; const float* beta;
+    float* qinv; float* pp; float* gg;
+    int T, Hh, N, Dv, rule, flags;
+};
+
+__host__ __device__ constexpr size_t prepm_lds_bytes(int NB)
+{   // kinv beta qinv pad | negB pairs | Ld | TmT | kni [4][NB] | mt [4][NB]   (images of 64 x f32x4)
+    return (size_t)(4 * 16 * NB + (NB * (NB - 1) / 2 + 2 * NB + 8 * NB) * 256) * sizeof(float);
+}
+
+template <int NB, int IO>
+__global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepMArgs a)
+{
+    constexpr int NP = 16 * NB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_kinv = smem;
+    float* s_beta = smem + NP;
+    float* s_qinv = smem + 2 * NP;
+    f32x4* s_negB = reinterpret_cast<f32x4*>(smem + 4 * NP);
+    f32x4* s_Ld = s_negB + (NB * (NB - 1) / 2) * 64;
+    f32x4* s_TmT = s_Ld + NB * 64;
+    f32x4* s_kni = s_TmT + NB * 64;
+    f32x4* s_mt = s_kni + 4 * NB * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fh = blockIdx.x;
+    const int h = fh % a.Hh;
+    const size_t bt = fh / a.Hh;
+    const int N = a.N, Hh = a.Hh, Dv = a.Dv, nsl = Dv / 16;
+    const bool seq = a.rule == GDKVM_RULE_DELTA_SEQUENTIAL;
+    const bool p_identity = a.rule == GDKVM_RULE_GATED_LINEAR;
+
+    // this wave's Kn column tile and its first V tile, raw, in the accumulator layout: x[I][r] = X[token 16I+4g+r][16c+li]
+    float xk[NB][4], xv[2][NB][4];
+    auto load_v = [&](int cV, float (&d)[NB][4]) __attribute__((always_inline)) {
+        cV = min(cV, nsl - 1);
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                d[I][r] = load1<IO>(a.v, ((bt * N + min(16 * I + 4 * g + r, N - 1)) * Hh + h) * Dv + 16 * cV + li);
+    };
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            xk[I][r] = load1<IO>(a.k, ((bt * N + min(16 * I + 4 * g + r, N - 1)) * Hh + h) * GDKVM_DK + 16 * w + li);
+    load_v(w, xv[0]);
+
+    // ---- phase 0
+    for (int n = tid; n < NP; n += 256) {
+        float kinv = 0.f, qinv = 0.f, bta = 0.f;
+        if (n < N) {
+            kinv = qinv = 1.f;
+            if (a.flags & GDKVM_FLAG_NORMALIZE_QK) {
+                float sk = 0.f, sq = 0.f;
+#pragma unroll
+                for (int c = 0; c < GDKVM_DK; c += 4) {
+                    const f32x4 x = load4<IO>(a.k, ((bt * N + n) * Hh + h) * GDKVM_DK + c);
+                    const f32x4 y = load4<IO>(a.q, ((bt * N + n) * Hh + h) * GDKVM_DK + c);
+                    sk += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+                    sq += y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+                }
+                kinv = 1.0f / sqrtf(sk + GDKVM_EPS_NORM);
+                qinv = 1.0f / sqrtf(sq + GDKVM_EPS_NORM);
+            }
+            bta = a.beta[(bt * N + n) * Hh + h];
+            if (a.flags & GDKVM_FLAG_GATE_LOGITS) bta = 1.0f / (1.0f + expf(-bta));
+        }
+        s_kinv[n] = kinv;
+        s_beta[n] = bta;
+        s_qinv[n] = qinv;
+        a.qinv[(size_t)fh * NP + n] = qinv;
+    }
+    __syncthreads();
+
+    if (seq) {
+        // ---- phase 1
+        for (int p = w; p < NB * (NB + 1) / 2; p += 4) {
+            int I = 0;
+            while ((I + 1) * (I + 2) / 2 <= p) ++I;
+            const int J = p - I * (I + 1) / 2;                                  // J <= I
+            const int nI = 16 * I + li, nJ = 16 * J + li;
+            f32x4 kI[4], kJ[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                kI[m] = load4<IO>(a.k, ((bt * N + min(nI, N - 1)) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
+                kJ[m] = load4<IO>(a.k, ((bt * N + min(nJ, N - 1)) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
+            }
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if (J == I) {                      // lane (g,li) reg r = k_{I,4g+r} . k_{I,li}: the image of L_II[li][4g+r]
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (m & 1) acc1 = mfma4(kJ[m][r], kI[m][r], acc1);
+                        else acc0 = mfma4(kJ[m][r], kI[m][r], acc0);
+                    }
+                f32x4 acc = acc0 + acc1;
+                const float rowscale = s_kinv[nI] * s_beta[nI];
+                const f32x4 kinvJ = *reinterpret_cast<const f32x4*>(s_kinv + 16 * J + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = (4 * g + r >= li) ? 0.f : acc[r] * rowscale * kinvJ[r];
+                s_Ld[I * 64 + lane] = acc;
+            } else {                           // lane (g,li) reg r = L_IJ[4g+r][li] = b_{I,4g+r} kn_{I,4g+r} . kn_{J,li}  (I > J)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (m & 1) acc1 = mfma4(kI[m][r], kJ[m][r], acc1);
+                        else acc0 = mfma4(kI[m][r], kJ[m][r], acc0);
+                    }
+                f32x4 acc = acc0 + acc1;
+                const f32x4 kiI = *reinterpret_cast<const f32x4*>(s_kinv + 16 * I + 4 * g);
+                const f32x4 btI = *reinterpret_cast<const f32x4*>(s_beta + 16 * I + 4 * g);
+                const float colscale = s_kinv[nJ];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] *= -(kiI[r] * btI[r] * colscale);
+                s_negB[pair_slot(I, J) * 64 + lane] = acc;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: T_II by forward substitution (16 threads per block, one column each), stored transposed
+        {
+            const int I = tid >> 4, j = tid & 15;
+            if (I < NB) {
+                float t[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t[i] = (i == j) ? 1.f : 0.f;
+#pragma unroll
+                for (int i = 1; i < 16; ++i) {
+                    float sm = 0.f;
+#pragma unroll
+                    for (int gg = 0; gg * 4 < i; ++gg) {
+                        const f32x4 Lr = s_Ld[I * 64 + gg * 16 + i];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (4 * gg + r < i) sm += Lr[r] * t[4 * gg + r];
+                    }
+                    t[i] = (i > j) ? -sm : t[i];
+                }
+                float* Tm = reinterpret_cast<float*>(s_TmT + I * 64);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) Tm[((i >> 2) * 16 + j) * 4 + (i & 3)] = t[i];   // lane (i>>2, j) reg i&3 = T[i][j]
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 3: back substitution on Kn column tile w
+    f32x4 KN[NB], Z[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        const f32x4 ki4 = *reinterpret_cast<const f32x4*>(s_kinv + 16 * I + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) KN[I][r] = xk[I][r] * ki4[r];
+        s_kni[(w * NB + I) * 64 + lane] = KN[I];
+    }
+    if (seq) {
+        static_for<0, NB>([&](auto ic) {
+            constexpr int I = NB - 1 - decltype(ic)::value;
+            f32x4 acc = KN[I];
+            static_for<I + 1, NB>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                const f32x4 nb = s_negB[pair_slot(J, I) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = mfma4(nb[r], Z[J][r], acc);
+            });
+            const f32x4 t4 = s_TmT[I * 64 + lane];
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z = mfma4(t4[r], acc[r], z);
+            Z[I] = z;
+        });
+    } else {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) Z[I] = KN[I];
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        const f32x4 bt4 = *reinterpret_cast<const f32x4*>(s_beta + 16 * I + 4 * g);
+        s_mt[(w * NB + I) * 64 + lane] = Z[I] * bt4;
+    }
+    __syncthreads();
+
+    // ---- phase 4: P images and G tiles
+    f32x4 mt[4][NB];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) mt[m][I] = s_mt[(m * NB + I) * 64 + lane];
+    f32x4* pp = reinterpret_cast<f32x4*>(a.pp) + (size_t)fh * 16 * 64;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (!p_identity) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int I = 0; I < NB; ++I) {
+                    if (I & 1) acc1 = mfma4(KN[I][r], mt[m][I][r], acc1);
+                    else acc0 = mfma4(KN[I][r], mt[m][I][r], acc0);
+                }
+        }
+        f32x4 o;                              // lane (g,li) reg r = P[16m + li][16w + 4g + r]: image (row tile m, k tile w)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = ((16 * m + li == 16 * w + 4 * g + r) ? 1.f : 0.f) - (acc0[r] + acc1[r]);
+        pp[(m * 4 + w) * 64 + lane] = o;
+    }
+    f32x4* gg = reinterpret_cast<f32x4*>(a.gg) + (size_t)fh * nsl * 4 * 64;
+    auto g_tiles = [&](int cV, const float (&x)[NB][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int I = 0; I < NB; ++I) {
+                    if (I & 1) acc1 = mfma4(mt[m][I][r], x[I][r], acc1);
+                    else acc0 = mfma4(mt[m][I][r], x[I][r], acc0);
+                }
+            if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = acc0 + acc1;
+        }
+    };
+    for (int cV = w; cV < nsl; cV += 8) {     // two V tiles per trip: the next tile's loads are in flight behind the MFMAs
+        load_v(cV + 4, xv[1]);
+        g_tiles(cV, xv[0]);
+        load_v(cV + 8, xv[0]);
+        g_tiles(cV + 4, xv[1]);
+    }
+}
+
+template <int NB, int IO>
+int launch_prepm(const PrepMArgs& pa, int FH, hipStream_t st)
+{
+    const size_t lds = prepm_lds_bytes(NB);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_prepm_kernel<NB, IO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_prepm: LDS attribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL((gdr_prepm_kernel<NB, IO>), dim3(FH), dim3(256), lds, st, pa);
+    GDKVM_LAUNCH_CHECK("gdr_prepm_kernel");
+    return GDKVM_OK;
+}
+
+// gdr_affine_scan_kernel: the serial recurrence on the folded operands.  12 waves per workgroup in three fixed roles:
+//   state waves  0-3   S_t tile (rows 16w.., this slice's 16 columns) = a_t * (P_t[rows 16w..] S_{t-1}) + G_t tile; the B
+//                      operand is the four waves' accumulator tiles as published in LDS (double-buffered by frame parity:
+//                      one barrier per frame).  These waves issue NO vector-memory instruction: a 1 KiB wave load holds
+//                      the issue port for ~60 cycles (the CU's 64 B/clk address/data path), which between the MFMAs of
+//                      the chain cost more than the MFMAs themselves.
+//   read waves   4-7   R_t = (Qn_t S_{t-1}) * qinv from the same images (bf16 arm: S = S_hi + S_lo split here, bf16 MFMA),
+//                      with their own register prefetch of q.
+//   loader waves 8-11  stream P_t (16 KiB), G_t's tiles (4 KiB) and a_t into an LDS ring by LDS-DMA (global_load_lds, no
+//                      registers), AFF_D frames ahead; wave 8+w fetches exactly what state wave w consumes, lane-linear.
+// Ring protocol (AFF_NS = AFF_D + 1 slots): in iteration t the loaders issue frame t+AFF_D into the slot frame t-1 used
+// (free: every wave passed barrier t-1), wait with a counted vmcnt until frame t+1 has landed, and join barrier t; the
+// state waves read frame t+1 only after that barrier.  Barriers are raw s_barrier + lgkmcnt(0): __syncthreads() would add
+// vmcnt(0) and drain the DMA queue every frame.
 struct AffArgs {
     const void* q; const float* alpha; const float* s_in;
     const float* pp; const float* gg; const float* qinv;
@@ -766,18 +1035,23 @@ struct AffArgs {
     unsigned long long* diag;
 #endif
 };
-struct PItem { f32x4 p[4]; f32x4 gt; float alpha; };
+constexpr int AFF_D = 5, AFF_NS = AFF_D + 1;
+constexpr int AFF_SLOT_F4 = 16 * 64 + 4 * 64 + 16;               // f32x4 per ring slot: P [4][4][64] | G [4][64] | alpha [64 floats]
+constexpr size_t AFF_LDS_BYTES = (size_t)(2 * 4 * 64 + AFF_NS * AFF_SLOT_F4) * sizeof(f32x4);
+
+__device__ __forceinline__ void aff_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int IO, int NB, bool SAVE>
-__global__ __launch_bounds__(512) void gdr_affine_scan_kernel(AffArgs a)
+__global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
 {
-    constexpr int NP = 16 * NB, JT = NB / 4, NBUF = 8, DEPTH = 6, UFR = NBUF / JT;
-    __shared__ __attribute__((aligned(16))) f32x4 s_S[2][4 * 64];
+    constexpr int NP = 16 * NB, JT = NB / 4, NBUF = 4, DEPTH = 3, UFR = NBUF / JT;
+    extern __shared__ __attribute__((aligned(16))) f32x4 aff_smem[];
+    f32x4* s_S = aff_smem;                                // [2][4*64]
+    f32x4* s_ring = aff_smem + 2 * 4 * 64;                // [AFF_NS][AFF_SLOT_F4]
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = wave & 3;
-    const bool read_role = wave >= 4;
+    const int w = wave & 3, role = wave >> 2;             // 0 state, 1 read-out, 2 loader
     const int nsl = a.Dv / 16, N = a.N, Hh = a.Hh, Dv = a.Dv, T = a.T;
     int bh, sl;
     {
@@ -789,11 +1063,45 @@ __global__ __launch_bounds__(512) void gdr_affine_scan_kernel(AffArgs a)
     const size_t fh0 = (size_t)b * T * Hh + h;
     constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
 
-    // Only the fp32 accumulator image is published: the bf16 arm's S = S_hi + S_lo split is the read waves' own work, off
-    // the S -> S chain.
-    auto publish_state = [&](int par, const f32x4& sv) { s_S[par][w * 64 + lane] = sv; };
+    if (role == 2) {
+        // ------------------------------------------------------------------------------ loader waves
+        const float* pp_lane = a.pp + ((fh0 * 4 + w) * 4 * 64 + lane) * 4;      // images [fh][w][m][lane][4]: 1 KiB per DMA
+        const size_t pp_fstride = (size_t)Hh * GDKVM_DK * GDKVM_DK;
+        const float* gg_lane = a.gg + ((a.zero_g ? 0 : ((fh0 * nsl + sl) * 4 + w) * 64) + lane) * 4;
+        const size_t gg_fstride = a.zero_g ? 0 : (size_t)Hh * nsl * 4 * 64 * 4;
+        const float* al_ptr = a.alpha + fh0;
+        auto issue = [&](int f) {
+            const int slot = f % AFF_NS;
+#ifdef GDKVM_ABL_NOP
+            f = 0;
+#endif
+            f = min(f, T - 1);                            // past the end: refetch the last frame into a slot nobody reads
+            f32x4* dst = s_ring + slot * AFF_SLOT_F4;
+            const float* pr = pp_lane + f * pp_fstride;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                __builtin_amdgcn_global_load_lds(pr + 256 * m, reinterpret_cast<__attribute__((address_space(3))) void*>(
+                    reinterpret_cast<uintptr_t>(dst + (w * 4 + m) * 64)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(gg_lane + f * gg_fstride, reinterpret_cast<__attribute__((address_space(3))) void*>(
+                reinterpret_cast<uintptr_t>(dst + 16 * 64 + w * 64)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(al_ptr + (size_t)f * Hh, reinterpret_cast<__attribute__((address_space(3))) void*>(
+                reinterpret_cast<uintptr_t>(dst + 16 * 64 + 4 * 64)), 4, 0, 0);       // 64 copies of a_t (each loader wave: same value)
+        };
+        for (int f = 0; f < AFF_D; ++f) issue(f);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (AFF_D - 1)) : "memory");         // frame 0 has landed
+        aff_barrier();
+        for (int t = 0; t < T; ++t) {
+            issue(t + AFF_D);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (AFF_D - 1)) : "memory");     // frame t+1 has landed
+            aff_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after the workgroup is gone
+        return;
+    }
+
+    auto publish_state = [&](int par, const f32x4& sv) { s_S[par * 256 + w * 64 + lane] = sv; };
     f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
-    if (!read_role) {
+    if (role == 0) {
         if (a.s_in) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) sacc[r] = a.s_in[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li];
@@ -804,7 +1112,7 @@ __global__ __launch_bounds__(512) void gdr_affine_scan_kernel(AffArgs a)
         publish_state(0, sacc);
     }
 
-    if (read_role) {
+    if (role == 1) {
         // ------------------------------------------------------------------------------ read-out waves
         const int last_item = T * JT - 1;
         const char* qbase = static_cast<const char*>(a.q) + (((size_t)b * T * N * Hh + h) * GDKVM_DK) * ESZ;
@@ -812,7 +1120,7 @@ __global__ __launch_bounds__(512) void gdr_affine_scan_kernel(AffArgs a)
         const float* qinv_lane = a.qinv + fh0 * NP + 4 * g;
         char* rbase = static_cast<char*>(a.r_out) + ((size_t)b * T * N * Hh * Dv + h * Dv + 16 * sl + li) * ESZ;
         const size_t r_fstride = (size_t)N * Hh * Dv * ESZ;
-        auto load_q = [&](int item, QItem<IO>& d) {
+        auto load_q = [&](int item, QItem<IO>& d) __attribute__((always_inline)) {
 #ifdef GDKVM_ABL_NOQ
             item = 0;
 #endif
@@ -832,20 +1140,20 @@ __global__ __launch_bounds__(512) void gdr_affine_scan_kernel(AffArgs a)
         QItem<IO> qb[NBUF];
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) load_q(i, qb[i]);
-        __syncthreads();
+        aff_barrier();
         // B operand of the frame's read-out, fetched once per frame.  fp32 arm: the four accumulator images (k = 16m + 4g + r).
         // bf16 arm: k = 32ks + 8g + j is row 16m + 4g' + r with m = 2ks + (g>>1), g' = 2(g&1) + (j>>2), r = j&3 -- two 16-byte
         // reads per ks -- split into bf16 S_hi + S_lo here.
         struct SB { f32x4 f[4]; bf16x8 h[2], l[2]; };
-        auto load_sb = [&](int par, SB& sb) {
+        auto load_sb = [&](int par, SB& sb) __attribute__((always_inline)) {
             if constexpr (IO == GDKVM_F32) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) sb.f[m] = s_S[par][m * 64 + lane];
+                for (int m = 0; m < 4; ++m) sb.f[m] = s_S[par * 256 + m * 64 + lane];
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    const int src = (2 * ks + (g >> 1)) * 64 + 32 * (g & 1) + li;
-                    const f32x4 x0 = s_S[par][src], x1 = s_S[par][src + 16];
+                    const int src = par * 256 + (2 * ks + (g >> 1)) * 64 + 32 * (g & 1) + li;
+                    const f32x4 x0 = s_S[src], x1 = s_S[src + 16];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float x = j < 4 ? x0[j & 3] : x1[j & 3];
@@ -856,7 +1164,7 @@ __global__ __launch_bounds__(512) void gdr_affine_scan_kernel(AffArgs a)
                 }
             }
         };
-        auto read_item = [&](int t, int j, const SB& sb, const QItem<IO>& cur, QItem<IO>& nxt) {
+        auto read_item = [&](int t, int j, const SB& sb, const QItem<IO>& cur, QItem<IO>& nxt) __attribute__((always_inline)) {
             const int tt = w + 4 * j;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             if constexpr (IO == GDKVM_F32) {
@@ -883,12 +1191,15 @@ __global__ __launch_bounds__(512) void gdr_affine_scan_kernel(AffArgs a)
 #ifdef GDKVM_ABL_NOR
                 p = a.trash;
 #endif
+#ifdef GDKVM_ABL_NOST
+                if (t >= 0) continue;
+#endif
                 if constexpr (IO == GDKVM_F32) *reinterpret_cast<float*>(p) = accR[r];
                 else *reinterpret_cast<bf16_t*>(p) = f32_to_bf16(accR[r]);
             }
             load_q(t * JT + j + DEPTH, nxt);
         };
-        auto frame = [&](int t, auto fc) {
+        auto frame = [&](int t, auto fc) __attribute__((always_inline)) {
             constexpr int F = decltype(fc)::value;
             SB sb;
             load_sb(t & 1, sb);
@@ -896,7 +1207,7 @@ __global__ __launch_bounds__(512) void gdr_affine_scan_kernel(AffArgs a)
                 constexpr int i = F * JT + decltype(jc)::value;
                 read_item(t, decltype(jc)::value, sb, qb[i % NBUF], qb[(i + DEPTH) % NBUF]);
             });
-            __syncthreads();                               // S_{t-1} consumed / S_t published
+            aff_barrier();                                 // S_{t-1} consumed / S_t published
         };
         int t0 = 0;
         for (; t0 + UFR <= T; t0 += UFR)
@@ -908,34 +1219,10 @@ __global__ __launch_bounds__(512) void gdr_affine_scan_kernel(AffArgs a)
     }
 
     // ---------------------------------------------------------------------------------- state waves
-    __builtin_amdgcn_s_setprio(2);                        // the S -> S chain goes first at the SIMD's issue port and the LDS
+    __builtin_amdgcn_s_setprio(2);                        // the S -> S chain goes first at the SIMD's issue port
     const bool gate_logits = a.flags & GDKVM_FLAG_GATE_LOGITS;
-    const float* pp_lane = a.pp + (fh0 * GDKVM_DK + 16 * w + li) * GDKVM_DK + 4 * g;
-    const size_t pp_fstride = (size_t)Hh * GDKVM_DK * GDKVM_DK;
-    // (a select "zero_g ? 0 : gt" would be hoisted onto the freshly issued prefetch and wait for it: strides instead)
-    const f32x4* gg_lane = reinterpret_cast<const f32x4*>(a.gg) + (a.zero_g ? 0 : ((fh0 * nsl + sl) * 4 + w) * 64) + lane;
-    const size_t gg_fstride = a.zero_g ? 0 : (size_t)Hh * nsl * 4 * 64;
-    const float* al_ptr = a.alpha + fh0;
-    int vzero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));       // opaque per-lane zero: keeps the alpha prefetch off the SMEM path
-    auto load_p = [&](int t, PItem& d) {
-#ifdef GDKVM_ABL_NOP
-        t = 0;
-#endif
-        t = min(t, T - 1);
-        const float* pr = pp_lane + t * pp_fstride;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) d.p[m] = *reinterpret_cast<const f32x4*>(pr + 16 * m);
-        d.gt = gg_lane[t * gg_fstride];
-        d.alpha = al_ptr[(size_t)t * Hh + vzero];
-    };
-    PItem pb[NBUF];
-#pragma unroll
-    for (int i = 0; i < DEPTH; ++i) load_p(i, pb[i]);
-    __syncthreads();
-    auto frame = [&](int t, auto fc) {
-        constexpr int F = decltype(fc)::value;
-        const PItem& cur = pb[F % NBUF];
+    aff_barrier();
+    auto frame = [&](int t, int slot) __attribute__((always_inline)) {
         const int par = t & 1;
         DIAG_STAMP(0);
         if constexpr (SAVE) {
@@ -943,39 +1230,68 @@ __global__ __launch_bounds__(512) void gdr_affine_scan_kernel(AffArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) hp[(size_t)r * Dv] = sacc[r];
         }
-        f32x4 sreg[4];
+        const f32x4* rs = s_ring + slot * AFF_SLOT_F4;
+        f32x4 sreg[4], pa[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) sreg[m] = s_S[par][m * 64 + lane];
+        for (int m = 0; m < 4; ++m) sreg[m] = s_S[par * 256 + m * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) pa[m] = rs[(w * 4 + m) * 64 + lane];
+        const f32x4 gt = rs[16 * 64 + w * 64 + lane];
+        const float al = reinterpret_cast<const float*>(rs + 16 * 64 + 4 * 64)[lane];
         DIAG_STAMP(4);
-        load_p(t + DEPTH, pb[(F + DEPTH) % NBUF]);
         DIAG_STAMP(5);
-        const float alpha = gate_logits ? fast_sigmoid(cur.alpha) : cur.alpha;
         DIAG_STAMP(6);
+        const float alpha = gate_logits ? fast_sigmoid(al) : al;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                if (m & 1) acc1 = mfma4(cur.p[m][r], sreg[m][r], acc1);
-                else acc0 = mfma4(cur.p[m][r], sreg[m][r], acc0);
+                if (m & 1) acc1 = mfma4(pa[m][r], sreg[m][r], acc1);
+                else acc0 = mfma4(pa[m][r], sreg[m][r], acc0);
             }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[r] = alpha * (acc0[r] + acc1[r]) + cur.gt[r];
+        for (int r = 0; r < 4; ++r) sacc[r] = alpha * (acc0[r] + acc1[r]) + gt[r];
         DIAG_STAMP(1);
         publish_state(par ^ 1, sacc);
         DIAG_STAMP(2);
-        __syncthreads();
+        aff_barrier();
         DIAG_STAMP(3);
     };
     int t0 = 0;
-    for (; t0 + NBUF <= T; t0 += NBUF)
-        static_for<0, NBUF>([&](auto fc) { frame(t0 + decltype(fc)::value, fc); });
-    static_for<0, NBUF - 1>([&](auto fc) {
-        if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, fc);
+    for (; t0 + AFF_NS <= T; t0 += AFF_NS)                // t0 is a multiple of AFF_NS: slot index = position in the group
+        static_for<0, AFF_NS>([&](auto fc) { frame(t0 + decltype(fc)::value, decltype(fc)::value); });
+    static_for<0, AFF_NS - 1>([&](auto fc) {
+        if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, decltype(fc)::value);
     });
     if (a.s_out) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) a.s_out[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li] = sacc[r];
+    }
+}
+
+template <int IO, int NB, bool SV>
+int launch_affine(const AffArgs& sa, dim3 grid, hipStream_t st)
+{
+    static bool attr_set = false;                         // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_affine_scan_kernel<IO, NB, SV>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)AFF_LDS_BYTES);
+        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_affine_scan: LDS attribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, NB, SV>), grid, dim3(768), AFF_LDS_BYTES, st, sa);
+    GDKVM_LAUNCH_CHECK("gdr_affine_scan_kernel");
+    return GDKVM_OK;
+}
+
+template <int IO, bool SV>
+int launch_affine_nb(int nb, const AffArgs& sa, dim3 grid, hipStream_t st)
+{
+    switch (nb) {
+        case 4: return launch_affine<IO, 4, SV>(sa, grid, st);
+        case 8: return launch_affine<IO, 8, SV>(sa, grid, st);
+        default: return launch_affine<IO, 16, SV>(sa, grid, st);
     }
 }
 
@@ -1036,6 +1352,11 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
     if (int rc = gdkvm_check_device()) return rc;
     PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, ws.kn, ws.wtT, ws.qnT, ws.tii, ws.wti, T, Hh, N, Dv, rule, flags};
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!(flags & GDKVM_FLAG_TRAIN) && ws.nb <= 8) {     // inference: P and G directly, nothing else written
+        PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, T, Hh, N, Dv, rule, flags};
+        if (io_dtype == GDKVM_F32) return ws.nb == 4 ? launch_prepm<4, GDKVM_F32>(pm, B * T * Hh, st) : launch_prepm<8, GDKVM_F32>(pm, B * T * Hh, st);
+        return ws.nb == 4 ? launch_prepm<4, GDKVM_BF16>(pm, B * T * Hh, st) : launch_prepm<8, GDKVM_BF16>(pm, B * T * Hh, st);
+    }
     if (int rc = io_dtype == GDKVM_F32 ? launch_prep_nb<GDKVM_F32>(ws.nb, pa, B * T * Hh, st)
                                        : launch_prep_nb<GDKVM_BF16>(ws.nb, pa, B * T * Hh, st)) return rc;
     FoldArgs fa{ws.wti, ws.knT, ws.ut, ws.pp, ws.gg, Dv};
@@ -1079,17 +1400,8 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
     sa.diag = g_diag_buf;
 #endif
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
-#define GDKVM_SCAN_LAUNCH(IO, SV)                                                                         \
-    switch (ws.nb) {                                                                                      \
-        case 4: hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, 4, SV>), grid, dim3(512), 0, st, sa); break;      \
-        case 8: hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, 8, SV>), grid, dim3(512), 0, st, sa); break;      \
-        default: hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, 16, SV>), grid, dim3(512), 0, st, sa); break;    \
-    }
-    if (io_dtype == GDKVM_F32) { if (s_hist) { GDKVM_SCAN_LAUNCH(GDKVM_F32, true) } else { GDKVM_SCAN_LAUNCH(GDKVM_F32, false) } }
-    else { if (s_hist) { GDKVM_SCAN_LAUNCH(GDKVM_BF16, true) } else { GDKVM_SCAN_LAUNCH(GDKVM_BF16, false) } }
-#undef GDKVM_SCAN_LAUNCH
-    GDKVM_LAUNCH_CHECK("gdr_affine_scan_kernel");
-    return GDKVM_OK;
+    if (io_dtype == GDKVM_F32) return s_hist ? launch_affine_nb<GDKVM_F32, true>(ws.nb, sa, grid, st) : launch_affine_nb<GDKVM_F32, false>(ws.nb, sa, grid, st);
+    return s_hist ? launch_affine_nb<GDKVM_BF16, true>(ws.nb, sa, grid, st) : launch_affine_nb<GDKVM_BF16, false>(ws.nb, sa, grid, st);
 }
 
 extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* phi_out, const void* workspace, size_t workspace_bytes,
@@ -1111,16 +1423,7 @@ extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* p
     sa.diag = nullptr;
 #endif
     const dim3 grid((unsigned)(B * Hh * (GDKVM_DK / 16)));
-#define GDKVM_TR_LAUNCH(IO)                                                                              \
-    switch (ws.nb) {                                                                                     \
-        case 4: hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, 4, false>), grid, dim3(512), 0, st, sa); break;   \
-        case 8: hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, 8, false>), grid, dim3(512), 0, st, sa); break;   \
-        default: hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, 16, false>), grid, dim3(512), 0, st, sa); break; \
-    }
-    if (io_dtype == GDKVM_F32) { GDKVM_TR_LAUNCH(GDKVM_F32) } else { GDKVM_TR_LAUNCH(GDKVM_BF16) }
-#undef GDKVM_TR_LAUNCH
-    GDKVM_LAUNCH_CHECK("gdr_affine_scan_kernel<transition>");
-    return GDKVM_OK;
+    return io_dtype == GDKVM_F32 ? launch_affine_nb<GDKVM_F32, false>(ws.nb, sa, grid, st) : launch_affine_nb<GDKVM_BF16, false>(ws.nb, sa, grid, st);
 }
 
 extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,

@@ -11,7 +11,7 @@ static inline int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
 // and, filled only by a training-mode prep (GDKVM_FLAG_TRAIN) for the backward:  kn [NP][64] | wtT [64][NP] | qnT [64][NP]
 // | tii [nb][16][16] (the diagonal-block inverses T_II)
 // wti [4][nb][64][4] = Wt as accumulator images (like ut), the fold kernel's B operand
-// and the folded per-frame affine map the forward scan consumes (gdr_fold_kernel):  pp [64][64] = I - Kn^T Wt (row-major)
+// and the folded per-frame affine map the forward scan consumes (gdr_fold_kernel):  pp [4][4][64][4] = I - Kn^T Wt as A-operand images (row tile, k tile, lane)
 // | gg [Dv/16][4][64][4] = Kn^T Ut as accumulator images (slice, row tile, lane)
 struct WsView { float* wt; float* knT; float* ut; float* qinv; float* kn; float* wtT; float* qnT; float* tii; float* wti; float* pp; float* gg; float* zero; char* trash; int nb; };
 
