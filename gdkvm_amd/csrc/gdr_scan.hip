@@ -764,15 +764,31 @@ void launch_fold(const FoldArgs& fa, int FH, hipStream_t st)
 //             Kn and M^T tiles -> LDS as accumulator images
 //   phase 4   wave w: P^T tiles (w, m) = delta - Kn_w^T-image x M^T_m  (the C layout of P^T IS the state waves' A layout
 //             of P), then G tiles (m, cV) = M_m x V_cV for cV = w, w+4, ...
+//             bf16 I/O, N <= 64: V is exactly bf16, so G runs on v_mfma_f32_16x16x32_bf16 with M split into three bf16
+//             terms (split3): 6 MFMA of 16 cycles per tile instead of 16 of 32, same accuracy.
 struct PrepMArgs {
     const void* q; const void* k; const void* v; const float* beta;
     float* qinv; float* pp; float* gg;
     int T, Hh, N, Dv, rule, flags;
+#ifdef GDKVM_DIAG
+    unsigned long long* diag;
+#endif
 };
 
-__host__ __device__ constexpr size_t prepm_lds_bytes(int NB)
-{   // kinv beta qinv pad | negB pairs | Ld | TmT | kni [4][NB] | mt [4][NB]   (images of 64 x f32x4)
-    return (size_t)(4 * 16 * NB + (NB * (NB - 1) / 2 + 2 * NB + 8 * NB) * 256) * sizeof(float);
+__host__ __device__ constexpr bool prepm_split(int NB, int IO) { return NB == 4 && IO == GDKVM_BF16; }
+__host__ __device__ constexpr size_t prepm_lds_bytes(int NB, int IO)
+{   // kinv beta qinv pad | negB pairs | Ld | TmT | kni [4][NB] | mt [4][NB]   (images of 64 x f32x4) | m3 [3][4][NB/2] (bf16 arm)
+    return (size_t)(4 * 16 * NB + (NB * (NB - 1) / 2 + 2 * NB + 8 * NB + (prepm_split(NB, IO) ? 3 * 4 * (NB / 2) : 0)) * 256) * sizeof(float);
+}
+
+// x = h + m + l with h, m, l bfloat16: 24 significant bits, every step exact in fp32.  A product of such a triple with an
+// exact bf16 operand on the bf16 MFMA (fp32 accumulate) is as accurate as the fp32 MFMA at 3/16 of its issue cycles.
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
+{
+    h = static_cast<__bf16>(x);
+    const float r1 = x - static_cast<float>(h);
+    m = static_cast<__bf16>(r1);
+    l = static_cast<__bf16>(r1 - static_cast<float>(m));
 }
 
 template <int NB, int IO>
@@ -788,6 +804,12 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
     f32x4* s_TmT = s_Ld + NB * 64;
     f32x4* s_kni = s_TmT + NB * 64;
     f32x4* s_mt = s_kni + 4 * NB * 64;
+    constexpr bool SPLIT = prepm_split(NB, IO);
+    constexpr int KS = NB / 2;                            // 32-token k-steps of the bf16 MFMA
+    uint2* s_m3 = reinterpret_cast<uint2*>(s_mt + 4 * NB * 64);   // [3 terms][4 m][KS][64 lanes][2 halves]: A images of M
+    float* s_K = reinterpret_cast<float*>(s_kni);         // raw K rows [NP][KLD] fp32 until phase 3 overwrites the region
+    constexpr int KLD = GDKVM_DK + 4;
+    static_assert(NP * KLD <= 8 * NB * 256, "the K staging tile aliases kni + mt");
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -797,50 +819,74 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
     const int N = a.N, Hh = a.Hh, Dv = a.Dv, nsl = Dv / 16;
     const bool seq = a.rule == GDKVM_RULE_DELTA_SEQUENTIAL;
     const bool p_identity = a.rule == GDKVM_RULE_GATED_LINEAR;
+    const int t = a.T;                                    // diagnostic builds: stamps go to row T of the buffer
+    (void)t;
+    DIAG_STAMP(0);
 
-    // this wave's Kn column tile and its first V tile, raw, in the accumulator layout: x[I][r] = X[token 16I+4g+r][16c+li]
-    float xk[NB][4], xv[2][NB][4];
-    auto load_v = [&](int cV, float (&d)[NB][4]) __attribute__((always_inline)) {
+    // this wave's first V tile, raw, in the accumulator layout: x[I][r] = V[token 16I+4g+r][16cV+li]
+    float xk[NB][4], xv[SPLIT ? 1 : 2][SPLIT ? 1 : NB][4];
+    bf16x8 vb[2][KS];                                     // SPLIT: B operand of the bf16 MFMA, k = 32ks + 8g + j
+    auto load_v = [&](int cV, float (&d)[SPLIT ? 1 : NB][4]) __attribute__((always_inline)) {
         cV = min(cV, nsl - 1);
 #pragma unroll
-        for (int I = 0; I < NB; ++I)
+        for (int I = 0; I < (SPLIT ? 1 : NB); ++I)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 d[I][r] = load1<IO>(a.v, ((bt * N + min(16 * I + 4 * g + r, N - 1)) * Hh + h) * Dv + 16 * cV + li);
     };
+    auto load_vb = [&](int cV, bf16x8 (&d)[KS]) __attribute__((always_inline)) {
+        cV = min(cV, nsl - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                d[ks][j] = static_cast<const __bf16*>(a.v)[((bt * N + min(32 * ks + 8 * g + j, N - 1)) * Hh + h) * Dv + 16 * cV + li];
+    };
+
+    // ---- phase 0 (a5 prologue): ONE pass over the k and q rows by all 256 threads (4 threads per token, 16 channels each):
+    //      K staged in LDS as fp32 for the Gram blocks and the Kn tiles, inverse norms by a 4-lane reduction, gates
+#pragma unroll
+    for (int rep = 0; rep < NP / 64; ++rep) {
+        const int n = rep * 64 + (tid >> 2), qd = tid & 3;
+        float sk = 0.f, sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = {0.f, 0.f, 0.f, 0.f};
+            if (n < N) {
+                x = load4<IO>(a.k, ((bt * N + n) * Hh + h) * GDKVM_DK + 16 * qd + 4 * j);
+                y = load4<IO>(a.q, ((bt * N + n) * Hh + h) * GDKVM_DK + 16 * qd + 4 * j);
+            }
+            *reinterpret_cast<f32x4*>(s_K + n * KLD + 16 * qd + 4 * j) = x;
+            sk += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+            sq += y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+        }
+        sk += __shfl_xor(sk, 1); sq += __shfl_xor(sq, 1);
+        sk += __shfl_xor(sk, 2); sq += __shfl_xor(sq, 2);
+        if (qd == 0) {
+            float kinv = 0.f, qinv = 0.f, bta = 0.f;
+            if (n < N) {
+                kinv = qinv = 1.f;
+                if (a.flags & GDKVM_FLAG_NORMALIZE_QK) {
+                    kinv = 1.0f / sqrtf(sk + GDKVM_EPS_NORM);
+                    qinv = 1.0f / sqrtf(sq + GDKVM_EPS_NORM);
+                }
+                bta = a.beta[(bt * N + n) * Hh + h];
+                if (a.flags & GDKVM_FLAG_GATE_LOGITS) bta = 1.0f / (1.0f + expf(-bta));
+            }
+            s_kinv[n] = kinv;
+            s_beta[n] = bta;
+            s_qinv[n] = qinv;
+            a.qinv[(size_t)fh * NP + n] = qinv;
+        }
+    }
+    __syncthreads();
+    DIAG_STAMP(1);
+    if constexpr (SPLIT) load_vb(w, vb[0]);               // first V tile: in flight behind phases 1-3
+    else load_v(w, xv[0]);
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            xk[I][r] = load1<IO>(a.k, ((bt * N + min(16 * I + 4 * g + r, N - 1)) * Hh + h) * GDKVM_DK + 16 * w + li);
-    load_v(w, xv[0]);
-
-    // ---- phase 0
-    for (int n = tid; n < NP; n += 256) {
-        float kinv = 0.f, qinv = 0.f, bta = 0.f;
-        if (n < N) {
-            kinv = qinv = 1.f;
-            if (a.flags & GDKVM_FLAG_NORMALIZE_QK) {
-                float sk = 0.f, sq = 0.f;
-#pragma unroll
-                for (int c = 0; c < GDKVM_DK; c += 4) {
-                    const f32x4 x = load4<IO>(a.k, ((bt * N + n) * Hh + h) * GDKVM_DK + c);
-                    const f32x4 y = load4<IO>(a.q, ((bt * N + n) * Hh + h) * GDKVM_DK + c);
-                    sk += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
-                    sq += y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
-                }
-                kinv = 1.0f / sqrtf(sk + GDKVM_EPS_NORM);
-                qinv = 1.0f / sqrtf(sq + GDKVM_EPS_NORM);
-            }
-            bta = a.beta[(bt * N + n) * Hh + h];
-            if (a.flags & GDKVM_FLAG_GATE_LOGITS) bta = 1.0f / (1.0f + expf(-bta));
-        }
-        s_kinv[n] = kinv;
-        s_beta[n] = bta;
-        s_qinv[n] = qinv;
-        a.qinv[(size_t)fh * NP + n] = qinv;
-    }
-    __syncthreads();
+        for (int r = 0; r < 4; ++r) xk[I][r] = s_K[(16 * I + 4 * g + r) * KLD + 16 * w + li];
 
     if (seq) {
         // ---- phase 1
@@ -852,8 +898,8 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
             f32x4 kI[4], kJ[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                kI[m] = load4<IO>(a.k, ((bt * N + min(nI, N - 1)) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
-                kJ[m] = load4<IO>(a.k, ((bt * N + min(nJ, N - 1)) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
+                kI[m] = *reinterpret_cast<const f32x4*>(s_K + nI * KLD + 16 * m + 4 * g);
+                kJ[m] = *reinterpret_cast<const f32x4*>(s_K + nJ * KLD + 16 * m + 4 * g);
             }
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             if (J == I) {                      // lane (g,li) reg r = k_{I,4g+r} . k_{I,li}: the image of L_II[li][4g+r]
@@ -888,6 +934,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
             }
         }
         __syncthreads();
+        DIAG_STAMP(2);
         // ---- phase 2: T_II by forward substitution (16 threads per block, one column each), stored transposed
         {
             const int I = tid >> 4, j = tid & 15;
@@ -913,8 +960,10 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
         }
         __syncthreads();
     }
+    DIAG_STAMP(3);
 
     // ---- phase 3: back substitution on Kn column tile w
+    if (!seq) __syncthreads();                            // every wave has taken its Kn tile out of the staging tile (kni aliases it)
     f32x4 KN[NB], Z[NB];
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
@@ -946,11 +995,27 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
         const f32x4 bt4 = *reinterpret_cast<const f32x4*>(s_beta + 16 * I + 4 * g);
-        s_mt[(w * NB + I) * 64 + lane] = Z[I] * bt4;
+        const f32x4 mtI = Z[I] * bt4;
+        s_mt[(w * NB + I) * 64 + lane] = mtI;
+        if constexpr (SPLIT) {             // this lane's 4 tokens 16I+4g+r of row 16w+li are half (g&1) of A lane (2(I&1)+(g>>1), li), ks = I>>1
+            __bf16 hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) split3(mtI[r], hh[r], mm[r], ll[r]);
+            auto pack = [](const __bf16 (&x)[4]) {
+                return make_uint2((unsigned)__builtin_bit_cast(unsigned short, x[0]) | ((unsigned)__builtin_bit_cast(unsigned short, x[1]) << 16),
+                                  (unsigned)__builtin_bit_cast(unsigned short, x[2]) | ((unsigned)__builtin_bit_cast(unsigned short, x[3]) << 16));
+            };
+            const int slot = (((w * KS + (I >> 1)) * 64 + (2 * (I & 1) + (g >> 1)) * 16 + li) << 1) + (g & 1);
+            s_m3[slot] = pack(hh);
+            s_m3[4 * KS * 128 + slot] = pack(mm);
+            s_m3[2 * 4 * KS * 128 + slot] = pack(ll);
+        }
     }
     __syncthreads();
+    DIAG_STAMP(4);
 
     // ---- phase 4: P images and G tiles
+    const int nlast = N - 16 * (NB - 1);                  // real tokens in the last block (<= 0: none)
     f32x4 mt[4][NB];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -964,43 +1029,89 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int I = 0; I < NB; ++I) {
+                for (int I = 0; I < NB - 1; ++I) {
                     if (I & 1) acc1 = mfma4(KN[I][r], mt[m][I][r], acc1);
                     else acc0 = mfma4(KN[I][r], mt[m][I][r], acc0);
                 }
+            // k-step (I, r) covers tokens 16I + 4g + r: in the last block only the first nlast steps hold real tokens
+            if (nlast > 0) { acc0 = mfma4(KN[NB - 1][0], mt[m][NB - 1][0], acc0);
+                if (nlast > 1) { acc1 = mfma4(KN[NB - 1][1], mt[m][NB - 1][1], acc1);
+                    if (nlast > 2) { acc0 = mfma4(KN[NB - 1][2], mt[m][NB - 1][2], acc0);
+                        if (nlast > 3) acc1 = mfma4(KN[NB - 1][3], mt[m][NB - 1][3], acc1); } } }
         }
         f32x4 o;                              // lane (g,li) reg r = P[16m + li][16w + 4g + r]: image (row tile m, k tile w)
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = ((16 * m + li == 16 * w + 4 * g + r) ? 1.f : 0.f) - (acc0[r] + acc1[r]);
         pp[(m * 4 + w) * 64 + lane] = o;
     }
+    DIAG_STAMP(5);
     f32x4* gg = reinterpret_cast<f32x4*>(a.gg) + (size_t)fh * nsl * 4 * 64;
-    auto g_tiles = [&](int cV, const float (&x)[NB][4]) __attribute__((always_inline)) {
+    auto g_tiles = [&](int cV, const float (&x)[SPLIT ? 1 : NB][4]) __attribute__((always_inline)) {
+        if constexpr (!SPLIT)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int I = 0; I < NB; ++I) {
+                for (int I = 0; I < NB - 1; ++I) {
                     if (I & 1) acc1 = mfma4(mt[m][I][r], x[I][r], acc1);
                     else acc0 = mfma4(mt[m][I][r], x[I][r], acc0);
                 }
+            if (nlast > 0) { acc0 = mfma4(mt[m][NB - 1][0], x[NB - 1][0], acc0);
+                if (nlast > 1) { acc1 = mfma4(mt[m][NB - 1][1], x[NB - 1][1], acc1);
+                    if (nlast > 2) { acc0 = mfma4(mt[m][NB - 1][2], x[NB - 1][2], acc0);
+                        if (nlast > 3) acc1 = mfma4(mt[m][NB - 1][3], x[NB - 1][3], acc1); } } }
             if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = acc0 + acc1;
         }
     };
-    for (int cV = w; cV < nsl; cV += 8) {     // two V tiles per trip: the next tile's loads are in flight behind the MFMAs
-        load_v(cV + 4, xv[1]);
-        g_tiles(cV, xv[0]);
-        load_v(cV + 8, xv[0]);
-        g_tiles(cV + 4, xv[1]);
+    if constexpr (SPLIT) {
+        bf16x8 am[4][KS][3];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+                    am[m][ks][sp] = *reinterpret_cast<const bf16x8*>(&s_m3[sp * 4 * KS * 128 + ((m * KS + ks) * 64 + lane) * 2]);
+        auto g_tiles3 = [&](int cV, const bf16x8 (&x)[KS]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {          // smallest terms first
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m][ks][2], x[ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m][ks][1], x[ks], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m][ks][0], x[ks], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m][ks][0], x[ks], acc0, 0, 0, 0);
+                }
+                if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = acc0 + acc1;
+            }
+        };
+        for (int cV = w; cV < nsl; cV += 8) {
+            load_vb(cV + 4, vb[1]);
+            g_tiles3(cV, vb[0]);
+            load_vb(cV + 8, vb[0]);
+            g_tiles3(cV + 4, vb[1]);
+        }
+    } else {
+        for (int cV = w; cV < nsl; cV += 8) {     // two V tiles per trip: the next tile's loads are in flight behind the MFMAs
+            load_v(cV + 4, xv[1]);
+            g_tiles(cV, xv[0]);
+            load_v(cV + 8, xv[0]);
+            g_tiles(cV + 4, xv[1]);
+        }
     }
+    DIAG_STAMP(6);
 }
 
 template <int NB, int IO>
 int launch_prepm(const PrepMArgs& pa, int FH, hipStream_t st)
 {
-    const size_t lds = prepm_lds_bytes(NB);
+    const size_t lds = prepm_lds_bytes(NB, IO);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_prepm_kernel<NB, IO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1354,6 +1465,9 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!(flags & GDKVM_FLAG_TRAIN) && ws.nb <= 8) {     // inference: P and G directly, nothing else written
         PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, T, Hh, N, Dv, rule, flags};
+#ifdef GDKVM_DIAG
+        pm.diag = g_diag_buf;
+#endif
         if (io_dtype == GDKVM_F32) return ws.nb == 4 ? launch_prepm<4, GDKVM_F32>(pm, B * T * Hh, st) : launch_prepm<8, GDKVM_F32>(pm, B * T * Hh, st);
         return ws.nb == 4 ? launch_prepm<4, GDKVM_BF16>(pm, B * T * Hh, st) : launch_prepm<8, GDKVM_BF16>(pm, B * T * Hh, st);
     }

@@ -31,7 +31,7 @@ def main():
     wsb = lib.gdkvm_scan_workspace_bytes(B, T, Hh, N, Dk, Dv)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     r = torch.empty(B, T, N, Hh, Dv, device=dev, dtype=torch.bfloat16); s = torch.empty(B, Hh, Dk, Dv, device=dev)
-    diag = torch.zeros(T * 8, dtype=torch.int64, device=dev)
+    diag = torch.zeros((T + 1) * 8, dtype=torch.int64, device=dev)
     lib.gdkvm_diag_set_buffer(ctypes.c_void_p(diag.data_ptr()))
     vp = ctypes.c_void_p
     lib.gdkvm_scan_fwd.argtypes = [vp] * 10 + [ctypes.c_size_t] + [ctypes.c_int] * 9 + [vp]
@@ -40,7 +40,14 @@ def main():
                                 s.data_ptr(), None, ws.data_ptr(), wsb, B, T, Hh, N, Dk, Dv, 1, 2, 3, None)
         assert rc == 0
         torch.cuda.synchronize()
-    d8 = diag.cpu().reshape(T, 8)
+    dall = diag.cpu().reshape(T + 1, 8)
+    pr = dall[T]
+    print("prep (gdr_prepm_kernel), block 0 wave 0, ticks:")
+    for i, n in enumerate(["entry loads issued + norms/gates (phase 0)", "Gram blocks (phase 1)", "T_II forward substitution (phase 2)",
+                           "back substitution on Kn tile (phase 3)", "P tiles (phase 4a)", "G tiles (phase 4b)"]):
+        print(f"  {n:48s} {int(pr[i + 1] - pr[i]):8d}")
+    print(f"  total {int(pr[6] - pr[0])}")
+    d8 = dall[:T]
     d = d8[:, :4]
     seg = torch.stack([d8[:, 4] - d8[:, 0], d8[:, 5] - d8[:, 4], d8[:, 6] - d8[:, 5], d8[:, 1] - d8[:, 6], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2]], 1).float()
     names = ["S images: 4 ds_read_b128 (waited)", "issue prefetch of frame t+6 (6 loads)", "gate (sigmoid of alpha_t; waits its load)",
