@@ -340,6 +340,47 @@ struct GItem { f32x4 a[4]; float b[4][4]; };                           // BWD re
 struct XItem { f32x4 w[4]; f32x4 u; float alpha; };                    // state waves:     X = Wt S, U = Ut - aX
 struct KItem { f32x4 k[4]; };                                          // state waves:     S <- aS + Kn^T U (4 token tiles)
 
+// x = h + m + l with h, m, l bfloat16: 24 significant bits, every step exact in fp32.  A product of such a triple with an
+// exact bf16 operand on the bf16 MFMA (fp32 accumulate) is as accurate as the fp32 MFMA at 3/16 of its issue cycles; a
+// product of two triples needs the six terms down to 2^-16 (hh, hm, mh, hl, lh, mm): 12 MFMA of 16 cycles for K = 64
+// instead of 16 of 32.
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
+{
+    h = static_cast<__bf16>(x);
+    const float r1 = x - static_cast<float>(h);
+    m = static_cast<__bf16>(r1);
+    l = static_cast<__bf16>(r1 - static_cast<float>(m));
+}
+// split3 of four values at once on the packed converter: the three terms as 4 x bf16 each
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
+{
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){a, b}, bf16x2_t));
+}
+__device__ __forceinline__ void split3x4(const f32x4& x, uint2& h, uint2& m, uint2& l)
+{
+    h = make_uint2(cvt_pk_bf16(x[0], x[1]), cvt_pk_bf16(x[2], x[3]));
+    const float r0 = x[0] - __uint_as_float(h.x << 16), r1 = x[1] - __uint_as_float(h.x & 0xffff0000u);
+    const float r2 = x[2] - __uint_as_float(h.y << 16), r3 = x[3] - __uint_as_float(h.y & 0xffff0000u);
+    m = make_uint2(cvt_pk_bf16(r0, r1), cvt_pk_bf16(r2, r3));
+    l = make_uint2(cvt_pk_bf16(r0 - __uint_as_float(m.x << 16), r1 - __uint_as_float(m.x & 0xffff0000u)),
+                   cvt_pk_bf16(r2 - __uint_as_float(m.y << 16), r3 - __uint_as_float(m.y & 0xffff0000u)));
+}
+__device__ __forceinline__ uint2 pack_bf16x4(const __bf16 (&x)[4])
+{
+    return make_uint2((unsigned)__builtin_bit_cast(unsigned short, x[0]) | ((unsigned)__builtin_bit_cast(unsigned short, x[1]) << 16),
+                      (unsigned)__builtin_bit_cast(unsigned short, x[2]) | ((unsigned)__builtin_bit_cast(unsigned short, x[3]) << 16));
+}
+// Four consecutive k values (k0 = 16c + 4g .. +3, accumulator layout of k tile c) of row `row16` of a 16-row tile go to the
+// bf16 A/B-operand image of that tile as half (g & 1) of lane (2(c&1) + (g>>1), row16) of k step c >> 1.  Returns the index in
+// 8-byte units inside a [2 ksteps][64 lanes][2 halves] image.
+__device__ __forceinline__ int split_slot(int c, int g, int row16)
+{
+    return ((((c >> 1) * 64) + (2 * (c & 1) + (g >> 1)) * 16 + row16) << 1) + (g & 1);
+}
+constexpr int SPLIT_IMG = 2 * 64 * 2;                    // uint2 per term image of one 16-row tile (K = 64)
+
 __device__ __forceinline__ float fast_sigmoid(float x)
 {   // v_exp_f32 + v_rcp_f32 (1 ulp each): relative error < 1e-6 for |x| < 16, far inside the 1e-4 budget
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
@@ -732,9 +773,14 @@ __global__ __launch_bounds__(256) void gdr_fold_kernel(FoldArgs a)
             if (c < nlim) {
                 if (isP) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {                  // P[16w + 4g + r][16c + li] -> image (w, m = c), lane (li>>2, 4g+r), reg li&3
+                    for (int r = 0; r < 4; ++r) {                  // P[16w + 4g + r][k = 16c + li] -> term images of row tile w
                         const int row = 16 * w + 4 * g + r, col = 16 * c + li;
-                        a.pp[(((fh * 4 + w) * 4 + c) * 64 + (li >> 2) * 16 + 4 * g + r) * 4 + (li & 3)] = (row == col ? 1.f : 0.f) - o[r];
+                        __bf16 t3[3];
+                        split3((row == col ? 1.f : 0.f) - o[r], t3[0], t3[1], t3[2]);
+                        __bf16* img = reinterpret_cast<__bf16*>(a.pp) + (fh * 4 + w) * (size_t)(3 * SPLIT_IMG * 4);
+                        const int e = split_slot(c, li >> 2, 4 * g + r) * 4 + (li & 3);      // k0 = 16c + 4(li>>2), element li&3
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) img[sp * SPLIT_IMG * 4 + e] = t3[sp];
                     }
                 } else {
                     reinterpret_cast<f32x4*>(a.gg)[((fh * nsl + c) * 4 + w) * 64 + lane] = o;
@@ -781,15 +827,7 @@ __host__ __device__ constexpr size_t prepm_lds_bytes(int NB, int IO)
     return (size_t)(4 * 16 * NB + (NB * (NB - 1) / 2 + 2 * NB + 8 * NB + (prepm_split(NB, IO) ? 3 * 4 * (NB / 2) : 0)) * 256) * sizeof(float);
 }
 
-// x = h + m + l with h, m, l bfloat16: 24 significant bits, every step exact in fp32.  A product of such a triple with an
-// exact bf16 operand on the bf16 MFMA (fp32 accumulate) is as accurate as the fp32 MFMA at 3/16 of its issue cycles.
-__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l)
-{
-    h = static_cast<__bf16>(x);
-    const float r1 = x - static_cast<float>(h);
-    m = static_cast<__bf16>(r1);
-    l = static_cast<__bf16>(r1 - static_cast<float>(m));
-}
+
 
 template <int NB, int IO>
 __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepMArgs a)
@@ -1001,14 +1039,10 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
             __bf16 hh[4], mm[4], ll[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) split3(mtI[r], hh[r], mm[r], ll[r]);
-            auto pack = [](const __bf16 (&x)[4]) {
-                return make_uint2((unsigned)__builtin_bit_cast(unsigned short, x[0]) | ((unsigned)__builtin_bit_cast(unsigned short, x[1]) << 16),
-                                  (unsigned)__builtin_bit_cast(unsigned short, x[2]) | ((unsigned)__builtin_bit_cast(unsigned short, x[3]) << 16));
-            };
-            const int slot = (((w * KS + (I >> 1)) * 64 + (2 * (I & 1) + (g >> 1)) * 16 + li) << 1) + (g & 1);
-            s_m3[slot] = pack(hh);
-            s_m3[4 * KS * 128 + slot] = pack(mm);
-            s_m3[2 * 4 * KS * 128 + slot] = pack(ll);
+            const int slot = w * KS * 128 + split_slot(I, g, li);
+            s_m3[slot] = pack_bf16x4(hh);
+            s_m3[4 * KS * 128 + slot] = pack_bf16x4(mm);
+            s_m3[2 * 4 * KS * 128 + slot] = pack_bf16x4(ll);
         }
     }
     __syncthreads();
@@ -1021,7 +1055,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int I = 0; I < NB; ++I) mt[m][I] = s_mt[(m * NB + I) * 64 + lane];
-    f32x4* pp = reinterpret_cast<f32x4*>(a.pp) + (size_t)fh * 16 * 64;
+    uint2* pp = reinterpret_cast<uint2*>(a.pp) + (size_t)fh * (4 * 3 * SPLIT_IMG);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -1039,10 +1073,14 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
                     if (nlast > 2) { acc0 = mfma4(KN[NB - 1][2], mt[m][NB - 1][2], acc0);
                         if (nlast > 3) acc1 = mfma4(KN[NB - 1][3], mt[m][NB - 1][3], acc1); } } }
         }
-        f32x4 o;                              // lane (g,li) reg r = P[16m + li][16w + 4g + r]: image (row tile m, k tile w)
+        // lane (g,li) reg r = P[16m + li][k = 16w + 4g + r]: four consecutive k of row li of row tile m -> its term images
+        __bf16 t3[3][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = ((16 * m + li == 16 * w + 4 * g + r) ? 1.f : 0.f) - (acc0[r] + acc1[r]);
-        pp[(m * 4 + w) * 64 + lane] = o;
+        for (int r = 0; r < 4; ++r)
+            split3(((16 * m + li == 16 * w + 4 * g + r) ? 1.f : 0.f) - (acc0[r] + acc1[r]), t3[0][r], t3[1][r], t3[2][r]);
+        const int e = split_slot(w, g, li);
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) pp[(m * 3 + sp) * SPLIT_IMG + e] = pack_bf16x4(t3[sp]);
     }
     DIAG_STAMP(5);
     f32x4* gg = reinterpret_cast<f32x4*>(a.gg) + (size_t)fh * nsl * 4 * 64;
@@ -1146,9 +1184,19 @@ struct AffArgs {
     unsigned long long* diag;
 #endif
 };
-constexpr int AFF_D = 5, AFF_NS = AFF_D + 1;
-constexpr int AFF_SLOT_F4 = 16 * 64 + 4 * 64 + 16;               // f32x4 per ring slot: P [4][4][64] | G [4][64] | alpha [64 floats]
-constexpr size_t AFF_LDS_BYTES = (size_t)(2 * 4 * 64 + AFF_NS * AFF_SLOT_F4) * sizeof(f32x4);
+// LDS (16-byte units): S term images [2 parities][3 terms][2 ksteps][64] | (fp32 arm) S fp32 images [2][4][64] | ring slots
+template <int IO> struct RItem;                                        // read-out operands of one 16-token tile
+template <> struct RItem<GDKVM_F32> { f32x4 q[4]; float qinv; };
+template <> struct RItem<GDKVM_BF16> { bf16x8 q[2]; float qinv; };
+constexpr int AFF_P_F4 = 4 * 3 * 2 * 64;                  // P of one frame: [4 row tiles][3 terms][2 ksteps][64 lanes] x 16 B = 24 KiB
+constexpr int AFF_SLOT_F4 = AFF_P_F4 + 4 * 64 + 16;       // + G [4][64] f32x4 + alpha [64 floats]
+constexpr int AFF_S3_F4 = 2 * 3 * 2 * 64;
+constexpr int AFF_LOADS = 8;                              // LDS-DMA instructions per loader wave per frame
+__host__ __device__ constexpr int aff_slots(int IO) { return IO == GDKVM_F32 ? 4 : 5; }
+__host__ __device__ constexpr size_t aff_lds_bytes(int IO)
+{
+    return (size_t)(AFF_S3_F4 + (IO == GDKVM_F32 ? 2 * 4 * 64 : 0) + aff_slots(IO) * AFF_SLOT_F4) * 16;
+}
 
 __device__ __forceinline__ void aff_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -1156,9 +1204,11 @@ template <int IO, int NB, bool SAVE>
 __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
 {
     constexpr int NP = 16 * NB, JT = NB / 4, NBUF = 4, DEPTH = 3, UFR = NBUF / JT;
+    constexpr int NS = aff_slots(IO), D = NS - 1;
     extern __shared__ __attribute__((aligned(16))) f32x4 aff_smem[];
-    f32x4* s_S = aff_smem;                                // [2][4*64]
-    f32x4* s_ring = aff_smem + 2 * 4 * 64;                // [AFF_NS][AFF_SLOT_F4]
+    uint2* s_S3 = reinterpret_cast<uint2*>(aff_smem);      // [parity][term] images of SPLIT_IMG uint2: B operand of the bf16 MFMA
+    f32x4* s_Sf = aff_smem + AFF_S3_F4;                    // fp32 arm only: accumulator images for the exact fp32 read-out
+    f32x4* s_ring = s_Sf + (IO == GDKVM_F32 ? 2 * 4 * 64 : 0);
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1176,13 +1226,13 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
 
     if (role == 2) {
         // ------------------------------------------------------------------------------ loader waves
-        const float* pp_lane = a.pp + ((fh0 * 4 + w) * 4 * 64 + lane) * 4;      // images [fh][w][m][lane][4]: 1 KiB per DMA
-        const size_t pp_fstride = (size_t)Hh * GDKVM_DK * GDKVM_DK;
+        const float* pp_lane = a.pp + ((fh0 * 4 + w) * (3 * 2 * 64) + lane) * 4;      // row tile w: 6 KiB contiguous
+        const size_t pp_fstride = (size_t)Hh * (GDKVM_DK * GDKVM_DK * 3 / 2);
         const float* gg_lane = a.gg + ((a.zero_g ? 0 : ((fh0 * nsl + sl) * 4 + w) * 64) + lane) * 4;
         const size_t gg_fstride = a.zero_g ? 0 : (size_t)Hh * nsl * 4 * 64 * 4;
         const float* al_ptr = a.alpha + fh0;
         auto issue = [&](int f) {
-            const int slot = f % AFF_NS;
+            const int slot = f % NS;
 #ifdef GDKVM_ABL_NOP
             f = 0;
 #endif
@@ -1190,27 +1240,36 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
             f32x4* dst = s_ring + slot * AFF_SLOT_F4;
             const float* pr = pp_lane + f * pp_fstride;
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-                __builtin_amdgcn_global_load_lds(pr + 256 * m, reinterpret_cast<__attribute__((address_space(3))) void*>(
-                    reinterpret_cast<uintptr_t>(dst + (w * 4 + m) * 64)), 16, 0, 0);
+            for (int i = 0; i < 6; ++i)
+                __builtin_amdgcn_global_load_lds(pr + 256 * i, reinterpret_cast<__attribute__((address_space(3))) void*>(
+                    reinterpret_cast<uintptr_t>(dst + (w * 6 + i) * 64)), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(gg_lane + f * gg_fstride, reinterpret_cast<__attribute__((address_space(3))) void*>(
-                reinterpret_cast<uintptr_t>(dst + 16 * 64 + w * 64)), 16, 0, 0);
+                reinterpret_cast<uintptr_t>(dst + AFF_P_F4 + w * 64)), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(al_ptr + (size_t)f * Hh, reinterpret_cast<__attribute__((address_space(3))) void*>(
-                reinterpret_cast<uintptr_t>(dst + 16 * 64 + 4 * 64)), 4, 0, 0);       // 64 copies of a_t (each loader wave: same value)
+                reinterpret_cast<uintptr_t>(dst + AFF_P_F4 + 4 * 64)), 4, 0, 0);       // 64 copies of a_t (each loader wave: same value)
         };
-        for (int f = 0; f < AFF_D; ++f) issue(f);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (AFF_D - 1)) : "memory");         // frame 0 has landed
+        for (int f = 0; f < D; ++f) issue(f);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFF_LOADS * (D - 2)) : "memory");     // frames 0 and 1 have landed
         aff_barrier();
         for (int t = 0; t < T; ++t) {
-            issue(t + AFF_D);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (AFF_D - 1)) : "memory");     // frame t+1 has landed
+            issue(t + D);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFF_LOADS * (D - 2)) : "memory"); // frame t+2 has landed
             aff_barrier();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after the workgroup is gone
         return;
     }
 
-    auto publish_state = [&](int par, const f32x4& sv) { s_S[par * 256 + w * 64 + lane] = sv; };
+    // Publishing S: the three bf16 terms of this wave's rows 16w + 4g + r (k of the next product) as B images; the fp32
+    // arm also keeps the accumulator image for its exact fp32 read-out.
+    auto publish_state = [&](int par, const f32x4& sv) __attribute__((always_inline)) {
+        uint2 t3[3];
+        split3x4(sv, t3[0], t3[1], t3[2]);
+        const int e = split_slot(w, g, li);
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) s_S3[(par * 3 + sp) * SPLIT_IMG + e] = t3[sp];
+        if constexpr (IO == GDKVM_F32) s_Sf[par * 256 + w * 64 + lane] = sv;
+    };
     f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
     if (role == 0) {
         if (a.s_in) {
@@ -1228,10 +1287,14 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
         const int last_item = T * JT - 1;
         const char* qbase = static_cast<const char*>(a.q) + (((size_t)b * T * N * Hh + h) * GDKVM_DK) * ESZ;
         const size_t q_fstride = (size_t)N * Hh * GDKVM_DK * ESZ;
-        const float* qinv_lane = a.qinv + fh0 * NP + 4 * g;
-        char* rbase = static_cast<char*>(a.r_out) + ((size_t)b * T * N * Hh * Dv + h * Dv + 16 * sl + li) * ESZ;
+        const float* qinv_lane = a.qinv + fh0 * NP + li;
+        // The read-out is computed TRANSPOSED, R^T = S^T Qn^T: the S images are also the A operand of S^T and the q rows as
+        // loaded are also the B operand of Qn^T, so only the two MFMA arguments swap -- and lane (g, li) ends up with columns
+        // 4g..4g+3 of token li: one 8- or 16-byte store per lane into the token's row instead of four scattered 2-byte ones
+        // (the store issue made the read waves the slowest role of a frame).
+        char* rbase = static_cast<char*>(a.r_out) + ((size_t)b * T * N * Hh * Dv + h * Dv + 16 * sl + 4 * g) * ESZ;
         const size_t r_fstride = (size_t)N * Hh * Dv * ESZ;
-        auto load_q = [&](int item, QItem<IO>& d) __attribute__((always_inline)) {
+        auto load_q = [&](int item, RItem<IO>& d) __attribute__((always_inline)) {
 #ifdef GDKVM_ABL_NOQ
             item = 0;
 #endif
@@ -1246,36 +1309,28 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) d.q[ks] = *reinterpret_cast<const bf16x8*>(p + 64 * ks + 16 * g);
             }
-            d.qinv = *reinterpret_cast<const f32x4*>(qinv_lane + (size_t)t * Hh * NP + 16 * tt);
+            d.qinv = qinv_lane[(size_t)t * Hh * NP + 16 * tt];
         };
-        QItem<IO> qb[NBUF];
+        RItem<IO> qb[NBUF];
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) load_q(i, qb[i]);
         aff_barrier();
-        // B operand of the frame's read-out, fetched once per frame.  fp32 arm: the four accumulator images (k = 16m + 4g + r).
-        // bf16 arm: k = 32ks + 8g + j is row 16m + 4g' + r with m = 2ks + (g>>1), g' = 2(g&1) + (j>>2), r = j&3 -- two 16-byte
-        // reads per ks -- split into bf16 S_hi + S_lo here.
-        struct SB { f32x4 f[4]; bf16x8 h[2], l[2]; };
+        // B operand of the frame's read-out, fetched once per frame: fp32 arm the four accumulator images (k = 16m + 4g + r,
+        // exact fp32 MFMA); bf16 arm the three term images (q is exactly bf16: two bf16 MFMA per k step).
+        struct SB { f32x4 f[4]; bf16x8 t[2][2]; };
         auto load_sb = [&](int par, SB& sb) __attribute__((always_inline)) {
             if constexpr (IO == GDKVM_F32) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) sb.f[m] = s_S[par * 256 + m * 64 + lane];
+                for (int m = 0; m < 4; ++m) sb.f[m] = s_Sf[par * 256 + m * 64 + lane];
             } else {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int src = par * 256 + (2 * ks + (g >> 1)) * 64 + 32 * (g & 1) + li;
-                    const f32x4 x0 = s_S[src], x1 = s_S[src + 16];
+                for (int sp = 0; sp < 2; ++sp)         // h + m: 16 bits of S, far inside the bf16 output's 2^-9
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float x = j < 4 ? x0[j & 3] : x1[j & 3];
-                        const __bf16 hi = static_cast<__bf16>(x);
-                        sb.h[ks][j] = hi;
-                        sb.l[ks][j] = static_cast<__bf16>(x - static_cast<float>(hi));
-                    }
-                }
+                    for (int ks = 0; ks < 2; ++ks)
+                        sb.t[sp][ks] = *reinterpret_cast<const bf16x8*>(&s_S3[(par * 3 + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
             }
         };
-        auto read_item = [&](int t, int j, const SB& sb, const QItem<IO>& cur, QItem<IO>& nxt) __attribute__((always_inline)) {
+        auto read_item = [&](int t, int j, const SB& sb, const RItem<IO>& cur, RItem<IO>& nxt) __attribute__((always_inline)) {
             const int tt = w + 4 * j;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             if constexpr (IO == GDKVM_F32) {
@@ -1283,41 +1338,33 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (m & 1) acc1 = mfma4(cur.q[m][r], sb.f[m][r], acc1);
-                        else acc0 = mfma4(cur.q[m][r], sb.f[m][r], acc0);
+                        if (m & 1) acc1 = mfma4(sb.f[m][r], cur.q[m][r], acc1);
+                        else acc0 = mfma4(sb.f[m][r], cur.q[m][r], acc0);
                     }
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.q[ks], sb.h[ks], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.q[ks], sb.l[ks], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb.t[1][ks], cur.q[ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb.t[0][ks], cur.q[ks], acc1, 0, 0, 0);
                 }
             }
             const f32x4 accR = (acc0 + acc1) * cur.qinv;
-            char* rp = rbase + t * r_fstride;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int nr = 16 * tt + 4 * g + r;
-                char* p = (nr < N && a.r_out) ? rp + (size_t)nr * (Hh * Dv * ESZ) : a.trash;
-#ifdef GDKVM_ABL_NOR
-                p = a.trash;
-#endif
-#ifdef GDKVM_ABL_NOST
-                if (t >= 0) continue;
-#endif
-                if constexpr (IO == GDKVM_F32) *reinterpret_cast<float*>(p) = accR[r];
-                else *reinterpret_cast<bf16_t*>(p) = f32_to_bf16(accR[r]);
-            }
+            const int nr = 16 * tt + li;                   // this lane's token; its columns 16sl + 4g .. +3
+            char* p = (nr < N && a.r_out) ? rbase + t * r_fstride + (size_t)nr * (Hh * Dv * ESZ) : a.trash;
+            if constexpr (IO == GDKVM_F32) *reinterpret_cast<f32x4*>(p) = accR;
+            else *reinterpret_cast<uint2*>(p) = make_uint2(cvt_pk_bf16(accR[0], accR[1]), cvt_pk_bf16(accR[2], accR[3]));
             load_q(t * JT + j + DEPTH, nxt);
         };
         auto frame = [&](int t, auto fc) __attribute__((always_inline)) {
             constexpr int F = decltype(fc)::value;
             SB sb;
+#ifndef GDKVM_ABL_NOREAD
             load_sb(t & 1, sb);
             static_for<0, JT>([&](auto jc) {
                 constexpr int i = F * JT + decltype(jc)::value;
                 read_item(t, decltype(jc)::value, sb, qb[i % NBUF], qb[(i + DEPTH) % NBUF]);
             });
+#endif
             aff_barrier();                                 // S_{t-1} consumed / S_t published
         };
         int t0 = 0;
@@ -1333,7 +1380,21 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
     __builtin_amdgcn_s_setprio(2);                        // the S -> S chain goes first at the SIMD's issue port
     const bool gate_logits = a.flags & GDKVM_FLAG_GATE_LOGITS;
     aff_barrier();
-    auto frame = [&](int t, int slot) __attribute__((always_inline)) {
+    // P, G and a of frame t+1 are read out of the ring during frame t (the loaders keep two frames landed), so after the
+    // barrier only the six S term images stand between the wave and its MFMAs
+    struct POp { bf16x8 pa[3][2]; f32x4 gt; float al; };
+    auto load_op = [&](int slot, POp& d) __attribute__((always_inline)) {
+        const f32x4* rs = s_ring + slot * AFF_SLOT_F4;
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) d.pa[sp][ks] = *reinterpret_cast<const bf16x8*>(&rs[(w * 6 + sp * 2 + ks) * 64 + lane]);
+        d.gt = rs[AFF_P_F4 + w * 64 + lane];
+        d.al = reinterpret_cast<const float*>(rs + AFF_P_F4 + 4 * 64)[lane];
+    };
+    POp ob[2];
+    load_op(0, ob[0]);
+    auto frame = [&](int t, int slot, const POp& op, POp& nxt) __attribute__((always_inline)) {
         const int par = t & 1;
         DIAG_STAMP(0);
         if constexpr (SAVE) {
@@ -1341,39 +1402,46 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) hp[(size_t)r * Dv] = sacc[r];
         }
-        const f32x4* rs = s_ring + slot * AFF_SLOT_F4;
-        f32x4 sreg[4], pa[4];
+        bf16x8 sb[3][2];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) sreg[m] = s_S[par * 256 + m * 64 + lane];
+        for (int sp = 0; sp < 3; ++sp)
 #pragma unroll
-        for (int m = 0; m < 4; ++m) pa[m] = rs[(w * 4 + m) * 64 + lane];
-        const f32x4 gt = rs[16 * 64 + w * 64 + lane];
-        const float al = reinterpret_cast<const float*>(rs + 16 * 64 + 4 * 64)[lane];
+            for (int ks = 0; ks < 2; ++ks)
+                sb[sp][ks] = *reinterpret_cast<const bf16x8*>(&s_S3[(par * 3 + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
         DIAG_STAMP(4);
-        DIAG_STAMP(5);
+        load_op((slot + 1) % NS, nxt);
+        __builtin_amdgcn_sched_barrier(0);                 // issued here, behind the S reads: left to the scheduler they sink below
+        DIAG_STAMP(5);                                     // the MFMAs and their latency lands on the final FMA
+        const float alpha = gate_logits ? fast_sigmoid(op.al) : op.al;
         DIAG_STAMP(6);
-        const float alpha = gate_logits ? fast_sigmoid(al) : al;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#define GDKVM_PS(ACC, PT, ST, KS) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op.pa[PT][KS], sb[ST][KS], ACC, 0, 0, 0)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int ks = 0; ks < 2; ++ks) {                   // the six terms down to 2^-16, smallest first, two chains
+            GDKVM_PS(acc0, 2, 0, ks); GDKVM_PS(acc1, 0, 2, ks); GDKVM_PS(acc0, 1, 1, ks);
+        }
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if (m & 1) acc1 = mfma4(pa[m][r], sreg[m][r], acc1);
-                else acc0 = mfma4(pa[m][r], sreg[m][r], acc0);
-            }
+        for (int ks = 0; ks < 2; ++ks) { GDKVM_PS(acc1, 1, 0, ks); GDKVM_PS(acc0, 0, 1, ks); }
+        GDKVM_PS(acc1, 0, 0, 0); GDKVM_PS(acc0, 0, 0, 1);
+#undef GDKVM_PS
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[r] = alpha * (acc0[r] + acc1[r]) + gt[r];
+        for (int r = 0; r < 4; ++r) sacc[r] = alpha * (acc0[r] + acc1[r]) + op.gt[r];
         DIAG_STAMP(1);
         publish_state(par ^ 1, sacc);
         DIAG_STAMP(2);
         aff_barrier();
         DIAG_STAMP(3);
     };
+    constexpr int UFS = NS % 2 == 0 ? NS : 2 * NS;        // t0 stays a multiple of NS and of 2: slot and buffer ids are static
     int t0 = 0;
-    for (; t0 + AFF_NS <= T; t0 += AFF_NS)                // t0 is a multiple of AFF_NS: slot index = position in the group
-        static_for<0, AFF_NS>([&](auto fc) { frame(t0 + decltype(fc)::value, decltype(fc)::value); });
-    static_for<0, AFF_NS - 1>([&](auto fc) {
-        if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, decltype(fc)::value);
+    for (; t0 + UFS <= T; t0 += UFS)
+        static_for<0, UFS>([&](auto fc) {
+            constexpr int F = decltype(fc)::value;
+            frame(t0 + F, F % NS, ob[F & 1], ob[(F + 1) & 1]);
+        });
+    static_for<0, UFS - 1>([&](auto fc) {
+        constexpr int F = decltype(fc)::value;
+        if (t0 + F < T) frame(t0 + F, F % NS, ob[F & 1], ob[(F + 1) & 1]);
     });
     if (a.s_out) {
 #pragma unroll
@@ -1387,11 +1455,11 @@ int launch_affine(const AffArgs& sa, dim3 grid, hipStream_t st)
     static bool attr_set = false;                         // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_affine_scan_kernel<IO, NB, SV>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)AFF_LDS_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)aff_lds_bytes(IO));
         if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_affine_scan: LDS attribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, NB, SV>), grid, dim3(768), AFF_LDS_BYTES, st, sa);
+    hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, NB, SV>), grid, dim3(768), aff_lds_bytes(IO), st, sa);
     GDKVM_LAUNCH_CHECK("gdr_affine_scan_kernel");
     return GDKVM_OK;
 }

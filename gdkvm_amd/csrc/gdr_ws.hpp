@@ -11,7 +11,8 @@ static inline int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
 // and, filled only by a training-mode prep (GDKVM_FLAG_TRAIN) for the backward:  kn [NP][64] | wtT [64][NP] | qnT [64][NP]
 // | tii [nb][16][16] (the diagonal-block inverses T_II)
 // wti [4][nb][64][4] = Wt as accumulator images (like ut), the fold kernel's B operand
-// and the folded per-frame affine map the forward scan consumes (gdr_fold_kernel):  pp [4][4][64][4] = I - Kn^T Wt as A-operand images (row tile, k tile, lane)
+// and the folded per-frame affine map the forward scan consumes (gdr_fold_kernel):  pp [4][3][2][64][8] bf16 = I - Kn^T Wt split into three bf16 terms (split3), as A-operand images of the
+// bf16 MFMA (row tile, term, 32-wide k step, lane, 8 k values): 24 KiB, in units of float = 1.5 Dk Dk
 // | gg [Dv/16][4][64][4] = Kn^T Ut as accumulator images (slice, row tile, lane)
 struct WsView { float* wt; float* knT; float* ut; float* qinv; float* kn; float* wtT; float* qnT; float* tii; float* wti; float* pp; float* gg; float* zero; char* trash; int nb; };
 
@@ -19,7 +20,7 @@ static inline size_t gdr_workspace_bytes(int B, int T, int Hh, int N, int Dk, in
 {
     if (B <= 0 || T <= 0 || Hh <= 0 || N <= 0 || Dk <= 0 || Dv <= 0 || N > GDKVM_MAX_N) return GDKVM_WS_TAIL;
     const size_t NP = 16 * (size_t)tiles_for(N);
-    return (size_t)B * T * Hh * (NP * (6 * (size_t)Dk + Dv + 1 + 16) + (size_t)Dk * (Dk + Dv)) * sizeof(float) + GDKVM_WS_TAIL;
+    return (size_t)B * T * Hh * (NP * (6 * (size_t)Dk + Dv + 1 + 16) + (size_t)Dk * (Dk + Dk / 2 + Dv)) * sizeof(float) + GDKVM_WS_TAIL;
 }
 
 static inline int carve(const char* fn, void* workspace, size_t workspace_bytes, int B, int T, int Hh, int N, int Dk, int Dv, WsView* v)
@@ -39,7 +40,7 @@ static inline int carve(const char* fn, void* workspace, size_t workspace_bytes,
     v->tii = v->qnT + FH * NP * GDKVM_DK;
     v->wti = v->tii + FH * NP * 16;
     v->pp = v->wti + FH * NP * GDKVM_DK;
-    v->gg = v->pp + FH * GDKVM_DK * GDKVM_DK;
+    v->gg = v->pp + FH * (GDKVM_DK * GDKVM_DK * 3 / 2);
     v->zero = v->gg + FH * GDKVM_DK * Dv;                                 // 256 floats, zeroed by gdkvm_scan_transition
     v->trash = reinterpret_cast<char*>(v->zero + 256);   // write-only slot for read-out rows of padding tokens
     return GDKVM_OK;

@@ -50,8 +50,8 @@ def main():
     d8 = dall[:T]
     d = d8[:, :4]
     seg = torch.stack([d8[:, 4] - d8[:, 0], d8[:, 5] - d8[:, 4], d8[:, 6] - d8[:, 5], d8[:, 1] - d8[:, 6], d[:, 2] - d[:, 1], d[:, 3] - d[:, 2]], 1).float()
-    names = ["S images: 4 ds_read_b128 (waited)", "issue prefetch of frame t+6 (6 loads)", "gate (sigmoid of alpha_t; waits its load)",
-             "16 MFMA + a*acc + G", "publish S (1 ds_write_b128, waited)", "barrier"]
+    names = ["S term images: 6 ds_read_b128 (waited)", "next frame's P/G/a out of the ring (8 reads, waited)", "gate (sigmoid of alpha_t)",
+             "12 bf16 MFMA + a*acc + G", "publish S (split3 + 3 ds_write_b64, waited)", "barrier"]
     print("s_memtime ticks per frame (median over frames 2..T-1), block 0 wave 0 (a state wave)")
     for i, n in enumerate(names):
         print(f"  {n:48s} {seg[2:, i].median().item():8.0f}  (min {seg[2:, i].min().item():.0f} max {seg[2:, i].max().item():.0f})")
