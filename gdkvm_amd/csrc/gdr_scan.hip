@@ -815,7 +815,8 @@ void launch_fold(const FoldArgs& fa, int FH, hipStream_t st)
 struct PrepMArgs {
     const void* q; const void* k; const void* v; const float* beta;
     float* qinv; float* pp; float* gg;
-    int T, Hh, N, Dv, rule, flags;
+    float* x0; float* ppc; float* ggc;                  // frames of more than 64 tokens: chunk 0 -> x0, chunk c >= 1 -> ppc/ggc[c-1]
+    int T, Hh, N, Dv, rule, flags, np_total;            // N = tokens of the frame, np_total = its padded count (qinv row length)
 #ifdef GDKVM_DIAG
     unsigned long long* diag;
 #endif
@@ -853,8 +854,9 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fh = blockIdx.x;
     const int h = fh % a.Hh;
-    const size_t bt = fh / a.Hh;
-    const int N = a.N, Hh = a.Hh, Dv = a.Dv, nsl = Dv / 16;
+    const int Ntot = a.N, chunk = blockIdx.y, nchunk = gridDim.y, tok0 = chunk * NP;
+    const size_t bt = (size_t)(fh / a.Hh) * Ntot + tok0;   // row of this chunk's first token; rows are addressed bt*1 + n below
+    const int N = min(NP, Ntot - tok0), Hh = a.Hh, Dv = a.Dv, nsl = Dv / 16;
     const bool seq = a.rule == GDKVM_RULE_DELTA_SEQUENTIAL;
     const bool p_identity = a.rule == GDKVM_RULE_GATED_LINEAR;
     const int t = a.T;                                    // diagnostic builds: stamps go to row T of the buffer
@@ -870,7 +872,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
         for (int I = 0; I < (SPLIT ? 1 : NB); ++I)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                d[I][r] = load1<IO>(a.v, ((bt * N + min(16 * I + 4 * g + r, N - 1)) * Hh + h) * Dv + 16 * cV + li);
+                d[I][r] = load1<IO>(a.v, ((bt + min(16 * I + 4 * g + r, N - 1)) * Hh + h) * Dv + 16 * cV + li);
     };
     auto load_vb = [&](int cV, bf16x8 (&d)[KS]) __attribute__((always_inline)) {
         cV = min(cV, nsl - 1);
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                d[ks][j] = static_cast<const __bf16*>(a.v)[((bt * N + min(32 * ks + 8 * g + j, N - 1)) * Hh + h) * Dv + 16 * cV + li];
+                d[ks][j] = static_cast<const __bf16*>(a.v)[((bt + min(32 * ks + 8 * g + j, N - 1)) * Hh + h) * Dv + 16 * cV + li];
     };
 
     // ---- phase 0 (a5 prologue): ONE pass over the k and q rows by all 256 threads (4 threads per token, 16 channels each):
@@ -891,8 +893,8 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
         for (int j = 0; j < 4; ++j) {
             f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = {0.f, 0.f, 0.f, 0.f};
             if (n < N) {
-                x = load4<IO>(a.k, ((bt * N + n) * Hh + h) * GDKVM_DK + 16 * qd + 4 * j);
-                y = load4<IO>(a.q, ((bt * N + n) * Hh + h) * GDKVM_DK + 16 * qd + 4 * j);
+                x = load4<IO>(a.k, ((bt + n) * Hh + h) * GDKVM_DK + 16 * qd + 4 * j);
+                y = load4<IO>(a.q, ((bt + n) * Hh + h) * GDKVM_DK + 16 * qd + 4 * j);
             }
             *reinterpret_cast<f32x4*>(s_K + n * KLD + 16 * qd + 4 * j) = x;
             sk += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
@@ -908,13 +910,13 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
                     kinv = 1.0f / sqrtf(sk + GDKVM_EPS_NORM);
                     qinv = 1.0f / sqrtf(sq + GDKVM_EPS_NORM);
                 }
-                bta = a.beta[(bt * N + n) * Hh + h];
+                bta = a.beta[(bt + n) * Hh + h];
                 if (a.flags & GDKVM_FLAG_GATE_LOGITS) bta = 1.0f / (1.0f + expf(-bta));
             }
             s_kinv[n] = kinv;
             s_beta[n] = bta;
             s_qinv[n] = qinv;
-            a.qinv[(size_t)fh * NP + n] = qinv;
+            a.qinv[(size_t)fh * a.np_total + tok0 + n] = qinv;
         }
     }
     __syncthreads();
@@ -1055,7 +1057,14 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int I = 0; I < NB; ++I) mt[m][I] = s_mt[(m * NB + I) * 64 + lane];
-    uint2* pp = reinterpret_cast<uint2*>(a.pp) + (size_t)fh * (4 * 3 * SPLIT_IMG);
+    // chunk 0 of a chunked frame starts the composition as [P | G] accumulator tiles; under delta_parallel (every token sees
+    // the frame's old state) the chunks combine additively, P = I - sum_c (I - P_c), so all of them are written as tiles
+    const bool first_of_many = nchunk > 1 && chunk == 0;
+    const bool p_tiles = nchunk > 1 && (chunk == 0 || a.rule == GDKVM_RULE_DELTA_PARALLEL);
+    uint2* pp = (chunk == 0 ? reinterpret_cast<uint2*>(a.pp) + (size_t)fh * (4 * 3 * SPLIT_IMG)
+                            : reinterpret_cast<uint2*>(a.ppc) + ((size_t)fh * (nchunk - 1) + chunk - 1) * (4 * 3 * SPLIT_IMG));
+    f32x4* x0 = reinterpret_cast<f32x4*>(a.x0) + (size_t)fh * (4 + nsl) * 4 * 64;
+    f32x4* ptile = chunk == 0 ? x0 : reinterpret_cast<f32x4*>(pp);      // P tiles of a later chunk take the place of its images
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -1073,6 +1082,23 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
                     if (nlast > 2) { acc0 = mfma4(KN[NB - 1][2], mt[m][NB - 1][2], acc0);
                         if (nlast > 3) acc1 = mfma4(KN[NB - 1][3], mt[m][NB - 1][3], acc1); } } }
         }
+        if (p_tiles) {                         // the composition wants chunk 0 as [P | G] accumulator tiles: P tile (m, w),
+            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};          // the same product with the operands swapped
+            if (!p_identity) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int I = 0; I < NB; ++I) {
+                        if (I & 1) b1 = mfma4(mt[m][I][r], KN[I][r], b1);
+                        else b0 = mfma4(mt[m][I][r], KN[I][r], b0);
+                    }
+            }
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = ((16 * m + 4 * g + r == 16 * w + li) ? 1.f : 0.f) - (b0[r] + b1[r]);
+            ptile[(w * 4 + m) * 64 + lane] = o;
+            continue;
+        }
         // lane (g,li) reg r = P[16m + li][k = 16w + 4g + r]: four consecutive k of row li of row tile m -> its term images
         __bf16 t3[3][4];
 #pragma unroll
@@ -1083,7 +1109,9 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
         for (int sp = 0; sp < 3; ++sp) pp[(m * 3 + sp) * SPLIT_IMG + e] = pack_bf16x4(t3[sp]);
     }
     DIAG_STAMP(5);
-    f32x4* gg = reinterpret_cast<f32x4*>(a.gg) + (size_t)fh * nsl * 4 * 64;
+    f32x4* gg = first_of_many ? x0 + 4 * 4 * 64
+              : (chunk == 0 ? reinterpret_cast<f32x4*>(a.gg) + (size_t)fh * nsl * 4 * 64
+                            : reinterpret_cast<f32x4*>(a.ggc) + ((size_t)fh * (nchunk - 1) + chunk - 1) * nsl * 4 * 64);
     auto g_tiles = [&](int cV, const float (&x)[SPLIT ? 1 : NB][4]) __attribute__((always_inline)) {
         if constexpr (!SPLIT)
 #pragma unroll
@@ -1147,7 +1175,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
 }
 
 template <int NB, int IO>
-int launch_prepm(const PrepMArgs& pa, int FH, hipStream_t st)
+int launch_prepm(const PrepMArgs& pa, int FH, int nchunk, hipStream_t st)
 {
     const size_t lds = prepm_lds_bytes(NB, IO);
     if (lds > 64 * 1024) {
@@ -1155,9 +1183,108 @@ int launch_prepm(const PrepMArgs& pa, int FH, hipStream_t st)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_prepm: LDS attribute: %s", hipGetErrorString(e));
     }
-    hipLaunchKernelGGL((gdr_prepm_kernel<NB, IO>), dim3(FH), dim3(256), lds, st, pa);
+    hipLaunchKernelGGL((gdr_prepm_kernel<NB, IO>), dim3(FH, nchunk), dim3(256), lds, st, pa);
     GDKVM_LAUNCH_CHECK("gdr_prepm_kernel");
     return GDKVM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gdr_compose_kernel -- frames of more than 64 tokens.  The tokens of a frame act on the state in order, so the frame's
+// affine map is the composition of its 64-token chunks' maps:  [P | G] <- P_c [P | G] + [0 | G_c],  c = 1 .. nchunk-1,
+// starting from chunk 0.  Columns never mix: one workgroup carries four column tiles of [P | G] (64 x 64 fp32 in
+// accumulators, wave w = row tile w) through all steps, exactly like the serial scan carries S -- P_c as three-term A
+// images (as prepm wrote them), the running columns re-split into three-term B images through LDS each step.
+// Output: the final P as term images (pp) and G as accumulator images (gg), the formats the scan consumes.
+struct ComposeArgs { const float* x0; const float* ppc; const float* ggc; float* pp; float* gg; int Dv, nchunk, additive; };
+
+__global__ __launch_bounds__(256) void gdr_compose_kernel(ComposeArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint2 s_X3[4 * 3 * SPLIT_IMG];        // [col tile j][term] B images
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t fh = blockIdx.x;
+    const int nsl = a.Dv / 16, ncol = 4 + nsl, c0 = 4 * blockIdx.y;               // this block's column tiles c0 .. c0+3 of [P | G]
+    f32x4 X[4];
+    const f32x4* x0 = reinterpret_cast<const f32x4*>(a.x0) + fh * ncol * 4 * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) X[j] = x0[((size_t)min(c0 + j, ncol - 1) * 4 + w) * 64 + lane];
+    for (int c = 1; c < a.nchunk && a.additive; ++c) {     // delta_parallel: [P | G] += [P_c - I | G_c]  (ppc holds P_c tiles)
+        const size_t ci = fh * (a.nchunk - 1) + (c - 1);
+        const f32x4* pc = reinterpret_cast<const f32x4*>(a.ppc) + ci * (size_t)(GDKVM_DK * GDKVM_DK * 3 / 8);
+        const f32x4* gc = reinterpret_cast<const f32x4*>(a.ggc) + ci * nsl * 4 * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = min(c0 + j, ncol - 1);
+            f32x4 d = col < 4 ? pc[(col * 4 + w) * 64 + lane] : gc[((size_t)(col - 4) * 4 + w) * 64 + lane];
+            if (col < 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] -= (16 * w + 4 * g + r == 16 * col + li) ? 1.f : 0.f;
+            }
+            X[j] += d;
+        }
+    }
+    for (int c = 1; c < a.nchunk && !a.additive; ++c) {
+        const size_t ci = fh * (a.nchunk - 1) + (c - 1);
+        const bf16x8* pimg = reinterpret_cast<const bf16x8*>(a.ppc) + (ci * 4 + w) * (3 * 2 * 64) + lane;
+        bf16x8 pa[3][2];
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) pa[sp][ks] = pimg[(sp * 2 + ks) * 64];
+        const f32x4* gc = reinterpret_cast<const f32x4*>(a.ggc) + ci * nsl * 4 * 64;
+        f32x4 gadd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = c0 + j;
+            gadd[j] = gc[((size_t)min(max(col - 4, 0), nsl - 1) * 4 + w) * 64 + lane];
+            if (col < 4) gadd[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                      // rows 16w + 4g + r of column tile j -> its term images
+            uint2 t3[3];
+            split3x4(X[j], t3[0], t3[1], t3[2]);
+            const int e = split_slot(w, g, li);
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) s_X3[(j * 3 + sp) * SPLIT_IMG + e] = t3[sp];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x8 xb[3][2];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) xb[sp][ks] = *reinterpret_cast<const bf16x8*>(&s_X3[(j * 3 + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#define GDKVM_PX(ACC, PT, XT, KS) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[PT][KS], xb[XT][KS], ACC, 0, 0, 0)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { GDKVM_PX(acc0, 2, 0, ks); GDKVM_PX(acc1, 0, 2, ks); GDKVM_PX(acc0, 1, 1, ks); }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { GDKVM_PX(acc1, 1, 0, ks); GDKVM_PX(acc0, 0, 1, ks); }
+            GDKVM_PX(acc1, 0, 0, 0); GDKVM_PX(acc0, 0, 0, 1);
+#undef GDKVM_PX
+            X[j] = acc0 + acc1 + gadd[j];
+        }
+        __syncthreads();                                   // the images are rewritten in the next step
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = c0 + j;
+        if (col >= ncol) continue;
+        if (col < 4) {                                     // P[16w + 4g + r][k = 16 col + li] -> term images of row tile w
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                __bf16 t3[3];
+                split3(X[j][r], t3[0], t3[1], t3[2]);
+                __bf16* img = reinterpret_cast<__bf16*>(a.pp) + (fh * 4 + w) * (size_t)(3 * SPLIT_IMG * 4);
+                const int e = split_slot(col, li >> 2, 4 * g + r) * 4 + (li & 3);
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) img[sp * SPLIT_IMG * 4 + e] = t3[sp];
+            }
+        } else {
+            reinterpret_cast<f32x4*>(a.gg)[((fh * nsl + (col - 4)) * 4 + w) * 64 + lane] = X[j];
+        }
+    }
 }
 
 // gdr_affine_scan_kernel: the serial recurrence on the folded operands.  12 waves per workgroup in three fixed roles:
@@ -1502,16 +1629,6 @@ int launch_prep(const PrepArgs& pa, int FH, hipStream_t st)
     return GDKVM_OK;
 }
 
-template <int IO>
-int launch_prep_nb(int nb, const PrepArgs& pa, int FH, hipStream_t st)
-{
-    switch (nb) {
-        case 4: return launch_prep<4, IO, 5>(pa, FH, st);
-        case 8: return launch_prep<8, IO, 2>(pa, FH, st);
-        default: return launch_prep<16, IO, 1>(pa, FH, st);
-    }
-}
-
 }  // namespace
 
 extern "C" size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
@@ -1529,24 +1646,26 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
     WsView ws;
     if (int rc = carve("scan_prep", workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
     if (int rc = gdkvm_check_device()) return rc;
-    PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, ws.kn, ws.wtT, ws.qnT, ws.tii, ws.wti, T, Hh, N, Dv, rule, flags};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!(flags & GDKVM_FLAG_TRAIN) && ws.nb <= 8) {     // inference: P and G directly, nothing else written
-        PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, T, Hh, N, Dv, rule, flags};
+    if (!(flags & GDKVM_FLAG_TRAIN) || ws.nchunk > 1) {  // P and G directly (frames of > 64 tokens: per 64-token chunk, then composed)
+        PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, ws.x0, ws.ppc, ws.ggc, T, Hh, N, Dv, rule, flags, 16 * ws.nb};
 #ifdef GDKVM_DIAG
         pm.diag = g_diag_buf;
 #endif
-        if (io_dtype == GDKVM_F32) return ws.nb == 4 ? launch_prepm<4, GDKVM_F32>(pm, B * T * Hh, st) : launch_prepm<8, GDKVM_F32>(pm, B * T * Hh, st);
-        return ws.nb == 4 ? launch_prepm<4, GDKVM_BF16>(pm, B * T * Hh, st) : launch_prepm<8, GDKVM_BF16>(pm, B * T * Hh, st);
+        if (int rc = io_dtype == GDKVM_F32 ? launch_prepm<4, GDKVM_F32>(pm, B * T * Hh, ws.nchunk, st)
+                                           : launch_prepm<4, GDKVM_BF16>(pm, B * T * Hh, ws.nchunk, st)) return rc;
+        if (ws.nchunk > 1) {
+            ComposeArgs ca{ws.x0, ws.ppc, ws.ggc, ws.pp, ws.gg, Dv, ws.nchunk, rule == GDKVM_RULE_DELTA_PARALLEL};
+            hipLaunchKernelGGL(gdr_compose_kernel, dim3((unsigned)(B * T * Hh), (unsigned)((4 + Dv / 16 + 3) / 4)), dim3(256), 0, st, ca);
+            GDKVM_LAUNCH_CHECK("gdr_compose_kernel");
+        }
+        return GDKVM_OK;
     }
-    if (int rc = io_dtype == GDKVM_F32 ? launch_prep_nb<GDKVM_F32>(ws.nb, pa, B * T * Hh, st)
-                                       : launch_prep_nb<GDKVM_BF16>(ws.nb, pa, B * T * Hh, st)) return rc;
+    // training, <= 64 tokens: the WY factors the backward consumes, then folded
+    PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, ws.kn, ws.wtT, ws.qnT, ws.tii, ws.wti, T, Hh, N, Dv, rule, flags};
+    if (int rc = io_dtype == GDKVM_F32 ? launch_prep<4, GDKVM_F32, 5>(pa, B * T * Hh, st) : launch_prep<4, GDKVM_BF16, 5>(pa, B * T * Hh, st)) return rc;
     FoldArgs fa{ws.wti, ws.knT, ws.ut, ws.pp, ws.gg, Dv};
-    switch (ws.nb) {
-        case 4: launch_fold<4>(fa, B * T * Hh, st); break;
-        case 8: launch_fold<8>(fa, B * T * Hh, st); break;
-        default: launch_fold<16>(fa, B * T * Hh, st); break;
-    }
+    launch_fold<4>(fa, B * T * Hh, st);
     GDKVM_LAUNCH_CHECK("gdr_fold_kernel");
     return GDKVM_OK;
 }

@@ -7,20 +7,33 @@
 constexpr size_t GDKVM_WS_TAIL = 256 + 1024;   // one zero Ut tile (1 KiB) + trash slot for padded read-out rows
 static inline int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
 
-// fp32 workspace per frame-head, NP = 16*nb padded tokens:  wt [NP][64] | knT [64][NP] | ut [Dv/16][nb][64][4] | qinv [NP]
-// and, filled only by a training-mode prep (GDKVM_FLAG_TRAIN) for the backward:  kn [NP][64] | wtT [64][NP] | qnT [64][NP]
-// | tii [nb][16][16] (the diagonal-block inverses T_II)
-// wti [4][nb][64][4] = Wt as accumulator images (like ut), the fold kernel's B operand
-// and the folded per-frame affine map the forward scan consumes (gdr_fold_kernel):  pp [4][3][2][64][8] bf16 = I - Kn^T Wt split into three bf16 terms (split3), as A-operand images of the
-// bf16 MFMA (row tile, term, 32-wide k step, lane, 8 k values): 24 KiB, in units of float = 1.5 Dk Dk
-// | gg [Dv/16][4][64][4] = Kn^T Ut as accumulator images (slice, row tile, lane)
-struct WsView { float* wt; float* knT; float* ut; float* qinv; float* kn; float* wtT; float* qnT; float* tii; float* wti; float* pp; float* gg; float* zero; char* trash; int nb; };
+// fp32 workspace per frame-head fh.  NP = 16*nb padded tokens (nb = 4, 8 or 16), NL = min(NP, 64):
+//   legacy WY regions, written by the training-mode prep for frames of <= 64 tokens (the backward's operands), NL tokens wide:
+//     wt [NL][64] | knT [64][NL] | ut [Dv/16][4][64][4] | kn [NL][64] | wtT [64][NL] | qnT [64][NL] | tii [4][16][16] | wti [4][4][64][4]
+//   qinv [NP]
+//   the folded per-frame affine map the forward scan consumes:
+//     pp [4][3][2][64][8] bf16 = P = I - Kn^T Wt split into three bf16 terms (split3) as A-operand images of the bf16 MFMA
+//        (row tile, term, 32-wide k step, lane, 8 k values): 24 KiB = 1.5 Dk Dk floats
+//     gg [Dv/16][4][64][4] = G = Kn^T Ut as accumulator images (slice, row tile, lane)
+//   frames of more than 64 tokens are folded in chunks of 64 tokens whose affine maps are then composed (nchunk = NP/64):
+//     x0  [4 + Dv/16][4][64][4]  chunk 0 as accumulator images of [P | G]
+//     ppc [nchunk-1] x pp, ggc [nchunk-1] x gg  for chunks 1..
+struct WsView {
+    float* wt; float* knT; float* ut; float* qinv; float* kn; float* wtT; float* qnT; float* tii; float* wti;
+    float* pp; float* gg; float* x0; float* ppc; float* ggc; float* zero; char* trash; int nb; int nchunk;
+};
+
+static inline size_t gdr_ws_floats_per_fh(int N, int Dk, int Dv)
+{
+    const size_t NP = 16 * (size_t)tiles_for(N), NL = NP < 64 ? NP : 64, C = (NP + 63) / 64;
+    const size_t pg = (size_t)Dk * Dk * 3 / 2 + (size_t)Dk * Dv;
+    return NL * (6 * (size_t)Dk + Dv + 16) + NP + pg + (C > 1 ? (size_t)Dk * (Dk + Dv) + (C - 1) * pg : 0);
+}
 
 static inline size_t gdr_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
 {
     if (B <= 0 || T <= 0 || Hh <= 0 || N <= 0 || Dk <= 0 || Dv <= 0 || N > GDKVM_MAX_N) return GDKVM_WS_TAIL;
-    const size_t NP = 16 * (size_t)tiles_for(N);
-    return (size_t)B * T * Hh * (NP * (6 * (size_t)Dk + Dv + 1 + 16) + (size_t)Dk * (Dk + Dk / 2 + Dv)) * sizeof(float) + GDKVM_WS_TAIL;
+    return (size_t)B * T * Hh * gdr_ws_floats_per_fh(N, Dk, Dv) * sizeof(float) + GDKVM_WS_TAIL;
 }
 
 static inline int carve(const char* fn, void* workspace, size_t workspace_bytes, int B, int T, int Hh, int N, int Dk, int Dv, WsView* v)
@@ -29,19 +42,25 @@ static inline int carve(const char* fn, void* workspace, size_t workspace_bytes,
     if (workspace_bytes < need)
         return gdkvm_fail(GDKVM_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, workspace_bytes, need);
     v->nb = tiles_for(N);
-    const size_t NP = 16 * (size_t)v->nb, FH = (size_t)B * T * Hh;
-    v->wt = static_cast<float*>(workspace);
-    v->knT = v->wt + FH * NP * GDKVM_DK;
-    v->ut = v->knT + FH * NP * GDKVM_DK;
-    v->qinv = v->ut + FH * NP * Dv;
-    v->kn = v->qinv + FH * NP;
-    v->wtT = v->kn + FH * NP * GDKVM_DK;
-    v->qnT = v->wtT + FH * NP * GDKVM_DK;
-    v->tii = v->qnT + FH * NP * GDKVM_DK;
-    v->wti = v->tii + FH * NP * 16;
-    v->pp = v->wti + FH * NP * GDKVM_DK;
-    v->gg = v->pp + FH * (GDKVM_DK * GDKVM_DK * 3 / 2);
-    v->zero = v->gg + FH * GDKVM_DK * Dv;                                 // 256 floats, zeroed by gdkvm_scan_transition
+    const size_t NP = 16 * (size_t)v->nb, NL = NP < 64 ? NP : 64, FH = (size_t)B * T * Hh;
+    v->nchunk = N > 64 ? (N + 63) / 64 : 1;              // sized for NP/64, the upper bound
+    const size_t ppf = (size_t)GDKVM_DK * GDKVM_DK * 3 / 2, ggf = (size_t)GDKVM_DK * Dv;
+    float* p = static_cast<float*>(workspace);
+    v->wt = p;    p += FH * NL * GDKVM_DK;
+    v->knT = p;   p += FH * NL * GDKVM_DK;
+    v->ut = p;    p += FH * NL * Dv;
+    v->kn = p;    p += FH * NL * GDKVM_DK;
+    v->wtT = p;   p += FH * NL * GDKVM_DK;
+    v->qnT = p;   p += FH * NL * GDKVM_DK;
+    v->tii = p;   p += FH * NL * 16;
+    v->wti = p;   p += FH * NL * GDKVM_DK;
+    v->qinv = p;  p += FH * NP;
+    v->pp = p;    p += FH * ppf;
+    v->gg = p;    p += FH * ggf;
+    v->x0 = p;    p += v->nchunk > 1 ? FH * (size_t)GDKVM_DK * (GDKVM_DK + Dv) : 0;
+    v->ppc = p;   p += v->nchunk > 1 ? FH * (v->nchunk - 1) * ppf : 0;
+    v->ggc = p;   p += v->nchunk > 1 ? FH * (v->nchunk - 1) * ggf : 0;
+    v->zero = p;                                         // 256 floats, zeroed by gdkvm_scan_transition
     v->trash = reinterpret_cast<char*>(v->zero + 256);   // write-only slot for read-out rows of padding tokens
     return GDKVM_OK;
 }

@@ -50,6 +50,21 @@ def test_scan_fp32_ragged_shapes(hip, shape):
     assert np.abs(Rg - Ro).max() <= TOL and np.abs(Sg - So).max() <= TOL
 
 
+@pytest.mark.parametrize("rule", [0, 1, 2])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_chunked_frames_every_rule(hip, rule, dtype):
+    """Frames of more than 64 tokens are folded per 64-token chunk and the chunks' affine maps composed
+    (gdr_compose_kernel): 130 tokens = 64 + 64 + 2, every rule, with the a5 prologue and a carried state."""
+    q, k, v, a, b = make_scan_inputs(2, 3, 130, 2, 64, 48, seed=40 + rule, normalized=False, logits=True, corr=0.6)
+    s0 = np.random.default_rng(2).standard_normal((2, 2, 64, 48)).astype(np.float32) * 0.1
+    if dtype == torch.bfloat16:
+        q, k, v = (O.to_bf16_f32(x) for x in (q, k, v))
+    Rg, Sg = _run(hip, q, k, v, a, b, s0, rule, 3, dtype=dtype)
+    Ro, So = c_oracle.scan(q, k, v, a, b, s0, rule, 3, math="f64")
+    assert np.abs(Sg - So).max() <= TOL
+    assert np.all(np.abs(Rg - Ro) <= TOL + (np.abs(Ro) * 2.0 ** -8 if dtype == torch.bfloat16 else 0))
+
+
 def test_scan_matches_numpy_oracle_too(hip):
     q, k, v, a, b = make_scan_inputs(1, 3, 20, 2, 64, 16, seed=5)
     Rg, Sg = _run(hip, q, k, v, a, b)
