@@ -5,7 +5,7 @@ BASELINE.json configs[1]: EchoNet-Dynamic 112x112x32 clips, bf16 inference, batc
     python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
 
 Prints ONE JSON line on rank 0 (contract in the task prompt) with two extra objects:
-  roofline      the hot path's dominant kernels (gdr_prep_kernel + gdr_scan_kernel = one gdkvm_scan_fwd), timed
+  roofline      the hot path's dominant kernels (gdr_prepm_kernel + gdr_affine_scan_kernel = one gdkvm_scan_fwd), timed
                 live with HIP events on the launch stream; achieved = SURVEY.md §8(d) algorithmic bytes / time
   cpu_baseline  the CPU oracle module (oracle/model_ref.py: PyTorch CPU convs + scalar C memory path) on a
                 bounded sample of the same workload, rank 0, N=1 only
@@ -57,7 +57,7 @@ def committed_traffic():
         return None, None
     total = 0.0
     for row in csv.DictReader(l for l in open(files[-1]) if not l.startswith("#")):
-        if row["Kernel"].startswith(("gdr_prep_kernel", "gdr_scan_kernel")):
+        if row["Kernel"].startswith(("gdr_prepm_kernel", "gdr_affine_scan_kernel", "gdr_compose_kernel")):
             total += float(row["hbm_bytes_read_x2"])
     return (int(total) if total else None), os.path.relpath(files[-1], ROOT)
 
@@ -221,11 +221,11 @@ def main():
         alg = scan_algorithmic_bytes(B, T, N, Hh, Dk, Dv, 2)
         achieved = alg / (both_ms * 1e-3) / 1e9
         traffic, traffic_src = committed_traffic() if (B, T, S) == (16, 32, 112) else (None, None)
-        out["roofline"] = {"kernel": "gdr_prep_kernel+gdr_scan_kernel (one gdkvm_scan_fwd)", "bound": "hbm",
+        out["roofline"] = {"kernel": "gdr_prepm_kernel+gdr_affine_scan_kernel (one gdkvm_scan_fwd)", "bound": "hbm",
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-                           "algorithmic_bytes": alg, "avg_ms": {"gdr_prep_kernel": round(prep_ms, 4),
-                                                                "gdr_scan_kernel": round(scan_ms, 4),
+                           "algorithmic_bytes": alg, "avg_ms": {"gdr_prepm_kernel": round(prep_ms, 4),
+                                                                "gdr_affine_scan_kernel": round(scan_ms, 4),
                                                                 "scan_fwd_total": round(both_ms, 4)}}
         # ---- CPU baseline: the oracle module on a bounded sample of the same workload (N=1 only) -----------
         if world == 1 and not args.no_cpu_baseline:

@@ -1,24 +1,20 @@
 // gdr_scan.hip -- LKVA read + gated-delta-rule write for gfx950.
 //
-// Two kernels per call, both exact fp32 on v_mfma_f32_16x16x4_f32:
+// SPEC-v0 per frame (WY form):  R = Qn S,  X = Wt S,  U = Ut - a X,  S' = a S + Kn^T U  with
+//     Wt = T diag(b) Kn,  Ut = T diag(b) V,  T = (I + tril(diag(b) Kn Kn^T, -1))^-1 .
+// Substituting U:  S' = a P S + G,  P = I - Kn^T Wt,  G = Kn^T Ut  -- state-independent.  Kernels, in file order:
 //
-//  gdr_prep_kernel   one workgroup per (clip, frame, head); fully parallel over frames.  Computes the
-//                    state-INDEPENDENT WY factors of SURVEY.md A.3
-//                        Wt = T diag(b) Kn,  Ut = T diag(b) V,  T = (I + tril(diag(b) Kn Kn^T, -1))^-1
-//                    by a blocked forward substitution that lives entirely in MFMA accumulators: the Gram
-//                    blocks are produced TRANSPOSED so their C/D registers are directly the A operand of the
-//                    next product, and each solved 16-token block Y_J stays in registers as a B operand
-//                    (k order permuted consistently on both operands).  Also applies the a5 prologue
-//                    (L2-normalise k, sigmoid gates) and emits Kn^T.
-//  gdr_scan_kernel   one workgroup per (clip, head, 16-column slice of Dv) -- the delta rule never mixes
-//                    columns of S, so Dv is the parallel axis.  Serial over frames with the 64x16 state
-//                    slice held in MFMA accumulators; per frame only two dependent products remain:
-//                        [R ; X] = [Qn ; Wt] S          U = Ut - a X          S <- a S + Kn^T U
-//
-// Workspace (fp32), per frame-head fh, NP = 16*NB padded tokens:
-//   wt  [FH][NP][64]                natural rows  -> A operand of X = Wt S by 16-byte loads
-//   knT [FH][64][NP]                transposed    -> A operand of Kn^T U by 16-byte loads
-//   ut  [FH][Dv/16][NB][64 lanes][4] accumulator images -> one 16-byte load per lane per tile
+//  gdr_prep_kernel         training only (N <= 64): the WY factors by a blocked forward substitution that lives entirely
+//                          in MFMA accumulators, plus the extra operand layouts and T_II the backward consumes.
+//  gdr_scan_kernel         the round's first serial kernel (two dependent products per frame).  Only its BWD mode is
+//                          still launched: the reverse-time recurrence of the backward pass.
+//  gdr_fold_kernel         training: P and G from the stored WY factors.
+//  gdr_prepm_kernel        inference: P and G directly, M = Kn^T T b by a back substitution on four Kn tiles, G = M V.
+//  gdr_compose_kernel      frames of more than 64 tokens: composition of the 64-token chunks' affine maps.
+//  gdr_affine_scan_kernel  the forward recurrence: one workgroup per (clip, head, 16-column slice of Dv), 12 waves in
+//                          three roles (state / read-out / LDS-DMA loader), one barrier per frame.
+// Products that dominate a kernel run on v_mfma_f32_16x16x32_bf16 with fp32 operands carried as three bf16 terms
+// (split3, below); everything else is exact fp32 on v_mfma_f32_16x16x4_f32.  Workspace layout: gdr_ws.hpp.
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>

@@ -74,9 +74,11 @@ int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const float* alp
                    int io_dtype, int rule, int flags, void* stream);
 
 /* The two stages of gdkvm_scan_fwd as separate entry points (gdkvm_scan_fwd == prep then apply on one stream).
- * `prep` is state-independent and parallel over frames (a5 prologue incl. the query norms + the WY factors of
- * SURVEY.md A.3 into the workspace); `apply` is the serial-in-time read/write recurrence.  Exposed so a caller can run the prep of
- * chunk c+1 on a second stream while chunk c is being applied, and so each kernel can be timed on its own. */
+ * `prep` is state-independent and parallel over frames: the a5 prologue incl. the query norms, and every frame folded
+ * into the affine map S' = alpha (P S) + G of SURVEY.md A.3 (P = I - Kn^T Wt, G = Kn^T Ut) in the workspace; with
+ * GDKVM_FLAG_TRAIN also the WY factors the backward needs.  `apply` is the serial-in-time read/write recurrence.
+ * Exposed so a caller can run the prep of chunk c+1 on a second stream while chunk c is being applied, and so each
+ * kernel can be timed on its own. */
 int gdkvm_scan_prep(const void* q, const void* k, const void* v, const float* beta, void* workspace, size_t workspace_bytes,
                     int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream);
 int gdkvm_scan_apply(const void* q, const float* alpha, const float* s_in, void* r_out, float* s_out,
