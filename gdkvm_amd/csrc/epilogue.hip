@@ -84,6 +84,67 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const void* x, const floa
     for (; i < nvec; i += stride) finish(i, xv[i], res ? rv[i] : vec_t{0, 0, 0, 0});
 }
 
+// Stem tail: y = relu(max over the 3x3 / stride 2 / pad 1 window of x + bias).  One thread per (output pixel, 16-byte channel
+// group): its nine window loads are independent and all in flight; neighbouring windows overlap in L1/L2, HBM sees x once.
+template <int IO>
+__global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(const void* x, const float* bias, void* y,
+                                                                int N, int H, int W, int C, int Ho, int Wo)
+{
+    constexpr int V = IO == GDKVM_F32 ? 4 : 8;
+    const int cg = C / V;
+    const size_t total = (size_t)N * Ho * Wo * cg;
+    const uint4* xv = static_cast<const uint4*>(x);
+    uint4* yv = static_cast<uint4*>(y);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % cg);
+        size_t p = i / cg;
+        const int ow = (int)(p % Wo); p /= Wo;
+        const int oh = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        uint4 win[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {                // out-of-range taps re-read the (always valid) centre: max unchanged
+                const int ih = 2 * oh - 1 + dy, iw = 2 * ow - 1 + dx;
+                const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                const int hh = ok ? ih : 2 * oh, ww = ok ? iw : 2 * ow;
+                win[3 * dy + dx] = xv[(((size_t)n * H + hh) * W + ww) * cg + c];
+            }
+        float m[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) m[j] = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const unsigned w4[4] = {win[t].x, win[t].y, win[t].z, win[t].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (IO == GDKVM_F32) m[j] = fmaxf(m[j], __uint_as_float(w4[j]));
+                else {
+                    m[2 * j] = fmaxf(m[2 * j], __uint_as_float(w4[j] << 16));
+                    m[2 * j + 1] = fmaxf(m[2 * j + 1], __uint_as_float(w4[j] & 0xffff0000u));
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < V; j += 4) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + c * V + j);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) m[j + q] = fmaxf(m[j + q] + b4[q], 0.f);
+        }
+        uint4 o;
+        if constexpr (IO == GDKVM_F32) {
+            o.x = __float_as_uint(m[0]); o.y = __float_as_uint(m[1]); o.z = __float_as_uint(m[2]); o.w = __float_as_uint(m[3]);
+        } else {
+            o.x = (unsigned)f32_to_bf16(m[0]) | ((unsigned)f32_to_bf16(m[1]) << 16);
+            o.y = (unsigned)f32_to_bf16(m[2]) | ((unsigned)f32_to_bf16(m[3]) << 16);
+            o.z = (unsigned)f32_to_bf16(m[4]) | ((unsigned)f32_to_bf16(m[5]) << 16);
+            o.w = (unsigned)f32_to_bf16(m[6]) | ((unsigned)f32_to_bf16(m[7]) << 16);
+        }
+        yv[i] = o;
+    }
+}
+
 }  // namespace
 
 extern "C" int gdkvm_bias_act(const void* x, const float* bias, const void* residual, void* y,
@@ -181,5 +242,28 @@ extern "C" int gdkvm_upsample_cat(const void* lo, const void* skip, void* out,
                        static_cast<const bf16_t*>(lo), static_cast<const bf16_t*>(skip), static_cast<bf16_t*>(out),
                        Nimg, hl, wl, H, W, C1, C2, (float)hl / (float)H, (float)wl / (float)W);
     GDKVM_LAUNCH_CHECK("upsample_cat_bf16_kernel");
+    return GDKVM_OK;
+}
+
+extern "C" int gdkvm_bias_relu_maxpool(const void* x, const float* bias, void* y, int N, int H, int W, int C, int io_dtype, void* stream)
+{
+    if (N < 0 || H <= 0 || W <= 0 || C <= 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "bias_relu_maxpool: N=%d H=%d W=%d C=%d", N, H, W, C);
+    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "bias_relu_maxpool: io_dtype=%d", io_dtype);
+    const int V = io_dtype == GDKVM_F32 ? 4 : 8;
+    if (C % V) return gdkvm_fail(GDKVM_ERR_SHAPE, "bias_relu_maxpool: C=%d must be a multiple of %d", C, V);
+    if (N == 0) return GDKVM_OK;
+    if (!x || !bias || !y) return gdkvm_fail(GDKVM_ERR_ARG, "bias_relu_maxpool: null pointer");
+    if (!gdkvm_aligned16(x) || !gdkvm_aligned16(y) || !gdkvm_aligned16(bias))
+        return gdkvm_fail(GDKVM_ERR_ARG, "bias_relu_maxpool: pointers must be 16-byte aligned");
+    if (x == y) return gdkvm_fail(GDKVM_ERR_ARG, "bias_relu_maxpool: cannot run in place");
+    if (int rc = gdkvm_check_device()) return rc;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t total = (size_t)N * Ho * Wo * (C / V);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((bias_relu_maxpool_kernel<GDKVM_F32>), dim3((unsigned)blocks), dim3(256), 0, st, x, bias, y, N, H, W, C, Ho, Wo);
+    else hipLaunchKernelGGL((bias_relu_maxpool_kernel<GDKVM_BF16>), dim3((unsigned)blocks), dim3(256), 0, st, x, bias, y, N, H, W, C, Ho, Wo);
+    GDKVM_LAUNCH_CHECK("bias_relu_maxpool_kernel");
     return GDKVM_OK;
 }

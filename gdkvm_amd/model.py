@@ -147,6 +147,17 @@ class FusedConv(nn.Module):
         return ops.bias_act_(y, self.epi.bias, residual, self.relu)
 
 
+class FusedConvPool(FusedConv):
+    """The stem: conv -> bias + ReLU + 3x3/2 max-pool as ONE HIP pass over the conv output (the full-resolution activation is
+    read once and never written back)."""
+
+    def forward(self, x, residual=None):
+        y = self.conv(x)
+        if not y.is_cuda:
+            return F.max_pool2d(F.relu(y + self.epi.bias.to(y.dtype).reshape(1, -1, 1, 1)), 3, 2, 1)
+        return ops.bias_relu_maxpool(y.contiguous(memory_format=torch.channels_last), self.epi.bias)
+
+
 class _EpilogueBias(nn.Module):
     """fp32 bias that survives .to(bfloat16) on the parent."""
 
@@ -300,7 +311,14 @@ class GDKVM(nn.Module):
                     m.down = fuse_seq(m.down)
             elif isinstance(m, UpBlock):
                 m.conv = fuse_seq(m.conv)
-        self.encoder.stem = fuse_seq(self.encoder.stem)
+        stem = fuse_seq(self.encoder.stem)
+        if (len(stem) == 2 and isinstance(stem[0], FusedConv) and stem[0].relu and isinstance(stem[1], nn.MaxPool2d)
+                and (stem[1].kernel_size, stem[1].stride, stem[1].padding) == (3, 2, 1)):
+            fused = FusedConvPool.__new__(FusedConvPool)
+            nn.Module.__init__(fused)
+            fused.conv, fused.epi, fused.relu = stem[0].conv, stem[0].epi, True
+            stem = nn.Sequential(fused)
+        self.encoder.stem = stem
         return self
 
     @torch.no_grad()

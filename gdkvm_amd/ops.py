@@ -41,6 +41,7 @@ SIGNATURES = {
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "gdkvm_bias_act": (_i, [_vp] * 4 + [_sz] + [_i] * 3 + [_vp]),
     "gdkvm_upsample_cat": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
+    "gdkvm_bias_relu_maxpool": (_i, [_vp] * 3 + [_i] * 5 + [_vp]),
     "gdkvm_upsample_argmax_dice": (_i, [_vp] * 4 + [_i] * 7 + [_vp]),
 }
 
@@ -430,6 +431,23 @@ def bias_act_(x: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tens
                                 n * hh * ww, c, int(relu), _io_dtype(x), _stream(x.device))
     _check(rc, "gdkvm_bias_act")
     return x
+
+
+def bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """relu(max_pool2d(x, 3, 2, 1) + bias[c]) on a channels_last conv output in one pass (gdkvm_bias_relu_maxpool);
+    equals max_pool2d(relu(x + bias), 3, 2, 1)."""
+    lib = load()
+    if x.dim() != 4 or not x.is_cuda or not x.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("bias_relu_maxpool needs a channels_last [N,C,H,W] device tensor")
+    if bias.dtype != torch.float32 or bias.numel() != x.shape[1]:
+        raise GdkvmError("bias must be float32 [C]")
+    n, c, hh, ww = x.shape
+    out = torch.empty((n, c, (hh - 1) // 2 + 1, (ww - 1) // 2 + 1), device=x.device, dtype=x.dtype,
+                      memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = lib.gdkvm_bias_relu_maxpool(x.data_ptr(), bias.data_ptr(), out.data_ptr(), n, hh, ww, c, _io_dtype(x), _stream(x.device))
+    _check(rc, "gdkvm_bias_relu_maxpool")
+    return out
 
 
 def upsample_cat(lo: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:

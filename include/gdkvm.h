@@ -169,6 +169,11 @@ int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* target, uint8_
 int gdkvm_bias_act(const void* x, const float* bias, const void* residual, void* y,
                    size_t rows, int C, int relu, int io_dtype, void* stream);
 
+/* Row n1, the stem: bias + ReLU + 3x3 / stride 2 / pad 1 max-pool in one pass over the NHWC conv output
+ * x [N, H, W, C] -> y [N, (H-1)/2+1, (W-1)/2+1, C]:  y = relu(max_window(x) + bias)  (== max_window(relu(x + bias)), the
+ * rounding of x + b being monotonic).  The full-resolution activation is read once and never written back. */
+int gdkvm_bias_relu_maxpool(const void* x, const float* bias, void* y, int N, int H, int W, int C, int io_dtype, void* stream);
+
 /* SURVEY.md §8(f) row n1 (inference build only): decoder glue, out = concat(bilinear_upsample(lo -> H x W), skip) over
  * NHWC tensors  lo [N,hl,wl,C1], skip [N,H,W,C2], out [N,H,W,C1+C2]; align_corners = false; bf16 only. */
 int gdkvm_upsample_cat(const void* lo, const void* skip, void* out,

@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import c_oracle
 from oracle import gdkvm_oracle as O
@@ -120,3 +121,17 @@ def test_upsample_cat(hip, case):
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got[:, c1:], sk)
     assert (got[:, :c1].float() - up).abs().max() <= 2.0 ** -7 * up.abs().max()     # one bf16 rounding of an fp32 blend
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 16, 9, 11), (2, 64, 56, 56), (1, 8, 1, 1), (2, 24, 4, 7)])
+def test_bias_relu_maxpool(hip, dtype, shape):
+    """Stem tail (row n1): one pass == max_pool2d(relu(x + b), 3, 2, 1), bit for bit (max commutes with the monotonic x + b)."""
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(n, c, h, w, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(c, generator=g).cuda()
+    got = hip.bias_relu_maxpool(x, b)
+    want = F.max_pool2d(F.relu(x.float() + b.reshape(1, -1, 1, 1)).to(dtype).float(), 3, 2, 1).to(dtype)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
