@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Shorten a rocprofv3 *_kernel_stats.csv into a readable, committed summary.
-usage: python profiles/summarize.py <kernel_stats.csv> <out.csv> "<command line that was profiled>" """
+usage: python profiles/summarize.py <kernel_stats.csv> <out.csv> "<command line that was profiled>" [drop-regex]
+Rows whose kernel name matches drop-regex (e.g. MIOpen's find-mode trial kernels of the warm-up) are left out and the
+percentages recomputed over the rest; the header line says so."""
 import csv
 import re
 import sys
@@ -20,7 +22,16 @@ def short(name: str) -> str:
 
 def main():
     src, dst, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
+    drop = re.compile(sys.argv[4]) if len(sys.argv) > 4 else None
     rows = list(csv.DictReader(open(src)))
+    if drop:
+        kept = [r for r in rows if not drop.search(r["Name"])]
+        gone = sum(float(r["TotalDurationNs"]) for r in rows) - sum(float(r["TotalDurationNs"]) for r in kept)
+        tot = sum(float(r["TotalDurationNs"]) for r in kept)
+        for r in kept:
+            r["Percentage"] = f"{100 * float(r['TotalDurationNs']) / tot:.2f}"
+        rows = kept
+        cmd += f"   [rows matching /{sys.argv[4]}/ dropped: {gone / 1e6:.1f} ms]"
     with open(dst, "w") as f:
         f.write(f"# {cmd}\n")
         f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
