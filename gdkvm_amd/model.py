@@ -264,21 +264,28 @@ class GDKVM(nn.Module):
         f4, f8, f16 = self.encoder(x)
         h, w = f16.shape[-2:]
         N = h * w
-        key = self.key_proj(f16)
-        val = self.value_proj(f16)
+        # The four 1x1 projections are token-major GEMMs on the (free) [BT*N, Cp] view of the channels_last feature, with
+        # the bias in the GEMM epilogue: their outputs ARE the contiguous [.., N, C] rows the memory path reads -- no
+        # conv -> bias-add -> permute-copy chain per projection (done at the framework level).
+        p_tok = self._tokens(f16)                                                # [BT,N,Cp] view, no copy
+        tok2d = p_tok.reshape(B * T * N, -1)
+
+        def proj(conv):
+            return F.linear(tok2d, conv.weight.reshape(conv.out_channels, -1), conv.bias)
+
+        k_tok = proj(self.key_proj).reshape(B * T, N, Hh * Dk)                   # local key feature
+        q = proj(self.query_proj).reshape(B, T, N, Hh, Dk)
+        v = proj(self.value_proj).reshape(B, T, N, Hh * Dv)
         if mask0 is not None:
-            m = F.adaptive_avg_pool2d(mask0.to(val.dtype), (h, w))
-            val = val.reshape(B, T, *val.shape[1:])
-            val = torch.cat([val[:, :1] + self.mask_embed(m).unsqueeze(1), val[:, 1:]], 1).reshape(B * T, Hh * Dv, h, w)
+            m = F.adaptive_avg_pool2d(mask0.to(v.dtype), (h, w))
+            me = self._tokens(self.mask_embed(m))                                # [B,N,Hh*Dv]
+            v = torch.cat([v[:, :1] + me.unsqueeze(1), v[:, 1:]], 1)
         elif torch.is_grad_enabled() and self.mask_embed.weight.requires_grad:
-            val = val + 0.0 * self.mask_embed.weight.sum()        # keep every parameter in the graph (DDP: no unused params)
-        k_tok = self._tokens(key)                                                # [BT,N,Hh*Dk] local key feature
-        q = self._tokens(self.query_proj(f16)).reshape(B, T, N, Hh, Dk)
-        v = self._tokens(val).reshape(B, T, N, Hh, Dv)
-        beta = self._tokens(self.gate_proj(f16)).float().reshape(B, T, N, Hh).contiguous()
-        alpha = self.decay_proj(f16.mean((2, 3))).float().reshape(B, T, Hh).contiguous()
+            v = v + 0.0 * self.mask_embed.weight.sum()            # keep every parameter in the graph (DDP: no unused params)
+        v = v.reshape(B, T, N, Hh, Dv)
+        beta = proj(self.gate_proj).float().reshape(B, T, N, Hh)
+        alpha = self.decay_proj(p_tok.mean(1)).float().reshape(B, T, Hh)
         r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state)
-        p_tok = self._tokens(f16)
         fused = self._fuse(k_tok, r.reshape(B * T, N, Hh * Dv), p_tok, h, w)       # [BT,N,Cp]
         fmap = fused.reshape(B * T, h, w, -1).permute(0, 3, 1, 2)                  # channels_last view, no copy
         logits = self.decoder(fmap, f8, f4, None if _lowres else (H, W))
