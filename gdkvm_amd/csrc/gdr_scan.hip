@@ -1407,6 +1407,11 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
 
     if (role == 1) {
         // ------------------------------------------------------------------------------ read-out waves
+        if (!a.r_out) {                                    // states only (transition matrices, segment end states): just keep the
+            aff_barrier();                                 // barrier count
+            for (int t = 0; t < T; ++t) aff_barrier();
+            return;
+        }
         const int last_item = T * JT - 1;
         const char* qbase = static_cast<const char*>(a.q) + (((size_t)b * T * N * Hh + h) * GDKVM_DK) * ESZ;
         const size_t q_fstride = (size_t)N * Hh * GDKVM_DK * ESZ;
