@@ -6,13 +6,13 @@
 //
 //  gdr_prep_kernel         training only (N <= 64): the WY factors by a blocked forward substitution that lives entirely
 //                          in MFMA accumulators, plus the extra operand layouts and T_II the backward consumes.
-//  gdr_scan_kernel         the round's first serial kernel (two dependent products per frame).  Only its BWD mode is
-//                          still launched: the reverse-time recurrence of the backward pass.
-//  gdr_fold_kernel         training: P and G from the stored WY factors.
+//  gdr_fold_kernel         training: P and G (and P^T for the backward) from the stored WY factors.
 //  gdr_prepm_kernel        inference: P and G directly, M = Kn^T T b by a back substitution on four Kn tiles, G = M V.
 //  gdr_compose_kernel      frames of more than 64 tokens: composition of the 64-token chunks' affine maps.
-//  gdr_affine_scan_kernel  the forward recurrence: one workgroup per (clip, head, 16-column slice of Dv), 12 waves in
-//                          three roles (state / read-out / LDS-DMA loader), one barrier per frame.
+//  gdr_affine_scan_kernel  the serial recurrence: one workgroup per (clip, head, 16-column slice of Dv), 12 waves in
+//                          three roles (state / read-out / LDS-DMA loader), one barrier per frame.  Also the backward's
+//                          reverse recurrence (reverse mode) and the state-transition matrix (transition mode).
+//  gdr_bwd_g_kernel        backward: Gb = Qn^T dR per frame, the additive term of the reverse recurrence.
 // Products that dominate a kernel run on v_mfma_f32_16x16x32_bf16 with fp32 operands carried as three bf16 terms
 // (split3, below); everything else is exact fp32 on v_mfma_f32_16x16x4_f32.  Workspace layout: gdr_ws.hpp.
 #include <stdarg.h>
@@ -284,41 +284,6 @@ extern "C" void gdkvm_diag_set_buffer(unsigned long long* p) { g_diag_buf = p; }
 #define DIAG_STAMP(slot) do {} while (0)
 #endif
 
-struct ScanArgs {
-    const void* q; const float* alpha; const float* s_in;
-    const float* wt; const float* knT; const float* ut; const float* qinv;
-    void* r_out; float* s_out; float* s_hist; char* trash;
-    const float* qnT; const void* d_r;                    // BWD mode: read waves form Qn^T dR
-    size_t ut_fstride, ut_slstride;                       // Ut image strides in float4 (both 0: every tile reads one zero tile)
-    int init_identity;                                    // start from S = I (Dv == Dk): the call's state-transition matrix
-    int T, Hh, N, Dv, flags, BH;
-#ifdef GDKVM_DIAG
-    unsigned long long* diag;
-#endif
-};
-
-// 4 consecutive channels as fetched (bf16 stays packed until use, so a prefetched tile costs half the VGPRs)
-template <int IO> struct Raw4;
-template <> struct Raw4<GDKVM_F32> { f32x4 v; };
-template <> struct Raw4<GDKVM_BF16> { uint2 v; };
-template <int IO> __device__ __forceinline__ Raw4<IO> raw_load4(const void* base, size_t off)
-{
-    Raw4<IO> r;
-    if constexpr (IO == GDKVM_F32) r.v = *reinterpret_cast<const f32x4*>(static_cast<const float*>(base) + off);
-    else r.v = *reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(base) + off);
-    return r;
-}
-template <int IO> __device__ __forceinline__ f32x4 widen(const Raw4<IO>& r)
-{
-    if constexpr (IO == GDKVM_F32) return r.v;
-    else {
-        f32x4 x;
-        x[0] = __uint_as_float(r.v.x << 16); x[1] = __uint_as_float(r.v.x & 0xffff0000u);
-        x[2] = __uint_as_float(r.v.y << 16); x[3] = __uint_as_float(r.v.y & 0xffff0000u);
-        return x;
-    }
-}
-
 template <int I, int E, class F>
 __device__ __forceinline__ void static_for(F&& f)
 {
@@ -327,14 +292,6 @@ __device__ __forceinline__ void static_for(F&& f)
         static_for<I + 1, E>(f);
     }
 }
-
-// Operands of one item (one 16-token tile of one frame) per role, as prefetched into registers.
-template <int IO> struct QItem;                                        // read-out waves:  R = (Q S) * qinv
-template <> struct QItem<GDKVM_F32> { f32x4 q[4]; f32x4 qinv; };       //   fp32 I/O: exact fp32 MFMA, k = 16m + 4g + r
-template <> struct QItem<GDKVM_BF16> { bf16x8 q[2]; f32x4 qinv; };     //   bf16 I/O: bf16 MFMA on S = S_hi + S_lo, k = 32s + 8g + j
-struct GItem { f32x4 a[4]; float b[4][4]; };                           // BWD read waves: Qn^T rows 16w.. and dR rows, 4 token tiles
-struct XItem { f32x4 w[4]; f32x4 u; float alpha; };                    // state waves:     X = Wt S, U = Ut - aX
-struct KItem { f32x4 k[4]; };                                          // state waves:     S <- aS + Kn^T U (4 token tiles)
 
 // x = h + m + l with h, m, l bfloat16: 24 significant bits, every step exact in fp32.  A product of such a triple with an
 // exact bf16 operand on the bf16 MFMA (fp32 accumulate) is as accurate as the fp32 MFMA at 3/16 of its issue cycles; a
@@ -382,335 +339,6 @@ __device__ __forceinline__ float fast_sigmoid(float x)
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
-// Serial-in-time recurrence, 8 waves per workgroup in two roles (wave-specialised):
-//   state waves 0-3   the critical path.  Per frame: X = Wt S (16 MFMA per tile), U = Ut - aX -> LDS, barrier,
-//                     S <- aS + Kn^T U (this wave owns S rows 16w..16w+15; 4*NB MFMA), S -> LDS, barrier.
-//   read waves  4-7   the LKVA read-out R = Qn S_{t-1} (16 MFMA per tile) with its loads, L2 normalisation and
-//                     stores -- everything that is NOT on the S -> S dependency chain.  They share the two barriers
-//                     per frame and the S image in LDS; their VALU/memory work overlaps the state waves' MFMA chain
-//                     on the same SIMD (one wave of each role per SIMD).
-// Operands live in 4 rotating register buffers per role; item i computes from buffer i%4 and, when done, prefetches
-// item i+3 into the buffer item i-1 freed (>= 3000 cycles ahead; the measured latency of these MALL/HBM-resident
-// operands under load is ~2500 cycles).  The loops are branch-free (clamped indices, read-out rows of padding tokens
-// go to a trash slot): a CFG merge makes hipcc's vmcnt bookkeeping conservative, and a conservative wait lands on
-// the freshly issued loads and exposes the full latency every frame.
-// SAVE: training mode -- also write the state BEFORE every frame (s_hist [B,T,Hh,Dk,Dv]) for the backward pass.
-// BWD:  the reverse-time recurrence of the backward pass has the same shape,
-//           dS = a (dS' - Wt^T (Kn dS')) + Qn^T dR ,
-//       so the same kernel runs it with the operand roles swapped (Wt -> Kn, Kn^T -> Wt^T, no Ut term), frames visited
-//       last to first, the read waves producing the state-independent term Qn^T dR, and "s_hist" receiving dS' of every
-//       frame.  (NB = 4 only: the per-frame assembly kernel is limited to 64 tokens.)
-template <int IO, int NB, bool SAVE, bool BWD>
-__global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
-{
-    static_assert(!BWD || NB == 4, "backward: N <= 64");
-    constexpr int NP = 16 * NB, JT = NB / 4, NG = NB / 4, NBUF = 4, DEPTH = 3, UF = NBUF / JT;
-    static_assert(JT == 1 || JT == 2 || JT == 4, "token tiles per wave");
-    __shared__ __attribute__((aligned(16))) f32x4 s_S[4 * 64];
-    __shared__ __attribute__((aligned(16))) f32x4 s_U[NB * 64];
-    __shared__ __attribute__((aligned(16))) uint2 s_Sh[2 * 64 * 2], s_Sl[2 * 64 * 2];   // bf16 hi / lo B-operand images of S
-    __shared__ __attribute__((aligned(16))) f32x4 s_G[4 * 64];                           // BWD: Qn^T dR tiles from the read waves
-
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = wave & 3;
-    const bool read_role = wave >= 4;
-    const int nsl = a.Dv / 16, N = a.N, Hh = a.Hh, Dv = a.Dv, T = a.T;
-    // XCD-aware mapping: blocks x and x+8 share an XCD (L2); keep the slices of one (clip, head) -- which
-    // re-read the same q / wt / knT -- on one XCD when the grid allows it (speed only, never correctness).
-    int bh, sl;
-    {
-        const int x = blockIdx.x;
-        if (a.BH % 8 == 0) { bh = (x & 7) + 8 * ((x >> 3) / nsl); sl = (x >> 3) % nsl; }
-        else { bh = x / nsl; sl = x % nsl; }
-    }
-    const int b = bh / Hh, h = bh % Hh;
-    const size_t fh0 = (size_t)b * T * Hh + h;           // frame-head index of frame 0; +Hh per frame
-    const int last_item = T * JT - 1;
-    constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
-    auto tmap = [&](int t) { return BWD ? T - 1 - t : t; };   // frame visited at step t
-
-    // Publishing S for the next frame: the fp32 accumulator image (B operand of the state waves' exact products) and,
-    // for the bf16 arm, S = S_hi + S_lo in bf16 as the B operand of the read-out's 16x16x32 MFMA.  This wave's rows
-    // 16w+4g+r are k = 32s + 8g' + j with s = w>>1, g' = 2(w&1) + (g>>1), j = 4(g&1) + r  ->  half a fragment lane.
-    auto publish_state = [&](const f32x4& sv) {
-        s_S[w * 64 + lane] = sv;
-        if constexpr (IO == GDKVM_BF16 && !BWD) {
-            unsigned h0 = f32_to_bf16(sv[0]), h1 = f32_to_bf16(sv[1]), h2 = f32_to_bf16(sv[2]), h3 = f32_to_bf16(sv[3]);
-            const float l0 = sv[0] - __uint_as_float(h0 << 16), l1 = sv[1] - __uint_as_float(h1 << 16);
-            const float l2 = sv[2] - __uint_as_float(h2 << 16), l3 = sv[3] - __uint_as_float(h3 << 16);
-            const int slot = (((w >> 1) * 64 + (2 * (w & 1) + (g >> 1)) * 16 + li) << 1) + (g & 1);
-            s_Sh[slot] = make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
-            s_Sl[slot] = make_uint2((unsigned)f32_to_bf16(l0) | ((unsigned)f32_to_bf16(l1) << 16),
-                                    (unsigned)f32_to_bf16(l2) | ((unsigned)f32_to_bf16(l3) << 16));
-        }
-    };
-    // state tile of wave w: rows 16w + 4g + r of S, column 16*sl + li.  Both roles start from the LDS images.
-    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
-    if (!read_role) {
-        if (a.s_in) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sacc[r] = a.s_in[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li];
-        } else if (a.init_identity) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sacc[r] = (16 * w + 4 * g + r == 16 * sl + li) ? 1.f : 0.f;
-        }
-        publish_state(sacc);
-    }
-
-    if constexpr (BWD) if (read_role) {
-        // ------------------------------------------------------------------ BWD read waves: G_t = Qn_t^T dR_t
-        const float* qn_lane = a.qnT + fh0 * GDKVM_DK * NP + (size_t)(16 * w + li) * NP + 4 * g;
-        const size_t qn_fstride = (size_t)Hh * GDKVM_DK * NP;
-        const char* drbase = static_cast<const char*>(a.d_r) + ((size_t)b * T * N * Hh * Dv + h * Dv + 16 * sl + li) * ESZ;
-        const size_t dr_fstride = (size_t)N * Hh * Dv * ESZ;
-        auto load_g = [&](int item, GItem& d) {
-            const int t = tmap(min(item, last_item));
-            const float* qp = qn_lane + t * qn_fstride;
-            const char* rp = drbase + t * dr_fstride;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                d.a[j] = *reinterpret_cast<const f32x4*>(qp + 16 * j);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = min(16 * j + 4 * g + r, N - 1);       // padding tokens: Qn^T column is zero
-                    if constexpr (IO == GDKVM_F32) d.b[j][r] = *reinterpret_cast<const float*>(rp + (size_t)n * (Hh * Dv * ESZ));
-                    else d.b[j][r] = bf16_to_f32(*reinterpret_cast<const bf16_t*>(rp + (size_t)n * (Hh * Dv * ESZ)));
-                }
-            }
-        };
-        GItem gb[NBUF];
-#pragma unroll
-        for (int i = 0; i < DEPTH; ++i) load_g(i, gb[i]);
-        __syncthreads();
-        auto frame = [&](int t, auto fc) {
-            constexpr int F = decltype(fc)::value;
-            const GItem& cur = gb[F % NBUF];
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j & 1) acc1 = mfma4(cur.a[j][r], cur.b[j][r], acc1);
-                    else acc0 = mfma4(cur.a[j][r], cur.b[j][r], acc0);
-                }
-            s_G[w * 64 + lane] = acc0 + acc1;
-            load_g(t + DEPTH, gb[(F + DEPTH) % NBUF]);
-            __syncthreads();                               // (1) G_t and V' complete
-            __syncthreads();                               // (2) dS published
-        };
-        int t0 = 0;
-        for (; t0 + UF <= T; t0 += UF)
-            static_for<0, UF>([&](auto fc) { frame(t0 + decltype(fc)::value, fc); });
-        static_for<0, UF - 1>([&](auto fc) {
-            if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, fc);
-        });
-        return;
-    }
-    if (read_role) {
-        // ------------------------------------------------------------------------------ read-out waves
-        const char* qbase = static_cast<const char*>(a.q) + (((size_t)b * T * N * Hh + h) * GDKVM_DK) * ESZ;
-        const size_t q_fstride = (size_t)N * Hh * GDKVM_DK * ESZ;               // bytes per frame
-        const float* qinv_lane = a.qinv + fh0 * NP + 4 * g;
-        char* rbase = static_cast<char*>(a.r_out) + ((size_t)b * T * N * Hh * Dv + h * Dv + 16 * sl + li) * ESZ;
-        const size_t r_fstride = (size_t)N * Hh * Dv * ESZ;
-        auto load_q = [&](int item, QItem<IO>& d) {
-            item = min(item, last_item);                  // past the end: re-fetch the last item (never used)
-            const int t = item / JT, tt = w + 4 * (item - t * JT);
-            const int nq = min(16 * tt + li, N - 1);      // padding tokens fetch a real row; their qinv is 0
-            const char* p = qbase + t * q_fstride + (size_t)nq * (Hh * GDKVM_DK * ESZ);
-            if constexpr (IO == GDKVM_F32) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) d.q[m] = *reinterpret_cast<const f32x4*>(p + 64 * m + 16 * g);
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) d.q[ks] = *reinterpret_cast<const bf16x8*>(p + 64 * ks + 16 * g);
-            }
-            d.qinv = *reinterpret_cast<const f32x4*>(qinv_lane + (size_t)t * Hh * NP + 16 * tt);
-        };
-        QItem<IO> qb[NBUF];
-#pragma unroll
-        for (int i = 0; i < DEPTH; ++i) load_q(i, qb[i]);
-        __syncthreads();
-
-        auto read_item = [&](int t, int j, const QItem<IO>& cur, QItem<IO>& nxt) {
-            const int tt = w + 4 * j;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (IO == GDKVM_F32) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const f32x4 sm = s_S[m * 64 + lane];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (m & 1) acc1 = mfma4(cur.q[m][r], sm[r], acc1);
-                        else acc0 = mfma4(cur.q[m][r], sm[r], acc0);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&s_Sh[(ks * 64 + lane) * 2]);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&s_Sl[(ks * 64 + lane) * 2]);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.q[ks], bh, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur.q[ks], bl, acc1, 0, 0, 0);
-                }
-            }
-            const f32x4 accR = (acc0 + acc1) * cur.qinv;        // rows 4g+r of the tile: L2 normalisation folded here
-            char* rp = rbase + t * r_fstride;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int nr = 16 * tt + 4 * g + r;
-                char* p = (nr < N && a.r_out) ? rp + (size_t)nr * (Hh * Dv * ESZ) : a.trash;    // no read-out wanted -> trash
-                if constexpr (IO == GDKVM_F32) *reinterpret_cast<float*>(p) = accR[r];
-                else *reinterpret_cast<bf16_t*>(p) = f32_to_bf16(accR[r]);
-            }
-            load_q(t * JT + j + DEPTH, nxt);               // after every use of `cur`: waits above never see these
-        };
-        auto frame = [&](int t, auto fc) {
-            constexpr int F = decltype(fc)::value;         // frame index inside the unrolled group: buffer ids static
-            static_for<0, JT>([&](auto jc) {
-                constexpr int i = F * JT + decltype(jc)::value;
-                read_item(t, decltype(jc)::value, qb[i % NBUF], qb[(i + DEPTH) % NBUF]);
-            });
-            __syncthreads();                               // (1) U complete / this wave is done reading S_{t-1}
-            __syncthreads();                               // (2) S_t published
-        };
-        int t0 = 0;
-        for (; t0 + UF <= T; t0 += UF)                     // full groups: a straight-line body, no CFG merge inside
-            static_for<0, UF>([&](auto fc) { frame(t0 + decltype(fc)::value, fc); });
-        static_for<0, UF - 1>([&](auto fc) {               // tail: the last T % UF frames
-            if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, fc);
-        });
-        return;
-    }
-
-    // ---------------------------------------------------------------------------------- state waves
-    const bool gate_logits = a.flags & GDKVM_FLAG_GATE_LOGITS;
-    const float* wt_lane = a.wt + fh0 * NP * GDKVM_DK + (size_t)li * GDKVM_DK + 4 * g;
-    const size_t wt_fstride = (size_t)Hh * NP * GDKVM_DK;
-    const f32x4* ut_lane = reinterpret_cast<const f32x4*>(a.ut) + fh0 * a.ut_fstride + (size_t)sl * a.ut_slstride + lane;
-    const size_t ut_fstride = (size_t)Hh * a.ut_fstride, ut_tstride = a.ut_slstride ? 64 : 0;
-    const float* kn_lane = a.knT + fh0 * GDKVM_DK * NP + (size_t)(16 * w + li) * NP + 4 * g;
-    const size_t kn_fstride = (size_t)Hh * GDKVM_DK * NP;
-    const float* al_ptr = a.alpha + fh0;
-    int vzero;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));       // opaque per-lane zero: keeps the alpha prefetch off the SMEM path
-
-    auto load_x = [&](int item, XItem& d) {              // item = t*JT + j  -> token tile tt = w + 4j of frame t
-        item = min(item, last_item);
-        const int ts = item / JT, tt = w + 4 * (item - ts * JT), t = tmap(ts);
-        const float* wt = wt_lane + t * wt_fstride + tt * (16 * GDKVM_DK);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) d.w[m] = *reinterpret_cast<const f32x4*>(wt + 16 * m);
-        if constexpr (!BWD) d.u = ut_lane[t * ut_fstride + tt * ut_tstride];
-        d.alpha = al_ptr[(size_t)t * Hh + vzero];       // VECTOR load on purpose: a scalar load shares lgkmcnt with the
-    };                                                   // LDS reads, whose lgkmcnt(0) would then wait ~1 us for it
-    auto load_k = [&](int item, KItem& d) {              // item = t*NG + gi -> token tiles 4gi..4gi+3 of frame t
-        item = min(item, last_item);
-        const int ts = item / NG, gi = item - ts * NG, t = tmap(ts);
-        const float* kp = kn_lane + t * kn_fstride + 64 * gi;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d.k[j] = *reinterpret_cast<const f32x4*>(kp + 16 * j);
-    };
-    XItem xb[NBUF];
-    KItem kb[NBUF];
-#pragma unroll
-    for (int i = 0; i < DEPTH; ++i) { load_x(i, xb[i]); load_k(i, kb[i]); }
-    __syncthreads();
-
-    auto x_item = [&](int t, int j, const XItem& cur, XItem& nxt, const f32x4 (&sreg)[4], float& alpha) {
-        const int tt = w + 4 * j;
-        load_x(t * JT + j + DEPTH, nxt);                 // issued first so its address math and loads can sit in MFMA gaps
-        alpha = gate_logits ? fast_sigmoid(cur.alpha) : cur.alpha;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        // alternate the two accumulation chains on every instruction: a dependent 16x16x4 MFMA needs 40 cycles,
-        // an independent one issues after 32
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if (m & 1) acc1 = mfma4(cur.w[m][r], sreg[m][r], acc1);
-                else acc0 = mfma4(cur.w[m][r], sreg[m][r], acc0);
-            }
-#ifdef GDKVM_SCHED
-        // an MFMA holds the issue port for 8 of its 32 cycles: put the independent prefetch work into the gaps
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x006, 3, 0);     // up to 3 VALU/SALU
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // up to 1 VMEM read
-        }
-#endif
-        f32x4 u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) u[r] = (BWD ? 0.f : cur.u[r]) - alpha * (acc0[r] + acc1[r]);
-        s_U[tt * 64 + lane] = u;
-    };
-    auto k_item = [&](int t, int gi, const KItem& cur, KItem& nxt, f32x4& acc0, f32x4& acc1) {
-        load_k(t * NG + gi + DEPTH, nxt);
-        f32x4 ub[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ub[j] = s_U[(4 * gi + j) * 64 + lane];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j & 1) acc1 = mfma4(cur.k[j][r], ub[j][r], acc1);
-                else acc0 = mfma4(cur.k[j][r], ub[j][r], acc0);
-            }
-#ifdef GDKVM_SCHED
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        }
-#endif
-    };
-    auto frame = [&](int t, auto fc) {
-        constexpr int F = decltype(fc)::value;
-        DIAG_STAMP(0);
-        if constexpr (SAVE) {
-            float* hp = a.s_hist + ((fh0 + (size_t)tmap(t) * Hh) * GDKVM_DK + 16 * w + 4 * g) * Dv + 16 * sl + li;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) hp[(size_t)r * Dv] = sacc[r];
-        }
-        f32x4 sreg[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) sreg[m] = s_S[m * 64 + lane];
-        float alpha = 0.f;
-        static_for<0, JT>([&](auto jc) {
-            constexpr int i = F * JT + decltype(jc)::value;
-            x_item(t, decltype(jc)::value, xb[i % NBUF], xb[(i + DEPTH) % NBUF], sreg, alpha);
-        });
-        DIAG_STAMP(1);
-        __syncthreads();
-        DIAG_STAMP(2);
-        f32x4 acc0 = sacc * alpha, acc1 = {0.f, 0.f, 0.f, 0.f};      // two chains: hide the 40-cycle MFMA latency
-        static_for<0, NG>([&](auto gc) {
-            constexpr int i = F * NG + decltype(gc)::value;
-            k_item(t, decltype(gc)::value, kb[i % NBUF], kb[(i + DEPTH) % NBUF], acc0, acc1);
-        });
-        sacc = acc0 + acc1;
-        if constexpr (BWD) sacc += s_G[w * 64 + lane];    // + Qn^T dR of this frame (written before barrier 1)
-        DIAG_STAMP(3);
-        publish_state(sacc);
-        __syncthreads();
-        DIAG_STAMP(4);
-    };
-    int t0 = 0;
-    for (; t0 + UF <= T; t0 += UF)                         // full groups: a straight-line body, no CFG merge inside
-        static_for<0, UF>([&](auto fc) { frame(t0 + decltype(fc)::value, fc); });
-    static_for<0, UF - 1>([&](auto fc) {                   // tail: the last T % UF frames
-        if (t0 + decltype(fc)::value < T) frame(t0 + decltype(fc)::value, fc);
-    });
-    if (a.s_out) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a.s_out[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li] = sacc[r];
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------------------------
 // The frame as ONE affine map of the state.  Substituting U = Ut - a Wt S into S' = a S + Kn^T U gives
 //        S' = a (I - Kn^T Wt) S + Kn^T Ut  =  a P S + G ,
@@ -721,7 +349,7 @@ __global__ __launch_bounds__(512) void gdr_scan_kernel(ScanArgs a)
 // gdr_fold_kernel: P = I - Kn^T Wt and G = Kn^T Ut for one frame-head; wave w owns row tile w (Dk rows 16w..16w+15), the
 // 4 + Dv/16 column tiles are split over gridDim.y workgroups.  A operands are rows of knT (k = 16I + 4g + r, the
 // permutation under which the Ut images -- prep's accumulator layout -- are B operands as stored).
-struct FoldArgs { const float* wti; const float* knT; const float* ut; float* pp; float* gg; int Dv; };
+struct FoldArgs { const float* wti; const float* knT; const float* ut; float* pp; float* gg; float* ppt; int Dv; };
 
 // grid (FH, 1 + ceil(Dv/64)): block y = 0 folds the four Wt tiles into P, block y > 0 four Ut tiles into G.  Every operand
 // of the block's four tiles is requested up front (20 16-byte loads per lane), then 4 x 4NB MFMA run back to back.
@@ -768,6 +396,16 @@ __global__ __launch_bounds__(256) void gdr_fold_kernel(FoldArgs a)
             const f32x4 o = acc0 + acc1;
             if (c < nlim) {
                 if (isP) {
+                    {   // P^T for the backward's reverse recurrence dS = a P^T dS' + Qn^T dR: this lane's four values are
+                        // P^T[16c + li][k = 16w + 4g + r], four consecutive k of row li of row tile c
+                        __bf16 t3[3][4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            split3(((16 * w + 4 * g + r == 16 * c + li) ? 1.f : 0.f) - o[r], t3[0][r], t3[1][r], t3[2][r]);
+                        uint2* pt = reinterpret_cast<uint2*>(a.ppt) + (fh * 4 + c) * (size_t)(3 * SPLIT_IMG);
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) pt[sp * SPLIT_IMG + split_slot(w, g, li)] = pack_bf16x4(t3[sp]);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {                  // P[16w + 4g + r][k = 16c + li] -> term images of row tile w
                         const int row = 16 * w + 4 * g + r, col = 16 * c + li;
@@ -1303,6 +941,7 @@ struct AffArgs {
     void* r_out; float* s_out; float* s_hist; char* trash;
     int init_identity, zero_g;                       // transition mode: S_0 = I, and gg is ONE zero tile (all strides 0)
     int T, Hh, N, Dv, flags, BH;
+    int reverse;                                     // visit the frames last to first (the backward's reverse recurrence)
 #ifdef GDKVM_DIAG
     unsigned long long* diag;
 #endif
@@ -1360,6 +999,7 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
             f = 0;
 #endif
             f = min(f, T - 1);                            // past the end: refetch the last frame into a slot nobody reads
+            if (a.reverse) f = T - 1 - f;
             f32x4* dst = s_ring + slot * AFF_SLOT_F4;
             const float* pr = pp_lane + f * pp_fstride;
 #pragma unroll
@@ -1526,7 +1166,7 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
         const int par = t & 1;
         DIAG_STAMP(0);
         if constexpr (SAVE) {
-            float* hp = a.s_hist + ((fh0 + (size_t)t * Hh) * GDKVM_DK + 16 * w + 4 * g) * Dv + 16 * sl + li;
+            float* hp = a.s_hist + ((fh0 + (size_t)(a.reverse ? T - 1 - t : t) * Hh) * GDKVM_DK + 16 * w + 4 * g) * Dv + 16 * sl + li;
 #pragma unroll
             for (int r = 0; r < 4; ++r) hp[(size_t)r * Dv] = sacc[r];
         }
@@ -1665,7 +1305,7 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
     // training, <= 64 tokens: the WY factors the backward consumes, then folded
     PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, ws.kn, ws.wtT, ws.qnT, ws.tii, ws.wti, T, Hh, N, Dv, rule, flags};
     if (int rc = io_dtype == GDKVM_F32 ? launch_prep<4, GDKVM_F32, 5>(pa, B * T * Hh, st) : launch_prep<4, GDKVM_BF16, 5>(pa, B * T * Hh, st)) return rc;
-    FoldArgs fa{ws.wti, ws.knT, ws.ut, ws.pp, ws.gg, Dv};
+    FoldArgs fa{ws.wti, ws.knT, ws.ut, ws.pp, ws.gg, ws.ppt, Dv};
     launch_fold<4>(fa, B * T * Hh, st);
     GDKVM_LAUNCH_CHECK("gdr_fold_kernel");
     return GDKVM_OK;
@@ -1697,7 +1337,7 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
         }
         return GDKVM_OK;
     }
-    AffArgs sa{q, alpha, s_in, ws.pp, ws.gg, ws.qinv, r_out, s_out, s_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh};
+    AffArgs sa{q, alpha, s_in, ws.pp, ws.gg, ws.qinv, r_out, s_out, s_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 0};
 #ifdef GDKVM_DIAG
     sa.diag = g_diag_buf;
 #endif
@@ -1720,7 +1360,7 @@ extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* p
     // the recurrence on Dk columns from S = I with G = 0 and no read-out:  Phi = prod_t a_t P_t
     hipError_t e = hipMemsetAsync(ws.zero, 0, 64 * 4 * sizeof(float), st);       // the one G tile every frame and slice reads
     if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_transition: memset: %s", hipGetErrorString(e));
-    AffArgs sa{q, alpha, nullptr, ws.pp, ws.zero, ws.qinv, nullptr, phi_out, nullptr, ws.trash, 1, 1, T, Hh, N, GDKVM_DK, flags, B * Hh};
+    AffArgs sa{q, alpha, nullptr, ws.pp, ws.zero, ws.qinv, nullptr, phi_out, nullptr, ws.trash, 1, 1, T, Hh, N, GDKVM_DK, flags, B * Hh, 0};
 #ifdef GDKVM_DIAG
     sa.diag = nullptr;
 #endif
@@ -1738,18 +1378,55 @@ extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const
     return gdkvm_scan_apply(q, alpha, s_in, r_out, s_out, s_hist, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, flags, stream);
 }
 
-// Reverse-time recurrence of the backward pass on the forward kernel (BWD mode); called by gdkvm_scan_bwd.
-int gdr_launch_reverse_scan(const WsView& ws, const float* alpha, const void* d_r, const float* ds_out, float* ds_hist,
-                            float* ds_in, int B, int T, int Hh, int N, int Dv, int io_dtype, int flags, hipStream_t st)
+// Backward pass (called by gdkvm_scan_bwd).  The reverse-time recurrence has the forward's affine shape,
+//     dS = a (dS' - Wt^T (Kn dS')) + Qn^T dR  =  a P^T dS' + Gb,      Gb = Qn^T dR  [Dk, Dv] per frame,
+// so it runs on gdr_affine_scan_kernel itself: P^T images from the training-mode fold, Gb tiles from the kernel below,
+// frames visited last to first, no read-out, and the state BEFORE every step (= dS' of that frame) written like s_hist.
+struct BwdGArgs { const float* qnT; const void* d_r; float* gb; int Hh, N, Dv; };
+
+template <int IO>
+__global__ __launch_bounds__(256) void gdr_bwd_g_kernel(BwdGArgs a)
 {
-    ScanArgs sa{nullptr, alpha, ds_out, ws.kn, ws.wtT, nullptr, nullptr, nullptr, ds_in, ds_hist, ws.trash, ws.qnT, d_r,
-                0, 0, 0, T, Hh, N, Dv, flags, B * Hh};
+    constexpr int NB = 4, NP = 64;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t fh = blockIdx.x;
+    const int h = (int)(fh % a.Hh), N = a.N, Dv = a.Dv, nsl = Dv / 16;
+    const size_t bt = fh / a.Hh;
+    f32x4 qa[NB];                                          // A operand: Qn^T rows 16w + li, k = token 16I + 4g + r (padding columns are 0)
+#pragma unroll
+    for (int I = 0; I < NB; ++I) qa[I] = *reinterpret_cast<const f32x4*>(a.qnT + (fh * GDKVM_DK + 16 * w + li) * NP + 16 * I + 4 * g);
+    for (int cV = blockIdx.y; cV < nsl; cV += gridDim.y) {
+        float x[NB][4];
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                x[I][r] = load1<IO>(a.d_r, ((bt * N + min(16 * I + 4 * g + r, N - 1)) * a.Hh + h) * Dv + 16 * cV + li);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int I = 0; I < NB; ++I) {
+                if (I & 1) acc1 = mfma4(qa[I][r], x[I][r], acc1);
+                else acc0 = mfma4(qa[I][r], x[I][r], acc0);
+            }
+        reinterpret_cast<f32x4*>(a.gb)[((fh * nsl + cV) * 4 + w) * 64 + lane] = acc0 + acc1;
+    }
+}
+
+int gdr_launch_reverse_scan(const WsView& ws, const float* alpha, const void* d_r, const float* ds_out, float* ds_hist,
+                            float* ds_in, float* gb, int B, int T, int Hh, int N, int Dv, int io_dtype, int flags, hipStream_t st)
+{
+    BwdGArgs ga{ws.qnT, d_r, gb, Hh, N, Dv};
+    const dim3 ggrid((unsigned)(B * T * Hh), (unsigned)((Dv / 16 + 3) / 4));
+    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_bwd_g_kernel<GDKVM_F32>), ggrid, dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL((gdr_bwd_g_kernel<GDKVM_BF16>), ggrid, dim3(256), 0, st, ga);
+    GDKVM_LAUNCH_CHECK("gdr_bwd_g_kernel");
+    AffArgs sa{nullptr, alpha, ds_out, ws.ppt, gb, nullptr, nullptr, ds_in, ds_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 1};
 #ifdef GDKVM_DIAG
     sa.diag = nullptr;
 #endif
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
-    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_scan_kernel<GDKVM_F32, 4, true, true>), grid, dim3(512), 0, st, sa);
-    else hipLaunchKernelGGL((gdr_scan_kernel<GDKVM_BF16, 4, true, true>), grid, dim3(512), 0, st, sa);
-    GDKVM_LAUNCH_CHECK("gdr_scan_kernel<BWD>");
-    return GDKVM_OK;
+    return io_dtype == GDKVM_F32 ? launch_affine<GDKVM_F32, 4, true>(sa, grid, st) : launch_affine<GDKVM_BF16, 4, true>(sa, grid, st);
 }

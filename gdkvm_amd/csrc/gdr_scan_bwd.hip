@@ -2,10 +2,11 @@
 //
 // With the forward per frame   R = Qn S,  X = Wt S,  U = Ut - a X,  S' = a S + Kn^T U   (Wt = T b Kn, Ut = T b V):
 //
-//  reverse scan          the reverse-time recurrence on dS has the shape of the forward one,
-//                            dS = a (dS' - Wt^T (Kn dS')) + Qn^T dR ,
-//                        and runs on the forward kernel itself in BWD mode (gdr_scan.hip: operand roles swapped, frames
-//                        visited last to first, read waves forming Qn^T dR).  Writes dS' of every frame (ds_hist).
+//  reverse scan          the reverse-time recurrence on dS has the forward's affine shape,
+//                            dS = a (dS' - Wt^T (Kn dS')) + Qn^T dR  =  a P^T dS' + Gb ,
+//                        and runs on the forward's serial kernel (gdr_scan.hip: gdr_affine_scan_kernel in reverse mode, P^T
+//                        images from the training-mode fold, Gb = Qn^T dR from gdr_bwd_g_kernel).  Writes dS' of every
+//                        frame (ds_hist).
 //  gdr_bwd_frame_kernel  everything else is frame-local given S (s_hist, saved by the forward) and dS' (ds_hist):
 //                            dU = Kn dS'   dKn = U dS'^T   dWt = -a dU S^T   dQn = dR S^T   da = <S,dS'> - <X,dU>
 //                            Z = T^T [dWt | dU]  (back substitution)   db, dV, dKn through diag(b) and A = tril(b Kn Kn^T)
@@ -20,7 +21,7 @@
 #include "gdr_ws.hpp"
 
 int gdr_launch_reverse_scan(const WsView& ws, const float* alpha, const void* d_r, const float* ds_out, float* ds_hist,
-                            float* ds_in, int B, int T, int Hh, int N, int Dv, int io_dtype, int flags, hipStream_t st);
+                            float* ds_in, float* gb, int B, int T, int Hh, int N, int Dv, int io_dtype, int flags, hipStream_t st);
 
 namespace {
 
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
 extern "C" size_t gdkvm_scan_bwd_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
 {
     if (B <= 0 || T <= 0 || Hh <= 0 || N <= 0 || Dk <= 0 || Dv <= 0) return 16;
-    return (size_t)B * T * Hh * Dk * Dv * sizeof(float) + 16;
+    return 2 * (size_t)B * T * Hh * Dk * Dv * sizeof(float) + 16;       // dS' of every frame + Gb = Qn^T dR of every frame
 }
 
 extern "C" int gdkvm_scan_bwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
@@ -381,9 +382,10 @@ extern "C" int gdkvm_scan_bwd(const void* q, const void* k, const void* v, const
     if (int rc = gdkvm_check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* ds_hist = static_cast<float*>(bwd_workspace);
+    float* gb = ds_hist + (size_t)B * T * Hh * Dk * Dv;
 
-    // reverse recurrence: the tuned forward kernel in BWD mode (operands from the training-mode workspace)
-    if (int rc = gdr_launch_reverse_scan(ws, alpha, d_r, d_s_out, ds_hist, d_s_in, B, T, Hh, N, Dv, io_dtype, flags, st)) return rc;
+    // reverse recurrence on the forward's serial kernel (operands from the training-mode workspace)
+    if (int rc = gdr_launch_reverse_scan(ws, alpha, d_r, d_s_out, ds_hist, d_s_in, gb, B, T, Hh, N, Dv, io_dtype, flags, st)) return rc;
 
     BwdFrameArgs fa{q, k, v, alpha, beta, ws.qinv, ws.kn, ws.wt, ws.ut, ws.tii, s_hist, ds_hist, d_r,
                     d_q, d_k, d_v, d_alpha, d_beta, T, Hh, N, Dv, rule, flags};

@@ -10,6 +10,7 @@ static inline int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
 // fp32 workspace per frame-head fh.  NP = 16*nb padded tokens (nb = 4, 8 or 16), NL = min(NP, 64):
 //   legacy WY regions, written by the training-mode prep for frames of <= 64 tokens (the backward's operands), NL tokens wide:
 //     wt [NL][64] | knT [64][NL] | ut [Dv/16][4][64][4] | kn [NL][64] | wtT [64][NL] | qnT [64][NL] | tii [4][16][16] | wti [4][4][64][4]
+//     ppt = P^T as split3 images (like pp), the operator of the backward's reverse recurrence
 //   qinv [NP]
 //   the folded per-frame affine map the forward scan consumes:
 //     pp [4][3][2][64][8] bf16 = P = I - Kn^T Wt split into three bf16 terms (split3) as A-operand images of the bf16 MFMA
@@ -19,7 +20,7 @@ static inline int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
 //     x0  [4 + Dv/16][4][64][4]  chunk 0 as accumulator images of [P | G]
 //     ppc [nchunk-1] x pp, ggc [nchunk-1] x gg  for chunks 1..
 struct WsView {
-    float* wt; float* knT; float* ut; float* qinv; float* kn; float* wtT; float* qnT; float* tii; float* wti;
+    float* wt; float* knT; float* ut; float* qinv; float* kn; float* wtT; float* qnT; float* tii; float* wti; float* ppt;
     float* pp; float* gg; float* x0; float* ppc; float* ggc; float* zero; char* trash; int nb; int nchunk;
 };
 
@@ -27,7 +28,7 @@ static inline size_t gdr_ws_floats_per_fh(int N, int Dk, int Dv)
 {
     const size_t NP = 16 * (size_t)tiles_for(N), NL = NP < 64 ? NP : 64, C = (NP + 63) / 64;
     const size_t pg = (size_t)Dk * Dk * 3 / 2 + (size_t)Dk * Dv;
-    return NL * (6 * (size_t)Dk + Dv + 16) + NP + pg + (C > 1 ? (size_t)Dk * (Dk + Dv) + (C - 1) * pg : 0);
+    return NL * (6 * (size_t)Dk + Dv + 16) + (size_t)Dk * Dk * 3 / 2 + NP + pg + (C > 1 ? (size_t)Dk * (Dk + Dv) + (C - 1) * pg : 0);
 }
 
 static inline size_t gdr_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
@@ -54,6 +55,7 @@ static inline int carve(const char* fn, void* workspace, size_t workspace_bytes,
     v->qnT = p;   p += FH * NL * GDKVM_DK;
     v->tii = p;   p += FH * NL * 16;
     v->wti = p;   p += FH * NL * GDKVM_DK;
+    v->ppt = p;   p += FH * ppf;
     v->qinv = p;  p += FH * NP;
     v->pp = p;    p += FH * ppf;
     v->gg = p;    p += FH * ggf;
