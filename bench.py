@@ -232,6 +232,28 @@ def main():
                            "algorithmic_bytes": alg, "avg_ms": {"gdr_prepm_kernel": round(prep_ms, 4),
                                                                 "gdr_affine_scan_kernel": round(scan_ms, 4),
                                                                 "scan_fwd_total": round(both_ms, 4)}}
+        # the other hot-path kernels of one forward, same timing method (informational: the contract's `roofline` object
+        # above is the scan pair)
+        Cp, hw = cfg.pixel_dim, S // 16
+        Lk = torch.randn(B * T, N, Hh * Dk, device=dev, generator=gq).bfloat16()
+        Pk = torch.randn(B * T, N, Cp, device=dev, generator=gq).bfloat16()
+        kp = model.kpff
+        fo = torch.empty(B * T, N, Cp, device=dev, dtype=torch.bfloat16)
+        kws = torch.empty(ops.load().gdkvm_kpff_workspace_bytes(Hh * Dk, Hh * Dv, Cp, 1), dtype=torch.uint8, device=dev)
+        ops.kpff_fwd(Lk, r.reshape(B * T, N, Hh * Dv), Pk, kp.wa, kp.ba, kp.wl, kp.wg, hw, hw, out=fo, workspace=kws)
+        kpff_ms, _ = time_events(lambda: ops.kpff_fwd(Lk, r.reshape(B * T, N, Hh * Dv), Pk, kp.wa, kp.ba, kp.wl, kp.wg, hw, hw,
+                                                      out=fo, workspace=kws, packed=True), args.kernel_iters)
+        kpff_bytes = 2 * B * T * N * (Hh * Dk + Hh * Dv + 2 * Cp) + 2 * (2 * Cp * (Cp + Hh * Dk + Hh * Dv) + Cp * Hh * Dk + Cp * Hh * Dv)
+        lowres = torch.randn(B * T, cfg.num_classes, S // 4, S // 4, device=dev, generator=gq).bfloat16()
+        am_ms, _ = time_events(lambda: ops.upsample_argmax_dice(lowres, S, S, None), args.kernel_iters)
+        am_bytes = lowres.numel() * 2 + B * T * S * S
+        out["roofline"]["other_kernels"] = {
+            "kpff_bf16_kernel": {"avg_ms": round(kpff_ms, 4), "algorithmic_bytes": kpff_bytes,
+                                 "achieved_GBps": round(kpff_bytes / (kpff_ms * 1e-3) / 1e9, 1),
+                                 "frac": round(kpff_bytes / (kpff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "upsample_argmax_dice_kernel": {"avg_ms": round(am_ms, 4), "algorithmic_bytes": am_bytes,
+                                            "achieved_GBps": round(am_bytes / (am_ms * 1e-3) / 1e9, 1),
+                                            "frac": round(am_bytes / (am_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
         # ---- CPU baseline: the oracle module on a bounded sample of the same workload (N=1 only) -----------
         if world == 1 and not args.no_cpu_baseline:
             cores = host_cores()

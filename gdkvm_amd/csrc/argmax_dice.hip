@@ -113,37 +113,49 @@ __global__ __launch_bounds__(256) void upsample_argmax_dice_kernel(UpArgs a)
         for (int i = threadIdx.x; i < ncls * 3; i += 256) s_cnt[i] = 0;
         __syncthreads();
     }
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < ((HW + 255) / 256) * 256; p += gridDim.x * 256) {
-        const bool act = p < HW;
-        int arg = 0;
+    // PX consecutive pixels of a row per thread (4 when W % 4 == 0): one 4-byte mask store and one 4-byte target load
+    // instead of four 1-byte ones, and the vertical taps / weights computed once per thread
+    const int PX = (a.W % 4 == 0) ? 4 : 1, nq = HW / PX;
+    for (int qd = blockIdx.x * 256 + threadIdx.x; qd < ((nq + 255) / 256) * 256; qd += gridDim.x * 256) {
+        const bool act = qd < nq;
+        int arg[4] = {0, 0, 0, 0};
+        const int p0 = qd * PX;
         if (act) {
-            const int y = p / a.W, x = p - y * a.W;
-            const float fy = up_src(a.sy, y), fx = up_src(a.sx, x);
-            const int y0 = (int)fy, x0 = (int)fx;
-            const int y1 = min(y0 + 1, a.hl - 1), x1 = min(x0 + 1, a.wl - 1);
-            const float ly = __fsub_rn(fy, (float)y0), lx = __fsub_rn(fx, (float)x0);
-            const float hy = __fsub_rn(1.0f, ly), hx = __fsub_rn(1.0f, lx);
-            float best = 0.f;
-            for (int c = 0; c < ncls; ++c) {
-                const size_t base = ((size_t)f * ncls + c) * hw;
-                const float v00 = load1<IO>(a.logits, base + y0 * a.wl + x0), v01 = load1<IO>(a.logits, base + y0 * a.wl + x1);
-                const float v10 = load1<IO>(a.logits, base + y1 * a.wl + x0), v11 = load1<IO>(a.logits, base + y1 * a.wl + x1);
-                const float top = __fadd_rn(__fmul_rn(hx, v00), __fmul_rn(lx, v01));
-                const float bot = __fadd_rn(__fmul_rn(hx, v10), __fmul_rn(lx, v11));
-                const float v = __fadd_rn(__fmul_rn(hy, top), __fmul_rn(ly, bot));
-                if (c == 0 || v > best) { best = v; arg = c; }
+            const int y = p0 / a.W, xb = p0 - y * a.W;
+            const float fy = up_src(a.sy, y);
+            const int y0 = (int)fy, y1 = min(y0 + 1, a.hl - 1);
+            const float ly = __fsub_rn(fy, (float)y0), hy = __fsub_rn(1.0f, ly);
+            for (int e = 0; e < PX; ++e) {
+                const float fx = up_src(a.sx, xb + e);
+                const int x0 = (int)fx, x1 = min(x0 + 1, a.wl - 1);
+                const float lx = __fsub_rn(fx, (float)x0), hx = __fsub_rn(1.0f, lx);
+                float best = 0.f;
+                for (int c = 0; c < ncls; ++c) {
+                    const size_t base = ((size_t)f * ncls + c) * hw;
+                    const float v00 = load1<IO>(a.logits, base + y0 * a.wl + x0), v01 = load1<IO>(a.logits, base + y0 * a.wl + x1);
+                    const float v10 = load1<IO>(a.logits, base + y1 * a.wl + x0), v11 = load1<IO>(a.logits, base + y1 * a.wl + x1);
+                    const float top = __fadd_rn(__fmul_rn(hx, v00), __fmul_rn(lx, v01));
+                    const float bot = __fadd_rn(__fmul_rn(hx, v10), __fmul_rn(lx, v11));
+                    const float v = __fadd_rn(__fmul_rn(hy, top), __fmul_rn(ly, bot));
+                    if (c == 0 || v > best) { best = v; arg[e] = c; }
+                }
             }
-            a.mask[(size_t)f * HW + p] = (uint8_t)arg;
+            if (PX == 4) *reinterpret_cast<unsigned*>(a.mask + (size_t)f * HW + p0) = (unsigned)arg[0] | ((unsigned)arg[1] << 8) | ((unsigned)arg[2] << 16) | ((unsigned)arg[3] << 24);
+            else a.mask[(size_t)f * HW + p0] = (uint8_t)arg[0];
         }
         if (dice) {
-            const int tc = act ? a.target[(size_t)f * HW + p] : -1;
-            for (int c = 0; c < ncls; ++c) {
-                const unsigned long long mp = __ballot(act && arg == c), mt = __ballot(tc == c);
-                if ((threadIdx.x & 63) == 0 && (mp | mt)) {
-                    const int ni = __popcll(mp & mt), np = __popcll(mp), nt = __popcll(mt);
-                    if (ni) atomicAdd(&s_cnt[c * 3 + 0], ni);
-                    if (np) atomicAdd(&s_cnt[c * 3 + 1], np);
-                    if (nt) atomicAdd(&s_cnt[c * 3 + 2], nt);
+            unsigned tw = 0xffffffffu;
+            if (act) tw = PX == 4 ? *reinterpret_cast<const unsigned*>(a.target + (size_t)f * HW + p0) : (0xffffff00u | a.target[(size_t)f * HW + p0]);
+            for (int e = 0; e < PX; ++e) {
+                const int tc = act ? (int)((tw >> (8 * e)) & 0xff) : -1;
+                for (int c = 0; c < ncls; ++c) {
+                    const unsigned long long mp = __ballot(act && arg[e] == c), mt = __ballot(tc == c);
+                    if ((threadIdx.x & 63) == 0 && (mp | mt)) {
+                        const int ni = __popcll(mp & mt), np = __popcll(mp), nt = __popcll(mt);
+                        if (ni) atomicAdd(&s_cnt[c * 3 + 0], ni);
+                        if (np) atomicAdd(&s_cnt[c * 3 + 1], np);
+                        if (nt) atomicAdd(&s_cnt[c * 3 + 2], nt);
+                    }
                 }
             }
         }
@@ -214,8 +226,10 @@ extern "C" int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* tar
         if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "upsample_argmax_dice: memset: %s", hipGetErrorString(e));
     }
     UpArgs a{logits, target, mask, counts, ncls, hl, wl, H, W, (float)hl / (float)H, (float)wl / (float)W};
-    int gx = (H * W + 255) / 256;
-    if (gx > 64) gx = 64;
+    const int nq = (W % 4 == 0) ? H * W / 4 : H * W;       // work items per frame (pixel quads when rows allow)
+    int gx = (nq + 255) / 256;
+    const int cap = BT >= 1024 ? 2 : (BT >= 256 ? 4 : 16);  // enough blocks to fill the chip, few enough that launch and the
+    if (gx > cap) gx = cap;                                //   per-block count reduction do not dominate
     const dim3 grid((unsigned)gx, (unsigned)BT);
     const size_t lds = sizeof(int) * (size_t)ncls * 3;
     if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((upsample_argmax_dice_kernel<GDKVM_F32>), grid, dim3(256), lds, st, a);
