@@ -965,7 +965,7 @@ __device__ __forceinline__ void aff_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int IO, int NB, bool SAVE>
 __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
 {
-    constexpr int NP = 16 * NB, JT = NB / 4, NBUF = 4, DEPTH = 3, UFR = NBUF / JT;
+    constexpr int NP = 16 * NB, JT = NB / 4, NBUF = (JT > 1 && IO == GDKVM_BF16) ? 8 : 4, DEPTH = NBUF - 1, UFR = NBUF / JT;
     constexpr int NS = aff_slots(IO), D = NS - 1;
     extern __shared__ __attribute__((aligned(16))) f32x4 aff_smem[];
     uint2* s_S3 = reinterpret_cast<uint2*>(aff_smem);      // [parity][term] images of SPLIT_IMG uint2: B operand of the bf16 MFMA

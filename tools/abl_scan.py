@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic only: builds ablation variants of the library (extra -D flags on the command line, e.g. -DGDKVM_ABL_NOST)
+"""Diagnostic only: builds ablation variants of the library (extra -D flags on the command line, -DGDKVM_ABL_NOQ | _NOP | _NOREAD)
 into gpurun_out/ and times scan_prep / scan_apply with them.  Ablated builds compute wrong results by design; their
 timings say which role of the serial kernel bounds a frame.  Never part of the product."""
 import glob
