@@ -65,6 +65,21 @@ def test_scan_chunked_frames_every_rule(hip, rule, dtype):
     assert np.all(np.abs(Rg - Ro) <= TOL + (np.abs(Ro) * 2.0 ** -8 if dtype == torch.bfloat16 else 0))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_every_clip_length_1_to_13(hip, dtype):
+    """The serial kernel unrolls its frame loop (10 frames in the bf16 arm, 4 in the fp32 arm, ring of 5 / 4 slots, read
+    waves by 4): every residue of T must take the right peeled tail, ring slot and operand buffer."""
+    for T in range(1, 14):
+        q, k, v, a, b = make_scan_inputs(1, T, 20, 1, 64, 32, seed=100 + T, normalized=False, logits=True, corr=0.5)
+        if dtype == torch.bfloat16:
+            q, k, v = (O.to_bf16_f32(x) for x in (q, k, v))
+        s0 = np.random.default_rng(T).standard_normal((1, 1, 64, 32)).astype(np.float32) * 0.2
+        Rg, Sg = _run(hip, q, k, v, a, b, s0, 2, 3, dtype=dtype)
+        Ro, So = c_oracle.scan(q, k, v, a, b, s0, 2, 3, math="f64")
+        assert np.abs(Sg - So).max() <= TOL, T
+        assert np.all(np.abs(Rg - Ro) <= TOL + (np.abs(Ro) * 2.0 ** -8 if dtype == torch.bfloat16 else 0)), T
+
+
 def test_scan_matches_numpy_oracle_too(hip):
     q, k, v, a, b = make_scan_inputs(1, 3, 20, 2, 64, 16, seed=5)
     Rg, Sg = _run(hip, q, k, v, a, b)
