@@ -3,6 +3,8 @@
 // After BatchNorm folding every conv carries a bias; PyTorch then runs the bias add, the residual add and the ReLU as
 // three separate full-tensor passes (1.1 ms of a 3.6 ms cfg2 forward).  This is one pass: 16-byte loads/stores,
 // HBM-bound by construction.
+#include <type_traits>
+
 #include "gdkvm_common.hpp"
 
 namespace {
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const void* x, const floa
 // group): its nine window loads are independent and all in flight; neighbouring windows overlap in L1/L2, HBM sees x once.
 template <int IO>
 __global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(const void* x, const float* bias, void* y,
-                                                                int N, int H, int W, int C, int Ho, int Wo)
+                                                                int N, int H, int W, int C, int Ho, int Wo, int Hp, int Wp)
 {
     constexpr int V = IO == GDKVM_F32 ? 4 : 8;
     const int cg = C / V;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(const void* x, c
                 const int ih = 2 * oh - 1 + dy, iw = 2 * ow - 1 + dx;
                 const bool ok = ih >= 0 && ih < H && iw >= 0 && iw < W;
                 const int hh = ok ? ih : 2 * oh, ww = ok ? iw : 2 * ow;
-                win[3 * dy + dx] = xv[(((size_t)n * H + hh) * W + ww) * cg + c];
+                win[3 * dy + dx] = xv[(((size_t)n * Hp + hh) * Wp + ww) * cg + c];     // Hp x Wp: the rows / columns x is stored with
             }
         float m[V];
 #pragma unroll
@@ -142,6 +144,32 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool_kernel(const void* x, c
             o.w = (unsigned)f32_to_bf16(m[6]) | ((unsigned)f32_to_bf16(m[7]) << 16);
         }
         yv[i] = o;
+    }
+}
+
+// Stem input in space-to-depth form: a 7x7 / stride 2 convolution on C channels is a 4x4 / stride 1 convolution on the
+// 4C channels (c, row parity, column parity) of the half-resolution image.  MIOpen runs the 3-channel 7x7 stem at 220 us
+// (implicit-GEMM K = 147, plus a zero-fill pass for its atomics) and the 16-channel 4x4 form at 100 us.  This kernel builds
+// that input from the NCHW frames in the one pass that used to be the channels_last copy:
+//     out[n, i, j, (c*2 + p)*2 + q] = x[n, c, 2i + p, 2j + q],  channels >= 4C zero;  out is NHWC with Cp channels.
+template <int IO>
+__global__ __launch_bounds__(256) void stem_s2d_kernel(const void* x, void* out, int N, int C, int H, int W, int Cp)
+{
+    typedef typename std::conditional<IO == GDKVM_F32, float, bf16_t>::type T;
+    const T* xi = static_cast<const T*>(x);
+    T* o = static_cast<T*>(out);
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)N * Ho * Wo;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int j = (int)(i % Wo);
+        const size_t r = i / Wo;
+        const int ih = (int)(r % Ho), n = (int)(r / Ho);
+        T* dst = o + i * Cp;
+        for (int c = 0; c < C; ++c) {
+            const T* src = xi + (((size_t)n * C + c) * H + 2 * ih) * W + 2 * j;
+            dst[4 * c + 0] = src[0]; dst[4 * c + 1] = src[1]; dst[4 * c + 2] = src[W]; dst[4 * c + 3] = src[W + 1];
+        }
+        for (int c = 4 * C; c < Cp; ++c) dst[c] = T(0);
     }
 }
 
@@ -279,9 +307,11 @@ extern "C" int gdkvm_upsample_cat(const void* lo, const void* skip, void* out,
     return GDKVM_OK;
 }
 
-extern "C" int gdkvm_bias_relu_maxpool(const void* x, const float* bias, void* y, int N, int H, int W, int C, int io_dtype, void* stream)
+extern "C" int gdkvm_bias_relu_maxpool(const void* x, const float* bias, void* y, int N, int H, int W, int C,
+                                       int x_rows, int x_cols, int io_dtype, void* stream)
 {
-    if (N < 0 || H <= 0 || W <= 0 || C <= 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "bias_relu_maxpool: N=%d H=%d W=%d C=%d", N, H, W, C);
+    if (N < 0 || H <= 0 || W <= 0 || C <= 0 || x_rows < H || x_cols < W)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "bias_relu_maxpool: N=%d H=%d W=%d C=%d stored %dx%d", N, H, W, C, x_rows, x_cols);
     if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "bias_relu_maxpool: io_dtype=%d", io_dtype);
     const int V = io_dtype == GDKVM_F32 ? 4 : 8;
     if (C % V) return gdkvm_fail(GDKVM_ERR_SHAPE, "bias_relu_maxpool: C=%d must be a multiple of %d", C, V);
@@ -296,8 +326,26 @@ extern "C" int gdkvm_bias_relu_maxpool(const void* x, const float* bias, void* y
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((bias_relu_maxpool_kernel<GDKVM_F32>), dim3((unsigned)blocks), dim3(256), 0, st, x, bias, y, N, H, W, C, Ho, Wo);
-    else hipLaunchKernelGGL((bias_relu_maxpool_kernel<GDKVM_BF16>), dim3((unsigned)blocks), dim3(256), 0, st, x, bias, y, N, H, W, C, Ho, Wo);
+    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((bias_relu_maxpool_kernel<GDKVM_F32>), dim3((unsigned)blocks), dim3(256), 0, st, x, bias, y, N, H, W, C, Ho, Wo, x_rows, x_cols);
+    else hipLaunchKernelGGL((bias_relu_maxpool_kernel<GDKVM_BF16>), dim3((unsigned)blocks), dim3(256), 0, st, x, bias, y, N, H, W, C, Ho, Wo, x_rows, x_cols);
     GDKVM_LAUNCH_CHECK("bias_relu_maxpool_kernel");
+    return GDKVM_OK;
+}
+
+extern "C" int gdkvm_stem_s2d(const void* x, void* out, int N, int C, int H, int W, int Cp, int io_dtype, void* stream)
+{
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cp < 4 * C)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "stem_s2d: N=%d C=%d H=%d W=%d Cp=%d (H, W even; Cp >= 4C)", N, C, H, W, Cp);
+    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "stem_s2d: io_dtype=%d", io_dtype);
+    if (N == 0) return GDKVM_OK;
+    if (!x || !out) return gdkvm_fail(GDKVM_ERR_ARG, "stem_s2d: null pointer");
+    if (int rc = gdkvm_check_device()) return rc;
+    const size_t total = (size_t)N * (H / 2) * (W / 2);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((stem_s2d_kernel<GDKVM_F32>), dim3((unsigned)blocks), dim3(256), 0, st, x, out, N, C, H, W, Cp);
+    else hipLaunchKernelGGL((stem_s2d_kernel<GDKVM_BF16>), dim3((unsigned)blocks), dim3(256), 0, st, x, out, N, C, H, W, Cp);
+    GDKVM_LAUNCH_CHECK("stem_s2d_kernel");
     return GDKVM_OK;
 }

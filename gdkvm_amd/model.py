@@ -149,9 +149,38 @@ class FusedConv(nn.Module):
 
 class FusedConvPool(FusedConv):
     """The stem: conv -> bias + ReLU + 3x3/2 max-pool as ONE HIP pass over the conv output (the full-resolution activation is
-    read once and never written back)."""
+    read once and never written back).  A 7x7 / stride 2 / pad 3 stem additionally runs in space-to-depth form on the GPU:
+    the same arithmetic as a 4x4 / stride 1 convolution on the (c, row parity, column parity) channels of the half-resolution
+    image, which MIOpen executes 2.2x faster than the 3-channel 7x7 kernel (implicit-GEMM K = 147 and a zero-fill pass)."""
+
+    S2D_CH = 16
+
+    def enable_s2d(self):
+        cv = self.conv
+        if (cv.kernel_size, cv.stride, cv.padding, cv.dilation, cv.groups) != ((7, 7), (2, 2), (3, 3), (1, 1), 1) \
+                or 4 * cv.in_channels > self.S2D_CH:
+            return self
+        w7 = cv.weight.data
+        w4 = torch.zeros(cv.out_channels, self.S2D_CH, 4, 4, dtype=w7.dtype, device=w7.device)
+        for a in range(-2, 2):                          # tap u of the 7x7 kernel = 2a + p + 3 on the half-resolution grid
+            for p_ in range(2):
+                u = 2 * a + p_ + 3
+                if not 0 <= u <= 6:
+                    continue
+                for b in range(-2, 2):
+                    for q_ in range(2):
+                        v = 2 * b + q_ + 3
+                        if 0 <= v <= 6:
+                            w4[:, p_ * 2 + q_:4 * cv.in_channels:4, a + 2, b + 2] = w7[:, :, u, v]
+        self.register_buffer("w_s2d", w4.contiguous(memory_format=torch.channels_last))
+        return self
 
     def forward(self, x, residual=None):
+        if x.is_cuda and getattr(self, "w_s2d", None) is not None and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            xs = ops.stem_s2d(x.contiguous(), self.S2D_CH)                       # NCHW frames -> NHWC space-to-depth, one pass
+            y = F.conv2d(xs, self.w_s2d, None, 1, 2)                             # [N, Cout, H/2 + 1, W/2 + 1]: last row/col unused
+            return ops.bias_relu_maxpool(y.contiguous(memory_format=torch.channels_last)[:, :, :x.shape[2] // 2, :x.shape[3] // 2],
+                                         self.epi.bias)
         y = self.conv(x)
         if not y.is_cuda:
             return F.max_pool2d(F.relu(y + self.epi.bias.to(y.dtype).reshape(1, -1, 1, 1)), 3, 2, 1)
@@ -260,7 +289,9 @@ class GDKVM(nn.Module):
             frames = frames.to(self.key_proj.weight.dtype)
         B, T, C, H, W = frames.shape
         Hh, Dk, Dv = cfg.heads, cfg.key_dim, cfg.value_dim
-        x = frames.reshape(B * T, C, H, W).contiguous(memory_format=torch.channels_last)
+        x = frames.reshape(B * T, C, H, W)
+        if not (x.is_cuda and isinstance(self.encoder.stem[0], FusedConvPool) and getattr(self.encoder.stem[0], "w_s2d", None) is not None):
+            x = x.contiguous(memory_format=torch.channels_last)                  # (the space-to-depth stem reads NCHW frames itself)
         f4, f8, f16 = self.encoder(x)
         h, w = f16.shape[-2:]
         N = h * w
@@ -324,7 +355,7 @@ class GDKVM(nn.Module):
             fused = FusedConvPool.__new__(FusedConvPool)
             nn.Module.__init__(fused)
             fused.conv, fused.epi, fused.relu = stem[0].conv, stem[0].epi, True
-            stem = nn.Sequential(fused)
+            stem = nn.Sequential(fused.enable_s2d())
         self.encoder.stem = stem
         return self
 

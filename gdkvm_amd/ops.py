@@ -41,7 +41,8 @@ SIGNATURES = {
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "gdkvm_bias_act": (_i, [_vp] * 4 + [_sz] + [_i] * 3 + [_vp]),
     "gdkvm_upsample_cat": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
-    "gdkvm_bias_relu_maxpool": (_i, [_vp] * 3 + [_i] * 5 + [_vp]),
+    "gdkvm_bias_relu_maxpool": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
+    "gdkvm_stem_s2d": (_i, [_vp] * 2 + [_i] * 6 + [_vp]),
     "gdkvm_upsample_argmax_dice": (_i, [_vp] * 4 + [_i] * 7 + [_vp]),
 }
 
@@ -435,18 +436,41 @@ def bias_act_(x: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tens
 
 def bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """relu(max_pool2d(x, 3, 2, 1) + bias[c]) on a channels_last conv output in one pass (gdkvm_bias_relu_maxpool);
-    equals max_pool2d(relu(x + bias), 3, 2, 1)."""
+    equals max_pool2d(relu(x + bias), 3, 2, 1).  x may be a top-left spatial crop (a view) of a larger channels_last tensor."""
     lib = load()
-    if x.dim() != 4 or not x.is_cuda or not x.is_contiguous(memory_format=torch.channels_last):
-        raise GdkvmError("bias_relu_maxpool needs a channels_last [N,C,H,W] device tensor")
-    if bias.dtype != torch.float32 or bias.numel() != x.shape[1]:
-        raise GdkvmError("bias must be float32 [C]")
+    if x.dim() != 4 or not x.is_cuda:
+        raise GdkvmError("bias_relu_maxpool needs a channels_last [N,C,H,W] device tensor (or a spatial crop of one)")
     n, c, hh, ww = x.shape
+    if x.is_contiguous(memory_format=torch.channels_last):
+        x_rows, x_cols = hh, ww
+    else:                                                   # a top-left spatial crop: the strides carry the stored size
+        sn, sc, sh, sw = x.stride()
+        if sc != 1 or sw != c or sh % c or (n > 1 and sn % sh):
+            raise GdkvmError("bias_relu_maxpool needs a channels_last [N,C,H,W] device tensor (or a spatial crop of one)")
+        x_cols = sh // c
+        x_rows = sn // sh if n > 1 else hh
+    if bias.dtype != torch.float32 or bias.numel() != c:
+        raise GdkvmError("bias must be float32 [C]")
     out = torch.empty((n, c, (hh - 1) // 2 + 1, (ww - 1) // 2 + 1), device=x.device, dtype=x.dtype,
                       memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
-        rc = lib.gdkvm_bias_relu_maxpool(x.data_ptr(), bias.data_ptr(), out.data_ptr(), n, hh, ww, c, _io_dtype(x), _stream(x.device))
+        rc = lib.gdkvm_bias_relu_maxpool(x.data_ptr(), bias.data_ptr(), out.data_ptr(), n, hh, ww, c, x_rows, x_cols,
+                                         _io_dtype(x), _stream(x.device))
     _check(rc, "gdkvm_bias_relu_maxpool")
+    return out
+
+
+def stem_s2d(x: torch.Tensor, cpad: int) -> torch.Tensor:
+    """Space-to-depth of NCHW frames for the stem: [N,C,H,W] contiguous -> channels_last [N,cpad,H/2,W/2] with channel
+    (c*2+p)*2+q = x[c, 2i+p, 2j+q] and zeros above 4C (gdkvm_stem_s2d)."""
+    lib = load()
+    if x.dim() != 4 or not x.is_cuda or not x.is_contiguous():
+        raise GdkvmError("stem_s2d needs a contiguous NCHW device tensor")
+    n, c, hh, ww = x.shape
+    out = torch.empty((n, cpad, hh // 2, ww // 2), device=x.device, dtype=x.dtype, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = lib.gdkvm_stem_s2d(x.data_ptr(), out.data_ptr(), n, c, hh, ww, cpad, _io_dtype(x), _stream(x.device))
+    _check(rc, "gdkvm_stem_s2d")
     return out
 
 

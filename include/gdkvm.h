@@ -171,8 +171,15 @@ int gdkvm_bias_act(const void* x, const float* bias, const void* residual, void*
 
 /* Row n1, the stem: bias + ReLU + 3x3 / stride 2 / pad 1 max-pool in one pass over the NHWC conv output
  * x [N, H, W, C] -> y [N, (H-1)/2+1, (W-1)/2+1, C]:  y = relu(max_window(x) + bias)  (== max_window(relu(x + bias)), the
- * rounding of x + b being monotonic).  The full-resolution activation is read once and never written back. */
-int gdkvm_bias_relu_maxpool(const void* x, const float* bias, void* y, int N, int H, int W, int C, int io_dtype, void* stream);
+ * rounding of x + b being monotonic).  The full-resolution activation is read once and never written back.  x may be the
+ * top-left H x W corner of a larger stored image of x_rows x x_cols pixels (x_rows >= H, x_cols >= W). */
+int gdkvm_bias_relu_maxpool(const void* x, const float* bias, void* y, int N, int H, int W, int C,
+                            int x_rows, int x_cols, int io_dtype, void* stream);
+
+/* Row n1, the stem input: NCHW frames x [N, C, H, W] (H, W even) -> the space-to-depth image out [N, H/2, W/2, Cp] (NHWC),
+ * out[n, i, j, (c*2 + p)*2 + q] = x[n, c, 2i + p, 2j + q], channels 4C .. Cp-1 zero.  A k x k / stride 2 convolution on x is
+ * a ceil(k/2)+... x stride 1 convolution on out (gdkvm_amd/model.py::FusedConvPool builds the 4x4 kernel of a 7x7 stem). */
+int gdkvm_stem_s2d(const void* x, void* out, int N, int C, int H, int W, int Cp, int io_dtype, void* stream);
 
 /* SURVEY.md §8(f) row n1 (inference build only): decoder glue, out = concat(bilinear_upsample(lo -> H x W), skip) over
  * NHWC tensors  lo [N,hl,wl,C1], skip [N,H,W,C2], out [N,H,W,C1+C2]; align_corners = false; bf16 only. */

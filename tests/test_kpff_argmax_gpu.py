@@ -135,3 +135,37 @@ def test_bias_relu_maxpool(hip, dtype, shape):
     want = F.max_pool2d(F.relu(x.float() + b.reshape(1, -1, 1, 1)).to(dtype).float(), 3, 2, 1).to(dtype)
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got, want)
+
+
+def test_bias_relu_maxpool_on_a_cropped_view(hip):
+    """The stem's space-to-depth convolution returns one row and column too many: the pool reads the top-left corner."""
+    g = torch.Generator().manual_seed(3)
+    big = torch.randn(2, 16, 9, 11, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(16, generator=g).cuda()
+    x = big[:, :, :8, :10]
+    got = hip.bias_relu_maxpool(x, b)
+    want = F.max_pool2d(F.relu(x.float() + b.reshape(1, -1, 1, 1)).bfloat16().float(), 3, 2, 1).bfloat16()
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_stem_s2d_and_its_convolution(hip, dtype):
+    """gdkvm_stem_s2d == pixel_unshuffle (+ zero channels), and the 4x4 space-to-depth kernel FusedConvPool builds reproduces the
+    7x7 / stride 2 / pad 3 convolution."""
+    from gdkvm_amd.model import FusedConv, FusedConvPool
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 3, 20, 24, generator=g).to(dtype).cuda()
+    xs = hip.stem_s2d(x, 16)
+    want = torch.zeros(3, 16, 10, 12, dtype=dtype, device="cuda")
+    want[:, :12] = F.pixel_unshuffle(x, 2)
+    assert xs.is_contiguous(memory_format=torch.channels_last) and torch.equal(xs, want)
+    conv = torch.nn.Conv2d(3, 8, 7, 2, 3, bias=True)
+    torch.nn.init.normal_(conv.weight, std=0.1, generator=g)
+    fc = FusedConvPool.__new__(FusedConvPool)
+    torch.nn.Module.__init__(fc)
+    base = FusedConv(conv, True)
+    fc.conv, fc.epi, fc.relu = base.conv, base.epi, True
+    fc = fc.enable_s2d().cuda()
+    y7 = F.conv2d(x.float(), conv.weight.cuda().float(), None, 2, 3)
+    y4 = F.conv2d(xs.float(), fc.w_s2d.float(), None, 1, 2)[:, :, :10, :12]
+    assert (y7 - y4).abs().max().item() <= 1e-4 * max(1.0, y7.abs().max().item())
