@@ -165,6 +165,19 @@ __global__ __launch_bounds__(256) void stem_s2d_kernel(const void* x, void* out,
         const size_t r = i / Wo;
         const int ih = (int)(r % Ho), n = (int)(r / Ho);
         T* dst = o + i * Cp;
+        if constexpr (IO == GDKVM_BF16) {
+            if (Cp == 16 && C <= 4) {                      // the stem's case: six 4-byte loads, two 16-byte stores per pixel
+                unsigned pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // channel pairs (c, p): [x(2i+p, 2j), x(2i+p, 2j+1)]
+                for (int c = 0; c < C; ++c) {
+                    const bf16_t* src = xi + (((size_t)n * C + c) * H + 2 * ih) * W + 2 * j;
+                    pr[2 * c] = *reinterpret_cast<const unsigned*>(src);
+                    pr[2 * c + 1] = *reinterpret_cast<const unsigned*>(src + W);
+                }
+                reinterpret_cast<uint4*>(dst)[0] = make_uint4(pr[0], pr[1], pr[2], pr[3]);
+                reinterpret_cast<uint4*>(dst)[1] = make_uint4(pr[4], pr[5], pr[6], pr[7]);
+                continue;
+            }
+        }
         for (int c = 0; c < C; ++c) {
             const T* src = xi + (((size_t)n * C + c) * H + 2 * ih) * W + 2 * j;
             dst[4 * c + 0] = src[0]; dst[4 * c + 1] = src[1]; dst[4 * c + 2] = src[W]; dst[4 * c + 3] = src[W + 1];
