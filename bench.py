@@ -101,7 +101,7 @@ def bench_train(args, world, rank, dev):
             dist.barrier()
         torch.cuda.synchronize()
 
-    loss = None
+    loss = train_step(ddp, opt, frames, target, torch.bfloat16)      # set-up: MIOpen's solver search (find mode), not a step
     for _ in range(args.warmup):
         loss = train_step(ddp, opt, frames, target, torch.bfloat16)
     barrier()
@@ -185,7 +185,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    step()                                                  # set-up, not a step: MIOpen's solver search for these shapes (find
+    for _ in range(args.warmup):                            # mode) runs on the first call of every convolution
         step()
     barrier()
     t0 = time.perf_counter()
