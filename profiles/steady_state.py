@@ -2,7 +2,9 @@
 """Per-step kernel table of the STEADY STATE of a profiled bench run, from rocprofv3's kernel_trace.csv: MIOpen's find
 mode runs trial and reference kernels (naive_conv, 36 ms each) during warm-up, which swamp the --stats summary; this takes
 the last K forward steps (a step ends with upsample_argmax_dice_kernel) and averages over them.
-usage: python profiles/steady_state.py <kernel_trace.csv> <out.csv> "<command line that was profiled>" [K=10]"""
+usage: python profiles/steady_state.py <kernel_trace.csv> <out.csv> "<command line that was profiled>" [K=10] [end-marker]
+end-marker: substring of the kernel that ends a step (default upsample_argmax_dice; training: multi_tensor = the fused AdamW
+kernels; runs of marker kernels closer than 50 dispatches count as one step end)."""
 import collections
 import csv
 import sys
@@ -13,10 +15,16 @@ from summarize import short
 def main():
     src, dst, cmd = sys.argv[1:4]
     K = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+    marker = sys.argv[5] if len(sys.argv) > 5 else "upsample_argmax_dice"
     rows = sorted(csv.DictReader(open(src)), key=lambda r: int(r["Start_Timestamp"]))
-    ends = [i for i, r in enumerate(rows) if "upsample_argmax_dice" in r["Kernel_Name"]]
-    # the bench's roofline timing launches come after the timed steps: the last forward step is the last one that is
-    # preceded by a convolution within the same step
+    ends = []
+    for i, r in enumerate(rows):
+        if marker in r["Kernel_Name"]:
+            if ends and i - ends[-1] <= 50:
+                ends[-1] = i
+            else:
+                ends.append(i)
+    # the bench's roofline timing launches come after the timed steps: a forward step contains convolutions
     steps = [(ends[i - 1] + 1, ends[i] + 1) for i in range(1, len(ends))
              if any("conv" in r["Kernel_Name"] or "igemm" in r["Kernel_Name"] for r in rows[ends[i - 1] + 1:ends[i] + 1])]
     steps = steps[-K:]
