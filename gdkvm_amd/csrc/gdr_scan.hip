@@ -12,6 +12,7 @@
 //  gdr_affine_scan_kernel  the serial recurrence: one workgroup per (clip, head, 16-column slice of Dv), 12 waves in
 //                          three roles (state / read-out / LDS-DMA loader), one barrier per frame.  Also the backward's
 //                          reverse recurrence (reverse mode) and the state-transition matrix (transition mode).
+//  gdr_readout_kernel      frames of more than 64 tokens: the LKVA read-out, frame-parallel, from state images the serial kernel dumps.
 //  gdr_bwd_g_kernel        backward: Gb = Qn^T dR per frame, the additive term of the reverse recurrence.
 // Products that dominate a kernel run on v_mfma_f32_16x16x32_bf16 with fp32 operands carried as three bf16 terms
 // (split3, below); everything else is exact fp32 on v_mfma_f32_16x16x4_f32.  Workspace layout: gdr_ws.hpp.
@@ -942,6 +943,7 @@ struct AffArgs {
     int init_identity, zero_g;                       // transition mode: S_0 = I, and gg is ONE zero tile (all strides 0)
     int T, Hh, N, Dv, flags, BH;
     int reverse;                                     // visit the frames last to first (the backward's reverse recurrence)
+    float* simg;                                     // DEFER: per-frame operand images of the state for gdr_readout_kernel
 #ifdef GDKVM_DIAG
     unsigned long long* diag;
 #endif
@@ -962,10 +964,13 @@ __host__ __device__ constexpr size_t aff_lds_bytes(int IO)
 
 __device__ __forceinline__ void aff_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int IO, int NB, bool SAVE>
+// DEFER (frames of more than 64 tokens): every slice workgroup would re-read the whole frame's q -- 32 KB at 256 tokens, and the
+// CU's vector-memory path saturates (1.35 us per frame) -- so the read waves only dump the state's operand images (4 KB per
+// frame and slice) and gdr_readout_kernel does the read-out frame-parallel, reading q once per frame.
+template <int IO, bool DEFER, bool SAVE>
 __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
 {
-    constexpr int NP = 16 * NB, JT = NB / 4, NBUF = (JT > 1 && IO == GDKVM_BF16) ? 8 : 4, DEPTH = NBUF - 1, UFR = NBUF / JT;
+    constexpr int NB = 4, NP = 16 * NB, JT = 1, NBUF = 4, DEPTH = NBUF - 1, UFR = NBUF / JT;
     constexpr int NS = aff_slots(IO), D = NS - 1;
     extern __shared__ __attribute__((aligned(16))) f32x4 aff_smem[];
     uint2* s_S3 = reinterpret_cast<uint2*>(aff_smem);      // [parity][term] images of SPLIT_IMG uint2: B operand of the bf16 MFMA
@@ -1047,6 +1052,20 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
 
     if (role == 1) {
         // ------------------------------------------------------------------------------ read-out waves
+        if constexpr (DEFER) {                             // dump the images of S_{t-1}: 1 KiB per read wave and frame
+            uint4* dst = reinterpret_cast<uint4*>(a.simg) + ((fh0 * nsl + sl) * 4 + w) * 64 + lane;
+            const size_t d_fstride = (size_t)Hh * nsl * 4 * 64;
+            aff_barrier();
+            for (int t = 0; t < T; ++t) {
+                const int par = t & 1;
+                uint4 img;
+                if constexpr (IO == GDKVM_F32) img = *reinterpret_cast<const uint4*>(&s_Sf[par * 256 + w * 64 + lane]);
+                else img = *reinterpret_cast<const uint4*>(&s_S3[(par * 3 + (w >> 1)) * SPLIT_IMG + ((w & 1) * 64 + lane) * 2]);
+                dst[(size_t)(a.reverse ? T - 1 - t : t) * d_fstride] = img;
+                aff_barrier();
+            }
+            return;
+        }
         if (!a.r_out) {                                    // states only (transition matrices, segment end states): just keep the
             aff_barrier();                                 // barrier count
             for (int t = 0; t < T; ++t) aff_barrier();
@@ -1217,28 +1236,102 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
     }
 }
 
-template <int IO, int NB, bool SV>
+template <int IO, bool DEFER, bool SV>
 int launch_affine(const AffArgs& sa, dim3 grid, hipStream_t st)
 {
     static bool attr_set = false;                         // > 64 KiB of dynamic LDS needs the opt-in once per kernel
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_affine_scan_kernel<IO, NB, SV>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_affine_scan_kernel<IO, DEFER, SV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)aff_lds_bytes(IO));
         if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_affine_scan: LDS attribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, NB, SV>), grid, dim3(768), aff_lds_bytes(IO), st, sa);
+    hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, DEFER, SV>), grid, dim3(768), aff_lds_bytes(IO), st, sa);
     GDKVM_LAUNCH_CHECK("gdr_affine_scan_kernel");
     return GDKVM_OK;
 }
 
-template <int IO, bool SV>
-int launch_affine_nb(int nb, const AffArgs& sa, dim3 grid, hipStream_t st)
+template <int IO>
+int launch_affine_any(bool defer, bool save, const AffArgs& sa, dim3 grid, hipStream_t st)
 {
-    switch (nb) {
-        case 4: return launch_affine<IO, 4, SV>(sa, grid, st);
-        case 8: return launch_affine<IO, 8, SV>(sa, grid, st);
-        default: return launch_affine<IO, 16, SV>(sa, grid, st);
+    if (defer) return save ? launch_affine<IO, true, true>(sa, grid, st) : launch_affine<IO, true, false>(sa, grid, st);
+    return save ? launch_affine<IO, false, true>(sa, grid, st) : launch_affine<IO, false, false>(sa, grid, st);
+}
+
+// gdr_readout_kernel -- LKVA read-out for frames of more than 64 tokens, frame-parallel: R_t = (Qn_t S_{t-1}) from the operand
+// images the serial kernel dumped.  One workgroup per (frame-head, 8 column tiles); a wave keeps the images of its two column
+// tiles in registers and walks the frame's token tiles, so q is read once per workgroup and nothing goes through LDS.  Same
+// arithmetic and operation order as the in-scan read-out (R^T = S^T Qn^T: h + m terms on the bf16 MFMA, or exact fp32).
+struct ReadoutArgs { const void* q; const float* qinv; const float* simg; void* r_out; int Hh, N, Dv, NP; };
+
+template <int IO>
+__global__ __launch_bounds__(256) void gdr_readout_kernel(ReadoutArgs a)
+{
+    constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t fh = blockIdx.x;
+    const int h = (int)(fh % a.Hh), N = a.N, Dv = a.Dv, nsl = Dv / 16;
+    const size_t bt = fh / a.Hh;
+    const int c0 = (blockIdx.y * 4 + w) * 2;
+    if (c0 >= nsl) return;
+    const bool two = c0 + 1 < nsl;
+    const uint4* img = reinterpret_cast<const uint4*>(a.simg) + (fh * nsl + c0) * 4 * 64 + lane;
+    uint4 sb[2][4];                                        // [col tile][bf16: term*2 + ks | fp32: k tile m]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sb[c][i] = img[((c && two) ? 4 * 64 : 0) + i * 64];
+    const char* qbase = static_cast<const char*>(a.q) + ((bt * N * a.Hh + h) * GDKVM_DK) * ESZ;
+    const float* qinv = a.qinv + fh * a.NP;
+    char* rbase = static_cast<char*>(a.r_out) + ((bt * N * a.Hh + h) * (size_t)Dv + 16 * c0 + 4 * g) * ESZ;
+    const size_t rowq = (size_t)a.Hh * GDKVM_DK * ESZ, rowr = (size_t)a.Hh * Dv * ESZ;
+    const int ntt = (N + 15) / 16;
+    struct QT { uint4 q[IO == GDKVM_F32 ? 4 : 2]; float qi; };
+    auto load_q = [&](int tt, QT& d) __attribute__((always_inline)) {
+        const int nq = min(16 * min(tt, ntt - 1) + li, N - 1);
+        const char* p = qbase + (size_t)nq * rowq + 16 * g;
+#pragma unroll
+        for (int i = 0; i < (IO == GDKVM_F32 ? 4 : 2); ++i) d.q[i] = *reinterpret_cast<const uint4*>(p + 64 * i);
+        d.qi = qinv[min(16 * min(tt, ntt - 1) + li, a.NP - 1)];
+    };
+    auto tile = [&](int tt, const QT& d) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (IO == GDKVM_F32) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const f32x4 sm = __builtin_bit_cast(f32x4, sb[c][m]), qm = __builtin_bit_cast(f32x4, d.q[m]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (m & 1) acc1 = mfma4(sm[r], qm[r], acc1);
+                        else acc0 = mfma4(sm[r], qm[r], acc0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, sb[c][2 + ks]), __builtin_bit_cast(bf16x8, d.q[ks]), acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, sb[c][ks]), __builtin_bit_cast(bf16x8, d.q[ks]), acc1, 0, 0, 0);
+                }
+            }
+            const f32x4 accR = (acc0 + acc1) * d.qi;
+            const int nr = 16 * tt + li;
+            if (nr < N && (c == 0 || two)) {
+                char* p = rbase + (size_t)nr * rowr + c * 16 * ESZ;
+                if constexpr (IO == GDKVM_F32) *reinterpret_cast<f32x4*>(p) = accR;
+                else *reinterpret_cast<uint2*>(p) = make_uint2(cvt_pk_bf16(accR[0], accR[1]), cvt_pk_bf16(accR[2], accR[3]));
+            }
+        }
+    };
+    QT qa, qb;
+    load_q(0, qa);
+    for (int tt = 0; tt < ntt; tt += 2) {
+        load_q(tt + 1, qb);
+        tile(tt, qa);
+        load_q(tt + 2, qa);
+        if (tt + 1 < ntt) tile(tt + 1, qb);
     }
 }
 
@@ -1337,13 +1430,22 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
         }
         return GDKVM_OK;
     }
-    AffArgs sa{q, alpha, s_in, ws.pp, ws.gg, ws.qinv, r_out, s_out, s_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 0};
+    const bool defer = ws.nb > 4 && r_out != nullptr;     // > 64 tokens per frame: read-out by its own frame-parallel kernel
+    AffArgs sa{q, alpha, s_in, ws.pp, ws.gg, ws.qinv, defer ? nullptr : r_out, s_out, s_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 0, ws.simg};
 #ifdef GDKVM_DIAG
     sa.diag = g_diag_buf;
 #endif
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
-    if (io_dtype == GDKVM_F32) return s_hist ? launch_affine_nb<GDKVM_F32, true>(ws.nb, sa, grid, st) : launch_affine_nb<GDKVM_F32, false>(ws.nb, sa, grid, st);
-    return s_hist ? launch_affine_nb<GDKVM_BF16, true>(ws.nb, sa, grid, st) : launch_affine_nb<GDKVM_BF16, false>(ws.nb, sa, grid, st);
+    if (int rc = io_dtype == GDKVM_F32 ? launch_affine_any<GDKVM_F32>(defer, s_hist != nullptr, sa, grid, st)
+                                       : launch_affine_any<GDKVM_BF16>(defer, s_hist != nullptr, sa, grid, st)) return rc;
+    if (defer) {
+        ReadoutArgs ra{q, ws.qinv, ws.simg, r_out, Hh, N, Dv, 16 * ws.nb};
+        const dim3 rgrid((unsigned)(B * T * Hh), (unsigned)((Dv / 16 + 7) / 8));
+        if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32>), rgrid, dim3(256), 0, st, ra);
+        else hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16>), rgrid, dim3(256), 0, st, ra);
+        GDKVM_LAUNCH_CHECK("gdr_readout_kernel");
+    }
+    return GDKVM_OK;
 }
 
 extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* phi_out, const void* workspace, size_t workspace_bytes,
@@ -1360,12 +1462,12 @@ extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* p
     // the recurrence on Dk columns from S = I with G = 0 and no read-out:  Phi = prod_t a_t P_t
     hipError_t e = hipMemsetAsync(ws.zero, 0, 64 * 4 * sizeof(float), st);       // the one G tile every frame and slice reads
     if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_transition: memset: %s", hipGetErrorString(e));
-    AffArgs sa{q, alpha, nullptr, ws.pp, ws.zero, ws.qinv, nullptr, phi_out, nullptr, ws.trash, 1, 1, T, Hh, N, GDKVM_DK, flags, B * Hh, 0};
+    AffArgs sa{q, alpha, nullptr, ws.pp, ws.zero, ws.qinv, nullptr, phi_out, nullptr, ws.trash, 1, 1, T, Hh, N, GDKVM_DK, flags, B * Hh, 0, nullptr};
 #ifdef GDKVM_DIAG
     sa.diag = nullptr;
 #endif
     const dim3 grid((unsigned)(B * Hh * (GDKVM_DK / 16)));
-    return io_dtype == GDKVM_F32 ? launch_affine_nb<GDKVM_F32, false>(ws.nb, sa, grid, st) : launch_affine_nb<GDKVM_BF16, false>(ws.nb, sa, grid, st);
+    return io_dtype == GDKVM_F32 ? launch_affine<GDKVM_F32, false, false>(sa, grid, st) : launch_affine<GDKVM_BF16, false, false>(sa, grid, st);
 }
 
 extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
@@ -1423,10 +1525,10 @@ int gdr_launch_reverse_scan(const WsView& ws, const float* alpha, const void* d_
     if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_bwd_g_kernel<GDKVM_F32>), ggrid, dim3(256), 0, st, ga);
     else hipLaunchKernelGGL((gdr_bwd_g_kernel<GDKVM_BF16>), ggrid, dim3(256), 0, st, ga);
     GDKVM_LAUNCH_CHECK("gdr_bwd_g_kernel");
-    AffArgs sa{nullptr, alpha, ds_out, ws.ppt, gb, nullptr, nullptr, ds_in, ds_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 1};
+    AffArgs sa{nullptr, alpha, ds_out, ws.ppt, gb, nullptr, nullptr, ds_in, ds_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 1, nullptr};
 #ifdef GDKVM_DIAG
     sa.diag = nullptr;
 #endif
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
-    return io_dtype == GDKVM_F32 ? launch_affine<GDKVM_F32, 4, true>(sa, grid, st) : launch_affine<GDKVM_BF16, 4, true>(sa, grid, st);
+    return io_dtype == GDKVM_F32 ? launch_affine<GDKVM_F32, false, true>(sa, grid, st) : launch_affine<GDKVM_BF16, false, true>(sa, grid, st);
 }

@@ -19,16 +19,18 @@ static inline int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
 //   frames of more than 64 tokens are folded in chunks of 64 tokens whose affine maps are then composed (nchunk = NP/64):
 //     x0  [4 + Dv/16][4][64][4]  chunk 0 as accumulator images of [P | G]
 //     ppc [nchunk-1] x pp, ggc [nchunk-1] x gg  for chunks 1..
+//     simg [Dv/16][4][64][4]  the state before the frame as MFMA operand images (per slice: the h and m bf16 term images, or the
+//          fp32 accumulator images), dumped by the serial kernel for the frame-parallel read-out kernel
 struct WsView {
     float* wt; float* knT; float* ut; float* qinv; float* kn; float* wtT; float* qnT; float* tii; float* wti; float* ppt;
-    float* pp; float* gg; float* x0; float* ppc; float* ggc; float* zero; char* trash; int nb; int nchunk;
+    float* pp; float* gg; float* x0; float* ppc; float* ggc; float* simg; float* zero; char* trash; int nb; int nchunk;
 };
 
 static inline size_t gdr_ws_floats_per_fh(int N, int Dk, int Dv)
 {
     const size_t NP = 16 * (size_t)tiles_for(N), NL = NP < 64 ? NP : 64, C = (NP + 63) / 64;
     const size_t pg = (size_t)Dk * Dk * 3 / 2 + (size_t)Dk * Dv;
-    return NL * (6 * (size_t)Dk + Dv + 16) + (size_t)Dk * Dk * 3 / 2 + NP + pg + (C > 1 ? (size_t)Dk * (Dk + Dv) + (C - 1) * pg : 0);
+    return NL * (6 * (size_t)Dk + Dv + 16) + (size_t)Dk * Dk * 3 / 2 + NP + pg + (C > 1 ? (size_t)Dk * (Dk + Dv) + (C - 1) * pg + (size_t)Dk * Dv : 0);
 }
 
 static inline size_t gdr_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
@@ -59,9 +61,10 @@ static inline int carve(const char* fn, void* workspace, size_t workspace_bytes,
     v->qinv = p;  p += FH * NP;
     v->pp = p;    p += FH * ppf;
     v->gg = p;    p += FH * ggf;
-    v->x0 = p;    p += v->nchunk > 1 ? FH * (size_t)GDKVM_DK * (GDKVM_DK + Dv) : 0;
-    v->ppc = p;   p += v->nchunk > 1 ? FH * (v->nchunk - 1) * ppf : 0;
-    v->ggc = p;   p += v->nchunk > 1 ? FH * (v->nchunk - 1) * ggf : 0;
+    v->x0 = p;    p += NP > 64 ? FH * (size_t)GDKVM_DK * (GDKVM_DK + Dv) : 0;      // (sized for NP / 64 chunks, the upper bound)
+    v->ppc = p;   p += NP > 64 ? FH * (NP / 64 - 1) * ppf : 0;
+    v->ggc = p;   p += NP > 64 ? FH * (NP / 64 - 1) * ggf : 0;
+    v->simg = p;  p += NP > 64 ? FH * ggf : 0;
     v->zero = p;                                         // 256 floats, zeroed by gdkvm_scan_transition
     v->trash = reinterpret_cast<char*>(v->zero + 256);   // write-only slot for read-out rows of padding tokens
     return GDKVM_OK;
