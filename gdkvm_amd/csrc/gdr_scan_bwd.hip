@@ -72,11 +72,6 @@ __device__ __forceinline__ float row16_sum(float x)        // sum over the 16 la
     x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
     return x;
 }
-__device__ __forceinline__ float quad_sum(float x)         // sum over 4 adjacent lanes
-{
-    x += __shfl_xor(x, 1); x += __shfl_xor(x, 2);
-    return x;
-}
 
 // One workgroup (4 waves) per (clip, frame, head).  Wave w owns the 16 x 64 row band w of every 64 x 64 result as four
 // accumulator tiles: element (reg r of tile nt, lane (li, g)) = [row 16w + 4g + r][col 16nt + li].

@@ -493,7 +493,7 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
         const int total_tiles = BT * tiles;
         const bool pair = 2 * lds1 <= 160 * 1024 && total_tiles >= 2;     // two 64-token tiles per 8-wave workgroup
         bf16_t* wab = static_cast<bf16_t*>(workspace);
-        const size_t na = (size_t)2 * Cp * Cin, nl = (size_t)Cp * Ck, ng = (size_t)Cp * Cv;
+        const size_t na = (size_t)2 * Cp * Cin, nl = (size_t)Cp * Ck;
         if (!g_kpff_skip_pack) {
             hipLaunchKernelGGL(kpff_pack_weights_kernel, dim3(256), dim3(256), 0, st, wa, wl, wg, wab, Cp, Ck, Cv);
             GDKVM_LAUNCH_CHECK("kpff_pack_weights_kernel");
