@@ -176,3 +176,25 @@ def test_scan_cfg2_full_size_properties(hip):
         assert np.abs(S[c:c + 1].cpu().numpy() - So).max() <= TOL
         Rg = R[c:c + 1].float().cpu().numpy()
         assert np.all(np.abs(Rg - Ro) <= TOL + np.abs(Ro) * 2.0 ** -8)
+
+
+def test_scan_randomized_sweep(hip):
+    """60 random (shape, rule, flags, dtype, carried state) cases against the fp64 oracle -- the short form of
+    tools/stress_scan.py.  delta_parallel is not contractive, so errors are judged relative to the magnitude reached."""
+    rng = np.random.default_rng(11)
+    for i in range(60):
+        B, T, Hh = int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(1, 3))
+        N = int(rng.choice([1, 7, 16, 17, 49, 63, 64, 65, 100, 128, 130, 196, 256]))
+        Dv = int(rng.choice([16, 32, 48, 64])) if N > 64 else int(rng.choice([16, 32, 48, 64, 256]))
+        rule, flags, bf, with_state = int(rng.integers(0, 3)), int(rng.choice([0, 3])), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        q, k, v, a, b = make_scan_inputs(B, T, N, Hh, 64, Dv, seed=int(rng.integers(1 << 30)), normalized=not flags,
+                                         logits=bool(flags), corr=float(rng.uniform(0, 0.9)))
+        if bf:
+            q, k, v = (O.to_bf16_f32(x) for x in (q, k, v))
+        s0 = (rng.standard_normal((B, Hh, 64, Dv)) * 0.3).astype(np.float32) if with_state else None
+        Rg, Sg = _run(hip, q, k, v, a, b, s0, rule, flags, dtype=torch.bfloat16 if bf else torch.float32)
+        Ro, So = c_oracle.scan(q, k, v, a, b, s0, rule, flags, math="f64")
+        scale = max(1.0, float(np.abs(So).max()), float(np.abs(Ro).max()))
+        case = (i, B, T, N, Hh, Dv, rule, flags, bf, with_state)
+        assert np.abs(Sg - So).max() <= TOL * scale, case
+        assert np.all(np.abs(Rg - Ro) <= TOL * scale + (np.abs(Ro) * 2.0 ** -8 if bf else 0)), case
