@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void upsample_cat_bf16_kernel(const bf16_t* lo
 {
     const int C = C1 + C2, c1n = C1 / 8, c2n = C2 / 8, n1 = W * c1n, n2 = W * c2n, tid = threadIdx.x;
     constexpr int MAXV = 2;                                // interpolated vectors per thread per trip (W*C1/8 <= 512 in one trip)
+    const bool exact2x = H == 2 * hl && W == 2 * wl;
     for (int row = blockIdx.x; row < Nimg * H; row += gridDim.x) {
         const int n = row / H, y = row - n * H;
         const float fy = fmaxf(sy * ((float)y + 0.5f) - 0.5f, 0.f);
@@ -249,6 +250,35 @@ __global__ __launch_bounds__(256) void upsample_cat_bf16_kernel(const bf16_t* lo
         uint4 cp[MAXV];                                    // this thread's first copy vectors, in flight behind the taps
 #pragma unroll
         for (int u = 0; u < MAXV; ++u) cp[u] = *reinterpret_cast<const uint4*>(sk + min(u * 256 + tid, n2 - 1) * 8);
+        if (exact2x) {
+            // exactly 2x: output columns 2jp+1 and 2jp+2 share the horizontal taps jp and jp+1 (weights 1/4 and 3/4), so a
+            // thread owns one such pair per trip -- four tap loads for two outputs; jp = -1 and jp = wl-1 are the borders
+            const int nu = (wl + 1) * c1n;
+            for (int u0 = 0; u0 < nu; u0 += 256) {
+                const int u = min(u0 + tid, nu - 1);
+                const int jq = u / c1n, c = (u - jq * c1n) * 8, jp = jq - 1;
+                const int x0 = max(jp, 0), x1 = min(jp + 1, wl - 1);
+                const uint4 t00 = *reinterpret_cast<const uint4*>(lo0 + x0 * C1 + c), t01 = *reinterpret_cast<const uint4*>(lo0 + x1 * C1 + c);
+                const uint4 t10 = *reinterpret_cast<const uint4*>(lo1 + x0 * C1 + c), t11 = *reinterpret_cast<const uint4*>(lo1 + x1 * C1 + c);
+                if (u0 + tid >= nu) continue;
+                float a[8], b[8], cc[8], d[8];
+                unpack8(t00, a); unpack8(t01, b); unpack8(t10, cc); unpack8(t11, d);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int x = 2 * jp + 1 + e;
+                    if (x < 0 || x >= W) continue;
+                    const float lx = e ? 0.75f : 0.25f, hx = 1.f - lx;
+                    unsigned r[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v0 = hy * (hx * a[2 * q] + lx * b[2 * q]) + ly * (hx * cc[2 * q] + lx * d[2 * q]);
+                        const float v1 = hy * (hx * a[2 * q + 1] + lx * b[2 * q + 1]) + ly * (hx * cc[2 * q + 1] + lx * d[2 * q + 1]);
+                        r[q] = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
+                    }
+                    *reinterpret_cast<uint4*>(orow + x * C + c) = make_uint4(r[0], r[1], r[2], r[3]);
+                }
+            }
+        } else
         for (int j0 = 0; j0 < n1; j0 += MAXV * 256) {
             uint4 t[MAXV][4];
             float lx[MAXV];
