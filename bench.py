@@ -67,6 +67,21 @@ def committed_traffic():
     return (int(total) if total else None), os.path.relpath(files[-1], ROOT)
 
 
+def committed_mfma_busy():
+    """MFMA-pipe busy fraction of the scan pair from the newest committed SQ counter summary (profiles/*_pmc_sq.csv,
+    profiles/pmc_sq_summary.py): SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), both kernels together."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_sq.csv")))
+    if not files:
+        return None, None
+    busy = cyc = 0.0
+    for row in csv.DictReader(l for l in open(files[-1]) if not l.startswith("#")):
+        if row["Kernel"].startswith(("gdr_prepm_kernel", "gdr_affine_scan_kernel", "gdr_compose_kernel")):
+            busy += float(row["SQ_VALU_MFMA_BUSY_CYCLES"]); cyc += float(row["kernel_cycles"])
+    return (round(busy / (cyc * 1024), 4) if cyc else None), os.path.relpath(files[-1], ROOT)
+
+
 def time_events(fn, iters, warmup=3):
     for _ in range(warmup):
         fn()
@@ -227,9 +242,11 @@ def main():
         alg = scan_algorithmic_bytes(B, T, N, Hh, Dk, Dv, 2)
         achieved = alg / (both_ms * 1e-3) / 1e9
         traffic, traffic_src = committed_traffic() if (B, T, S) == (16, 32, 112) else (None, None)
+        mfma_busy, mfma_src = committed_mfma_busy() if (B, T, S) == (16, 32, 112) else (None, None)
         out["roofline"] = {"kernel": "gdr_prepm_kernel+gdr_affine_scan_kernel (one gdkvm_scan_fwd)", "bound": "hbm",
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                           "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src,
                            "algorithmic_bytes": alg, "avg_ms": {"gdr_prepm_kernel": round(prep_ms, 4),
                                                                 "gdr_affine_scan_kernel": round(scan_ms, 4),
                                                                 "scan_fwd_total": round(both_ms, 4)}}

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Per-kernel MFMA-busy and wave-state fractions from one rocprofv3 SQ counter pass
+(--pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE).
+usage: python profiles/pmc_sq_summary.py <counter_collection.csv> <out.csv> "<cmd>"
+mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter is
+summed over the 8 XCDs; MI355X_MICROARCH.md, DVFS note).  SQ_VALU_MFMA_BUSY_CYCLES counts pipe cycles: 16 per
+v_mfma_f32_16x16x32_bf16, 32 per v_mfma_f32_16x16x4_f32.  The wave-state columns are shares of SQ_WAVE_CYCLES."""
+import collections
+import csv
+import re
+import sys
+
+from summarize import short
+
+
+def main():
+    src, dst, cmd = sys.argv[1:4]
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(src)):
+        d[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    with open(dst, "w") as f:
+        f.write(f"# {cmd}\n# per-launch means\n")
+        f.write("Kernel,launches,kernel_cycles,SQ_VALU_MFMA_BUSY_CYCLES,mfma_busy_frac,wait_any_share,wait_inst_share,active_inst_share\n")
+        for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", [0]))):
+            if not re.search(r"gdr_|kpff|argmax", k):
+                continue
+            m = {c: sum(x) / len(x) for c, x in v.items()}
+            cyc = m["GRBM_GUI_ACTIVE"] / 8
+            wc = m["SQ_WAVE_CYCLES"] or 1.0
+            f.write(f"{k},{len(v['GRBM_GUI_ACTIVE'])},{cyc:.0f},{m['SQ_VALU_MFMA_BUSY_CYCLES']:.0f},"
+                    f"{m['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024):.4f},{m['SQ_WAIT_ANY'] / wc:.3f},"
+                    f"{m['SQ_WAIT_INST_ANY'] / wc:.3f},{m['SQ_ACTIVE_INST_ANY'] / wc:.3f}\n")
+
+
+if __name__ == "__main__":
+    main()
