@@ -211,7 +211,8 @@ def scan(q, k, v, alpha, beta, state=None, rule: int = RULE_DELTA_SEQUENTIAL, fl
 
 
 def scan_prep(q, k, v, beta, workspace, rule=RULE_DELTA_SEQUENTIAL, flags=0):
-    """Stage 1 of scan_fwd alone (gdkvm_scan_prep): fills ``workspace`` with the per-frame WY factors."""
+    """Stage 1 of scan_fwd alone (gdkvm_scan_prep): folds every frame into its affine map S' = a P S + G in ``workspace``
+    (with FLAG_TRAIN also the WY factors the backward consumes)."""
     B, T, N, Hh, Dk = k.shape
     Dv = v.shape[-1]
     dev = _dev(q, k, v, beta, workspace)
