@@ -139,6 +139,8 @@ class FusedConv(nn.Module):
 
     def forward(self, x, residual=None):
         y = self.conv(x)
+        if getattr(self, "bias_folded_downstream", False):  # the bias was added to the consumer's epilogue bias: nothing to do here
+            return y
         if not y.is_cuda:                                  # CPU reference module (oracle/model_ref.py): plain torch
             y = y + self.epi.bias.to(y.dtype).reshape(1, -1, 1, 1)
             y = y if residual is None else y + residual
@@ -347,6 +349,11 @@ class GDKVM(nn.Module):
                 m.conv2, m.bn2 = FusedConv(_fold_bn(m.conv2, m.bn2), True), nn.Identity()   # + residual, then ReLU
                 if m.down is not None:
                     m.down = fuse_seq(m.down)
+                    d = m.down[0]
+                    if len(m.down) == 1 and isinstance(d, FusedConv) and not d.relu:
+                        # out = relu(conv2(.) + b2 + (down(x) + bd)): one bias, one epilogue pass instead of two
+                        m.conv2.epi.bias.data += d.epi.bias.data
+                        d.bias_folded_downstream = True
             elif isinstance(m, UpBlock):
                 m.conv = fuse_seq(m.conv)
         stem = fuse_seq(self.encoder.stem)
