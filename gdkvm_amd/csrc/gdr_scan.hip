@@ -466,7 +466,7 @@ __host__ __device__ constexpr size_t prepm_lds_bytes(int NB, int IO)
 
 
 template <int NB, int IO>
-__global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepMArgs a)
+__global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(1, 2))) void gdr_prepm_kernel(PrepMArgs a)
 {
     constexpr int NP = 16 * NB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -500,7 +500,6 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
 
     // this wave's first V tile, raw, in the accumulator layout: x[I][r] = V[token 16I+4g+r][16cV+li]
     float xk[NB][4], xv[SPLIT ? 1 : 2][SPLIT ? 1 : NB][4];
-    bf16x8 vb[2][KS];                                     // SPLIT: B operand of the bf16 MFMA, k = 32ks + 8g + j
     auto load_v = [&](int cV, float (&d)[SPLIT ? 1 : NB][4]) __attribute__((always_inline)) {
         cV = min(cV, nsl - 1);
 #pragma unroll
@@ -509,13 +508,15 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
             for (int r = 0; r < 4; ++r)
                 d[I][r] = load1<IO>(a.v, ((bt + min(16 * I + 4 * g + r, N - 1)) * Hh + h) * Dv + 16 * cV + li);
     };
-    auto load_vb = [&](int cV, bf16x8 (&d)[KS]) __attribute__((always_inline)) {
+    // SPLIT: a V tile (64 tokens x 16 columns bf16 = 2 KiB) is fetched as 128 row-major 16-byte pieces, two per lane, staged in
+    // a wave-private LDS tile and read back TRANSPOSED (ds_read_b64_tr_b16: four rows x 16 columns per 16-lane group, column-
+    // major) as the B operand -- 2 vector loads + 2 LDS writes + 4 LDS reads per tile instead of 16 two-byte gathers.
+    uint4 vA0, vA1, vB0, vB1;                              // (scalars, not an array: an array of these ends up in scratch)
+    auto load_vraw = [&](int cV, uint4& d0, uint4& d1) __attribute__((always_inline)) {
         cV = min(cV, nsl - 1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                d[ks][j] = static_cast<const __bf16*>(a.v)[((bt + min(32 * ks + 8 * g + j, N - 1)) * Hh + h) * Dv + 16 * cV + li];
+        const bf16_t* vp = static_cast<const bf16_t*>(a.v) + 16 * cV + 8 * (lane & 1);
+        d0 = *reinterpret_cast<const uint4*>(vp + ((bt + min(lane >> 1, N - 1)) * Hh + h) * Dv);
+        d1 = *reinterpret_cast<const uint4*>(vp + ((bt + min(32 + (lane >> 1), N - 1)) * Hh + h) * Dv);
     };
 
     // ---- phase 0 (a5 prologue): ONE pass over the k and q rows by all 256 threads (4 threads per token, 16 channels each):
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
     }
     __syncthreads();
     DIAG_STAMP(1);
-    if constexpr (SPLIT) load_vb(w, vb[0]);               // first V tile: in flight behind phases 1-3
+    if constexpr (SPLIT) load_vraw(w, vA0, vA1);          // first V tile: in flight behind phases 1-3
     else load_v(w, xv[0]);
 #pragma unroll
     for (int I = 0; I < NB; ++I)
@@ -645,7 +646,6 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
         const f32x4 ki4 = *reinterpret_cast<const f32x4*>(s_kinv + 16 * I + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) KN[I][r] = xk[I][r] * ki4[r];
-        s_kni[(w * NB + I) * 64 + lane] = KN[I];
     }
     if (seq) {
         static_for<0, NB>([&](auto ic) {
@@ -792,11 +792,35 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prepm_kernel(PrepM
                 if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = acc0 + acc1;
             }
         };
+        char* vst = reinterpret_cast<char*>(s_kni) + w * 4096;          // two wave-private 2 KiB tiles (the K staging area is free)
+        auto stage = [&](int buf, const uint4& d0, const uint4& d1) __attribute__((always_inline)) {
+            *reinterpret_cast<uint4*>(vst + buf * 2048 + lane * 16) = d0;              // piece p = lane: token p>>1, half p&1
+            *reinterpret_cast<uint4*>(vst + buf * 2048 + 1024 + lane * 16) = d1;       // piece p = lane + 64
+        };
+        auto read_b = [&](int buf, bf16x8 (&x)[KS]) __attribute__((always_inline)) {
+            // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of the group's 4-row block; the group of lanes
+            // 16g.. takes rows 32ks + 8g + 4*half + (0..3); lane i receives column i of those rows
+            const unsigned addr = (unsigned)(uintptr_t)(vst + buf * 2048 + ((8 * g + (li >> 2)) * 16 + 4 * (li & 3)) * 2);
+            uint2 r00, r01, r10, r11;
+            asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                         "ds_read_b64_tr_b16 %1, %4 offset:128\n\t"
+                         "ds_read_b64_tr_b16 %2, %4 offset:1024\n\t"
+                         "ds_read_b64_tr_b16 %3, %4 offset:1152\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(r00), "=&v"(r01), "=&v"(r10), "=&v"(r11) : "v"(addr) : "memory");
+            x[0] = __builtin_bit_cast(bf16x8, make_uint4(r00.x, r00.y, r01.x, r01.y));
+            x[1] = __builtin_bit_cast(bf16x8, make_uint4(r10.x, r10.y, r11.x, r11.y));
+        };
+        bf16x8 xb[KS];
         for (int cV = w; cV < nsl; cV += 8) {
-            load_vb(cV + 4, vb[1]);
-            g_tiles3(cV, vb[0]);
-            load_vb(cV + 8, vb[0]);
-            g_tiles3(cV + 4, vb[1]);
+            load_vraw(cV + 4, vB0, vB1);
+            stage(0, vA0, vA1);
+            read_b(0, xb);
+            g_tiles3(cV, xb);
+            load_vraw(cV + 8, vA0, vA1);
+            stage(1, vB0, vB1);
+            read_b(1, xb);
+            g_tiles3(cV + 4, xb);
         }
     } else {
         for (int cV = w; cV < nsl; cV += 8) {     // two V tiles per trip: the next tile's loads are in flight behind the MFMAs
