@@ -198,3 +198,24 @@ def test_scan_randomized_sweep(hip):
         case = (i, B, T, N, Hh, Dv, rule, flags, bf, with_state)
         assert np.abs(Sg - So).max() <= TOL * scale, case
         assert np.all(np.abs(Rg - Ro) <= TOL * scale + (np.abs(Ro) * 2.0 ** -8 if bf else 0)), case
+
+
+@pytest.mark.parametrize("N", [49, 130])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_state_history(hip, N, dtype):
+    """s_hist (the training forward's by-product) holds the state BEFORE every frame -- also for frames of more than 64 tokens,
+    where the read-out runs as its own kernel: entry t equals the end state of a call on the first t frames, and the read-out
+    is the one of the call without history (up to fp32 re-association: with a history the frame-parallel side runs the
+    training kernels, WY factors + fold, instead of the direct M-form)."""
+    B, T, Hh, Dv = 2, 5, 1, 32
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, 64, Dv, seed=77, normalized=False, logits=True, corr=0.5)
+    t = [_dev(x, dtype) for x in (q, k, v)] + [_dev(a), _dev(b)]
+    hist = torch.empty(B, T, Hh, 64, Dv, device="cuda")
+    R, S = hip.scan_fwd(*t, flags=3, state_hist=hist)
+    R0, S0 = hip.scan_fwd(*t, flags=3)
+    tol = dict(rtol=0, atol=2e-5)
+    assert torch.allclose(S, S0, **tol) and torch.allclose(R.float(), R0.float(), rtol=2.0 ** -7, atol=2e-5)
+    assert torch.count_nonzero(hist[:, 0]) == 0
+    for n in range(1, T):
+        _, Sn = hip.scan_fwd(*(x[:, :n].contiguous() for x in t), flags=3)
+        assert torch.allclose(hist[:, n], Sn, **tol), n
