@@ -487,7 +487,16 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fh = blockIdx.x;
+    // XCD-aware: the serial kernel runs clip-head bh on XCD bh % 8 (when their count is a multiple of 8); fold the frames of
+    // that clip-head on the same XCD so its P and G are read from the L2 they were written through (speed only)
+    int fh = blockIdx.x;
+    {
+        const int BH = (int)(gridDim.x / a.T), per_clip = a.T * a.Hh;       // gridDim.x = B * T * Hh; BH = B * Hh clip-heads
+        if (BH % 8 == 0 && a.Hh == 1) {
+            const int x = blockIdx.x, xcd = x & 7, idx = x >> 3;
+            fh = (xcd + 8 * (idx / per_clip)) * per_clip + idx % per_clip;
+        }
+    }
     const int h = fh % a.Hh;
     const int Ntot = a.N, chunk = blockIdx.y, nchunk = gridDim.y, tok0 = chunk * NP;
     const size_t bt = (size_t)(fh / a.Hh) * Ntot + tok0;   // row of this chunk's first token; rows are addressed bt*1 + n below
