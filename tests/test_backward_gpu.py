@@ -57,6 +57,24 @@ def test_scan_backward_shapes(hip, shape):
         assert np.abs(g - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), (name, np.abs(g - r).max())
 
 
+def test_scan_backward_randomized_sweep(hip):
+    """30 random (shape, rule, flags) cases, T = 1..9 (every tail of the reverse-mode serial kernel's unrolled loop), N <= 64."""
+    rng = np.random.default_rng(5)
+    for i in range(30):
+        B, T, Hh = int(rng.integers(1, 3)), int(rng.integers(1, 10)), int(rng.integers(1, 3))
+        N, Dv = int(rng.choice([1, 5, 16, 17, 33, 49, 64])), int(rng.choice([16, 32, 48, 80]))
+        rule, flags = int(rng.choice([0, 2])), int(rng.choice([0, 3]))
+        q, k, v, a, b = make_scan_inputs(B, T, N, Hh, 64, Dv, seed=int(rng.integers(1 << 30)), normalized=not flags,
+                                         logits=bool(flags), corr=float(rng.uniform(0, 0.8)))
+        s0 = (0.3 * rng.standard_normal((B, Hh, 64, Dv))).astype(np.float32)
+        dR = rng.standard_normal((B, T, N, Hh, Dv)).astype(np.float32)
+        dS = rng.standard_normal((B, Hh, 64, Dv)).astype(np.float32)
+        ref = _ref_grads(q, k, v, a, b, s0, dR, dS, rule, flags)
+        got = _hip_grads(hip, q, k, v, a, b, s0, dR, dS, rule, flags)
+        for name, g, r in zip("q k v alpha beta s0".split(), got, ref):
+            assert np.abs(g - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), (i, B, T, N, Hh, Dv, rule, flags, name, np.abs(g - r).max())
+
+
 def test_scan_backward_bf16_io(hip):
     """bf16 tensors: the kernels differentiate the exact-fp32 function of the bf16-rounded inputs; the returned
     gradients are rounded to bf16 (2^-8 relative)."""
