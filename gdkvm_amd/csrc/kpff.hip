@@ -200,17 +200,22 @@ __device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, i
                                             f32x4 (&acc0)[MT], f32x4 (&acc1)[MT])
 {
     if (n <= 0) return;
+#ifdef KPFF_ABL_WSAME                                       // ablation: every weight fragment from one L1-resident KiB
+#define KPFF_WOFF(x) ((size_t)0 * (x))
+#else
+#define KPFF_WOFF(x) (x)
+#endif
     bf16x8 b0[4], b1[4];                                   // [0] = current, [1..3] = the next three k-steps
 #pragma unroll
     for (int d = 1; d < 4; ++d) {
-        const size_t off = (size_t)min(d - 1, n - 1) * 512;
+        const size_t off = KPFF_WOFF((size_t)min(d - 1, n - 1) * 512);
         b0[d] = *reinterpret_cast<const bf16x8*>(w0 + off);
         if constexpr (NS == 2) b1[d] = *reinterpret_cast<const bf16x8*>(w1 + off);
     }
     for (int i = 0; i < n; ++i) {
         b0[0] = b0[1]; b0[1] = b0[2]; b0[2] = b0[3];
         if constexpr (NS == 2) { b1[0] = b1[1]; b1[1] = b1[2]; b1[2] = b1[3]; }
-        const size_t off = (size_t)min(i + 3, n - 1) * 512;
+        const size_t off = KPFF_WOFF((size_t)min(i + 3, n - 1) * 512);
         b0[3] = *reinterpret_cast<const bf16x8*>(w0 + off);
         if constexpr (NS == 2) b1[3] = *reinterpret_cast<const bf16x8*>(w1 + off);
 #pragma unroll

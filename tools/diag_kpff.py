@@ -50,6 +50,6 @@ def run(flags):
 
 
 if __name__ == "__main__":
-    for fl in ([], ["-DKPFF_SKIP_GEMM"], ["-DKPFF_SKIP_EPI"], ["-DKPFF_SKIP_POOL"], ["-DKPFF_SKIP_GEMM", "-DKPFF_SKIP_EPI"],
+    for fl in ([], ["-DKPFF_ABL_WSAME"], ["-DKPFF_SKIP_GEMM"], ["-DKPFF_SKIP_EPI"], ["-DKPFF_SKIP_POOL"], ["-DKPFF_SKIP_GEMM", "-DKPFF_SKIP_EPI"],
                ["-DKPFF_SKIP_GEMM", "-DKPFF_SKIP_EPI", "-DKPFF_SKIP_POOL"]):
         run(fl)
