@@ -195,9 +195,11 @@ __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c)
 // stores, one 8-byte LDS read for the residual) instead of one channel of 4 tokens (four 2-byte stores).  Weight
 // fragments are prefetched three k-steps ahead (L2 latency ~600-800 cycles vs ~130-400 cycles of MFMA per step); the
 // rotation is done with register copies, which only ever wait on the OLDEST fetch.
-template <int NS, int MT>
-__device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, int n, const bf16_t* w0, const bf16_t* w1,
-                                            f32x4 (&acc0)[MT], f32x4 (&acc1)[MT])
+// OT output tiles at once: a token fragment read from LDS feeds NS*OT MFMAs (the kernel is LDS-read-bound at OT = 1: every
+// 32-deep k-step re-reads MT KiB of tokens for MT*NS MFMAs); ot_stride = elements between consecutive output tiles' packs.
+template <int NS, int MT, int OT>
+__device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, int n, const bf16_t* w0, const bf16_t* w1, size_t ot_stride,
+                                            f32x4 (&acc0)[OT][MT], f32x4 (&acc1)[OT][MT])
 {
     if (n <= 0) return;
 #ifdef KPFF_ABL_WSAME                                       // ablation: every weight fragment from one L1-resident KiB
@@ -205,34 +207,48 @@ __device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, i
 #else
 #define KPFF_WOFF(x) (x)
 #endif
-    bf16x8 b0[4], b1[4];                                   // [0] = current, [1..3] = the next three k-steps
+    bf16x8 b0[OT][4], b1[OT][4];                           // [0] = current, [1..3] = the next three k-steps
 #pragma unroll
     for (int d = 1; d < 4; ++d) {
         const size_t off = KPFF_WOFF((size_t)min(d - 1, n - 1) * 512);
-        b0[d] = *reinterpret_cast<const bf16x8*>(w0 + off);
-        if constexpr (NS == 2) b1[d] = *reinterpret_cast<const bf16x8*>(w1 + off);
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+            b0[o][d] = *reinterpret_cast<const bf16x8*>(w0 + o * ot_stride + off);
+            if constexpr (NS == 2) b1[o][d] = *reinterpret_cast<const bf16x8*>(w1 + o * ot_stride + off);
+        }
     }
     for (int i = 0; i < n; ++i) {
-        b0[0] = b0[1]; b0[1] = b0[2]; b0[2] = b0[3];
-        if constexpr (NS == 2) { b1[0] = b1[1]; b1[1] = b1[2]; b1[2] = b1[3]; }
         const size_t off = KPFF_WOFF((size_t)min(i + 3, n - 1) * 512);
-        b0[3] = *reinterpret_cast<const bf16x8*>(w0 + off);
-        if constexpr (NS == 2) b1[3] = *reinterpret_cast<const bf16x8*>(w1 + off);
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+            b0[o][0] = b0[o][1]; b0[o][1] = b0[o][2]; b0[o][2] = b0[o][3];
+            if constexpr (NS == 2) { b1[o][0] = b1[o][1]; b1[o][1] = b1[o][2]; b1[o][2] = b1[o][3]; }
+            b0[o][3] = *reinterpret_cast<const bf16x8*>(w0 + o * ot_stride + off);
+            if constexpr (NS == 2) b1[o][3] = *reinterpret_cast<const bf16x8*>(w1 + o * ot_stride + off);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xb + (size_t)mt * 16 * ld + 32 * (ks0 + i));
-            acc0[mt] = mfma_bf16(b0[0], xv, acc0[mt]);
-            if constexpr (NS == 2) acc1[mt] = mfma_bf16(b1[0], xv, acc1[mt]);
+#pragma unroll
+            for (int o = 0; o < OT; ++o) {
+                acc0[o][mt] = mfma_bf16(b0[o][0], xv, acc0[o][mt]);
+                if constexpr (NS == 2) acc1[o][mt] = mfma_bf16(b1[o][0], xv, acc1[o][mt]);
+            }
         }
     }
 }
 
 // NT = 64-token tiles per workgroup (4*NT waves).  NT = 2 halves the weight traffic per token: at 64 tokens per
 // workgroup the kernel sits at the L2 balance point (0.75 MB of weights per 64 tokens ~ 64 flop per L2 byte).
-template <int NT>
-__global__ __launch_bounds__(256 * NT, (NT == 1 ? 2 : 1)) void kpff_bf16_kernel(KpffBf16Args a, int total_tiles)
+// OT = output tiles a wave accumulates at once; the workgroup has 4*NT/OT waves (NT = 2, OT = 2: four waves with up to 512
+// registers each, 64 accumulator tiles per wave).
+#ifndef KPFF_OT
+#define KPFF_OT 1
+#endif
+template <int NT, int OT>
+__global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_kernel(KpffBf16Args a, int total_tiles)
 {
-    constexpr int NTHR = 256 * NT, MT = 4 * NT, TMW = KPFF_TM * NT;
+    constexpr int NTHR = 256 * NT / OT, MT = 4 * NT, TMW = KPFF_TM * NT;
     extern __shared__ __attribute__((aligned(16))) bf16_t s_xb[];   // [TMW][Cin + PAD16]
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w_id = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -328,20 +344,27 @@ __global__ __launch_bounds__(256 * NT, (NT == 1 ? 2 : 1)) void kpff_bf16_kernel(
 
     // ---- fused channel mixes: wave owns output channels 16*(4*NT*chunk + wave) .. +15 for all TMW tokens ------
     const int ksP = Cp / 32, ksL = Ck / 32, KSa = Cin / 32;
-    for (int ob = 16 * w_id; ob < Cp; ob += 64 * NT) {
-        f32x4 gl[MT], gg[MT], lp[MT], gp[MT];
+    for (int ob0 = 16 * OT * w_id; ob0 < Cp; ob0 += 16 * OT * (NTHR / 64)) {
+        f32x4 gl[OT][MT], gg[OT][MT], lp[OT][MT], gp[OT][MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) gl[mt] = gg[mt] = lp[mt] = gp[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < OT; ++o)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) gl[o][mt] = gg[o][mt] = lp[o][mt] = gp[o][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const bf16_t* xb = s_xb + (size_t)li * ld + 8 * g;             // B fragment: token 16mt+li, k 8g..8g+7
 #ifndef KPFF_SKIP_GEMM
         // fragment-order packs: k-step ks of output tile ot lives at ((ot*KS + ks)*64 + lane)*8
-        kpff_stream<2, MT>(xb, ld, 0, KSa, a.wa + ((size_t)(ob / 16) * KSa * 64 + lane) * 8,
-                           a.wa + ((size_t)((Cp + ob) / 16) * KSa * 64 + lane) * 8, gl, gg);                        // gates
-        kpff_stream<1, MT>(xb, ld, ksP, ksL, a.wl + ((size_t)(ob / 16) * ksL * 64 + lane) * 8, nullptr, lp, lp);    // L Wl^T
-        kpff_stream<1, MT>(xb, ld, ksP + ksL, Cv / 32, a.wg + ((size_t)(ob / 16) * (Cv / 32) * 64 + lane) * 8, nullptr, gp, gp);
+        kpff_stream<2, MT, OT>(xb, ld, 0, KSa, a.wa + ((size_t)(ob0 / 16) * KSa * 64 + lane) * 8,
+                               a.wa + ((size_t)((Cp + ob0) / 16) * KSa * 64 + lane) * 8, (size_t)KSa * 512, gl, gg);                  // gates
+        kpff_stream<1, MT, OT>(xb, ld, ksP, ksL, a.wl + ((size_t)(ob0 / 16) * ksL * 64 + lane) * 8, nullptr, (size_t)ksL * 512, lp, lp);   // L Wl^T
+        kpff_stream<1, MT, OT>(xb, ld, ksP + ksL, Cv / 32, a.wg + ((size_t)(ob0 / 16) * (Cv / 32) * 64 + lane) * 8, nullptr,
+                               (size_t)(Cv / 32) * 512, gp, gp);
 #else
-        gl[0][0] = xb[0]; (void)ksP; (void)ksL; (void)KSa;
+        gl[0][0][0] = xb[0]; (void)ksP; (void)ksL; (void)KSa;
 #endif
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+        const int ob = ob0 + 16 * o;
+        if (ob >= Cp) continue;
         // epilogue: this lane holds channels oc..oc+3 of token 16mt+li for every token tile mt
         const int oc = ob + 4 * g;
         const f32x4 bl4 = *reinterpret_cast<const f32x4*>(a.ba + oc), bg4 = *reinterpret_cast<const f32x4*>(a.ba + Cp + oc);
@@ -349,7 +372,7 @@ __global__ __launch_bounds__(256 * NT, (NT == 1 ? 2 : 1)) void kpff_bf16_kernel(
         for (int mt = 0; mt < MT; ++mt) {
             const int trow = 16 * mt + li, sb = trow >> 6, tok = trow & 63;
 #ifdef KPFF_SKIP_EPI
-            if (tok < t_ntok[sb] && gl[mt][0] == 123.f) {
+            if (tok < t_ntok[sb] && gl[o][mt][0] == 123.f) {
 #else
             if (tok < t_ntok[sb]) {
 #endif
@@ -359,9 +382,9 @@ __global__ __launch_bounds__(256 * NT, (NT == 1 ? 2 : 1)) void kpff_bf16_kernel(
                 float y[4], sl[4], sg[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    sl[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (gl[mt][r] + bl4[r])));
-                    sg[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (gg[mt][r] + bg4[r])));
-                    y[r] = pv[r] + sl[r] * lp[mt][r] + sg[r] * gp[mt][r];
+                    sl[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (gl[o][mt][r] + bl4[r])));
+                    sg[r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * (gg[o][mt][r] + bg4[r])));
+                    y[r] = pv[r] + sl[r] * lp[o][mt][r] + sg[r] * gp[o][mt][r];
                 }
                 auto pack4 = [](const float (&v)[4]) {
                     return make_uint2((unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16),
@@ -371,13 +394,14 @@ __global__ __launch_bounds__(256 * NT, (NT == 1 ? 2 : 1)) void kpff_bf16_kernel(
                 *reinterpret_cast<uint2*>(a.out + grow * Cp + oc) = pack4(y);
                 if (a.sv.gates) {
                     bf16_t* sg_ = static_cast<bf16_t*>(a.sv.gates);
-                    const float lpv[4] = {lp[mt][0], lp[mt][1], lp[mt][2], lp[mt][3]}, gpv[4] = {gp[mt][0], gp[mt][1], gp[mt][2], gp[mt][3]};
+                    const float lpv[4] = {lp[o][mt][0], lp[o][mt][1], lp[o][mt][2], lp[o][mt][3]}, gpv[4] = {gp[o][mt][0], gp[o][mt][1], gp[o][mt][2], gp[o][mt][3]};
                     *reinterpret_cast<uint2*>(sg_ + grow * 2 * Cp + oc) = pack4(sl);
                     *reinterpret_cast<uint2*>(sg_ + grow * 2 * Cp + Cp + oc) = pack4(sg);
                     *reinterpret_cast<uint2*>(static_cast<bf16_t*>(a.sv.lp) + grow * Cp + oc) = pack4(lpv);
                     *reinterpret_cast<uint2*>(static_cast<bf16_t*>(a.sv.gp) + grow * Cp + oc) = pack4(gpv);
                 }
             }
+        }
         }
     }
 }
@@ -506,13 +530,13 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
         KpffBf16Args b{static_cast<const bf16_t*>(local), static_cast<const bf16_t*>(global), static_cast<const bf16_t*>(pixel),
                        wab, ba, wab + na, wab + na + nl, static_cast<bf16_t*>(out), Ck, Cv, Cp, h, w, rows, tiles, sv};
         const size_t lds = pair ? 2 * lds1 : lds1;
-        const void* fn = pair ? reinterpret_cast<const void*>(kpff_bf16_kernel<2>) : reinterpret_cast<const void*>(kpff_bf16_kernel<1>);
+        const void* fn = pair ? reinterpret_cast<const void*>(kpff_bf16_kernel<2, KPFF_OT>) : reinterpret_cast<const void*>(kpff_bf16_kernel<1, 1>);
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "kpff_fwd: LDS attribute: %s", hipGetErrorString(e));
         }
-        if (pair) hipLaunchKernelGGL(kpff_bf16_kernel<2>, dim3((unsigned)((total_tiles + 1) / 2)), dim3(512), lds, st, b, total_tiles);
-        else hipLaunchKernelGGL(kpff_bf16_kernel<1>, dim3((unsigned)total_tiles), dim3(256), lds, st, b, total_tiles);
+        if (pair) hipLaunchKernelGGL((kpff_bf16_kernel<2, KPFF_OT>), dim3((unsigned)((total_tiles + 1) / 2)), dim3(512 / KPFF_OT), lds, st, b, total_tiles);
+        else hipLaunchKernelGGL((kpff_bf16_kernel<1, 1>), dim3((unsigned)total_tiles), dim3(256), lds, st, b, total_tiles);
         GDKVM_LAUNCH_CHECK("kpff_bf16_kernel");
         return GDKVM_OK;
     }
