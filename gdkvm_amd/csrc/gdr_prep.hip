@@ -1,0 +1,934 @@
+// gdr_prep.hip -- the frame-parallel side of the GDR memory path for gfx950: every frame folded
+// into the affine map of the state,  S' = a P S + G,  P = I - Kn^T Wt,  G = Kn^T Ut  (SPEC-v0, SURVEY.md A.3, with
+// U = Ut - a Wt S substituted).  Kernels, in file order:
+//
+//  gdr_prep_kernel     training only (N <= 64): the WY factors Wt = T b Kn, Ut = T b V by a blocked forward substitution that
+//                      lives entirely in MFMA accumulators, plus the extra operand layouts and T_II the backward consumes.
+//  gdr_fold_kernel     training: P and G (and P^T for the backward) from the stored WY factors.
+//  gdr_prepm_kernel    inference: P and G directly, M = Kn^T T b by a back substitution on four Kn tiles, G = M V.
+//  gdr_compose_kernel  frames of more than 64 tokens: composition of the 64-token chunks' affine maps.
+// The serial recurrence that consumes P and G is in gdr_scan.hip; the workspace layout in gdr_ws.hpp.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <initializer_list>
+#include <type_traits>
+
+#include "gdkvm_common.hpp"
+#include "gdr_device.hpp"
+#include "gdr_ws.hpp"
+
+namespace {
+
+
+struct PrepArgs {
+    const void* q; const void* k; const void* v; const float* beta;
+    float* wt; float* knT; float* ut; float* qinv;
+    float* kn; float* wtT; float* qnT; float* tii;      // training mode only (GDKVM_FLAG_TRAIN); so is wt
+    float* wti;                                         // Wt as accumulator images, for the fold kernel
+    int T, Hh, N, Dv, rule, flags;
+};
+
+__device__ __forceinline__ int pair_slot(int I, int J) { return I * (I - 1) / 2 + J; }   // J < I
+
+// LDS carve for NB token tiles (floats): kinv[NP] beta[NP] qinv[NP] pad[NP] | negA[NB(NB-1)/2][64][4] | Ld[NB][64][4] | Tm[NB][64][4]
+__host__ __device__ constexpr size_t prep_lds_bytes(int NB)
+{
+    return (size_t)(4 * 16 * NB + (NB * (NB - 1) / 2 + 2 * NB) * 256) * sizeof(float);
+}
+
+// TPR = column tiles a wave solves at once.  Their operands are fetched at kernel entry (latency hidden behind
+// the norm / Gram / T_II phases) and their substitution chains are interleaved (TPR independent MFMA chains).
+template <int NB, int IO, int TPR>
+__global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prep_kernel(PrepArgs a)
+{
+    constexpr int NP = 16 * NB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_kinv = smem;
+    float* s_beta = smem + NP;
+    float* s_qinv = smem + 2 * NP;                        // (+ NP floats of padding keeps the images 16-byte aligned)
+    f32x4* s_negA = reinterpret_cast<f32x4*>(smem + 4 * NP);
+    f32x4* s_Ld = s_negA + (NB * (NB - 1) / 2) * 64;
+    f32x4* s_Tm = s_Ld + NB * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fh = blockIdx.x;                       // (b*T + t)*Hh + h
+    const int h = fh % a.Hh;
+    const size_t bt = fh / a.Hh;
+    const int N = a.N, Hh = a.Hh, Dv = a.Dv;
+    const bool seq = a.rule == GDKVM_RULE_DELTA_SEQUENTIAL;
+    const int ntile = GDKVM_DK / 16 + Dv / 16;       // column tiles: 4 of K (-> Wt, Kn^T) then Dv/16 of V (-> Ut)
+    const int nround = (ntile + 4 * TPR - 1) / (4 * TPR);
+
+    // raw operands of this wave's column tiles for one round: x[i][I][r] = X[token 16I+4g+r][col 16c+li]
+    float xr[TPR][NB][4];
+    auto fetch_round = [&](int rd) {
+#pragma unroll
+        for (int i = 0; i < TPR; ++i) {
+            const int c = min((rd * TPR + i) * 4 + w, ntile - 1);          // clamp: surplus slots refetch a real tile
+            const bool isK = c < GDKVM_DK / 16;
+#pragma unroll
+            for (int I = 0; I < NB; ++I)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = min(16 * I + 4 * g + r, N - 1);          // padding tokens: real row, zeroed by beta = 0
+                    xr[i][I][r] = isK ? load1<IO>(a.k, ((bt * N + n) * Hh + h) * GDKVM_DK + 16 * c + li)
+                                      : load1<IO>(a.v, ((bt * N + n) * Hh + h) * Dv + 16 * (c - 4) + li);
+                }
+        }
+    };
+    fetch_round(0);
+
+    // ---- phase 0 (a5 prologue): inverse key / query norms and gates ----------------------------------
+    for (int n = tid; n < NP; n += 256) {
+        float kinv = 0.f, qinv = 0.f, bta = 0.f;
+        if (n < N) {
+            kinv = qinv = 1.f;
+            if (a.flags & GDKVM_FLAG_NORMALIZE_QK) {
+                float sk = 0.f, sq = 0.f;
+#pragma unroll
+                for (int c = 0; c < GDKVM_DK; c += 4) {
+                    const f32x4 x = load4<IO>(a.k, ((bt * N + n) * Hh + h) * GDKVM_DK + c);
+                    const f32x4 y = load4<IO>(a.q, ((bt * N + n) * Hh + h) * GDKVM_DK + c);
+                    sk += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+                    sq += y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+                }
+                kinv = 1.0f / sqrtf(sk + GDKVM_EPS_NORM);
+                qinv = 1.0f / sqrtf(sq + GDKVM_EPS_NORM);
+            }
+            bta = a.beta[(bt * N + n) * Hh + h];
+            if (a.flags & GDKVM_FLAG_GATE_LOGITS) bta = 1.0f / (1.0f + expf(-bta));
+        }
+        s_kinv[n] = kinv;
+        s_beta[n] = bta;
+        s_qinv[n] = qinv;
+        a.qinv[(size_t)fh * NP + n] = qinv;
+    }
+    __syncthreads();
+
+    if (seq) {
+        // ---- phase 1: Gram blocks, transposed:  C = K_J K_I^T, lane (i,g) reg r = k_{J,4g+r} . k_{I,i}
+        //      = the A-operand image of A_IJ[i][4g+r];  stored negated and scaled by b_i (row gate).
+        for (int p = w; p < NB * (NB + 1) / 2; p += 4) {
+            int I = 0;
+            while ((I + 1) * (I + 2) / 2 <= p) ++I;
+            const int J = p - I * (I + 1) / 2;
+            const int nI = 16 * I + li, nJ = 16 * J + li;
+            f32x4 kI[4], kJ[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                kI[m] = load4<IO>(a.k, ((bt * N + min(nI, N - 1)) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
+                kJ[m] = load4<IO>(a.k, ((bt * N + min(nJ, N - 1)) * Hh + h) * GDKVM_DK + 16 * m + 4 * g);
+            }
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (m & 1) acc1 = mfma4(kJ[m][r], kI[m][r], acc1);
+                    else acc0 = mfma4(kJ[m][r], kI[m][r], acc0);
+                }
+            f32x4 acc = acc0 + acc1;
+            const float rowscale = s_kinv[nI] * s_beta[nI];                 // 0 for padding rows (kinv = beta = 0)
+            const f32x4 kinvJ = *reinterpret_cast<const f32x4*>(s_kinv + 16 * J + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] *= rowscale * kinvJ[r];
+            if (J < I) {
+                s_negA[pair_slot(I, J) * 64 + lane] = -acc;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (4 * g + r >= li) acc[r] = 0.f;   // strictly lower: col < row
+                s_Ld[I * 64 + lane] = acc;
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: T_II = (I + L_II)^-1 by forward substitution; 16 threads per block, one column each
+        {
+            const int I = tid >> 4, j = tid & 15;
+            if (I < NB) {
+                float t[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t[i] = (i == j) ? 1.f : 0.f;
+#pragma unroll
+                for (int i = 1; i < 16; ++i) {
+                    float sm = 0.f;
+#pragma unroll
+                    for (int gg = 0; gg * 4 < i; ++gg) {
+                        const f32x4 Lr = s_Ld[I * 64 + gg * 16 + i];        // L[i][4gg .. 4gg+3]
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (4 * gg + r < i) sm += Lr[r] * t[4 * gg + r];
+                    }
+                    t[i] = (i > j) ? -sm : t[i];
+                }
+                float* Tm = reinterpret_cast<float*>(s_Tm + I * 64);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) Tm[((j >> 2) * 16 + i) * 4 + (j & 3)] = t[i];   // image of T[i][j]
+                if (a.flags & GDKVM_FLAG_TRAIN) {                                        // T_II row-major for the backward
+                    float* tg = a.tii + ((size_t)fh * NB + I) * 256;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) tg[i * 16 + j] = t[i];
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 3: blocked forward substitution entirely in accumulators, TPR column tiles interleaved ----
+    float* wt = a.wt + (size_t)fh * NP * GDKVM_DK;
+    f32x4* wti = reinterpret_cast<f32x4*>(a.wti) + (size_t)fh * NP * GDKVM_DK / 4;
+    float* knT = a.knT + (size_t)fh * GDKVM_DK * NP;
+    f32x4* ut = reinterpret_cast<f32x4*>(a.ut + (size_t)fh * NP * Dv);
+    const bool train = a.flags & GDKVM_FLAG_TRAIN;
+    float* kn_nat = a.kn + (size_t)fh * NP * GDKVM_DK;
+    float* wtT = a.wtT + (size_t)fh * GDKVM_DK * NP;
+    if (train) {                                          // Qn^T for the backward's Qn^T dR: 4 tokens per 16-byte store
+        float* qnT = a.qnT + (size_t)fh * GDKVM_DK * NP;
+        for (int idx = tid; idx < GDKVM_DK * (NP / 4); idx += 256) {
+            const int d = idx / (NP / 4), n0 = (idx - d * (NP / 4)) * 4;
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                o[r] = n0 + r < N ? load1<IO>(a.q, ((bt * N + n0 + r) * Hh + h) * GDKVM_DK + d) * s_qinv[n0 + r] : 0.f;
+            *reinterpret_cast<f32x4*>(qnT + (size_t)d * NP + n0) = o;
+        }
+    }
+    for (int rd = 0; rd < nround; ++rd) {
+        if (rd > 0) fetch_round(rd);
+        f32x4 Y[TPR][NB];
+#pragma unroll
+        for (int I = 0; I < NB; ++I) {
+            const int n0 = 16 * I + 4 * g;
+            const f32x4 bt4 = *reinterpret_cast<const f32x4*>(s_beta + n0);
+            const f32x4 ki4 = *reinterpret_cast<const f32x4*>(s_kinv + n0);
+            f32x4 acc[TPR];
+#pragma unroll
+            for (int i = 0; i < TPR; ++i) {
+                const int c = (rd * TPR + i) * 4 + w;
+                const bool isK = c < GDKVM_DK / 16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][r] = isK ? xr[i][I][r] * ki4[r] : xr[i][I][r];
+                if (isK) {
+                    *reinterpret_cast<f32x4*>(knT + (size_t)(16 * c + li) * NP + n0) = acc[i];   // Kn^T, 4 tokens
+                    if (train) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) kn_nat[(size_t)(n0 + r) * GDKVM_DK + 16 * c + li] = acc[i][r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][r] *= bt4[r];
+            }
+            if (seq) {
+#pragma unroll
+                for (int J = 0; J < I; ++J) {
+                    const f32x4 na = s_negA[pair_slot(I, J) * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int i = 0; i < TPR; ++i) acc[i] = mfma4(na[r], Y[i][J][r], acc[i]);
+                }
+                const f32x4 t4 = s_Tm[I * 64 + lane];
+                f32x4 y[TPR];
+#pragma unroll
+                for (int i = 0; i < TPR; ++i) y[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int i = 0; i < TPR; ++i) y[i] = mfma4(t4[r], acc[i][r], y[i]);
+#pragma unroll
+                for (int i = 0; i < TPR; ++i) acc[i] = y[i];
+            }
+#pragma unroll
+            for (int i = 0; i < TPR; ++i) {
+                const int c = (rd * TPR + i) * 4 + w;
+                const bool isK = c < GDKVM_DK / 16;
+                if (isK && a.rule == GDKVM_RULE_GATED_LINEAR) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                Y[i][I] = acc[i];
+                if (c < ntile) {
+                    if (isK) {
+                        wti[((size_t)c * NB + I) * 64 + lane] = acc[i];
+                        if (train) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) wt[(size_t)(n0 + r) * GDKVM_DK + 16 * c + li] = acc[i][r];
+                            *reinterpret_cast<f32x4*>(wtT + (size_t)(16 * c + li) * NP + n0) = acc[i];
+                        }
+                    } else {
+                        ut[((size_t)(c - 4) * NB + I) * 64 + lane] = acc[i];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The frame as ONE affine map of the state.  Substituting U = Ut - a Wt S into S' = a S + Kn^T U gives
+//        S' = a (I - Kn^T Wt) S + Kn^T Ut  =  a P S + G ,
+// and neither P [Dk,Dk] nor G [Dk,Dv] depends on S: they belong to the state-independent (frame-parallel) side.  The
+// serial chain per frame drops from two dependent GEMMs with an LDS exchange between them (and a cost that grows with the
+// token count) to one [Dk,Dk]x[Dk,16] product per slice -- 16 fp32 MFMA per state wave, one barrier, independent of N.
+//
+// gdr_fold_kernel: P = I - Kn^T Wt and G = Kn^T Ut for one frame-head; wave w owns row tile w (Dk rows 16w..16w+15), the
+// 4 + Dv/16 column tiles are split over gridDim.y workgroups.  A operands are rows of knT (k = 16I + 4g + r, the
+// permutation under which the Ut images -- prep's accumulator layout -- are B operands as stored).
+struct FoldArgs { const float* wti; const float* knT; const float* ut; float* pp; float* gg; float* ppt; int Dv; };
+
+// grid (FH, 1 + ceil(Dv/64)): block y = 0 folds the four Wt tiles into P, block y > 0 four Ut tiles into G.  Every operand
+// of the block's four tiles is requested up front (20 16-byte loads per lane), then 4 x 4NB MFMA run back to back.
+template <int NB>
+__global__ __launch_bounds__(256) void gdr_fold_kernel(FoldArgs a)
+{
+    constexpr int NP = 16 * NB;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t fh = blockIdx.x;
+    const int nsl = a.Dv / 16;
+    const bool isP = blockIdx.y == 0;
+    const int c0 = isP ? 0 : 4 * ((int)blockIdx.y - 1);               // first of this block's column tiles
+    const int nlim = isP ? GDKVM_DK / 16 : nsl;
+    const f32x4* img = isP ? reinterpret_cast<const f32x4*>(a.wti) + fh * (NP * (size_t)GDKVM_DK / 4)
+                           : reinterpret_cast<const f32x4*>(a.ut) + fh * (NP * (size_t)a.Dv / 4);
+    f32x4 ka[NB];
+    {
+        const float* kp = a.knT + (fh * GDKVM_DK + 16 * w + li) * NP + 4 * g;
+#pragma unroll
+        for (int I = 0; I < NB; ++I) ka[I] = *reinterpret_cast<const f32x4*>(kp + 16 * I);
+    }
+    constexpr int TB = NB <= 8 ? 4 : 2;                                // tiles whose operands are in registers together
+#pragma unroll
+    for (int j0 = 0; j0 < 4; j0 += TB) {
+        f32x4 y[TB][NB];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int c = min(c0 + j0 + j, nlim - 1);
+#pragma unroll
+            for (int I = 0; I < NB; ++I) y[j][I] = img[((size_t)c * NB + I) * 64 + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < TB; ++j) {
+            const int c = c0 + j0 + j;
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int I = 0; I < NB; ++I) {
+                    if (I & 1) acc1 = mfma4(ka[I][r], y[j][I][r], acc1);
+                    else acc0 = mfma4(ka[I][r], y[j][I][r], acc0);
+                }
+            const f32x4 o = acc0 + acc1;
+            if (c < nlim) {
+                if (isP) {
+                    {   // P^T for the backward's reverse recurrence dS = a P^T dS' + Qn^T dR: this lane's four values are
+                        // P^T[16c + li][k = 16w + 4g + r], four consecutive k of row li of row tile c
+                        __bf16 t3[3][4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            split3(((16 * w + 4 * g + r == 16 * c + li) ? 1.f : 0.f) - o[r], t3[0][r], t3[1][r], t3[2][r]);
+                        uint2* pt = reinterpret_cast<uint2*>(a.ppt) + (fh * 4 + c) * (size_t)(3 * SPLIT_IMG);
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) pt[sp * SPLIT_IMG + split_slot(w, g, li)] = pack_bf16x4(t3[sp]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {                  // P[16w + 4g + r][k = 16c + li] -> term images of row tile w
+                        const int row = 16 * w + 4 * g + r, col = 16 * c + li;
+                        __bf16 t3[3];
+                        split3((row == col ? 1.f : 0.f) - o[r], t3[0], t3[1], t3[2]);
+                        __bf16* img = reinterpret_cast<__bf16*>(a.pp) + (fh * 4 + w) * (size_t)(3 * SPLIT_IMG * 4);
+                        const int e = split_slot(c, li >> 2, 4 * g + r) * 4 + (li & 3);      // k0 = 16c + 4(li>>2), element li&3
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) img[sp * SPLIT_IMG * 4 + e] = t3[sp];
+                    }
+                } else {
+                    reinterpret_cast<f32x4*>(a.gg)[((fh * nsl + c) * 4 + w) * 64 + lane] = o;
+                }
+            }
+        }
+    }
+}
+
+template <int NB>
+void launch_fold(const FoldArgs& fa, int FH, hipStream_t st)
+{
+    hipLaunchKernelGGL((gdr_fold_kernel<NB>), dim3((unsigned)FH, (unsigned)(1 + (fa.Dv / 16 + 3) / 4)), dim3(256), 0, st, fa);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gdr_prepm_kernel -- the frame-parallel side for INFERENCE (N <= 128), producing the affine map of the frame directly:
+//        M = Kn^T T diag(b)  [Dk, N]          P = I - M Kn          G = M V
+// (P = I - Kn^T Wt and G = Kn^T Ut with Wt = T b Kn, Ut = T b V substituted).  Only the FOUR column tiles of Kn go through
+// the triangular solve -- M^T = diag(b) T^T Kn is a BACK substitution with the transposed Gram blocks -- and V is used
+// raw: its tiles, fetched in the accumulator layout, are B operands as loaded.  Wt and Ut never exist, nothing but P, G
+// and qinv is written.  (Training keeps gdr_prep_kernel + gdr_fold_kernel: the backward consumes Wt, Ut, T_II.)
+//   phase 0   norms and gates (as gdr_prep_kernel)
+//   phase 1   Gram blocks: L_II (row gate, strictly lower) and, for J > I, -L_JI as the A image of (L_JI)^T
+//   phase 2   T_II = (I + L_II)^-1 by forward substitution, stored as the A image of T_II^T
+//   phase 3   wave w: Kn column tile w;  Z_I = T_II^T (Kn_I - sum_{J>I} L_JI^T Z_J), I = NB-1 .. 0;  M^T_I = b_I Z_I;
+//             Kn and M^T tiles -> LDS as accumulator images
+//   phase 4   wave w: P^T tiles (w, m) = delta - Kn_w^T-image x M^T_m  (the C layout of P^T IS the state waves' A layout
+//             of P), then G tiles (m, cV) = M_m x V_cV for cV = w, w+4, ...
+//             bf16 I/O, N <= 64: V is exactly bf16, so G runs on v_mfma_f32_16x16x32_bf16 with M split into three bf16
+//             terms (split3): 6 MFMA of 16 cycles per tile instead of 16 of 32, same accuracy.
+struct PrepMArgs {
+    const void* q; const void* k; const void* v; const float* beta;
+    float* qinv; float* pp; float* gg;
+    float* x0; float* ppc; float* ggc;                  // frames of more than 64 tokens: chunk 0 -> x0, chunk c >= 1 -> ppc/ggc[c-1]
+    int T, Hh, N, Dv, rule, flags, np_total;            // N = tokens of the frame, np_total = its padded count (qinv row length)
+#ifdef GDKVM_DIAG
+    unsigned long long* diag;
+#endif
+};
+
+__host__ __device__ constexpr bool prepm_split(int NB, int IO) { return NB == 4 && IO == GDKVM_BF16; }
+__host__ __device__ constexpr size_t prepm_lds_bytes(int NB, int IO)
+{   // kinv beta qinv pad | negB pairs | Ld | TmT | kni [4][NB] | mt [4][NB]   (images of 64 x f32x4) | m3 [3][4][NB/2] (bf16 arm)
+    return (size_t)(4 * 16 * NB + (NB * (NB - 1) / 2 + 2 * NB + 8 * NB + (prepm_split(NB, IO) ? 3 * 4 * (NB / 2) : 0)) * 256) * sizeof(float);
+}
+
+
+
+template <int NB, int IO>
+__global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(1, 2))) void gdr_prepm_kernel(PrepMArgs a)
+{
+    constexpr int NP = 16 * NB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_kinv = smem;
+    float* s_beta = smem + NP;
+    float* s_qinv = smem + 2 * NP;
+    f32x4* s_negB = reinterpret_cast<f32x4*>(smem + 4 * NP);
+    f32x4* s_Ld = s_negB + (NB * (NB - 1) / 2) * 64;
+    f32x4* s_TmT = s_Ld + NB * 64;
+    f32x4* s_kni = s_TmT + NB * 64;
+    f32x4* s_mt = s_kni + 4 * NB * 64;
+    constexpr bool SPLIT = prepm_split(NB, IO);
+    constexpr int KS = NB / 2;                            // 32-token k-steps of the bf16 MFMA
+    uint2* s_m3 = reinterpret_cast<uint2*>(s_mt + 4 * NB * 64);   // [3 terms][4 m][KS][64 lanes][2 halves]: A images of M
+    float* s_K = reinterpret_cast<float*>(s_kni);         // raw K rows [NP][KLD] fp32 until phase 3 overwrites the region
+    constexpr int KLD = GDKVM_DK + 4;
+    static_assert(NP * KLD <= 8 * NB * 256, "the K staging tile aliases kni + mt");
+
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // XCD-aware: the serial kernel runs clip-head bh on XCD bh % 8 (when their count is a multiple of 8); fold the frames of
+    // that clip-head on the same XCD so its P and G are read from the L2 they were written through (speed only)
+    int fh = blockIdx.x;
+    {
+        const int BH = (int)(gridDim.x / a.T), per_clip = a.T * a.Hh;       // gridDim.x = B * T * Hh; BH = B * Hh clip-heads
+        if (BH % 8 == 0 && a.Hh == 1) {
+            const int x = blockIdx.x, xcd = x & 7, idx = x >> 3;
+            fh = (xcd + 8 * (idx / per_clip)) * per_clip + idx % per_clip;
+        }
+    }
+    const int h = fh % a.Hh;
+    const int Ntot = a.N, chunk = blockIdx.y, nchunk = gridDim.y, tok0 = chunk * NP;
+    const size_t bt = (size_t)(fh / a.Hh) * Ntot + tok0;   // row of this chunk's first token; rows are addressed bt*1 + n below
+    const int N = min(NP, Ntot - tok0), Hh = a.Hh, Dv = a.Dv, nsl = Dv / 16;
+    const bool seq = a.rule == GDKVM_RULE_DELTA_SEQUENTIAL;
+    const bool p_identity = a.rule == GDKVM_RULE_GATED_LINEAR;
+    const int t = a.T;                                    // diagnostic builds: stamps go to row T of the buffer
+    (void)t;
+    DIAG_STAMP(0);
+
+    // this wave's first V tile, raw, in the accumulator layout: x[I][r] = V[token 16I+4g+r][16cV+li]
+    float xk[NB][4], xv[SPLIT ? 1 : 2][SPLIT ? 1 : NB][4];
+    auto load_v = [&](int cV, float (&d)[SPLIT ? 1 : NB][4]) __attribute__((always_inline)) {
+        cV = min(cV, nsl - 1);
+#pragma unroll
+        for (int I = 0; I < (SPLIT ? 1 : NB); ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                d[I][r] = load1<IO>(a.v, ((bt + min(16 * I + 4 * g + r, N - 1)) * Hh + h) * Dv + 16 * cV + li);
+    };
+    // SPLIT: a V tile (64 tokens x 16 columns bf16 = 2 KiB) is fetched as 128 row-major 16-byte pieces, two per lane, staged in
+    // a wave-private LDS tile and read back TRANSPOSED (ds_read_b64_tr_b16: four rows x 16 columns per 16-lane group, column-
+    // major) as the B operand -- 2 vector loads + 2 LDS writes + 4 LDS reads per tile instead of 16 two-byte gathers.
+    uint4 vA0, vA1, vB0, vB1;                              // (scalars, not an array: an array of these ends up in scratch)
+    auto load_vraw = [&](int cV, uint4& d0, uint4& d1) __attribute__((always_inline)) {
+        cV = min(cV, nsl - 1);
+        const bf16_t* vp = static_cast<const bf16_t*>(a.v) + 16 * cV + 8 * (lane & 1);
+        d0 = *reinterpret_cast<const uint4*>(vp + ((bt + min(lane >> 1, N - 1)) * Hh + h) * Dv);
+        d1 = *reinterpret_cast<const uint4*>(vp + ((bt + min(32 + (lane >> 1), N - 1)) * Hh + h) * Dv);
+    };
+
+    // ---- phase 0 (a5 prologue): ONE pass over the k and q rows by all 256 threads (4 threads per token, 16 channels each):
+    //      K staged in LDS as fp32 for the Gram blocks and the Kn tiles, inverse norms by a 4-lane reduction, gates
+#pragma unroll
+    for (int rep = 0; rep < NP / 64; ++rep) {
+        const int n = rep * 64 + (tid >> 2), qd = tid & 3;
+        float sk = 0.f, sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = {0.f, 0.f, 0.f, 0.f};
+            if (n < N) {
+                x = load4<IO>(a.k, ((bt + n) * Hh + h) * GDKVM_DK + 16 * qd + 4 * j);
+                y = load4<IO>(a.q, ((bt + n) * Hh + h) * GDKVM_DK + 16 * qd + 4 * j);
+            }
+            *reinterpret_cast<f32x4*>(s_K + n * KLD + 16 * qd + 4 * j) = x;
+            sk += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+            sq += y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+        }
+        sk += __shfl_xor(sk, 1); sq += __shfl_xor(sq, 1);
+        sk += __shfl_xor(sk, 2); sq += __shfl_xor(sq, 2);
+        if (qd == 0) {
+            float kinv = 0.f, qinv = 0.f, bta = 0.f;
+            if (n < N) {
+                kinv = qinv = 1.f;
+                if (a.flags & GDKVM_FLAG_NORMALIZE_QK) {
+                    kinv = 1.0f / sqrtf(sk + GDKVM_EPS_NORM);
+                    qinv = 1.0f / sqrtf(sq + GDKVM_EPS_NORM);
+                }
+                bta = a.beta[(bt + n) * Hh + h];
+                if (a.flags & GDKVM_FLAG_GATE_LOGITS) bta = 1.0f / (1.0f + expf(-bta));
+            }
+            s_kinv[n] = kinv;
+            s_beta[n] = bta;
+            s_qinv[n] = qinv;
+            a.qinv[(size_t)fh * a.np_total + tok0 + n] = qinv;
+        }
+    }
+    __syncthreads();
+    DIAG_STAMP(1);
+    if constexpr (SPLIT) load_vraw(w, vA0, vA1);          // first V tile: in flight behind phases 1-3
+    else load_v(w, xv[0]);
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xk[I][r] = s_K[(16 * I + 4 * g + r) * KLD + 16 * w + li];
+
+    if (seq) {
+        // ---- phase 1
+        for (int p = w; p < NB * (NB + 1) / 2; p += 4) {
+            int I = 0;
+            while ((I + 1) * (I + 2) / 2 <= p) ++I;
+            const int J = p - I * (I + 1) / 2;                                  // J <= I
+            const int nI = 16 * I + li, nJ = 16 * J + li;
+            f32x4 kI[4], kJ[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                kI[m] = *reinterpret_cast<const f32x4*>(s_K + nI * KLD + 16 * m + 4 * g);
+                kJ[m] = *reinterpret_cast<const f32x4*>(s_K + nJ * KLD + 16 * m + 4 * g);
+            }
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            if (J == I) {                      // lane (g,li) reg r = k_{I,4g+r} . k_{I,li}: the image of L_II[li][4g+r]
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (m & 1) acc1 = mfma4(kJ[m][r], kI[m][r], acc1);
+                        else acc0 = mfma4(kJ[m][r], kI[m][r], acc0);
+                    }
+                f32x4 acc = acc0 + acc1;
+                const float rowscale = s_kinv[nI] * s_beta[nI];
+                const f32x4 kinvJ = *reinterpret_cast<const f32x4*>(s_kinv + 16 * J + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = (4 * g + r >= li) ? 0.f : acc[r] * rowscale * kinvJ[r];
+                s_Ld[I * 64 + lane] = acc;
+            } else {                           // lane (g,li) reg r = L_IJ[4g+r][li] = b_{I,4g+r} kn_{I,4g+r} . kn_{J,li}  (I > J)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (m & 1) acc1 = mfma4(kI[m][r], kJ[m][r], acc1);
+                        else acc0 = mfma4(kI[m][r], kJ[m][r], acc0);
+                    }
+                f32x4 acc = acc0 + acc1;
+                const f32x4 kiI = *reinterpret_cast<const f32x4*>(s_kinv + 16 * I + 4 * g);
+                const f32x4 btI = *reinterpret_cast<const f32x4*>(s_beta + 16 * I + 4 * g);
+                const float colscale = s_kinv[nJ];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] *= -(kiI[r] * btI[r] * colscale);
+                s_negB[pair_slot(I, J) * 64 + lane] = acc;
+            }
+        }
+        __syncthreads();
+        DIAG_STAMP(2);
+        // ---- phase 2: T_II by forward substitution (16 threads per block, one column each), stored transposed
+        {
+            const int I = tid >> 4, j = tid & 15;
+            if (I < NB) {
+                float t[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t[i] = (i == j) ? 1.f : 0.f;
+#pragma unroll
+                for (int i = 1; i < 16; ++i) {
+                    float sm = 0.f;
+#pragma unroll
+                    for (int gg = 0; gg * 4 < i; ++gg) {
+                        const f32x4 Lr = s_Ld[I * 64 + gg * 16 + i];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (4 * gg + r < i) sm += Lr[r] * t[4 * gg + r];
+                    }
+                    t[i] = (i > j) ? -sm : t[i];
+                }
+                float* Tm = reinterpret_cast<float*>(s_TmT + I * 64);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) Tm[((i >> 2) * 16 + j) * 4 + (i & 3)] = t[i];   // lane (i>>2, j) reg i&3 = T[i][j]
+            }
+        }
+        __syncthreads();
+    }
+    DIAG_STAMP(3);
+
+    // ---- phase 3: back substitution on Kn column tile w
+    if (!seq) __syncthreads();                            // every wave has taken its Kn tile out of the staging tile (kni aliases it)
+    f32x4 KN[NB], Z[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        const f32x4 ki4 = *reinterpret_cast<const f32x4*>(s_kinv + 16 * I + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) KN[I][r] = xk[I][r] * ki4[r];
+    }
+    if (seq) {
+        static_for<0, NB>([&](auto ic) {
+            constexpr int I = NB - 1 - decltype(ic)::value;
+            f32x4 acc = KN[I];
+            static_for<I + 1, NB>([&](auto jc) {
+                constexpr int J = decltype(jc)::value;
+                const f32x4 nb = s_negB[pair_slot(J, I) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = mfma4(nb[r], Z[J][r], acc);
+            });
+            const f32x4 t4 = s_TmT[I * 64 + lane];
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z = mfma4(t4[r], acc[r], z);
+            Z[I] = z;
+        });
+    } else {
+#pragma unroll
+        for (int I = 0; I < NB; ++I) Z[I] = KN[I];
+    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+        const f32x4 bt4 = *reinterpret_cast<const f32x4*>(s_beta + 16 * I + 4 * g);
+        const f32x4 mtI = Z[I] * bt4;
+        s_mt[(w * NB + I) * 64 + lane] = mtI;
+        if constexpr (SPLIT) {             // this lane's 4 tokens 16I+4g+r of row 16w+li are half (g&1) of A lane (2(I&1)+(g>>1), li), ks = I>>1
+            __bf16 hh[4], mm[4], ll[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) split3(mtI[r], hh[r], mm[r], ll[r]);
+            const int slot = w * KS * 128 + split_slot(I, g, li);
+            s_m3[slot] = pack_bf16x4(hh);
+            s_m3[4 * KS * 128 + slot] = pack_bf16x4(mm);
+            s_m3[2 * 4 * KS * 128 + slot] = pack_bf16x4(ll);
+        }
+    }
+    __syncthreads();
+    DIAG_STAMP(4);
+
+    // ---- phase 4: P images and G tiles
+    const int nlast = N - 16 * (NB - 1);                  // real tokens in the last block (<= 0: none)
+    f32x4 mt[4][NB];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int I = 0; I < NB; ++I) mt[m][I] = s_mt[(m * NB + I) * 64 + lane];
+    // chunk 0 of a chunked frame starts the composition as [P | G] accumulator tiles; under delta_parallel (every token sees
+    // the frame's old state) the chunks combine additively, P = I - sum_c (I - P_c), so all of them are written as tiles
+    const bool first_of_many = nchunk > 1 && chunk == 0;
+    const bool p_tiles = nchunk > 1 && (chunk == 0 || a.rule == GDKVM_RULE_DELTA_PARALLEL);
+    uint2* pp = (chunk == 0 ? reinterpret_cast<uint2*>(a.pp) + (size_t)fh * (4 * 3 * SPLIT_IMG)
+                            : reinterpret_cast<uint2*>(a.ppc) + ((size_t)fh * (nchunk - 1) + chunk - 1) * (4 * 3 * SPLIT_IMG));
+    f32x4* x0 = reinterpret_cast<f32x4*>(a.x0) + (size_t)fh * (4 + nsl) * 4 * 64;
+    f32x4* ptile = chunk == 0 ? x0 : reinterpret_cast<f32x4*>(pp);      // P tiles of a later chunk take the place of its images
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (!p_identity) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int I = 0; I < NB - 1; ++I) {
+                    if (I & 1) acc1 = mfma4(KN[I][r], mt[m][I][r], acc1);
+                    else acc0 = mfma4(KN[I][r], mt[m][I][r], acc0);
+                }
+            // k-step (I, r) covers tokens 16I + 4g + r: in the last block only the first nlast steps hold real tokens
+            if (nlast > 0) { acc0 = mfma4(KN[NB - 1][0], mt[m][NB - 1][0], acc0);
+                if (nlast > 1) { acc1 = mfma4(KN[NB - 1][1], mt[m][NB - 1][1], acc1);
+                    if (nlast > 2) { acc0 = mfma4(KN[NB - 1][2], mt[m][NB - 1][2], acc0);
+                        if (nlast > 3) acc1 = mfma4(KN[NB - 1][3], mt[m][NB - 1][3], acc1); } } }
+        }
+        if (p_tiles) {                         // the composition wants chunk 0 as [P | G] accumulator tiles: P tile (m, w),
+            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};          // the same product with the operands swapped
+            if (!p_identity) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int I = 0; I < NB; ++I) {
+                        if (I & 1) b1 = mfma4(mt[m][I][r], KN[I][r], b1);
+                        else b0 = mfma4(mt[m][I][r], KN[I][r], b0);
+                    }
+            }
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = ((16 * m + 4 * g + r == 16 * w + li) ? 1.f : 0.f) - (b0[r] + b1[r]);
+            ptile[(w * 4 + m) * 64 + lane] = o;
+            continue;
+        }
+        // lane (g,li) reg r = P[16m + li][k = 16w + 4g + r]: four consecutive k of row li of row tile m -> its term images
+        __bf16 t3[3][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            split3(((16 * m + li == 16 * w + 4 * g + r) ? 1.f : 0.f) - (acc0[r] + acc1[r]), t3[0][r], t3[1][r], t3[2][r]);
+        const int e = split_slot(w, g, li);
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) pp[(m * 3 + sp) * SPLIT_IMG + e] = pack_bf16x4(t3[sp]);
+    }
+    DIAG_STAMP(5);
+    f32x4* gg = first_of_many ? x0 + 4 * 4 * 64
+              : (chunk == 0 ? reinterpret_cast<f32x4*>(a.gg) + (size_t)fh * nsl * 4 * 64
+                            : reinterpret_cast<f32x4*>(a.ggc) + ((size_t)fh * (nchunk - 1) + chunk - 1) * nsl * 4 * 64);
+    auto g_tiles = [&](int cV, const float (&x)[SPLIT ? 1 : NB][4]) __attribute__((always_inline)) {
+        if constexpr (!SPLIT)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int I = 0; I < NB - 1; ++I) {
+                    if (I & 1) acc1 = mfma4(mt[m][I][r], x[I][r], acc1);
+                    else acc0 = mfma4(mt[m][I][r], x[I][r], acc0);
+                }
+            if (nlast > 0) { acc0 = mfma4(mt[m][NB - 1][0], x[NB - 1][0], acc0);
+                if (nlast > 1) { acc1 = mfma4(mt[m][NB - 1][1], x[NB - 1][1], acc1);
+                    if (nlast > 2) { acc0 = mfma4(mt[m][NB - 1][2], x[NB - 1][2], acc0);
+                        if (nlast > 3) acc1 = mfma4(mt[m][NB - 1][3], x[NB - 1][3], acc1); } } }
+            if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = acc0 + acc1;
+        }
+    };
+    if constexpr (SPLIT) {
+        bf16x8 am[4][KS][3];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+                    am[m][ks][sp] = *reinterpret_cast<const bf16x8*>(&s_m3[sp * 4 * KS * 128 + ((m * KS + ks) * 64 + lane) * 2]);
+        auto g_tiles3 = [&](int cV, const bf16x8 (&x)[KS]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {          // smallest terms first
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m][ks][2], x[ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m][ks][1], x[ks], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m][ks][0], x[ks], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m][ks][0], x[ks], acc0, 0, 0, 0);
+                }
+                if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = acc0 + acc1;
+            }
+        };
+        char* vst = reinterpret_cast<char*>(s_kni) + w * 4096;          // two wave-private 2 KiB tiles (the K staging area is free)
+        auto stage = [&](int buf, const uint4& d0, const uint4& d1) __attribute__((always_inline)) {
+            *reinterpret_cast<uint4*>(vst + buf * 2048 + lane * 16) = d0;              // piece p = lane: token p>>1, half p&1
+            *reinterpret_cast<uint4*>(vst + buf * 2048 + 1024 + lane * 16) = d1;       // piece p = lane + 64
+        };
+        auto read_b = [&](int buf, bf16x8 (&x)[KS]) __attribute__((always_inline)) {
+            // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of the group's 4-row block; the group of lanes
+            // 16g.. takes rows 32ks + 8g + 4*half + (0..3); lane i receives column i of those rows
+            const unsigned addr = (unsigned)(uintptr_t)(vst + buf * 2048 + ((8 * g + (li >> 2)) * 16 + 4 * (li & 3)) * 2);
+            uint2 r00, r01, r10, r11;
+            asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                         "ds_read_b64_tr_b16 %1, %4 offset:128\n\t"
+                         "ds_read_b64_tr_b16 %2, %4 offset:1024\n\t"
+                         "ds_read_b64_tr_b16 %3, %4 offset:1152\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(r00), "=&v"(r01), "=&v"(r10), "=&v"(r11) : "v"(addr) : "memory");
+            x[0] = __builtin_bit_cast(bf16x8, make_uint4(r00.x, r00.y, r01.x, r01.y));
+            x[1] = __builtin_bit_cast(bf16x8, make_uint4(r10.x, r10.y, r11.x, r11.y));
+        };
+        bf16x8 xb[KS];
+        for (int cV = w; cV < nsl; cV += 8) {
+            load_vraw(cV + 4, vB0, vB1);
+            stage(0, vA0, vA1);
+            read_b(0, xb);
+            g_tiles3(cV, xb);
+            load_vraw(cV + 8, vA0, vA1);
+            stage(1, vB0, vB1);
+            read_b(1, xb);
+            g_tiles3(cV + 4, xb);
+        }
+    } else {
+        for (int cV = w; cV < nsl; cV += 8) {     // two V tiles per trip: the next tile's loads are in flight behind the MFMAs
+            load_v(cV + 4, xv[1]);
+            g_tiles(cV, xv[0]);
+            load_v(cV + 8, xv[0]);
+            g_tiles(cV + 4, xv[1]);
+        }
+    }
+    DIAG_STAMP(6);
+}
+
+template <int NB, int IO>
+int launch_prepm(const PrepMArgs& pa, int FH, int nchunk, hipStream_t st)
+{
+    const size_t lds = prepm_lds_bytes(NB, IO);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_prepm_kernel<NB, IO>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_prepm: LDS attribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL((gdr_prepm_kernel<NB, IO>), dim3(FH, nchunk), dim3(256), lds, st, pa);
+    GDKVM_LAUNCH_CHECK("gdr_prepm_kernel");
+    return GDKVM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// gdr_compose_kernel -- frames of more than 64 tokens.  The tokens of a frame act on the state in order, so the frame's
+// affine map is the composition of its 64-token chunks' maps:  [P | G] <- P_c [P | G] + [0 | G_c],  c = 1 .. nchunk-1,
+// starting from chunk 0.  Columns never mix: one workgroup carries four column tiles of [P | G] (64 x 64 fp32 in
+// accumulators, wave w = row tile w) through all steps, exactly like the serial scan carries S -- P_c as three-term A
+// images (as prepm wrote them), the running columns re-split into three-term B images through LDS each step.
+// Output: the final P as term images (pp) and G as accumulator images (gg), the formats the scan consumes.
+struct ComposeArgs { const float* x0; const float* ppc; const float* ggc; float* pp; float* gg; int Dv, nchunk, additive; };
+
+__global__ __launch_bounds__(256) void gdr_compose_kernel(ComposeArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint2 s_X3[4 * 3 * SPLIT_IMG];        // [col tile j][term] B images
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t fh = blockIdx.x;
+    const int nsl = a.Dv / 16, ncol = 4 + nsl, c0 = 4 * blockIdx.y;               // this block's column tiles c0 .. c0+3 of [P | G]
+    f32x4 X[4];
+    const f32x4* x0 = reinterpret_cast<const f32x4*>(a.x0) + fh * ncol * 4 * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) X[j] = x0[((size_t)min(c0 + j, ncol - 1) * 4 + w) * 64 + lane];
+    for (int c = 1; c < a.nchunk && a.additive; ++c) {     // delta_parallel: [P | G] += [P_c - I | G_c]  (ppc holds P_c tiles)
+        const size_t ci = fh * (a.nchunk - 1) + (c - 1);
+        const f32x4* pc = reinterpret_cast<const f32x4*>(a.ppc) + ci * (size_t)(GDKVM_DK * GDKVM_DK * 3 / 8);
+        const f32x4* gc = reinterpret_cast<const f32x4*>(a.ggc) + ci * nsl * 4 * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = min(c0 + j, ncol - 1);
+            f32x4 d = col < 4 ? pc[(col * 4 + w) * 64 + lane] : gc[((size_t)(col - 4) * 4 + w) * 64 + lane];
+            if (col < 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d[r] -= (16 * w + 4 * g + r == 16 * col + li) ? 1.f : 0.f;
+            }
+            X[j] += d;
+        }
+    }
+    for (int c = 1; c < a.nchunk && !a.additive; ++c) {
+        const size_t ci = fh * (a.nchunk - 1) + (c - 1);
+        const bf16x8* pimg = reinterpret_cast<const bf16x8*>(a.ppc) + (ci * 4 + w) * (3 * 2 * 64) + lane;
+        bf16x8 pa[3][2];
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) pa[sp][ks] = pimg[(sp * 2 + ks) * 64];
+        const f32x4* gc = reinterpret_cast<const f32x4*>(a.ggc) + ci * nsl * 4 * 64;
+        f32x4 gadd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = c0 + j;
+            gadd[j] = gc[((size_t)min(max(col - 4, 0), nsl - 1) * 4 + w) * 64 + lane];
+            if (col < 4) gadd[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                      // rows 16w + 4g + r of column tile j -> its term images
+            uint2 t3[3];
+            split3x4(X[j], t3[0], t3[1], t3[2]);
+            const int e = split_slot(w, g, li);
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) s_X3[(j * 3 + sp) * SPLIT_IMG + e] = t3[sp];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x8 xb[3][2];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) xb[sp][ks] = *reinterpret_cast<const bf16x8*>(&s_X3[(j * 3 + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#define GDKVM_PX(ACC, PT, XT, KS) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[PT][KS], xb[XT][KS], ACC, 0, 0, 0)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { GDKVM_PX(acc0, 2, 0, ks); GDKVM_PX(acc1, 0, 2, ks); GDKVM_PX(acc0, 1, 1, ks); }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { GDKVM_PX(acc1, 1, 0, ks); GDKVM_PX(acc0, 0, 1, ks); }
+            GDKVM_PX(acc1, 0, 0, 0); GDKVM_PX(acc0, 0, 0, 1);
+#undef GDKVM_PX
+            X[j] = acc0 + acc1 + gadd[j];
+        }
+        __syncthreads();                                   // the images are rewritten in the next step
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = c0 + j;
+        if (col >= ncol) continue;
+        if (col < 4) {                                     // P[16w + 4g + r][k = 16 col + li] -> term images of row tile w
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                __bf16 t3[3];
+                split3(X[j][r], t3[0], t3[1], t3[2]);
+                __bf16* img = reinterpret_cast<__bf16*>(a.pp) + (fh * 4 + w) * (size_t)(3 * SPLIT_IMG * 4);
+                const int e = split_slot(col, li >> 2, 4 * g + r) * 4 + (li & 3);
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) img[sp * SPLIT_IMG * 4 + e] = t3[sp];
+            }
+        } else {
+            reinterpret_cast<f32x4*>(a.gg)[((fh * nsl + (col - 4)) * 4 + w) * 64 + lane] = X[j];
+        }
+    }
+}
+
+template <int NB, int IO, int TPR>
+int launch_prep(const PrepArgs& pa, int FH, hipStream_t st)
+{
+    const size_t lds = prep_lds_bytes(NB);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_prep_kernel<NB, IO, TPR>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_prep: LDS attribute: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL((gdr_prep_kernel<NB, IO, TPR>), dim3(FH), dim3(256), lds, st, pa);
+    GDKVM_LAUNCH_CHECK("gdr_prep_kernel");
+    return GDKVM_OK;
+}
+
+}  // namespace
+
+extern "C" size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
+{
+    return gdr_workspace_bytes(B, T, Hh, N, Dk, Dv);
+}
+
+extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, const float* beta, void* workspace, size_t workspace_bytes,
+                               int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
+{
+    if (int rc = check_common("scan_prep", B, T, Hh, N, Dk, Dv, io_dtype, flags)) return rc;
+    if (rule < 0 || rule > 2) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_prep: rule=%d", rule);
+    if (B == 0 || T == 0 || N == 0) return GDKVM_OK;
+    if (int rc = check_ptrs("scan_prep", {q, k, v, beta, workspace}, {})) return rc;
+    WsView ws;
+    if (int rc = carve("scan_prep", workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
+    if (int rc = gdkvm_check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!(flags & GDKVM_FLAG_TRAIN) || ws.nchunk > 1) {  // P and G directly (frames of > 64 tokens: per 64-token chunk, then composed)
+        PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, ws.x0, ws.ppc, ws.ggc, T, Hh, N, Dv, rule, flags, 16 * ws.nb};
+#ifdef GDKVM_DIAG
+        pm.diag = g_gdkvm_diag_buf;
+#endif
+        if (int rc = io_dtype == GDKVM_F32 ? launch_prepm<4, GDKVM_F32>(pm, B * T * Hh, ws.nchunk, st)
+                                           : launch_prepm<4, GDKVM_BF16>(pm, B * T * Hh, ws.nchunk, st)) return rc;
+        if (ws.nchunk > 1) {
+            ComposeArgs ca{ws.x0, ws.ppc, ws.ggc, ws.pp, ws.gg, Dv, ws.nchunk, rule == GDKVM_RULE_DELTA_PARALLEL};
+            hipLaunchKernelGGL(gdr_compose_kernel, dim3((unsigned)(B * T * Hh), (unsigned)((4 + Dv / 16 + 3) / 4)), dim3(256), 0, st, ca);
+            GDKVM_LAUNCH_CHECK("gdr_compose_kernel");
+        }
+        return GDKVM_OK;
+    }
+    // training, <= 64 tokens: the WY factors the backward consumes, then folded
+    PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, ws.kn, ws.wtT, ws.qnT, ws.tii, ws.wti, T, Hh, N, Dv, rule, flags};
+    if (int rc = io_dtype == GDKVM_F32 ? launch_prep<4, GDKVM_F32, 5>(pa, B * T * Hh, st) : launch_prep<4, GDKVM_BF16, 5>(pa, B * T * Hh, st)) return rc;
+    FoldArgs fa{ws.wti, ws.knT, ws.ut, ws.pp, ws.gg, ws.ppt, Dv};
+    launch_fold<4>(fa, B * T * Hh, st);
+    GDKVM_LAUNCH_CHECK("gdr_fold_kernel");
+    return GDKVM_OK;
+}
+

@@ -17,7 +17,7 @@ SO = os.path.join(ROOT, "gpurun_out", "libgdkvm_hip_diag.so")
 
 def main():
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in ("gdr_scan.hip", "gdkvm_api.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("gdr_prep.hip", "gdr_scan.hip", "gdkvm_api.hip")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGDKVM_DIAG"] + sys.argv[1:] + [
                            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", SO] + srcs)
     print("variant:", sys.argv[1:])
