@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <initializer_list>
 #include <type_traits>
 
@@ -346,12 +347,17 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
 template <int IO, bool DEFER, bool SV>
 int launch_affine(const AffArgs& sa, dim3 grid, hipStream_t st)
 {
-    static bool attr_set = false;                         // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_set) {
+    // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device (a process may drive several devices from several
+    // threads: the cache is a lock-free bit mask, a lost race only repeats the idempotent call)
+    static std::atomic<unsigned long long> done_mask{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_affine_scan: hipGetDevice");
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_affine_scan_kernel<IO, DEFER, SV>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)aff_lds_bytes(IO));
         if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_affine_scan: LDS attribute: %s", hipGetErrorString(e));
-        attr_set = true;
+        done_mask.fetch_or(bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, DEFER, SV>), grid, dim3(768), aff_lds_bytes(IO), st, sa);
     GDKVM_LAUNCH_CHECK("gdr_affine_scan_kernel");
