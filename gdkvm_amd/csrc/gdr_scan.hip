@@ -580,11 +580,13 @@ __global__ __launch_bounds__(256) void gdr_bwd_g_kernel(BwdGArgs a)
 int gdr_launch_reverse_scan(const WsView& ws, const float* alpha, const void* d_r, const float* ds_out, float* ds_hist,
                             float* ds_in, float* gb, int B, int T, int Hh, int N, int Dv, int io_dtype, int flags, hipStream_t st)
 {
-    BwdGArgs ga{ws.qnT, d_r, gb, Hh, N, Dv};
-    const dim3 ggrid((unsigned)(B * T * Hh), (unsigned)((Dv / 16 + 3) / 4));
-    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_bwd_g_kernel<GDKVM_F32>), ggrid, dim3(256), 0, st, ga);
-    else hipLaunchKernelGGL((gdr_bwd_g_kernel<GDKVM_BF16>), ggrid, dim3(256), 0, st, ga);
-    GDKVM_LAUNCH_CHECK("gdr_bwd_g_kernel");
+    if (d_r) {                                             // (d_r == NULL: the caller has filled gb itself)
+        BwdGArgs ga{ws.qnT, d_r, gb, Hh, N, Dv};
+        const dim3 ggrid((unsigned)(B * T * Hh), (unsigned)((Dv / 16 + 3) / 4));
+        if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_bwd_g_kernel<GDKVM_F32>), ggrid, dim3(256), 0, st, ga);
+        else hipLaunchKernelGGL((gdr_bwd_g_kernel<GDKVM_BF16>), ggrid, dim3(256), 0, st, ga);
+        GDKVM_LAUNCH_CHECK("gdr_bwd_g_kernel");
+    }
     AffArgs sa{nullptr, alpha, ds_out, ws.ppt, gb, nullptr, nullptr, ds_in, ds_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 1, nullptr};
 #ifdef GDKVM_DIAG
     sa.diag = nullptr;

@@ -198,13 +198,13 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
     // ---- phase 1: contractions over Dv, 64 columns at a time --------------------------------------------------
     for (int ch = 0; ch < nchunk; ++ch) {
         const int cb = 64 * ch, CW = min(64, Dv - cb);
-        load_chunk(cb, CW, true);
+        load_chunk(cb, CW, a.d_r != nullptr);
         __syncthreads();
         xu_du(true);
         __syncthreads();
         tile_gemm<true>(dKn, b3, b1, w, li, g);             // dKn += U dS'^T
         tile_gemm<true>(dWt, b4, b0, w, li, g);             // dWt += dU S^T      (scaled by -a below)
-        tile_gemm<true>(dQn, b2, b0, w, li, g);             // dQn += dR S^T
+        if (a.d_r) tile_gemm<true>(dQn, b2, b0, w, li, g);  // dQn += dR S^T   (state-only mode: no read-out, no dQ)
         __syncthreads();
     }
 #pragma unroll
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
         tile_gemm<false>(dKn, b1, Kn, w, li, g);
     }
     // ---- gates, L2 normalisation, stores ---------------------------------------------------------------------
-    load_rows_io(b2, a.q, GDKVM_DK, 0, 64, s_qinv);                                     // Qn = q * qinv -> b2
+    if (a.d_q) load_rows_io(b2, a.q, GDKVM_DK, 0, 64, s_qinv);                          // Qn = q * qinv -> b2
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -328,22 +328,37 @@ __global__ __launch_bounds__(256) void gdr_bwd_frame_kernel(BwdFrameArgs a)
         const float db = row16_sum(dbeta[r]);
         float dotk = 0.f, dotq = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) { dotk += Kn[at(nt, r)] * dKn[nt][r]; dotq += b2[at(nt, r)] * dQn[nt][r]; }
+        for (int nt = 0; nt < 4; ++nt) { dotk += Kn[at(nt, r)] * dKn[nt][r]; if (a.d_q) dotq += b2[at(nt, r)] * dQn[nt][r]; }
         dotk = row16_sum(dotk); dotq = row16_sum(dotq);
         if (row < N) {
             const float bi = s_beta[row], ki = s_kinv[row], qi = s_qinv[row];
             if (li == 0) a.d_beta[(bt * N + row) * Hh + h] = logits ? db * bi * (1.f - bi) : db;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                float gk = dKn[nt][r], gq = dQn[nt][r];
-                if (normalize) {
-                    gk = ki * (gk - Kn[at(nt, r)] * dotk);
-                    gq = qi * (gq - b2[at(nt, r)] * dotq);
-                }
+                float gk = dKn[nt][r];
+                if (normalize) gk = ki * (gk - Kn[at(nt, r)] * dotk);
                 store1<IO>(a.d_k, ((bt * N + row) * Hh + h) * GDKVM_DK + 16 * nt + li, gk);
-                store1<IO>(a.d_q, ((bt * N + row) * Hh + h) * GDKVM_DK + 16 * nt + li, gq);
+                if (a.d_q) {
+                    float gq = dQn[nt][r];
+                    if (normalize) gq = qi * (gq - b2[at(nt, r)] * dotq);
+                    store1<IO>(a.d_q, ((bt * N + row) * Hh + h) * GDKVM_DK + 16 * nt + li, gq);
+                }
             }
         }
+    }
+}
+
+// [FH][Dk][Dv] row-major (a gradient with respect to the state before every frame) -> the accumulator images the serial kernel
+// takes as its additive term: out[((fh*nsl + sl)*4 + w)*64 + lane][r] = in[fh][16w + 4g + r][16sl + li]
+__global__ void gdr_rows_to_img_kernel(const float* in, float* out, size_t n_img, int Dv)
+{
+    const int nsl = Dv / 16;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_img; i += (size_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63), li = lane & 15, g = lane >> 4, w = (int)((i >> 6) & 3);
+        const size_t fs = i >> 8, fh = fs / nsl;
+        const int sl = (int)(fs - fh * nsl);
+        const float* src = in + (fh * GDKVM_DK + 16 * w + 4 * g) * Dv + 16 * sl + li;
+        reinterpret_cast<f32x4*>(out)[i] = f32x4{src[0], src[Dv], src[2 * (size_t)Dv], src[3 * (size_t)Dv]};
     }
 }
 
@@ -355,20 +370,25 @@ extern "C" size_t gdkvm_scan_bwd_workspace_bytes(int B, int T, int Hh, int N, in
     return 2 * (size_t)B * T * Hh * Dk * Dv * sizeof(float) + 16;       // dS' of every frame + Gb = Qn^T dR of every frame
 }
 
-extern "C" int gdkvm_scan_bwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
-                              const float* s_hist, const void* fwd_workspace, size_t fwd_workspace_bytes,
-                              const void* d_r, const float* d_s_out,
-                              void* d_q, void* d_k, void* d_v, float* d_alpha, float* d_beta, float* d_s_in,
-                              void* bwd_workspace, size_t bwd_workspace_bytes,
-                              int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
+// Shared body of gdkvm_scan_bwd (read-out gradient d_r, query gradient d_q) and gdkvm_scan_state_bwd (no read-out: q, d_r,
+// d_q NULL; instead d_hist, the gradient with respect to the state before every frame, enters the reverse recurrence as its
+// additive term).
+static int scan_bwd_impl(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
+                         const float* s_hist, const void* fwd_workspace, size_t fwd_workspace_bytes,
+                         const void* d_r, const float* d_hist, const float* d_s_out,
+                         void* d_q, void* d_k, void* d_v, float* d_alpha, float* d_beta, float* d_s_in,
+                         void* bwd_workspace, size_t bwd_workspace_bytes,
+                         int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
 {
     if (int rc = check_common("scan_bwd", B, T, Hh, N, Dk, Dv, io_dtype, flags)) return rc;
     if (rule < 0 || rule > 2) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_bwd: rule=%d", rule);
     if (B == 0) return GDKVM_OK;
     if (T == 0 || N == 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_bwd: T and N must be positive");
     if (N > 64) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_bwd: N=%d > 64 tokens per frame is not supported yet", N);
-    if (int rc = check_ptrs("scan_bwd", {q, k, v, alpha, beta, s_hist, fwd_workspace, d_r, d_q, d_k, d_v, d_alpha, d_beta, bwd_workspace},
-                            {d_s_out, d_s_in})) return rc;
+    if (int rc = check_ptrs("scan_bwd", {k, v, alpha, beta, s_hist, fwd_workspace, d_k, d_v, d_alpha, d_beta, bwd_workspace},
+                            {q, d_r, d_q, d_hist, d_s_out, d_s_in})) return rc;
+    if ((d_r != nullptr) != (d_q != nullptr) || (d_q && !q))
+        return gdkvm_fail(GDKVM_ERR_ARG, "scan_bwd: q, d_r and d_q come together");
     WsView ws;
     if (int rc = carve("scan_bwd", const_cast<void*>(fwd_workspace), fwd_workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
     if (bwd_workspace_bytes < gdkvm_scan_bwd_workspace_bytes(B, T, Hh, N, Dk, Dv) - 16)
@@ -379,6 +399,18 @@ extern "C" int gdkvm_scan_bwd(const void* q, const void* k, const void* v, const
     float* ds_hist = static_cast<float*>(bwd_workspace);
     float* gb = ds_hist + (size_t)B * T * Hh * Dk * Dv;
 
+    // the additive term of the reverse recurrence when it does not come from a read-out: d_hist as images, or zero
+    if (!d_r) {
+        const size_t n_img = (size_t)B * T * Hh * (Dv / 16) * 4 * 64;
+        if (d_hist) {
+            hipLaunchKernelGGL(gdr_rows_to_img_kernel, dim3((unsigned)((n_img + 255) / 256 > 8192 ? 8192 : (n_img + 255) / 256)), dim3(256), 0, st,
+                               d_hist, gb, n_img, Dv);
+            GDKVM_LAUNCH_CHECK("gdr_rows_to_img_kernel");
+        } else {
+            hipError_t e = hipMemsetAsync(gb, 0, n_img * 16, st);
+            if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_bwd: memset: %s", hipGetErrorString(e));
+        }
+    }
     // reverse recurrence on the forward's serial kernel (operands from the training-mode workspace)
     if (int rc = gdr_launch_reverse_scan(ws, alpha, d_r, d_s_out, ds_hist, d_s_in, gb, B, T, Hh, N, Dv, io_dtype, flags, st)) return rc;
 
@@ -394,4 +426,27 @@ extern "C" int gdkvm_scan_bwd(const void* q, const void* k, const void* v, const
     else hipLaunchKernelGGL((gdr_bwd_frame_kernel<GDKVM_BF16>), fgrid, dim3(256), lds, st, fa);
     GDKVM_LAUNCH_CHECK("gdr_bwd_frame_kernel");
     return GDKVM_OK;
+}
+
+extern "C" int gdkvm_scan_bwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
+                              const float* s_hist, const void* fwd_workspace, size_t fwd_workspace_bytes,
+                              const void* d_r, const float* d_s_out,
+                              void* d_q, void* d_k, void* d_v, float* d_alpha, float* d_beta, float* d_s_in,
+                              void* bwd_workspace, size_t bwd_workspace_bytes,
+                              int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
+{
+    if (!q || !d_r || !d_q) return gdkvm_fail(GDKVM_ERR_ARG, "scan_bwd: null pointer");
+    return scan_bwd_impl(q, k, v, alpha, beta, s_hist, fwd_workspace, fwd_workspace_bytes, d_r, nullptr, d_s_out, d_q, d_k, d_v,
+                         d_alpha, d_beta, d_s_in, bwd_workspace, bwd_workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream);
+}
+
+extern "C" int gdkvm_scan_state_bwd(const void* k, const void* v, const float* alpha, const float* beta,
+                                    const float* s_hist, const void* fwd_workspace, size_t fwd_workspace_bytes,
+                                    const float* d_hist, const float* d_s_out,
+                                    void* d_k, void* d_v, float* d_alpha, float* d_beta, float* d_s_in,
+                                    void* bwd_workspace, size_t bwd_workspace_bytes,
+                                    int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
+{
+    return scan_bwd_impl(nullptr, k, v, alpha, beta, s_hist, fwd_workspace, fwd_workspace_bytes, nullptr, d_hist, d_s_out, nullptr, d_k, d_v,
+                         d_alpha, d_beta, d_s_in, bwd_workspace, bwd_workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream);
 }

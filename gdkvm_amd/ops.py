@@ -31,6 +31,7 @@ SIGNATURES = {
     "gdkvm_scan_apply": (_i, [_vp] * 7 + [_sz] + [_i] * 8 + [_vp]),
     "gdkvm_scan_transition": (_i, [_vp] * 4 + [_sz] + [_i] * 8 + [_vp]),
     "gdkvm_scan_bwd_workspace_bytes": (_sz, [_i] * 6),
+    "gdkvm_scan_state_bwd": (_i, [_vp] * 6 + [_sz] + [_vp] * 8 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_bwd": (_i, [_vp] * 7 + [_sz] + [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_kpff_workspace_bytes": (_sz, [_i] * 4),
     "gdkvm_kpff_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 7 + [_vp]),
@@ -123,8 +124,8 @@ def scan_workspace_bytes(B, T, Hh, N, Dk, Dv) -> int:
 def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor,
              state: Optional[torch.Tensor] = None, rule: int = RULE_DELTA_SEQUENTIAL, flags: int = 0,
              workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-             state_out: Optional[torch.Tensor] = None, state_hist: Optional[torch.Tensor] = None
-             ) -> Tuple[torch.Tensor, torch.Tensor]:
+             state_out: Optional[torch.Tensor] = None, state_hist: Optional[torch.Tensor] = None,
+             readout: bool = True) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
     """Fused LKVA read + GDR write over T frames (gdkvm_scan_fwd).
 
     q,k [B,T,N,Hh,Dk]  v [B,T,N,Hh,Dv]  (f32|bf16)   alpha [B,T,Hh]  beta [B,T,N,Hh]  state [B,Hh,Dk,Dv] (f32)
@@ -147,7 +148,7 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
     need = scan_workspace_bytes(B, T, Hh, N, Dk, Dv)
     if workspace is None:
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
-    r = out if out is not None else torch.empty((B, T, N, Hh, Dv), dtype=q.dtype, device=dev)
+    r = None if not readout else (out if out is not None else torch.empty((B, T, N, Hh, Dv), dtype=q.dtype, device=dev))
     s = state_out if state_out is not None else torch.empty((B, Hh, Dk, Dv), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = lib.gdkvm_scan_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(alpha), _ptr(beta), _ptr(state), _ptr(r), _ptr(s),
@@ -205,8 +206,88 @@ class _ScanFunction(torch.autograd.Function):
         return dq, dk, dv, da, db, ds, None, None
 
 
+def scan_state_bwd(k, v, alpha, beta, state_hist, workspace, d_hist=None, d_state_out=None, rule=RULE_DELTA_SEQUENTIAL, flags=0,
+                   need_d_state_in=True):
+    """Backward of the state recurrence alone (gdkvm_scan_state_bwd): ``d_hist`` [B,T,Hh,Dk,Dv] is the gradient with respect to
+    the state before every frame.  Returns (d_k, d_v, d_alpha, d_beta, d_state_in | None)."""
+    lib = load()
+    B, T, N, Hh, Dk = k.shape
+    Dv = v.shape[-1]
+    dev = _dev(k, v, alpha, beta, state_hist, workspace, d_hist, d_state_out)
+    dk, dv = torch.empty_like(k), torch.empty_like(v)
+    da = torch.empty((B, T, Hh), dtype=torch.float32, device=dev)
+    db = torch.empty((B, T, N, Hh), dtype=torch.float32, device=dev)
+    ds = torch.empty((B, Hh, Dk, Dv), dtype=torch.float32, device=dev) if need_d_state_in else None
+    bws = torch.empty(int(lib.gdkvm_scan_bwd_workspace_bytes(B, T, Hh, N, Dk, Dv)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gdkvm_scan_state_bwd(_ptr(k), _ptr(v), _ptr(alpha), _ptr(beta), _ptr(state_hist), workspace.data_ptr(),
+                                      workspace.numel(), _ptr(d_hist), _ptr(d_state_out), _ptr(dk), _ptr(dv), _ptr(da), _ptr(db),
+                                      _ptr(ds), bws.data_ptr(), bws.numel(), B, T, Hh, N, Dk, Dv, _io_dtype(k), rule, flags,
+                                      _stream(dev))
+    _check(rc, "gdkvm_scan_state_bwd")
+    return dk, dv, da, db, ds
+
+
+class _StateScanFunction(torch.autograd.Function):
+    """The state recurrence alone, differentiable: (k, v, alpha, beta, S_0) -> (the state before every frame, S_T).  The forward
+    is gdkvm_scan_fwd without a read-out, the backward gdkvm_scan_state_bwd fed with the gradient of the state history."""
+
+    @staticmethod
+    def forward(ctx, k, v, alpha, beta, state, rule, flags):
+        B, T, N, Hh, Dk = k.shape
+        Dv = v.shape[-1]
+        ws = torch.empty(scan_workspace_bytes(B, T, Hh, N, Dk, Dv), dtype=torch.uint8, device=k.device)
+        hist = torch.empty((B, T, Hh, Dk, Dv), dtype=torch.float32, device=k.device)
+        _, s = scan_fwd(k, k, v, alpha, beta, state, rule=rule, flags=flags, workspace=ws, state_hist=hist, readout=False)
+        ctx.save_for_backward(k, v, alpha, beta, hist, ws)
+        ctx.rule, ctx.flags, ctx.has_state = rule, flags, state is not None
+        return hist, s
+
+    @staticmethod
+    def backward(ctx, d_hist, d_s):
+        k, v, alpha, beta, hist, ws = ctx.saved_tensors
+        d_hist = None if d_hist is None else d_hist.contiguous().float()
+        d_s = None if d_s is None else d_s.contiguous().float()
+        dk, dv, da, db, ds = scan_state_bwd(k, v, alpha, beta, hist, ws, d_hist, d_s, ctx.rule, ctx.flags,
+                                            need_d_state_in=ctx.has_state)
+        return dk, dv, da, db, ds, None, None
+
+
+_BIG_LOGIT = 1.0e30           # sigmoid(+-1e30) is exactly 1 / 0 in the kernels' formulas
+
+
+def _scan_chunked(q, k, v, alpha, beta, state, rule, flags):
+    """Training path for frames of more than 64 tokens.  The tokens of a frame act on the state in order, so a frame is a
+    sequence of 64-token pseudo-frames: the first carries the frame's gate, the others gate 1, padding tokens beta = 0; the
+    state recurrence and its backward run on the 64-token kernels over T * chunks steps.  The read-out of ALL the frame's tokens
+    uses the state before the frame, i.e. before its first pseudo-frame: a batched matmul on the saved state history, whose
+    gradient returns into the reverse recurrence through gdkvm_scan_state_bwd's d_hist."""
+    if rule == RULE_DELTA_PARALLEL:
+        raise GdkvmError("training with rule delta_parallel is limited to 64 tokens per frame (its chunks combine additively)")
+    B, T, N, Hh, Dk = q.shape
+    Dv = v.shape[-1]
+    C = (N + 63) // 64
+    pad = 64 * C - N
+    logits = bool(flags & FLAG_GATE_LOGITS)
+    Fn = torch.nn.functional
+    k_p = Fn.pad(k, (0, 0, 0, 0, 0, pad)).reshape(B, T * C, 64, Hh, Dk)
+    v_p = Fn.pad(v, (0, 0, 0, 0, 0, pad)).reshape(B, T * C, 64, Hh, Dv)
+    beta_p = Fn.pad(beta, (0, 0, 0, pad), value=-_BIG_LOGIT if logits else 0.0).reshape(B, T * C, 64, Hh)
+    one = torch.full((B, T, C - 1, Hh), _BIG_LOGIT if logits else 1.0, dtype=alpha.dtype, device=alpha.device)
+    alpha_p = torch.cat([alpha.unsqueeze(2), one], 2).reshape(B, T * C, Hh)
+    hist, s_T = _StateScanFunction.apply(k_p.contiguous(), v_p.contiguous(), alpha_p.contiguous(), beta_p.contiguous(), state, rule, flags)
+    s_read = hist.reshape(B, T, C, Hh, Dk, Dv)[:, :, 0]                          # the state before every frame
+    qf = q.float()
+    if flags & FLAG_NORMALIZE_QK:
+        qf = qf * torch.rsqrt((qf * qf).sum(-1, keepdim=True) + 1.0e-12)
+    r = torch.einsum("btnhd,bthde->btnhe", qf, s_read).to(q.dtype)
+    return r, s_T
+
+
 def scan(q, k, v, alpha, beta, state=None, rule: int = RULE_DELTA_SEQUENTIAL, flags: int = 0):
     """scan_fwd with autograd support (training).  Inference callers should use scan_fwd directly (no history)."""
+    if q.shape[2] > 64:
+        return _scan_chunked(q, k, v, alpha, beta, state, rule, flags)
     return _ScanFunction.apply(q, k, v, alpha, beta, state, rule, flags)
 
 

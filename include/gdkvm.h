@@ -108,6 +108,18 @@ int gdkvm_scan_bwd(const void* q, const void* k, const void* v, const float* alp
                    void* bwd_workspace, size_t bwd_workspace_bytes,
                    int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream);
 
+/* Row a7 for frames of more than 64 tokens (and any caller that does its own read-out): the backward of the STATE recurrence
+ * alone.  No q / d_r / d_q; instead d_hist [B,T,Hh,Dk,Dv] fp32 (may be NULL) is the gradient with respect to the state before
+ * every frame (what a read-out R_t = f(S_{t-1}) done outside sends back), which enters the reverse recurrence as its additive
+ * term.  gdkvm_amd/ops.py::scan uses it with every 64-token chunk of a frame as a pseudo-frame (gate 1 after the first, padding
+ * tokens with beta = 0) and the read-out as a batched matmul on the saved states.  Same workspaces as gdkvm_scan_bwd. */
+int gdkvm_scan_state_bwd(const void* k, const void* v, const float* alpha, const float* beta,
+                         const float* s_hist, const void* fwd_workspace, size_t fwd_workspace_bytes,
+                         const float* d_hist, const float* d_s_out,
+                         void* d_k, void* d_v, float* d_alpha, float* d_beta, float* d_s_in,
+                         void* bwd_workspace, size_t bwd_workspace_bytes,
+                         int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream);
+
 /* Row a4: Key-Pixel Feature Fusion ("fuses the local key feature, the global key feature with the pixel
  * feature", /root/reference/website/src/content/homepage/en.json:20; "multiple scales", README.md:20).
  *   local [BT,N,Ck]  global [BT,N,Cv]  pixel [BT,N,Cp]  out [BT,N,Cp]   (io_dtype), N = h*w

@@ -75,6 +75,31 @@ def test_scan_backward_randomized_sweep(hip):
             assert np.abs(g - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), (i, B, T, N, Hh, Dv, rule, flags, name, np.abs(g - r).max())
 
 
+@pytest.mark.parametrize("case", [(2, 3, 100, 1, 32, 2, 3), (1, 2, 130, 2, 48, 2, 3), (1, 3, 256, 1, 64, 2, 0), (2, 2, 65, 1, 16, 0, 3)])
+def test_scan_backward_more_than_64_tokens(hip, case):
+    """Frames of more than 64 tokens train through 64-token pseudo-frames (ops._scan_chunked): gradients of the whole op --
+    incl. the read-out's path back into the state recurrence (gdkvm_scan_state_bwd's d_hist) -- against fp64 autograd."""
+    B, T, N, Hh, Dv, rule, flags = case
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, 64, Dv, seed=sum(case), normalized=not flags, logits=bool(flags), corr=0.5)
+    rng = np.random.default_rng(47)
+    s0 = (0.3 * rng.standard_normal((B, Hh, 64, Dv))).astype(np.float32)
+    dR = rng.standard_normal((B, T, N, Hh, Dv)).astype(np.float32)
+    dS = rng.standard_normal((B, Hh, 64, Dv)).astype(np.float32)
+    ref = _ref_grads(q, k, v, a, b, s0, dR, dS, rule, flags)
+    got = _hip_grads(hip, q, k, v, a, b, s0, dR, dS, rule, flags)
+    for name, g, r in zip("q k v alpha beta s0".split(), got, ref):
+        assert np.abs(g - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), (name, np.abs(g - r).max(), np.abs(r).max())
+
+
+def test_scan_forward_values_through_the_chunked_training_path(hip):
+    """... and its forward values equal the inference path's."""
+    q, k, v, a, b = make_scan_inputs(2, 3, 130, 1, 64, 32, seed=9, normalized=False, logits=True, corr=0.5)
+    t = [torch.from_numpy(x).cuda() for x in (q, k, v, a, b)]
+    R0, S0 = hip.scan_fwd(*t, flags=3)
+    R1, S1 = hip.scan(*(x.clone().requires_grad_() for x in t), None, 2, 3)
+    assert torch.allclose(R1, R0, atol=2e-5) and torch.allclose(S1, S0, atol=2e-5)
+
+
 def test_scan_backward_bf16_io(hip):
     """bf16 tensors: the kernels differentiate the exact-fp32 function of the bf16-rounded inputs; the returned
     gradients are rounded to bf16 (2^-8 relative)."""
