@@ -1,0 +1,417 @@
+// bn.hip -- training-mode BatchNorm fused with the residual add and the ReLU that follow it, forward and backward, for the
+// NHWC conv outputs either side of the memory path (the training side).
+//
+// In a cfg4 training step the library BatchNorm kernels were 38 % of the GPU time (7.1 ms of 18.6 ms,
+// profiles/r01_l_train_cfg4_steady_state.csv) for work that is three streaming passes forward and two backward.  Here:
+//   forward   bn_stats (x once) -> bn_finalize (C channels) -> bn_apply  y = act(x*scale + shift (+ residual))
+//   backward  bn_bwd_reduce (x, y, dy once) -> bn_bwd_finalize -> bn_bwd_dx  dx (and the masked gradient for the residual branch)
+// All passes are HBM-bound by construction: 16-byte accesses, a thread keeps ONE channel group for the whole pass (its
+// per-channel parameters and accumulators live in registers), every trip has UNR independent loads in flight.
+// Reductions are deterministic (fixed partial layout, fixed summation order; no atomics).  The variance is accumulated on
+// values shifted by the first row of the tensor, so it does not cancel when |mean| >> std.
+#include "gdkvm_common.hpp"
+
+namespace {
+
+constexpr int BN_MAX_PART = 512;        // partial-sum rows (one per workgroup of the reduction passes)
+
+template <int IO> struct VecOf { static constexpr int V = IO == GDKVM_F32 ? 4 : 8; };
+
+template <int IO>
+__device__ __forceinline__ void unpack(const uint4& a, float (&v)[VecOf<IO>::V])
+{
+    const unsigned w[4] = {a.x, a.y, a.z, a.w};
+    if constexpr (IO == GDKVM_F32) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(w[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] = __uint_as_float(w[j] << 16); v[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+    }
+}
+
+template <int IO>
+__device__ __forceinline__ uint4 pack(const float (&v)[VecOf<IO>::V])
+{
+    uint4 o;
+    if constexpr (IO == GDKVM_F32) {
+        o.x = __float_as_uint(v[0]); o.y = __float_as_uint(v[1]); o.z = __float_as_uint(v[2]); o.w = __float_as_uint(v[3]);
+    } else {
+        o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+        o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+    }
+    return o;
+}
+
+template <int V>
+__device__ __forceinline__ void load_param(const float* p, int c0, float (&v)[V])
+{
+#pragma unroll
+    for (int j = 0; j < V; j += 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p + c0 + j);
+        v[j] = t[0]; v[j + 1] = t[1]; v[j + 2] = t[2]; v[j + 3] = t[3];
+    }
+}
+
+// Thread -> data map shared by every pass: the tensor is M rows of G = C/V 16-byte vectors; a workgroup owns the rows
+// [r0, r1) and walks them RP = 256/G rows per trip, so thread `tid` (< RP*G) reads vector r0*G + tid + trip*RP*G --
+// contiguous across the workgroup -- and its channel group is always tid % G.
+struct Walk {
+    size_t v, vend, step;
+    bool active;
+    int cg;
+    __device__ Walk(int M, int G, int rows_per_block)
+    {
+        const int tid = threadIdx.x, nact = (256 / G) * G;
+        const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+        const size_t r1 = min((size_t)M, r0 + rows_per_block);
+        active = tid < nact && r0 < r1;
+        cg = tid % G;
+        v = r0 * G + tid; vend = r1 * G; step = nact;
+    }
+};
+
+// Workgroup reduction of per-thread accumulators acc[2][V] into part[blockIdx.x][2*C] (layout: stat-major, channel minor).
+template <int V>
+__device__ __forceinline__ void block_reduce_store(const float (&a1)[V], const float (&a2)[V], float* part, int C, int G)
+{
+    __shared__ float s[256][2 * V + 1];
+    const int tid = threadIdx.x, RP = 256 / G;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s[tid][j] = a1[j]; s[tid][V + j] = a2[j]; }
+    __syncthreads();
+    for (int o = tid; o < 2 * C; o += 256) {
+        const int stat = o >= C, c = o - stat * C, cg = c / V, j = c - cg * V;
+        float t = 0.f;
+        for (int rp = 0; rp < RP; ++rp) t += s[rp * G + cg][stat * V + j];
+        part[(size_t)blockIdx.x * 2 * C + o] = t;
+    }
+}
+
+template <int IO>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const uint4* __restrict__ x, float* __restrict__ part, int M, int C, int G,
+                                                       int rows_per_block)
+{
+    constexpr int V = VecOf<IO>::V, UNR = 8;
+    Walk w(M, G, rows_per_block);
+    float s1[V], s2[V], kk[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s1[j] = s2[j] = 0.f;
+    if (w.active) {
+        unpack<IO>(x[w.cg], kk);                                   // shift = row 0 of these channels
+        auto eat = [&](const uint4& a) __attribute__((always_inline)) {
+            float f[V];
+            unpack<IO>(a, f);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { const float d = f[j] - kk[j]; s1[j] += d; s2[j] = fmaf(d, d, s2[j]); }
+        };
+        size_t v = w.v;
+        for (; v + (UNR - 1) * w.step < w.vend; v += UNR * w.step) {
+            uint4 a[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) a[u] = x[v + u * w.step];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) eat(a[u]);
+        }
+        for (; v < w.vend; v += w.step) eat(x[v]);
+    }
+    block_reduce_store<V>(s1, s2, part, C, G);
+}
+
+// Sum of the partial rows for 32 channels x 2 statistics per workgroup of 1024 threads: 16 disjoint row subsets, every load
+// of a thread independent.  Returns (to threads 0..31) the two sums of channel blockIdx.x*32 + tid.
+__device__ __forceinline__ void sum_partials(const float* part, int nblk, int C, float& S1, float& S2)
+{
+    __shared__ float s[16][64];
+    const int tid = threadIdx.x, c = blockIdx.x * 32 + (tid & 31), stat = (tid >> 5) & 1, sub = tid >> 6;
+    float acc = 0.f;
+    if (c < C)
+        for (int b = sub; b < nblk; b += 16) acc += part[(size_t)b * 2 * C + stat * C + c];
+    s[sub][tid & 63] = acc;
+    __syncthreads();
+    S1 = S2 = 0.f;
+    if (tid < 32) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { S1 += s[k][tid]; S2 += s[k][32 + tid]; }
+    }
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nblk, const void* x, int io,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* running_mean, float* running_var, float* save_mean,
+                                                           float* save_rstd, float* scale, float* shift, int M, int C, float eps,
+                                                           float momentum)
+{
+    float d1, d2;
+    sum_partials(part, nblk, C, d1, d2);
+    const int c = blockIdx.x * 32 + threadIdx.x;
+    if (threadIdx.x < 32 && c < C) {
+        const float k = io == GDKVM_F32 ? static_cast<const float*>(x)[c] : bf16_to_f32(static_cast<const bf16_t*>(x)[c]);
+        const double n = (double)M, m = (double)d1 / n;
+        double var = (double)d2 / n - m * m;
+        var = var > 0.0 ? var : 0.0;
+        const float mean = (float)((double)k + m);
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * rstd;
+        save_mean[c] = mean; save_rstd[c] = rstd;
+        scale[c] = sc; shift[c] = beta[c] - mean * sc;
+        if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (M > 1 ? n / (n - 1.0) : 1.0));
+    }
+}
+
+template <int IO, bool RELU, bool RES>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const uint4* __restrict__ x, const uint4* __restrict__ res,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       uint4* __restrict__ y, int M, int G, int rows_per_block)
+{
+    constexpr int V = VecOf<IO>::V, UNR = 4;
+    Walk w(M, G, rows_per_block);
+    if (!w.active) return;
+    float sc[V], sh[V];
+    load_param<V>(scale, w.cg * V, sc); load_param<V>(shift, w.cg * V, sh);
+    auto finish = [&](size_t i, const uint4& a, const uint4& r) __attribute__((always_inline)) {
+        float f[V], g[V];
+        unpack<IO>(a, f);
+        if constexpr (RES) unpack<IO>(r, g);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            float t = fmaf(f[j], sc[j], sh[j]);
+            if constexpr (RES) t += g[j];
+            f[j] = RELU ? fmaxf(t, 0.f) : t;
+        }
+        y[i] = pack<IO>(f);
+    };
+    size_t v = w.v;
+    for (; v + (UNR - 1) * w.step < w.vend; v += UNR * w.step) {
+        uint4 a[UNR], r[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) a[u] = x[v + u * w.step];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) r[u] = RES ? res[v + u * w.step] : uint4{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) finish(v + u * w.step, a[u], r[u]);
+    }
+    for (; v < w.vend; v += w.step) finish(v, x[v], RES ? res[v] : uint4{0, 0, 0, 0});
+}
+
+// ------------------------------------------------------------------------------------------------------------ backward
+// g = dy masked by the ReLU (y > 0);  S1 = sum g,  S2 = sum g (x - mean)  per channel.
+template <int IO, bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restrict__ x, const uint4* __restrict__ y,
+                                                            const uint4* __restrict__ dy, const float* __restrict__ mean,
+                                                            float* __restrict__ part, int M, int C, int G, int rows_per_block)
+{
+    constexpr int V = VecOf<IO>::V, UNR = 4;
+    Walk w(M, G, rows_per_block);
+    float s1[V], s2[V], mu[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s1[j] = s2[j] = 0.f;
+    if (w.active) {
+        load_param<V>(mean, w.cg * V, mu);
+        auto eat = [&](const uint4& xa, const uint4& ya, const uint4& da) __attribute__((always_inline)) {
+            float f[V], o[V], d[V];
+            unpack<IO>(xa, f); unpack<IO>(da, d);
+            if constexpr (RELU) unpack<IO>(ya, o);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float g = RELU ? (o[j] > 0.f ? d[j] : 0.f) : d[j];
+                s1[j] += g; s2[j] = fmaf(g, f[j] - mu[j], s2[j]);
+            }
+        };
+        size_t v = w.v;
+        for (; v + (UNR - 1) * w.step < w.vend; v += UNR * w.step) {
+            uint4 xa[UNR], ya[UNR], da[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) xa[u] = x[v + u * w.step];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) da[u] = dy[v + u * w.step];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) ya[u] = RELU ? y[v + u * w.step] : uint4{0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) eat(xa[u], ya[u], da[u]);
+        }
+        for (; v < w.vend; v += w.step) eat(x[v], RELU ? y[v] : uint4{0, 0, 0, 0}, dy[v]);
+    }
+    block_reduce_store<V>(s1, s2, part, C, G);
+}
+
+// d_beta = S1, d_gamma = rstd S2;  dx = cA g + c1 (x - mean) + c0  with  cA = gamma rstd, c1 = -cA rstd^2 S2 / n, c0 = -cA S1 / n.
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk,
+                                                               const float* __restrict__ gamma, const float* __restrict__ save_rstd,
+                                                               float* dgamma, float* dbeta, float* coef, int M, int C)
+{
+    float S1, S2;
+    sum_partials(part, nblk, C, S1, S2);
+    const int c = blockIdx.x * 32 + threadIdx.x;
+    if (threadIdx.x < 32 && c < C) {
+        const float rstd = save_rstd[c], cA = gamma[c] * rstd, inv_n = 1.f / (float)M;
+        dbeta[c] = S1; dgamma[c] = rstd * S2;
+        coef[c] = cA; coef[C + c] = -cA * S1 * inv_n; coef[2 * C + c] = -cA * rstd * rstd * S2 * inv_n;
+    }
+}
+
+template <int IO, bool RELU, bool DRES>
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const uint4* __restrict__ x, const uint4* __restrict__ y,
+                                                        const uint4* __restrict__ dy, const float* __restrict__ mean,
+                                                        const float* __restrict__ coef, uint4* __restrict__ dx,
+                                                        uint4* __restrict__ dres, int M, int C, int G, int rows_per_block)
+{
+    constexpr int V = VecOf<IO>::V, UNR = 4;
+    Walk w(M, G, rows_per_block);
+    if (!w.active) return;
+    float mu[V], cA[V], c0[V], c1[V];
+    load_param<V>(mean, w.cg * V, mu); load_param<V>(coef, w.cg * V, cA);
+    load_param<V>(coef + C, w.cg * V, c0); load_param<V>(coef + 2 * C, w.cg * V, c1);
+    auto finish = [&](size_t i, const uint4& xa, const uint4& ya, const uint4& da) __attribute__((always_inline)) {
+        float f[V], o[V], d[V];
+        unpack<IO>(xa, f); unpack<IO>(da, d);
+        if constexpr (RELU) unpack<IO>(ya, o);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float g = RELU ? (o[j] > 0.f ? d[j] : 0.f) : d[j];
+            d[j] = g;
+            f[j] = fmaf(cA[j], g, fmaf(c1[j], f[j] - mu[j], c0[j]));
+        }
+        dx[i] = pack<IO>(f);
+        if constexpr (DRES) dres[i] = pack<IO>(d);
+    };
+    size_t v = w.v;
+    for (; v + (UNR - 1) * w.step < w.vend; v += UNR * w.step) {
+        uint4 xa[UNR], ya[UNR], da[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) xa[u] = x[v + u * w.step];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) da[u] = dy[v + u * w.step];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) ya[u] = RELU ? y[v + u * w.step] : uint4{0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) finish(v + u * w.step, xa[u], ya[u], da[u]);
+    }
+    for (; v < w.vend; v += w.step) finish(v, x[v], RELU ? y[v] : uint4{0, 0, 0, 0}, dy[v]);
+}
+
+struct BnPlan {
+    int G, RP, nred, rpb_red, nmap, rpb_map;
+};
+
+// reduction passes: at most BN_MAX_PART workgroups (one partial row each); map passes: up to 8 workgroups per CU
+BnPlan bn_plan(long long M, int C, int V, int unr_red)
+{
+    BnPlan p;
+    p.G = C / V; p.RP = 256 / p.G;
+    auto split = [&](long long max_blocks, int unr, int& nb, int& rpb) {
+        const long long trip = (long long)p.RP * unr;
+        long long blocks = (M + trip - 1) / trip;
+        if (blocks > max_blocks) blocks = max_blocks;
+        if (blocks < 1) blocks = 1;
+        long long r = (M + blocks - 1) / blocks;
+        r = (r + p.RP - 1) / p.RP * p.RP;
+        rpb = (int)r; nb = (int)((M + r - 1) / r);
+    };
+    split(BN_MAX_PART, unr_red, p.nred, p.rpb_red);
+    split(256 * 8, 4, p.nmap, p.rpb_map);
+    return p;
+}
+
+int bn_check(const char* who, long long M, int C, int io)
+{
+    if (io != GDKVM_F32 && io != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "%s: io_dtype=%d", who, io);
+    const int V = io == GDKVM_F32 ? 4 : 8;
+    if (M < 1 || M > 0x7fffffffLL || C <= 0 || C % V || C / V > 256)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: rows=%lld C=%d (C a multiple of %d, at most %d)", who, M, C, V, 256 * V);
+    return GDKVM_OK;
+}
+
+}  // namespace
+
+extern "C" size_t gdkvm_bn_workspace_bytes(int C)
+{
+    return C > 0 ? ((size_t)BN_MAX_PART * 2 * C + 4 * (size_t)C) * sizeof(float) : 0;
+}
+
+extern "C" int gdkvm_bn_fwd_train(const void* x, const void* residual, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, void* y, float* save_mean, float* save_rstd,
+                                  void* ws, size_t ws_bytes, long long rows, int C, float eps, float momentum, int relu,
+                                  int io_dtype, void* stream)
+{
+    if (int rc = bn_check("bn_fwd_train", rows, C, io_dtype)) return rc;
+    if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !ws) return gdkvm_fail(GDKVM_ERR_ARG, "bn_fwd_train: null pointer");
+    if (!gdkvm_aligned16(x) || !gdkvm_aligned16(y) || !gdkvm_aligned16(ws) || (residual && !gdkvm_aligned16(residual)))
+        return gdkvm_fail(GDKVM_ERR_ARG, "bn_fwd_train: pointers must be 16-byte aligned");
+    if (ws_bytes < gdkvm_bn_workspace_bytes(C)) return gdkvm_fail(GDKVM_ERR_ARG, "bn_fwd_train: workspace too small");
+    if (int rc = gdkvm_check_device()) return rc;
+    const int V = io_dtype == GDKVM_F32 ? 4 : 8, M = (int)rows;
+    const BnPlan p = bn_plan(rows, C, V, 8);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(ws);
+    float* scale = part + (size_t)BN_MAX_PART * 2 * C;
+    float* shift = scale + C;
+    const uint4* xv = static_cast<const uint4*>(x);
+    const uint4* rv = static_cast<const uint4*>(residual);
+    uint4* yv = static_cast<uint4*>(y);
+    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((bn_stats_kernel<GDKVM_F32>), dim3(p.nred), dim3(256), 0, st, xv, part, M, C, p.G, p.rpb_red);
+    else hipLaunchKernelGGL((bn_stats_kernel<GDKVM_BF16>), dim3(p.nred), dim3(256), 0, st, xv, part, M, C, p.G, p.rpb_red);
+    GDKVM_LAUNCH_CHECK("bn_stats_kernel");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, p.nred, x, io_dtype, gamma, beta,
+                       running_mean, running_var, save_mean, save_rstd, scale, shift, M, C, eps, momentum);
+    GDKVM_LAUNCH_CHECK("bn_finalize_kernel");
+#define GDKVM_BN_APPLY(IO, RL, RS) \
+    hipLaunchKernelGGL((bn_apply_kernel<IO, RL, RS>), dim3(p.nmap), dim3(256), 0, st, xv, rv, scale, shift, yv, M, p.G, p.rpb_map)
+#define GDKVM_BN_APPLY_IO(IO)                                                         \
+    do {                                                                              \
+        if (relu) { if (residual) GDKVM_BN_APPLY(IO, true, true); else GDKVM_BN_APPLY(IO, true, false); }   \
+        else { if (residual) GDKVM_BN_APPLY(IO, false, true); else GDKVM_BN_APPLY(IO, false, false); }      \
+    } while (0)
+    if (io_dtype == GDKVM_F32) GDKVM_BN_APPLY_IO(GDKVM_F32); else GDKVM_BN_APPLY_IO(GDKVM_BF16);
+#undef GDKVM_BN_APPLY_IO
+#undef GDKVM_BN_APPLY
+    GDKVM_LAUNCH_CHECK("bn_apply_kernel");
+    return GDKVM_OK;
+}
+
+extern "C" int gdkvm_bn_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* save_mean,
+                            const float* save_rstd, void* dx, void* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                            long long rows, int C, int relu, int io_dtype, void* stream)
+{
+    if (int rc = bn_check("bn_bwd", rows, C, io_dtype)) return rc;
+    if (!x || !dy || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !ws || (relu && !y))
+        return gdkvm_fail(GDKVM_ERR_ARG, "bn_bwd: null pointer");
+    if (!gdkvm_aligned16(x) || !gdkvm_aligned16(dy) || !gdkvm_aligned16(dx) || !gdkvm_aligned16(ws) || (y && !gdkvm_aligned16(y))
+        || (dres && !gdkvm_aligned16(dres)))
+        return gdkvm_fail(GDKVM_ERR_ARG, "bn_bwd: pointers must be 16-byte aligned");
+    if (ws_bytes < gdkvm_bn_workspace_bytes(C)) return gdkvm_fail(GDKVM_ERR_ARG, "bn_bwd: workspace too small");
+    if (int rc = gdkvm_check_device()) return rc;
+    const int V = io_dtype == GDKVM_F32 ? 4 : 8, M = (int)rows;
+    const BnPlan p = bn_plan(rows, C, V, 4);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(ws);
+    float* coef = part + (size_t)BN_MAX_PART * 2 * C;
+    const uint4* xv = static_cast<const uint4*>(x);
+    const uint4* yv = static_cast<const uint4*>(y);
+    const uint4* dv = static_cast<const uint4*>(dy);
+    uint4* dxv = static_cast<uint4*>(dx);
+    uint4* drv = static_cast<uint4*>(dres);
+#define GDKVM_BN_RED(IO, RL) \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<IO, RL>), dim3(p.nred), dim3(256), 0, st, xv, yv, dv, save_mean, part, M, C, p.G, p.rpb_red)
+    if (io_dtype == GDKVM_F32) { if (relu) GDKVM_BN_RED(GDKVM_F32, true); else GDKVM_BN_RED(GDKVM_F32, false); }
+    else { if (relu) GDKVM_BN_RED(GDKVM_BF16, true); else GDKVM_BN_RED(GDKVM_BF16, false); }
+#undef GDKVM_BN_RED
+    GDKVM_LAUNCH_CHECK("bn_bwd_reduce_kernel");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, p.nred, gamma, save_rstd, dgamma, dbeta, coef, M, C);
+    GDKVM_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+#define GDKVM_BN_DX(IO, RL, DR) \
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<IO, RL, DR>), dim3(p.nmap), dim3(256), 0, st, xv, yv, dv, save_mean, coef, dxv, drv, M, C, p.G, p.rpb_map)
+#define GDKVM_BN_DX_IO(IO)                                                            \
+    do {                                                                              \
+        if (relu) { if (dres) GDKVM_BN_DX(IO, true, true); else GDKVM_BN_DX(IO, true, false); }   \
+        else { if (dres) GDKVM_BN_DX(IO, false, true); else GDKVM_BN_DX(IO, false, false); }      \
+    } while (0)
+    if (io_dtype == GDKVM_F32) GDKVM_BN_DX_IO(GDKVM_F32); else GDKVM_BN_DX_IO(GDKVM_BF16);
+#undef GDKVM_BN_DX_IO
+#undef GDKVM_BN_DX
+    GDKVM_LAUNCH_CHECK("bn_bwd_dx_kernel");
+    return GDKVM_OK;
+}

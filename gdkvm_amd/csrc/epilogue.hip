@@ -327,6 +327,90 @@ __global__ __launch_bounds__(256) void upsample_cat_bf16_kernel(const bf16_t* lo
     }
 }
 
+// Backward of the pass above (training): d_lo[n, i, j, :] = sum over the output pixels whose bilinear taps touch (i, j) of
+// weight * d_out[.., :C1] -- a gather, so it is deterministic (PyTorch's backward scatters with float atomics into an fp32
+// copy: 0.93 ms per cfg4 step) -- and d_skip = d_out[.., C1:].  One workgroup per low-resolution row; a thread owns one
+// 16-byte channel group of one pixel, its taps (4 x 4 at exactly 2x) all in flight before the first add.  The weights come
+// from the forward's own index formula evaluated per candidate row / column, so the borders need no special case.
+__device__ __forceinline__ float tap_weight(int o, int i, float s, int n_in)
+{
+    const float f = fmaxf(s * ((float)o + 0.5f) - 0.5f, 0.f);
+    const int i0 = (int)f, i1 = min(i0 + 1, n_in - 1);
+    const float l = f - (float)i0;
+    return (i0 == i ? 1.f - l : 0.f) + (i1 == i ? l : 0.f);
+}
+
+__global__ __launch_bounds__(256) void upsample_cat_bwd_bf16_kernel(const bf16_t* dout, bf16_t* dlo, bf16_t* dskip,
+                                                                    int Nimg, int hl, int wl, int H, int W, int C1, int C2,
+                                                                    float sy, float sx, int ry, int rx)
+{
+    const int C = C1 + C2, c1n = C1 / 8, c2n = C2 / 8, tid = threadIdx.x;
+    const bool exact2x = H == 2 * hl && W == 2 * wl;
+    for (int row = blockIdx.x; row < Nimg * hl; row += gridDim.x) {
+        const int n = row / hl, i = row - n * hl;
+        const bf16_t* dimg = dout + (size_t)n * H * W * C;
+        for (int u = tid; u < wl * c1n; u += 256) {
+            const int j = u / c1n, c = (u - j * c1n) * 8;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            if (exact2x) {
+                uint4 t[4][4];
+                float wy[4], wx[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int oy = 2 * i - 1 + a, ox = 2 * j - 1 + a;
+                    wy[a] = (oy >= 0 && oy < H) ? tap_weight(oy, i, sy, hl) : 0.f;
+                    wx[a] = (ox >= 0 && ox < W) ? tap_weight(ox, j, sx, wl) : 0.f;
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int oy = min(max(2 * i - 1 + a, 0), H - 1), ox = min(max(2 * j - 1 + b, 0), W - 1);
+                        t[a][b] = *reinterpret_cast<const uint4*>(dimg + ((size_t)oy * W + ox) * C + c);
+                    }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        float v[8];
+                        unpack8(t[a][b], v);
+                        const float wgt = wy[a] * wx[b];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e] = fmaf(wgt, v[e], acc[e]);
+                    }
+            } else {
+                const int oy0 = max((int)(((float)i - 0.5f) / sy - 0.5f) - ry, 0), oy1 = min((int)(((float)i + 1.5f) / sy - 0.5f) + ry, H - 1);
+                const int ox0 = max((int)(((float)j - 0.5f) / sx - 0.5f) - rx, 0), ox1 = min((int)(((float)j + 1.5f) / sx - 0.5f) + rx, W - 1);
+                for (int oy = oy0; oy <= oy1; ++oy) {
+                    const float wy = tap_weight(oy, i, sy, hl);
+                    if (wy == 0.f) continue;
+                    for (int ox = ox0; ox <= ox1; ++ox) {
+                        const float wgt = wy * tap_weight(ox, j, sx, wl);
+                        if (wgt == 0.f) continue;
+                        float v[8];
+                        unpack8(*reinterpret_cast<const uint4*>(dimg + ((size_t)oy * W + ox) * C + c), v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[e] = fmaf(wgt, v[e], acc[e]);
+                    }
+                }
+            }
+            unsigned r[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = (unsigned)f32_to_bf16(acc[2 * q]) | ((unsigned)f32_to_bf16(acc[2 * q + 1]) << 16);
+            *reinterpret_cast<uint4*>(dlo + ((size_t)row * wl + j) * C1 + c) = make_uint4(r[0], r[1], r[2], r[3]);
+        }
+    }
+    // the skip half: a strided copy, split evenly over the workgroups
+    const size_t ncopy = (size_t)Nimg * H * W * c2n;
+    for (size_t v = (size_t)blockIdx.x * 256 + tid; v < ncopy; v += (size_t)gridDim.x * 256) {
+        const size_t pix = v / c2n;
+        const int cv = (int)(v - pix * c2n) * 8;
+        *reinterpret_cast<uint4*>(dskip + pix * C2 + cv) = *reinterpret_cast<const uint4*>(dout + pix * C + C1 + cv);
+    }
+}
+
 }  // namespace
 
 extern "C" int gdkvm_upsample_cat(const void* lo, const void* skip, void* out,
@@ -347,6 +431,29 @@ extern "C" int gdkvm_upsample_cat(const void* lo, const void* skip, void* out,
                        static_cast<const bf16_t*>(lo), static_cast<const bf16_t*>(skip), static_cast<bf16_t*>(out),
                        Nimg, hl, wl, H, W, C1, C2, (float)hl / (float)H, (float)wl / (float)W);
     GDKVM_LAUNCH_CHECK("upsample_cat_bf16_kernel");
+    return GDKVM_OK;
+}
+
+extern "C" int gdkvm_upsample_cat_bwd(const void* dout, void* dlo, void* dskip,
+                                      int Nimg, int hl, int wl, int H, int W, int C1, int C2, int io_dtype, void* stream)
+{
+    if (Nimg < 0 || hl <= 0 || wl <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 <= 0)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_cat_bwd: bad shape");
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "upsample_cat_bwd: only bf16 is implemented");
+    if (C1 % 8 || C2 % 8) return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_cat_bwd: channel counts must be multiples of 8");
+    if (Nimg == 0) return GDKVM_OK;
+    if (!dout || !dlo || !dskip || !gdkvm_aligned16(dout) || !gdkvm_aligned16(dlo) || !gdkvm_aligned16(dskip))
+        return gdkvm_fail(GDKVM_ERR_ARG, "upsample_cat_bwd: null or misaligned pointer");
+    if (int rc = gdkvm_check_device()) return rc;
+    if ((size_t)H * W * (C1 + C2) >= (1u << 30)) return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_cat_bwd: image too large");
+    size_t blocks = (size_t)Nimg * hl;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const float sy = (float)hl / (float)H, sx = (float)wl / (float)W;
+    // candidate range slack (general path): one output row / column either side of the analytic bounds
+    hipLaunchKernelGGL(upsample_cat_bwd_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(dout), static_cast<bf16_t*>(dlo), static_cast<bf16_t*>(dskip),
+                       Nimg, hl, wl, H, W, C1, C2, sy, sx, 1, 1);
+    GDKVM_LAUNCH_CHECK("upsample_cat_bwd_bf16_kernel");
     return GDKVM_OK;
 }
 

@@ -46,6 +46,27 @@ def _bn(c):
     return nn.BatchNorm2d(c)
 
 
+def _bn_act(bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(bn(x) (+ residual)).  Training mode on the GPU runs the fused HIP passes of csrc/bn.hip in both directions
+    (ops.bn_act: statistics, normalise + add + ReLU; the library BatchNorm kernels were 38 % of a training step); eval mode of
+    the un-folded model and the CPU reference module use torch."""
+    v = 8 if x.dtype == torch.bfloat16 else 4
+    if (x.is_cuda and bn.training and bn.affine and x.dtype in (torch.bfloat16, torch.float32) and bn.weight.dtype == torch.float32
+            and x.shape[1] % v == 0 and x.shape[1] // v <= 256):
+        momentum = bn.momentum
+        if bn.track_running_stats:
+            bn.num_batches_tracked.add_(1)
+            if momentum is None:
+                momentum = 1.0 / float(bn.num_batches_tracked)
+        res = None if residual is None else residual.to(x.dtype)
+        return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                          bn.running_var if bn.track_running_stats else None, res, momentum or 0.0, bn.eps, relu)
+    y = bn(x)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y, inplace=True) if relu else y
+
+
 class BasicBlock(nn.Module):
     def __init__(self, cin, cout, stride):
         super().__init__()
@@ -61,9 +82,9 @@ class BasicBlock(nn.Module):
         if isinstance(self.conv1, FusedConv):              # inference build: conv -> one fused epilogue pass
             skip = x if self.down is None else self.down(x)
             return self.conv2(self.conv1(x), skip.contiguous(memory_format=torch.channels_last) if skip.is_cuda else skip)
-        y = F.relu(self.bn1(self.conv1(x)), inplace=True)
-        y = self.bn2(self.conv2(y))
-        return F.relu(y + (x if self.down is None else self.down(x)), inplace=True)
+        y = _bn_act(self.bn1, self.conv1(x), True)
+        skip = x if self.down is None else _bn_act(self.down[1], self.down[0](x), False)
+        return _bn_act(self.bn2, self.conv2(y), True, skip)
 
 
 class Encoder(nn.Module):
@@ -79,7 +100,12 @@ class Encoder(nn.Module):
         self.layer3 = nn.Sequential(BasicBlock(w8, w16, 2), BasicBlock(w16, w16, 1))
 
     def forward(self, x):
-        f4 = self.layer1(self.stem(x))
+        s = self.stem
+        if len(s) == 4 and isinstance(s[1], nn.BatchNorm2d):                  # training build: conv, fused BN + ReLU, pool
+            x = s[3](_bn_act(s[1], s[0](x), True))
+        else:
+            x = s(x)
+        f4 = self.layer1(x)
         f8 = self.layer2(f4)
         return f4, f8, self.layer3(f8)
 
@@ -91,12 +117,16 @@ class UpBlock(nn.Module):
                                   nn.Conv2d(cout, cout, 3, 1, 1, bias=False), _bn(cout), nn.ReLU(inplace=True))
 
     def forward(self, x, skip):
-        if (isinstance(self.conv[0], FusedConv) and x.is_cuda and x.dtype == torch.bfloat16
-                and x.shape[1] % 8 == 0 and skip.shape[1] % 8 == 0):            # inference build: one fused HIP pass
-            return self.conv(ops.upsample_cat(x.contiguous(memory_format=torch.channels_last),
-                                              skip.contiguous(memory_format=torch.channels_last)))
-        x = F.interpolate(x, size=skip.shape[-2:], mode="bilinear", align_corners=False)
-        return self.conv(torch.cat([x, skip], 1))
+        c = self.conv
+        if (x.is_cuda and x.dtype == torch.bfloat16 and skip.dtype == torch.bfloat16
+                and x.shape[1] % 8 == 0 and skip.shape[1] % 8 == 0):            # one fused HIP pass (differentiable)
+            x = ops.upsample_cat(x.contiguous(memory_format=torch.channels_last),
+                                 skip.contiguous(memory_format=torch.channels_last))
+        else:
+            x = torch.cat([F.interpolate(x, size=skip.shape[-2:], mode="bilinear", align_corners=False), skip], 1)
+        if len(c) == 6 and isinstance(c[1], nn.BatchNorm2d):                    # training build
+            return _bn_act(c[4], c[3](_bn_act(c[1], c[0](x), True)), True)
+        return c(x)
 
 
 class Decoder(nn.Module):

@@ -42,9 +42,13 @@ SIGNATURES = {
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "gdkvm_bias_act": (_i, [_vp] * 4 + [_sz] + [_i] * 3 + [_vp]),
     "gdkvm_upsample_cat": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
+    "gdkvm_upsample_cat_bwd": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_bias_relu_maxpool": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
     "gdkvm_stem_s2d": (_i, [_vp] * 2 + [_i] * 6 + [_vp]),
     "gdkvm_upsample_argmax_dice": (_i, [_vp] * 4 + [_i] * 7 + [_vp]),
+    "gdkvm_bn_workspace_bytes": (_sz, [_i]),
+    "gdkvm_bn_fwd_train": (_i, [_vp] * 10 + [_sz, ctypes.c_longlong, _i, ctypes.c_float, ctypes.c_float, _i, _i, _vp]),
+    "gdkvm_bn_bwd": (_i, [_vp] * 11 + [_sz, ctypes.c_longlong, _i, _i, _i, _vp]),
 }
 
 
@@ -556,9 +560,7 @@ def stem_s2d(x: torch.Tensor, cpad: int) -> torch.Tensor:
     return out
 
 
-def upsample_cat(lo: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:
-    """concat(bilinear_upsample(lo -> skip's H x W, align_corners=False), skip) along channels, both channels_last
-    bf16 [N,C,h,w]; returns a channels_last [N,C1+C2,H,W] tensor (gdkvm_upsample_cat)."""
+def _upsample_cat_fwd(lo: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:
     lib = load()
     for t in (lo, skip):
         if t.dim() != 4 or not t.is_cuda or not t.is_contiguous(memory_format=torch.channels_last):
@@ -572,6 +574,125 @@ def upsample_cat(lo: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:
         rc = lib.gdkvm_upsample_cat(lo.data_ptr(), skip.data_ptr(), out.data_ptr(), n, hl, wl, H, W, c1, c2, BF16, _stream(lo.device))
     _check(rc, "gdkvm_upsample_cat")
     return out
+
+
+def upsample_cat_bwd(dout: torch.Tensor, lo_shape, skip_shape) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(d_lo, d_skip) of upsample_cat for d_out [N,C1+C2,H,W] channels_last bf16 (gdkvm_upsample_cat_bwd)."""
+    lib = load()
+    dout = _nhwc(dout, "upsample_cat_bwd")
+    if dout.dtype != torch.bfloat16:
+        dout = dout.to(torch.bfloat16)
+    n, c1, hl, wl = lo_shape
+    _, c2, H, W = skip_shape
+    if tuple(dout.shape) != (n, c1 + c2, H, W):
+        raise GdkvmError(f"upsample_cat_bwd: d_out {tuple(dout.shape)} does not match {lo_shape} + {skip_shape}")
+    dlo = torch.empty((n, c1, hl, wl), dtype=dout.dtype, device=dout.device, memory_format=torch.channels_last)
+    dskip = torch.empty((n, c2, H, W), dtype=dout.dtype, device=dout.device, memory_format=torch.channels_last)
+    with torch.cuda.device(dout.device):
+        rc = lib.gdkvm_upsample_cat_bwd(dout.data_ptr(), dlo.data_ptr(), dskip.data_ptr(), n, hl, wl, H, W, c1, c2, BF16,
+                                        _stream(dout.device))
+    _check(rc, "gdkvm_upsample_cat_bwd")
+    return dlo, dskip
+
+
+class _UpsampleCatFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lo, skip):
+        ctx.shapes = (tuple(lo.shape), tuple(skip.shape))
+        return _upsample_cat_fwd(lo, skip)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return upsample_cat_bwd(dout, *ctx.shapes)
+
+
+def upsample_cat(lo: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:
+    """concat(bilinear_upsample(lo -> skip's H x W, align_corners=False), skip) along channels, both channels_last
+    bf16 [N,C,h,w]; returns a channels_last [N,C1+C2,H,W] tensor (gdkvm_upsample_cat; differentiable:
+    gdkvm_upsample_cat_bwd)."""
+    if torch.is_grad_enabled() and (lo.requires_grad or skip.requires_grad):
+        return _UpsampleCatFunction.apply(lo, skip)
+    return _upsample_cat_fwd(lo, skip)
+
+
+def _nhwc(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dim() != 4 or not t.is_cuda:
+        raise GdkvmError(f"{what}: needs a [N,C,H,W] device tensor (no CPU path)")
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def bn_act_fwd(x, weight, bias, running_mean=None, running_var=None, residual=None, momentum: float = 0.1, eps: float = 1e-5,
+               relu: bool = True):
+    """Batch-statistics BatchNorm + optional residual add + optional ReLU on a channels_last tensor in three streaming
+    passes (gdkvm_bn_fwd_train).  Updates running_mean / running_var in place.  Returns (y, save_mean, save_rstd)."""
+    lib = load()
+    x = _nhwc(x, "bn_act_fwd")
+    n, c, hh, ww = x.shape
+    if residual is not None:
+        residual = _nhwc(residual, "bn_act_fwd")
+        if residual.shape != x.shape or residual.dtype != x.dtype:
+            raise GdkvmError("bn_act_fwd: residual must match x (shape, dtype)")
+    for t in (weight, bias, running_mean, running_var):
+        if t is not None and (t.dtype != torch.float32 or t.numel() != c or not t.is_contiguous()):
+            raise GdkvmError("bn_act_fwd: weight / bias / running statistics must be contiguous float32 [C]")
+    y = torch.empty_like(x)
+    mean = torch.empty(c, dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    ws = torch.empty(int(lib.gdkvm_bn_workspace_bytes(c)), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.gdkvm_bn_fwd_train(x.data_ptr(), _ptr(residual), weight.data_ptr(), bias.data_ptr(), _ptr(running_mean),
+                                    _ptr(running_var), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    n * hh * ww, c, float(eps), float(momentum), int(relu), _io_dtype(x), _stream(x.device))
+    _check(rc, "gdkvm_bn_fwd_train")
+    return y, mean, rstd
+
+
+def bn_act_bwd(x, y, dy, weight, mean, rstd, relu: bool = True, want_dres: bool = False):
+    """Backward of bn_act_fwd (gdkvm_bn_bwd): returns (dx, dres | None, dweight, dbias)."""
+    lib = load()
+    x, dy = _nhwc(x, "bn_act_bwd"), _nhwc(dy, "bn_act_bwd")
+    if dy.dtype != x.dtype:
+        dy = dy.to(x.dtype)
+    if dy.shape != x.shape or (relu and (y is None or y.shape != x.shape)):
+        raise GdkvmError("bn_act_bwd: shape mismatch")
+    n, c, hh, ww = x.shape
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if (want_dres and relu) else None
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    ws = torch.empty(int(lib.gdkvm_bn_workspace_bytes(c)), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.gdkvm_bn_bwd(x.data_ptr(), _ptr(y) if relu else None, dy.data_ptr(), weight.data_ptr(), mean.data_ptr(),
+                              rstd.data_ptr(), dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+                              ws.numel(), n * hh * ww, c, int(relu), _io_dtype(x), _stream(x.device))
+    _check(rc, "gdkvm_bn_bwd")
+    if want_dres and not relu:
+        dres = dy                                           # no mask: the residual branch receives dy itself
+    return dx, dres, dgamma, dbeta
+
+
+class _BNActFunction(torch.autograd.Function):
+    """y = act(BatchNorm_train(x) (+ residual)) with the HIP passes of csrc/bn.hip in both directions."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu):
+        x = _nhwc(x, "bn_act")
+        y, mean, rstd = bn_act_fwd(x, weight, bias, running_mean, running_var, residual, momentum, eps, relu)
+        ctx.relu, ctx.has_res = relu, residual is not None
+        ctx.save_for_backward(x, y if relu else None, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, mean, rstd = ctx.saved_tensors
+        dx, dres, dgamma, dbeta = bn_act_bwd(x, y, dy, weight, mean, rstd, ctx.relu, ctx.has_res and ctx.needs_input_grad[3])
+        return dx, dgamma, dbeta, dres, None, None, None, None, None
+
+
+def bn_act(x, weight, bias, running_mean=None, running_var=None, residual=None, momentum: float = 0.1, eps: float = 1e-5,
+           relu: bool = True):
+    """Differentiable fused BatchNorm(batch statistics) (+ residual) (+ ReLU); see bn_act_fwd."""
+    return _BNActFunction.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu)
 
 
 def dice_from_counts(counts: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:

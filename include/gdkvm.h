@@ -193,10 +193,33 @@ int gdkvm_bias_relu_maxpool(const void* x, const float* bias, void* y, int N, in
  * a ceil(k/2)+... x stride 1 convolution on out (gdkvm_amd/model.py::FusedConvPool builds the 4x4 kernel of a 7x7 stem). */
 int gdkvm_stem_s2d(const void* x, void* out, int N, int C, int H, int W, int Cp, int io_dtype, void* stream);
 
-/* SURVEY.md §8(f) row n1 (inference build only): decoder glue, out = concat(bilinear_upsample(lo -> H x W), skip) over
+/* Row n1, the training side: BatchNorm in batch-statistics mode fused with the residual add and the ReLU that follow it
+ * (what torch.nn.BatchNorm2d(train) -> (+ skip) -> ReLU computes on an NHWC conv output), forward and backward.
+ * x, residual, y, dy, dx, dres: [rows, C] in io_dtype (rows = N*H*W of an NHWC tensor, C a multiple of 8 (bf16) / 4 (f32));
+ * gamma, beta, running_*, save_*, dgamma, dbeta: fp32 [C].
+ *   fwd:  mean, var (biased) over the rows;  y = act(gamma (x - mean) / sqrt(var + eps) + beta (+ residual));
+ *         running = (1 - momentum) running + momentum stat (variance unbiased; either pointer may be NULL);
+ *         save_mean / save_rstd feed the backward.
+ *   bwd:  g = dy masked by y > 0 (relu) ;  dbeta = sum g,  dgamma = sum g xhat,  dx = gamma rstd (g - dbeta/n - xhat dgamma/n);
+ *         dres (optional) receives g, the gradient of the residual branch.  y is only read when relu != 0.
+ * Deterministic (no atomics).  ws: gdkvm_bn_workspace_bytes(C) bytes of scratch per call. */
+size_t gdkvm_bn_workspace_bytes(int C);
+int gdkvm_bn_fwd_train(const void* x, const void* residual, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, void* y, float* save_mean, float* save_rstd,
+                       void* ws, size_t ws_bytes, long long rows, int C, float eps, float momentum, int relu,
+                       int io_dtype, void* stream);
+int gdkvm_bn_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* save_mean,
+                 const float* save_rstd, void* dx, void* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                 long long rows, int C, int relu, int io_dtype, void* stream);
+
+/* decoder glue, out = concat(bilinear_upsample(lo -> H x W), skip) over
  * NHWC tensors  lo [N,hl,wl,C1], skip [N,H,W,C2], out [N,H,W,C1+C2]; align_corners = false; bf16 only. */
 int gdkvm_upsample_cat(const void* lo, const void* skip, void* out,
                        int Nimg, int hl, int wl, int H, int W, int C1, int C2, int io_dtype, void* stream);
+/* Backward of gdkvm_upsample_cat (training): dlo [Nimg, hl, wl, C1] = transpose of the bilinear enlargement applied to
+ * dout[..., :C1] (a deterministic gather: no atomics), dskip [Nimg, H, W, C2] = dout[..., C1:].  bf16 only. */
+int gdkvm_upsample_cat_bwd(const void* dout, void* dlo, void* dskip,
+                           int Nimg, int hl, int wl, int H, int W, int C1, int C2, int io_dtype, void* stream);
 
 #ifdef __cplusplus
 }

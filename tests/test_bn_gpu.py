@@ -1,0 +1,133 @@
+"""Row n1, training side: the fused BatchNorm (+ residual) (+ ReLU) passes (csrc/bn.hip) and the decoder glue's backward
+(gdkvm_upsample_cat_bwd) against torch autograd in fp64 on the CPU, same inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(8, 64, 28, 28), (3, 128, 7, 5), (2, 256, 7, 7), (5, 24, 9, 4), (2, 8, 1, 2), (16, 64, 56, 56)]
+
+
+def _reference(x, w, b, res, relu, dy, mask, eps=1e-5):
+    x64 = x.double().cpu().requires_grad_(True)
+    w64, b64 = w.double().cpu().requires_grad_(True), b.double().cpu().requires_grad_(True)
+    r64 = None if res is None else res.double().cpu().requires_grad_(True)
+    rm, rv = torch.zeros(x.shape[1], dtype=torch.float64), torch.ones(x.shape[1], dtype=torch.float64)
+    y = F.batch_norm(x64, rm, rv, w64, b64, True, 0.1, eps)
+    if r64 is not None:
+        y = y + r64
+    if relu:                                    # the mask of the run under test: an output within one rounding of zero may
+        y = y * mask.double().cpu()             # legitimately fall on either side
+    y.backward(dy.double().cpu())
+    return y.detach(), x64.grad, w64.grad, b64.grad, (None if r64 is None else r64.grad), rm, rv
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("mode", ["relu", "plain", "res_relu", "res"])
+def test_bn_act_forward_backward(hip, dtype, shape, mode):
+    if dtype == torch.float32 and shape[1] % 4:
+        pytest.skip("fp32 needs C % 4 == 0")
+    torch.manual_seed(sum(shape) + len(mode))
+    relu, has_res = "relu" in mode, "res" in mode
+    cl = dict(memory_format=torch.channels_last)
+    x = (3.0 + 2.0 * torch.randn(shape, device="cuda")).to(dtype).contiguous(**cl)
+    res = torch.randn(shape, device="cuda").to(dtype).contiguous(**cl) if has_res else None
+    w = torch.rand(shape[1], device="cuda") + 0.5
+    b = 0.3 * torch.randn(shape[1], device="cuda")
+    dy = torch.randn(shape, device="cuda").to(dtype).contiguous(**cl)
+    rm, rv = torch.zeros(shape[1], device="cuda"), torch.ones(shape[1], device="cuda")
+    xg = x.clone(**cl).requires_grad_(True)
+    wg, bg = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    rg = None if res is None else res.clone(**cl).requires_grad_(True)
+    y = hip.bn_act(xg, wg, bg, rm, rv, rg, 0.1, 1e-5, relu)
+    assert y.dtype == dtype and y.is_contiguous(**cl)
+    y.backward(dy)
+    y_ref, dx_ref, dw_ref, db_ref, dr_ref, rm_ref, rv_ref = _reference(x, w, b, res, relu, dy, y.detach() > 0)
+    # forward: fp32 arithmetic on the same inputs, one rounding to the io dtype
+    eps_io = 2.0 ** -8 if dtype == torch.bfloat16 else 1e-5
+    assert (y.double().cpu() - y_ref).abs().max() <= eps_io * max(1.0, y_ref.abs().max().item())
+    assert (rm.double().cpu() - rm_ref).abs().max() <= 1e-5 and (rv.double().cpu() - rv_ref).abs().max() <= 1e-4
+    tol = 3e-2 if dtype == torch.bfloat16 else 2e-4
+    scale = max(dx_ref.abs().max().item(), 1e-6)
+    assert (xg.grad.double().cpu() - dx_ref).abs().max() <= tol * scale
+    assert (wg.grad.double().cpu() - dw_ref).abs().max() <= tol * max(dw_ref.abs().max().item(), 1.0)
+    assert (bg.grad.double().cpu() - db_ref).abs().max() <= tol * max(db_ref.abs().max().item(), 1.0)
+    if has_res:
+        assert (rg.grad.double().cpu() - dr_ref).abs().max() <= tol * max(dr_ref.abs().max().item(), 1.0)
+
+
+def test_bn_variance_of_a_far_from_zero_signal(hip):
+    """|mean| = 1000 std: a plain sum-of-squares variance in fp32 would lose every digit; the shifted sums do not."""
+    torch.manual_seed(0)
+    x = (500.0 + 0.5 * torch.randn(4, 32, 16, 16, device="cuda")).contiguous(memory_format=torch.channels_last)
+    w, b = torch.ones(32, device="cuda"), torch.zeros(32, device="cuda")
+    y, mean, rstd = hip.bn_act_fwd(x, w, b, relu=False)
+    x64 = x.double().cpu()
+    var = x64.var((0, 2, 3), unbiased=False)
+    assert (mean.double().cpu() - x64.mean((0, 2, 3))).abs().max() < 1e-3
+    assert ((1.0 / rstd.double().cpu() ** 2 - 1e-5) / var - 1).abs().max() < 1e-3
+
+
+def test_bn_is_deterministic(hip):
+    torch.manual_seed(1)
+    x = torch.randn(32, 64, 28, 28, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    w, b = torch.rand(64, device="cuda"), torch.rand(64, device="cuda")
+    dy = torch.randn_like(x)
+    outs = []
+    for _ in range(2):
+        y, mean, rstd = hip.bn_act_fwd(x, w, b, relu=True)
+        outs.append((y, mean, rstd) + tuple(t for t in hip.bn_act_bwd(x, y, dy, w, mean, rstd, True, True)))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+
+
+def test_bn_module_path_matches_torch_batchnorm(hip):
+    """model._bn_act on a BatchNorm2d in training mode: same output, same running statistics, same parameter gradients as
+    torch's own BatchNorm2d -> ReLU (fp32)."""
+    from gdkvm_amd.model import _bn_act
+    torch.manual_seed(2)
+    bn_a, bn_b = torch.nn.BatchNorm2d(32).cuda().train(), torch.nn.BatchNorm2d(32).cuda().train()
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5); bn_a.bias.normal_()
+    bn_b.load_state_dict(bn_a.state_dict())
+    x = torch.randn(6, 32, 10, 10, device="cuda").contiguous(memory_format=torch.channels_last)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = _bn_act(bn_a, xa, True)
+    yb = F.relu(bn_b(xb))
+    assert torch.allclose(ya, yb, atol=1e-5, rtol=1e-5)
+    (ya * ya).sum().backward(); (yb * yb).sum().backward()
+    assert torch.allclose(xa.grad, xb.grad, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(bn_a.weight.grad, bn_b.weight.grad, atol=1e-3, rtol=1e-4)
+    assert torch.allclose(bn_a.bias.grad, bn_b.bias.grad, atol=1e-3, rtol=1e-4)
+    assert torch.allclose(bn_a.running_mean, bn_b.running_mean, atol=1e-6)
+    assert torch.allclose(bn_a.running_var, bn_b.running_var, atol=1e-6)
+    assert int(bn_a.num_batches_tracked) == 1
+
+
+def test_bn_rejects_bad_arguments(hip):
+    x = torch.randn(2, 12, 4, 4, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    w = torch.ones(12, device="cuda")
+    with pytest.raises(hip.GdkvmError):
+        hip.bn_act_fwd(x, w, w)                                   # C = 12 is not a multiple of 8 in bf16
+    with pytest.raises(hip.GdkvmError):
+        hip.bn_act_fwd(x.cpu(), w.cpu(), w.cpu())                 # no CPU path
+
+
+@pytest.mark.parametrize("case", [(4, 256, 7, 7, 128, 14, 14), (2, 128, 14, 14, 64, 28, 28), (1, 16, 5, 3, 8, 9, 7),
+                                  (2, 8, 6, 6, 8, 13, 11), (1, 8, 1, 1, 8, 2, 2), (2, 8, 9, 8, 16, 4, 5)])
+def test_upsample_cat_backward(hip, case):
+    n, c1, hl, wl, c2, H, W = case
+    torch.manual_seed(sum(case))
+    cl = dict(memory_format=torch.channels_last)
+    lo = torch.randn(n, c1, hl, wl, device="cuda").bfloat16().contiguous(**cl).requires_grad_(True)
+    sk = torch.randn(n, c2, H, W, device="cuda").bfloat16().contiguous(**cl).requires_grad_(True)
+    dout = torch.randn(n, c1 + c2, H, W, device="cuda").bfloat16().contiguous(**cl)
+    out = hip.upsample_cat(lo, sk)
+    out.backward(dout)
+    lo64 = lo.detach().double().cpu().requires_grad_(True)
+    up = F.interpolate(lo64, size=(H, W), mode="bilinear", align_corners=False)
+    up.backward(dout[:, :c1].double().cpu())
+    assert torch.equal(sk.grad, dout[:, c1:])
+    assert (lo.grad.double().cpu() - lo64.grad).abs().max() <= 2.0 ** -7 * max(lo64.grad.abs().max().item(), 1.0)
