@@ -128,7 +128,16 @@ __device__ __forceinline__ void sum_partials(const float* part, int nblk, int C,
     const int tid = threadIdx.x, c = blockIdx.x * 32 + (tid & 31), stat = (tid >> 5) & 1, sub = tid >> 6;
     float acc = 0.f;
     if (c < C)
-        for (int b = sub; b < nblk; b += 16) acc += part[(size_t)b * 2 * C + stat * C + c];
+        for (int b0 = sub; b0 < nblk; b0 += 16 * 8) {     // eight independent loads per trip (a dynamic-trip-count loop of
+            float t[8];                                    // dependent adds was one L2 round trip per partial row: 11 us)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 16 * u;
+                t[u] = b < nblk ? part[(size_t)b * 2 * C + stat * C + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += t[u];
+        }
     s[sub][tid & 63] = acc;
     __syncthreads();
     S1 = S2 = 0.f;

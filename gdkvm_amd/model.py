@@ -102,7 +102,13 @@ class Encoder(nn.Module):
     def forward(self, x):
         s = self.stem
         if len(s) == 4 and isinstance(s[1], nn.BatchNorm2d):                  # training build: conv, fused BN + ReLU, pool
-            x = s[3](_bn_act(s[1], s[0](x), True))
+            x = _bn_act(s[1], s[0](x), True)
+            p = s[3]
+            if (x.is_cuda and isinstance(p, nn.MaxPool2d) and (p.kernel_size, p.stride, p.padding, p.dilation, p.ceil_mode) == (3, 2, 1, 1, False)
+                    and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0 and x.dtype in (torch.bfloat16, torch.float32)):
+                x = ops.maxpool3x3s2(x)                   # HIP pool + gather backward
+            else:
+                x = p(x)
         else:
             x = s(x)
         f4 = self.layer1(x)
@@ -333,8 +339,13 @@ class GDKVM(nn.Module):
         p_tok = self._tokens(f16)                                                # [BT,N,Cp] view, no copy
         tok2d = p_tok.reshape(B * T * N, -1)
 
+        train_gpu = tok2d.is_cuda and torch.is_grad_enabled() and tok2d.requires_grad
+
         def proj(conv):
-            return F.linear(tok2d, conv.weight.reshape(conv.out_channels, -1), conv.bias)
+            w2 = conv.weight.reshape(conv.out_channels, -1)
+            if train_gpu and conv.out_channels >= 8:         # weight gradient over the B*T*N token axis: split-K (ops.wgrad)
+                return ops.token_linear(tok2d, w2, conv.bias)
+            return F.linear(tok2d, w2, conv.bias)
 
         k_tok = proj(self.key_proj).reshape(B * T, N, Hh * Dk)                   # local key feature
         q = proj(self.query_proj).reshape(B, T, N, Hh, Dk)

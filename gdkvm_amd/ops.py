@@ -46,6 +46,8 @@ SIGNATURES = {
     "gdkvm_bias_relu_maxpool": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
     "gdkvm_stem_s2d": (_i, [_vp] * 2 + [_i] * 6 + [_vp]),
     "gdkvm_upsample_argmax_dice": (_i, [_vp] * 4 + [_i] * 7 + [_vp]),
+    "gdkvm_maxpool_fwd": (_i, [_vp] * 3 + [_i] * 5 + [_vp]),
+    "gdkvm_maxpool_bwd": (_i, [_vp] * 3 + [_i] * 5 + [_vp]),
     "gdkvm_bn_workspace_bytes": (_sz, [_i]),
     "gdkvm_bn_fwd_train": (_i, [_vp] * 10 + [_sz, ctypes.c_longlong, _i, ctypes.c_float, ctypes.c_float, _i, _i, _vp]),
     "gdkvm_bn_bwd": (_i, [_vp] * 11 + [_sz, ctypes.c_longlong, _i, _i, _i, _vp]),
@@ -450,9 +452,9 @@ class _KpffFunction(torch.autograd.Function):
         dx = dz @ wa_c                                   # [M, Cin]      plain library GEMMs from here ...
         dl_add = dlp @ wl_c                              # [M, Ck]
         dg_add = dgp @ wg_c                              # [M, Cv]
-        d_wa = torch.cat([dz.t() @ P2, dz.t() @ L2, dz.t() @ gms], 1).float()
-        d_wl = (dlp.t() @ L2).float()
-        d_wg = (dgp.t() @ gms).float()                   # ... to here
+        d_wa = torch.cat([wgrad(dz, P2), wgrad(dz, L2), wgrad(dz, gms)], 1)       # K = B*T*N tokens: split-K, fp32 partials
+        d_wl = wgrad(dlp, L2)
+        d_wg = wgrad(dgp, gms)                           # ... to here
         d_ba = dz.float().sum(0)
         d_p, d_l, d_g = torch.empty_like(pixel), torch.empty_like(local), torch.empty((BT, N, Cv), dtype=dt, device=dev)
         with torch.cuda.device(dev):
@@ -693,6 +695,82 @@ def bn_act(x, weight, bias, running_mean=None, running_var=None, residual=None, 
            relu: bool = True):
     """Differentiable fused BatchNorm(batch statistics) (+ residual) (+ ReLU); see bn_act_fwd."""
     return _BNActFunction.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu)
+
+
+class _MaxPoolFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = load()
+        x = _nhwc(x, "maxpool3x3s2")
+        n, c, hh, ww = x.shape
+        ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+        y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.gdkvm_maxpool_fwd(x.data_ptr(), y.data_ptr(), idx.data_ptr(), n, hh, ww, c, _io_dtype(x), _stream(x.device))
+        _check(rc, "gdkvm_maxpool_fwd")
+        ctx.save_for_backward(idx)
+        ctx.in_shape = (n, c, hh, ww)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load()
+        (idx,) = ctx.saved_tensors
+        n, c, hh, ww = ctx.in_shape
+        dy = _nhwc(dy, "maxpool3x3s2 backward")
+        dx = torch.empty((n, c, hh, ww), dtype=dy.dtype, device=dy.device, memory_format=torch.channels_last)
+        with torch.cuda.device(dy.device):
+            rc = lib.gdkvm_maxpool_bwd(dy.data_ptr(), idx.data_ptr(), dx.data_ptr(), n, hh, ww, c, _io_dtype(dy), _stream(dy.device))
+        _check(rc, "gdkvm_maxpool_bwd")
+        return dx
+
+
+def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
+    """max_pool2d(x, 3, 2, 1) on a channels_last tensor, differentiable (gdkvm_maxpool_fwd / _bwd: the backward is a gather
+    from the recorded winning taps, PyTorch's tie rule)."""
+    return _MaxPoolFunction.apply(x)
+
+
+def wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, splits: int = 16) -> torch.Tensor:
+    """dW [M,N] (fp32) = dy^T x for token-major operands dy [K,M], x [K,N] with K (tokens of the batch) >> M, N.  As one
+    library GEMM the K = 25088 reduction of cfg4 lands on four to sixteen workgroups (85-137 us per product,
+    tools/wgrad_probe.py); as a batched split-K call with fp32 partials it is 25-28 us and carries no bf16 rounding of the sum."""
+    K, M = dy2d.shape
+    if dy2d.dtype != x2d.dtype:
+        x2d = x2d.to(dy2d.dtype)
+    if K % splits or K // splits < 64 or not dy2d.is_contiguous() or not x2d.is_contiguous():
+        return (dy2d.t() @ x2d).float()
+    a3 = dy2d.view(splits, K // splits, M).transpose(1, 2)
+    b3 = x2d.view(splits, K // splits, x2d.shape[1])
+    if dy2d.dtype == torch.float32:
+        return torch.bmm(a3, b3).sum(0)
+    return torch.bmm(a3, b3, out_dtype=torch.float32).sum(0)
+
+
+class _TokenLinear(torch.autograd.Function):
+    """y = x W^T + b on token rows [K, Cin] (the 1x1 projections).  Forward: one library GEMM with the bias in its epilogue;
+    backward: dX as a library GEMM, dW through wgrad (split-K)."""
+
+    @staticmethod
+    def forward(ctx, x2d, weight, bias):
+        w = weight.to(x2d.dtype)
+        ctx.save_for_backward(x2d, w)
+        ctx.has_bias, ctx.wdtype = bias is not None, weight.dtype
+        return torch.nn.functional.linear(x2d, w, None if bias is None else bias.to(x2d.dtype))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy @ w if ctx.needs_input_grad[0] else None
+        dw = wgrad(dy, x2d).to(ctx.wdtype) if ctx.needs_input_grad[1] else None
+        db = dy.float().sum(0).to(ctx.wdtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def token_linear(x2d: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    return _TokenLinear.apply(x2d, weight, bias)
 
 
 def dice_from_counts(counts: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:

@@ -188,6 +188,13 @@ int gdkvm_bias_act(const void* x, const float* bias, const void* residual, void*
 int gdkvm_bias_relu_maxpool(const void* x, const float* bias, void* y, int N, int H, int W, int C,
                             int x_rows, int x_cols, int io_dtype, void* stream);
 
+/* Row n1, the training stem: 3x3 / stride 2 / pad 1 max-pool of an NHWC tensor x [N, H, W, C] -> y [N, Ho, Wo, C]
+ * (Ho = (H-1)/2+1) recording the winning tap of every output element in idx (one byte each, [N, Ho, Wo, C]: 3*dy + dx in
+ * window coordinates; first maximum in scan order, NaN wins -- PyTorch's rule), and its backward: dx [N, H, W, C] gathers dy
+ * from the at most four windows that contain a pixel (deterministic, dx written once). */
+int gdkvm_maxpool_fwd(const void* x, void* y, void* idx, int N, int H, int W, int C, int io_dtype, void* stream);
+int gdkvm_maxpool_bwd(const void* dy, const void* idx, void* dx, int N, int H, int W, int C, int io_dtype, void* stream);
+
 /* Row n1, the stem input: NCHW frames x [N, C, H, W] (H, W even) -> the space-to-depth image out [N, H/2, W/2, Cp] (NHWC),
  * out[n, i, j, (c*2 + p)*2 + q] = x[n, c, 2i + p, 2j + q], channels 4C .. Cp-1 zero.  A k x k / stride 2 convolution on x is
  * a ceil(k/2)+... x stride 1 convolution on out (gdkvm_amd/model.py::FusedConvPool builds the 4x4 kernel of a 7x7 stem). */

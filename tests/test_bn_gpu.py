@@ -131,3 +131,51 @@ def test_upsample_cat_backward(hip, case):
     up.backward(dout[:, :c1].double().cpu())
     assert torch.equal(sk.grad, dout[:, c1:])
     assert (lo.grad.double().cpu() - lo64.grad).abs().max() <= 2.0 ** -7 * max(lo64.grad.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(3, 16, 9, 11), (2, 64, 56, 56), (1, 8, 1, 1), (2, 24, 4, 7), (2, 8, 2, 5)])
+def test_maxpool_forward_and_gather_backward(hip, dtype, shape):
+    """Values bit-equal to torch's max_pool2d; gradients equal to torch's backward, ties included (coarse values force many)."""
+    if dtype == torch.float32 and shape[1] % 4 or dtype == torch.bfloat16 and shape[1] % 8:
+        pytest.skip("channel multiple")
+    torch.manual_seed(sum(shape))
+    cl = dict(memory_format=torch.channels_last)
+    x = (torch.randn(shape, device="cuda") * 2).round().div(2).clamp_min(0).to(dtype).contiguous(**cl)     # ReLU-like, many ties
+    dy_shape = (shape[0], shape[1], (shape[2] - 1) // 2 + 1, (shape[3] - 1) // 2 + 1)
+    dy = torch.randn(dy_shape, device="cuda").to(dtype).contiguous(**cl)
+    xa, xb = x.clone(**cl).requires_grad_(True), x.clone(**cl).float().requires_grad_(True)
+    ya = hip.maxpool3x3s2(xa)
+    yb = F.max_pool2d(xb, 3, 2, 1)
+    assert torch.equal(ya.float(), yb)
+    ya.backward(dy); yb.backward(dy.float())
+    assert (xa.grad.float() - xb.grad).abs().max() <= (2.0 ** -7 if dtype == torch.bfloat16 else 1e-6) * max(1.0, xb.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_token_linear_and_split_k_weight_gradient(hip, dtype):
+    torch.manual_seed(5)
+    K, cin, cout = 16 * 49 * 8, 64, 40
+    x = torch.randn(K, cin, device="cuda").to(dtype)
+    w = (torch.randn(cout, cin, device="cuda") / 8).requires_grad_(True)
+    b = torch.randn(cout, device="cuda").requires_grad_(True)
+    dy = torch.randn(K, cout, device="cuda").to(dtype)
+    xg = x.clone().requires_grad_(True)
+    y = hip.token_linear(xg, w, b)
+    y.backward(dy)
+    x64, w64, b64 = x.double().cpu().requires_grad_(True), w.detach().double().cpu().requires_grad_(True), b.detach().double().cpu().requires_grad_(True)
+    if dtype == torch.bfloat16:
+        w_used = w.detach().bfloat16().double().cpu()
+        y64 = x64 @ w_used.t() + b.detach().bfloat16().double().cpu()
+    else:
+        y64 = F.linear(x64, w64, b64)
+    tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-4
+    assert (y.double().cpu() - y64.detach()).abs().max() <= tol * y64.abs().max().item()
+    dw_ref = dy.double().cpu().t() @ x.double().cpu()
+    assert w.grad.dtype == torch.float32
+    assert (w.grad.double().cpu() - dw_ref).abs().max() <= 1e-5 * dw_ref.abs().max().item()        # fp32 partials: no bf16 rounding
+    assert (b.grad.double().cpu() - dy.double().cpu().sum(0)).abs().max() <= 1e-4 * K ** 0.5
+    dx_ref = dy.double().cpu() @ (w.detach().to(dtype).double().cpu())
+    assert (xg.grad.double().cpu() - dx_ref).abs().max() <= tol * dx_ref.abs().max().item()
+    # odd token counts fall back to the single GEMM
+    assert torch.allclose(hip.wgrad(dy[:1001], x[:1001]), (dy[:1001].float().t() @ x[:1001].float()), rtol=2e-2, atol=0.5)
