@@ -48,6 +48,9 @@ SIGNATURES = {
     "gdkvm_upsample_argmax_dice": (_i, [_vp] * 4 + [_i] * 7 + [_vp]),
     "gdkvm_maxpool_fwd": (_i, [_vp] * 3 + [_i] * 5 + [_vp]),
     "gdkvm_maxpool_bwd": (_i, [_vp] * 3 + [_i] * 5 + [_vp]),
+    "gdkvm_seg_loss_workspace_bytes": (_sz, [_i]),
+    "gdkvm_seg_loss_fwd": (_i, [_vp] * 4 + [_sz] + [_i] * 6 + [ctypes.c_float] * 2 + [_i, _i, _vp]),
+    "gdkvm_seg_loss_bwd": (_i, [_vp] * 3 + [_sz] + [_vp] * 2 + [_i] * 8 + [_vp]),
     "gdkvm_bn_workspace_bytes": (_sz, [_i]),
     "gdkvm_bn_fwd_train": (_i, [_vp] * 10 + [_sz, ctypes.c_longlong, _i, ctypes.c_float, ctypes.c_float, _i, _i, _vp]),
     "gdkvm_bn_bwd": (_i, [_vp] * 11 + [_sz, ctypes.c_longlong, _i, _i, _i, _vp]),
@@ -771,6 +774,47 @@ class _TokenLinear(torch.autograd.Function):
 
 def token_linear(x2d: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     return _TokenLinear.apply(x2d, weight, bias)
+
+
+class _SegLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, target, H, W, dice_weight, eps):
+        lib = load()
+        if z.dim() != 4 or not z.is_cuda or target.dim() != 3 or target.shape[0] != z.shape[0]:
+            raise GdkvmError("seg_loss: logits [images,C,h,w] and labels [images,H,W] on the device (no CPU path)")
+        if target.dtype not in (torch.int64, torch.uint8) or tuple(target.shape[1:]) != (H, W):
+            raise GdkvmError("seg_loss: labels must be int64 or uint8 [images,H,W]")
+        z, target = z.contiguous(), target.contiguous()
+        ni, c, h, w = z.shape
+        out = torch.empty(3, dtype=torch.float32, device=z.device)
+        ws = torch.empty(int(lib.gdkvm_seg_loss_workspace_bytes(c)), dtype=torch.uint8, device=z.device)
+        tb = 8 if target.dtype == torch.int64 else 1
+        with torch.cuda.device(z.device):
+            rc = lib.gdkvm_seg_loss_fwd(z.data_ptr(), target.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), ni, c, h, w, H, W,
+                                        float(dice_weight), float(eps), _io_dtype(z), tb, _stream(z.device))
+        _check(rc, "gdkvm_seg_loss_fwd")
+        ctx.save_for_backward(z, target, ws)
+        ctx.dims = (ni, c, h, w, H, W, tb)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = load()
+        z, target, ws = ctx.saved_tensors
+        ni, c, h, w, H, W, tb = ctx.dims
+        g = g.to(torch.float32).reshape(1).contiguous()
+        dz = torch.empty_like(z)
+        with torch.cuda.device(z.device):
+            rc = lib.gdkvm_seg_loss_bwd(z.data_ptr(), target.data_ptr(), ws.data_ptr(), ws.numel(), g.data_ptr(), dz.data_ptr(),
+                                        ni, c, h, w, H, W, _io_dtype(z), tb, _stream(z.device))
+        _check(rc, "gdkvm_seg_loss_bwd")
+        return dz, None, None, None, None, None
+
+
+def seg_loss(lowres_logits: torch.Tensor, target: torch.Tensor, dice_weight: float = 1.0, eps: float = 1.0) -> torch.Tensor:
+    """Cross-entropy + soft Dice of bilinear_upsample(lowres_logits -> target's H x W) against integer labels, without the
+    full-resolution logits (gdkvm_seg_loss_fwd / _bwd).  lowres_logits [images,C,h,w], target [images,H,W]; scalar loss."""
+    return _SegLossFunction.apply(lowres_logits, target, target.shape[-2], target.shape[-1], dice_weight, eps)
 
 
 def dice_from_counts(counts: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:

@@ -27,6 +27,14 @@ def segmentation_loss(logits: torch.Tensor, target: torch.Tensor, dice_weight: f
     return ce + dice_weight * dice
 
 
+def segmentation_loss_lowres(lowres_logits: torch.Tensor, target: torch.Tensor, dice_weight: float = 1.0, eps: float = 1.0) -> torch.Tensor:
+    """segmentation_loss(bilinear_upsample(lowres_logits -> target size), target) as one fused HIP forward / backward
+    (ops.seg_loss): the full-resolution logits, their softmax and one-hot tensors never exist.  [B,T,ncls,h,w] logits."""
+    from . import ops
+    B, T, C, h, w = lowres_logits.shape
+    return ops.seg_loss(lowres_logits.reshape(B * T, C, h, w), target.reshape(B * T, *target.shape[-2:]), dice_weight, eps)
+
+
 def wrap_ddp(model: nn.Module, device: Optional[torch.device] = None, bucket_cap_mb: int = 25) -> nn.Module:
     """DistributedDataParallel over the default process group (gradient all-reduce bucketed and overlapped with the
     backward).  xGMI is point-to-point, so buckets are kept large enough to amortise ring latency: the whole model is
@@ -43,12 +51,14 @@ def train_step(model: nn.Module, opt: torch.optim.Optimizer, frames: torch.Tenso
                autocast_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """forward -> loss -> backward (HIP backward kernels; DDP all-reduce if wrapped) -> optimiser step."""
     opt.zero_grad(set_to_none=True)
+    fused = frames.is_cuda                      # GPU: the objective is evaluated on the stride-4 logits by the HIP loss kernels
+    kw = {"_lowres": True} if fused else {}
     if autocast_dtype is not None:
         with torch.autocast(frames.device.type, dtype=autocast_dtype):
-            logits = model(frames)
+            logits = model(frames, **kw)
     else:
-        logits = model(frames)
-    loss = segmentation_loss(logits, target)
+        logits = model(frames, **kw)
+    loss = segmentation_loss_lowres(logits, target) if fused else segmentation_loss(logits, target)
     loss.backward()
     opt.step()
     return loss.detach()

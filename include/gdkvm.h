@@ -228,6 +228,20 @@ int gdkvm_upsample_cat(const void* lo, const void* skip, void* out,
 int gdkvm_upsample_cat_bwd(const void* dout, void* dlo, void* dskip,
                            int Nimg, int hl, int wl, int H, int W, int C1, int C2, int io_dtype, void* stream);
 
+/* Rows n1/n2, the training objective on the decoder's stride-4 logits z [images, C, h, w] (NCHW, io_dtype) and integer labels
+ * target [images, H, W] (target_bytes = 1: uint8, 8: int64), 2 <= C <= 8:
+ *   l = bilinear_upsample(z -> H x W, align_corners = false) in fp32;  p = softmax(l);
+ *   loss = mean CE(l, target) + dice_weight * (1 - mean_c (2 I_c + eps) / (P_c + O_c + eps)),  sums over the whole batch.
+ * fwd: out[0] = loss, out[1] = CE, out[2] = Dice term; ws keeps the per-class coefficients the backward needs.
+ * bwd: dz [images, C, h, w] = (*grad_out, or 1 if NULL) * dloss/dz -- a gather per stride-4 pixel, deterministic.
+ * Full-resolution logits are never materialised.  ws: gdkvm_seg_loss_workspace_bytes(C), the SAME buffer for fwd and bwd. */
+size_t gdkvm_seg_loss_workspace_bytes(int C);
+int gdkvm_seg_loss_fwd(const void* z, const void* target, float* out, void* ws, size_t ws_bytes,
+                       int images, int C, int h, int w, int H, int W, float dice_weight, float eps,
+                       int io_dtype, int target_bytes, void* stream);
+int gdkvm_seg_loss_bwd(const void* z, const void* target, const void* ws, size_t ws_bytes, const float* grad_out, void* dz,
+                       int images, int C, int h, int w, int H, int W, int io_dtype, int target_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,6 @@
-"""Row n1, training side: the fused BatchNorm (+ residual) (+ ReLU) passes (csrc/bn.hip) and the decoder glue's backward
-(gdkvm_upsample_cat_bwd) against torch autograd in fp64 on the CPU, same inputs."""
+"""Row n1, training side: the fused BatchNorm (+ residual) (+ ReLU) passes (csrc/bn.hip), the decoder glue's backward
+(gdkvm_upsample_cat_bwd), the stem max-pool, the split-K weight gradients and the fused objective (csrc/loss.hip), each
+against torch autograd (fp64 on the CPU where rounding matters), same inputs."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -179,3 +180,59 @@ def test_token_linear_and_split_k_weight_gradient(hip, dtype):
     assert (xg.grad.double().cpu() - dx_ref).abs().max() <= tol * dx_ref.abs().max().item()
     # odd token counts fall back to the single GEMM
     assert torch.allclose(hip.wgrad(dy[:1001], x[:1001]), (dy[:1001].float().t() @ x[:1001].float()), rtol=2e-2, atol=0.5)
+
+
+@pytest.mark.parametrize("case", [(6, 2, 28, 28, 112, 112, torch.int64), (3, 4, 64, 64, 256, 256, torch.uint8), (2, 3, 7, 5, 30, 17, torch.int64),
+                                  (1, 8, 4, 4, 4, 4, torch.int64), (2, 2, 9, 9, 5, 6, torch.uint8)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_objective_matches_the_torch_loss(hip, case, dtype):
+    """ops.seg_loss(lowres, target) == segmentation_loss(interpolate(lowres), target), value and gradient."""
+    from gdkvm_amd.train import segmentation_loss
+    ni, c, h, w, H, W, tdt = case
+    torch.manual_seed(sum(case[:6]))
+    z = (2.0 * torch.randn(ni, c, h, w, device="cuda")).to(dtype)
+    tgt = torch.randint(0, c, (ni, H, W), device="cuda").to(tdt)
+    za = z.clone().requires_grad_(True)
+    loss = hip.seg_loss(za, tgt, 0.7, 1.0)
+    (3.0 * loss).backward()
+    zb = z.double().cpu().requires_grad_(True)
+    up = F.interpolate(zb, size=(H, W), mode="bilinear", align_corners=False)
+    ref = segmentation_loss(up.reshape(1, ni, c, H, W), tgt.long().cpu().reshape(1, ni, H, W), 0.7, 1.0)
+    # segmentation_loss computes in fp32 internally (.float()): restate in fp64 for the check of the gradient
+    lg = up
+    ce = F.cross_entropy(lg, tgt.long().cpu())
+    p = lg.softmax(1)
+    oh = F.one_hot(tgt.long().cpu(), c).permute(0, 3, 1, 2).double()
+    dice = 1.0 - ((2 * (p * oh).sum((0, 2, 3)) + 1.0) / (p.sum((0, 2, 3)) + oh.sum((0, 2, 3)) + 1.0)).mean()
+    ref64 = ce + 0.7 * dice
+    (3.0 * ref64).backward()
+    assert abs(loss.item() - ref64.item()) <= 1e-5 * max(1.0, abs(ref64.item()))
+    assert abs(ref.item() - ref64.item()) <= 1e-4
+    tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-4
+    assert (za.grad.double().cpu() - zb.grad).abs().max() <= tol * zb.grad.abs().max().item()
+
+
+def test_train_step_uses_the_fused_objective(hip):
+    """train_step on the GPU (stride-4 logits + HIP loss) and the plain route (full-resolution logits + torch loss) give the
+    same loss and the same parameter gradients (fp32, no autocast)."""
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    from gdkvm_amd.train import segmentation_loss, segmentation_loss_lowres
+    torch.manual_seed(11)
+    cfg = GDKVMConfig(widths=(16, 32, 64), pixel_dim=64, value_dim=64)
+    model = GDKVM(cfg).cuda().train().to(memory_format=torch.channels_last)
+    frames = torch.rand(2, 3, 3, 64, 64, device="cuda")
+    target = (torch.rand(2, 3, 64, 64, device="cuda") > 0.5).long()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    la = segmentation_loss_lowres(model(frames, _lowres=True), target)
+    la.backward()
+    ga = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    model.load_state_dict(state)                       # same BatchNorm running statistics as before the first pass
+    lb = segmentation_loss(model(frames), target)
+    lb.backward()
+    assert abs(la.item() - lb.item()) <= 1e-5 * max(1.0, abs(lb.item()))
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        scale = max(p.grad.abs().max().item(), 1e-6)
+        assert (ga[n] - p.grad).abs().max().item() <= 2e-3 * scale, n
