@@ -149,9 +149,8 @@ __device__ __forceinline__ void sum_partials(const float* part, int nblk, int C,
 
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nblk, const void* x, int io,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           float* running_mean, float* running_var, float* save_mean,
-                                                           float* save_rstd, float* scale, float* shift, int M, int C, float eps,
-                                                           float momentum)
+                                                           float* running_mean, float* running_var, float* stats, int M, int C,
+                                                           float eps, float momentum)
 {
     float d1, d2;
     sum_partials(part, nblk, C, d1, d2);
@@ -164,8 +163,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         const float mean = (float)((double)k + m);
         const float rstd = (float)(1.0 / sqrt(var + (double)eps));
         const float sc = gamma[c] * rstd;
-        save_mean[c] = mean; save_rstd[c] = rstd;
-        scale[c] = sc; shift[c] = beta[c] - mean * sc;
+        stats[c] = mean; stats[C + c] = rstd;                                       // [4][C]: mean, rstd, scale, shift
+        stats[2 * C + c] = sc; stats[3 * C + c] = beta[c] - mean * sc;
         if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
         if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (M > 1 ? n / (n - 1.0) : 1.0));
     }
@@ -207,26 +206,31 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint4* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------------ backward
-// g = dy masked by the ReLU (y > 0);  S1 = sum g,  S2 = sum g (x - mean)  per channel.
-template <int IO, bool RELU>
+// g = dy masked by the ReLU;  S1 = sum g,  S2 = sum g (x - mean)  per channel.
+// MASK: 0 = no ReLU, 1 = from the saved output (y > 0), 2 = recomputed from x with the forward's own fma (x*scale + shift > 0:
+// the same expression bn_apply_kernel evaluated, so the same mask) -- the y tensor is then not read at all (no residual case).
+template <int IO, int MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restrict__ x, const uint4* __restrict__ y,
-                                                            const uint4* __restrict__ dy, const float* __restrict__ mean,
+                                                            const uint4* __restrict__ dy, const float* __restrict__ stats,
                                                             float* __restrict__ part, int M, int C, int G, int rows_per_block)
 {
     constexpr int V = VecOf<IO>::V, UNR = 4;
+    constexpr bool RELU = MASK == 1;
     Walk w(M, G, rows_per_block);
-    float s1[V], s2[V], mu[V];
+    float s1[V], s2[V], mu[V], sc[V], sh[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) s1[j] = s2[j] = 0.f;
     if (w.active) {
-        load_param<V>(mean, w.cg * V, mu);
+        load_param<V>(stats, w.cg * V, mu);
+        if constexpr (MASK == 2) { load_param<V>(stats + 2 * C, w.cg * V, sc); load_param<V>(stats + 3 * C, w.cg * V, sh); }
         auto eat = [&](const uint4& xa, const uint4& ya, const uint4& da) __attribute__((always_inline)) {
             float f[V], o[V], d[V];
             unpack<IO>(xa, f); unpack<IO>(da, d);
             if constexpr (RELU) unpack<IO>(ya, o);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                const float g = RELU ? (o[j] > 0.f ? d[j] : 0.f) : d[j];
+                if constexpr (MASK == 2) o[j] = fmaf(f[j], sc[j], sh[j]);
+                const float g = MASK ? (o[j] > 0.f ? d[j] : 0.f) : d[j];
                 s1[j] += g; s2[j] = fmaf(g, f[j] - mu[j], s2[j]);
             }
         };
@@ -249,38 +253,41 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restr
 
 // d_beta = S1, d_gamma = rstd S2;  dx = cA g + c1 (x - mean) + c0  with  cA = gamma rstd, c1 = -cA rstd^2 S2 / n, c0 = -cA S1 / n.
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk,
-                                                               const float* __restrict__ gamma, const float* __restrict__ save_rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ stats,
                                                                float* dgamma, float* dbeta, float* coef, int M, int C)
 {
     float S1, S2;
     sum_partials(part, nblk, C, S1, S2);
     const int c = blockIdx.x * 32 + threadIdx.x;
     if (threadIdx.x < 32 && c < C) {
-        const float rstd = save_rstd[c], cA = gamma[c] * rstd, inv_n = 1.f / (float)M;
+        const float rstd = stats[C + c], cA = gamma[c] * rstd, inv_n = 1.f / (float)M;
         dbeta[c] = S1; dgamma[c] = rstd * S2;
         coef[c] = cA; coef[C + c] = -cA * S1 * inv_n; coef[2 * C + c] = -cA * rstd * rstd * S2 * inv_n;
     }
 }
 
-template <int IO, bool RELU, bool DRES>
+template <int IO, int MASK, bool DRES>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const uint4* __restrict__ x, const uint4* __restrict__ y,
-                                                        const uint4* __restrict__ dy, const float* __restrict__ mean,
+                                                        const uint4* __restrict__ dy, const float* __restrict__ stats,
                                                         const float* __restrict__ coef, uint4* __restrict__ dx,
                                                         uint4* __restrict__ dres, int M, int C, int G, int rows_per_block)
 {
     constexpr int V = VecOf<IO>::V, UNR = 4;
+    constexpr bool RELU = MASK == 1;
     Walk w(M, G, rows_per_block);
     if (!w.active) return;
-    float mu[V], cA[V], c0[V], c1[V];
-    load_param<V>(mean, w.cg * V, mu); load_param<V>(coef, w.cg * V, cA);
+    float mu[V], cA[V], c0[V], c1[V], sc[V], sh[V];
+    load_param<V>(stats, w.cg * V, mu); load_param<V>(coef, w.cg * V, cA);
     load_param<V>(coef + C, w.cg * V, c0); load_param<V>(coef + 2 * C, w.cg * V, c1);
+    if constexpr (MASK == 2) { load_param<V>(stats + 2 * C, w.cg * V, sc); load_param<V>(stats + 3 * C, w.cg * V, sh); }
     auto finish = [&](size_t i, const uint4& xa, const uint4& ya, const uint4& da) __attribute__((always_inline)) {
         float f[V], o[V], d[V];
         unpack<IO>(xa, f); unpack<IO>(da, d);
         if constexpr (RELU) unpack<IO>(ya, o);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-            const float g = RELU ? (o[j] > 0.f ? d[j] : 0.f) : d[j];
+            if constexpr (MASK == 2) o[j] = fmaf(f[j], sc[j], sh[j]);
+            const float g = MASK ? (o[j] > 0.f ? d[j] : 0.f) : d[j];
             d[j] = g;
             f[j] = fmaf(cA[j], g, fmaf(c1[j], f[j] - mu[j], c0[j]));
         }
@@ -338,17 +345,18 @@ int bn_check(const char* who, long long M, int C, int io)
 
 extern "C" size_t gdkvm_bn_workspace_bytes(int C)
 {
-    return C > 0 ? ((size_t)BN_MAX_PART * 2 * C + 4 * (size_t)C) * sizeof(float) : 0;
+    return C > 0 ? ((size_t)BN_MAX_PART * 2 * C + 4 * (size_t)C) * sizeof(float) : 0;      // partial rows + backward coefficients
 }
 
 extern "C" int gdkvm_bn_fwd_train(const void* x, const void* residual, const float* gamma, const float* beta,
-                                  float* running_mean, float* running_var, void* y, float* save_mean, float* save_rstd,
+                                  float* running_mean, float* running_var, void* y, float* save_stats,
                                   void* ws, size_t ws_bytes, long long rows, int C, float eps, float momentum, int relu,
                                   int io_dtype, void* stream)
 {
     if (int rc = bn_check("bn_fwd_train", rows, C, io_dtype)) return rc;
-    if (!x || !gamma || !beta || !y || !save_mean || !save_rstd || !ws) return gdkvm_fail(GDKVM_ERR_ARG, "bn_fwd_train: null pointer");
-    if (!gdkvm_aligned16(x) || !gdkvm_aligned16(y) || !gdkvm_aligned16(ws) || (residual && !gdkvm_aligned16(residual)))
+    if (!x || !gamma || !beta || !y || !save_stats || !ws) return gdkvm_fail(GDKVM_ERR_ARG, "bn_fwd_train: null pointer");
+    if (!gdkvm_aligned16(x) || !gdkvm_aligned16(y) || !gdkvm_aligned16(ws) || !gdkvm_aligned16(save_stats)
+        || (residual && !gdkvm_aligned16(residual)))
         return gdkvm_fail(GDKVM_ERR_ARG, "bn_fwd_train: pointers must be 16-byte aligned");
     if (ws_bytes < gdkvm_bn_workspace_bytes(C)) return gdkvm_fail(GDKVM_ERR_ARG, "bn_fwd_train: workspace too small");
     if (int rc = gdkvm_check_device()) return rc;
@@ -356,8 +364,8 @@ extern "C" int gdkvm_bn_fwd_train(const void* x, const void* residual, const flo
     const BnPlan p = bn_plan(rows, C, V, 8);
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* part = static_cast<float*>(ws);
-    float* scale = part + (size_t)BN_MAX_PART * 2 * C;
-    float* shift = scale + C;
+    const float* scale = save_stats + 2 * (size_t)C;
+    const float* shift = save_stats + 3 * (size_t)C;
     const uint4* xv = static_cast<const uint4*>(x);
     const uint4* rv = static_cast<const uint4*>(residual);
     uint4* yv = static_cast<uint4*>(y);
@@ -365,7 +373,7 @@ extern "C" int gdkvm_bn_fwd_train(const void* x, const void* residual, const flo
     else hipLaunchKernelGGL((bn_stats_kernel<GDKVM_BF16>), dim3(p.nred), dim3(256), 0, st, xv, part, M, C, p.G, p.rpb_red);
     GDKVM_LAUNCH_CHECK("bn_stats_kernel");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, p.nred, x, io_dtype, gamma, beta,
-                       running_mean, running_var, save_mean, save_rstd, scale, shift, M, C, eps, momentum);
+                       running_mean, running_var, save_stats, M, C, eps, momentum);
     GDKVM_LAUNCH_CHECK("bn_finalize_kernel");
 #define GDKVM_BN_APPLY(IO, RL, RS) \
     hipLaunchKernelGGL((bn_apply_kernel<IO, RL, RS>), dim3(p.nmap), dim3(256), 0, st, xv, rv, scale, shift, yv, M, p.G, p.rpb_map)
@@ -381,15 +389,16 @@ extern "C" int gdkvm_bn_fwd_train(const void* x, const void* residual, const flo
     return GDKVM_OK;
 }
 
-extern "C" int gdkvm_bn_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* save_mean,
-                            const float* save_rstd, void* dx, void* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+extern "C" int gdkvm_bn_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* save_stats,
+                            void* dx, void* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                             long long rows, int C, int relu, int io_dtype, void* stream)
 {
     if (int rc = bn_check("bn_bwd", rows, C, io_dtype)) return rc;
-    if (!x || !dy || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !ws || (relu && !y))
+    if (relu < 0 || relu > 2) return gdkvm_fail(GDKVM_ERR_ARG, "bn_bwd: relu=%d (0 none, 1 mask from y, 2 mask recomputed from x)", relu);
+    if (!x || !dy || !gamma || !save_stats || !dx || !dgamma || !dbeta || !ws || (relu == 1 && !y))
         return gdkvm_fail(GDKVM_ERR_ARG, "bn_bwd: null pointer");
-    if (!gdkvm_aligned16(x) || !gdkvm_aligned16(dy) || !gdkvm_aligned16(dx) || !gdkvm_aligned16(ws) || (y && !gdkvm_aligned16(y))
-        || (dres && !gdkvm_aligned16(dres)))
+    if (!gdkvm_aligned16(x) || !gdkvm_aligned16(dy) || !gdkvm_aligned16(dx) || !gdkvm_aligned16(ws) || !gdkvm_aligned16(save_stats)
+        || (relu == 1 && !gdkvm_aligned16(y)) || (dres && !gdkvm_aligned16(dres)))
         return gdkvm_fail(GDKVM_ERR_ARG, "bn_bwd: pointers must be 16-byte aligned");
     if (ws_bytes < gdkvm_bn_workspace_bytes(C)) return gdkvm_fail(GDKVM_ERR_ARG, "bn_bwd: workspace too small");
     if (int rc = gdkvm_check_device()) return rc;
@@ -403,20 +412,22 @@ extern "C" int gdkvm_bn_bwd(const void* x, const void* y, const void* dy, const 
     const uint4* dv = static_cast<const uint4*>(dy);
     uint4* dxv = static_cast<uint4*>(dx);
     uint4* drv = static_cast<uint4*>(dres);
-#define GDKVM_BN_RED(IO, RL) \
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<IO, RL>), dim3(p.nred), dim3(256), 0, st, xv, yv, dv, save_mean, part, M, C, p.G, p.rpb_red)
-    if (io_dtype == GDKVM_F32) { if (relu) GDKVM_BN_RED(GDKVM_F32, true); else GDKVM_BN_RED(GDKVM_F32, false); }
-    else { if (relu) GDKVM_BN_RED(GDKVM_BF16, true); else GDKVM_BN_RED(GDKVM_BF16, false); }
+#define GDKVM_BN_RED(IO, MK) \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<IO, MK>), dim3(p.nred), dim3(256), 0, st, xv, yv, dv, save_stats, part, M, C, p.G, p.rpb_red)
+#define GDKVM_BN_RED_IO(IO) do { if (relu == 2) GDKVM_BN_RED(IO, 2); else if (relu) GDKVM_BN_RED(IO, 1); else GDKVM_BN_RED(IO, 0); } while (0)
+    if (io_dtype == GDKVM_F32) GDKVM_BN_RED_IO(GDKVM_F32); else GDKVM_BN_RED_IO(GDKVM_BF16);
+#undef GDKVM_BN_RED_IO
 #undef GDKVM_BN_RED
     GDKVM_LAUNCH_CHECK("bn_bwd_reduce_kernel");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, p.nred, gamma, save_rstd, dgamma, dbeta, coef, M, C);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, p.nred, gamma, save_stats, dgamma, dbeta, coef, M, C);
     GDKVM_LAUNCH_CHECK("bn_bwd_finalize_kernel");
-#define GDKVM_BN_DX(IO, RL, DR) \
-    hipLaunchKernelGGL((bn_bwd_dx_kernel<IO, RL, DR>), dim3(p.nmap), dim3(256), 0, st, xv, yv, dv, save_mean, coef, dxv, drv, M, C, p.G, p.rpb_map)
+#define GDKVM_BN_DX(IO, MK, DR) \
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<IO, MK, DR>), dim3(p.nmap), dim3(256), 0, st, xv, yv, dv, save_stats, coef, dxv, drv, M, C, p.G, p.rpb_map)
 #define GDKVM_BN_DX_IO(IO)                                                            \
     do {                                                                              \
-        if (relu) { if (dres) GDKVM_BN_DX(IO, true, true); else GDKVM_BN_DX(IO, true, false); }   \
-        else { if (dres) GDKVM_BN_DX(IO, false, true); else GDKVM_BN_DX(IO, false, false); }      \
+        if (relu == 2) { if (dres) GDKVM_BN_DX(IO, 2, true); else GDKVM_BN_DX(IO, 2, false); }      \
+        else if (relu) { if (dres) GDKVM_BN_DX(IO, 1, true); else GDKVM_BN_DX(IO, 1, false); }      \
+        else { if (dres) GDKVM_BN_DX(IO, 0, true); else GDKVM_BN_DX(IO, 0, false); }                \
     } while (0)
     if (io_dtype == GDKVM_F32) GDKVM_BN_DX_IO(GDKVM_F32); else GDKVM_BN_DX_IO(GDKVM_BF16);
 #undef GDKVM_BN_DX_IO

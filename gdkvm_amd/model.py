@@ -46,6 +46,9 @@ def _bn(c):
     return nn.BatchNorm2d(c)
 
 
+_BN_COUNTED_BY_MODEL = [False]
+
+
 def _bn_act(bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act(bn(x) (+ residual)).  Training mode on the GPU runs the fused HIP passes of csrc/bn.hip in both directions
     (ops.bn_act: statistics, normalise + add + ReLU; the library BatchNorm kernels were 38 % of a training step); eval mode of
@@ -55,12 +58,15 @@ def _bn_act(bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, residual: Optional[
             and x.shape[1] % v == 0 and x.shape[1] // v <= 256):
         momentum = bn.momentum
         if bn.track_running_stats:
-            bn.num_batches_tracked.add_(1)
+            if not _BN_COUNTED_BY_MODEL[0]:                 # GDKVM.forward bumps all counters in one foreach launch
+                bn.num_batches_tracked.add_(1)
             if momentum is None:
                 momentum = 1.0 / float(bn.num_batches_tracked)
         res = None if residual is None else residual.to(x.dtype)
         return ops.bn_act(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
                           bn.running_var if bn.track_running_stats else None, res, momentum or 0.0, bn.eps, relu)
+    if _BN_COUNTED_BY_MODEL[0] and bn.training and bn.track_running_stats:
+        bn.num_batches_tracked.sub_(1)                      # torch's own layer counts this step itself
     y = bn(x)
     if residual is not None:
         y = y + residual
@@ -323,14 +329,32 @@ class GDKVM(nn.Module):
         if frames.dim() != 5:
             raise ValueError("frames must be [B,T,C,H,W]")
         cfg = self.cfg
-        if not torch.is_autocast_enabled():
-            frames = frames.to(self.key_proj.weight.dtype)
         B, T, C, H, W = frames.shape
         Hh, Dk, Dv = cfg.heads, cfg.key_dim, cfg.value_dim
         x = frames.reshape(B * T, C, H, W)
-        if not (x.is_cuda and isinstance(self.encoder.stem[0], FusedConvPool) and getattr(self.encoder.stem[0], "w_s2d", None) is not None):
-            x = x.contiguous(memory_format=torch.channels_last)                  # (the space-to-depth stem reads NCHW frames itself)
-        f4, f8, f16 = self.encoder(x)
+        dt = self.key_proj.weight.dtype
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_dtype(x.device.type) if x.is_cuda else x.dtype
+        if x.is_cuda and isinstance(self.encoder.stem[0], FusedConvPool) and getattr(self.encoder.stem[0], "w_s2d", None) is not None:
+            x = x.to(dt)                                                         # (the space-to-depth stem reads NCHW frames itself)
+        else:
+            x = x.to(dtype=dt, memory_format=torch.channels_last)                # cast + NHWC in one pass
+        counted = self.training and x.is_cuda
+        if counted:                                                              # BatchNorm step counters: one launch, not 19
+            nbt = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.track_running_stats]
+            if nbt:
+                torch._foreach_add_(nbt, 1)
+        _BN_COUNTED_BY_MODEL[0] = counted
+        try:
+            f4, f8, f16 = self.encoder(x)
+            return self._after_encoder(f4, f8, f16, mask0, state, return_state, _lowres, (B, T, H, W))
+        finally:
+            _BN_COUNTED_BY_MODEL[0] = False
+
+    def _after_encoder(self, f4, f8, f16, mask0, state, return_state, _lowres, dims):
+        cfg = self.cfg
+        B, T, H, W = dims
+        Hh, Dk, Dv = cfg.heads, cfg.key_dim, cfg.value_dim
         h, w = f16.shape[-2:]
         N = h * w
         # The four 1x1 projections are token-major GEMMs on the (free) [BT*N, Cp] view of the channels_last feature, with

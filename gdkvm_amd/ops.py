@@ -52,8 +52,8 @@ SIGNATURES = {
     "gdkvm_seg_loss_fwd": (_i, [_vp] * 4 + [_sz] + [_i] * 6 + [ctypes.c_float] * 2 + [_i, _i, _vp]),
     "gdkvm_seg_loss_bwd": (_i, [_vp] * 3 + [_sz] + [_vp] * 2 + [_i] * 8 + [_vp]),
     "gdkvm_bn_workspace_bytes": (_sz, [_i]),
-    "gdkvm_bn_fwd_train": (_i, [_vp] * 10 + [_sz, ctypes.c_longlong, _i, ctypes.c_float, ctypes.c_float, _i, _i, _vp]),
-    "gdkvm_bn_bwd": (_i, [_vp] * 11 + [_sz, ctypes.c_longlong, _i, _i, _i, _vp]),
+    "gdkvm_bn_fwd_train": (_i, [_vp] * 9 + [_sz, ctypes.c_longlong, _i, ctypes.c_float, ctypes.c_float, _i, _i, _vp]),
+    "gdkvm_bn_bwd": (_i, [_vp] * 10 + [_sz, ctypes.c_longlong, _i, _i, _i, _vp]),
 }
 
 
@@ -629,7 +629,8 @@ def _nhwc(t: torch.Tensor, what: str) -> torch.Tensor:
 def bn_act_fwd(x, weight, bias, running_mean=None, running_var=None, residual=None, momentum: float = 0.1, eps: float = 1e-5,
                relu: bool = True):
     """Batch-statistics BatchNorm + optional residual add + optional ReLU on a channels_last tensor in three streaming
-    passes (gdkvm_bn_fwd_train).  Updates running_mean / running_var in place.  Returns (y, save_mean, save_rstd)."""
+    passes (gdkvm_bn_fwd_train).  Updates running_mean / running_var in place.  Returns (y, stats) with stats fp32 [4, C] =
+    (mean, 1/sqrt(var + eps), scale, shift)."""
     lib = load()
     x = _nhwc(x, "bn_act_fwd")
     n, c, hh, ww = x.shape
@@ -641,35 +642,36 @@ def bn_act_fwd(x, weight, bias, running_mean=None, running_var=None, residual=No
         if t is not None and (t.dtype != torch.float32 or t.numel() != c or not t.is_contiguous()):
             raise GdkvmError("bn_act_fwd: weight / bias / running statistics must be contiguous float32 [C]")
     y = torch.empty_like(x)
-    mean = torch.empty(c, dtype=torch.float32, device=x.device)
-    rstd = torch.empty_like(mean)
+    stats = torch.empty((4, c), dtype=torch.float32, device=x.device)
     ws = torch.empty(int(lib.gdkvm_bn_workspace_bytes(c)), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
         rc = lib.gdkvm_bn_fwd_train(x.data_ptr(), _ptr(residual), weight.data_ptr(), bias.data_ptr(), _ptr(running_mean),
-                                    _ptr(running_var), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    _ptr(running_var), y.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws.numel(),
                                     n * hh * ww, c, float(eps), float(momentum), int(relu), _io_dtype(x), _stream(x.device))
     _check(rc, "gdkvm_bn_fwd_train")
-    return y, mean, rstd
+    return y, stats
 
 
-def bn_act_bwd(x, y, dy, weight, mean, rstd, relu: bool = True, want_dres: bool = False):
-    """Backward of bn_act_fwd (gdkvm_bn_bwd): returns (dx, dres | None, dweight, dbias)."""
+def bn_act_bwd(x, y, dy, weight, stats, relu: bool = True, want_dres: bool = False):
+    """Backward of bn_act_fwd (gdkvm_bn_bwd): returns (dx, dres | None, dweight, dbias).  y = None with relu: the forward had
+    no residual and the ReLU mask is recomputed from x (one tensor less to read)."""
     lib = load()
     x, dy = _nhwc(x, "bn_act_bwd"), _nhwc(dy, "bn_act_bwd")
     if dy.dtype != x.dtype:
         dy = dy.to(x.dtype)
-    if dy.shape != x.shape or (relu and (y is None or y.shape != x.shape)):
+    if dy.shape != x.shape or (y is not None and y.shape != x.shape):
         raise GdkvmError("bn_act_bwd: shape mismatch")
     n, c, hh, ww = x.shape
+    mode = 0 if not relu else (2 if y is None else 1)
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if (want_dres and relu) else None
     dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
     dbeta = torch.empty_like(dgamma)
     ws = torch.empty(int(lib.gdkvm_bn_workspace_bytes(c)), dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        rc = lib.gdkvm_bn_bwd(x.data_ptr(), _ptr(y) if relu else None, dy.data_ptr(), weight.data_ptr(), mean.data_ptr(),
-                              rstd.data_ptr(), dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
-                              ws.numel(), n * hh * ww, c, int(relu), _io_dtype(x), _stream(x.device))
+        rc = lib.gdkvm_bn_bwd(x.data_ptr(), _ptr(y) if mode == 1 else None, dy.data_ptr(), weight.data_ptr(), stats.data_ptr(),
+                              dx.data_ptr(), _ptr(dres), dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(),
+                              ws.numel(), n * hh * ww, c, mode, _io_dtype(x), _stream(x.device))
     _check(rc, "gdkvm_bn_bwd")
     if want_dres and not relu:
         dres = dy                                           # no mask: the residual branch receives dy itself
@@ -682,15 +684,15 @@ class _BNActFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, residual, running_mean, running_var, momentum, eps, relu):
         x = _nhwc(x, "bn_act")
-        y, mean, rstd = bn_act_fwd(x, weight, bias, running_mean, running_var, residual, momentum, eps, relu)
+        y, stats = bn_act_fwd(x, weight, bias, running_mean, running_var, residual, momentum, eps, relu)
         ctx.relu, ctx.has_res = relu, residual is not None
-        ctx.save_for_backward(x, y if relu else None, weight, mean, rstd)
+        ctx.save_for_backward(x, y if (relu and residual is not None) else None, weight, stats)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, weight, mean, rstd = ctx.saved_tensors
-        dx, dres, dgamma, dbeta = bn_act_bwd(x, y, dy, weight, mean, rstd, ctx.relu, ctx.has_res and ctx.needs_input_grad[3])
+        x, y, weight, stats = ctx.saved_tensors
+        dx, dres, dgamma, dbeta = bn_act_bwd(x, y, dy, weight, stats, ctx.relu, ctx.has_res and ctx.needs_input_grad[3])
         return dx, dgamma, dbeta, dres, None, None, None, None, None
 
 

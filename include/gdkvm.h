@@ -203,20 +203,21 @@ int gdkvm_stem_s2d(const void* x, void* out, int N, int C, int H, int W, int Cp,
 /* Row n1, the training side: BatchNorm in batch-statistics mode fused with the residual add and the ReLU that follow it
  * (what torch.nn.BatchNorm2d(train) -> (+ skip) -> ReLU computes on an NHWC conv output), forward and backward.
  * x, residual, y, dy, dx, dres: [rows, C] in io_dtype (rows = N*H*W of an NHWC tensor, C a multiple of 8 (bf16) / 4 (f32));
- * gamma, beta, running_*, save_*, dgamma, dbeta: fp32 [C].
- *   fwd:  mean, var (biased) over the rows;  y = act(gamma (x - mean) / sqrt(var + eps) + beta (+ residual));
- *         running = (1 - momentum) running + momentum stat (variance unbiased; either pointer may be NULL);
- *         save_mean / save_rstd feed the backward.
- *   bwd:  g = dy masked by y > 0 (relu) ;  dbeta = sum g,  dgamma = sum g xhat,  dx = gamma rstd (g - dbeta/n - xhat dgamma/n);
- *         dres (optional) receives g, the gradient of the residual branch.  y is only read when relu != 0.
+ * gamma, beta, running_*, dgamma, dbeta: fp32 [C];  save_stats: fp32 [4][C] = mean, 1/sqrt(var+eps), scale, shift.
+ *   fwd:  mean, var (biased) over the rows;  y = act(x*scale + shift (+ residual)),  scale = gamma rstd, shift = beta - mean scale;
+ *         running = (1 - momentum) running + momentum stat (variance unbiased; either pointer may be NULL).
+ *   bwd:  g = dy masked by the ReLU;  dbeta = sum g,  dgamma = sum g xhat,  dx = gamma rstd (g - dbeta/n - xhat dgamma/n);
+ *         dres (optional) receives g, the gradient of the residual branch.
+ *         relu: 0 = none, 1 = mask from the saved output (y > 0), 2 = mask recomputed from x (x*scale + shift > 0, the forward's
+ *         own expression: valid when the forward had NO residual; y is then not read and may be NULL).
  * Deterministic (no atomics).  ws: gdkvm_bn_workspace_bytes(C) bytes of scratch per call. */
 size_t gdkvm_bn_workspace_bytes(int C);
 int gdkvm_bn_fwd_train(const void* x, const void* residual, const float* gamma, const float* beta,
-                       float* running_mean, float* running_var, void* y, float* save_mean, float* save_rstd,
+                       float* running_mean, float* running_var, void* y, float* save_stats,
                        void* ws, size_t ws_bytes, long long rows, int C, float eps, float momentum, int relu,
                        int io_dtype, void* stream);
-int gdkvm_bn_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* save_mean,
-                 const float* save_rstd, void* dx, void* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+int gdkvm_bn_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* save_stats,
+                 void* dx, void* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                  long long rows, int C, int relu, int io_dtype, void* stream);
 
 /* decoder glue, out = concat(bilinear_upsample(lo -> H x W), skip) over

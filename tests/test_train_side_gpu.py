@@ -64,7 +64,8 @@ def test_bn_variance_of_a_far_from_zero_signal(hip):
     torch.manual_seed(0)
     x = (500.0 + 0.5 * torch.randn(4, 32, 16, 16, device="cuda")).contiguous(memory_format=torch.channels_last)
     w, b = torch.ones(32, device="cuda"), torch.zeros(32, device="cuda")
-    y, mean, rstd = hip.bn_act_fwd(x, w, b, relu=False)
+    y, stats = hip.bn_act_fwd(x, w, b, relu=False)
+    mean, rstd = stats[0], stats[1]
     x64 = x.double().cpu()
     var = x64.var((0, 2, 3), unbiased=False)
     assert (mean.double().cpu() - x64.mean((0, 2, 3))).abs().max() < 1e-3
@@ -78,10 +79,13 @@ def test_bn_is_deterministic(hip):
     dy = torch.randn_like(x)
     outs = []
     for _ in range(2):
-        y, mean, rstd = hip.bn_act_fwd(x, w, b, relu=True)
-        outs.append((y, mean, rstd) + tuple(t for t in hip.bn_act_bwd(x, y, dy, w, mean, rstd, True, True)))
+        y, stats = hip.bn_act_fwd(x, w, b, relu=True)
+        outs.append((y, stats) + tuple(hip.bn_act_bwd(x, y, dy, w, stats, True, True)))
     for a, c in zip(*outs):
         assert torch.equal(a, c)
+    # the ReLU mask recomputed from x (no y read) is the mask of the saved output
+    dx2, _, dg2, db2 = hip.bn_act_bwd(x, None, dy, w, stats, True)
+    assert torch.equal(dx2, outs[0][2]) and torch.equal(dg2, outs[0][4]) and torch.equal(db2, outs[0][5])
 
 
 def test_bn_module_path_matches_torch_batchnorm(hip):
