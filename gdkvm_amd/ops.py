@@ -41,6 +41,7 @@ SIGNATURES = {
     "gdkvm_kpff_bwd_post": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "gdkvm_bias_act": (_i, [_vp] * 4 + [_sz] + [_i] * 3 + [_vp]),
+    "gdkvm_conv_bias_act": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
     "gdkvm_upsample_cat": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_upsample_cat_bwd": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_bias_relu_maxpool": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
@@ -523,6 +524,32 @@ def bias_act_(x: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tens
                                 n * hh * ww, c, int(relu), _io_dtype(x), _stream(x.device))
     _check(rc, "gdkvm_bias_act")
     return x
+
+
+def conv_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tensor] = None,
+                  stride: int = 1, padding: int = 1, relu: bool = True, tile: int = 0) -> torch.Tensor:
+    """act(conv2d(x, weight) + bias[k] (+ residual)) as ONE kernel on channels_last bf16 tensors (gdkvm_conv_bias_act): the
+    epilogue runs on the fp32 accumulator inside the implicit-GEMM kernel, no second pass over the output."""
+    lib = load()
+    if x.dim() != 4 or not x.is_cuda or x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("conv_bias_act needs a channels_last bf16 [N,C,H,W] device tensor (no CPU path)")
+    if weight.dim() != 4 or weight.dtype != torch.bfloat16 or weight.shape[1] != x.shape[1] or \
+            not weight.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("conv_bias_act: weight must be channels_last bf16 [K,C,R,S]")
+    n, c, hh, ww = x.shape
+    k, _, r, s = weight.shape
+    if bias.dtype != torch.float32 or bias.numel() != k:
+        raise GdkvmError("bias must be float32 [K]")
+    ho, wo = (hh + 2 * padding - r) // stride + 1, (ww + 2 * padding - s) // stride + 1
+    y = torch.empty((n, k, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if residual is not None and (residual.shape != y.shape or residual.dtype != y.dtype or
+                                 not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise GdkvmError("residual must match the output (shape, dtype, channels_last)")
+    with torch.cuda.device(x.device):
+        rc = lib.gdkvm_conv_bias_act(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(residual), y.data_ptr(),
+                                     n, c, hh, ww, k, r, s, stride, padding, int(relu), tile, BF16, _stream(x.device))
+    _check(rc, "gdkvm_conv_bias_act")
+    return y
 
 
 def bias_relu_maxpool(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:

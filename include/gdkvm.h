@@ -181,6 +181,17 @@ int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* target, uint8_
 int gdkvm_bias_act(const void* x, const float* bias, const void* residual, void* y,
                    size_t rows, int C, int relu, int io_dtype, void* stream);
 
+/* Row n1 (inference build): convolution with the folded-BatchNorm bias, the residual add and the ReLU in its epilogue,
+ *   y = act(conv(x, w) + bias[k] (+ residual)),  x [N, H, W, C] (NHWC), w [K, R, S, C] (channels_last weights), y / residual
+ *   [N, Ho, Wo, K], bias fp32 [K]; bf16 only; C and K multiples of 8.  The fp32 accumulator is rounded ONCE (after the epilogue).
+ * tile selects the implicit-GEMM tile configuration (composable_kernel templates, the configurations MIOpen's search picks
+ * for this network): 0 = 128x64x32 (64-channel 28x28 layers), 1 = 256x128x32 (128-channel 14x14), 2 = 128x128x64 (256-channel
+ * 7x7), 3 = 128x64x64 (deep-K 64-channel).  The choice is speed only: a configuration that cannot address a problem (very few
+ * channels) is replaced by tile 0. */
+int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y,
+                        int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, int tile,
+                        int io_dtype, void* stream);
+
 /* Row n1, the stem: bias + ReLU + 3x3 / stride 2 / pad 1 max-pool in one pass over the NHWC conv output
  * x [N, H, W, C] -> y [N, (H-1)/2+1, (W-1)/2+1, C]:  y = relu(max_window(x) + bias)  (== max_window(relu(x + bias)), the
  * rounding of x + b being monotonic).  The full-resolution activation is read once and never written back.  x may be the

@@ -169,3 +169,27 @@ def test_stem_s2d_and_its_convolution(hip, dtype):
     y7 = F.conv2d(x.float(), conv.weight.cuda().float(), None, 2, 3)
     y4 = F.conv2d(xs.float(), fc.w_s2d.float(), None, 1, 2)[:, :, :10, :12]
     assert (y7 - y4).abs().max().item() <= 1e-4 * max(1.0, y7.abs().max().item())
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("case", [(3, 64, 9, 11, 64, 1, True), (2, 16, 28, 28, 24, 2, False), (1, 128, 7, 7, 256, 1, True), (5, 8, 5, 4, 8, 1, False),
+                                  (2, 192, 12, 12, 64, 1, False)])
+def test_conv_with_fused_epilogue(hip, tile, case):
+    """gdkvm_conv_bias_act (every tile configuration) == act(conv2d + bias (+ residual)) computed in fp32 and rounded once."""
+    n, c, h, w, k, stride, with_res = case
+    torch.manual_seed(sum(case[:6]) + tile)
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(n, c, h, w, device="cuda").bfloat16().contiguous(**cl)
+    wt = (torch.randn(k, c, 3, 3, device="cuda") / (9 * c) ** 0.5).bfloat16().contiguous(**cl)
+    b = torch.randn(k, device="cuda")
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    r = torch.randn(n, k, ho, wo, device="cuda").bfloat16().contiguous(**cl) if with_res else None
+    for relu in (True, False):
+        got = hip.conv_bias_act(x, wt, b, r, stride, 1, relu, tile)
+        want = torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), stride, 1)
+        want = want + r.double() if with_res else want
+        want = want.relu() if relu else want
+        assert got.shape == want.shape and got.is_contiguous(**cl) and got.dtype == torch.bfloat16
+        assert (got.double() - want).abs().max() <= 2.0 ** -7 * max(1.0, want.abs().max().item())
+    with pytest.raises(hip.GdkvmError):
+        hip.conv_bias_act(x.float(), wt, b, r, stride, 1, True, tile)
