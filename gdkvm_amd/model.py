@@ -184,7 +184,7 @@ class FusedConv(nn.Module):
         """Tile configuration of gdkvm_conv_bias_act per layer shape, from tools/conv_probe.py at cfg2 (512 frames); None = the
         MIOpen convolution + epilogue pass is at least as fast there.  Any choice computes the same result: this is speed only."""
         if cout <= 64:
-            return 0 if has_res else 3
+            return 4 if cin == 64 else (0 if has_res else 3)        # 4: the hand-written 64 -> 64 kernel (csrc/conv3x3_c64.hip)
         if cout <= 128:
             if has_res:
                 return None

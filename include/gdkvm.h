@@ -186,7 +186,8 @@ int gdkvm_bias_act(const void* x, const float* bias, const void* residual, void*
  *   [N, Ho, Wo, K], bias fp32 [K]; bf16 only; C and K multiples of 8.  The fp32 accumulator is rounded ONCE (after the epilogue).
  * tile selects the implicit-GEMM tile configuration (composable_kernel templates, the configurations MIOpen's search picks
  * for this network): 0 = 128x64x32 (64-channel 28x28 layers), 1 = 256x128x32 (128-channel 14x14), 2 = 128x128x64 (256-channel
- * 7x7), 3 = 128x64x64 (deep-K 64-channel).  The choice is speed only: a configuration that cannot address a problem (very few
+ * 7x7), 3 = 128x64x64 (deep-K 64-channel); 4 = the hand-written 64 -> 64 channel 3x3 / stride 1 kernel (conv3x3_c64.hip: LDS halo
+ * band, weights in registers; other shapes fall to tile 3).  The choice is speed only: a configuration that cannot address a problem (very few
  * channels) is replaced by tile 0. */
 int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y,
                         int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, int tile,

@@ -171,9 +171,10 @@ def test_stem_s2d_and_its_convolution(hip, dtype):
     assert (y7 - y4).abs().max().item() <= 1e-4 * max(1.0, y7.abs().max().item())
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("case", [(3, 64, 9, 11, 64, 1, True), (2, 16, 28, 28, 24, 2, False), (1, 128, 7, 7, 256, 1, True), (5, 8, 5, 4, 8, 1, False),
-                                  (2, 192, 12, 12, 64, 1, False)])
+                                  (2, 192, 12, 12, 64, 1, False), (5, 64, 28, 28, 64, 1, True), (2, 64, 30, 41, 64, 1, False),
+                                  (1, 64, 64, 64, 64, 1, True), (3, 64, 1, 1, 64, 1, False), (700, 64, 6, 5, 64, 1, True)])
 def test_conv_with_fused_epilogue(hip, tile, case):
     """gdkvm_conv_bias_act (every tile configuration) == act(conv2d + bias (+ residual)) computed in fp32 and rounded once."""
     n, c, h, w, k, stride, with_res = case

@@ -48,7 +48,7 @@ def main():
                 z = torch.nn.functional.conv2d(x, w, None, st, pad)
                 return ops.bias_act_(z, b, r, True)
             line = f"{name:24s} {'+res' if res else '    '} miopen+epilogue {ev(mi):6.1f} us (conv {ev(lambda: torch.nn.functional.conv2d(x, w, None, st, pad)):6.1f}) | fused tiles:"
-            for t in range(4):
+            for t in range(5):
                 try:
                     y = ops.conv_bias_act(x, w, b, r, st, pad, True, t)
                     err = (y.float() - ref).abs().max().item() / ref.abs().max().item()
