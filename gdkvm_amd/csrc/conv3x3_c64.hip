@@ -17,6 +17,8 @@
 //     16-byte zero constant (the DMA writes lane-linear, so the padding slots are fetched from there too).
 // HBM traffic: input once (+ halo rows from L2), output once.  Arithmetic: fp32 accumulation over the same 576 products as the
 // library kernel, one rounding after the epilogue.
+#include <type_traits>
+
 #include "gdkvm_common.hpp"
 
 namespace {
@@ -58,17 +60,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(Conv64Args a)
         bia[nt][0] = b4[0]; bia[nt][1] = b4[1]; bia[nt][2] = b4[2]; bia[nt][3] = b4[3];
     }
 
-    // band fetch by LDS-DMA: piece j (64 consecutive 16-byte LDS slots) is issued by wave j % 4; slot d = 10 pix + c holds channel
-    // chunk c of band pixel pix (c = 8, 9: padding)
+    // band fetch by LDS-DMA: piece j = w + 4u (64 consecutive 16-byte LDS slots) is issued by wave w; slot d = 10 pix + c holds
+    // channel chunk c of band pixel pix (c = 8, 9: padding).  The slot geometry does not depend on the tile: kept in registers.
+    constexpr int PP = (NPIECES + 3) / 4;
+    int g_rel[PP], g_yx[PP];                               // element offset from the band's (0, 0) pixel; (by << 8 | bx), -1 = no data
+#pragma unroll
+    for (int u = 0; u < PP; ++u) {
+        const int j = w + 4 * u, d = 64 * j + lane, pix = d / 10, c = d - 10 * pix;
+        const int by = pix / BW, bx = pix - by * BW;
+        g_rel[u] = (by * a.W + bx) * CV_C + c * 8;
+        g_yx[u] = (j < NPIECES && c < 8 && pix < BAND_PIX) ? (by << 8 | bx) : -1;
+    }
     auto fetch = [&](int tile, int buf) __attribute__((always_inline)) {
         const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
         const int y0 = ty * CV_TH - 1, x0 = tx * TW - 1;
-        for (int j = w; j < NPIECES; j += 4) {
-            const int d = 64 * j + lane, pix = d / 10, c = d - 10 * pix;
-            const int by = pix / BW, bx = pix - by * BW, yy = y0 + by, xx = x0 + bx;
-            const bool ok = c < 8 && pix < BAND_PIX && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-            const bf16_t* src = ok ? a.x + ((((size_t)n * a.H + yy) * a.W + xx) * CV_C + c * 8)
-                                   : reinterpret_cast<const bf16_t*>(&g_conv_zero16);
+        const bf16_t* origin = a.x + (((long long)n * a.H + y0) * a.W + x0) * CV_C;
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            const int j = w + 4 * u;
+            if (j >= NPIECES) break;                       // (wave-uniform)
+            const int yy = y0 + (g_yx[u] >> 8), xx = x0 + (g_yx[u] & 255);
+            const bool ok = g_yx[u] >= 0 && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            const bf16_t* src = ok ? origin + g_rel[u] : reinterpret_cast<const bf16_t*>(&g_conv_zero16);
             __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(
                 reinterpret_cast<uintptr_t>(band2 + buf * BAND_BYTES + 1024 * j)), 16, 0, 0);
         }
@@ -96,35 +109,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(Conv64Args a)
         f32x4 acc[4][2];
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto load_x = [&](bf16x8 (&xb)[4], int ks) __attribute__((always_inline)) {
-            const int tap = ks >> 1, kh = ks & 1, dy = tap / 3, dx = tap - 3 * dy;
+        // NM = m-tiles of this wave that hold pixels (wave wm = 1 of a 4 x 28 tile has three): no MFMA is spent on padding
+        auto compute = [&](auto nm_c) __attribute__((always_inline)) {
+            constexpr int NM = decltype(nm_c)::value;
+            auto load_x = [&](bf16x8 (&xb)[4], int ks) __attribute__((always_inline)) {
+                const int tap = ks >> 1, kh = ks & 1, dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-                xb[m] = *reinterpret_cast<const bf16x8*>(band + pbase[m] + (dy * BW + dx) * CV_PIX + kh * 64);
-        };
-        auto mfmas = [&](const bf16x8 (&xb)[4], int ks) __attribute__((always_inline)) {
+                for (int m = 0; m < NM; ++m)
+                    xb[m] = *reinterpret_cast<const bf16x8*>(band + pbase[m] + (dy * BW + dx) * CV_PIX + kh * 64);
+            };
+            auto mfmas = [&](const bf16x8 (&xb)[4], int ks) __attribute__((always_inline)) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {                  // (an m-tile beyond the tile's pixels computes a clamped pixel: never stored)
-                acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ks], xb[m], acc[m][0], 0, 0, 0);
-                acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ks], xb[m], acc[m][1], 0, 0, 0);
+                for (int m = 0; m < NM; ++m) {
+                    acc[m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ks], xb[m], acc[m][0], 0, 0, 0);
+                    acc[m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ks], xb[m], acc[m][1], 0, 0, 0);
+                }
+            };
+            bf16x8 xa[4], xb[4];
+            load_x(xa, 0);
+#pragma unroll
+            for (int ks = 0; ks < 18; ks += 2) {           // operands one k-step ahead of the MFMAs that use them
+                load_x(xb, ks + 1);
+                mfmas(xa, ks);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 2 < 18) load_x(xa, ks + 2);
+                mfmas(xb, ks + 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
-        bf16x8 xa[4], xb[4];
-        load_x(xa, 0);
-#pragma unroll
-        for (int ks = 0; ks < 18; ks += 2) {               // operands one k-step ahead of the MFMAs that use them
-            load_x(xb, ks + 1);
-            mfmas(xa, ks);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ks + 2 < 18) load_x(xa, ks + 2);
-            mfmas(xb, ks + 1);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        constexpr int NMT = (NPIX + 15) / 16, NM1 = NMT - 4;            // m-tiles in all, and those of the wm = 1 waves
+        if (wm == 0 || NM1 == 4) compute(std::integral_constant<int, (NMT < 4 ? NMT : 4)>{});
+        else if constexpr (NM1 > 0 && NM1 < 4) compute(std::integral_constant<int, (NM1 > 0 ? NM1 : 1)>{});
 
         __syncthreads();                                   // everyone is done with this band; the next one has landed
+
         if (tile + 2 * (int)gridDim.x < ntiles) fetch(tile + 2 * gridDim.x, cur);
 
         // epilogue: lane (li, g) of tile (m, nt) holds channels 32wn + 16nt + 4g .. +3 of pixel 16(4wm+m) + li
+        // (hoisting the residual loads above the DMA issue was tried: the 16 extra live registers spill, 41 -> 50 us)
         const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
