@@ -4,7 +4,7 @@ mode runs trial and reference kernels (naive_conv, 36 ms each) during warm-up, w
 the last K forward steps (a step ends with upsample_argmax_dice_kernel) and averages over them.
 usage: python profiles/steady_state.py <kernel_trace.csv> <out.csv> "<command line that was profiled>" [K=10] [end-marker]
 end-marker: substring of the kernel that ends a step (default upsample_argmax_dice; training: multi_tensor = the fused AdamW
-kernels; runs of marker kernels closer than 50 dispatches count as one step end)."""
+kernels; runs of marker kernels closer than 8 dispatches count as one step end)."""
 import collections
 import csv
 import sys
@@ -20,7 +20,7 @@ def main():
     ends = []
     for i, r in enumerate(rows):
         if marker in r["Kernel_Name"]:
-            if ends and i - ends[-1] <= 50:
+            if ends and i - ends[-1] <= 8:
                 ends[-1] = i
             else:
                 ends.append(i)
