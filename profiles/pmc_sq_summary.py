@@ -12,6 +12,9 @@ import sys
 
 from summarize import short
 
+# kernels kept in the summary: the product's own (hot path, epilogues, convolutions) -- MIOpen's find-mode trial kernels are dropped
+KEEP = r"gdr_|kpff|argmax|conv3x3_c64|grouped_conv|upsample_cat|bias_|stem_s2d|maxpool|bn_|seg_loss"
+
 
 def main():
     src, dst, cmd = sys.argv[1:4]
@@ -22,7 +25,7 @@ def main():
         f.write(f"# {cmd}\n# per-launch means\n")
         f.write("Kernel,launches,kernel_cycles,SQ_VALU_MFMA_BUSY_CYCLES,mfma_busy_frac,wait_any_share,wait_inst_share,active_inst_share\n")
         for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", [0]))):
-            if not re.search(r"gdr_|kpff|argmax", k):
+            if not re.search(KEEP, k):
                 continue
             m = {c: sum(x) / len(x) for c, x in v.items()}
             cyc = m["GRBM_GUI_ACTIVE"] / 8

@@ -12,6 +12,9 @@ import sys
 
 from summarize import short
 
+# kernels kept in the summary: the product's own (hot path, epilogues, convolutions) -- MIOpen's find-mode trial kernels are dropped
+KEEP = r"gdr_|kpff|argmax|conv3x3_c64|grouped_conv|upsample_cat|bias_|stem_s2d|maxpool|bn_|seg_loss"
+
 
 def load(path, counter):
     d = collections.defaultdict(list)
@@ -28,7 +31,7 @@ def main():
         o.write(f"# {cmd}\n# per-launch means; KiB as reported by rocprofv3; read_x2 = FETCH_SIZE*2 (gfx950 wide-read correction)\n")
         o.write("Kernel,launches,FETCH_SIZE_KiB,WRITE_SIZE_KiB,hbm_bytes_raw,hbm_bytes_read_x2\n")
         for k in sorted(fe, key=lambda k: -sum(fe[k])):
-            if not re.search(r"gdr_|kpff|argmax", k):
+            if not re.search(KEEP, k):
                 continue
             fv = sum(fe[k]) / len(fe[k])
             wv = sum(wr[k]) / len(wr[k]) if wr.get(k) else 0.0
