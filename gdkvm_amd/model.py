@@ -402,8 +402,22 @@ class GDKVM(nn.Module):
         elif torch.is_grad_enabled() and self.mask_embed.weight.requires_grad:
             v = v + 0.0 * self.mask_embed.weight.sum()            # keep every parameter in the graph (DDP: no unused params)
         v = v.reshape(B, T, N, Hh, Dv)
-        beta = proj(self.gate_proj).float().reshape(B, T, N, Hh)
-        alpha = self.decay_proj(p_tok.mean(1)).float().reshape(B, T, Hh)
+        v8 = 8 if p_tok.dtype == torch.bfloat16 else 4
+        g_lanes = p_tok.shape[-1] // v8
+        if (p_tok.is_cuda and not train_gpu and not torch.is_grad_enabled() and p_tok.dtype in (torch.bfloat16, torch.float32)
+                and p_tok.shape[-1] % v8 == 0 and g_lanes <= 64 and g_lanes & (g_lanes - 1) == 0):
+            # both gate logits in one pass over the feature (token mean + two N = 1 projections + casts as framework ops: 6 launches)
+            gp, dp = self.gate_proj, self.decay_proj
+            key = (gp.weight._version, gp.bias._version, dp.weight._version, dp.bias._version, gp.weight.data_ptr(), p_tok.device)
+            cache = getattr(self, "_gate_w32", None)
+            if cache is None or cache[0] != key:
+                cache = (key, tuple(t.detach().float().contiguous() for t in (gp.weight.reshape(Hh, -1), gp.bias, dp.weight, dp.bias)))
+                self._gate_w32 = cache
+            beta, alpha = ops.gate_logits(p_tok, *cache[1])
+            beta, alpha = beta.reshape(B, T, N, Hh), alpha.reshape(B, T, Hh)
+        else:
+            beta = proj(self.gate_proj).float().reshape(B, T, N, Hh)
+            alpha = self.decay_proj(p_tok.mean(1)).float().reshape(B, T, Hh)
         r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state)
         fused = self._fuse(k_tok, r.reshape(B * T, N, Hh * Dv), p_tok, h, w)       # [BT,N,Cp]
         fmap = fused.reshape(B * T, h, w, -1).permute(0, 3, 1, 2)                  # channels_last view, no copy

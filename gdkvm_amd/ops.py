@@ -41,6 +41,7 @@ SIGNATURES = {
     "gdkvm_kpff_bwd_post": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "gdkvm_bias_act": (_i, [_vp] * 4 + [_sz] + [_i] * 3 + [_vp]),
+    "gdkvm_gate_logits": (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     "gdkvm_conv_bias_act": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
     "gdkvm_upsample_cat": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_upsample_cat_bwd": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
@@ -524,6 +525,26 @@ def bias_act_(x: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tens
                                 n * hh * ww, c, int(relu), _io_dtype(x), _stream(x.device))
     _check(rc, "gdkvm_bias_act")
     return x
+
+
+def gate_logits(p_tok: torch.Tensor, w_gate: torch.Tensor, b_gate: torch.Tensor, w_decay: torch.Tensor, b_decay: torch.Tensor):
+    """(beta_logit [F,N,Hh], alpha_logit [F,Hh]) in fp32 from the pixel feature p_tok [F,N,Cp] in one pass (gdkvm_gate_logits):
+    the gate projection per token and the decay projection of the token mean."""
+    lib = load()
+    if p_tok.dim() != 3 or not p_tok.is_cuda or not p_tok.is_contiguous():
+        raise GdkvmError("gate_logits needs a contiguous [frames, N, Cp] device tensor (no CPU path)")
+    fr, n, cp = p_tok.shape
+    hh = w_gate.shape[0]
+    ws = [t.detach().float().contiguous() for t in (w_gate.reshape(hh, -1), b_gate, w_decay.reshape(hh, -1), b_decay)]
+    if ws[0].shape != (hh, cp) or ws[2].shape != (hh, cp) or ws[1].numel() != hh or ws[3].numel() != hh:
+        raise GdkvmError("gate_logits: weights must be [Hh, Cp], biases [Hh]")
+    beta = torch.empty((fr, n, hh), dtype=torch.float32, device=p_tok.device)
+    alpha = torch.empty((fr, hh), dtype=torch.float32, device=p_tok.device)
+    with torch.cuda.device(p_tok.device):
+        rc = lib.gdkvm_gate_logits(p_tok.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ws[3].data_ptr(),
+                                   beta.data_ptr(), alpha.data_ptr(), fr, n, cp, hh, _io_dtype(p_tok), _stream(p_tok.device))
+    _check(rc, "gdkvm_gate_logits")
+    return beta, alpha
 
 
 def conv_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tensor] = None,

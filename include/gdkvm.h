@@ -181,6 +181,13 @@ int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* target, uint8_
 int gdkvm_bias_act(const void* x, const float* bias, const void* residual, void* y,
                    size_t rows, int C, int relu, int io_dtype, void* stream);
 
+/* Row n4, the gates of the memory path in one pass over the stride-16 pixel feature p [frames, N, Cp] (io_dtype):
+ *   beta_logit [frames, N, Hh]  = <p[f, n, :], w_gate[h, :]> + b_gate[h]           (per token; what the gate 1x1 projection computes)
+ *   alpha_logit [frames, Hh]    = <mean_n p[f, n, :], w_decay[h, :]> + b_decay[h]  (per frame; token mean -> decay projection)
+ * both fp32 (the dtype gdkvm_scan_prep / gdkvm_scan_apply read), weights fp32 [Hh, Cp], fp32 accumulation throughout. */
+int gdkvm_gate_logits(const void* p, const float* w_gate, const float* b_gate, const float* w_decay, const float* b_decay,
+                      float* beta, float* alpha, int frames, int N, int Cp, int Hh, int io_dtype, void* stream);
+
 /* Row n1 (inference build): convolution with the folded-BatchNorm bias, the residual add and the ReLU in its epilogue,
  *   y = act(conv(x, w) + bias[k] (+ residual)),  x [N, H, W, C] (NHWC), w [K, R, S, C] (channels_last weights), y / residual
  *   [N, Ho, Wo, K], bias fp32 [K]; bf16 only; C and K multiples of 8.  The fp32 accumulator is rounded ONCE (after the epilogue).

@@ -194,3 +194,21 @@ def test_conv_with_fused_epilogue(hip, tile, case):
         assert (got.double() - want).abs().max() <= 2.0 ** -7 * max(1.0, want.abs().max().item())
     with pytest.raises(hip.GdkvmError):
         hip.conv_bias_act(x.float(), wt, b, r, stride, 1, True, tile)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(6, 49, 256, 1), (3, 256, 256, 2), (2, 7, 64, 1), (5, 1, 32, 3)])
+def test_gate_logits_one_pass(hip, dtype, case):
+    """gdkvm_gate_logits == gate projection per token and decay projection of the token mean, in fp32 from the same inputs."""
+    fr, n, cp, hh = case
+    torch.manual_seed(sum(case))
+    p = torch.randn(fr, n, cp, device="cuda").to(dtype)
+    wg, bg = torch.randn(hh, cp, device="cuda") / cp ** 0.5, torch.randn(hh, device="cuda")
+    wd, bd = torch.randn(hh, cp, device="cuda") / cp ** 0.5, torch.randn(hh, device="cuda")
+    beta, alpha = hip.gate_logits(p, wg, bg, wd, bd)
+    p64 = p.double()
+    beta_ref = p64 @ wg.double().t() + bg.double()
+    alpha_ref = p64.mean(1) @ wd.double().t() + bd.double()
+    assert beta.dtype == torch.float32 and beta.shape == (fr, n, hh) and alpha.shape == (fr, hh)
+    assert (beta.double() - beta_ref).abs().max() <= 1e-5 * max(1.0, beta_ref.abs().max().item())
+    assert (alpha.double() - alpha_ref).abs().max() <= 1e-5 * max(1.0, alpha_ref.abs().max().item())
