@@ -243,6 +243,9 @@ class FusedConvPool(FusedConv):
     def forward(self, x, residual=None):
         if x.is_cuda and getattr(self, "w_s2d", None) is not None and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
             xs = ops.stem_s2d(x.contiguous(), self.S2D_CH)                       # NCHW frames -> NHWC space-to-depth, one pass
+            if (xs.dtype == torch.bfloat16 and self.w_s2d.dtype == torch.bfloat16 and tuple(self.w_s2d.shape) == (64, 16, 4, 4)
+                    and self.w_s2d.is_contiguous(memory_format=torch.channels_last)):
+                return ops.stem_conv_pool(xs, self.w_s2d, self.epi.bias)         # convolution + bias + ReLU + max-pool: one kernel
             y = F.conv2d(xs, self.w_s2d, None, 1, 2)                             # [N, Cout, H/2 + 1, W/2 + 1]: last row/col unused
             return ops.bias_relu_maxpool(y.contiguous(memory_format=torch.channels_last)[:, :, :x.shape[2] // 2, :x.shape[3] // 2],
                                          self.epi.bias)

@@ -41,6 +41,7 @@ SIGNATURES = {
     "gdkvm_kpff_bwd_post": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "gdkvm_bias_act": (_i, [_vp] * 4 + [_sz] + [_i] * 3 + [_vp]),
+    "gdkvm_stem_conv_pool": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
     "gdkvm_gate_logits": (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     "gdkvm_conv_bias_act": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
     "gdkvm_upsample_cat": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
@@ -627,6 +628,25 @@ def _upsample_cat_fwd(lo: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:
         rc = lib.gdkvm_upsample_cat(lo.data_ptr(), skip.data_ptr(), out.data_ptr(), n, hl, wl, H, W, c1, c2, BF16, _stream(lo.device))
     _check(rc, "gdkvm_upsample_cat")
     return out
+
+
+def stem_conv_pool(xs: torch.Tensor, w_s2d: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """max_pool2d(relu(conv2d(xs, w_s2d, padding=2)[..., :Hs, :Ws] + bias), 3, 2, 1) in one kernel (gdkvm_stem_conv_pool):
+    xs channels_last bf16 [N,16,Hs,Ws] (ops.stem_s2d), w_s2d channels_last bf16 [64,16,4,4], bias fp32 [64]."""
+    lib = load()
+    if xs.dim() != 4 or not xs.is_cuda or xs.dtype != torch.bfloat16 or xs.shape[1] != 16 or \
+            not xs.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("stem_conv_pool needs a channels_last bf16 [N,16,Hs,Ws] device tensor (no CPU path)")
+    if tuple(w_s2d.shape) != (64, 16, 4, 4) or w_s2d.dtype != torch.bfloat16 or not w_s2d.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("stem_conv_pool: weight must be channels_last bf16 [64,16,4,4]")
+    if bias.dtype != torch.float32 or bias.numel() != 64:
+        raise GdkvmError("bias must be float32 [64]")
+    n, _, hs, ws = xs.shape
+    y = torch.empty((n, 64, (hs - 1) // 2 + 1, (ws - 1) // 2 + 1), dtype=xs.dtype, device=xs.device, memory_format=torch.channels_last)
+    with torch.cuda.device(xs.device):
+        rc = lib.gdkvm_stem_conv_pool(xs.data_ptr(), w_s2d.data_ptr(), bias.data_ptr(), y.data_ptr(), n, hs, ws, BF16, _stream(xs.device))
+    _check(rc, "gdkvm_stem_conv_pool")
+    return y
 
 
 def upsample_cat_bwd(dout: torch.Tensor, lo_shape, skip_shape) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -207,6 +207,13 @@ int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const v
 int gdkvm_bias_relu_maxpool(const void* x, const float* bias, void* y, int N, int H, int W, int C,
                             int x_rows, int x_cols, int io_dtype, void* stream);
 
+/* Row n1, the inference stem in one kernel: y = maxpool3x3/2/pad1(relu(conv4x4/1/pad2(xs, w) + bias)) cropped to the Hs x Ws
+ * convolution outputs -- xs [N, Hs, Ws, 16] is the space-to-depth image of gdkvm_stem_s2d, w [64, 4, 4, 16] the 4x4 kernel
+ * model.FusedConvPool.enable_s2d builds from a 7x7 / stride 2 stem, y [N, (Hs-1)/2+1, (Ws-1)/2+1, 64]; bf16, 64 output
+ * channels.  The full-resolution activation exists only as an LDS tile (csrc/stem_conv_pool.hip). */
+int gdkvm_stem_conv_pool(const void* xs, const void* w, const float* bias, void* y, int N, int Hs, int Ws,
+                         int io_dtype, void* stream);
+
 /* Row n1, the training stem: 3x3 / stride 2 / pad 1 max-pool of an NHWC tensor x [N, H, W, C] -> y [N, Ho, Wo, C]
  * (Ho = (H-1)/2+1) recording the winning tap of every output element in idx (one byte each, [N, Ho, Wo, C]: 3*dy + dx in
  * window coordinates; first maximum in scan order, NaN wins -- PyTorch's rule), and its backward: dx [N, H, W, C] gathers dy

@@ -212,3 +212,19 @@ def test_gate_logits_one_pass(hip, dtype, case):
     assert beta.dtype == torch.float32 and beta.shape == (fr, n, hh) and alpha.shape == (fr, hh)
     assert (beta.double() - beta_ref).abs().max() <= 1e-5 * max(1.0, beta_ref.abs().max().item())
     assert (alpha.double() - alpha_ref).abs().max() <= 1e-5 * max(1.0, alpha_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(3, 56, 56), (2, 128, 128), (1, 8, 8), (2, 30, 44), (5, 2, 2), (1, 57, 23)])
+def test_stem_conv_pool_in_one_kernel(hip, case):
+    """gdkvm_stem_conv_pool == max_pool(relu(conv4x4 pad 2 cropped + bias)) computed in fp64 from the same bf16 inputs, rounded once."""
+    n, hs, ws = case
+    torch.manual_seed(sum(case))
+    cl = dict(memory_format=torch.channels_last)
+    xs = torch.randn(n, 16, hs, ws, device="cuda").bfloat16().contiguous(**cl)
+    w = (torch.randn(64, 16, 4, 4, device="cuda") / 16).bfloat16().contiguous(**cl)
+    b = torch.randn(64, device="cuda")
+    got = hip.stem_conv_pool(xs, w, b)
+    conv = torch.nn.functional.conv2d(xs.double(), w.double(), b.double(), 1, 2)[:, :, :hs, :ws]
+    want = torch.nn.functional.max_pool2d(conv.relu().bfloat16().double(), 3, 2, 1)      # the kernel rounds before pooling (max commutes)
+    assert got.shape == want.shape and got.is_contiguous(**cl)
+    assert (got.double() - want).abs().max() <= 2.0 ** -7 * max(1.0, want.abs().max().item())
