@@ -98,20 +98,24 @@ __global__ __launch_bounds__(512, 1) void stem_conv_pool_kernel(StemArgs a)
             f32x4 acc[3][2];
 #pragma unroll
             for (int r = 0; r < 3; ++r) acc[r][0] = acc[r][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // the three rows of a group read band rows 3grp .. 3grp + 5 (row r + ky): each of the 12 operand fragments (6 rows x 2
+            // K halves) is loaded ONCE and feeds every (row, ky) pair that meets it -- half the LDS reads of a per-k-step reload
+            bf16x8 xf[6][2];
+#pragma unroll
+            for (int rho = 0; rho < 6; ++rho)
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+                    xf[rho][half] = *reinterpret_cast<const bf16x8*>(band + xoff + ((3 * grp + rho) * SP_BC) * 32 + half * 64);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 const int ky = ks >> 1, half = ks & 1;
-                bf16x8 xb[3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-                    xb[r] = *reinterpret_cast<const bf16x8*>(band + xoff + ((3 * grp + r + ky) * SP_BC) * 32 + half * 64);
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
 #ifdef STEM_ABL_NOMFMA                                      // (tools/abl_stem.py: timing ablations, wrong results by design)
-                    acc[r][0][0] += __builtin_bit_cast(f32x4, xb[r])[0];
+                    acc[r][0][0] += __builtin_bit_cast(f32x4, xf[r + ky][half])[0];
 #else
-                    acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ks], xb[r], acc[r][0], 0, 0, 0);
-                    acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ks], xb[r], acc[r][1], 0, 0, 0);
+                    acc[r][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ks], xf[r + ky][half], acc[r][0], 0, 0, 0);
+                    acc[r][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ks], xf[r + ky][half], acc[r][1], 0, 0, 0);
 #endif
                 }
             }
@@ -119,19 +123,17 @@ __global__ __launch_bounds__(512, 1) void stem_conv_pool_kernel(StemArgs a)
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const int cr = 3 * grp + r, cy = cy0 + cr;
-                const bool ok = col_ok && cy >= 0 && cy < a.Hs;
-                float v[8];
+                const float keep = (col_ok && cy >= 0 && cy < a.Hs) ? 1.f : 0.f;        // (values are >= 0 after the ReLU: masking is a multiply)
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                unsigned ow[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[q] = ok ? fmaxf(acc[r][0][q] + bia[q], 0.f) : 0.f;
-                    v[4 + q] = ok ? fmaxf(acc[r][1][q] + bia[4 + q], 0.f) : 0.f;
+                for (int q = 0; q < 4; ++q) {                                            // packed fp32 pairs: add, max, mul
+                    const f32x2 t = {acc[r][q >> 1][2 * (q & 1)], acc[r][q >> 1][2 * (q & 1) + 1]};
+                    const f32x2 bb = {bia[2 * q], bia[2 * q + 1]};
+                    f32x2 v = __builtin_elementwise_max(t + bb, f32x2{0.f, 0.f}) * f32x2{keep, keep};
+                    ow[q] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
                 }
-                uint4 o;
-                o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-                o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
-                *reinterpret_cast<uint4*>(ctile + (cr * SP_CC + 16 * wm + li) * SP_CPIX + (32 * wn + 8 * g) * 2) = o;
+                *reinterpret_cast<uint4*>(ctile + (cr * SP_CC + 16 * wm + li) * SP_CPIX + (32 * wn + 8 * g) * 2) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
             }
         }
         __syncthreads();                                   // the convolution tile is complete (and the next band has landed)
