@@ -24,23 +24,29 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const void* p, const f
 #pragma unroll
         for (int j = 0; j < V; ++j) { wg[j] = w_gate[(size_t)h * Cp + cg * V + j]; wd[j] = w_decay[(size_t)h * Cp + cg * V + j]; }
         float dsum = 0.f;
-        for (int n0 = wv * tpw; n0 < N; n0 += 4 * tpw) {
-            const int n = n0 + sub;
-            const uint4 x = pv[(size_t)min(n, N - 1) * G + cg];
-            const unsigned xw[4] = {x.x, x.y, x.z, x.w};
-            float v[V];
+        constexpr int UNR = 4;                              // independent loads in flight per lane (a frame is a few KB: latency-bound)
+        for (int n0 = wv * tpw; n0 < N; n0 += 4 * tpw * UNR) {
+            uint4 x[UNR];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (IO == GDKVM_F32) v[j] = __uint_as_float(xw[j]);
-                else { v[2 * j] = __uint_as_float(xw[j] << 16); v[2 * j + 1] = __uint_as_float(xw[j] & 0xffff0000u); }
-            }
-            float dg = 0.f, dd = 0.f;
+            for (int u = 0; u < UNR; ++u) x[u] = pv[(size_t)min(n0 + 4 * tpw * u + sub, N - 1) * G + cg];
 #pragma unroll
-            for (int j = 0; j < V; ++j) { dg = fmaf(v[j], wg[j], dg); dd = fmaf(v[j], wd[j], dd); }
-            for (int o = G >> 1; o > 0; o >>= 1) { dg += __shfl_xor(dg, o); dd += __shfl_xor(dd, o); }
-            if (n < N) {
-                if (cg == 0) beta[((size_t)f * N + n) * Hh + h] = dg + b_gate[h];
-                dsum += cg == 0 ? dd : 0.f;
+            for (int u = 0; u < UNR; ++u) {
+                const int n = n0 + 4 * tpw * u + sub;
+                const unsigned xw[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+                float v[V];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (IO == GDKVM_F32) v[j] = __uint_as_float(xw[j]);
+                    else { v[2 * j] = __uint_as_float(xw[j] << 16); v[2 * j + 1] = __uint_as_float(xw[j] & 0xffff0000u); }
+                }
+                float dg = 0.f, dd = 0.f;
+#pragma unroll
+                for (int j = 0; j < V; ++j) { dg = fmaf(v[j], wg[j], dg); dd = fmaf(v[j], wd[j], dd); }
+                for (int o = G >> 1; o > 0; o >>= 1) { dg += __shfl_xor(dg, o); dd += __shfl_xor(dd, o); }
+                if (n < N) {
+                    if (cg == 0) beta[((size_t)f * N + n) * Hh + h] = dg + b_gate[h];
+                    dsum += cg == 0 ? dd : 0.f;
+                }
             }
         }
         for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
