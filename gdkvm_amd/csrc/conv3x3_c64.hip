@@ -71,8 +71,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(Conv64Args a)
         const int j = w + 4 * u, d = 64 * j + lane, pix = d / 10, c = d - 10 * pix;
         const int by = pix / BW, bx = pix - by * BW;
         g_rel[u] = (by * a.W + bx) * CV_C + c * 8;
-        g_yx[u] = (j < NPIECES && c < 8 && pix < BAND_PIX) ? (by << 8 | bx) : -1;
+        bool live = j < NPIECES && c < 8 && pix < BAND_PIX;
+        if (a.tiles_x == 1) live = live && bx >= 1 && bx <= a.W;     // one tile per row: the column test does not depend on the tile
+        g_yx[u] = live ? (by << 8 | bx) : -1;
     }
+    const bool one_col = a.tiles_x == 1;
     auto fetch = [&](int tile, int buf) __attribute__((always_inline)) {
         const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
         const int y0 = ty * CV_TH - 1, x0 = tx * TW - 1;
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(Conv64Args a)
             const int j = w + 4 * u;
             if (j >= NPIECES) break;                       // (wave-uniform)
             const int yy = y0 + (g_yx[u] >> 8), xx = x0 + (g_yx[u] & 255);
-            const bool ok = g_yx[u] >= 0 && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            const bool ok = g_yx[u] >= 0 && (unsigned)yy < (unsigned)a.H && (one_col || (unsigned)xx < (unsigned)a.W);
             const bf16_t* src = ok ? origin + g_rel[u] : reinterpret_cast<const bf16_t*>(&g_conv_zero16);
             __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(
                 reinterpret_cast<uintptr_t>(band2 + buf * BAND_BYTES + 1024 * j)), 16, 0, 0);
@@ -155,25 +158,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(Conv64Args a)
             const int py = p / TW, px = p - py * TW, yy = ty * CV_TH + py, xx = tx * TW + px;
             if (p >= NPIX || yy >= a.H || xx >= a.W) continue;
             const size_t o = (((size_t)n * a.H + yy) * a.W + xx) * CV_C + 32 * wn + 8 * g;
-            float v[8];
+            typedef float f32x2 __attribute__((ext_vector_type(2)));       // packed fp32 pairs: v_pk_add_f32 / v_pk_max_f32
+            f32x2 v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = acc[m][0][r] + bia[0][r]; v[4 + r] = acc[m][1][r] + bia[1][r]; }
+            for (int q = 0; q < 4; ++q)
+                v[q] = f32x2{acc[m][q >> 1][2 * (q & 1)], acc[m][q >> 1][2 * (q & 1) + 1]} + f32x2{bia[q >> 1][2 * (q & 1)], bia[q >> 1][2 * (q & 1) + 1]};
             if (a.res) {
                 const uint4 rr = *reinterpret_cast<const uint4*>(a.res + o);
                 const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { v[2 * q] += __uint_as_float(rw[q] << 16); v[2 * q + 1] += __uint_as_float(rw[q] & 0xffff0000u); }
+                for (int q = 0; q < 4; ++q) v[q] += f32x2{__uint_as_float(rw[q] << 16), __uint_as_float(rw[q] & 0xffff0000u)};
             }
-            if (a.relu) {
+            const float lo = a.relu ? 0.f : -INFINITY;
+            unsigned ow[4];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+            for (int q = 0; q < 4; ++q) {
+                v[q] = __builtin_elementwise_max(v[q], f32x2{lo, lo});
+                ow[q] = (unsigned)f32_to_bf16(v[q][0]) | ((unsigned)f32_to_bf16(v[q][1]) << 16);
             }
-            uint4 out;
-            out.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-            out.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-            out.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
-            out.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
-            *reinterpret_cast<uint4*>(a.y + o) = out;
+            *reinterpret_cast<uint4*>(a.y + o) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
     }
 }
