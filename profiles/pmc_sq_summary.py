@@ -13,7 +13,7 @@ import sys
 from summarize import short
 
 # kernels kept in the summary: the product's own (hot path, epilogues, convolutions) -- MIOpen's find-mode trial kernels are dropped
-KEEP = r"gdr_|kpff|argmax|conv3x3_c64|grouped_conv|upsample_cat|bias_|stem_s2d|maxpool|bn_|seg_loss"
+KEEP = r"gdr_|kpff|argmax|conv3x3_c64|grouped_conv|upsample_cat|bias_|stem_|gate_logits|maxpool|bn_|seg_loss"
 
 
 def main():
