@@ -469,6 +469,67 @@ __global__ __launch_bounds__(256) void kpff_bwd_post_kernel(const void* dF, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Row n4: the key / query / value 1x1 projections of the stride-16 feature as ONE pass over the tokens (inference).
+// As three library GEMMs (M = B*T*N tokens, K = Cp, N = 64 / 64 / 256) they cost 35 us of a 1.35 ms forward for 4.9 GFLOP;
+// the shape is KPFF's own -- a token tile staged once in LDS as the MFMA B operand, the weights streamed from L2 in fragment
+// order as the A operand (kpff_stream) -- so the same machinery serves: a workgroup stages 128 token rows, its 8 waves walk the
+// 16-channel output tiles of all three projections, and the epilogue adds the bias and writes each tile into the tensor it
+// belongs to (contiguous [tokens, width] rows: exactly what gdkvm_scan_prep and gdkvm_kpff_fwd read).
+struct ProjArgs {
+    const bf16_t* x; const bf16_t* wpack; const float* bias;
+    bf16_t* out[3];
+    int width[3];
+    int M, K, ntile_out;
+};
+
+template <int TM>
+__global__ __launch_bounds__(512) void proj_rows_kernel(ProjArgs a)
+{
+    constexpr int MT = TM / 16;
+    extern __shared__ __attribute__((aligned(16))) bf16_t s_px[];       // [TM][K + PAD16]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = a.K, ld = K + KPFF_PAD16, KS = K / 32, q8 = K / 8;
+    const size_t row0 = (size_t)blockIdx.x * TM;
+    for (int base = tid; base < TM * q8; base += 4 * 512) {            // stage the token rows (zero beyond M), 4 loads in flight
+        uint4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 512, r = idx / q8, c = (idx - r * q8) * 8;
+            x[u] = (idx < TM * q8 && row0 + r < (size_t)a.M) ? *reinterpret_cast<const uint4*>(a.x + (row0 + r) * K + c) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 512, r = idx / q8, c = (idx - r * q8) * 8;
+            if (idx < TM * q8) *reinterpret_cast<uint4*>(s_px + (size_t)r * ld + c) = x[u];
+        }
+    }
+    __syncthreads();
+    const bf16_t* xb = s_px + (size_t)li * ld + 8 * g;
+    for (int ot = w_id; ot < a.ntile_out; ot += 8) {
+        f32x4 acc[1][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        kpff_stream<1, MT, 1>(xb, ld, 0, KS, a.wpack + ((size_t)ot * KS * 64 + lane) * 8, nullptr, 0, acc, acc);
+        const int oc = 16 * ot + 4 * g;                               // this lane: channels oc .. oc+3 of token 16mt + li
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + oc);
+        const int seg = oc < a.width[0] ? 0 : (oc < a.width[0] + a.width[1] ? 1 : 2);
+        const int cbase = oc - (seg == 0 ? 0 : (seg == 1 ? a.width[0] : a.width[0] + a.width[1]));
+        bf16_t* dst = a.out[seg];
+        const int wd = a.width[seg];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const size_t row = row0 + 16 * mt + li;
+            if (row < (size_t)a.M) {
+                const uint2 o = make_uint2((unsigned)f32_to_bf16(acc[0][mt][0] + b4[0]) | ((unsigned)f32_to_bf16(acc[0][mt][1] + b4[1]) << 16),
+                                           (unsigned)f32_to_bf16(acc[0][mt][2] + b4[2]) | ((unsigned)f32_to_bf16(acc[0][mt][3] + b4[3]) << 16));
+                *reinterpret_cast<uint2*>(dst + row * wd + cbase) = o;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" size_t gdkvm_kpff_workspace_bytes(int Ck, int Cv, int Cp, int io_dtype)
@@ -612,4 +673,45 @@ extern "C" int gdkvm_kpff_fwd_packed(const void* local, const void* global, cons
                                         packed_workspace, workspace_bytes, BT, Ck, Cv, Cp, h, w, io_dtype, stream);
     g_kpff_skip_pack = 0;
     return rc;
+}
+
+extern "C" int gdkvm_proj_rows(const void* x, const void* wpack, const float* bias, void* out0, void* out1, void* out2,
+                               long long rows, int K, int w0, int w1, int w2, int io_dtype, void* stream)
+{
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "proj_rows: only bf16 is implemented");
+    if (rows < 0 || rows > 0x7fffffffLL || K <= 0 || K % 32 || K > 512 || w0 <= 0 || w1 < 0 || w2 < 0 || w0 % 16 || w1 % 16 || w2 % 16)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "proj_rows: rows=%lld K=%d widths %d %d %d (K a multiple of 32 up to 512, widths multiples of 16)",
+                          rows, K, w0, w1, w2);
+    if (rows == 0) return GDKVM_OK;
+    if (!x || !wpack || !bias || !out0 || (w1 && !out1) || (w2 && !out2)) return gdkvm_fail(GDKVM_ERR_ARG, "proj_rows: null pointer");
+    if (!gdkvm_aligned16(x) || !gdkvm_aligned16(wpack) || !gdkvm_aligned16(bias) || !gdkvm_aligned16(out0) || (out1 && !gdkvm_aligned16(out1))
+        || (out2 && !gdkvm_aligned16(out2)))
+        return gdkvm_fail(GDKVM_ERR_ARG, "proj_rows: pointers must be 16-byte aligned");
+    if (int rc = gdkvm_check_device()) return rc;
+    ProjArgs a;
+    a.x = static_cast<const bf16_t*>(x); a.wpack = static_cast<const bf16_t*>(wpack); a.bias = bias;
+    a.out[0] = static_cast<bf16_t*>(out0); a.out[1] = static_cast<bf16_t*>(out1); a.out[2] = static_cast<bf16_t*>(out2);
+    a.width[0] = w0; a.width[1] = w1; a.width[2] = w2;
+    a.M = (int)rows; a.K = K; a.ntile_out = (w0 + w1 + w2) / 16;
+    // token rows per workgroup: 128 when that still gives every CU at least two workgroups, else 64 (cfg2: 25088 rows -> 392 x 64)
+#ifndef PROJ_TM_SWITCH
+#define PROJ_TM_SWITCH (128 * 512)
+#endif
+    const int TM = rows >= PROJ_TM_SWITCH ? 128 : 64;
+    const size_t lds = (size_t)TM * (K + KPFF_PAD16) * sizeof(bf16_t);
+    static bool attr_set[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        const int cap = (int)((size_t)128 * (512 + KPFF_PAD16) * sizeof(bf16_t));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_rows_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_rows_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "proj_rows: %s", hipGetErrorString(e));
+        attr_set[dev] = true;
+    }
+    const unsigned grid = (unsigned)((rows + TM - 1) / TM);
+    if (TM == 128) hipLaunchKernelGGL(proj_rows_kernel<128>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(proj_rows_kernel<64>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+    GDKVM_LAUNCH_CHECK("proj_rows_kernel");
+    return GDKVM_OK;
 }

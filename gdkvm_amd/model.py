@@ -395,9 +395,25 @@ class GDKVM(nn.Module):
                 return ops.token_linear(tok2d, w2, conv.bias)
             return F.linear(tok2d, w2, conv.bias)
 
-        k_tok = proj(self.key_proj).reshape(B * T, N, Hh * Dk)                   # local key feature
-        q = proj(self.query_proj).reshape(B, T, N, Hh, Dk)
-        v = proj(self.value_proj).reshape(B, T, N, Hh * Dv)
+        wk, wq, wv = Hh * Dk, Hh * Dk, Hh * Dv
+        if (tok2d.is_cuda and not train_gpu and not torch.is_grad_enabled() and tok2d.dtype == torch.bfloat16
+                and tok2d.shape[1] % 32 == 0 and tok2d.shape[1] <= 512 and wk % 16 == 0 and wv % 16 == 0):
+            # the three projections in ONE pass over the tokens (ops.proj_rows: token tile in LDS, weights streamed in MFMA
+            # fragment order); the packed weight is rebuilt only when a projection's parameters change
+            projs = (self.key_proj, self.query_proj, self.value_proj)
+            key = tuple(t._version for c in projs for t in (c.weight, c.bias)) + (projs[0].weight.data_ptr(), tok2d.device)
+            cache = getattr(self, "_qkv_pack", None)
+            if cache is None or cache[0] != key:
+                w_all = torch.cat([c.weight.detach().reshape(c.out_channels, -1).float() for c in projs], 0)
+                b_all = torch.cat([c.bias.detach().float() for c in projs], 0).contiguous()
+                cache = (key, ops.pack_rows_weight(w_all), b_all)
+                self._qkv_pack = cache
+            k2d, q2d, v2d = ops.proj_rows(tok2d, cache[1], cache[2], (wk, wq, wv))
+            k_tok, q, v = k2d.reshape(B * T, N, wk), q2d.reshape(B, T, N, Hh, Dk), v2d.reshape(B, T, N, wv)
+        else:
+            k_tok = proj(self.key_proj).reshape(B * T, N, Hh * Dk)               # local key feature
+            q = proj(self.query_proj).reshape(B, T, N, Hh, Dk)
+            v = proj(self.value_proj).reshape(B, T, N, Hh * Dv)
         if mask0 is not None:
             m = F.adaptive_avg_pool2d(mask0.to(v.dtype), (h, w))
             me = self._tokens(self.mask_embed(m))                                # [B,N,Hh*Dv]

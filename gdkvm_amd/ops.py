@@ -41,6 +41,7 @@ SIGNATURES = {
     "gdkvm_kpff_bwd_post": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "gdkvm_bias_act": (_i, [_vp] * 4 + [_sz] + [_i] * 3 + [_vp]),
+    "gdkvm_proj_rows": (_i, [_vp] * 6 + [ctypes.c_longlong] + [_i] * 5 + [_vp]),
     "gdkvm_stem_conv_pool": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
     "gdkvm_gate_logits": (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     "gdkvm_conv_bias_act": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
@@ -526,6 +527,35 @@ def bias_act_(x: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tens
                                 n * hh * ww, c, int(relu), _io_dtype(x), _stream(x.device))
     _check(rc, "gdkvm_bias_act")
     return x
+
+
+def pack_rows_weight(weight: torch.Tensor) -> torch.Tensor:
+    """W [Nout, K] (Nout a multiple of 16, K of 32) -> bf16 in the MFMA fragment order gdkvm_proj_rows streams:
+    element ((ot * K/32 + ks) * 64 + lane) * 8 + j = W[16 ot + (lane & 15)][32 ks + 8 (lane >> 4) + j]."""
+    nout, k = weight.shape
+    if nout % 16 or k % 32:
+        raise GdkvmError("pack_rows_weight: [Nout, K] with Nout % 16 == 0 and K % 32 == 0")
+    w = weight.detach().reshape(nout // 16, 16, k // 32, 4, 8)            # [ot, i, ks, g, j]
+    return w.permute(0, 2, 3, 1, 4).contiguous().to(torch.bfloat16).reshape(-1)       # [ot, ks, g, i, j]: lane = 16 g + i
+
+
+def proj_rows(x2d: torch.Tensor, wpack: torch.Tensor, bias: torch.Tensor, widths) -> Tuple[torch.Tensor, ...]:
+    """The key / query / value projections of token rows x2d [rows, K] (bf16) in one pass (gdkvm_proj_rows): returns one
+    contiguous [rows, w] tensor per entry of `widths` (up to three)."""
+    lib = load()
+    if x2d.dim() != 2 or not x2d.is_cuda or x2d.dtype != torch.bfloat16 or not x2d.is_contiguous():
+        raise GdkvmError("proj_rows needs a contiguous bf16 [rows, K] device tensor (no CPU path)")
+    rows, k = x2d.shape
+    widths = list(widths) + [0] * (3 - len(widths))
+    if len(widths) != 3 or bias.dtype != torch.float32 or bias.numel() != sum(widths) or wpack.dtype != torch.bfloat16 \
+            or wpack.numel() != sum(widths) * k:
+        raise GdkvmError("proj_rows: up to three widths, fp32 bias [sum(widths)], packed bf16 weight [sum(widths) * K]")
+    outs = [torch.empty((rows, w), dtype=x2d.dtype, device=x2d.device) if w else None for w in widths]
+    with torch.cuda.device(x2d.device):
+        rc = lib.gdkvm_proj_rows(x2d.data_ptr(), wpack.data_ptr(), bias.data_ptr(), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]),
+                                 rows, k, widths[0], widths[1], widths[2], BF16, _stream(x2d.device))
+    _check(rc, "gdkvm_proj_rows")
+    return tuple(o for o in outs if o is not None)
 
 
 def gate_logits(p_tok: torch.Tensor, w_gate: torch.Tensor, b_gate: torch.Tensor, w_decay: torch.Tensor, b_decay: torch.Tensor):

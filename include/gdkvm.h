@@ -181,6 +181,14 @@ int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* target, uint8_
 int gdkvm_bias_act(const void* x, const float* bias, const void* residual, void* y,
                    size_t rows, int C, int relu, int io_dtype, void* stream);
 
+/* Row n4, the key / query / value projections in one pass over the token rows x [rows, K] (bf16):
+ *   [out0 | out1 | out2][row, :] = x[row, :] W^T + bias,  W [w0 + w1 + w2, K] -- three contiguous outputs [rows, w0], [rows, w1],
+ *   [rows, w2] (w1, w2 may be 0), widths multiples of 16, K a multiple of 32 up to 512, fp32 bias [w0 + w1 + w2].
+ * wpack is W in MFMA fragment order, bf16: element ((ot * K/32 + ks) * 64 + lane) * 8 + j = W[16 ot + (lane & 15)][32 ks + 8 (lane >> 4) + j]
+ * (gdkvm_amd/ops.py::pack_rows_weight builds it).  fp32 accumulation, one rounding. */
+int gdkvm_proj_rows(const void* x, const void* wpack, const float* bias, void* out0, void* out1, void* out2,
+                    long long rows, int K, int w0, int w1, int w2, int io_dtype, void* stream);
+
 /* Row n4, the gates of the memory path in one pass over the stride-16 pixel feature p [frames, N, Cp] (io_dtype):
  *   beta_logit [frames, N, Hh]  = <p[f, n, :], w_gate[h, :]> + b_gate[h]           (per token; what the gate 1x1 projection computes)
  *   alpha_logit [frames, Hh]    = <mean_n p[f, n, :], w_decay[h, :]> + b_decay[h]  (per frame; token mean -> decay projection)

@@ -228,3 +228,24 @@ def test_stem_conv_pool_in_one_kernel(hip, case):
     want = torch.nn.functional.max_pool2d(conv.relu().bfloat16().double(), 3, 2, 1)      # the kernel rounds before pooling (max commutes)
     assert got.shape == want.shape and got.is_contiguous(**cl)
     assert (got.double() - want).abs().max() <= 2.0 ** -7 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(25088, 256, (64, 64, 256)), (1000, 256, (64, 64, 256)), (77, 64, (16, 32)), (5, 512, (48,)), (129, 32, (16, 16, 16))])
+def test_key_query_value_projections_in_one_pass(hip, case):
+    """gdkvm_proj_rows == x W^T + b per projection, fp32 accumulation over the bf16-rounded weights, one rounding."""
+    rows, k, widths = case
+    torch.manual_seed(rows + k)
+    x = torch.randn(rows, k, device="cuda").bfloat16()
+    w = torch.randn(sum(widths), k, device="cuda") / k ** 0.5
+    b = torch.randn(sum(widths), device="cuda")
+    outs = hip.proj_rows(x, hip.pack_rows_weight(w), b, widths)
+    ref = x.double() @ w.bfloat16().double().t() + b.double()
+    assert len(outs) == len(widths)
+    c0 = 0
+    for o, wd in zip(outs, widths):
+        assert o.shape == (rows, wd) and o.is_contiguous() and o.dtype == torch.bfloat16
+        want = ref[:, c0:c0 + wd]
+        assert (o.double() - want).abs().max() <= 2.0 ** -7 * max(1.0, want.abs().max().item())
+        c0 += wd
+    with pytest.raises(hip.GdkvmError):
+        hip.proj_rows(x.float(), hip.pack_rows_weight(w), b, widths)
