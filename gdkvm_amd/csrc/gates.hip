@@ -77,3 +77,68 @@ extern "C" int gdkvm_gate_logits(const void* p, const float* w_gate, const float
     GDKVM_LAUNCH_CHECK("gate_logits_kernel");
     return GDKVM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The decoder's head: a 1x1 convolution from C channels to a few classes on the stride-4 map, written as NCHW planes -- the
+// layout gdkvm_upsample_argmax_dice and gdkvm_seg_loss_fwd read.  As framework ops: library convolution + bias add + an
+// NHWC -> NCHW copy (three launches, ~22 us); here one pass over the feature (the same lanes-per-pixel reduction as above).
+namespace {
+
+template <int IO>
+__global__ __launch_bounds__(256) void head_logits_kernel(const void* x, const float* w, const float* b, void* out,
+                                                          int HW, int C, int ncls, size_t npix)
+{
+    constexpr int V = IO == GDKVM_F32 ? 4 : 8;
+    const int G = C / V, ppw = 64 / G;                       // lanes per pixel, pixels per wave instruction
+    const int lane = threadIdx.x & 63, sub = lane / G, cg = lane % G;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (size_t)gridDim.x * 4;
+    const uint4* xv = static_cast<const uint4*>(x);
+    for (size_t p0 = wave * ppw; p0 < npix; p0 += nwave * ppw) {
+        const size_t p = p0 + sub;
+        const uint4 v4 = xv[min(p, npix - 1) * G + cg];
+        const unsigned xw[4] = {v4.x, v4.y, v4.z, v4.w};
+        float v[V];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (IO == GDKVM_F32) v[j] = __uint_as_float(xw[j]);
+            else { v[2 * j] = __uint_as_float(xw[j] << 16); v[2 * j + 1] = __uint_as_float(xw[j] & 0xffff0000u); }
+        }
+        float mine = 0.f;                                    // lane cg keeps class cg's logit (ncls <= G)
+        for (int c = 0; c < ncls; ++c) {
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < V; ++j) d = fmaf(v[j], w[(size_t)c * C + cg * V + j], d);
+            for (int o = G >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o);
+            if (cg == c) mine = d + b[c];
+        }
+        if (p < npix && cg < ncls) {
+            const size_t n = p / HW, r = p - n * HW;
+            store1<IO>(out, (n * ncls + cg) * HW + r, mine);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int gdkvm_head_logits(const void* x, const float* w, const float* b, void* out, int N, int H, int W, int C, int ncls,
+                                 int io_dtype, void* stream)
+{
+    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "head_logits: io_dtype=%d", io_dtype);
+    const int V = io_dtype == GDKVM_F32 ? 4 : 8;
+    const int G = C > 0 ? C / V : 0;
+    if (N < 0 || H <= 0 || W <= 0 || C <= 0 || C % V || G > 64 || (G & (G - 1)) || ncls <= 0 || ncls > G)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "head_logits: N=%d H=%d W=%d C=%d classes=%d (C/%d a power of two <= 64, classes <= C/%d)", N, H, W, C, ncls, V, V);
+    if (N == 0) return GDKVM_OK;
+    if (!x || !w || !b || !out) return gdkvm_fail(GDKVM_ERR_ARG, "head_logits: null pointer");
+    if (!gdkvm_aligned16(x)) return gdkvm_fail(GDKVM_ERR_ARG, "head_logits: the feature must be 16-byte aligned");
+    if (int rc = gdkvm_check_device()) return rc;
+    const size_t npix = (size_t)N * H * W;
+    const int ppw = 64 / G;
+    size_t blocks = (npix + 4 * (size_t)ppw - 1) / (4 * (size_t)ppw);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((head_logits_kernel<GDKVM_F32>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, b, out, H * W, C, ncls, npix);
+    else hipLaunchKernelGGL((head_logits_kernel<GDKVM_BF16>), dim3((unsigned)blocks), dim3(256), 0, st, x, w, b, out, H * W, C, ncls, npix);
+    GDKVM_LAUNCH_CHECK("head_logits_kernel");
+    return GDKVM_OK;
+}

@@ -152,7 +152,22 @@ class Decoder(nn.Module):
     def forward(self, f, f8, f4, size):
         """size = (H, W): full-resolution logits; size = None: the stride-4 logits (segment() upsamples them inside
         the fused argmax kernel instead of materialising them)."""
-        x = self.head(self.up4(self.up8(f, f8), f4))
+        y = self.up4(self.up8(f, f8), f4)
+        hd = self.head
+        v = 8 if y.dtype == torch.bfloat16 else 4
+        g = y.shape[1] // v
+        if (y.is_cuda and not torch.is_grad_enabled() and y.dtype in (torch.bfloat16, torch.float32) and hd.kernel_size == (1, 1)
+                and hd.stride == (1, 1) and hd.padding == (0, 0) and hd.groups == 1 and hd.bias is not None and y.shape[1] % v == 0
+                and g <= 64 and g & (g - 1) == 0 and hd.out_channels <= g and y.is_contiguous(memory_format=torch.channels_last)):
+            # 1x1 convolution + bias straight into the NCHW planes the argmax / loss kernels read (ops.head_logits): one pass
+            key = (hd.weight._version, hd.bias._version, hd.weight.data_ptr(), y.device)
+            cache = getattr(self, "_head_w32", None)
+            if cache is None or cache[0] != key:
+                cache = (key, hd.weight.detach().reshape(hd.out_channels, -1).float().contiguous(), hd.bias.detach().float().contiguous())
+                self._head_w32 = cache
+            x = ops.head_logits(y, cache[1], cache[2])
+        else:
+            x = hd(y)
         return x if size is None else F.interpolate(x, size=size, mode="bilinear", align_corners=False)
 
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     "gdkvm_kpff_bwd_post": (_i, [_vp] * 7 + [_i] * 7 + [_vp]),
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "gdkvm_bias_act": (_i, [_vp] * 4 + [_sz] + [_i] * 3 + [_vp]),
+    "gdkvm_head_logits": (_i, [_vp] * 4 + [_i] * 6 + [_vp]),
     "gdkvm_proj_rows": (_i, [_vp] * 6 + [ctypes.c_longlong] + [_i] * 5 + [_vp]),
     "gdkvm_stem_conv_pool": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
     "gdkvm_gate_logits": (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
@@ -527,6 +528,25 @@ def bias_act_(x: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tens
                                 n * hh * ww, c, int(relu), _io_dtype(x), _stream(x.device))
     _check(rc, "gdkvm_bias_act")
     return x
+
+
+def head_logits(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """1x1 convolution + bias of a channels_last feature [N,C,H,W] to contiguous NCHW class planes [N,classes,H,W] in x's dtype
+    (gdkvm_head_logits); weight fp32 [classes, C], bias fp32 [classes]."""
+    lib = load()
+    if x.dim() != 4 or not x.is_cuda or not x.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("head_logits needs a channels_last [N,C,H,W] device tensor (no CPU path)")
+    n, c, hh, ww = x.shape
+    ncls = weight.shape[0]
+    if weight.dtype != torch.float32 or bias.dtype != torch.float32 or tuple(weight.shape) != (ncls, c) or bias.numel() != ncls \
+            or not weight.is_contiguous():
+        raise GdkvmError("head_logits: weight fp32 [classes, C] (contiguous), bias fp32 [classes]")
+    out = torch.empty((n, ncls, hh, ww), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.gdkvm_head_logits(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), out.data_ptr(), n, hh, ww, c, ncls,
+                                   _io_dtype(x), _stream(x.device))
+    _check(rc, "gdkvm_head_logits")
+    return out
 
 
 def pack_rows_weight(weight: torch.Tensor) -> torch.Tensor:

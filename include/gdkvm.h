@@ -181,6 +181,12 @@ int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* target, uint8_
 int gdkvm_bias_act(const void* x, const float* bias, const void* residual, void* y,
                    size_t rows, int C, int relu, int io_dtype, void* stream);
 
+/* Row n1, the decoder's head: 1x1 convolution + bias from an NHWC feature x [N, H, W, C] to NCHW class planes out [N, classes, H, W]
+ * (io_dtype; weight fp32 [classes, C], bias fp32 [classes]; classes <= C/8 (bf16) / C/4 (f32)) -- the layout and dtype
+ * gdkvm_upsample_argmax_dice reads; one pass instead of convolution + bias add + layout copy. */
+int gdkvm_head_logits(const void* x, const float* w, const float* b, void* out, int N, int H, int W, int C, int classes,
+                      int io_dtype, void* stream);
+
 /* Row n4, the key / query / value projections in one pass over the token rows x [rows, K] (bf16):
  *   [out0 | out1 | out2][row, :] = x[row, :] W^T + bias,  W [w0 + w1 + w2, K] -- three contiguous outputs [rows, w0], [rows, w1],
  *   [rows, w2] (w1, w2 may be 0), widths multiples of 16, K a multiple of 32 up to 512, fp32 bias [w0 + w1 + w2].

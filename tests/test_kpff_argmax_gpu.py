@@ -249,3 +249,20 @@ def test_key_query_value_projections_in_one_pass(hip, case):
         c0 += wd
     with pytest.raises(hip.GdkvmError):
         hip.proj_rows(x.float(), hip.pack_rows_weight(w), b, widths)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(5, 64, 28, 28, 2), (2, 64, 64, 64, 4), (3, 32, 5, 7, 3), (1, 256, 3, 3, 8)])
+def test_head_logits_planes(hip, dtype, case):
+    """gdkvm_head_logits == 1x1 convolution + bias, written as contiguous NCHW planes."""
+    n, c, h, w, ncls = case
+    if dtype == torch.float32 and ncls > c // 4 or dtype == torch.bfloat16 and ncls > c // 8:
+        pytest.skip("more classes than lanes per pixel")
+    torch.manual_seed(sum(case))
+    x = torch.randn(n, c, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    wt, b = torch.randn(ncls, c, device="cuda") / c ** 0.5, torch.randn(ncls, device="cuda")
+    got = hip.head_logits(x, wt, b)
+    want = torch.nn.functional.conv2d(x.double(), wt.double().reshape(ncls, c, 1, 1), b.double())
+    assert got.shape == want.shape and got.is_contiguous() and got.dtype == dtype
+    tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-5
+    assert (got.double() - want).abs().max() <= tol * max(1.0, want.abs().max().item())
