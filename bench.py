@@ -2,7 +2,8 @@
 """bench.py -- frames/s of the GDKVM forward (encoder -> HIP memory path -> decoder -> HIP argmax mask) on
 BASELINE.json configs[1]: EchoNet-Dynamic 112x112x32 clips, bf16 inference, batch 16 per MI355X, synthetic data.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W        (N>1: one rank per GPU under torch.distributed.run -- either
+                                                          the caller's, or bench.py starts it itself as a child process)
 
 Prints ONE JSON line on rank 0 (contract in the task prompt) with two extra objects:
   roofline      the hot path's dominant kernels (gdr_prepm_kernel + gdr_affine_scan_kernel = one gdkvm_scan_fwd), timed
@@ -30,6 +31,7 @@ sys.path.insert(0, ROOT)
 torch.backends.cudnn.benchmark = True
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+BF16_MFMA_PEAK_TFS = 2500.0    # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA (spec)
 
 
 def host_cores() -> int:
@@ -51,35 +53,100 @@ def scan_algorithmic_bytes(B, T, N, Hh, Dk, Dv, s):
     return B * T * (s * N * (2 * ck + 2 * cv) + 4 * Hh * (1 + N)) + B * 2 * 4 * Hh * Dk * Dv
 
 
-def committed_traffic():
-    """HBM bytes per gdkvm_scan_fwd launch pair from the newest committed PMC summary (profiles/*_pmc_hbm.csv: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  PMC counters
-    cannot be collected from inside this process, so the bench line quotes the committed measurement and names it."""
-    import csv
+SCAN_KERNELS = ("gdr_prepm_kernel", "gdr_affine_scan_kernel", "gdr_compose_kernel", "gdr_readout_kernel")
+
+
+def newest_matching_summary(pattern):
+    """The committed PMC summary (profiles/<pattern>) with the newest `collected` stamp whose `scan_source_hash` equals the
+    hash of the scan kernels' sources in THIS tree (gdkvm_amd.build.source_hash; profiles/pmc_summary.py writes both into
+    the header).  Returns (path | None, why): a summary measured on other sources is stale and is not quoted."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.csv")))
-    if not files:
-        return None, None
+    import re
+    from gdkvm_amd.build import source_hash
+    want, best, seen = source_hash(), None, 0
+    for path in glob.glob(os.path.join(ROOT, "profiles", pattern)):
+        with open(path) as f:
+            m = re.match(r"# scan_source_hash: (\w+) collected: (\S+)", f.readline())
+        if not m:
+            continue                                        # round-1 summaries carry no stamp: never quoted
+        seen += 1
+        if m.group(1) == want and (best is None or m.group(2) > best[0]):
+            best = (m.group(2), path)
+    if best is None:
+        return None, f"no committed {pattern} summary matches scan source hash {want} ({seen} stamped, all stale)"
+    return best[1], os.path.relpath(best[1], ROOT)
+
+
+def committed_traffic():
+    """HBM bytes per gdkvm_scan_fwd (all its launches) from the newest committed PMC summary measured on these very kernel
+    sources (profiles/*_pmc_hbm.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per
+    MI355X_MICROARCH.md §HBM).  PMC counters cannot be collected from inside this process, so the bench line quotes the
+    committed measurement and names it -- or null when the kernels changed since."""
+    import csv
+    path, src = newest_matching_summary("*_pmc_hbm.csv")
+    if path is None:
+        return None, src
     total = 0.0
-    for row in csv.DictReader(l for l in open(files[-1]) if not l.startswith("#")):
-        if row["Kernel"].startswith(("gdr_prepm_kernel", "gdr_affine_scan_kernel", "gdr_compose_kernel")):
+    for row in csv.DictReader(l for l in open(path) if not l.startswith("#")):
+        if row["Kernel"].startswith(SCAN_KERNELS):
             total += float(row["hbm_bytes_read_x2"])
-    return (int(total) if total else None), os.path.relpath(files[-1], ROOT)
+    return (int(total) if total else None), src
 
 
 def committed_mfma_busy():
-    """MFMA-pipe busy fraction of the scan pair from the newest committed SQ counter summary (profiles/*_pmc_sq.csv,
-    profiles/pmc_sq_summary.py): SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), both kernels together."""
+    """MFMA-pipe busy fraction of the scan's kernels from the newest committed SQ counter summary measured on these sources
+    (profiles/*_pmc_sq.csv, profiles/pmc_sq_summary.py): SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1024 SIMDs), together."""
     import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_sq.csv")))
-    if not files:
-        return None, None
+    path, src = newest_matching_summary("*_pmc_sq.csv")
+    if path is None:
+        return None, src
     busy = cyc = 0.0
-    for row in csv.DictReader(l for l in open(files[-1]) if not l.startswith("#")):
-        if row["Kernel"].startswith(("gdr_prepm_kernel", "gdr_affine_scan_kernel", "gdr_compose_kernel")):
+    for row in csv.DictReader(l for l in open(path) if not l.startswith("#")):
+        if row["Kernel"].startswith(SCAN_KERNELS):
             busy += float(row["SQ_VALU_MFMA_BUSY_CYCLES"]); cyc += float(row["kernel_cycles"])
-    return (round(busy / (cyc * 1024), 4) if cyc else None), os.path.relpath(files[-1], ROOT)
+    return (round(busy / (cyc * 1024), 4) if cyc else None), src
+
+
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` without a launcher: start `torch.distributed.run` with N ranks as a CHILD process (this
+    process has not touched the GPU: device_count() does not initialise it on this image), relay its output and exit code.
+    Fewer visible GPUs than N is an error, never a silent one-rank measurement."""
+    import socket
+    import subprocess
+    if not args.selftest_launcher:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but {have} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def launcher_selftest(args, world, rank):
+    """The N > 1 control flow of this file on CPU ranks (gloo): rendezvous, barrier-bracketed timing, max over ranks, ONE
+    JSON line from rank 0.  tests/test_distributed_cpu.py runs it through self_launch(); no GPU, no kernels."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    assert dist.get_world_size() == world == args.gpus
+    x = torch.zeros(4)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x += 1
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ranks = torch.zeros(world, dtype=torch.int64); ranks[rank] = 1
+    dist.all_reduce(ranks)
+    if rank == 0:
+        print(json.dumps({"metric": "launcher selftest (no kernels)", "n_gpus": world, "world_size": dist.get_world_size(),
+                          "ranks_seen": int(ranks.sum()), "steps": args.steps, "backend": "gloo"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def time_events(fn, iters, warmup=3):
@@ -156,13 +223,19 @@ def main():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = BASELINE configs[1] (the headline metric); train = configs[3]: DDP training step")
     ap.add_argument("--kernel-iters", type=int, default=50)
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU/gloo ranks, no kernels: exercises the --gpus N launch path only (tests)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                   # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.selftest_launcher:
+        return launcher_selftest(args, world, rank)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -179,17 +252,32 @@ def main():
     torch.manual_seed(1)                                    # SURVEY.md §8(d) cfg2 seed; same weights on every rank
     ref_state = None
     model = GDKVM(cfg).eval()
+    B, T, S = args.batch, args.frames, args.size
+
+    def clips(seed, n):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        u = torch.rand(n, T, 3, S, S, generator=g)
+        speckle = torch.sqrt(-2.0 * torch.log(torch.rand(n, T, 1, S, S, generator=g).clamp_min(1e-7))) * 0.25
+        return (u * speckle).clamp_(0, 1)
+
+    # A random-init head puts ONE class on every pixel, and a constant mask scores Dice 1 / agreement 1 whatever the kernels
+    # compute.  Shift the head bias by the median logit gap of a calibration clip (the same clip and so the same weights on
+    # every rank) so that the masks the Dice leg compares are mixed; the shift is part of the weights both sides load.
+    with torch.no_grad():
+        m32 = model.to(dev).to(memory_format=torch.channels_last)
+        lg = m32(clips(999, 1).to(dev), _lowres=True).float()
+        for c in range(1, cfg.num_classes):
+            model.decoder.head.bias[c] += (lg[:, :, 0] - lg[:, :, c]).median()
+        model.decoder.head.bias.copy_(model.decoder.head.bias.bfloat16().float())   # exactly representable in the bf16 build
+        model.invalidate_packed_weights()
+        model = model.cpu()
     if rank == 0 and world == 1:
         ref_state = {k_: v_.clone() for k_, v_ in model.state_dict().items()}     # fp32, BatchNorm unfolded
     # inference build: BatchNorm folded into the convs, conv weights held in bf16 (no per-step autocast casts);
     # the KPFF weights and the recurrent state stay fp32
     model = model.fuse_for_inference().to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
-    B, T, S = args.batch, args.frames, args.size
-    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
-    u = torch.rand(B, T, 3, S, S, generator=g)
-    speckle = torch.sqrt(-2.0 * torch.log(torch.rand(B, T, 1, S, S, generator=g).clamp_min(1e-7))) * 0.25
-    frames32 = (u * speckle).clamp_(0, 1)
-    frames = frames32.to(dev).to(torch.bfloat16)            # resident in HBM before the timed region
+    frames32 = clips(1000 + rank, B)
+    frames = frames32.to(dev).to(torch.bfloat16)            # resident in HBM as bf16 before the timed region
 
     def step():
         with torch.no_grad():
@@ -222,7 +310,10 @@ def main():
            "config": {"workload": "BASELINE.json configs[1]: EchoNet-Dynamic 112x112x32 bf16 inference, batch=16 per GPU",
                       "clips_per_gpu": B, "frames_per_clip": T, "image": f"{S}x{S}", "tokens_per_frame": (S // 16) ** 2,
                       "heads": cfg.heads, "key_dim": cfg.key_dim, "value_dim": cfg.value_dim, "rule": cfg.rule,
-                      "sharding": f"clips over {world} GPU(s), no data-path collective"}}
+                      "input": "frames resident in HBM as bf16 before the timed region (host-to-device copy and cast untimed)",
+                      "sharding": f"clips over {world} GPU(s), no data-path collective",
+                      "world_size": (dist.get_world_size() if world > 1 else 1),
+                      "collective_backend": ("nccl (RCCL)" if world > 1 else None)}}
 
     if rank == 0:
         # ---- roofline of the hot path's dominant kernels, live HIP-event timing on the launch stream -------
@@ -265,10 +356,15 @@ def main():
         lowres = torch.randn(B * T, cfg.num_classes, S // 4, S // 4, device=dev, generator=gq).bfloat16()
         am_ms, _ = time_events(lambda: ops.upsample_argmax_dice(lowres, S, S, None), args.kernel_iters)
         am_bytes = lowres.numel() * 2 + B * T * S * S
+        ck_, cv_ = Hh * Dk, Hh * Dv
+        kpff_flops = B * T * 2 * N * (2 * Cp * (Cp + ck_ + cv_) + Cp * ck_ + Cp * cv_)
         out["roofline"]["other_kernels"] = {
+            # KPFF sits near the bf16 balance point: quoted against both ceilings
             "kpff_bf16_kernel": {"avg_ms": round(kpff_ms, 4), "algorithmic_bytes": kpff_bytes,
                                  "achieved_GBps": round(kpff_bytes / (kpff_ms * 1e-3) / 1e9, 1),
-                                 "frac": round(kpff_bytes / (kpff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                                 "frac": round(kpff_bytes / (kpff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                 "flops": kpff_flops, "achieved_TFLOPs": round(kpff_flops / (kpff_ms * 1e-3) / 1e12, 1),
+                                 "frac_bf16_mfma": round(kpff_flops / (kpff_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFS, 5)},
             "upsample_argmax_dice_kernel": {"avg_ms": round(am_ms, 4), "algorithmic_bytes": am_bytes,
                                             "achieved_GBps": round(am_bytes / (am_ms * 1e-3) / 1e9, 1),
                                             "frac": round(am_bytes / (am_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
@@ -296,8 +392,15 @@ def main():
             out["cpu_baseline"] = {"value": round(cpu_fps, 1), "unit": "frames/s", "cores": torch.get_num_threads(),
                                    "kind": "port", "sample": f"{cb} clips x {T} frames {S}x{S}, fp32, median of 3",
                                    "gpu_over_cpu": round(value / world / cpu_fps, 1)}
-            out["dice_vs_cpu"] = {"per_class": [round(d, 5) for d in dice],
-                                  "mask_agreement": round((gmask == cpu_mask).float().mean().item(), 6)}
+            fg = (cpu_mask != 0).float().mean().item()       # share of non-background pixels in the CPU reference's masks
+            if 0.2 < fg < 0.8:
+                out["dice_vs_cpu"] = {"per_class": [round(d, 5) for d in dice],
+                                      "mask_agreement": round((gmask == cpu_mask).float().mean().item(), 6),
+                                      "foreground_fraction": round(fg, 4),
+                                      "compared": "bf16 GPU masks vs fp32 CPU-oracle masks, same clips and weights, head bias balanced"}
+            else:                                            # a (nearly) constant mask says nothing about the kernels
+                out["dice_vs_cpu"] = None
+                out["dice_skipped"] = f"degenerate reference mask: foreground fraction {fg:.4f} outside (0.2, 0.8)"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

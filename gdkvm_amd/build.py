@@ -18,6 +18,21 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+# the files that define the kernels of one gdkvm_scan_fwd (prep + compose + apply + read-out): a committed PMC summary of
+# these kernels (profiles/*_pmc_*.csv) is only quoted by bench.py while this hash still matches the sources it was measured on
+SCAN_SOURCES = ("gdr_prep.hip", "gdr_scan.hip", "gdr_device.hpp", "gdr_ws.hpp", "gdkvm_common.hpp")
+
+
+def source_hash(names=SCAN_SOURCES) -> str:
+    """sha256 (first 16 hex digits) over the named csrc/ files, in the given order."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(CSRC, n), "rb") as f:
+            h.update(n.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def _stale() -> bool:
     if not os.path.exists(SO):
         return True

@@ -46,6 +46,13 @@ def _bn(c):
     return nn.BatchNorm2d(c)
 
 
+def _wkey(*tensors):
+    """Cache key of a weight pack: version counter AND storage address of EVERY source tensor.  In-place writes through
+    ``.data`` (``p.data.copy_()``: EMA swaps, weight surgery) bump neither -- after such a write call
+    ``GDKVM.invalidate_packed_weights()`` (load_state_dict / .to() / train() / fuse_for_inference() do it themselves)."""
+    return tuple((t._version, t.data_ptr()) for t in tensors)
+
+
 _BN_COUNTED_BY_MODEL = [False]
 
 
@@ -160,7 +167,7 @@ class Decoder(nn.Module):
                 and hd.stride == (1, 1) and hd.padding == (0, 0) and hd.groups == 1 and hd.bias is not None and y.shape[1] % v == 0
                 and g <= 64 and g & (g - 1) == 0 and hd.out_channels <= g and y.is_contiguous(memory_format=torch.channels_last)):
             # 1x1 convolution + bias straight into the NCHW planes the argmax / loss kernels read (ops.head_logits): one pass
-            key = (hd.weight._version, hd.bias._version, hd.weight.data_ptr(), y.device)
+            key = _wkey(hd.weight, hd.bias) + (y.device,)
             cache = getattr(self, "_head_w32", None)
             if cache is None or cache[0] != key:
                 cache = (key, hd.weight.detach().reshape(hd.out_channels, -1).float().contiguous(), hd.bias.detach().float().contiguous())
@@ -335,6 +342,27 @@ class GDKVM(nn.Module):
         self.kpff = KPFFParams(Hh * Dk, Hh * Dv, Cp)
         self.decoder = Decoder(Cp, cfg.widths, cfg.num_classes)
 
+    # ------------------------------------------------------------------ packed-weight caches of the inference build
+    def invalidate_packed_weights(self):
+        """Drop the weight packs the inference forward keeps between calls (K/Q/V fragment pack, fp32 gate and head weights,
+        KPFF bf16 pack).  They are keyed on every source tensor's version counter and address (`_wkey`), which catches
+        optimiser steps, ``load_state_dict`` and re-binding; an in-place write through ``.data`` changes neither, so code that
+        does one must call this.  Called by load_state_dict(), _apply() (.to / .cuda / .half ...), train() and
+        fuse_for_inference()."""
+        for name in ("_qkv_pack", "_gate_w32", "_kpff_pack"):
+            self.__dict__.pop(name, None)
+        dec = self._modules.get("decoder") if "_modules" in self.__dict__ else None
+        if dec is not None:
+            dec.__dict__.pop("_head_w32", None)
+
+    def _apply(self, fn, recurse=True):
+        self.invalidate_packed_weights()
+        return super()._apply(fn, recurse)
+
+    def train(self, mode: bool = True):
+        self.invalidate_packed_weights()
+        return super().train(mode)
+
     # ------------------------------------------------------------------ memory path (HIP; overridable hooks)
     def _memory_scan(self, q, k, v, alpha_logit, beta_logit, state):
         """q,k [B,T,N,Hh,Dk] v [B,T,N,Hh,Dv] alpha [B,T,Hh] beta [B,T,N,Hh] -> (R [B,T,N,Hh,Dv], S_T)."""
@@ -348,7 +376,7 @@ class GDKVM(nn.Module):
         if torch.is_grad_enabled() and (pixel.requires_grad or p.wa.requires_grad):
             return ops.kpff(local, glob, pixel, p.wa, p.ba, p.wl, p.wg, h, w)
         # inference: keep the bf16 weight pack of the previous call while the weight tensors are unchanged
-        key = (p.wa._version, p.wl._version, p.wg._version, p.wa.data_ptr(), local.dtype, local.device)
+        key = _wkey(p.wa, p.ba, p.wl, p.wg) + (local.dtype, local.device)
         cache = getattr(self, "_kpff_pack", None)
         hit = cache is not None and cache[0] == key
         ws = cache[1] if hit else torch.empty(ops.load().gdkvm_kpff_workspace_bytes(local.shape[-1], glob.shape[-1], pixel.shape[-1],
@@ -416,7 +444,7 @@ class GDKVM(nn.Module):
             # the three projections in ONE pass over the tokens (ops.proj_rows: token tile in LDS, weights streamed in MFMA
             # fragment order); the packed weight is rebuilt only when a projection's parameters change
             projs = (self.key_proj, self.query_proj, self.value_proj)
-            key = tuple(t._version for c in projs for t in (c.weight, c.bias)) + (projs[0].weight.data_ptr(), tok2d.device)
+            key = _wkey(*(t for c in projs for t in (c.weight, c.bias))) + (tok2d.device,)
             cache = getattr(self, "_qkv_pack", None)
             if cache is None or cache[0] != key:
                 w_all = torch.cat([c.weight.detach().reshape(c.out_channels, -1).float() for c in projs], 0)
@@ -442,7 +470,7 @@ class GDKVM(nn.Module):
                 and p_tok.shape[-1] % v8 == 0 and g_lanes <= 64 and g_lanes & (g_lanes - 1) == 0):
             # both gate logits in one pass over the feature (token mean + two N = 1 projections + casts as framework ops: 6 launches)
             gp, dp = self.gate_proj, self.decay_proj
-            key = (gp.weight._version, gp.bias._version, dp.weight._version, dp.bias._version, gp.weight.data_ptr(), p_tok.device)
+            key = _wkey(gp.weight, gp.bias, dp.weight, dp.bias) + (p_tok.device,)
             cache = getattr(self, "_gate_w32", None)
             if cache is None or cache[0] != key:
                 cache = (key, tuple(t.detach().float().contiguous() for t in (gp.weight.reshape(Hh, -1), gp.bias, dp.weight, dp.bias)))
@@ -466,6 +494,7 @@ class GDKVM(nn.Module):
         (profiles/r01_a_bench_cfg2_kernel_stats.csv)."""
         if self.training:
             raise RuntimeError("fuse_for_inference() needs eval() mode")
+        self.invalidate_packed_weights()
         def fuse_seq(seq):
             """conv, bn, relu -> FusedConv(relu) ; conv, bn -> FusedConv(no relu)"""
             mods, out, i = list(_fold_sequential(seq)), [], 0
@@ -519,4 +548,5 @@ class GDKVM(nn.Module):
                     key = new + key[len(old):]
                     break
             remapped[key] = val
+        self.invalidate_packed_weights()
         return super().load_state_dict(remapped, strict=strict, **kw)

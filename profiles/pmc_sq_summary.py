@@ -7,10 +7,21 @@ summed over the 8 XCDs; MI355X_MICROARCH.md, DVFS note).  SQ_VALU_MFMA_BUSY_CYCL
 v_mfma_f32_16x16x32_bf16, 32 per v_mfma_f32_16x16x4_f32.  The wave-state columns are shares of SQ_WAVE_CYCLES."""
 import collections
 import csv
+import os
 import re
 import sys
+import time
 
 from summarize import short
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def stamp() -> str:
+    """Header line tying the summary to the kernel sources it was measured on: bench.py quotes a summary only while the
+    hash still equals gdkvm_amd.build.source_hash(), and picks the newest summary by `collected`, not by file name."""
+    from gdkvm_amd.build import source_hash
+    return f"# scan_source_hash: {source_hash()} collected: {time.strftime('%Y-%m-%dT%H:%M:%SZ', time.gmtime())}\n"
 
 # kernels kept in the summary: the product's own (hot path, epilogues, convolutions) -- MIOpen's find-mode trial kernels are dropped
 KEEP = r"gdr_|kpff|argmax|conv3x3_c64|grouped_conv|upsample_cat|bias_|stem_|gate_logits|maxpool|bn_|seg_loss"
@@ -22,6 +33,7 @@ def main():
     for r in csv.DictReader(open(src)):
         d[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     with open(dst, "w") as f:
+        f.write(stamp())
         f.write(f"# {cmd}\n# per-launch means\n")
         f.write("Kernel,launches,kernel_cycles,SQ_VALU_MFMA_BUSY_CYCLES,mfma_busy_frac,wait_any_share,wait_inst_share,active_inst_share\n")
         for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", [0]))):

@@ -7,10 +7,21 @@ stores; other access widths are uncalibrated.  The summary therefore reports the
 read bytes side by side (the truth for mixed-width kernels lies between them)."""
 import collections
 import csv
+import os
 import re
 import sys
+import time
 
 from summarize import short
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def stamp() -> str:
+    """Header line tying the summary to the kernel sources it was measured on: bench.py quotes a summary only while the
+    hash still equals gdkvm_amd.build.source_hash(), and picks the newest summary by `collected`, not by file name."""
+    from gdkvm_amd.build import source_hash
+    return f"# scan_source_hash: {source_hash()} collected: {time.strftime('%Y-%m-%dT%H:%M:%SZ', time.gmtime())}\n"
 
 # kernels kept in the summary: the product's own (hot path, epilogues, convolutions) -- MIOpen's find-mode trial kernels are dropped
 KEEP = r"gdr_|kpff|argmax|conv3x3_c64|grouped_conv|upsample_cat|bias_|stem_|gate_logits|maxpool|bn_|seg_loss"
@@ -28,6 +39,7 @@ def main():
     f, w, out, cmd = sys.argv[1:5]
     fe, wr = load(f, "FETCH_SIZE"), load(w, "WRITE_SIZE")
     with open(out, "w") as o:
+        o.write(stamp())
         o.write(f"# {cmd}\n# per-launch means; KiB as reported by rocprofv3; read_x2 = FETCH_SIZE*2 (gfx950 wide-read correction)\n")
         o.write("Kernel,launches,FETCH_SIZE_KiB,WRITE_SIZE_KiB,hbm_bytes_raw,hbm_bytes_read_x2\n")
         for k in sorted(fe, key=lambda k: -sum(fe[k])):

@@ -31,6 +31,45 @@ def test_cfg3_camus_shape_scan_fp32_and_bf16(hip):
     assert np.all(np.abs(R16.float().cpu().numpy() - Rb) <= 1e-4 + np.abs(Rb) * 2.0 ** -8)
 
 
+def test_cfg3_full_size_scan_fp32_and_bf16(hip):
+    """configs[2] at its FULL size: B = 8 clips (4 x 2CH + 4 x 4CH), T = 20 frames of 256x256 (N = 256 tokens), Dv = 256.
+    fp32 I/O against the fp64 oracle at 1e-4 (north_star's tolerance); bf16 I/O against the oracle on the rounded inputs
+    (state 1e-4; the read-out is rounded to bf16 on store: 2^-8 relative on top)."""
+    B, T, N, Hh, Dk, Dv = 8, 20, 256, 1, 64, 256
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=2, normalized=False, logits=True, corr=0.6)
+    Ro, So = c_oracle.scan(q, k, v, a, b, None, 2, 3, math="f64")
+    R, S = hip.scan_fwd(_dev(q), _dev(k), _dev(v), _dev(a), _dev(b), flags=3)
+    assert np.abs(R.cpu().numpy() - Ro).max() <= 1e-4 and np.abs(S.cpu().numpy() - So).max() <= 1e-4
+    qb, kb, vb = (O.to_bf16_f32(x) for x in (q, k, v))
+    Rb, Sb = c_oracle.scan(qb, kb, vb, a, b, None, 2, 3, math="f64")
+    R16, S16 = hip.scan_fwd(_dev(q, torch.bfloat16), _dev(k, torch.bfloat16), _dev(v, torch.bfloat16), _dev(a), _dev(b), flags=3)
+    assert np.abs(S16.cpu().numpy() - Sb).max() <= 1e-4
+    assert np.all(np.abs(R16.float().cpu().numpy() - Rb) <= 1e-4 + np.abs(Rb) * 2.0 ** -8)
+
+
+def test_cfg5_full_size_long_clip_state_carry(hip):
+    """configs[4] at its FULL size: B = 2 clips of T = 512 frames of 256x256 (N = 256), Dv = 256, bf16 I/O, processed as 16
+    chunks of 32 frames with the state carried as a tensor: bit-identical to one call (R and S_T), and the whole 512-frame
+    result within 1e-4 of the fp64 oracle -- which also bounds the long-horizon drift of the split3 (three bf16 terms) chain."""
+    B, T, N, Hh, Dk, Dv = 2, 512, 256, 1, 64, 256
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=4, normalized=False, logits=True)
+    tq, tk, tv = (_dev(x, torch.bfloat16) for x in (q, k, v)); ta, tb = _dev(a), _dev(b)
+    R, S = hip.scan_fwd(tq, tk, tv, ta, tb, flags=3)
+    s, parts = None, []
+    for lo in range(0, T, 32):
+        r, s = hip.scan_fwd(*(x[:, lo:lo + 32].contiguous() for x in (tq, tk, tv, ta, tb)), s, flags=3)
+        parts.append(r)
+    assert torch.equal(torch.cat(parts, 1), R) and torch.equal(s, S)
+    del parts
+    Ro, So = c_oracle.scan(*(O.to_bf16_f32(x) for x in (q, k, v)), a, b, None, 2, 3, math="f64")
+    assert np.abs(S.cpu().numpy() - So).max() <= 1e-4
+    assert np.all(np.abs(R.float().cpu().numpy() - Ro) <= 1e-4 + np.abs(Ro) * 2.0 ** -8)
+    # fp32 I/O over the same 512 frames: one clip, against the oracle outright
+    R32, S32 = hip.scan_fwd(*(_dev(x[:1]) for x in (q, k, v, a, b)), flags=3)
+    Ro, So = c_oracle.scan(q[:1], k[:1], v[:1], a[:1], b[:1], None, 2, 3, math="f64")
+    assert np.abs(S32.cpu().numpy() - So).max() <= 1e-4 and np.abs(R32.cpu().numpy() - Ro).max() <= 1e-4
+
+
 def test_cfg3_camus_module_fp32_vs_bf16_dice(hip):
     """configs[2] end to end: 4-class CAMUS-style head, 256x256, fp32 run vs bf16 run of the SAME GPU module -> Dice of
     the two masks (the fp32 run itself is tied to the CPU reference in tests/test_model_gpu.py)."""
@@ -38,7 +77,7 @@ def test_cfg3_camus_module_fp32_vs_bf16_dice(hip):
     from gdkvm_amd.model import GDKVM, GDKVMConfig
     torch.manual_seed(2)
     model = GDKVM(GDKVMConfig(num_classes=4)).eval().cuda().to(memory_format=torch.channels_last)
-    frames = torch.rand(2, 5, 3, 256, 256, device="cuda")
+    frames = torch.rand(8, 20, 3, 256, 256, device="cuda")                    # configs[2] at full size: 8 clips x 20 frames
     with torch.no_grad():
         lg = model(frames)
         med = lg.float().flatten(3).median(-1).values.mean((0, 1))            # balance the random-init head

@@ -191,3 +191,34 @@ def test_context_parallel_scan_two_ranks():
         assert p.exitcode == 0
     np.testing.assert_allclose(np.concatenate([got[0][0], got[1][0]], 1), R, atol=1e-5)
     np.testing.assert_allclose(got[0][1], S, atol=1e-5); np.testing.assert_allclose(got[1][1], S, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------- bench.py --gpus N launch path
+def _bench(*argv, env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=e, capture_output=True, text=True, timeout=300)
+
+
+def test_bench_self_launches_two_gloo_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts torch.distributed.run itself (as a child process) and
+    relays rank 0's ONE JSON line; exercised on CPU ranks with --selftest-launcher (gloo, no kernels)."""
+    import json
+    p = _bench("--gpus", "2", "--steps", "3", "--selftest-launcher")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world_size"] == 2 and out["ranks_seen"] == 2
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """--gpus 2 on a box with fewer GPUs, or under a launcher with another world size, exits non-zero instead of silently
+    measuring one rank (this container has no GPU at all)."""
+    p = _bench("--gpus", "2", "--steps", "1")
+    assert p.returncode != 0 and "GPU(s) visible" in (p.stderr + p.stdout)
+    p = _bench("--gpus", "2", "--steps", "1", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
