@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <initializer_list>
 #include <type_traits>
 
@@ -276,10 +277,10 @@ struct FoldArgs { const float* wti; const float* knT; const float* ut; float* pp
 
 // grid (FH, 1 + ceil(Dv/64)): block y = 0 folds the four Wt tiles into P, block y > 0 four Ut tiles into G.  Every operand
 // of the block's four tiles is requested up front (20 16-byte loads per lane), then 4 x 4NB MFMA run back to back.
-template <int NB>
+template <int NB, int FMT>
 __global__ __launch_bounds__(256) void gdr_fold_kernel(FoldArgs a)
 {
-    constexpr int NP = 16 * NB;
+    constexpr int NP = 16 * NB, NT = fmt_terms(FMT);
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t fh = blockIdx.x;
@@ -332,15 +333,15 @@ __global__ __launch_bounds__(256) void gdr_fold_kernel(FoldArgs a)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {                  // P[16w + 4g + r][k = 16c + li] -> term images of row tile w
                         const int row = 16 * w + 4 * g + r, col = 16 * c + li;
-                        __bf16 t3[3];
-                        split3((row == col ? 1.f : 0.f) - o[r], t3[0], t3[1], t3[2]);
-                        __bf16* img = reinterpret_cast<__bf16*>(a.pp) + (fh * 4 + w) * (size_t)(3 * SPLIT_IMG * 4);
+                        unsigned short tt[3];
+                        OpFmt<FMT>::split1((row == col ? 1.f : 0.f) - o[r], tt);
+                        unsigned short* img = reinterpret_cast<unsigned short*>(a.pp) + fh * (size_t)(4 * 3 * SPLIT_IMG * 4) + w * (NT * SPLIT_IMG * 4);
                         const int e = split_slot(c, li >> 2, 4 * g + r) * 4 + (li & 3);      // k0 = 16c + 4(li>>2), element li&3
 #pragma unroll
-                        for (int sp = 0; sp < 3; ++sp) img[sp * SPLIT_IMG * 4 + e] = t3[sp];
+                        for (int sp = 0; sp < NT; ++sp) img[sp * SPLIT_IMG * 4 + e] = tt[sp];
                     }
                 } else {
-                    reinterpret_cast<f32x4*>(a.gg)[((fh * nsl + c) * 4 + w) * 64 + lane] = o;
+                    reinterpret_cast<f32x4*>(a.gg)[((fh * nsl + c) * 4 + w) * 64 + lane] = o * OpFmt<FMT>::STATE;   // the scan carries S * STATE
                 }
             }
         }
@@ -348,9 +349,11 @@ __global__ __launch_bounds__(256) void gdr_fold_kernel(FoldArgs a)
 }
 
 template <int NB>
-void launch_fold(const FoldArgs& fa, int FH, hipStream_t st)
+void launch_fold(const FoldArgs& fa, int FH, bool wide, hipStream_t st)
 {
-    hipLaunchKernelGGL((gdr_fold_kernel<NB>), dim3((unsigned)FH, (unsigned)(1 + (fa.Dv / 16 + 3) / 4)), dim3(256), 0, st, fa);
+    const dim3 grid((unsigned)FH, (unsigned)(1 + (fa.Dv / 16 + 3) / 4));
+    if (wide) hipLaunchKernelGGL((gdr_fold_kernel<NB, FMT_SPLIT3>), grid, dim3(256), 0, st, fa);
+    else hipLaunchKernelGGL((gdr_fold_kernel<NB, FMT_PAIR16>), grid, dim3(256), 0, st, fa);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -387,10 +390,10 @@ __host__ __device__ constexpr size_t prepm_lds_bytes(int NB, int IO)
 
 
 
-template <int NB, int IO>
+template <int NB, int IO, int FMT>
 __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(1, 2))) void gdr_prepm_kernel(PrepMArgs a)
 {
-    constexpr int NP = 16 * NB;
+    constexpr int NP = 16 * NB, NT = fmt_terms(FMT);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_kinv = smem;
     float* s_beta = smem + NP;
@@ -666,18 +669,21 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
             continue;
         }
         // lane (g,li) reg r = P[16m + li][k = 16w + 4g + r]: four consecutive k of row li of row tile m -> its term images
-        __bf16 t3[3][4];
+        f32x4 pv;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            split3(((16 * m + li == 16 * w + 4 * g + r) ? 1.f : 0.f) - (acc0[r] + acc1[r]), t3[0][r], t3[1][r], t3[2][r]);
+        for (int r = 0; r < 4; ++r) pv[r] = ((16 * m + li == 16 * w + 4 * g + r) ? 1.f : 0.f) - (acc0[r] + acc1[r]);
+        uint2 tt[3];
+        OpFmt<FMT>::split4(pv, tt);
         const int e = split_slot(w, g, li);
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) pp[(m * 3 + sp) * SPLIT_IMG + e] = pack_bf16x4(t3[sp]);
+        for (int sp = 0; sp < NT; ++sp) pp[(m * NT + sp) * SPLIT_IMG + e] = tt[sp];
     }
     DIAG_STAMP(5);
     f32x4* gg = first_of_many ? x0 + 4 * 4 * 64
               : (chunk == 0 ? reinterpret_cast<f32x4*>(a.gg) + (size_t)fh * nsl * 4 * 64
                             : reinterpret_cast<f32x4*>(a.ggc) + ((size_t)fh * (nchunk - 1) + chunk - 1) * nsl * 4 * 64);
+    // the frame's final G goes to the scan in the scan's scale (it carries S * STATE); chunk maps headed for the composition stay raw
+    const float gscale = nchunk == 1 ? OpFmt<FMT>::STATE : 1.0f;
     auto g_tiles = [&](int cV, const float (&x)[SPLIT ? 1 : NB][4]) __attribute__((always_inline)) {
         if constexpr (!SPLIT)
 #pragma unroll
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
                 if (nlast > 1) { acc1 = mfma4(mt[m][NB - 1][1], x[NB - 1][1], acc1);
                     if (nlast > 2) { acc0 = mfma4(mt[m][NB - 1][2], x[NB - 1][2], acc0);
                         if (nlast > 3) acc1 = mfma4(mt[m][NB - 1][3], x[NB - 1][3], acc1); } } }
-            if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = acc0 + acc1;
+            if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = (acc0 + acc1) * gscale;
         }
     };
     if constexpr (SPLIT) {
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
                     if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m][ks][0], x[ks], acc1, 0, 0, 0);
                     else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m][ks][0], x[ks], acc0, 0, 0, 0);
                 }
-                if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = acc0 + acc1;
+                if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = (acc0 + acc1) * gscale;
             }
         };
         char* vst = reinterpret_cast<char*>(s_kni) + w * 4096;          // two wave-private 2 KiB tiles (the K staging area is free)
@@ -764,18 +770,31 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
     DIAG_STAMP(6);
 }
 
-template <int NB, int IO>
-int launch_prepm(const PrepMArgs& pa, int FH, int nchunk, hipStream_t st)
+template <int NB, int IO, int FMT>
+int launch_prepm_fmt(const PrepMArgs& pa, int FH, int nchunk, hipStream_t st)
 {
     const size_t lds = prepm_lds_bytes(NB, IO);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_prepm_kernel<NB, IO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_prepm: LDS attribute: %s", hipGetErrorString(e));
+        // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device; lock-free cache as in gdr_scan.hip
+        static std::atomic<unsigned long long> done_mask{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_prepm: hipGetDevice");
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_prepm_kernel<NB, IO, FMT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_prepm: LDS attribute: %s", hipGetErrorString(e));
+            done_mask.fetch_or(bit, std::memory_order_relaxed);
+        }
     }
-    hipLaunchKernelGGL((gdr_prepm_kernel<NB, IO>), dim3(FH, nchunk), dim3(256), lds, st, pa);
+    hipLaunchKernelGGL((gdr_prepm_kernel<NB, IO, FMT>), dim3(FH, nchunk), dim3(256), lds, st, pa);
     GDKVM_LAUNCH_CHECK("gdr_prepm_kernel");
     return GDKVM_OK;
+}
+template <int NB, int IO>
+int launch_prepm(const PrepMArgs& pa, int FH, int nchunk, bool wide, hipStream_t st)
+{
+    return wide ? launch_prepm_fmt<NB, IO, FMT_SPLIT3>(pa, FH, nchunk, st) : launch_prepm_fmt<NB, IO, FMT_PAIR16>(pa, FH, nchunk, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -787,9 +806,11 @@ int launch_prepm(const PrepMArgs& pa, int FH, int nchunk, hipStream_t st)
 // Output: the final P as term images (pp) and G as accumulator images (gg), the formats the scan consumes.
 struct ComposeArgs { const float* x0; const float* ppc; const float* ggc; float* pp; float* gg; int Dv, nchunk, additive; };
 
+template <int FMT>
 __global__ __launch_bounds__(256) void gdr_compose_kernel(ComposeArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint2 s_X3[4 * 3 * SPLIT_IMG];        // [col tile j][term] B images
+    constexpr int NT = fmt_terms(FMT);
+    __shared__ __attribute__((aligned(16))) uint2 s_X3[4 * NT * SPLIT_IMG];       // [col tile j][term] B images (pair16: at 2^-4)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t fh = blockIdx.x;
@@ -815,10 +836,10 @@ __global__ __launch_bounds__(256) void gdr_compose_kernel(ComposeArgs a)
     }
     for (int c = 1; c < a.nchunk && !a.additive; ++c) {
         const size_t ci = fh * (a.nchunk - 1) + (c - 1);
-        const bf16x8* pimg = reinterpret_cast<const bf16x8*>(a.ppc) + (ci * 4 + w) * (3 * 2 * 64) + lane;
-        bf16x8 pa[3][2];
+        const uint4* pimg = reinterpret_cast<const uint4*>(a.ppc) + ci * (4 * 3 * 2 * 64) + w * (NT * 2 * 64) + lane;
+        uint4 pa[NT][2];
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp)
+        for (int sp = 0; sp < NT; ++sp)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) pa[sp][ks] = pimg[(sp * 2 + ks) * 64];
         const f32x4* gc = reinterpret_cast<const f32x4*>(a.ggc) + ci * nsl * 4 * 64;
@@ -831,29 +852,21 @@ __global__ __launch_bounds__(256) void gdr_compose_kernel(ComposeArgs a)
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                      // rows 16w + 4g + r of column tile j -> its term images
-            uint2 t3[3];
-            split3x4(X[j], t3[0], t3[1], t3[2]);
+            uint2 tt[3];
+            OpFmt<FMT>::split4(X[j] * OpFmt<FMT>::STATE, tt);
             const int e = split_slot(w, g, li);
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp) s_X3[(j * 3 + sp) * SPLIT_IMG + e] = t3[sp];
+            for (int sp = 0; sp < NT; ++sp) s_X3[(j * NT + sp) * SPLIT_IMG + e] = tt[sp];
         }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            bf16x8 xb[3][2];
+            uint4 xb[NT][2];
 #pragma unroll
-            for (int sp = 0; sp < 3; ++sp)
+            for (int sp = 0; sp < NT; ++sp)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) xb[sp][ks] = *reinterpret_cast<const bf16x8*>(&s_X3[(j * 3 + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#define GDKVM_PX(ACC, PT, XT, KS) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[PT][KS], xb[XT][KS], ACC, 0, 0, 0)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) { GDKVM_PX(acc0, 2, 0, ks); GDKVM_PX(acc1, 0, 2, ks); GDKVM_PX(acc0, 1, 1, ks); }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) { GDKVM_PX(acc1, 1, 0, ks); GDKVM_PX(acc0, 0, 1, ks); }
-            GDKVM_PX(acc1, 0, 0, 0); GDKVM_PX(acc0, 0, 0, 1);
-#undef GDKVM_PX
-            X[j] = acc0 + acc1 + gadd[j];
+                for (int ks = 0; ks < 2; ++ks) xb[sp][ks] = *reinterpret_cast<const uint4*>(&s_X3[(j * NT + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
+            X[j] = OpFmt<FMT>::STATE_INV * OpFmt<FMT>::product(pa, xb) + gadd[j];
         }
         __syncthreads();                                   // the images are rewritten in the next step
     }
@@ -864,15 +877,15 @@ __global__ __launch_bounds__(256) void gdr_compose_kernel(ComposeArgs a)
         if (col < 4) {                                     // P[16w + 4g + r][k = 16 col + li] -> term images of row tile w
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                __bf16 t3[3];
-                split3(X[j][r], t3[0], t3[1], t3[2]);
-                __bf16* img = reinterpret_cast<__bf16*>(a.pp) + (fh * 4 + w) * (size_t)(3 * SPLIT_IMG * 4);
+                unsigned short tt[3];
+                OpFmt<FMT>::split1(X[j][r], tt);
+                unsigned short* img = reinterpret_cast<unsigned short*>(a.pp) + fh * (size_t)(4 * 3 * SPLIT_IMG * 4) + w * (NT * SPLIT_IMG * 4);
                 const int e = split_slot(col, li >> 2, 4 * g + r) * 4 + (li & 3);
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp) img[sp * SPLIT_IMG * 4 + e] = t3[sp];
+                for (int sp = 0; sp < NT; ++sp) img[sp * SPLIT_IMG * 4 + e] = tt[sp];
             }
         } else {
-            reinterpret_cast<f32x4*>(a.gg)[((fh * nsl + (col - 4)) * 4 + w) * 64 + lane] = X[j];
+            reinterpret_cast<f32x4*>(a.gg)[((fh * nsl + (col - 4)) * 4 + w) * 64 + lane] = X[j] * OpFmt<FMT>::STATE;   // the scan carries S * STATE
         }
     }
 }
@@ -914,11 +927,14 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
 #ifdef GDKVM_DIAG
         pm.diag = g_gdkvm_diag_buf;
 #endif
-        if (int rc = io_dtype == GDKVM_F32 ? launch_prepm<4, GDKVM_F32>(pm, B * T * Hh, ws.nchunk, st)
-                                           : launch_prepm<4, GDKVM_BF16>(pm, B * T * Hh, ws.nchunk, st)) return rc;
+        const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
+        if (int rc = io_dtype == GDKVM_F32 ? launch_prepm<4, GDKVM_F32>(pm, B * T * Hh, ws.nchunk, wide, st)
+                                           : launch_prepm<4, GDKVM_BF16>(pm, B * T * Hh, ws.nchunk, wide, st)) return rc;
         if (ws.nchunk > 1) {
             ComposeArgs ca{ws.x0, ws.ppc, ws.ggc, ws.pp, ws.gg, Dv, ws.nchunk, rule == GDKVM_RULE_DELTA_PARALLEL};
-            hipLaunchKernelGGL(gdr_compose_kernel, dim3((unsigned)(B * T * Hh), (unsigned)((4 + Dv / 16 + 3) / 4)), dim3(256), 0, st, ca);
+            const dim3 cgrid((unsigned)(B * T * Hh), (unsigned)((4 + Dv / 16 + 3) / 4));
+            if (wide) hipLaunchKernelGGL(gdr_compose_kernel<FMT_SPLIT3>, cgrid, dim3(256), 0, st, ca);
+            else hipLaunchKernelGGL(gdr_compose_kernel<FMT_PAIR16>, cgrid, dim3(256), 0, st, ca);
             GDKVM_LAUNCH_CHECK("gdr_compose_kernel");
         }
         return GDKVM_OK;
@@ -927,7 +943,7 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
     PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, ws.kn, ws.wtT, ws.qnT, ws.tii, ws.wti, T, Hh, N, Dv, rule, flags};
     if (int rc = io_dtype == GDKVM_F32 ? launch_prep<4, GDKVM_F32, 5>(pa, B * T * Hh, st) : launch_prep<4, GDKVM_BF16, 5>(pa, B * T * Hh, st)) return rc;
     FoldArgs fa{ws.wti, ws.knT, ws.ut, ws.pp, ws.gg, ws.ppt, Dv};
-    launch_fold<4>(fa, B * T * Hh, st);
+    launch_fold<4>(fa, B * T * Hh, flags & GDKVM_FLAG_WIDE_RANGE, st);
     GDKVM_LAUNCH_CHECK("gdr_fold_kernel");
     return GDKVM_OK;
 }

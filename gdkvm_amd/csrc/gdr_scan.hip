@@ -52,22 +52,20 @@ struct AffArgs {
     int T, Hh, N, Dv, flags, BH;
     int reverse;                                     // visit the frames last to first (the backward's reverse recurrence)
     float* simg;                                     // DEFER: per-frame operand images of the state for gdr_readout_kernel
-#ifdef GDKVM_DIAG
-    unsigned long long* diag;
-#endif
 };
 // LDS (16-byte units): S term images [2 parities][3 terms][2 ksteps][64] | (fp32 arm) S fp32 images [2][4][64] | ring slots
 template <int IO> struct RItem;                                        // read-out operands of one 16-token tile
 template <> struct RItem<GDKVM_F32> { f32x4 q[4]; float qinv; };
 template <> struct RItem<GDKVM_BF16> { bf16x8 q[2]; float qinv; };
-constexpr int AFF_P_F4 = 4 * 3 * 2 * 64;                  // P of one frame: [4 row tiles][3 terms][2 ksteps][64 lanes] x 16 B = 24 KiB
-constexpr int AFF_SLOT_F4 = AFF_P_F4 + 4 * 64 + 16;       // + G [4][64] f32x4 + alpha [64 floats]
-constexpr int AFF_S3_F4 = 2 * 3 * 2 * 64;
-constexpr int AFF_LOADS = 8;                              // LDS-DMA instructions per loader wave per frame
-__host__ __device__ constexpr int aff_slots(int IO) { return IO == GDKVM_F32 ? 4 : 5; }
-__host__ __device__ constexpr size_t aff_lds_bytes(int IO)
+// (16-byte units; NT = terms of the operand format: 3 = split3 bf16, 2 = pair16 fp16)
+__host__ __device__ constexpr int aff_p_f4(int NT) { return 4 * NT * 2 * 64; }     // P of one frame: [4 row tiles][NT][2 ksteps][64 lanes] = 8 NT KiB
+__host__ __device__ constexpr int aff_slot_f4(int NT) { return aff_p_f4(NT) + 4 * 64 + 16; }   // + G [4][64] f32x4 + alpha [64 floats]
+__host__ __device__ constexpr int aff_s_f4(int NT) { return 2 * NT * 2 * 64; }     // S term images, two parities
+__host__ __device__ constexpr int aff_loads(int NT) { return 2 * NT + 2; }         // LDS-DMA instructions per loader wave per frame
+__host__ __device__ constexpr int aff_slots(int IO, int NT) { return NT == 2 ? 6 : (IO == GDKVM_F32 ? 4 : 5); }
+__host__ __device__ constexpr size_t aff_lds_bytes(int IO, int NT)
 {
-    return (size_t)(AFF_S3_F4 + (IO == GDKVM_F32 ? 2 * 4 * 64 : 0) + aff_slots(IO) * AFF_SLOT_F4) * 16;
+    return (size_t)(aff_s_f4(NT) + (IO == GDKVM_F32 ? 2 * 4 * 64 : 0) + aff_slots(IO, NT) * aff_slot_f4(NT)) * 16;
 }
 
 __device__ __forceinline__ void aff_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -75,14 +73,18 @@ __device__ __forceinline__ void aff_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // DEFER (frames of more than 64 tokens): every slice workgroup would re-read the whole frame's q -- 32 KB at 256 tokens, and the
 // CU's vector-memory path saturates (1.35 us per frame) -- so the read waves only dump the state's operand images (4 KB per
 // frame and slice) and gdr_readout_kernel does the read-out frame-parallel, reading q once per frame.
-template <int IO, bool DEFER, bool SAVE>
+template <int IO, int FMT, bool DEFER, bool SAVE>
 __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
 {
     constexpr int NB = 4, NP = 16 * NB, JT = 1, NBUF = 4, DEPTH = NBUF - 1, UFR = NBUF / JT;
-    constexpr int NS = aff_slots(IO), D = NS - 1;
+    constexpr int NT = fmt_terms(FMT);
+    constexpr bool PAIR = FMT == FMT_PAIR16;
+    constexpr int NS = aff_slots(IO, NT), D = NS - 1;
+    constexpr int AFF_P_F4 = aff_p_f4(NT), AFF_SLOT_F4 = aff_slot_f4(NT), AFF_LOADS = aff_loads(NT);
+    constexpr float STATE = OpFmt<FMT>::STATE, STATE_INV = OpFmt<FMT>::STATE_INV;      // the kernel carries S' = S * STATE (G arrives scaled alike)
     extern __shared__ __attribute__((aligned(16))) f32x4 aff_smem[];
-    uint2* s_S3 = reinterpret_cast<uint2*>(aff_smem);      // [parity][term] images of SPLIT_IMG uint2: B operand of the bf16 MFMA
-    f32x4* s_Sf = aff_smem + AFF_S3_F4;                    // fp32 arm only: accumulator images for the exact fp32 read-out
+    uint2* s_S3 = reinterpret_cast<uint2*>(aff_smem);      // [parity][term] images of SPLIT_IMG uint2: B operand of the 16x16x32 MFMA
+    f32x4* s_Sf = aff_smem + aff_s_f4(NT);                 // fp32 arm only: accumulator images for the exact fp32 read-out
     f32x4* s_ring = s_Sf + (IO == GDKVM_F32 ? 2 * 4 * 64 : 0);
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
@@ -101,24 +103,21 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
 
     if (role == 2) {
         // ------------------------------------------------------------------------------ loader waves
-        const float* pp_lane = a.pp + ((fh0 * 4 + w) * (3 * 2 * 64) + lane) * 4;      // row tile w: 6 KiB contiguous
-        const size_t pp_fstride = (size_t)Hh * (GDKVM_DK * GDKVM_DK * 3 / 2);
+        const size_t pp_fstride = (size_t)Hh * (GDKVM_DK * GDKVM_DK * 3 / 2);           // a frame-head's slot is sized for three terms
+        const float* pp_lane = a.pp + fh0 * (GDKVM_DK * GDKVM_DK * 3 / 2) + (w * (NT * 2 * 64) + lane) * 4;   // row tile w: 2 NT KiB contiguous
         const float* gg_lane = a.gg + ((a.zero_g ? 0 : ((fh0 * nsl + sl) * 4 + w) * 64) + lane) * 4;
         const size_t gg_fstride = a.zero_g ? 0 : (size_t)Hh * nsl * 4 * 64 * 4;
         const float* al_ptr = a.alpha + fh0;
         auto issue = [&](int f) {
             const int slot = f % NS;
-#ifdef GDKVM_ABL_NOP
-            f = 0;
-#endif
             f = min(f, T - 1);                            // past the end: refetch the last frame into a slot nobody reads
             if (a.reverse) f = T - 1 - f;
             f32x4* dst = s_ring + slot * AFF_SLOT_F4;
             const float* pr = pp_lane + f * pp_fstride;
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < 2 * NT; ++i)
                 __builtin_amdgcn_global_load_lds(pr + 256 * i, reinterpret_cast<__attribute__((address_space(3))) void*>(
-                    reinterpret_cast<uintptr_t>(dst + (w * 6 + i) * 64)), 16, 0, 0);
+                    reinterpret_cast<uintptr_t>(dst + (w * 2 * NT + i) * 64)), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(gg_lane + f * gg_fstride, reinterpret_cast<__attribute__((address_space(3))) void*>(
                 reinterpret_cast<uintptr_t>(dst + AFF_P_F4 + w * 64)), 16, 0, 0);
             __builtin_amdgcn_global_load_lds(al_ptr + (size_t)f * Hh, reinterpret_cast<__attribute__((address_space(3))) void*>(
@@ -140,20 +139,20 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
     // arm also keeps the accumulator image for its exact fp32 read-out.
     auto publish_state = [&](int par, const f32x4& sv) __attribute__((always_inline)) {
         uint2 t3[3];
-        split3x4(sv, t3[0], t3[1], t3[2]);
+        OpFmt<FMT>::split4(sv, t3);
         const int e = split_slot(w, g, li);
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) s_S3[(par * 3 + sp) * SPLIT_IMG + e] = t3[sp];
+        for (int sp = 0; sp < NT; ++sp) s_S3[(par * NT + sp) * SPLIT_IMG + e] = t3[sp];
         if constexpr (IO == GDKVM_F32) s_Sf[par * 256 + w * 64 + lane] = sv;
     };
     f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
     if (role == 0) {
         if (a.s_in) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sacc[r] = a.s_in[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li];
+            for (int r = 0; r < 4; ++r) sacc[r] = STATE * a.s_in[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li];
         } else if (a.init_identity) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sacc[r] = (16 * w + 4 * g + r == 16 * sl + li) ? 1.f : 0.f;
+            for (int r = 0; r < 4; ++r) sacc[r] = (16 * w + 4 * g + r == 16 * sl + li) ? STATE : 0.f;
         }
         publish_state(0, sacc);
     }
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
                 const int par = t & 1;
                 uint4 img;
                 if constexpr (IO == GDKVM_F32) img = *reinterpret_cast<const uint4*>(&s_Sf[par * 256 + w * 64 + lane]);
-                else img = *reinterpret_cast<const uint4*>(&s_S3[(par * 3 + (w >> 1)) * SPLIT_IMG + ((w & 1) * 64 + lane) * 2]);
+                else img = *reinterpret_cast<const uint4*>(&s_S3[(par * NT + (w >> 1)) * SPLIT_IMG + ((w & 1) * 64 + lane) * 2]);
                 dst[(size_t)(a.reverse ? T - 1 - t : t) * d_fstride] = img;
                 aff_barrier();
             }
@@ -190,9 +189,6 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
         char* rbase = static_cast<char*>(a.r_out) + ((size_t)b * T * N * Hh * Dv + h * Dv + 16 * sl + 4 * g) * ESZ;
         const size_t r_fstride = (size_t)N * Hh * Dv * ESZ;
         auto load_q = [&](int item, RItem<IO>& d) __attribute__((always_inline)) {
-#ifdef GDKVM_ABL_NOQ
-            item = 0;
-#endif
             item = min(item, last_item);
             const int t = item / JT, tt = w + 4 * (item - t * JT);
             const int nq = min(16 * tt + li, N - 1);
@@ -219,15 +215,16 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
                 for (int m = 0; m < 4; ++m) sb.f[m] = s_Sf[par * 256 + m * 64 + lane];
             } else {
 #pragma unroll
-                for (int sp = 0; sp < 2; ++sp)         // h + m: 16 bits of S, far inside the bf16 output's 2^-9
+                for (int sp = 0; sp < 2; ++sp)         // split3: h + m, 16 bits of S, far inside the bf16 output's 2^-9; pair16: both terms
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
-                        sb.t[sp][ks] = *reinterpret_cast<const bf16x8*>(&s_S3[(par * 3 + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
+                        sb.t[sp][ks] = *reinterpret_cast<const bf16x8*>(&s_S3[(par * NT + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
             }
         };
         auto read_item = [&](int t, int j, const SB& sb, const RItem<IO>& cur, RItem<IO>& nxt) __attribute__((always_inline)) {
             const int tt = w + 4 * j;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            float rscale = cur.qinv * STATE_INV;
             if constexpr (IO == GDKVM_F32) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
@@ -236,6 +233,16 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
                         if (m & 1) acc1 = mfma4(sb.f[m][r], cur.q[m][r], acc1);
                         else acc0 = mfma4(sb.f[m][r], cur.q[m][r], acc0);
                     }
+            } else if constexpr (PAIR) {                   // q -> fp16 under an exact power-of-two scaling of the token's row
+                const float sc = pow2_floor(cur.qinv);
+                rscale = cur.qinv * pow2_inv(sc) * STATE_INV;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const f16x8 qh = bf16x8_to_f16(cur.q[ks], sc);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sb.t[1][ks]), qh, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sb.t[0][ks]), qh, acc0, 0, 0, 0);
+                }
+                acc1 *= PAIR_LO_INV;
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -243,7 +250,7 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb.t[0][ks], cur.q[ks], acc1, 0, 0, 0);
                 }
             }
-            const f32x4 accR = (acc0 + acc1) * cur.qinv;
+            const f32x4 accR = (acc0 + acc1) * rscale;
             const int nr = 16 * tt + li;                   // this lane's token; its columns 16sl + 4g .. +3
             char* p = (nr < N && a.r_out) ? rbase + t * r_fstride + (size_t)nr * (Hh * Dv * ESZ) : a.trash;
             if constexpr (IO == GDKVM_F32) *reinterpret_cast<f32x4*>(p) = accR;
@@ -253,13 +260,11 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
         auto frame = [&](int t, auto fc) __attribute__((always_inline)) {
             constexpr int F = decltype(fc)::value;
             SB sb;
-#ifndef GDKVM_ABL_NOREAD
             load_sb(t & 1, sb);
             static_for<0, JT>([&](auto jc) {
                 constexpr int i = F * JT + decltype(jc)::value;
                 read_item(t, decltype(jc)::value, sb, qb[i % NBUF], qb[(i + DEPTH) % NBUF]);
             });
-#endif
             aff_barrier();                                 // S_{t-1} consumed / S_t published
         };
         int t0 = 0;
@@ -277,13 +282,13 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
     aff_barrier();
     // P, G and a of frame t+1 are read out of the ring during frame t (the loaders keep two frames landed), so after the
     // barrier only the six S term images stand between the wave and its MFMAs
-    struct POp { bf16x8 pa[3][2]; f32x4 gt; float al; };
+    struct POp { uint4 pa[NT][2]; f32x4 gt; float al; };
     auto load_op = [&](int slot, POp& d) __attribute__((always_inline)) {
         const f32x4* rs = s_ring + slot * AFF_SLOT_F4;
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp)
+        for (int sp = 0; sp < NT; ++sp)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) d.pa[sp][ks] = *reinterpret_cast<const bf16x8*>(&rs[(w * 6 + sp * 2 + ks) * 64 + lane]);
+            for (int ks = 0; ks < 2; ++ks) d.pa[sp][ks] = *reinterpret_cast<const uint4*>(&rs[(w * 2 * NT + sp * 2 + ks) * 64 + lane]);
         d.gt = rs[AFF_P_F4 + w * 64 + lane];
         d.al = reinterpret_cast<const float*>(rs + AFF_P_F4 + 4 * 64)[lane];
     };
@@ -291,41 +296,26 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
     load_op(0, ob[0]);
     auto frame = [&](int t, int slot, const POp& op, POp& nxt) __attribute__((always_inline)) {
         const int par = t & 1;
-        DIAG_STAMP(0);
         if constexpr (SAVE) {
             float* hp = a.s_hist + ((fh0 + (size_t)(a.reverse ? T - 1 - t : t) * Hh) * GDKVM_DK + 16 * w + 4 * g) * Dv + 16 * sl + li;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hp[(size_t)r * Dv] = sacc[r];
+            for (int r = 0; r < 4; ++r) hp[(size_t)r * Dv] = STATE_INV * sacc[r];
         }
-        bf16x8 sb[3][2];
+        uint4 sb[NT][2];
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp)
+        for (int sp = 0; sp < NT; ++sp)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                sb[sp][ks] = *reinterpret_cast<const bf16x8*>(&s_S3[(par * 3 + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
-        DIAG_STAMP(4);
+                sb[sp][ks] = *reinterpret_cast<const uint4*>(&s_S3[(par * NT + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
         load_op((slot + 1) % NS, nxt);
         __builtin_amdgcn_sched_barrier(0);                 // issued here, behind the S reads: left to the scheduler they sink below
-        DIAG_STAMP(5);                                     // the MFMAs and their latency lands on the final FMA
+                                                           // the MFMAs and their latency lands on the final FMA
         const float alpha = gate_logits ? fast_sigmoid(op.al) : op.al;
-        DIAG_STAMP(6);
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#define GDKVM_PS(ACC, PT, ST, KS) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(op.pa[PT][KS], sb[ST][KS], ACC, 0, 0, 0)
+        const f32x4 ps = OpFmt<FMT>::product(op.pa, sb);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {                   // the six terms down to 2^-16, smallest first, two chains
-            GDKVM_PS(acc0, 2, 0, ks); GDKVM_PS(acc1, 0, 2, ks); GDKVM_PS(acc0, 1, 1, ks);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) { GDKVM_PS(acc1, 1, 0, ks); GDKVM_PS(acc0, 0, 1, ks); }
-        GDKVM_PS(acc1, 0, 0, 0); GDKVM_PS(acc0, 0, 0, 1);
-#undef GDKVM_PS
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[r] = alpha * (acc0[r] + acc1[r]) + op.gt[r];
-        DIAG_STAMP(1);
+        for (int r = 0; r < 4; ++r) sacc[r] = alpha * ps[r] + op.gt[r];
         publish_state(par ^ 1, sacc);
-        DIAG_STAMP(2);
         aff_barrier();
-        DIAG_STAMP(3);
     };
     constexpr int UFS = NS % 2 == 0 ? NS : 2 * NS;        // t0 stays a multiple of NS and of 2: slot and buffer ids are static
     int t0 = 0;
@@ -340,13 +330,14 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
     });
     if (a.s_out) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.s_out[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li] = sacc[r];
+        for (int r = 0; r < 4; ++r) a.s_out[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li] = STATE_INV * sacc[r];
     }
 }
 
-template <int IO, bool DEFER, bool SV>
+template <int IO, int FMT, bool DEFER, bool SV>
 int launch_affine(const AffArgs& sa, dim3 grid, hipStream_t st)
 {
+    constexpr int NT = fmt_terms(FMT);
     // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device (a process may drive several devices from several
     // threads: the cache is a lock-free bit mask, a lost race only repeats the idempotent call)
     static std::atomic<unsigned long long> done_mask{0};
@@ -354,32 +345,38 @@ int launch_affine(const AffArgs& sa, dim3 grid, hipStream_t st)
     if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_affine_scan: hipGetDevice");
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_affine_scan_kernel<IO, DEFER, SV>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)aff_lds_bytes(IO));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_affine_scan_kernel<IO, FMT, DEFER, SV>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)aff_lds_bytes(IO, NT));
         if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_affine_scan: LDS attribute: %s", hipGetErrorString(e));
         done_mask.fetch_or(bit, std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, DEFER, SV>), grid, dim3(768), aff_lds_bytes(IO), st, sa);
+    hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, FMT, DEFER, SV>), grid, dim3(768), aff_lds_bytes(IO, NT), st, sa);
     GDKVM_LAUNCH_CHECK("gdr_affine_scan_kernel");
     return GDKVM_OK;
 }
 
-template <int IO>
-int launch_affine_any(bool defer, bool save, const AffArgs& sa, dim3 grid, hipStream_t st)
+template <int IO, int FMT>
+int launch_affine_fmt(bool defer, bool save, const AffArgs& sa, dim3 grid, hipStream_t st)
 {
-    if (defer) return save ? launch_affine<IO, true, true>(sa, grid, st) : launch_affine<IO, true, false>(sa, grid, st);
-    return save ? launch_affine<IO, false, true>(sa, grid, st) : launch_affine<IO, false, false>(sa, grid, st);
+    if (defer) return save ? launch_affine<IO, FMT, true, true>(sa, grid, st) : launch_affine<IO, FMT, true, false>(sa, grid, st);
+    return save ? launch_affine<IO, FMT, false, true>(sa, grid, st) : launch_affine<IO, FMT, false, false>(sa, grid, st);
+}
+template <int IO>
+int launch_affine_any(bool wide, bool defer, bool save, const AffArgs& sa, dim3 grid, hipStream_t st)
+{
+    return wide ? launch_affine_fmt<IO, FMT_SPLIT3>(defer, save, sa, grid, st) : launch_affine_fmt<IO, FMT_PAIR16>(defer, save, sa, grid, st);
 }
 
 // gdr_readout_kernel -- LKVA read-out for frames of more than 64 tokens, frame-parallel: R_t = (Qn_t S_{t-1}) from the operand
 // images the serial kernel dumped.  One workgroup per (frame-head, 8 column tiles); a wave keeps the images of its two column
 // tiles in registers and walks the frame's token tiles, so q is read once per workgroup and nothing goes through LDS.  Same
-// arithmetic and operation order as the in-scan read-out (R^T = S^T Qn^T: h + m terms on the bf16 MFMA, or exact fp32).
+// arithmetic and operation order as the in-scan read-out (R^T = S^T Qn^T: pair16 terms on the f16 MFMA, or exact fp32).
 struct ReadoutArgs { const void* q; const float* qinv; const float* simg; void* r_out; int Hh, N, Dv, NP; };
 
-template <int IO>
+template <int IO, int FMT>
 __global__ __launch_bounds__(256) void gdr_readout_kernel(ReadoutArgs a)
 {
+    constexpr bool PAIR = FMT == FMT_PAIR16;
     constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -409,6 +406,14 @@ __global__ __launch_bounds__(256) void gdr_readout_kernel(ReadoutArgs a)
         d.qi = qinv[min(16 * min(tt, ntt - 1) + li, a.NP - 1)];
     };
     auto tile = [&](int tt, const QT& d) __attribute__((always_inline)) {
+        float rscale = d.qi * OpFmt<FMT>::STATE_INV;         // (the dumped images are those of S * STATE)
+        f16x8 qh[2];
+        if constexpr (IO == GDKVM_BF16 && PAIR) {
+            const float sc = pow2_floor(d.qi);
+            rscale = d.qi * pow2_inv(sc) * OpFmt<FMT>::STATE_INV;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qh[ks] = bf16x8_to_f16(__builtin_bit_cast(bf16x8, d.q[ks]), sc);
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -422,14 +427,21 @@ __global__ __launch_bounds__(256) void gdr_readout_kernel(ReadoutArgs a)
                         else acc0 = mfma4(sm[r], qm[r], acc0);
                     }
                 }
-            } else {
+            } else if constexpr (PAIR) {                   // pair16 images of S (h, l at 2^11), q -> fp16 under a power-of-two scaling
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sb[c][2 + ks]), qh[ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sb[c][ks]), qh[ks], acc1, 0, 0, 0);
+                }
+                acc0 *= PAIR_LO_INV;
+            } else {                                       // split3: the h and m term images, q exactly bf16
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, sb[c][2 + ks]), __builtin_bit_cast(bf16x8, d.q[ks]), acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, sb[c][ks]), __builtin_bit_cast(bf16x8, d.q[ks]), acc1, 0, 0, 0);
                 }
             }
-            const f32x4 accR = (acc0 + acc1) * d.qi;
+            const f32x4 accR = (acc0 + acc1) * rscale;
             const int nr = 16 * tt + li;
             if (nr < N && (c == 0 || two)) {
                 char* p = rbase + (size_t)nr * rowr + c * 16 * ESZ;
@@ -492,17 +504,17 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
     }
     const bool defer = ws.nb > 4 && r_out != nullptr;     // > 64 tokens per frame: read-out by its own frame-parallel kernel
     AffArgs sa{q, alpha, s_in, ws.pp, ws.gg, ws.qinv, defer ? nullptr : r_out, s_out, s_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 0, ws.simg};
-#ifdef GDKVM_DIAG
-    sa.diag = g_gdkvm_diag_buf;
-#endif
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
-    if (int rc = io_dtype == GDKVM_F32 ? launch_affine_any<GDKVM_F32>(defer, s_hist != nullptr, sa, grid, st)
-                                       : launch_affine_any<GDKVM_BF16>(defer, s_hist != nullptr, sa, grid, st)) return rc;
+    const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
+    if (int rc = io_dtype == GDKVM_F32 ? launch_affine_any<GDKVM_F32>(wide, defer, s_hist != nullptr, sa, grid, st)
+                                       : launch_affine_any<GDKVM_BF16>(wide, defer, s_hist != nullptr, sa, grid, st)) return rc;
     if (defer) {
         ReadoutArgs ra{q, ws.qinv, ws.simg, r_out, Hh, N, Dv, 16 * ws.nb};
         const dim3 rgrid((unsigned)(B * T * Hh), (unsigned)((Dv / 16 + 7) / 8));
-        if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32>), rgrid, dim3(256), 0, st, ra);
-        else hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16>), rgrid, dim3(256), 0, st, ra);
+        if (io_dtype == GDKVM_F32 && wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
+        else if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
+        else if (wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
+        else hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
         GDKVM_LAUNCH_CHECK("gdr_readout_kernel");
     }
     return GDKVM_OK;
@@ -523,11 +535,10 @@ extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* p
     hipError_t e = hipMemsetAsync(ws.zero, 0, 64 * 4 * sizeof(float), st);       // the one G tile every frame and slice reads
     if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_transition: memset: %s", hipGetErrorString(e));
     AffArgs sa{q, alpha, nullptr, ws.pp, ws.zero, ws.qinv, nullptr, phi_out, nullptr, ws.trash, 1, 1, T, Hh, N, GDKVM_DK, flags, B * Hh, 0, nullptr};
-#ifdef GDKVM_DIAG
-    sa.diag = nullptr;
-#endif
     const dim3 grid((unsigned)(B * Hh * (GDKVM_DK / 16)));
-    return io_dtype == GDKVM_F32 ? launch_affine<GDKVM_F32, false, false>(sa, grid, st) : launch_affine<GDKVM_BF16, false, false>(sa, grid, st);
+    const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
+    return io_dtype == GDKVM_F32 ? launch_affine_any<GDKVM_F32>(wide, false, false, sa, grid, st)
+                                 : launch_affine_any<GDKVM_BF16>(wide, false, false, sa, grid, st);
 }
 
 extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
@@ -536,6 +547,7 @@ extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const
                               int io_dtype, int rule, int flags, void* stream)
 {
     if (s_hist) flags |= GDKVM_FLAG_TRAIN;              // the backward reads extra operand layouts from the workspace
+    if (rule == GDKVM_RULE_DELTA_PARALLEL) flags |= GDKVM_FLAG_WIDE_RANGE;      // not contractive: full-range operands
     if (int rc = gdkvm_scan_prep(q, k, v, beta, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream)) return rc;
     return gdkvm_scan_apply(q, alpha, s_in, r_out, s_out, s_hist, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, flags, stream);
 }
@@ -588,9 +600,8 @@ int gdr_launch_reverse_scan(const WsView& ws, const float* alpha, const void* d_
         GDKVM_LAUNCH_CHECK("gdr_bwd_g_kernel");
     }
     AffArgs sa{nullptr, alpha, ds_out, ws.ppt, gb, nullptr, nullptr, ds_in, ds_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 1, nullptr};
-#ifdef GDKVM_DIAG
-    sa.diag = nullptr;
-#endif
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
-    return io_dtype == GDKVM_F32 ? launch_affine<GDKVM_F32, false, true>(sa, grid, st) : launch_affine<GDKVM_BF16, false, true>(sa, grid, st);
+    // gradients have no natural magnitude: the reverse recurrence keeps the full-range three-term bf16 operands (P^T images)
+    return io_dtype == GDKVM_F32 ? launch_affine<GDKVM_F32, FMT_SPLIT3, false, true>(sa, grid, st)
+                                 : launch_affine<GDKVM_BF16, FMT_SPLIT3, false, true>(sa, grid, st);
 }

@@ -4,17 +4,19 @@
 
 #include "gdkvm_common.hpp"
 
-constexpr size_t GDKVM_WS_TAIL = 256 + 1024;   // one zero Ut tile (1 KiB) + trash slot for padded read-out rows
+constexpr size_t GDKVM_WS_TAIL = 1024 + 1024;  // one zero G tile (1 KiB) + write-only slot for padded read-out rows (16 B per lane)
 static inline int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
 
 // fp32 workspace per frame-head fh.  NP = 16*nb padded tokens (nb = 4, 8 or 16), NL = min(NP, 64):
 //   legacy WY regions, written by the training-mode prep for frames of <= 64 tokens (the backward's operands), NL tokens wide:
 //     wt [NL][64] | knT [64][NL] | ut [Dv/16][4][64][4] | kn [NL][64] | wtT [64][NL] | qnT [64][NL] | tii [4][16][16] | wti [4][4][64][4]
-//     ppt = P^T as split3 images (like pp), the operator of the backward's reverse recurrence
+//     ppt = P^T as split3 images [4][3][2][64][8] bf16 (three bf16 terms: full fp32 range), the operator of the backward's
+//           reverse recurrence
 //   qinv [NP]
 //   the folded per-frame affine map the forward scan consumes:
-//     pp [4][3][2][64][8] bf16 = P = I - Kn^T Wt split into three bf16 terms (split3) as A-operand images of the bf16 MFMA
-//        (row tile, term, 32-wide k step, lane, 8 k values): 24 KiB = 1.5 Dk Dk floats
+//     pp [4][NT][2][64][8] x 16 bit = P = I - Kn^T Wt as A-operand images of the 16x16x32 MFMA (row tile, term, 32-wide k step,
+//        lane, 8 k values): NT = 2 fp16 terms (pair16, gdr_device.hpp: 16 KiB) by default, NT = 3 bf16 terms (split3: 24 KiB)
+//        under GDKVM_FLAG_WIDE_RANGE; the slot is 24 KiB = 1.5 Dk Dk floats either way
 //     gg [Dv/16][4][64][4] = G = Kn^T Ut as accumulator images (slice, row tile, lane)
 //   frames of more than 64 tokens are folded in chunks of 64 tokens whose affine maps are then composed (nchunk = NP/64):
 //     x0  [4 + Dv/16][4][64][4]  chunk 0 as accumulator images of [P | G]
@@ -47,6 +49,7 @@ static inline int carve(const char* fn, void* workspace, size_t workspace_bytes,
     v->nb = tiles_for(N);
     const size_t NP = 16 * (size_t)v->nb, NL = NP < 64 ? NP : 64, FH = (size_t)B * T * Hh;
     v->nchunk = N > 64 ? (N + 63) / 64 : 1;              // sized for NP/64, the upper bound
+    // every P slot is sized for three bf16 terms (1.5 Dk Dk floats); the default pair16 images use the first Dk Dk of it
     const size_t ppf = (size_t)GDKVM_DK * GDKVM_DK * 3 / 2, ggf = (size_t)GDKVM_DK * Dv;
     float* p = static_cast<float*>(workspace);
     v->wt = p;    p += FH * NL * GDKVM_DK;
@@ -78,7 +81,7 @@ static inline int check_common(const char* fn, int B, int T, int Hh, int N, int 
     if (Dv % 16 != 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: Dv=%d must be a multiple of 16", fn, Dv);
     if (N > GDKVM_MAX_N) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: N=%d exceeds %d tokens per frame", fn, N, GDKVM_MAX_N);
     if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "%s: io_dtype=%d", fn, io_dtype);
-    if (flags & ~7) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: unknown flags 0x%x", fn, flags);
+    if (flags & ~15) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: unknown flags 0x%x", fn, flags);
     return GDKVM_OK;
 }
 

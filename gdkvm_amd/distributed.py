@@ -70,6 +70,8 @@ def context_parallel_scan(q, k, v, alpha, beta, state=None, rule: int = 2, flags
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     ws = backend.new_workspace(B, T, Hh, N, Dk, Dv, q.device)
+    if rule == 1:                                       # delta_parallel: full-range operands in every stage (include/gdkvm.h)
+        flags |= 8                                      # GDKVM_FLAG_WIDE_RANGE
     backend.scan_prep(q, k, v, beta, ws, rule=rule, flags=flags)
     cur = state if state is not None else torch.zeros((B, Hh, Dk, Dv), dtype=torch.float32, device=q.device)
     if world > 1:

@@ -13,7 +13,13 @@ from typing import Optional, Tuple
 import torch
 
 RULE_GATED_LINEAR, RULE_DELTA_PARALLEL, RULE_DELTA_SEQUENTIAL = 0, 1, 2
-FLAG_NORMALIZE_QK, FLAG_GATE_LOGITS = 1, 2
+FLAG_NORMALIZE_QK, FLAG_GATE_LOGITS, FLAG_TRAIN, FLAG_WIDE_RANGE = 1, 2, 4, 8
+
+
+def recurrence_flags(rule: int, flags: int) -> int:
+    """Flags for the split prep / apply / transition entry points: rule delta_parallel is not contractive, so its state
+    recurrence runs on the full-range three-term operands (gdkvm_scan_fwd adds the flag itself)."""
+    return flags | FLAG_WIDE_RANGE if rule == RULE_DELTA_PARALLEL else flags
 F32, BF16 = 0, 1
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
@@ -343,6 +349,7 @@ def scan_fwd_segmented(q, k, v, alpha, beta, state=None, segments: int = 8, rule
     Dv = v.shape[-1]
     if segments <= 1 or T % segments:
         return scan_fwd(q, k, v, alpha, beta, state, rule=rule, flags=flags)
+    flags = recurrence_flags(rule, flags)
     Ts, BS = T // segments, B * segments
     seg = lambda x: x.reshape(BS, Ts, *x.shape[2:])                    # [B,T,...] -> [B*segments, T/segments, ...] (a view)
     qs, ks, vs, als, bes = seg(q), seg(k), seg(v), seg(alpha), seg(beta)

@@ -50,8 +50,13 @@ enum { GDKVM_RULE_GATED_LINEAR = 0,      /* S <- a S + sum_i b_i k_i v_i^T  (lit
 /* prologue flags */
 enum { GDKVM_FLAG_NORMALIZE_QK = 1,      /* q,k <- x * rsqrt(sum x^2 + 1e-12)   */
        GDKVM_FLAG_GATE_LOGITS = 2,       /* alpha, beta are logits -> sigmoid   */
-       GDKVM_FLAG_TRAIN = 4              /* prep also emits the operand layouts gdkvm_scan_bwd reads (set by
-                                            gdkvm_scan_fwd itself whenever s_hist != NULL) */ };
+       GDKVM_FLAG_TRAIN = 4,             /* prep also emits the operand layouts gdkvm_scan_bwd reads (set by
+                                            gdkvm_scan_fwd itself whenever s_hist != NULL) */
+       GDKVM_FLAG_WIDE_RANGE = 8         /* operands of the state recurrence as three bf16 terms (the whole fp32 range, twice
+                                            the MFMAs) instead of the default fp16 pairs, which hold |state| < 1e6 (beyond it
+                                            values saturate) at 22 bits.  gdkvm_scan_fwd sets it itself for rule
+                                            DELTA_PARALLEL, the one rule that is not contractive; a caller of the split
+                                            prep / apply / transition entry points passes the same flags to each. */ };
 
 int gdkvm_abi_version(void);
 const char* gdkvm_last_error(void);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic only: builds ablation variants of the library (extra -D flags on the command line, -DGDKVM_ABL_NOQ | _NOP | _NOREAD)
+"""Diagnostic only: builds ablation variants of the library (extra -D flags on the command line, -DGDKVM_ABL_RNOCVT | _RNOSTORE | _RNOLOAD | _RNOMMA)
 into gpurun_out/ and times scan_prep / scan_apply with them.  Ablated builds compute wrong results by design; their
 timings say which role of the serial kernel bounds a frame.  Never part of the product."""
 import glob
@@ -18,8 +18,12 @@ def main():
     flags = sys.argv[1:]
     so = os.path.join(ROOT, "gpurun_out", "libgdkvm_hip_abl.so")
     os.makedirs(os.path.dirname(so), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + flags +
-                          ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", so] + sorted(glob.glob(os.path.join(CSRC, "*.hip"))))
+    # only the scan kernel is rebuilt with the flags; every other object is the product build's (csrc/_obj travels with the tree)
+    obj = os.path.join(ROOT, "gpurun_out", "gdr_scan_abl.o")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-c"] + flags +
+                          ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, os.path.join(CSRC, "gdr_scan.hip"), "-o", obj])
+    others = [o for o in sorted(glob.glob(os.path.join(CSRC, "_obj", "*.o"))) if not o.endswith("gdr_scan.o")]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, obj] + others)
     from gdkvm_amd import ops
     ops._SO = so
     from tools.config_sweep import ev_time
