@@ -39,6 +39,8 @@ SIGNATURES = {
     "gdkvm_scan_bwd_workspace_bytes": (_sz, [_i] * 6),
     "gdkvm_scan_state_bwd": (_i, [_vp] * 6 + [_sz] + [_vp] * 8 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_bwd": (_i, [_vp] * 7 + [_sz] + [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
+    "gdkvm_readout_fwd": (_i, [_vp] * 3 + [_i] * 9 + [_vp]),
+    "gdkvm_readout_bwd": (_i, [_vp] * 5 + [_i] * 9 + [_vp]),
     "gdkvm_kpff_workspace_bytes": (_sz, [_i] * 4),
     "gdkvm_kpff_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 7 + [_vp]),
     "gdkvm_kpff_fwd_packed": (_i, [_vp] * 9 + [_sz] + [_i] * 7 + [_vp]),
@@ -273,6 +275,43 @@ class _StateScanFunction(torch.autograd.Function):
         return dk, dv, da, db, ds, None, None
 
 
+class _ReadoutFunction(torch.autograd.Function):
+    """The LKVA read-out of frames of more than 64 tokens from the saved state history (gdkvm_readout_fwd), differentiable:
+    the backward (gdkvm_readout_bwd) returns d_q and the gradient with respect to the states the frames read, in the history's
+    own layout, which autograd hands on to _StateScanFunction.backward -> gdkvm_scan_state_bwd.  No framework op computes."""
+
+    @staticmethod
+    def forward(ctx, q, hist, chunks, flags):
+        B, T, N, Hh, Dk = q.shape
+        Dv = hist.shape[-1]
+        dev = _dev(q, hist)
+        if hist.dtype != torch.float32 or tuple(hist.shape) != (B, T * chunks, Hh, Dk, Dv):
+            raise GdkvmError(f"state history must be float32 [B, T*chunks, Hh, Dk, Dv], got {tuple(hist.shape)}")
+        r = torch.empty((B, T, N, Hh, Dv), dtype=q.dtype, device=dev)
+        with torch.cuda.device(dev):
+            rc = load().gdkvm_readout_fwd(_ptr(q), _ptr(hist), _ptr(r), B, T, Hh, N, Dk, Dv, chunks, _io_dtype(q), flags, _stream(dev))
+        _check(rc, "gdkvm_readout_fwd")
+        ctx.save_for_backward(q, hist)
+        ctx.chunks, ctx.flags = chunks, flags
+        return r
+
+    @staticmethod
+    def backward(ctx, d_r):
+        q, hist = ctx.saved_tensors
+        B, T, N, Hh, Dk = q.shape
+        Dv = hist.shape[-1]
+        d_r = d_r.contiguous()
+        if d_r.dtype != q.dtype:
+            d_r = d_r.to(q.dtype)
+        dq = torch.empty_like(q)
+        d_hist = torch.zeros_like(hist)                     # only the states before the frames receive a gradient here
+        with torch.cuda.device(q.device):
+            rc = load().gdkvm_readout_bwd(_ptr(q), _ptr(hist), _ptr(d_r), _ptr(dq), _ptr(d_hist), B, T, Hh, N, Dk, Dv, ctx.chunks,
+                                          _io_dtype(q), ctx.flags, _stream(q.device))
+        _check(rc, "gdkvm_readout_bwd")
+        return dq, d_hist, None, None
+
+
 _BIG_LOGIT = 1.0e30           # sigmoid(+-1e30) is exactly 1 / 0 in the kernels' formulas
 
 
@@ -280,8 +319,8 @@ def _scan_chunked(q, k, v, alpha, beta, state, rule, flags):
     """Training path for frames of more than 64 tokens.  The tokens of a frame act on the state in order, so a frame is a
     sequence of 64-token pseudo-frames: the first carries the frame's gate, the others gate 1, padding tokens beta = 0; the
     state recurrence and its backward run on the 64-token kernels over T * chunks steps.  The read-out of ALL the frame's tokens
-    uses the state before the frame, i.e. before its first pseudo-frame: a batched matmul on the saved state history, whose
-    gradient returns into the reverse recurrence through gdkvm_scan_state_bwd's d_hist."""
+    uses the state before the frame, i.e. before its first pseudo-frame: gdkvm_readout_fwd on the saved state history, whose
+    backward (gdkvm_readout_bwd) sends the state gradients into the reverse recurrence through gdkvm_scan_state_bwd's d_hist."""
     if rule == RULE_DELTA_PARALLEL:
         raise GdkvmError("training with rule delta_parallel is limited to 64 tokens per frame (its chunks combine additively)")
     B, T, N, Hh, Dk = q.shape
@@ -296,11 +335,7 @@ def _scan_chunked(q, k, v, alpha, beta, state, rule, flags):
     one = torch.full((B, T, C - 1, Hh), _BIG_LOGIT if logits else 1.0, dtype=alpha.dtype, device=alpha.device)
     alpha_p = torch.cat([alpha.unsqueeze(2), one], 2).reshape(B, T * C, Hh)
     hist, s_T = _StateScanFunction.apply(k_p.contiguous(), v_p.contiguous(), alpha_p.contiguous(), beta_p.contiguous(), state, rule, flags)
-    s_read = hist.reshape(B, T, C, Hh, Dk, Dv)[:, :, 0]                          # the state before every frame
-    qf = q.float()
-    if flags & FLAG_NORMALIZE_QK:
-        qf = qf * torch.rsqrt((qf * qf).sum(-1, keepdim=True) + 1.0e-12)
-    r = torch.einsum("btnhd,bthde->btnhe", qf, s_read).to(q.dtype)
+    r = _ReadoutFunction.apply(q.contiguous(), hist, C, flags & FLAG_NORMALIZE_QK)   # every frame reads the state before its first chunk
     return r, s_T
 
 

@@ -125,6 +125,17 @@ int gdkvm_scan_state_bwd(const void* k, const void* v, const float* alpha, const
                          void* bwd_workspace, size_t bwd_workspace_bytes,
                          int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream);
 
+/* Rows a1 / a7 for training on frames of more than 64 tokens: the LKVA read-out R_t = diag(qinv) Q_t S_{t-1} of all N tokens of
+ * a frame from a saved state history, and its backward.  s_hist [B, T*hist_stride, Hh, Dk, Dv] fp32 is the history
+ * gdkvm_scan_fwd saves over the 64-token pseudo-frames of gdkvm_amd/ops.py::_scan_chunked (hist_stride of them per frame): frame
+ * t reads the state at index t*hist_stride.  q, r_out, d_r, d_q [B,T,N,Hh,*] in io_dtype.  gdkvm_readout_bwd writes
+ * d_q and the state gradients dS = Qn^T dR into d_hist at the same indices t*hist_stride (the caller zero-fills the rest and
+ * hands d_hist to gdkvm_scan_state_bwd).  GDKVM_FLAG_NORMALIZE_QK as in gdkvm_scan_fwd.  Any N >= 0; Dk == 64; exact fp32. */
+int gdkvm_readout_fwd(const void* q, const float* s_hist, void* r_out, int B, int T, int Hh, int N, int Dk, int Dv,
+                      int hist_stride, int io_dtype, int flags, void* stream);
+int gdkvm_readout_bwd(const void* q, const float* s_hist, const void* d_r, void* d_q, float* d_hist,
+                      int B, int T, int Hh, int N, int Dk, int Dv, int hist_stride, int io_dtype, int flags, void* stream);
+
 /* Row a4: Key-Pixel Feature Fusion ("fuses the local key feature, the global key feature with the pixel
  * feature", /root/reference/website/src/content/homepage/en.json:20; "multiple scales", README.md:20).
  *   local [BT,N,Ck]  global [BT,N,Cv]  pixel [BT,N,Cp]  out [BT,N,Cp]   (io_dtype), N = h*w

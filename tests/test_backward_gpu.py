@@ -159,3 +159,37 @@ def test_kpff_backward_bf16(hip):
         err = np.abs(g.grad.float().cpu().numpy() - r)
         scale = np.abs(r).max()
         assert err.max() <= 0.03 * scale + 1e-2 and err.mean() <= 4e-3 * scale + 1e-3, (name, err.max(), err.mean(), scale)
+
+
+@pytest.mark.parametrize("N,Dv,flags,dtype", [(65, 48, 1, torch.float32), (130, 64, 0, torch.float32), (256, 256, 1, torch.float32),
+                                             (196, 32, 1, torch.bfloat16), (7, 16, 1, torch.float32)])
+def test_readout_from_state_history_and_its_backward(hip, N, Dv, flags, dtype):
+    """gdkvm_readout_fwd / gdkvm_readout_bwd (the training read-out of frames of more than 64 tokens) against fp64 numpy:
+    R = diag(qinv) Q S,  dQ through the L2 normalisation,  dS = Qn^T dR written at the frames' slots of the history."""
+    from gdkvm_amd import ops
+    from oracle import gdkvm_oracle as O
+    B, T, Hh, Dk, C = 2, 3, 2, 64, 3                                   # C pseudo-frames per frame: frame t reads hist[:, t*C]
+    rng = np.random.default_rng(N + Dv)
+    q = rng.standard_normal((B, T, N, Hh, Dk)).astype(np.float32)
+    hist = rng.standard_normal((B, T * C, Hh, Dk, Dv)).astype(np.float32)
+    dR = rng.standard_normal((B, T, N, Hh, Dv)).astype(np.float32)
+    if dtype == torch.bfloat16:
+        q, dR = O.to_bf16_f32(q), O.to_bf16_f32(dR)
+    tq = torch.from_numpy(q).cuda().to(dtype).requires_grad_()
+    th = torch.from_numpy(hist).cuda().requires_grad_()
+    r = ops._ReadoutFunction.apply(tq, th, C, flags)
+    r.backward(torch.from_numpy(dR).cuda().to(dtype))
+    q64, S = q.astype(np.float64), hist.astype(np.float64)[:, ::C]      # [B,T,Hh,Dk,Dv]
+    qi = 1.0 / np.sqrt((q64 ** 2).sum(-1, keepdims=True) + 1e-12) if flags & 1 else np.ones_like(q64[..., :1])
+    qn = q64 * qi
+    R = np.einsum("btnhd,bthde->btnhe", qn, S)
+    dqn = np.einsum("btnhe,bthde->btnhd", dR.astype(np.float64), S)
+    dq = qi * (dqn - qn * (qn * dqn).sum(-1, keepdims=True)) if flags & 1 else dqn
+    dS = np.einsum("btnhd,btnhe->bthde", qn, dR.astype(np.float64))
+    tol = (lambda ref: 1e-4 * max(1.0, np.abs(ref).max()) + (np.abs(ref) * 2.0 ** -7 if dtype == torch.bfloat16 else 0))
+    assert np.all(np.abs(r.detach().float().cpu().numpy() - R) <= tol(R))
+    assert np.all(np.abs(tq.grad.float().cpu().numpy() - dq) <= tol(dq))
+    gh = th.grad.cpu().numpy()
+    assert np.abs(gh[:, ::C] - dS).max() <= 1e-4 * max(1.0, np.abs(dS).max())
+    mask = np.ones(T * C, bool); mask[::C] = False
+    assert not gh[:, mask].any()                                       # the other slots of the history get no gradient here
