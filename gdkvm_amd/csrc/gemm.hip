@@ -1,0 +1,280 @@
+// gemm.hip -- the plain products of the training backward (KPFF's dX / dW products and the 1x1
+// projections' gradients), hand-written for gfx950 instead of library GEMMs.  Token-major operands, fp32 accumulation.
+//
+//   gdkvm_gemm_nt   C[M,N]  = A[M,K] B[N,K]^T (+ bias[N])   both operands K-contiguous (token rows x weight rows): every MFMA fragment
+//                                                   is one 16-byte global load, no LDS.  (dX = dY W^T-form products: the caller
+//                                                   passes the weight with its input index leading, i.e. transposed once.)
+//   gdkvm_gemm_tn   C[K1,N] = A[M,K1]^T B[M,N]     the reduction runs over the ROWS (tokens of the batch: M ~ 25k >> K1, N): split
+//                                                   over workgroups into fp32 partial tiles, summed by a second kernel in a fixed
+//                                                   order (deterministic: no atomics).  Row-major slabs are staged in LDS and read
+//                                                   back transposed (ds_read_b64_tr_b16) as MFMA fragments.
+// bf16 operands run on v_mfma_f32_16x16x32_bf16, fp32 operands on the exact v_mfma_f32_16x16x4_f32.
+#include "gdkvm_common.hpp"
+
+namespace {
+
+struct GemmArgs { const void* a; const void* b; void* c; float* part; const float* bias; int M, N, K, K1, rows_per_split, splits; };
+
+// ---- NT: workgroup tile 128 (M) x 64 (N); wave w owns rows 32w .. 32w+31 and all 64 columns: 2 x 4 accumulator tiles.  The
+// product is computed transposed (C^T = B A^T: the weight rows are the A operand) so that a lane ends with four consecutive
+// columns of one output row (8/16-byte stores).
+template <int IO>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p)
+{
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = p.M, N = p.N, K = p.K;
+    const int m0 = blockIdx.x * 128 + 32 * w, n0 = blockIdx.y * 64;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (IO == GDKVM_BF16) {
+        const bf16_t* A = static_cast<const bf16_t*>(p.a);
+        const bf16_t* B = static_cast<const bf16_t*>(p.b);
+        const bf16_t* ar[2]; const bf16_t* br[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ar[i] = A + (size_t)min(m0 + 16 * i + li, M - 1) * K + 8 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) br[j] = B + (size_t)min(n0 + 16 * j + li, N - 1) * K + 8 * g;
+        bf16x8 av[2], bv[4], an[2], bn[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const bf16x8*>(ar[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const bf16x8*>(br[j]);
+        for (int k = 0; k < K; k += 32) {
+            const int kn = min(k + 32, K - 32);            // next step's fragments in flight behind this step's MFMAs
+#pragma unroll
+            for (int i = 0; i < 2; ++i) an[i] = *reinterpret_cast<const bf16x8*>(ar[i] + kn);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bn[j] = *reinterpret_cast<const bf16x8*>(br[j] + kn);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bv[j], av[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = an[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = bn[j];
+        }
+    } else {
+        // exact fp32: lane group g of k step s takes k = g K/4 + s, so four consecutive steps are one 16-byte load
+        const float* A = static_cast<const float*>(p.a);
+        const float* B = static_cast<const float*>(p.b);
+        const int q4 = K / 4;
+        const float* ar[2]; const float* br[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ar[i] = A + (size_t)min(m0 + 16 * i + li, M - 1) * K + g * q4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) br[j] = B + (size_t)min(n0 + 16 * j + li, N - 1) * K + g * q4;
+        for (int s = 0; s < q4; s += 4) {
+            f32x4 av[2], bv[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const f32x4*>(ar[i] + s);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const f32x4*>(br[j] + s);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma4(bv[j][r], av[i][r], acc[i][j]);
+        }
+    }
+    // acc[i][j][r] = C[m0 + 16i + li][n0 + 16j + 4g + r]
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + 16 * i + li;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 16 * j + 4 * g;
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += p.bias[min(n + r, N - 1)];
+            }
+            if (n + 3 < N && (N & 3) == 0) {
+                if constexpr (IO == GDKVM_F32) *reinterpret_cast<f32x4*>(static_cast<float*>(p.c) + (size_t)m * N + n) = acc[i][j];
+                else *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.c) + (size_t)m * N + n) =
+                         make_uint2((unsigned)f32_to_bf16(acc[i][j][0]) | ((unsigned)f32_to_bf16(acc[i][j][1]) << 16),
+                                    (unsigned)f32_to_bf16(acc[i][j][2]) | ((unsigned)f32_to_bf16(acc[i][j][3]) << 16));
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < N) store1<IO>(p.c, (size_t)m * N + n + r, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+// ---- TN: workgroup tile 64 (K1) x 64 (N) of one row split; wave w owns K1 tile w and all four N tiles.  Per step 32 rows of A
+// (64 columns of this tile) and of B are staged as 16-column sub-tiles [32 rows][16] (1 KiB each, two LDS buffers) and come
+// back through ds_read_b64_tr_b16 with the row index as the MFMA k index.  fp32: 16-row steps, plain LDS reads, exact MFMA.
+constexpr int TN_ROWS = 32;
+
+template <int IO>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p)
+{
+    constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
+    __shared__ __attribute__((aligned(16))) char s_slab[2][2][TN_ROWS * 64 * ESZ];   // [buffer][A | B][sub-tile][row][16]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K1 = p.K1, N = p.N, M = p.M;
+    const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64, z = blockIdx.z;
+    const int r_lo = z * p.rows_per_split, r_hi = min(M, r_lo + p.rows_per_split);
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // staging: thread t moves 16-byte pieces; piece = (row, 16-byte chunk c of the 64-column slab row)
+    constexpr int PIECES = TN_ROWS * 64 * ESZ / 16;        // per matrix: 256 (bf16) or 512 (fp32)
+    constexpr int PER = (PIECES + 255) / 256, CPR = 64 * ESZ / 16;     // pieces per thread, chunks per row
+    constexpr int EPC = 16 / ESZ;                          // elements per chunk
+    uint4 ra[PER], rb[PER];
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int pc = tid + 256 * u, row = pc / CPR, c = pc % CPR;
+            const int m = r0 + row;
+            ra[u] = rb[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (pc < PIECES && m < r_hi) {
+                const int ka = k0 + c * EPC, nb = n0 + c * EPC;
+                if (ka + EPC <= K1) ra[u] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.a) + ((size_t)m * K1 + ka) * ESZ);
+                if (nb + EPC <= N) rb[u] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.b) + ((size_t)m * N + nb) * ESZ);
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int pc = tid + 256 * u, row = pc / CPR, c = pc % CPR;
+            if (pc < PIECES) {
+                // sub-tile = 16 columns: chunk c covers columns c*EPC .. ; sub = column / 16, offset inside the sub-tile row
+                const int col = c * EPC, sub = col >> 4, off = ((row * 16) + (col & 15)) * ESZ + sub * (TN_ROWS * 16 * ESZ);
+                *reinterpret_cast<uint4*>(&s_slab[buf][0][off]) = ra[u];
+                *reinterpret_cast<uint4*>(&s_slab[buf][1][off]) = rb[u];
+            }
+        }
+    };
+    fetch(r_lo);
+    int buf = 0;
+    for (int r0 = r_lo; r0 < r_hi; r0 += TN_ROWS) {
+        stage(buf);
+        __syncthreads();
+        if (r0 + TN_ROWS < r_hi) fetch(r0 + TN_ROWS);      // next slab in flight behind this step's MFMAs
+        if constexpr (IO == GDKVM_BF16) {
+            // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of the group's 4-row block of a [32][16] sub-tile
+            const unsigned la = (unsigned)((8 * g + (li >> 2)) * 16 + 4 * (li & 3)) * 2;
+            auto frag = [&](const char* base) {
+                const unsigned addr = (unsigned)(uintptr_t)base + la;
+                uint2 x0, x1;
+                asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(x0), "=&v"(x1) : "v"(addr) : "memory");
+                return __builtin_bit_cast(bf16x8, make_uint4(x0.x, x0.y, x1.x, x1.y));
+            };
+            const bf16x8 af = frag(&s_slab[buf][0][w * (TN_ROWS * 16 * 2)]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bf16x8 bf = frag(&s_slab[buf][1][j * (TN_ROWS * 16 * 2)]);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[j], 0, 0, 0);
+            }
+        } else {
+            const float* sa = reinterpret_cast<const float*>(&s_slab[buf][0][w * (TN_ROWS * 16 * 4)]);
+#pragma unroll
+            for (int s = 0; s < TN_ROWS / 4; ++s) {        // k step: rows 4s + g
+                const float av = sa[(4 * s + g) * 16 + li];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float bv = reinterpret_cast<const float*>(&s_slab[buf][1][j * (TN_ROWS * 16 * 4)])[(4 * s + g) * 16 + li];
+                    acc[j] = mfma4(av, bv, acc[j]);
+                }
+            }
+        }
+        buf ^= 1;                                          // (the other buffer was last read two barriers ago)
+    }
+    // acc[j][r] = C[k0 + 16w + 4g + r][n0 + 16j + li] of this split
+    float* P = p.part + (size_t)z * K1 * N;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = k0 + 16 * w + 4 * g + r, n = n0 + 16 * j + li;
+            if (kk < K1 && n < N) P[(size_t)kk * N + n] = acc[j][r];
+        }
+}
+
+__global__ void gemm_reduce_kernel(const float* part, float* c, size_t n, int splits)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += part[(size_t)z * n + i];     // fixed order: deterministic
+        c[i] = s;
+    }
+}
+
+int check_gemm(const char* fn, int M, int N, int K, int io_dtype)
+{
+    if (M < 0 || N < 0 || K < 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: negative dimension (M=%d N=%d K=%d)", fn, M, N, K);
+    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "%s: io_dtype=%d", fn, io_dtype);
+    return GDKVM_OK;
+}
+
+}  // namespace
+
+extern "C" int gdkvm_gemm_nt(const void* a, const void* b, const float* bias, void* c, int M, int N, int K, int io_dtype, void* stream)
+{
+    if (int rc = check_gemm("gemm_nt", M, N, K, io_dtype)) return rc;
+    if (M == 0 || N == 0) return GDKVM_OK;
+    const int kq = io_dtype == GDKVM_BF16 ? 32 : 16;
+    if (K == 0 || K % kq) return gdkvm_fail(GDKVM_ERR_SHAPE, "gemm_nt: K=%d must be a positive multiple of %d", K, kq);
+    if (!a || !b || !c || !gdkvm_aligned16(a) || !gdkvm_aligned16(b) || !gdkvm_aligned16(c))
+        return gdkvm_fail(GDKVM_ERR_ARG, "gemm_nt: null or unaligned pointer");
+    if (int rc = gdkvm_check_device()) return rc;
+    GemmArgs ga{a, b, c, nullptr, bias, M, N, K, 0, 0, 0};
+    const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 63) / 64));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gemm_nt_kernel<GDKVM_F32>), grid, dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL((gemm_nt_kernel<GDKVM_BF16>), grid, dim3(256), 0, st, ga);
+    GDKVM_LAUNCH_CHECK("gemm_nt_kernel");
+    return GDKVM_OK;
+}
+
+static int tn_splits(int M) { const int s = (M + 1023) / 1024; return s < 1 ? 1 : s; }
+
+extern "C" size_t gdkvm_gemm_tn_workspace_bytes(int M, int K1, int N)
+{
+    if (M <= 0 || K1 <= 0 || N <= 0) return 16;
+    return (size_t)tn_splits(M) * K1 * N * sizeof(float);
+}
+
+extern "C" int gdkvm_gemm_tn(const void* a, const void* b, float* c, void* workspace, size_t workspace_bytes,
+                             int M, int K1, int N, int io_dtype, void* stream)
+{
+    if (int rc = check_gemm("gemm_tn", M, N, K1, io_dtype)) return rc;
+    if (K1 == 0 || N == 0) return GDKVM_OK;
+    const int eq = io_dtype == GDKVM_BF16 ? 8 : 4;
+    if (K1 % eq || N % eq) return gdkvm_fail(GDKVM_ERR_SHAPE, "gemm_tn: K1=%d and N=%d must be multiples of %d", K1, N, eq);
+    if (!c || !gdkvm_aligned16(c) || (M > 0 && (!a || !b || !gdkvm_aligned16(a) || !gdkvm_aligned16(b))))
+        return gdkvm_fail(GDKVM_ERR_ARG, "gemm_tn: null or unaligned pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = gdkvm_check_device()) return rc;
+    if (M == 0) {
+        hipError_t e = hipMemsetAsync(c, 0, (size_t)K1 * N * sizeof(float), st);
+        return e == hipSuccess ? GDKVM_OK : gdkvm_fail(GDKVM_ERR_LAUNCH, "gemm_tn: memset: %s", hipGetErrorString(e));
+    }
+    const size_t need = gdkvm_gemm_tn_workspace_bytes(M, K1, N);
+    if (!workspace || workspace_bytes < need) return gdkvm_fail(GDKVM_ERR_WORKSPACE, "gemm_tn: workspace %zu < %zu bytes", workspace_bytes, need);
+    const int splits = tn_splits(M);
+    const int rows = ((M + splits - 1) / splits + TN_ROWS - 1) / TN_ROWS * TN_ROWS;
+    GemmArgs ga{a, b, nullptr, static_cast<float*>(workspace), nullptr, M, N, 0, K1, rows, splits};
+    const dim3 grid((unsigned)((K1 + 63) / 64), (unsigned)((N + 63) / 64), (unsigned)splits);
+    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gemm_tn_kernel<GDKVM_F32>), grid, dim3(256), 0, st, ga);
+    else hipLaunchKernelGGL((gemm_tn_kernel<GDKVM_BF16>), grid, dim3(256), 0, st, ga);
+    GDKVM_LAUNCH_CHECK("gemm_tn_kernel");
+    const size_t n = (size_t)K1 * N;
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const float*>(workspace), c, n, splits);
+    GDKVM_LAUNCH_CHECK("gemm_reduce_kernel");
+    return GDKVM_OK;
+}

@@ -41,6 +41,9 @@ SIGNATURES = {
     "gdkvm_scan_bwd": (_i, [_vp] * 7 + [_sz] + [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_readout_fwd": (_i, [_vp] * 3 + [_i] * 9 + [_vp]),
     "gdkvm_readout_bwd": (_i, [_vp] * 5 + [_i] * 9 + [_vp]),
+    "gdkvm_gemm_nt": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
+    "gdkvm_gemm_tn_workspace_bytes": (_sz, [_i] * 3),
+    "gdkvm_gemm_tn": (_i, [_vp] * 4 + [_sz] + [_i] * 4 + [_vp]),
     "gdkvm_kpff_workspace_bytes": (_sz, [_i] * 4),
     "gdkvm_kpff_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 7 + [_vp]),
     "gdkvm_kpff_fwd_packed": (_i, [_vp] * 9 + [_sz] + [_i] * 7 + [_vp]),
@@ -458,8 +461,8 @@ def kpff_fwd(local: torch.Tensor, glob: torch.Tensor, pixel: torch.Tensor, wa: t
 
 
 class _KpffFunction(torch.autograd.Function):
-    """Differentiable KPFF: HIP forward (saving gates / mixes / pooled feature), HIP elementwise + pooling backward;
-    the six plain GEMMs of the backward are library GEMMs (torch.mm -> hipBLASLt/rocBLAS)."""
+    """Differentiable KPFF: HIP forward (saving gates / mixes / pooled feature), HIP elementwise + pooling backward, and the
+    six plain products of the backward on the hand-written MFMA kernels of csrc/gemm.hip."""
 
     @staticmethod
     def forward(ctx, local, glob, pixel, wa, ba, wl, wg, h, w):
@@ -498,13 +501,14 @@ class _KpffFunction(torch.autograd.Function):
             _check(lib.gdkvm_kpff_bwd_pre(_ptr(d_f), _ptr(gates), _ptr(lp), _ptr(gp), _ptr(dz), _ptr(dlp), _ptr(dgp),
                                           BT, N, Cp, io, _stream(dev)), "gdkvm_kpff_bwd_pre")
         L2, P2 = local.reshape(M, Ck), pixel.reshape(M, Cp)
-        wa_c, wl_c, wg_c = wa.to(dt), wl.to(dt), wg.to(dt)
-        dx = dz @ wa_c                                   # [M, Cin]      plain library GEMMs from here ...
-        dl_add = dlp @ wl_c                              # [M, Ck]
-        dg_add = dgp @ wg_c                              # [M, Cv]
-        d_wa = torch.cat([wgrad(dz, P2), wgrad(dz, L2), wgrad(dz, gms)], 1)       # K = B*T*N tokens: split-K, fp32 partials
+        # the six products of the backward on the hand-written kernels (csrc/gemm.hip): dX-type ones as gdkvm_gemm_nt against
+        # the weight with its input index leading (a one-off transpose of a small matrix), dW-type ones as gdkvm_gemm_tn
+        dx = gemm_nt(dz, wa.to(dt).t().contiguous())     # [M, Cin]
+        dl_add = gemm_nt(dlp, wl.to(dt).t().contiguous())   # [M, Ck]
+        dg_add = gemm_nt(dgp, wg.to(dt).t().contiguous())   # [M, Cv]
+        d_wa = torch.cat([wgrad(dz, P2), wgrad(dz, L2), wgrad(dz, gms)], 1)       # K = B*T*N tokens: split over workgroups, fp32 partials
         d_wl = wgrad(dlp, L2)
-        d_wg = wgrad(dgp, gms)                           # ... to here
+        d_wg = wgrad(dgp, gms)
         d_ba = dz.float().sum(0)
         d_p, d_l, d_g = torch.empty_like(pixel), torch.empty_like(local), torch.empty((BT, N, Cv), dtype=dt, device=dev)
         with torch.cuda.device(dev):
@@ -897,38 +901,67 @@ def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
     return _MaxPoolFunction.apply(x)
 
 
-def wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, splits: int = 16) -> torch.Tensor:
-    """dW [M,N] (fp32) = dy^T x for token-major operands dy [K,M], x [K,N] with K (tokens of the batch) >> M, N.  As one
-    library GEMM the K = 25088 reduction of cfg4 lands on four to sixteen workgroups (85-137 us per product,
-    tools/wgrad_probe.py); as a batched split-K call with fp32 partials it is 25-28 us and carries no bf16 rounding of the sum."""
-    K, M = dy2d.shape
+def gemm_nt(a: torch.Tensor, bt: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """C [M,N] = a [M,K] @ bt [N,K]^T (+ bias [N], fp32) on the hand-written MFMA kernel (gdkvm_gemm_nt); a, bt share one dtype
+    (bf16 or fp32), C comes back in it, accumulation is fp32."""
+    lib = load()
+    if a.dim() != 2 or bt.dim() != 2 or a.shape[1] != bt.shape[1] or a.dtype != bt.dtype:
+        raise GdkvmError(f"gemm_nt: a [M,K] and bt [N,K] of one dtype, got {tuple(a.shape)} {a.dtype} / {tuple(bt.shape)} {bt.dtype}")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != bt.shape[0]):
+        raise GdkvmError("gemm_nt: bias must be float32 [N]")
+    kq = 32 if a.dtype == torch.bfloat16 else 16
+    if a.shape[1] % kq:                                     # an odd contraction length: zero columns up to the MFMA's k step
+        pad = kq - a.shape[1] % kq
+        a, bt = torch.nn.functional.pad(a, (0, pad)), torch.nn.functional.pad(bt, (0, pad))
+    dev = _dev(a, bt, bias)
+    M, K = a.shape
+    N = bt.shape[0]
+    c = torch.empty((M, N), dtype=a.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gdkvm_gemm_nt(_ptr(a), _ptr(bt), _ptr(bias), _ptr(c), M, N, K, _io_dtype(a), _stream(dev))
+    _check(rc, "gdkvm_gemm_nt")
+    return c
+
+
+def wgrad(dy2d: torch.Tensor, x2d: torch.Tensor) -> torch.Tensor:
+    """dW [M,N] (fp32) = dy^T x for token-major operands dy [K,M], x [K,N] with K (the tokens of the batch) >> M, N: the
+    reduction over the tokens is split over workgroups into fp32 partial tiles and summed in a fixed order (gdkvm_gemm_tn);
+    the sum never passes through bf16."""
+    lib = load()
+    if dy2d.dim() != 2 or x2d.dim() != 2 or dy2d.shape[0] != x2d.shape[0]:
+        raise GdkvmError("wgrad: dy [K,M] and x [K,N] with equal K")
     if dy2d.dtype != x2d.dtype:
         x2d = x2d.to(dy2d.dtype)
-    if K % splits or K // splits < 64 or not dy2d.is_contiguous() or not x2d.is_contiguous():
-        return (dy2d.t() @ x2d).float()
-    a3 = dy2d.view(splits, K // splits, M).transpose(1, 2)
-    b3 = x2d.view(splits, K // splits, x2d.shape[1])
-    if dy2d.dtype == torch.float32:
-        return torch.bmm(a3, b3).sum(0)
-    return torch.bmm(a3, b3, out_dtype=torch.float32).sum(0)
+    dy2d, x2d = dy2d.contiguous(), x2d.contiguous()
+    dev = _dev(dy2d, x2d)
+    K, M = dy2d.shape
+    N = x2d.shape[1]
+    c = torch.empty((M, N), dtype=torch.float32, device=dev)
+    ws = torch.empty(int(lib.gdkvm_gemm_tn_workspace_bytes(K, M, N)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gdkvm_gemm_tn(_ptr(dy2d), _ptr(x2d), _ptr(c), ws.data_ptr(), ws.numel(), K, M, N, _io_dtype(dy2d), _stream(dev))
+    _check(rc, "gdkvm_gemm_tn")
+    return c
 
 
 class _TokenLinear(torch.autograd.Function):
-    """y = x W^T + b on token rows [K, Cin] (the 1x1 projections).  Forward: one library GEMM with the bias in its epilogue;
-    backward: dX as a library GEMM, dW through wgrad (split-K)."""
+    """y = x W^T + b on token rows [K, Cin] (the 1x1 projections), forward and backward on the hand-written products:
+    gdkvm_gemm_nt with the bias in its epilogue; dX = dY W as gdkvm_gemm_nt on the weight with its input index leading; dW
+    through wgrad (gdkvm_gemm_tn)."""
 
     @staticmethod
     def forward(ctx, x2d, weight, bias):
-        w = weight.to(x2d.dtype)
+        w = weight.to(x2d.dtype).contiguous()
+        x2d = x2d.contiguous()
         ctx.save_for_backward(x2d, w)
         ctx.has_bias, ctx.wdtype = bias is not None, weight.dtype
-        return torch.nn.functional.linear(x2d, w, None if bias is None else bias.to(x2d.dtype))
+        return gemm_nt(x2d, w, None if bias is None else bias.detach().float().contiguous())
 
     @staticmethod
     def backward(ctx, dy):
         x2d, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = dy @ w if ctx.needs_input_grad[0] else None
+        dx = gemm_nt(dy, w.t().contiguous()) if ctx.needs_input_grad[0] else None
         dw = wgrad(dy, x2d).to(ctx.wdtype) if ctx.needs_input_grad[1] else None
         db = dy.float().sum(0).to(ctx.wdtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db

@@ -136,6 +136,17 @@ int gdkvm_readout_fwd(const void* q, const float* s_hist, void* r_out, int B, in
 int gdkvm_readout_bwd(const void* q, const float* s_hist, const void* d_r, void* d_q, float* d_hist,
                       int B, int T, int Hh, int N, int Dk, int Dv, int hist_stride, int io_dtype, int flags, void* stream);
 
+/* Row a7: the plain products of the training backward (KPFF's dX / dW products, the 1x1 projections and their gradients),
+ * hand-written like the rest of the path.  Row-major operands in io_dtype, fp32 accumulation.
+ *   gdkvm_gemm_nt:  C[M,N] = A[M,K] B[N,K]^T (+ bias[N], fp32, may be NULL), C in io_dtype.  K % 32 == 0 (bf16) / % 16 (fp32).
+ *   gdkvm_gemm_tn:  C[K1,N] (fp32) = A[M,K1]^T B[M,N]: the reduction over the M rows (the tokens of a batch) is split over
+ *                   workgroups into fp32 partial tiles in `workspace` (gdkvm_gemm_tn_workspace_bytes) and summed in a fixed
+ *                   order (deterministic).  K1, N multiples of 8 (bf16) / 4 (fp32); any M >= 0. */
+int gdkvm_gemm_nt(const void* a, const void* b, const float* bias, void* c, int M, int N, int K, int io_dtype, void* stream);
+size_t gdkvm_gemm_tn_workspace_bytes(int M, int K1, int N);
+int gdkvm_gemm_tn(const void* a, const void* b, float* c, void* workspace, size_t workspace_bytes,
+                  int M, int K1, int N, int io_dtype, void* stream);
+
 /* Row a4: Key-Pixel Feature Fusion ("fuses the local key feature, the global key feature with the pixel
  * feature", /root/reference/website/src/content/homepage/en.json:20; "multiple scales", README.md:20).
  *   local [BT,N,Ck]  global [BT,N,Cv]  pixel [BT,N,Cp]  out [BT,N,Cp]   (io_dtype), N = h*w
