@@ -10,7 +10,7 @@ typedef unsigned short bf16_t;  // raw bfloat16 bits
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define GDKVM_DK 64             // per-head key dim the kernels are specialised for (SURVEY.md §8 defaults)
-#define GDKVM_MAX_N 256
+#define GDKVM_MAX_N 4096         // tokens per frame (frames of more than 64 are folded per 64-token chunk and composed)
 #define GDKVM_EPS_NORM 1e-12f
 
 // ---- host side -------------------------------------------------------------------------------------

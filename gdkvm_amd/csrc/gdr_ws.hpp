@@ -5,9 +5,9 @@
 #include "gdkvm_common.hpp"
 
 constexpr size_t GDKVM_WS_TAIL = 1024 + 1024;  // one zero G tile (1 KiB) + write-only slot for padded read-out rows (16 B per lane)
-static inline int tiles_for(int N) { return N <= 64 ? 4 : (N <= 128 ? 8 : 16); }
+static inline int tiles_for(int N) { return N <= 64 ? 4 : 4 * ((N + 63) / 64); }   // 16-token tiles of the padded frame: whole 64-token chunks
 
-// fp32 workspace per frame-head fh.  NP = 16*nb padded tokens (nb = 4, 8 or 16), NL = min(NP, 64):
+// fp32 workspace per frame-head fh.  NP = 16*nb padded tokens (nb = 4 per 64-token chunk), NL = min(NP, 64):
 //   legacy WY regions, written by the training-mode prep for frames of <= 64 tokens (the backward's operands), NL tokens wide:
 //     wt [NL][64] | knT [64][NL] | ut [Dv/16][4][64][4] | kn [NL][64] | wtT [64][NL] | qnT [64][NL] | tii [4][16][16] | wti [4][4][64][4]
 //     ppt = P^T as split3 images [4][3][2][64][8] bf16 (three bf16 terms: full fp32 range), the operator of the backward's

@@ -142,6 +142,18 @@ def _stream(dev) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+KERNEL_DK = 64                # per-head key dim the kernels are built for (include/gdkvm.h)
+
+
+def _pad_keys(q, k, state):
+    """Key dims below 64 run on the Dk = 64 kernels with zero channels appended: norms, Gram matrices and read-outs are
+    unchanged, P stays the identity on the extra rows and a zero extra block of the state stays zero -- the result on the real
+    rows is exactly that of the narrower problem (tests/test_scan_gpu.py).  Layout plumbing only; nothing is computed here."""
+    pad = KERNEL_DK - q.shape[-1]
+    Fn = torch.nn.functional
+    return Fn.pad(q, (0, pad)), Fn.pad(k, (0, pad)), (None if state is None else Fn.pad(state, (0, 0, 0, pad)))
+
+
 def scan_workspace_bytes(B, T, Hh, N, Dk, Dv) -> int:
     return int(load().gdkvm_scan_workspace_bytes(B, T, Hh, N, Dk, Dv))
 
@@ -158,6 +170,14 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
     lib = load()
     if q.dim() != 5 or k.shape != q.shape or v.dim() != 5 or v.shape[:4] != q.shape[:4]:
         raise GdkvmError(f"bad shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
+    if q.shape[-1] < KERNEL_DK and state_hist is None:      # narrower keys: exact through zero channels (see _pad_keys)
+        qp, kp, sp = _pad_keys(q, k, state)
+        r, s = scan_fwd(qp, kp, v, alpha, beta, sp, rule, flags, workspace, out, None, None, readout)
+        s = s[:, :, :q.shape[-1]].contiguous()
+        if state_out is not None:
+            state_out.copy_(s)
+            s = state_out
+        return r, s
     B, T, N, Hh, Dk = q.shape
     Dv = v.shape[-1]
     if tuple(alpha.shape) != (B, T, Hh) or tuple(beta.shape) != (B, T, N, Hh):
@@ -344,6 +364,10 @@ def _scan_chunked(q, k, v, alpha, beta, state, rule, flags):
 
 def scan(q, k, v, alpha, beta, state=None, rule: int = RULE_DELTA_SEQUENTIAL, flags: int = 0):
     """scan_fwd with autograd support (training).  Inference callers should use scan_fwd directly (no history)."""
+    if q.shape[-1] < KERNEL_DK:                            # narrower keys (differentiable: padding and slicing are autograd ops)
+        qp, kp, sp = _pad_keys(q, k, state)
+        r, s = scan(qp, kp, v, alpha, beta, sp, rule, flags)
+        return r, s[:, :, :q.shape[-1]]
     if q.shape[2] > 64:
         return _scan_chunked(q, k, v, alpha, beta, state, rule, flags)
     return _ScanFunction.apply(q, k, v, alpha, beta, state, rule, flags)

@@ -149,7 +149,7 @@ def test_scan_empty_and_degenerate(hip):
 
 
 def test_scan_error_codes(hip):
-    q, k, v, a, b = make_scan_inputs(1, 1, 4, 1, 32, 16)
+    q, k, v, a, b = make_scan_inputs(1, 1, 4, 1, 128, 16)          # (Dk below 64 is served through zero channels; above it is not)
     with pytest.raises(hip.GdkvmError, match="Dk"):
         _run(hip, q, k, v, a, b)
     q, k, v, a, b = make_scan_inputs(1, 1, 4, 1, 64, 24)
@@ -219,3 +219,43 @@ def test_scan_state_history(hip, N, dtype):
     for n in range(1, T):
         _, Sn = hip.scan_fwd(*(x[:, :n].contiguous() for x in t), flags=3)
         assert torch.allclose(hist[:, n], Sn, **tol), n
+
+
+@pytest.mark.parametrize("N,dtype", [(300, torch.float32), (1024, torch.bfloat16), (1000, torch.float32)])
+def test_scan_frames_of_more_than_256_tokens(hip, N, dtype):
+    """512x512 inputs give N = 1024 tokens per frame at stride 16: the per-64-token fold + composition carries any chunk count
+    (the round-1 ABI stopped at 256)."""
+    q, k, v, a, b = make_scan_inputs(1, 3, N, 2, 64, 32, seed=N, normalized=False, logits=True, corr=0.5)
+    s0 = np.random.default_rng(3).standard_normal((1, 2, 64, 32)).astype(np.float32) * 0.1
+    if dtype == torch.bfloat16:
+        q, k, v = (O.to_bf16_f32(x) for x in (q, k, v))
+    Rg, Sg = _run(hip, q, k, v, a, b, s0, 2, 3, dtype=dtype)
+    Ro, So = c_oracle.scan(q, k, v, a, b, s0, 2, 3, math="f64")
+    assert np.abs(Sg - So).max() <= TOL
+    assert np.all(np.abs(Rg - Ro) <= TOL + (np.abs(Ro) * 2.0 ** -8 if dtype == torch.bfloat16 else 0))
+
+
+def test_scan_rejects_what_the_kernels_are_not_built_for(hip):
+    """The limits that remain fail loudly with a message (never a silent fallback): Dk other than 64 at the C ABI, Dv not a
+    multiple of 16, more than 4096 tokens per frame, unknown flags."""
+    from gdkvm_amd import ops
+    def call(N=8, Dk=64, Dv=16, flags=0):
+        lib = ops.load()
+        z = torch.zeros(1 * 1 * max(N, 1) * 1 * max(Dk, Dv, 64) * 4 + 1024, device="cuda")
+        ws = torch.empty(max(ops.scan_workspace_bytes(1, 1, 1, min(N, 4096), 64, 16), 4096), dtype=torch.uint8, device="cuda")
+        return lib.gdkvm_scan_fwd(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.data_ptr(), z.data_ptr(), None,
+                                  ws.data_ptr(), ws.numel(), 1, 1, 1, N, Dk, Dv, 0, 2, flags, None)
+    assert call() == 0
+    for kw, msg in [(dict(Dk=32), "Dk=32"), (dict(Dk=128), "Dk=128"), (dict(Dv=24), "Dv=24"), (dict(N=4097), "N=4097"), (dict(flags=64), "flags")]:
+        assert call(**kw) == -1 and msg in ops.load().gdkvm_last_error().decode(), kw
+
+
+@pytest.mark.parametrize("Dk", [32, 16, 48])
+def test_scan_narrower_key_dims_through_zero_channels(hip, Dk):
+    """Dk below 64 at the host seam (gdkvm_amd/ops.py pads zero key channels onto the Dk = 64 kernels): exact against the oracle
+    run at the narrow Dk, state carried in and out at [B,Hh,Dk,Dv]."""
+    q, k, v, a, b = make_scan_inputs(2, 4, 49, 1, Dk, 32, seed=Dk, normalized=False, logits=True, corr=0.4)
+    s0 = np.random.default_rng(Dk).standard_normal((2, 1, Dk, 32)).astype(np.float32) * 0.2
+    Rg, Sg = _run(hip, q, k, v, a, b, s0, 2, 3)
+    Ro, So = c_oracle.scan(q, k, v, a, b, s0, 2, 3, math="f64")
+    assert Sg.shape == So.shape and np.abs(Sg - So).max() <= TOL and np.abs(Rg - Ro).max() <= TOL
