@@ -217,7 +217,15 @@ __device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, i
             if constexpr (NS == 2) b1[o][d] = *reinterpret_cast<const bf16x8*>(w1 + o * ot_stride + off);
         }
     }
-    for (int i = 0; i < n; ++i) {
+    // Token fragments are double-buffered in registers, a whole k-step at a time: with one fragment register re-used per token
+    // tile (what a plain loop compiles to) every ds_read_b128 is followed by a full lgkmcnt(0) wait -- eight exposed LDS
+    // latencies per k-step, about four times the step's MFMA time.
+    auto ldx = [&](int i, bf16x8 (&x)[MT]) __attribute__((always_inline)) {
+        const int ks = ks0 + min(i, n - 1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) x[mt] = *reinterpret_cast<const bf16x8*>(xb + (size_t)mt * 16 * ld + 32 * ks);
+    };
+    auto body = [&](int i, const bf16x8 (&x)[MT], bf16x8 (&xnext)[MT]) __attribute__((always_inline)) {
         const size_t off = KPFF_WOFF((size_t)min(i + 3, n - 1) * 512);
 #pragma unroll
         for (int o = 0; o < OT; ++o) {
@@ -226,16 +234,22 @@ __device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, i
             b0[o][3] = *reinterpret_cast<const bf16x8*>(w0 + o * ot_stride + off);
             if constexpr (NS == 2) b1[o][3] = *reinterpret_cast<const bf16x8*>(w1 + o * ot_stride + off);
         }
+        ldx(i + 1, xnext);                                 // next k-step's fragments: in flight behind this step's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const bf16x8 xv = *reinterpret_cast<const bf16x8*>(xb + (size_t)mt * 16 * ld + 32 * (ks0 + i));
 #pragma unroll
             for (int o = 0; o < OT; ++o) {
-                acc0[o][mt] = mfma_bf16(b0[o][0], xv, acc0[o][mt]);
-                if constexpr (NS == 2) acc1[o][mt] = mfma_bf16(b1[o][0], xv, acc1[o][mt]);
+                acc0[o][mt] = mfma_bf16(b0[o][0], x[mt], acc0[o][mt]);
+                if constexpr (NS == 2) acc1[o][mt] = mfma_bf16(b1[o][0], x[mt], acc1[o][mt]);
             }
         }
-    }
+    };
+    bf16x8 xa[MT], xc[MT];
+    ldx(0, xa);
+    int i = 0;
+    for (; i + 2 <= n; i += 2) { body(i, xa, xc); body(i + 1, xc, xa); }
+    if (i < n) body(i, xa, xc);
 }
 
 // NT = 64-token tiles per workgroup (4*NT waves).  NT = 2 halves the weight traffic per token: at 64 tokens per
