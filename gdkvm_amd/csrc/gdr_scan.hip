@@ -65,7 +65,7 @@ __host__ __device__ constexpr int aff_loads(int NT) { return 2 * NT + 2; }      
 __host__ __device__ constexpr int aff_slots(int IO, int NT) { return NT == 2 ? 6 : (IO == GDKVM_F32 ? 4 : 5); }
 __host__ __device__ constexpr size_t aff_lds_bytes(int IO, int NT)
 {
-    return (size_t)(aff_s_f4(NT) + (IO == GDKVM_F32 ? 2 * 4 * 64 : 0) + aff_slots(IO, NT) * aff_slot_f4(NT)) * 16;
+    return (size_t)(aff_s_f4(NT) + (IO == GDKVM_F32 && NT == 3 ? 2 * 4 * 64 : 0) + aff_slots(IO, NT) * aff_slot_f4(NT)) * 16;
 }
 
 __device__ __forceinline__ void aff_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -84,8 +84,9 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
     constexpr float STATE = OpFmt<FMT>::STATE, STATE_INV = OpFmt<FMT>::STATE_INV;      // the kernel carries S' = S * STATE (G arrives scaled alike)
     extern __shared__ __attribute__((aligned(16))) f32x4 aff_smem[];
     uint2* s_S3 = reinterpret_cast<uint2*>(aff_smem);      // [parity][term] images of SPLIT_IMG uint2: B operand of the 16x16x32 MFMA
-    f32x4* s_Sf = aff_smem + aff_s_f4(NT);                 // fp32 arm only: accumulator images for the exact fp32 read-out
-    f32x4* s_ring = s_Sf + (IO == GDKVM_F32 ? 2 * 4 * 64 : 0);
+    constexpr bool EXACT = IO == GDKVM_F32 && !PAIR;       // fp32 I/O on full-range operands: exact fp32 read-out from fp32 images of S
+    f32x4* s_Sf = aff_smem + aff_s_f4(NT);                 // EXACT only: accumulator images of S
+    f32x4* s_ring = s_Sf + (EXACT ? 2 * 4 * 64 : 0);
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
         const int e = split_slot(w, g, li);
 #pragma unroll
         for (int sp = 0; sp < NT; ++sp) s_S3[(par * NT + sp) * SPLIT_IMG + e] = t3[sp];
-        if constexpr (IO == GDKVM_F32) s_Sf[par * 256 + w * 64 + lane] = sv;
+        if constexpr (EXACT) s_Sf[par * 256 + w * 64 + lane] = sv;
     };
     f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
     if (role == 0) {
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
             for (int t = 0; t < T; ++t) {
                 const int par = t & 1;
                 uint4 img;
-                if constexpr (IO == GDKVM_F32) img = *reinterpret_cast<const uint4*>(&s_Sf[par * 256 + w * 64 + lane]);
+                if constexpr (EXACT) img = *reinterpret_cast<const uint4*>(&s_Sf[par * 256 + w * 64 + lane]);
                 else img = *reinterpret_cast<const uint4*>(&s_S3[(par * NT + (w >> 1)) * SPLIT_IMG + ((w & 1) * 64 + lane) * 2]);
                 dst[(size_t)(a.reverse ? T - 1 - t : t) * d_fstride] = img;
                 aff_barrier();
@@ -193,9 +194,12 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
             const int t = item / JT, tt = w + 4 * (item - t * JT);
             const int nq = min(16 * tt + li, N - 1);
             const char* p = qbase + t * q_fstride + (size_t)nq * (Hh * GDKVM_DK * ESZ);
-            if constexpr (IO == GDKVM_F32) {
+            if constexpr (EXACT) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) d.q[m] = *reinterpret_cast<const f32x4*>(p + 64 * m + 16 * g);
+            } else if constexpr (IO == GDKVM_F32) {        // pair16: channels 32ks + 8g .. +7 as q[2ks], q[2ks + 1]
+#pragma unroll
+                for (int m = 0; m < 4; ++m) d.q[m] = *reinterpret_cast<const f32x4*>(p + 128 * (m >> 1) + 32 * g + 16 * (m & 1));
             } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) d.q[ks] = *reinterpret_cast<const bf16x8*>(p + 64 * ks + 16 * g);
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
         // exact fp32 MFMA); bf16 arm the three term images (q is exactly bf16: two bf16 MFMA per k step).
         struct SB { f32x4 f[4]; bf16x8 t[2][2]; };
         auto load_sb = [&](int par, SB& sb) __attribute__((always_inline)) {
-            if constexpr (IO == GDKVM_F32) {
+            if constexpr (EXACT) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) sb.f[m] = s_Sf[par * 256 + m * 64 + lane];
             } else {
@@ -221,11 +225,34 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
                         sb.t[sp][ks] = *reinterpret_cast<const bf16x8*>(&s_S3[(par * NT + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
             }
         };
-        auto read_item = [&](int t, int j, const SB& sb, const RItem<IO>& cur, RItem<IO>& nxt) __attribute__((always_inline)) {
+        // pair16: the frame's q tile as halves (exact power-of-two scaling of the token's row) and the read-out's final factor
+        // are prepared BEFORE the barrier that releases the frame -- q was fetched three frames ago and does not depend on S --
+        // so that behind the barrier only the S images, four MFMAs and the store stand on the read wave's path.
+        struct QOp { f16x8 qh[2], ql[2]; float rscale; };   // (ql: fp32 I/O only -- q as a pair16 as well)
+        auto prepare = [&](const RItem<IO>& it, QOp& o) __attribute__((always_inline)) {
+            o.rscale = it.qinv * STATE_INV;
+            if constexpr (PAIR) {
+                const float sc = pow2_floor(it.qinv);
+                o.rscale = it.qinv * pow2_inv(sc) * STATE_INV;
+                if constexpr (IO == GDKVM_BF16) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) o.qh[ks] = bf16x8_to_f16(it.q[ks], sc);
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        uint2 h0, l0, h1, l1;
+                        pair16x4(it.q[2 * ks] * sc, h0, l0);
+                        pair16x4(it.q[2 * ks + 1] * sc, h1, l1);
+                        o.qh[ks] = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                        o.ql[ks] = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+                    }
+                }
+            }
+        };
+        auto read_item = [&](int t, int j, const SB& sb, const RItem<IO>& cur, const QOp& op, RItem<IO>& nxt) __attribute__((always_inline)) {
             const int tt = w + 4 * j;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            float rscale = cur.qinv * STATE_INV;
-            if constexpr (IO == GDKVM_F32) {
+            if constexpr (EXACT) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -233,14 +260,13 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
                         if (m & 1) acc1 = mfma4(sb.f[m][r], cur.q[m][r], acc1);
                         else acc0 = mfma4(sb.f[m][r], cur.q[m][r], acc0);
                     }
-            } else if constexpr (PAIR) {                   // q -> fp16 under an exact power-of-two scaling of the token's row
-                const float sc = pow2_floor(cur.qinv);
-                rscale = cur.qinv * pow2_inv(sc) * STATE_INV;
+            } else if constexpr (PAIR) {                   // acc0: hh; acc1: the cross terms carried at 2^11 (fp32 I/O: q is a pair too)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
-                    const f16x8 qh = bf16x8_to_f16(cur.q[ks], sc);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sb.t[1][ks]), qh, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sb.t[0][ks]), qh, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sb.t[1][ks]), op.qh[ks], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sb.t[0][ks]), op.qh[ks], acc0, 0, 0, 0);
+                    if constexpr (IO == GDKVM_F32)
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sb.t[0][ks]), op.ql[ks], acc1, 0, 0, 0);
                 }
                 acc1 *= PAIR_LO_INV;
             } else {
@@ -250,21 +276,23 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sb.t[0][ks], cur.q[ks], acc1, 0, 0, 0);
                 }
             }
-            const f32x4 accR = (acc0 + acc1) * rscale;
+            const f32x4 accR = (acc0 + acc1) * op.rscale;
             const int nr = 16 * tt + li;                   // this lane's token; its columns 16sl + 4g .. +3
-            char* p = (nr < N && a.r_out) ? rbase + t * r_fstride + (size_t)nr * (Hh * Dv * ESZ) : a.trash;
+            // rows of padding tokens go to a write-only slot, one address per lane (a branch would make the vmcnt counting
+            // conservative; one shared address serialises the lanes of a mostly-padded tile in the memory system)
+            char* p = (nr < N && a.r_out) ? rbase + t * r_fstride + (size_t)nr * (Hh * Dv * ESZ) : a.trash + lane * (4 * ESZ);
             if constexpr (IO == GDKVM_F32) *reinterpret_cast<f32x4*>(p) = accR;
             else *reinterpret_cast<uint2*>(p) = make_uint2(cvt_pk_bf16(accR[0], accR[1]), cvt_pk_bf16(accR[2], accR[3]));
             load_q(t * JT + j + DEPTH, nxt);
         };
+        QOp qop[2];
+        prepare(qb[0], qop[0]);
         auto frame = [&](int t, auto fc) __attribute__((always_inline)) {
             constexpr int F = decltype(fc)::value;
             SB sb;
             load_sb(t & 1, sb);
-            static_for<0, JT>([&](auto jc) {
-                constexpr int i = F * JT + decltype(jc)::value;
-                read_item(t, decltype(jc)::value, sb, qb[i % NBUF], qb[(i + DEPTH) % NBUF]);
-            });
+            read_item(t, 0, sb, qb[F % NBUF], qop[F & 1], qb[(F + DEPTH) % NBUF]);
+            prepare(qb[(F + 1) % NBUF], qop[(F + 1) & 1]);   // next frame's operand, off the released path
             aff_barrier();                                 // S_{t-1} consumed / S_t published
         };
         int t0 = 0;
@@ -386,6 +414,7 @@ __global__ __launch_bounds__(256) void gdr_readout_kernel(ReadoutArgs a)
     const int c0 = (blockIdx.y * 4 + w) * 2;
     if (c0 >= nsl) return;
     const bool two = c0 + 1 < nsl;
+    constexpr bool EXACT = IO == GDKVM_F32 && !PAIR;       // (as in the scan: fp32 images + exact fp32 MFMA only on full-range operands)
     const uint4* img = reinterpret_cast<const uint4*>(a.simg) + (fh * nsl + c0) * 4 * 64 + lane;
     uint4 sb[2][4];                                        // [col tile][bf16: term*2 + ks | fp32: k tile m]
 #pragma unroll
@@ -400,24 +429,38 @@ __global__ __launch_bounds__(256) void gdr_readout_kernel(ReadoutArgs a)
     struct QT { uint4 q[IO == GDKVM_F32 ? 4 : 2]; float qi; };
     auto load_q = [&](int tt, QT& d) __attribute__((always_inline)) {
         const int nq = min(16 * min(tt, ntt - 1) + li, N - 1);
-        const char* p = qbase + (size_t)nq * rowq + 16 * g;
+        const char* p = qbase + (size_t)nq * rowq;
+        if constexpr (IO == GDKVM_F32 && PAIR) {           // channels 32ks + 8g .. +7 as q[2ks], q[2ks + 1]
 #pragma unroll
-        for (int i = 0; i < (IO == GDKVM_F32 ? 4 : 2); ++i) d.q[i] = *reinterpret_cast<const uint4*>(p + 64 * i);
+            for (int i = 0; i < 4; ++i) d.q[i] = *reinterpret_cast<const uint4*>(p + 128 * (i >> 1) + 32 * g + 16 * (i & 1));
+        } else {
+#pragma unroll
+            for (int i = 0; i < (IO == GDKVM_F32 ? 4 : 2); ++i) d.q[i] = *reinterpret_cast<const uint4*>(p + 64 * i + 16 * g);
+        }
         d.qi = qinv[min(16 * min(tt, ntt - 1) + li, a.NP - 1)];
     };
     auto tile = [&](int tt, const QT& d) __attribute__((always_inline)) {
         float rscale = d.qi * OpFmt<FMT>::STATE_INV;         // (the dumped images are those of S * STATE)
-        f16x8 qh[2];
-        if constexpr (IO == GDKVM_BF16 && PAIR) {
+        f16x8 qh[2], ql[2];
+        if constexpr (PAIR) {
             const float sc = pow2_floor(d.qi);
             rscale = d.qi * pow2_inv(sc) * OpFmt<FMT>::STATE_INV;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) qh[ks] = bf16x8_to_f16(__builtin_bit_cast(bf16x8, d.q[ks]), sc);
+            for (int ks = 0; ks < 2; ++ks) {
+                if constexpr (IO == GDKVM_BF16) qh[ks] = bf16x8_to_f16(__builtin_bit_cast(bf16x8, d.q[ks]), sc);
+                else {
+                    uint2 h0, l0, h1, l1;
+                    pair16x4(__builtin_bit_cast(f32x4, d.q[2 * ks]) * sc, h0, l0);
+                    pair16x4(__builtin_bit_cast(f32x4, d.q[2 * ks + 1]) * sc, h1, l1);
+                    qh[ks] = __builtin_bit_cast(f16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+                    ql[ks] = __builtin_bit_cast(f16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+                }
+            }
         }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (IO == GDKVM_F32) {
+            if constexpr (EXACT) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const f32x4 sm = __builtin_bit_cast(f32x4, sb[c][m]), qm = __builtin_bit_cast(f32x4, d.q[m]);
@@ -432,6 +475,8 @@ __global__ __launch_bounds__(256) void gdr_readout_kernel(ReadoutArgs a)
                 for (int ks = 0; ks < 2; ++ks) {
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sb[c][2 + ks]), qh[ks], acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sb[c][ks]), qh[ks], acc1, 0, 0, 0);
+                    if constexpr (IO == GDKVM_F32)
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sb[c][ks]), ql[ks], acc0, 0, 0, 0);
                 }
                 acc0 *= PAIR_LO_INV;
             } else {                                       // split3: the h and m term images, q exactly bf16
