@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(Conv64Args a)
 
 }  // namespace
 
-// internal entry used by gdkvm_conv_bias_act (conv_ck.hip): returns 0 on launch
+// internal entry used by gdkvm_conv_bias_act (conv_dispatch.hip): returns 0 on launch
 int gdkvm_conv3x3_c64_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, int N, int H, int W,
                              int relu, hipStream_t st)
 {

@@ -1,0 +1,46 @@
+// conv_dispatch.hip -- C entry of the convolutions that carry their epilogue.  Both kernels behind it are
+// hand-written for gfx950: conv3x3_c64.hip (64 -> 64 channels: weights resident in registers) and conv3x3_tile.hip (input channels
+// in multiples of 64 walked in LDS chunks, weights streamed).  Shapes neither covers -- strided and 1x1 convolutions, channel
+// counts that are no multiple of 64 -- are NOT computed here: the caller keeps them on the framework convolution (north_star:
+// "PyTorch-ROCm for the unchanged encoder / decoder convs") followed by the gdkvm_bias_act epilogue pass.
+#include "gdkvm_common.hpp"
+
+int gdkvm_conv3x3_c64_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, int N, int H, int W,
+                             int relu, hipStream_t st);          // conv3x3_c64.hip
+int gdkvm_conv3x3_tile_launch(const void* x, const void* w, const float* bias, const void* residual, void* y,
+                              int N, int C, int H, int W, int K, int relu, hipStream_t st);   // conv3x3_tile.hip
+
+extern "C" int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y,
+                                   int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, int kernel,
+                                   int io_dtype, void* stream)
+{
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "conv_bias_act: only bf16 is implemented");
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0 || C % 8 || K % 8
+        || H + 2 * pad < R || W + 2 * pad < S)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: N=%d C=%d H=%d W=%d K=%d %dx%d stride %d pad %d (C, K multiples of 8)",
+                          N, C, H, W, K, R, S, stride, pad);
+    if (kernel != 0 && kernel != 4 && kernel != 5) return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: kernel=%d (0 = by shape, 4, 5)", kernel);
+    if (!(R == 3 && S == 3 && stride == 1 && pad == 1))
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: %dx%d stride %d pad %d is not served by the hand-written kernels (3x3 / 1 / 1): "
+                                           "use the framework convolution + gdkvm_bias_act", R, S, stride, pad);
+    if (N == 0) return GDKVM_OK;
+    if (!x || !w || !bias || !y) return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: null pointer");
+    if (!gdkvm_aligned16(x) || !gdkvm_aligned16(w) || !gdkvm_aligned16(y) || !gdkvm_aligned16(bias) || (residual && !gdkvm_aligned16(residual)))
+        return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: pointers must be 16-byte aligned");
+    if ((size_t)N * H * W * C >= (1ull << 31) || (size_t)N * H * W * K >= (1ull << 31))
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: tensor too large for 32-bit offsets");
+    if (int rc = gdkvm_check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool c64 = C == 64 && K == 64;
+    if (kernel == 4 && !c64) return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: kernel 4 serves 64 -> 64 channels only (C=%d K=%d)", C, K);
+    if (kernel == 4 || (kernel == 0 && c64)) {
+        if (gdkvm_conv3x3_c64_launch(x, w, bias, residual, y, N, H, W, relu, st)) return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: too many tiles");
+        GDKVM_LAUNCH_CHECK("conv3x3_c64_kernel");
+        return GDKVM_OK;
+    }
+    if (gdkvm_conv3x3_tile_launch(x, w, bias, residual, y, N, C, H, W, K, relu, st))
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: C=%d K=%d %dx%d is not served by the hand-written kernels (C a multiple of 64, K of "
+                                           "16, rows of at most 64 pixels): use the framework convolution + gdkvm_bias_act", C, K, H, W);
+    GDKVM_LAUNCH_CHECK("conv3x3_tile_kernel");
+    return GDKVM_OK;
+}

@@ -202,16 +202,15 @@ class FusedConv(nn.Module):
         self.relu = relu
 
     @staticmethod
-    def _tile(cin: int, cout: int, stride: int, has_res: bool) -> Optional[int]:
-        """Tile configuration of gdkvm_conv_bias_act per layer shape, from tools/conv_probe.py at cfg2 (512 frames); None = the
-        MIOpen convolution + epilogue pass is at least as fast there.  Any choice computes the same result: this is speed only."""
-        if cout <= 64:
-            return 4 if cin == 64 else (0 if has_res else 3)        # 4: the hand-written 64 -> 64 kernel (csrc/conv3x3_c64.hip)
-        if cout <= 128:
-            if has_res:
-                return None
-            return 3 if stride == 2 else (2 if cin >= 256 else 1)
-        return 2
+    def _tile(cin: int, cout: int, stride: int, has_res: bool, width: int = 0) -> Optional[int]:
+        """Which hand-written kernel of gdkvm_conv_bias_act serves a 3x3 layer (include/gdkvm.h): 4 = 64 -> 64 channels, 5 = input
+        channels in multiples of 64; None = none does (strided layers, odd channel counts): the framework convolution + one
+        epilogue pass.  Any choice computes the same result: this is speed only (tools/conv_probe.py)."""
+        if stride != 1 or cin % 64 or cout % 16:
+            return None
+        if cin == 64 and cout == 64:
+            return 4
+        return 5 if width <= 64 else None                   # (the chunked kernel tiles rows of at most 64 pixels)
 
     def forward(self, x, residual=None):
         cv = self.conv
@@ -219,7 +218,7 @@ class FusedConv(nn.Module):
         if (not folded and x.is_cuda and x.dtype == torch.bfloat16 and cv.kernel_size == (3, 3) and cv.groups == 1
                 and cv.dilation == (1, 1) and cv.stride[0] == cv.stride[1] and cv.padding == (1, 1) and cv.weight.dtype == torch.bfloat16
                 and cv.in_channels % 8 == 0 and cv.out_channels % 8 == 0 and cv.weight.is_contiguous(memory_format=torch.channels_last)):
-            tile = self._tile(cv.in_channels, cv.out_channels, cv.stride[0], residual is not None)
+            tile = self._tile(cv.in_channels, cv.out_channels, cv.stride[0], residual is not None, x.shape[-1])
             if tile is not None:                            # bias (+ residual) (+ ReLU) inside the implicit-GEMM kernel: one launch
                 return ops.conv_bias_act(x.contiguous(memory_format=torch.channels_last), cv.weight, self.epi.bias, residual,
                                          cv.stride[0], 1, self.relu, tile)

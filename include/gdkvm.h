@@ -229,16 +229,15 @@ int gdkvm_proj_rows(const void* x, const void* wpack, const float* bias, void* o
 int gdkvm_gate_logits(const void* p, const float* w_gate, const float* b_gate, const float* w_decay, const float* b_decay,
                       float* beta, float* alpha, int frames, int N, int Cp, int Hh, int io_dtype, void* stream);
 
-/* Row n1 (inference build): convolution with the folded-BatchNorm bias, the residual add and the ReLU in its epilogue,
- *   y = act(conv(x, w) + bias[k] (+ residual)),  x [N, H, W, C] (NHWC), w [K, R, S, C] (channels_last weights), y / residual
- *   [N, Ho, Wo, K], bias fp32 [K]; bf16 only; C and K multiples of 8.  The fp32 accumulator is rounded ONCE (after the epilogue).
- * tile selects the implicit-GEMM tile configuration (composable_kernel templates, the configurations MIOpen's search picks
- * for this network): 0 = 128x64x32 (64-channel 28x28 layers), 1 = 256x128x32 (128-channel 14x14), 2 = 128x128x64 (256-channel
- * 7x7), 3 = 128x64x64 (deep-K 64-channel); 4 = the hand-written 64 -> 64 channel 3x3 / stride 1 kernel (conv3x3_c64.hip: LDS halo
- * band, weights in registers; other shapes fall to tile 3).  The choice is speed only: a configuration that cannot address a problem (very few
- * channels) is replaced by tile 0. */
+/* Row n1 (inference build): 3x3 / stride 1 / pad 1 convolution with the folded-BatchNorm bias, the residual add and the ReLU
+ * in its epilogue,  y = act(conv(x, w) + bias[k] (+ residual)),  x [N, H, W, C] (NHWC), w [K, 3, 3, C] (channels_last weights),
+ * y / residual [N, H, W, K], bias fp32 [K]; bf16 only.  The fp32 accumulator is rounded ONCE (after the epilogue).  Both kernels
+ * are hand-written: kernel 4 = 64 -> 64 channels (conv3x3_c64.hip: LDS halo band, weights resident in registers), kernel 5 = C a
+ * multiple of 64, K of 16, rows of <= 64 pixels (conv3x3_tile.hip: 64-channel LDS chunks, weights streamed); kernel 0 picks by
+ * shape.  Anything else (strided, 1x1, odd channel counts) returns GDKVM_ERR_SHAPE: those stay on the framework convolution
+ * followed by gdkvm_bias_act. */
 int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y,
-                        int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, int tile,
+                        int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, int kernel,
                         int io_dtype, void* stream);
 
 /* Row n1, the stem: bias + ReLU + 3x3 / stride 2 / pad 1 max-pool in one pass over the NHWC conv output

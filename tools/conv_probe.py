@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Per-layer timing of the fused-epilogue convolutions (gdkvm_conv_bias_act, every tile) against the MIOpen convolution +
-gdkvm_bias_act pass they replace, at the cfg2 shapes of the encoder / decoder (512 frames).  Decides model.FusedConv's tile table."""
+"""Per-layer timing of the hand-written fused-epilogue convolutions (gdkvm_conv_bias_act: kernel 4 = 64 -> 64 channels, kernel 5 =
+64-channel LDS chunks) against the MIOpen convolution + gdkvm_bias_act pass they replace, at the cfg2 shapes of the encoder /
+decoder (512 frames).  Decides model.FusedConv's kernel choice."""
 import os
 import sys
 
@@ -47,14 +48,14 @@ def main():
             def mi():
                 z = torch.nn.functional.conv2d(x, w, None, st, pad)
                 return ops.bias_act_(z, b, r, True)
-            line = f"{name:24s} {'+res' if res else '    '} miopen+epilogue {ev(mi):6.1f} us (conv {ev(lambda: torch.nn.functional.conv2d(x, w, None, st, pad)):6.1f}) | fused tiles:"
-            for t in range(5):
+            line = f"{name:24s} {'+res' if res else '    '} miopen+epilogue {ev(mi):6.1f} us (conv {ev(lambda: torch.nn.functional.conv2d(x, w, None, st, pad)):6.1f}) | hand-written:"
+            for t in (4, 5):
                 try:
                     y = ops.conv_bias_act(x, w, b, r, st, pad, True, t)
                     err = (y.float() - ref).abs().max().item() / ref.abs().max().item()
-                    line += f" t{t} {ev(lambda: ops.conv_bias_act(x, w, b, r, st, pad, True, t)):6.1f}" + ("" if err < 1e-2 else f"(ERR {err:.1e})")
+                    line += f" k{t} {ev(lambda: ops.conv_bias_act(x, w, b, r, st, pad, True, t)):6.1f}" + ("" if err < 1e-2 else f"(ERR {err:.1e})")
                 except ops.GdkvmError:
-                    line += f" t{t}   n/a "
+                    line += f" k{t}   n/a "
             print(line, flush=True)
 
 
