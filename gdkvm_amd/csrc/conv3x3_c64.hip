@@ -4,7 +4,7 @@
 // Why not the implicit-GEMM library kernel: as a GEMM this layer is M = N*H*W pixels x K = 576 with only 64 output channels, so
 // the "A matrix" (every input pixel repeated for its nine taps) is 9x the input -- 462 MB through L2 and the vector-memory path
 // per call for a 51 MB tensor -- and the library kernels sit at ~62 us = 20 % of the MFMA rate whichever tile is chosen
-// (tools/ck_sweep).  Here the nine taps are nine SHIFTED READS of one LDS image:
+// (round-1 sweep).  Here the nine taps are nine SHIFTED READS of one LDS image:
 //   * a workgroup owns a 4 x TW pixel tile; its (4+2) x (TW+2) input halo band (64 channels = 128 B per pixel) is staged in LDS
 //     once, pixels 160 B apart (128 B of channels + 32 B of padding: a ds_read_b128 of 16 consecutive pixels is then
 //     conflict-free in every one of the instruction's four 16-lane groups, and every operand address is base + immediate);
