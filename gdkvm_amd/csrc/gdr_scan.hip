@@ -2,8 +2,8 @@
 //     R_t = Qn_t S_{t-1},      S_t = a_t P_t S_{t-1} + G_t
 // on the per-frame affine maps (P, G) that gdr_prep.hip folds.  Kernels, in file order:
 //
-//  gdr_affine_scan_kernel  one workgroup per (clip, head, 16-column slice of Dv), 12 waves in three roles (state / read-out /
-//                          LDS-DMA loader), one barrier per frame.  Also the backward's reverse recurrence (reverse mode) and
+//  gdr_affine_scan_kernel  one workgroup per (clip, head, 16-column slice of Dv), 8 waves in two roles (state / read-out),
+//                          one barrier per frame.  Also the backward's reverse recurrence (reverse mode) and
 //                          the state-transition matrix (transition mode).
 //  gdr_readout_kernel      frames of more than 64 tokens: the LKVA read-out, frame-parallel, from state images the serial
 //                          kernel dumps.
@@ -15,7 +15,6 @@
 #include <stdio.h>
 #include <string.h>
 
-#include <atomic>
 #include <initializer_list>
 #include <type_traits>
 
@@ -30,20 +29,16 @@ extern "C" void gdkvm_diag_set_buffer(unsigned long long* p) { g_gdkvm_diag_buf 
 
 namespace {
 
-// gdr_affine_scan_kernel: the serial recurrence on the folded operands.  12 waves per workgroup in three fixed roles:
+// gdr_affine_scan_kernel: the serial recurrence on the folded operands.  8 waves per workgroup in two fixed roles:
 //   state waves  0-3   S_t tile (rows 16w.., this slice's 16 columns) = a_t * (P_t[rows 16w..] S_{t-1}) + G_t tile; the B
 //                      operand is the four waves' accumulator tiles as published in LDS (double-buffered by frame parity:
-//                      one barrier per frame).  These waves issue NO vector-memory instruction: a 1 KiB wave load holds
-//                      the issue port for ~60 cycles (the CU's 64 B/clk address/data path), which between the MFMAs of
-//                      the chain cost more than the MFMAs themselves.
-//   read waves   4-7   R_t = (Qn_t S_{t-1}) * qinv from the same images (bf16 arm: S = S_hi + S_lo split here, bf16 MFMA),
-//                      with their own register prefetch of q.
-//   loader waves 8-11  stream P_t (16 KiB), G_t's tiles (4 KiB) and a_t into an LDS ring by LDS-DMA (global_load_lds, no
-//                      registers), AFF_D frames ahead; wave 8+w fetches exactly what state wave w consumes, lane-linear.
-// Ring protocol (AFF_NS = AFF_D + 1 slots): in iteration t the loaders issue frame t+AFF_D into the slot frame t-1 used
-// (free: every wave passed barrier t-1), wait with a counted vmcnt until frame t+1 has landed, and join barrier t; the
-// state waves read frame t+1 only after that barrier.  Barriers are raw s_barrier + lgkmcnt(0): __syncthreads() would add
-// vmcnt(0) and drain the DMA queue every frame.
+//                      one barrier per frame).  Each wave fetches its own operands -- its row tile of the P images, its G
+//                      tile and a_t -- from global memory straight into registers, AFF_PD frames ahead, the loads issued
+//                      behind the frame's S reads.  (Round 1 and the first half of round 2 streamed them through an LDS ring
+//                      filled by four LDS-DMA loader waves: measured, the ring's 40 KB of LDS traffic per frame cost the
+//                      chain as much as the loads' issue slots do here, and it held 120 KB of LDS and four more waves.)
+//   read waves   4-7   R_t = (Qn_t S_{t-1}) * qinv from the same images, with their own register prefetch of q.
+// Barriers are raw s_barrier + lgkmcnt(0): __syncthreads() would add vmcnt(0) and drain the prefetch queue every frame.
 struct AffArgs {
     const void* q; const float* alpha; const float* s_in;
     const float* pp; const float* gg; const float* qinv;
@@ -53,20 +48,18 @@ struct AffArgs {
     int reverse;                                     // visit the frames last to first (the backward's reverse recurrence)
     float* simg;                                     // DEFER: per-frame operand images of the state for gdr_readout_kernel
 };
-// LDS (16-byte units): S term images [2 parities][3 terms][2 ksteps][64] | (fp32 arm) S fp32 images [2][4][64] | ring slots
+// LDS (16-byte units): S term images [2 parities][NT terms][2 ksteps][64] | (fp32 I/O on split3) S fp32 images [2][4][64]
 template <int IO> struct RItem;                                        // read-out operands of one 16-token tile
 template <> struct RItem<GDKVM_F32> { f32x4 q[4]; float qinv; };
 template <> struct RItem<GDKVM_BF16> { bf16x8 q[2]; float qinv; };
-// (16-byte units; NT = terms of the operand format: 3 = split3 bf16, 2 = pair16 fp16)
-__host__ __device__ constexpr int aff_p_f4(int NT) { return 4 * NT * 2 * 64; }     // P of one frame: [4 row tiles][NT][2 ksteps][64 lanes] = 8 NT KiB
-__host__ __device__ constexpr int aff_slot_f4(int NT) { return aff_p_f4(NT) + 4 * 64 + 16; }   // + G [4][64] f32x4 + alpha [64 floats]
+// (NT = terms of the operand format: 3 = split3 bf16, 2 = pair16 fp16)
 __host__ __device__ constexpr int aff_s_f4(int NT) { return 2 * NT * 2 * 64; }     // S term images, two parities
-__host__ __device__ constexpr int aff_loads(int NT) { return 2 * NT + 2; }         // LDS-DMA instructions per loader wave per frame
-__host__ __device__ constexpr int aff_slots(int IO, int NT) { return NT == 2 ? 6 : (IO == GDKVM_F32 ? 4 : 5); }
 __host__ __device__ constexpr size_t aff_lds_bytes(int IO, int NT)
 {
-    return (size_t)(aff_s_f4(NT) + (IO == GDKVM_F32 && NT == 3 ? 2 * 4 * 64 : 0) + aff_slots(IO, NT) * aff_slot_f4(NT)) * 16;
+    return (size_t)(aff_s_f4(NT) + (IO == GDKVM_F32 && NT == 3 ? 2 * 4 * 64 : 0)) * 16;
 }
+constexpr int AFF_PD = 2;                            // operand prefetch distance of the state waves, in frames
+constexpr int AFF_THREADS = 512;
 
 __device__ __forceinline__ void aff_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -74,23 +67,20 @@ __device__ __forceinline__ void aff_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // CU's vector-memory path saturates (1.35 us per frame) -- so the read waves only dump the state's operand images (4 KB per
 // frame and slice) and gdr_readout_kernel does the read-out frame-parallel, reading q once per frame.
 template <int IO, int FMT, bool DEFER, bool SAVE>
-__global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
+__global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
 {
     constexpr int NB = 4, NP = 16 * NB, JT = 1, NBUF = 4, DEPTH = NBUF - 1, UFR = NBUF / JT;
     constexpr int NT = fmt_terms(FMT);
     constexpr bool PAIR = FMT == FMT_PAIR16;
-    constexpr int NS = aff_slots(IO, NT), D = NS - 1;
-    constexpr int AFF_P_F4 = aff_p_f4(NT), AFF_SLOT_F4 = aff_slot_f4(NT), AFF_LOADS = aff_loads(NT);
     constexpr float STATE = OpFmt<FMT>::STATE, STATE_INV = OpFmt<FMT>::STATE_INV;      // the kernel carries S' = S * STATE (G arrives scaled alike)
     extern __shared__ __attribute__((aligned(16))) f32x4 aff_smem[];
     uint2* s_S3 = reinterpret_cast<uint2*>(aff_smem);      // [parity][term] images of SPLIT_IMG uint2: B operand of the 16x16x32 MFMA
     constexpr bool EXACT = IO == GDKVM_F32 && !PAIR;       // fp32 I/O on full-range operands: exact fp32 read-out from fp32 images of S
     f32x4* s_Sf = aff_smem + aff_s_f4(NT);                 // EXACT only: accumulator images of S
-    f32x4* s_ring = s_Sf + (EXACT ? 2 * 4 * 64 : 0);
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = wave & 3, role = wave >> 2;             // 0 state, 1 read-out, 2 loader
+    const int w = wave & 3, role = wave >> 2;             // 0 state, 1 read-out
     const int nsl = a.Dv / 16, N = a.N, Hh = a.Hh, Dv = a.Dv, T = a.T;
     int bh, sl;
     {
@@ -101,40 +91,6 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
     const int b = bh / Hh, h = bh % Hh;
     const size_t fh0 = (size_t)b * T * Hh + h;
     constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
-
-    if (role == 2) {
-        // ------------------------------------------------------------------------------ loader waves
-        const size_t pp_fstride = (size_t)Hh * (GDKVM_DK * GDKVM_DK * 3 / 2);           // a frame-head's slot is sized for three terms
-        const float* pp_lane = a.pp + fh0 * (GDKVM_DK * GDKVM_DK * 3 / 2) + (w * (NT * 2 * 64) + lane) * 4;   // row tile w: 2 NT KiB contiguous
-        const float* gg_lane = a.gg + ((a.zero_g ? 0 : ((fh0 * nsl + sl) * 4 + w) * 64) + lane) * 4;
-        const size_t gg_fstride = a.zero_g ? 0 : (size_t)Hh * nsl * 4 * 64 * 4;
-        const float* al_ptr = a.alpha + fh0;
-        auto issue = [&](int f) {
-            const int slot = f % NS;
-            f = min(f, T - 1);                            // past the end: refetch the last frame into a slot nobody reads
-            if (a.reverse) f = T - 1 - f;
-            f32x4* dst = s_ring + slot * AFF_SLOT_F4;
-            const float* pr = pp_lane + f * pp_fstride;
-#pragma unroll
-            for (int i = 0; i < 2 * NT; ++i)
-                __builtin_amdgcn_global_load_lds(pr + 256 * i, reinterpret_cast<__attribute__((address_space(3))) void*>(
-                    reinterpret_cast<uintptr_t>(dst + (w * 2 * NT + i) * 64)), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(gg_lane + f * gg_fstride, reinterpret_cast<__attribute__((address_space(3))) void*>(
-                reinterpret_cast<uintptr_t>(dst + AFF_P_F4 + w * 64)), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(al_ptr + (size_t)f * Hh, reinterpret_cast<__attribute__((address_space(3))) void*>(
-                reinterpret_cast<uintptr_t>(dst + AFF_P_F4 + 4 * 64)), 4, 0, 0);       // 64 copies of a_t (each loader wave: same value)
-        };
-        for (int f = 0; f < D; ++f) issue(f);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFF_LOADS * (D - 2)) : "memory");     // frames 0 and 1 have landed
-        aff_barrier();
-        for (int t = 0; t < T; ++t) {
-            issue(t + D);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AFF_LOADS * (D - 2)) : "memory"); // frame t+2 has landed
-            aff_barrier();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after the workgroup is gone
-        return;
-    }
 
     // Publishing S: the three bf16 terms of this wave's rows 16w + 4g + r (k of the next product) as B images; the fp32
     // arm also keeps the accumulator image for its exact fp32 read-out.
@@ -308,77 +264,76 @@ __global__ __launch_bounds__(768) void gdr_affine_scan_kernel(AffArgs a)
     __builtin_amdgcn_s_setprio(2);                        // the S -> S chain goes first at the SIMD's issue port
     const bool gate_logits = a.flags & GDKVM_FLAG_GATE_LOGITS;
     aff_barrier();
-    // P, G and a of frame t+1 are read out of the ring during frame t (the loaders keep two frames landed), so after the
-    // barrier only the six S term images stand between the wave and its MFMAs
+    // P row-tile images, G tile and a_t of frame t + AFF_PD are fetched into registers during frame t, so after the barrier only
+    // the S term images stand between the wave and its MFMAs
     struct POp { uint4 pa[NT][2]; f32x4 gt; float al; };
-    auto load_op = [&](int slot, POp& d) __attribute__((always_inline)) {
-        const f32x4* rs = s_ring + slot * AFF_SLOT_F4;
+    {
+        // (a frame-head's P slot is sized for three terms whatever the format; row tile w is 2 NT KiB contiguous, lane-linear)
+        const size_t pp_fstride = (size_t)Hh * (GDKVM_DK * GDKVM_DK * 3 / 2);
+        const float* pp_lane = a.pp + fh0 * (GDKVM_DK * GDKVM_DK * 3 / 2) + (w * (NT * 2 * 64) + lane) * 4;
+        const float* gg_lane = a.gg + ((a.zero_g ? 0 : ((fh0 * nsl + sl) * 4 + w) * 64) + lane) * 4;
+        const size_t gg_fstride = a.zero_g ? 0 : (size_t)Hh * nsl * 4 * 64 * 4;
+        const float* al_ptr = a.alpha + fh0;
+        auto fetch_op = [&](int f, POp& d) __attribute__((always_inline)) {
+            f = min(f, T - 1);
+            if (a.reverse) f = T - 1 - f;
+            const float* pr = pp_lane + f * pp_fstride;
 #pragma unroll
-        for (int sp = 0; sp < NT; ++sp)
+            for (int sp = 0; sp < NT; ++sp)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) d.pa[sp][ks] = *reinterpret_cast<const uint4*>(&rs[(w * 2 * NT + sp * 2 + ks) * 64 + lane]);
-        d.gt = rs[AFF_P_F4 + w * 64 + lane];
-        d.al = reinterpret_cast<const float*>(rs + AFF_P_F4 + 4 * 64)[lane];
-    };
-    POp ob[2];
-    load_op(0, ob[0]);
-    auto frame = [&](int t, int slot, const POp& op, POp& nxt) __attribute__((always_inline)) {
-        const int par = t & 1;
-        if constexpr (SAVE) {
-            float* hp = a.s_hist + ((fh0 + (size_t)(a.reverse ? T - 1 - t : t) * Hh) * GDKVM_DK + 16 * w + 4 * g) * Dv + 16 * sl + li;
+                for (int ks = 0; ks < 2; ++ks) d.pa[sp][ks] = *reinterpret_cast<const uint4*>(pr + 256 * (sp * 2 + ks));
+            d.gt = *reinterpret_cast<const f32x4*>(gg_lane + f * gg_fstride);
+            d.al = al_ptr[(size_t)f * Hh];
+        };
+        POp od[AFF_PD + 1];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hp[(size_t)r * Dv] = STATE_INV * sacc[r];
-        }
-        uint4 sb[NT][2];
+        for (int i = 0; i < AFF_PD; ++i) fetch_op(i, od[i]);
+        auto frame = [&](int t, const POp& op, POp& far) __attribute__((always_inline)) {
+            const int par = t & 1;
+            if constexpr (SAVE) {
+                float* hp = a.s_hist + ((fh0 + (size_t)(a.reverse ? T - 1 - t : t) * Hh) * GDKVM_DK + 16 * w + 4 * g) * Dv + 16 * sl + li;
 #pragma unroll
-        for (int sp = 0; sp < NT; ++sp)
+                for (int r = 0; r < 4; ++r) hp[(size_t)r * Dv] = STATE_INV * sacc[r];
+            }
+            uint4 sb[NT][2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                sb[sp][ks] = *reinterpret_cast<const uint4*>(&s_S3[(par * NT + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
-        load_op((slot + 1) % NS, nxt);
-        __builtin_amdgcn_sched_barrier(0);                 // issued here, behind the S reads: left to the scheduler they sink below
-                                                           // the MFMAs and their latency lands on the final FMA
-        const float alpha = gate_logits ? fast_sigmoid(op.al) : op.al;
-        const f32x4 ps = OpFmt<FMT>::product(op.pa, sb);
+            for (int sp = 0; sp < NT; ++sp)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[r] = alpha * ps[r] + op.gt[r];
-        publish_state(par ^ 1, sacc);
-        aff_barrier();
-    };
-    constexpr int UFS = NS % 2 == 0 ? NS : 2 * NS;        // t0 stays a multiple of NS and of 2: slot and buffer ids are static
-    int t0 = 0;
-    for (; t0 + UFS <= T; t0 += UFS)
-        static_for<0, UFS>([&](auto fc) {
+                for (int ks = 0; ks < 2; ++ks)
+                    sb[sp][ks] = *reinterpret_cast<const uint4*>(&s_S3[(par * NT + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
+            __builtin_amdgcn_sched_barrier(0);
+            fetch_op(t + AFF_PD, far);                     // issued behind the S reads: the issue overlaps their latency
+            __builtin_amdgcn_sched_barrier(0);
+            const float alpha = gate_logits ? fast_sigmoid(op.al) : op.al;
+            const f32x4 ps = OpFmt<FMT>::product(op.pa, sb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[r] = alpha * ps[r] + op.gt[r];
+            publish_state(par ^ 1, sacc);
+            aff_barrier();
+        };
+        constexpr int NR = AFF_PD + 1, UFD = NR % 2 == 0 ? NR : 2 * NR;
+        int t0 = 0;
+        for (; t0 + UFD <= T; t0 += UFD)
+            static_for<0, UFD>([&](auto fc) {
+                constexpr int F = decltype(fc)::value;
+                frame(t0 + F, od[F % NR], od[(F + AFF_PD) % NR]);
+            });
+        static_for<0, UFD - 1>([&](auto fc) {
             constexpr int F = decltype(fc)::value;
-            frame(t0 + F, F % NS, ob[F & 1], ob[(F + 1) & 1]);
+            if (t0 + F < T) frame(t0 + F, od[F % NR], od[(F + AFF_PD) % NR]);
         });
-    static_for<0, UFS - 1>([&](auto fc) {
-        constexpr int F = decltype(fc)::value;
-        if (t0 + F < T) frame(t0 + F, F % NS, ob[F & 1], ob[(F + 1) & 1]);
-    });
-    if (a.s_out) {
+        if (a.s_out) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.s_out[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li] = STATE_INV * sacc[r];
+            for (int r = 0; r < 4; ++r) a.s_out[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li] = STATE_INV * sacc[r];
+        }
     }
 }
 
 template <int IO, int FMT, bool DEFER, bool SV>
 int launch_affine(const AffArgs& sa, dim3 grid, hipStream_t st)
 {
-    constexpr int NT = fmt_terms(FMT);
-    // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device (a process may drive several devices from several
-    // threads: the cache is a lock-free bit mask, a lost race only repeats the idempotent call)
-    static std::atomic<unsigned long long> done_mask{0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_affine_scan: hipGetDevice");
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_affine_scan_kernel<IO, FMT, DEFER, SV>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)aff_lds_bytes(IO, NT));
-        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_affine_scan: LDS attribute: %s", hipGetErrorString(e));
-        done_mask.fetch_or(bit, std::memory_order_relaxed);
-    }
-    hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, FMT, DEFER, SV>), grid, dim3(768), aff_lds_bytes(IO, NT), st, sa);
+    constexpr int NT = fmt_terms(FMT);                     // (8 or 20 KiB of LDS: no opt-in needed)
+    hipLaunchKernelGGL((gdr_affine_scan_kernel<IO, FMT, DEFER, SV>), grid, dim3(AFF_THREADS), aff_lds_bytes(IO, NT), st, sa);
     GDKVM_LAUNCH_CHECK("gdr_affine_scan_kernel");
     return GDKVM_OK;
 }

@@ -11,6 +11,7 @@
 // concatenated input: each wave owns 16 output channels x 64 tokens x {g_l, g_g, L Wl, Gms Wg} = 16
 // accumulator tiles, reads its weight rows straight from L2 with 16-byte loads (each weight element is
 // fetched once per workgroup), and fuses bias, sigmoid, gating and the residual into the epilogue.
+#include <atomic>
 #include "gdkvm_common.hpp"
 
 namespace {
@@ -713,15 +714,18 @@ extern "C" int gdkvm_proj_rows(const void* x, const void* wpack, const float* bi
 #endif
     const int TM = rows >= PROJ_TM_SWITCH ? 128 : 64;
     const size_t lds = (size_t)TM * (K + KPFF_PAD16) * sizeof(bf16_t);
-    static bool attr_set[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        const int cap = (int)((size_t)128 * (512 + KPFF_PAD16) * sizeof(bf16_t));
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_rows_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_rows_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "proj_rows: %s", hipGetErrorString(e));
-        attr_set[dev] = true;
+    {   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device; lock-free cache as in gdr_scan.hip
+        static std::atomic<unsigned long long> done_mask{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "proj_rows: hipGetDevice");
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
+            const int cap = (int)((size_t)128 * (512 + KPFF_PAD16) * sizeof(bf16_t));
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_rows_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_rows_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "proj_rows: %s", hipGetErrorString(e));
+            done_mask.fetch_or(bit, std::memory_order_relaxed);
+        }
     }
     const unsigned grid = (unsigned)((rows + TM - 1) / TM);
     if (TM == 128) hipLaunchKernelGGL(proj_rows_kernel<128>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);

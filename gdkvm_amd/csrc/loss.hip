@@ -115,6 +115,10 @@ __global__ __launch_bounds__(256) void seg_loss_finalize_kernel(const float* par
         __syncthreads();
     }
     if (threadIdx.x == 0) {
+        // labels outside [0, C) carry no class: the cross-entropy averages over the labelled pixels only (ignore_index semantics)
+        double labelled = 0.0;
+        for (int c = 0; c < C; ++c) labelled += tot[1 + 2 * C + c];
+        npix = labelled > 0.0 ? labelled : 1.0;
         const double ce = tot[0] / npix;
         double dsum = 0.0;
         for (int c = 0; c < C; ++c) {
@@ -153,11 +157,12 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const void* z, const 
         pixel_softmax<IO, C>(z, img, h * w, w, ty, tx, p, lg);
         const int t = target_at<TL>(target, ((size_t)n * H + y) * W + x);
         float u[C], dot = 0.f;
+        const float ce_w = (unsigned)t < (unsigned)C ? inv_n : 0.f;   // unlabelled pixel: no cross-entropy term
 #pragma unroll
         for (int c = 0; c < C; ++c) { u[c] = (t == c ? cI[c] : 0.f) + cP[c]; dot = fmaf(p[c], u[c], dot); }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float dl = (p[c] - (t == c ? 1.f : 0.f)) * inv_n + p[c] * (u[c] - dot);
+            const float dl = (p[c] - (t == c ? 1.f : 0.f)) * ce_w + p[c] * (u[c] - dot);
             acc[c] = fmaf(wgt, dl, acc[c]);
         }
     };

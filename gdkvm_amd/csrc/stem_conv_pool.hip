@@ -13,6 +13,7 @@
 //     applies the ReLU, zeroes positions outside the image (post-ReLU values are >= 0, so a zero is as good as -inf for the
 //     max) and writes bf16 into the LDS tile; after one barrier all 512 threads pool 3 x 3 windows out of LDS and store the
 //     pooled pixels -- 51 MB instead of 213 + 213 + 51.
+#include <atomic>
 #include "gdkvm_common.hpp"
 
 namespace {
@@ -187,13 +188,16 @@ extern "C" int gdkvm_stem_conv_pool(const void* xs, const void* w, const float* 
     const long long ntiles = (long long)N * a.tiles_x * a.tiles_y;
     if (ntiles > 0x7fffffffLL) return gdkvm_fail(GDKVM_ERR_SHAPE, "stem_conv_pool: too many tiles");
     const size_t lds = 2 * (size_t)SP_BAND_BYTES + SP_CONV_BYTES;
-    static bool attr_set[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "stem_conv_pool: %s", hipGetErrorString(e));
-        attr_set[dev] = true;
+    {   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device; lock-free cache as in gdr_scan.hip
+        static std::atomic<unsigned long long> done_mask{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "stem_conv_pool: hipGetDevice");
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "stem_conv_pool: %s", hipGetErrorString(e));
+            done_mask.fetch_or(bit, std::memory_order_relaxed);
+        }
     }
 #ifndef STEM_GRID
 #define STEM_GRID 256                                      // persistent, one workgroup per CU

@@ -15,13 +15,16 @@ import torch.nn.functional as F
 
 
 def segmentation_loss(logits: torch.Tensor, target: torch.Tensor, dice_weight: float = 1.0, eps: float = 1.0) -> torch.Tensor:
-    """Cross-entropy + soft Dice over [B,T,ncls,H,W] logits and [B,T,H,W] integer labels (fp32 math)."""
+    """Cross-entropy + soft Dice over [B,T,ncls,H,W] logits and [B,T,H,W] integer labels (fp32 math).  Labels outside
+    [0, ncls) are unlabelled pixels: left out of the cross-entropy mean and of every class's Dice target (gdkvm_seg_loss_fwd
+    does the same)."""
     B, T, C, H, W = logits.shape
     lg = logits.reshape(B * T, C, H, W).float()
     tg = target.reshape(B * T, H, W).long()
-    ce = F.cross_entropy(lg, tg)
+    labelled = (tg >= 0) & (tg < C)                 # anything else (255 in annotation masks) carries no class
+    ce = F.cross_entropy(lg, torch.where(labelled, tg, torch.full_like(tg, -100)), ignore_index=-100)
     p = lg.softmax(1)
-    oh = F.one_hot(tg, C).permute(0, 3, 1, 2).float()
+    oh = (F.one_hot(torch.where(labelled, tg, torch.zeros_like(tg)), C) * labelled.unsqueeze(-1)).permute(0, 3, 1, 2).float()
     inter = (p * oh).sum((0, 2, 3))
     dice = 1.0 - ((2 * inter + eps) / (p.sum((0, 2, 3)) + oh.sum((0, 2, 3)) + eps)).mean()
     return ce + dice_weight * dice

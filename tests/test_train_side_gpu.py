@@ -237,6 +237,34 @@ def test_fused_objective_matches_the_torch_loss(hip, case, dtype):
     assert (za.grad.double().cpu() - zb.grad).abs().max() <= tol * zb.grad.abs().max().item()
 
 
+def test_fused_objective_ignores_unlabelled_pixels(hip):
+    """Labels outside [0, C) (255 in uint8 annotation masks) carry no class: the cross-entropy averages over the labelled pixels
+    only, as F.cross_entropy(ignore_index=...) does; the Dice sums see them as 'no class'.  The host-side loss agrees."""
+    from gdkvm_amd.train import segmentation_loss
+    ni, c, h, w, H, W = 3, 2, 28, 28, 112, 112
+    torch.manual_seed(5)
+    z = 2.0 * torch.randn(ni, c, h, w, device="cuda")
+    tgt = torch.randint(0, c, (ni, H, W), device="cuda")
+    tgt[torch.rand(ni, H, W, device="cuda") < 0.3] = 255
+    for tdt in (torch.uint8, torch.int64):
+        za = z.clone().requires_grad_(True)
+        loss = hip.seg_loss(za, tgt.to(tdt), 0.7, 1.0)
+        loss.backward()
+        zb = z.double().cpu().requires_grad_(True)
+        up = F.interpolate(zb, size=(H, W), mode="bilinear", align_corners=False)
+        t = tgt.cpu()
+        ce = F.cross_entropy(up, t, ignore_index=255)
+        p = up.softmax(1)
+        oh = torch.stack([(t == k) for k in range(c)], 1).double()
+        dice = 1.0 - ((2 * (p * oh).sum((0, 2, 3)) + 1.0) / (p.sum((0, 2, 3)) + oh.sum((0, 2, 3)) + 1.0)).mean()
+        ref = ce + 0.7 * dice
+        ref.backward()
+        assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+        assert (za.grad.double().cpu() - zb.grad).abs().max() <= 1e-4 * zb.grad.abs().max().item()
+        host = segmentation_loss(up.detach().float().reshape(1, ni, c, H, W), t.reshape(1, ni, H, W), 0.7, 1.0)
+        assert abs(host.item() - ref.item()) <= 1e-4
+
+
 def test_train_step_uses_the_fused_objective(hip):
     """train_step on the GPU (stride-4 logits + HIP loss) and the plain route (full-resolution logits + torch loss) give the
     same loss and the same parameter gradients (fp32, no autocast)."""

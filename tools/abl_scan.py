@@ -1,34 +1,47 @@
 #!/usr/bin/env python3
-"""Diagnostic only: builds ablation variants of the library (extra -D flags on the command line, -DGDKVM_ABL_RNOCVT | _RNOSTORE | _RNOLOAD | _RNOMMA)
-into gpurun_out/ and times scan_prep / scan_apply with them.  Ablated builds compute wrong results by design; their
-timings say which role of the serial kernel bounds a frame.  Never part of the product."""
+"""Diagnostic only: ablation variants of the serial scan kernel (gdr_scan.hip compiled with -DGDKVM_ABL_* flags) and their
+timings.  Ablated builds compute wrong results by design; their timings say which role of the kernel bounds a frame.
+  python tools/abl_scan.py build            (here: cross-compiles every variant into tools/_abl/, which travels to the GPU box)
+  python tools/abl_scan.py run              (GPU box: times scan_prep / scan_apply with each variant)
+Never part of the product."""
 import glob
 import os
 import subprocess
 import sys
 
-import torch
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "gdkvm_amd", "csrc")
+OUT = os.path.join(ROOT, "tools", "_abl")
+VARIANTS = {
+    "baseline": [],
+}
 
 
-def main():
-    flags = sys.argv[1:]
-    so = os.path.join(ROOT, "gpurun_out", "libgdkvm_hip_abl.so")
-    os.makedirs(os.path.dirname(so), exist_ok=True)
-    # only the scan kernel is rebuilt with the flags; every other object is the product build's (csrc/_obj travels with the tree)
-    obj = os.path.join(ROOT, "gpurun_out", "gdr_scan_abl.o")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-c"] + flags +
-                          ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, os.path.join(CSRC, "gdr_scan.hip"), "-o", obj])
+def build(only=None):
+    from gdkvm_amd.build import EXTRA_FLAGS
+    os.makedirs(OUT, exist_ok=True)
     others = [o for o in sorted(glob.glob(os.path.join(CSRC, "_obj", "*.o"))) if not o.endswith("gdr_scan.o")]
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, obj] + others)
+    for name, flags in VARIANTS.items():
+        if only and name not in only:
+            continue
+        obj, so = os.path.join(OUT, name + ".o"), os.path.join(OUT, name + ".so")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c"] + EXTRA_FLAGS.get("gdr_scan.hip", []) +
+                              flags + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, os.path.join(CSRC, "gdr_scan.hip"), "-o", obj])
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, obj] + others)
+        os.remove(obj)
+        print("built", so, flush=True)
+
+
+def run_one(name):
+    import torch
     from gdkvm_amd import ops
-    ops._SO = so
+    ops._SO = os.path.join(OUT, name + ".so")
     from tools.config_sweep import ev_time
     dev = torch.device("cuda")
     out = []
+    torch.manual_seed(0)
+    ref_path = os.path.join(ROOT, "gpurun_out", "abl_ref.pt")
     for (B, T, N) in [(16, 32, 49), (16, 128, 49)]:
         Hh, Dk, Dv, dt = 1, 64, 256, torch.bfloat16
         q, k = (torch.randn(B, T, N, Hh, Dk, device=dev).to(dt) for _ in range(2))
@@ -36,11 +49,28 @@ def main():
         al = 2 + torch.randn(B, T, Hh, device=dev); be = torch.randn(B, T, N, Hh, device=dev)
         ws = torch.empty(ops.scan_workspace_bytes(B, T, Hh, N, Dk, Dv), dtype=torch.uint8, device=dev)
         r = torch.empty(B, T, N, Hh, Dv, device=dev, dtype=dt); s = torch.empty(B, Hh, Dk, Dv, device=dev)
+        ops.scan_prep(q, k, v, be, ws, flags=3)
+        ops.scan_apply(q, al, ws, Dv, flags=3, out=r, state_out=s)
+        if T == 32:                                   # same seeded inputs in every process: the baseline's result is the reference
+            if name == "baseline":
+                os.makedirs(os.path.dirname(ref_path), exist_ok=True)
+                torch.save((r.cpu(), s.cpu()), ref_path)
+            elif os.path.exists(ref_path):
+                r0, s0 = torch.load(ref_path)
+                out.append(f"[vs baseline: r {(r.cpu().float() - r0.float()).abs().max().item():.2e} s {(s.cpu() - s0).abs().max().item():.2e}]")
         tp = ev_time(lambda: ops.scan_prep(q, k, v, be, ws, flags=3))
         ta = ev_time(lambda: ops.scan_apply(q, al, ws, Dv, flags=3, out=r, state_out=s))
-        out.append(f"T={T}: prep {tp:.1f} scan {ta:.1f} us ({ta / T * 1e3:.0f} ns/frame)")
-    print(f"{' '.join(flags) or 'baseline':60s} " + " | ".join(out))
+        tn = ev_time(lambda: ops.scan_apply(q, al, ws, Dv, flags=3, state_out=s, want_readout=False))
+        out.append(f"T={T}: prep {tp:.1f} scan {ta:.1f} us ({ta / T * 1e3:.0f} ns/frame; states only {tn / T * 1e3:.0f})")
+    print(f"{name:28s} " + " | ".join(out), flush=True)
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1] == "build":
+        build(sys.argv[2:])
+    elif sys.argv[1] == "run":
+        # one process per variant: the library is loaded once per process
+        for name in (sys.argv[2:] or list(VARIANTS)):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "one", name])
+    else:
+        run_one(sys.argv[2])

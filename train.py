@@ -45,10 +45,11 @@ def main(argv=None):
     mcfg = GDKVMConfig(num_classes=cfg.data.num_classes, heads=cfg.model.heads, value_dim=cfg.model.value_dim, rule=cfg.model.rule)
     model = GDKVM(mcfg).train().to(dev).to(memory_format=torch.channels_last)
     opt = torch.optim.AdamW(model.parameters(), lr=cfg.learning_rate)
-    step0 = 0
+    step0, epoch0 = 0, None
     if args.resume:
         ck = torch.load(args.resume, map_location=dev)
         model.load_state_dict(ck["model"]); opt.load_state_dict(ck["optimizer"]); step0 = ck["step"]
+        epoch0 = ck.get("epoch")
     ddp = wrap_ddp(model, dev)
 
     ds = build_dataset(cfg, "train")
@@ -58,7 +59,12 @@ def main(argv=None):
     run = OfflineRun(cfg.run_dir, cfg.to_dict(), cfg.eval_stage.wandb_mode, enabled=rank == 0)
     amp = torch.bfloat16 if cfg.precision == "bf16" else None
 
-    step, epoch, t_log = step0, 0, time.perf_counter()
+    if len(dl) == 0:
+        raise SystemExit(f"train.py: {len(ds)} clips give no full batch of {cfg.batch_size} on each of {world} rank(s) (drop_last): "
+                         "lower batch_size or add data")
+    # a resumed run continues the shuffle sequence where the checkpoint left it (older checkpoints: derived from the step count)
+    epoch = epoch0 if epoch0 is not None else step0 // len(dl)
+    step, t_log = step0, time.perf_counter()
     while step < cfg.num_iterations:
         if sampler is not None:
             sampler.set_epoch(epoch)
@@ -73,7 +79,7 @@ def main(argv=None):
                 print(f"step {step:6d}  loss {float(loss):.4f}  {fps:9.0f} frames/s", flush=True)
             if (step % cfg.save_every == 0 or step == cfg.num_iterations) and rank == 0:
                 os.makedirs(cfg.run_dir, exist_ok=True)
-                torch.save({"model": model.state_dict(), "optimizer": opt.state_dict(), "step": step, "config": cfg.to_dict()},
+                torch.save({"model": model.state_dict(), "optimizer": opt.state_dict(), "step": step, "epoch": epoch, "config": cfg.to_dict()},
                            os.path.join(cfg.run_dir, f"gdkvm_step{step}.pth"))
             if step >= cfg.num_iterations:
                 break
