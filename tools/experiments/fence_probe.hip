@@ -11,7 +11,7 @@
 constexpr int FRAME_F4 = 80 * 1024 / 16;     // float4 per frame-head
 constexpr int READ_F4 = 20 * 1024 / 16;      // what one consumer reads of a frame
 
-// mode bit 0: producer does __threadfence() before the flag; bit 1: consumer flag load is an acquire (else relaxed + no fence)
+// mode bit 2: producer stores are device-scope write-through (sc1), no fence;  bit 0: producer does __threadfence() before the flag; bit 1: consumer flag load is an acquire (else relaxed + no fence)
 __global__ __launch_bounds__(256) void probe(float4* data, unsigned* flags, float* sink, int nprod, int BH, int T, int nsl, int mode, int work)
 {
     const int tid = threadIdx.x;
@@ -21,6 +21,14 @@ __global__ __launch_bounds__(256) void probe(float4* data, unsigned* flags, floa
             float acc = (float)idx;
             for (int i = 0; i < work; ++i) acc = acc * 1.0001f + 0.5f;         // stand-in for the solve
             float4* dst = data + (size_t)idx * FRAME_F4;
+            if (mode & 4) {                        // device-scope (write-through) stores instead of a release fence
+                for (int i = tid; i < FRAME_F4; i += 256) {
+                    typedef float vf4 __attribute__((ext_vector_type(4)));
+                    const vf4 v = {acc, (float)i, 0.f, 1.f};
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + i), "v"(v) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else
             for (int i = tid; i < FRAME_F4; i += 256) dst[i] = make_float4(acc, (float)i, 0.f, 1.f);
             if (mode & 1) __threadfence();
             __syncthreads();
@@ -54,7 +62,7 @@ int main()
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int work : {0, 20000}) {
-        for (int mode = 0; mode < 4; ++mode) {
+        for (int mode : {0, 1, 2, 3, 4}) {
             float best = 1e9f;
             for (int rep = 0; rep < 6; ++rep) {
                 CHECK(hipMemsetAsync(flags, 0, BH * T * sizeof(unsigned), 0));
@@ -65,7 +73,7 @@ int main()
                 float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
                 if (rep && ms < best) best = ms;
             }
-            printf("work %6d  producer fence %d  consumer acquire %d : %8.1f us\n", work, mode & 1, (mode >> 1) & 1, best * 1e3f);
+            printf("work %6d  producer fence %d  sc1 stores %d  consumer acquire %d : %8.1f us\n", work, mode & 1, (mode >> 2) & 1, (mode >> 1) & 1, best * 1e3f);
         }
     }
     // producers alone, and consumers alone on ready flags: the two serial pieces
