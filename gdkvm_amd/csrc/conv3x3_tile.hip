@@ -9,9 +9,9 @@
 //     channels + 16 B of padding per pixel: a ds_read_b128 of 16 consecutive pixels is conflict-free and every operand
 //     address is base + immediate) is staged in LDS by LDS-DMA, double-buffered: chunk c+1 streams in while chunk c computes;
 //     pixels outside the frame and the padding slots are fetched from a 16-byte zero constant;
-//   * the nine taps are nine SHIFTED READS of that image; the weights never touch LDS: a wave owns one 16-channel output tile
-//     and streams its weight fragments (one 16-byte load per k-step, four k-steps ahead, straight from L2) -- each is used for
-//     all the wave's pixel tiles (up to 13 MFMAs per load);
+//   * the nine taps are nine SHIFTED READS of that image; the weights never touch LDS: a wave owns one or two 16-channel output
+//     tiles and streams their weight fragments (one 16-byte load each per k-step, three k-steps ahead, straight from L2) -- each
+//     is used for all the wave's pixel tiles (7 MFMAs per load);
 //   * weights are the A operand, so a lane ends with 4 consecutive output channels of one pixel (8-byte stores / residual loads).
 // Arithmetic: fp32 accumulation over the same 9 C products as a library convolution, one rounding after the epilogue.
 #include <atomic>
@@ -22,12 +22,35 @@
 namespace {
 
 constexpr int CT_CK = 64;                // input channels per LDS chunk
-constexpr int CT_PIX = 160;              // bytes between LDS pixels: 8 data chunks + 2 padding chunks of 16 B (144 B is NOT
+#ifndef CT_PIX_BYTES
+#define CT_PIX_BYTES 160
+#endif
+constexpr int CT_PIX = CT_PIX_BYTES;              // bytes between LDS pixels: 8 data chunks + 2 padding chunks of 16 B (144 B is NOT
                                          // conflict-free for ds_read_b128: its 16-lane groups mix two lane quarters)
 constexpr int CT_SLOTS = CT_PIX / 16;    // 16-byte LDS slots per pixel
 constexpr int CT_MAXMT = 13;             // 16-pixel tiles per workgroup tile (208 pixels)
+// wave grids <NWN, NTW>: 1 = <4, 1>, 2 = <4, 2>, 3 = <2, 2>; the defaults are the measured picks (tools/conv_probe.py)
+constexpr int CT_VARIANT_128 = 2, CT_VARIANT_64 = 1;
 
 __device__ const uint4 g_ct_zero16 = {0, 0, 0, 0};
+
+#ifdef CT_DIAG
+// diagnostic builds (tools/abl_conv_tile.py stamps): s_memtime per wave of workgroup 0 around the barrier and the trips of a chunk
+__device__ unsigned long long* g_ct_diag = nullptr;
+#define CT_STAMP(slot) do { if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && gc < 8) { unsigned long long t__; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); g_ct_diag[(gc * 8 + w) * 8 + (slot)] = t__; } } while (0)
+#else
+#define CT_STAMP(slot) do {} while (0)
+#endif
+
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for_ct(F&& f)
+{
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for_ct<I + 1, E>(f);
+    }
+}
 
 struct ConvTileArgs {
     const bf16_t* x; const bf16_t* w; const float* bias; const bf16_t* res; bf16_t* y;
@@ -37,20 +60,22 @@ struct ConvTileArgs {
     int relu;
 };
 
-// Waves form a 2 (pixel-tile parity) x 4 (output-channel group) grid; a wave owns NTW 16-channel output tiles (the workgroup
-// 64 NTW output channels) and every other pixel tile (7 of 13).  Per 32-deep k-step and workgroup: 56 KB of LDS reads (about half
-// the LDS rate), 8 NTW KB of weight fragments over the vector-memory path, 7 NTW x 8 MFMAs -- MFMA-bound by construction.
-template <int NTW>
+// Waves form an MW (pixel-tile group) x NWN (output-channel group) grid, MW NWN = 8; a wave owns NTW 16-channel output tiles (the
+// workgroup 16 NTW NWN output channels) and every MW-th pixel tile (MTW of 13).  Per 32-deep k-step a wave reads MTW pixel
+// fragments from LDS and NTW weight fragments from L2 for MTW NTW MFMAs; per workgroup that is 8 MTW KB of LDS reads against
+// 32 MTW NTW cycles of MFMA per SIMD.  <4, 2> (MTW 7): 56 KB / 448 cycles; <2, 2> (MTW 4, the 64-channel layers): 32 KB / 256
+// cycles where <4, 1> had 56 KB / 224 -- the LDS read rate (128 B per cycle) is the co-bound, so the grid follows the channels.
+template <int NWN, int NTW, bool PK>
 __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
 {
-    constexpr int NWN = 4, MW = 2, MTW = (CT_MAXMT + MW - 1) / MW;     // channel groups, pixel-tile groups, pixel tiles per wave
+    constexpr int MW = 8 / NWN, MTW = (CT_MAXMT + MW - 1) / MW;        // pixel-tile groups, pixel tiles per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char ct_band[];    // [2][npieces * 1024] | 1 KiB dump slot
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wn = w % NWN, wm = w / NWN;
     const int H = a.H, W = a.W, C = a.C, K = a.K, BW = a.bw;
     const int band_bytes = a.npieces * 1024, nchunk = C / CT_CK;
     const int tpix = a.fpt * a.th * W;                     // output pixels of a full tile
-    const int co0 = blockIdx.y * (64 * NTW) + 16 * NTW * wn;           // this wave's output channels co0 .. co0 + 16 NTW - 1
+    const int co0 = blockIdx.y * (16 * NTW * NWN) + 16 * NTW * wn;     // this wave's output channels co0 .. co0 + 16 NTW - 1
 
     // DMA piece geometry (tile-invariant): piece j = w + 8u, slot d = 64 j + lane = CT_SLOTS pix + c; c >= 8 is padding
     constexpr int PP = 7;                                  // pieces per wave: npieces <= 56
@@ -71,6 +96,9 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
         const int nfr = min(a.fpt, a.N - fg * a.fpt);                   // frames that exist in the last group
         // straight-line on purpose (always PP pieces: surplus ones land in a dump slot): a branch would make the compiler's vmcnt
         // counting conservative for the weight fragments in flight around it
+#ifdef CT_ABL_NODMA
+        if (chunk > 0 || tile != (int)blockIdx.x) return;
+#endif
 #pragma unroll
         for (int u = 0; u < PP; ++u) {
             const int j = w + 8 * u;
@@ -96,27 +124,52 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
     for (int nt = 0; nt < NTW; ++nt) {
         bias4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (co0 + 16 * nt < K) bias4[nt] = *reinterpret_cast<const f32x4*>(a.bias + co0 + 16 * nt + 4 * g);
-        wrow[nt] = a.w + (size_t)min(co0 + 16 * nt + li, K - 1) * 9 * C + 8 * g;
+        // PK: the weights were re-laid out by gdkvm_conv3x3_pack_weights as [K / 16][k-step][lane][8], a fragment = 1 KiB contiguous
+        // (8 full cache lines per load instruction instead of 16 half-used ones: the vector-memory path is this kernel's bound)
+        if constexpr (PK) wrow[nt] = a.w + (size_t)min(co0 / 16 + nt, K / 16 - 1) * (9 * C * 16) + lane * 8;
+        else wrow[nt] = a.w + (size_t)min(co0 + 16 * nt + li, K - 1) * 9 * C + 8 * g;
     }
 
     // k-steps of one tile: chunk-major, then tap, then channel half: ks = (chunk * 9 + tap) * 2 + kh
     const int nks = nchunk * 18;
+    static_assert(NTW == 1 || NTW == 2, "wwait names the fragments of one or two output tiles");
+    // Weight fragments are fetched and waited for by hand (asm loads the compiler does not count, s_waitcnt with counts written out
+    // below): a wave that mixes LDS-DMA and register loads gets s_waitcnt vmcnt(0) from the compiler wherever it needs a loaded
+    // register -- it cannot order the two kinds -- which put the whole L2 latency on every second k-step (3x the MFMA time).
+    // The hardware returns them in issue order, so "at most N younger operations outstanding" is exact.
     struct WF { bf16x8 f[NTW]; };
-    auto wload = [&](int ks) __attribute__((always_inline)) {           // (wraps: a tile's last loads fetch the next tile's first k-steps)
+    auto wload = [&](WF& o, int ks) __attribute__((always_inline)) {    // (wraps: a tile's last loads fetch the next tile's first k-steps)
+#ifdef CT_ABL_NOWLOAD
+        if (ks >= 3) return;                               // (only the prologue's loads)
+#endif
         ks = ks >= nks ? ks - nks : ks;
 #ifdef CT_ABL_NOW
-        ks = 0;
+        ks = 0;                                            // (every weight fragment from one address: L1 hits)
 #endif
-        const int chunk = ks / 18, r = ks - 18 * chunk, tap = r >> 1, kh = r & 1;
-        const size_t off = (size_t)tap * C + chunk * CT_CK + 32 * kh;
-        WF o;
+        size_t off;
+        if constexpr (PK) off = (size_t)ks * 512;
+        else {
+            const int chunk = ks / 18, r = ks - 18 * chunk, tap = r >> 1, kh = r & 1;
+            off = (size_t)tap * C + chunk * CT_CK + 32 * kh;
+        }
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) o.f[nt] = *reinterpret_cast<const bf16x8*>(wrow[nt] + off);
-        return o;
+        for (int nt = 0; nt < NTW; ++nt) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(o.f[nt]) : "v"(wrow[nt] + off) : "memory");
+    };
+    // (the fragments are operands of the asm so that nothing that reads them can be scheduled above the wait)
+    auto wwait = [&](WF& o, auto nc) __attribute__((always_inline)) {
+        constexpr int N = decltype(nc)::value;
+        if constexpr (NTW == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(o.f[0]) : "n"(N) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(o.f[0]), "+v"(o.f[1]) : "n"(N) : "memory");
     };
     int tile = blockIdx.x, gc = 0;                          // gc: chunks processed so far; chunk gc lives in LDS buffer gc & 1
     if (tile < a.ntiles) fetch(tile, 0, 0);
-    WF wf0 = wload(0), wf1 = wload(1), wf2 = wload(2), wf3 = wload(3);           // weight fragments, four k-steps ahead
+    // weight fragments, WD k-steps ahead, in a ring of WD register sets with STATIC indices: k-step r uses set r % WD and refills it
+    // for k-step r + WD.  (Rotating named registers -- wf0 = wf1; ...; wf3 = load -- made the compiler copy the freshly loaded
+    // fragment at the loop's back edge behind an s_waitcnt vmcnt(0): the whole L2 latency every second k-step, 3x the MFMA time.)
+    constexpr int WD = 3, KU = 6;                           // 18 k-steps per chunk = 3 trips of KU; KU a multiple of WD and of 2
+    WF wr[WD];
+#pragma unroll
+    for (int j = 0; j < WD; ++j) wload(wr[j], j);
     for (; tile < a.ntiles; tile += gridDim.x) {
         f32x4 acc[MTW][NTW];
 #pragma unroll
@@ -125,7 +178,14 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
             for (int nt = 0; nt < NTW; ++nt) acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int chunk = 0; chunk < nchunk; ++chunk, ++gc) {
             const int buf = gc & 1;
-            __syncthreads();                               // vmcnt(0) + barrier: this chunk's band has landed, the other buffer is free
+            // this chunk's band (DMA issued a chunk ago) has landed once only the WD NTW weight loads of the last WD k-steps --
+            // all younger than it -- are outstanding; past the barrier the other buffer is free.  (Not __syncthreads: its vmcnt(0)
+            // would drain the weight fragments in flight.)
+            CT_STAMP(0);
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WD * NTW) : "memory");
+            CT_STAMP(1);
+            asm volatile("s_barrier" ::: "memory");
+            CT_STAMP(2);
             // the next band streams in behind this chunk's MFMAs: the tile's next chunk, or chunk 0 of the workgroup's next tile
             // (past the last tile: one more band of the last tile, into the buffer nobody reads again)
             {
@@ -135,32 +195,52 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
             }
             const unsigned char* band = ct_band + buf * band_bytes;
             auto load_x = [&](bf16x8 (&xb)[MTW], int r) __attribute__((always_inline)) {
+                r = min(r, 17);                            // (past the chunk's last k-step: the same fragments again, branch-free)
                 const int tap = r >> 1, kh = r & 1, dy = tap / 3, dx = tap - 3 * dy;
                 const unsigned off = (unsigned)((dy * BW + dx) * CT_PIX + kh * 64);
 #pragma unroll
-                for (int m = 0; m < MTW; ++m) xb[m] = *reinterpret_cast<const bf16x8*>(band + pbase[m] + off);
+                for (int m = 0; m < MTW; ++m) {
+#ifdef CT_ABL_NOLDS
+                    if (r > 1) { xb[m] = __builtin_bit_cast(bf16x8, make_uint4(off, r, m, off)); continue; }
+#endif
+                    xb[m] = *reinterpret_cast<const bf16x8*>(band + pbase[m] + off);
+                }
             };
             auto mfmas = [&](const bf16x8 (&xb)[MTW], const WF& wfr) __attribute__((always_inline)) {
 #pragma unroll
                 for (int m = 0; m < MTW; ++m)
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr.f[nt], xb[m], acc[m][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NTW; ++nt) {
+#ifdef CT_ABL_NOMFMA
+                        acc[m][nt] += __builtin_bit_cast(f32x4, wfr.f[nt]) * __builtin_bit_cast(f32x4, xb[m]);
+#else
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr.f[nt], xb[m], acc[m][nt], 0, 0, 0);
+#endif
+                    }
             };
             const int ksb = chunk * 18;
             bf16x8 xa[MTW], xb[MTW];
             load_x(xa, 0);
-            // (a rolled loop on purpose: fully unrolled, the scheduler hoists the LDS reads of many k-steps and spills 200 registers)
+            // KU k-steps per trip (not all 18: fully unrolled, the scheduler hoists the LDS reads of many k-steps and spills).
+            // Younger than the fragments of k-step r at the time they are used: the loads of k-steps r+1, r+2 -- and, for the
+            // first WD k-steps of a chunk, the PP band pieces issued above.
+            auto trip = [&](int r0, auto firstc) __attribute__((always_inline)) {
+                constexpr bool FIRST = decltype(firstc)::value;
+                static_for_ct<0, KU>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    wwait(wr[j % WD], std::integral_constant<int, (WD - 1) * NTW + (FIRST && j < WD ? PP : 0)>{});
+                    if constexpr (j % 2 == 0) { load_x(xb, r0 + j + 1); mfmas(xa, wr[j % WD]); }
+                    else { load_x(xa, r0 + j + 1); mfmas(xb, wr[j % WD]); }
+                    wload(wr[j % WD], ksb + r0 + j + WD);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            };
+            CT_STAMP(3);
+            trip(0, std::true_type{});
+            CT_STAMP(4);
 #pragma unroll 1
-            for (int r = 0; r < 18; r += 2) {              // operands one k-step ahead of the MFMAs that use them
-                load_x(xb, r + 1);
-                mfmas(xa, wf0);
-                wf0 = wf1; wf1 = wf2; wf2 = wf3; wf3 = wload(ksb + r + 4);
-                __builtin_amdgcn_sched_barrier(0);
-                if (r + 2 < 18) load_x(xa, r + 2);
-                mfmas(xb, wf0);
-                wf0 = wf1; wf1 = wf2; wf2 = wf3; wf3 = wload(ksb + r + 5);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            for (int r0 = KU; r0 < 18; r0 += KU) trip(r0, std::false_type{});
+            CT_STAMP(5);
         }
         // epilogue: lane (li, g) holds channels co0 + 16nt + 4g .. +3 of pixel 16 (wm + MW m) + li
 #ifndef CT_ABL_NOEPI
@@ -193,15 +273,61 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing may land in LDS after the workgroup is gone
 }
 
-}  // namespace
-
 // Shapes this kernel serves: 3x3 / stride 1 / pad 1, C a multiple of 64, K a multiple of 16, and a map that tiles into <= 208
 // pixels: whole frames of <= 208 pixels (several small frames per tile), or row bands of a wider frame.  Returns 0 when launched, 1
 // when the shape is not covered (the caller falls back to the framework convolution + epilogue pass).
-int gdkvm_conv3x3_tile_launch(const void* x, const void* w, const float* bias, const void* residual, void* y,
-                              int N, int C, int H, int W, int K, int relu, hipStream_t st)
+// weights [K][3][3][C] -> [K / 16][k-step = (chunk * 9 + tap) * 2 + kh][lane = 16 g + li][8]:  w[16 kt + li][tap][64 chunk + 32 kh + 8 g ..]
+__global__ __launch_bounds__(256) void conv3x3_pack_kernel(const uint4* w, uint4* packed, int K, int C)
 {
-    if (C % CT_CK || K % 16 || W > 64 || W < 1 || H < 1 || N < 1) return 1;
+    const int nks = C / CT_CK * 18;
+    const size_t total = (size_t)(K / 16) * nks * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63), li = lane & 15, g = lane >> 4;
+        const size_t f = i >> 6;
+        const int ks = (int)(f % nks), kt = (int)(f / nks);
+        const int chunk = ks / 18, r = ks - 18 * chunk, tap = r >> 1, kh = r & 1;
+        packed[i] = w[(((size_t)(16 * kt + li) * 9 + tap) * C + chunk * CT_CK + 32 * kh + 8 * g) / 8];
+    }
+}
+
+}  // namespace
+
+extern "C" int gdkvm_conv3x3_pack_weights(const void* w, void* packed, int K, int C, int io_dtype, void* stream)
+{
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "conv3x3_pack_weights: only bf16 is implemented");
+    if (K <= 0 || C <= 0 || K % 16 || C % CT_CK) return gdkvm_fail(GDKVM_ERR_SHAPE, "conv3x3_pack_weights: K=%d C=%d (K a multiple of 16, C of 64)", K, C);
+    if (!w || !packed || !gdkvm_aligned16(w) || !gdkvm_aligned16(packed)) return gdkvm_fail(GDKVM_ERR_ARG, "conv3x3_pack_weights: null or unaligned pointer");
+    if (int rc = gdkvm_check_device()) return rc;
+    const size_t total = (size_t)(K / 16) * (C / CT_CK * 18) * 64;
+    hipLaunchKernelGGL(conv3x3_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const uint4*>(w), static_cast<uint4*>(packed), K, C);
+    GDKVM_LAUNCH_CHECK("conv3x3_pack_kernel");
+    return GDKVM_OK;
+}
+
+namespace {
+template <int NWN, int NTW>
+void launch_tile(bool packed, dim3 grid, size_t lds, hipStream_t st, const ConvTileArgs& a)
+{
+    if (packed) hipLaunchKernelGGL((conv3x3_tile_kernel<NWN, NTW, true>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((conv3x3_tile_kernel<NWN, NTW, false>), grid, dim3(512), lds, st, a);
+}
+template <int NWN, int NTW>
+bool setattr_tile()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_tile_kernel<NWN, NTW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 113 * 1024) == hipSuccess
+        && hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_tile_kernel<NWN, NTW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 113 * 1024) == hipSuccess;
+}
+}  // namespace
+
+#ifdef CT_DIAG
+extern "C" void gdkvm_ct_diag_buffer(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ct_diag), &p, sizeof(p)); }
+#endif
+
+int gdkvm_conv3x3_tile_launch(const void* x, const void* w, const float* bias, const void* residual, void* y,
+                              int N, int C, int H, int W, int K, int relu, int variant, int packed, hipStream_t st)
+{
+    if (C % CT_CK || K % 16 || W > 64 || W < 1 || H < 1 || N < 1 || variant < 0 || variant > 3) return 1;
     ConvTileArgs a;
     a.x = static_cast<const bf16_t*>(x); a.w = static_cast<const bf16_t*>(w); a.bias = bias;
     a.res = static_cast<const bf16_t*>(residual); a.y = static_cast<bf16_t*>(y);
@@ -220,21 +346,25 @@ int gdkvm_conv3x3_tile_launch(const void* x, const void* w, const float* bias, c
     const long long ntiles = groups * a.tiles_y;
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 1;
     a.ntiles = (int)ntiles;
-    const int ntw = K % 128 == 0 ? 2 : 1;                  // output channels per workgroup: 128 or 64
-    const int gy = (K + 64 * ntw - 1) / (64 * ntw);
+    // wave grid by output channels (variant 0; 1..4 pick one for tuning): 128 per workgroup where K allows, else 64
+    if (variant == 0) variant = K % 128 == 0 ? CT_VARIANT_128 : CT_VARIANT_64;
+    const int kwg = variant == 2 ? 128 : 64;               // output channels per workgroup
+    const int gy = (K + kwg - 1) / kwg;
     const size_t lds = (size_t)2 * a.npieces * 1024 + 1024;
     int per = 256 / gy; if (per < 1) per = 1;
     const int gx = (int)(ntiles < per ? ntiles : per);     // persistent: one workgroup per CU
-    auto setattr = [&](const void* fn) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 113 * 1024); };
     static std::atomic<unsigned long long> done_mask{0};   // per device; a lost race only repeats the idempotent call
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
-        if (setattr(reinterpret_cast<const void*>(conv3x3_tile_kernel<2>)) != hipSuccess || setattr(reinterpret_cast<const void*>(conv3x3_tile_kernel<1>)) != hipSuccess) return 1;
+        if (!setattr_tile<4, 1>() || !setattr_tile<4, 2>() || !setattr_tile<2, 2>()) return 1;
         done_mask.fetch_or(bit, std::memory_order_relaxed);
     }
-    if (ntw == 2) hipLaunchKernelGGL(conv3x3_tile_kernel<2>, dim3(gx, gy), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL(conv3x3_tile_kernel<1>, dim3(gx, gy), dim3(512), lds, st, a);
+    switch (variant) {
+        case 1: launch_tile<4, 1>(packed, dim3(gx, gy), lds, st, a); break;
+        case 2: launch_tile<4, 2>(packed, dim3(gx, gy), lds, st, a); break;
+        default: launch_tile<2, 2>(packed, dim3(gx, gy), lds, st, a); break;
+    }
     return 0;
 }

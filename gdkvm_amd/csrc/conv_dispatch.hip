@@ -8,7 +8,7 @@
 int gdkvm_conv3x3_c64_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, int N, int H, int W,
                              int relu, hipStream_t st);          // conv3x3_c64.hip
 int gdkvm_conv3x3_tile_launch(const void* x, const void* w, const float* bias, const void* residual, void* y,
-                              int N, int C, int H, int W, int K, int relu, hipStream_t st);   // conv3x3_tile.hip
+                              int N, int C, int H, int W, int K, int relu, int variant, int packed, hipStream_t st);   // conv3x3_tile.hip
 
 extern "C" int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y,
                                    int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, int kernel,
@@ -19,7 +19,11 @@ extern "C" int gdkvm_conv_bias_act(const void* x, const void* w, const float* bi
         || H + 2 * pad < R || W + 2 * pad < S)
         return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: N=%d C=%d H=%d W=%d K=%d %dx%d stride %d pad %d (C, K multiples of 8)",
                           N, C, H, W, K, R, S, stride, pad);
-    if (kernel != 0 && kernel != 4 && kernel != 5) return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: kernel=%d (0 = by shape, 4, 5)", kernel);
+    const bool packed = kernel & GDKVM_CONV_PACKED_WEIGHTS;
+    kernel &= ~GDKVM_CONV_PACKED_WEIGHTS;
+    if (kernel != 0 && (kernel < 4 || kernel > 8)) return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: kernel=%d (0 = by shape, 4, 5, 6..8)", kernel);
+    if (packed && (kernel < 5 || C % 64 || K % 16))
+        return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: packed weights go with kernel 5 (C a multiple of 64, K of 16), not kernel=%d C=%d K=%d", kernel, C, K);
     if (!(R == 3 && S == 3 && stride == 1 && pad == 1))
         return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: %dx%d stride %d pad %d is not served by the hand-written kernels (3x3 / 1 / 1): "
                                            "use the framework convolution + gdkvm_bias_act", R, S, stride, pad);
@@ -38,7 +42,7 @@ extern "C" int gdkvm_conv_bias_act(const void* x, const void* w, const float* bi
         GDKVM_LAUNCH_CHECK("conv3x3_c64_kernel");
         return GDKVM_OK;
     }
-    if (gdkvm_conv3x3_tile_launch(x, w, bias, residual, y, N, C, H, W, K, relu, st))
+    if (gdkvm_conv3x3_tile_launch(x, w, bias, residual, y, N, C, H, W, K, relu, kernel >= 6 ? kernel - 5 : 0, packed ? 1 : 0, st))
         return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: C=%d K=%d %dx%d is not served by the hand-written kernels (C a multiple of 64, K of "
                                            "16, rows of at most 64 pixels): use the framework convolution + gdkvm_bias_act", C, K, H, W);
     GDKVM_LAUNCH_CHECK("conv3x3_tile_kernel");

@@ -220,8 +220,16 @@ class FusedConv(nn.Module):
                 and cv.in_channels % 8 == 0 and cv.out_channels % 8 == 0 and cv.weight.is_contiguous(memory_format=torch.channels_last)):
             tile = self._tile(cv.in_channels, cv.out_channels, cv.stride[0], residual is not None, x.shape[-1])
             if tile is not None:                            # bias (+ residual) (+ ReLU) inside the implicit-GEMM kernel: one launch
+                packed = None
+                if tile == 5:                               # fragment-ordered weights, kept until the weights change (_wkey)
+                    key = _wkey(cv.weight) + (x.device,)
+                    ent = self.__dict__.get("_wpack")
+                    if ent is None or ent[0] != key:
+                        ent = (key, ops.conv3x3_pack_weights(cv.weight))
+                        self.__dict__["_wpack"] = ent
+                    packed = ent[1]
                 return ops.conv_bias_act(x.contiguous(memory_format=torch.channels_last), cv.weight, self.epi.bias, residual,
-                                         cv.stride[0], 1, self.relu, tile)
+                                         cv.stride[0], 1, self.relu, tile, packed)
         y = self.conv(x)
         if folded:                                          # the bias was added to the consumer's epilogue bias: nothing to do here
             return y

@@ -57,6 +57,7 @@ SIGNATURES = {
     "gdkvm_stem_conv_pool": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
     "gdkvm_gate_logits": (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     "gdkvm_conv_bias_act": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
+    "gdkvm_conv3x3_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "gdkvm_upsample_cat": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_upsample_cat_bwd": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_bias_relu_maxpool": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
@@ -668,10 +669,30 @@ def gate_logits(p_tok: torch.Tensor, w_gate: torch.Tensor, b_gate: torch.Tensor,
     return beta, alpha
 
 
+CONV_PACKED_WEIGHTS = 32
+
+
+def conv3x3_pack_weights(weight: torch.Tensor) -> torch.Tensor:
+    """The fragment-ordered copy of channels_last bf16 [K,C,3,3] weights that conv_bias_act(..., packed=...) reads
+    (gdkvm_conv3x3_pack_weights): K a multiple of 16, C of 64.  Same bytes, another order; keep it next to the weights."""
+    lib = load()
+    if weight.dim() != 4 or weight.dtype != torch.bfloat16 or tuple(weight.shape[2:]) != (3, 3) or not weight.is_cuda or \
+            not weight.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("conv3x3_pack_weights: weight must be a channels_last bf16 [K,C,3,3] device tensor")
+    k, c = weight.shape[:2]
+    packed = torch.empty(k * 9 * c, dtype=torch.bfloat16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = lib.gdkvm_conv3x3_pack_weights(weight.data_ptr(), packed.data_ptr(), k, c, BF16, _stream(weight.device))
+    _check(rc, "gdkvm_conv3x3_pack_weights")
+    return packed
+
+
 def conv_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tensor] = None,
-                  stride: int = 1, padding: int = 1, relu: bool = True, tile: int = 0) -> torch.Tensor:
+                  stride: int = 1, padding: int = 1, relu: bool = True, tile: int = 0,
+                  packed: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act(conv2d(x, weight) + bias[k] (+ residual)) as ONE kernel on channels_last bf16 tensors (gdkvm_conv_bias_act): the
-    epilogue runs on the fp32 accumulator inside the implicit-GEMM kernel, no second pass over the output."""
+    epilogue runs on the fp32 accumulator inside the implicit-GEMM kernel, no second pass over the output.  packed: the
+    conv3x3_pack_weights copy of `weight` (kernel 5 reads it instead: faster, same result)."""
     lib = load()
     if x.dim() != 4 or not x.is_cuda or x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
         raise GdkvmError("conv_bias_act needs a channels_last bf16 [N,C,H,W] device tensor (no CPU path)")
@@ -688,8 +709,12 @@ def conv_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, res
                                  not residual.is_contiguous(memory_format=torch.channels_last)):
         raise GdkvmError("residual must match the output (shape, dtype, channels_last)")
     with torch.cuda.device(x.device):
-        rc = lib.gdkvm_conv_bias_act(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(residual), y.data_ptr(),
-                                     n, c, hh, ww, k, r, s, stride, padding, int(relu), tile, BF16, _stream(x.device))
+        if packed is not None:
+            if packed.dtype != torch.bfloat16 or packed.numel() != weight.numel() or packed.device != x.device:
+                raise GdkvmError("conv_bias_act: packed must be conv3x3_pack_weights(weight)")
+            tile = (tile or 5) | CONV_PACKED_WEIGHTS
+        rc = lib.gdkvm_conv_bias_act(x.data_ptr(), (packed if packed is not None else weight).data_ptr(), bias.data_ptr(), _ptr(residual),
+                                     y.data_ptr(), n, c, hh, ww, k, r, s, stride, padding, int(relu), tile, BF16, _stream(x.device))
     _check(rc, "gdkvm_conv_bias_act")
     return y
 

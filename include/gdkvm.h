@@ -234,8 +234,12 @@ int gdkvm_gate_logits(const void* p, const float* w_gate, const float* b_gate, c
  * y / residual [N, H, W, K], bias fp32 [K]; bf16 only.  The fp32 accumulator is rounded ONCE (after the epilogue).  Both kernels
  * are hand-written: kernel 4 = 64 -> 64 channels (conv3x3_c64.hip: LDS halo band, weights resident in registers), kernel 5 = C a
  * multiple of 64, K of 16, rows of <= 64 pixels (conv3x3_tile.hip: 64-channel LDS chunks, weights streamed); kernel 0 picks by
- * shape.  Anything else (strided, 1x1, odd channel counts) returns GDKVM_ERR_SHAPE: those stay on the framework convolution
- * followed by gdkvm_bias_act. */
+ * shape; 6, 7, 8 pin kernel 5's wave grid (4 channel groups x 1 tile, 4 x 2, 2 x 2: tuning; 5 picks by K).  Anything else
+ * (strided, 1x1, odd channel counts) returns GDKVM_ERR_SHAPE: those stay on the framework convolution followed by gdkvm_bias_act.
+ * kernel | GDKVM_CONV_PACKED_WEIGHTS (kernel 5..8): w is the fragment-ordered copy gdkvm_conv3x3_pack_weights made of the
+ * [K, 3, 3, C] weights (same size) -- each 1 KiB weight fragment is then one contiguous read; same result bit for bit. */
+enum { GDKVM_CONV_PACKED_WEIGHTS = 32 };
+int gdkvm_conv3x3_pack_weights(const void* w, void* packed, int K, int C, int io_dtype, void* stream);
 int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y,
                         int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, int kernel,
                         int io_dtype, void* stream);

@@ -206,6 +206,15 @@ def test_conv_with_fused_epilogue(hip, kernel, case):
         assert (got.double() - want).abs().max() <= 2.0 ** -7 * max(1.0, want.abs().max().item())
     with pytest.raises(hip.GdkvmError):
         hip.conv_bias_act(x.float(), wt, b, r, stride, 1, True, kernel)
+    if kernel == 5:
+        # the wave-grid variants (6..8) and the fragment-ordered weights compute the same sums in the same order: bit-identical
+        want = hip.conv_bias_act(x, wt, b, r, stride, 1, True, 5)
+        pk = hip.conv3x3_pack_weights(wt)
+        for variant in (5, 6, 7, 8):
+            assert torch.equal(hip.conv_bias_act(x, wt, b, r, stride, 1, True, variant), want)
+            assert torch.equal(hip.conv_bias_act(x, wt, b, r, stride, 1, True, variant, pk), want)
+        with pytest.raises(hip.GdkvmError):
+            hip.conv_bias_act(x, wt, b, r, stride, 1, True, 4, pk)          # (packed weights go with the chunked kernel only)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -49,13 +49,18 @@ def main():
                 z = torch.nn.functional.conv2d(x, w, None, st, pad)
                 return ops.bias_act_(z, b, r, True)
             line = f"{name:24s} {'+res' if res else '    '} miopen+epilogue {ev(mi):6.1f} us (conv {ev(lambda: torch.nn.functional.conv2d(x, w, None, st, pad)):6.1f}) | hand-written:"
-            for t in (4, 5):
+            for t in (4, 5, 6, 7, 8):
                 try:
                     y = ops.conv_bias_act(x, w, b, r, st, pad, True, t)
                     err = (y.float() - ref).abs().max().item() / ref.abs().max().item()
                     line += f" k{t} {ev(lambda: ops.conv_bias_act(x, w, b, r, st, pad, True, t)):6.1f}" + ("" if err < 1e-2 else f"(ERR {err:.1e})")
                 except ops.GdkvmError:
                     line += f" k{t}   n/a "
+            if R == 3 and st == 1 and C % 64 == 0 and not (C == 64 and K == 64):
+                pk = ops.conv3x3_pack_weights(w)
+                y = ops.conv_bias_act(x, w, b, r, st, pad, True, 5, pk)
+                err = (y.float() - ref).abs().max().item() / ref.abs().max().item()
+                line += f" | k5 packed {ev(lambda: ops.conv_bias_act(x, w, b, r, st, pad, True, 5, pk)):6.1f}" + ("" if err < 1e-2 else f"(ERR {err:.1e})")
             print(line, flush=True)
 
 
