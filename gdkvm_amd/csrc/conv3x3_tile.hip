@@ -58,7 +58,22 @@ struct ConvTileArgs {
     int fpt, th, tiles_y, ntiles;        // frames per tile, rows per tile, row tiles per frame, tiles in all
     int bw, bh, band_px, npieces;        // band geometry: (th + 2) x (W + 2) pixels per frame; 1 KiB DMA pieces per chunk
     int relu;
+    float inv_band, inv_bw, inv_tw, inv_w;   // 1 / (bh bw), 1 / bw, 1 / (th W), 1 / W: index arithmetic without integer division
+    int perm;                                // K % 32 == 0: output channels permuted within groups of 32 (ct_channel)
 };
+
+// floor(n / d) for the small non-negative indices of this kernel (n < 2^16), inv = 1.0f / d: exact, and 3 instructions where an
+// integer division is ~40 (the prologue and every tile's epilogue do dozens of them per lane: 17 % of a 128 -> 128 layer)
+__device__ __forceinline__ int ct_div(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
+
+// Row j of the 16-channel output tile kt is output channel ct_channel(kt, j).  With K a multiple of 32 the two tiles of a
+// 32-channel group interleave in fours, so that the accumulator rows 4g .. 4g+3 of BOTH tiles of a wave are 8 consecutive
+// channels 32G + 8g .. +7: one 16-byte store (and residual load) per pixel and lane instead of two 8-byte ones.  The weights
+// are addressed (or packed) in the same order, so the result is that of the plain order.
+__host__ __device__ __forceinline__ int ct_channel(int kt, int j, int perm)
+{
+    return perm ? 32 * (kt >> 1) + 8 * (j >> 2) + 4 * (kt & 1) + (j & 3) : 16 * kt + j;
+}
 
 // Waves form an MW (pixel-tile group) x NWN (output-channel group) grid, MW NWN = 8; a wave owns NTW 16-channel output tiles (the
 // workgroup 16 NTW NWN output channels) and every MW-th pixel tile (MTW of 13).  Per 32-deep k-step a wave reads MTW pixel
@@ -72,6 +87,9 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char ct_band[];    // [2][npieces * 1024] | 1 KiB dump slot
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wn = w % NWN, wm = w / NWN;
+#ifdef CT_DIAG
+    { const int gc = 0; CT_STAMP(6); }                      // kernel entry (slot 6 of chunk 0)
+#endif
     const int H = a.H, W = a.W, C = a.C, K = a.K, BW = a.bw;
     const int band_bytes = a.npieces * 1024, nchunk = C / CT_CK;
     const int tpix = a.fpt * a.th * W;                     // output pixels of a full tile
@@ -83,7 +101,7 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
 #pragma unroll
     for (int u = 0; u < PP; ++u) {
         const int j = w + 8 * u, d = 64 * j + lane, pix = d / CT_SLOTS, c = d - CT_SLOTS * pix;
-        const int f = pix / (a.bh * BW), r = pix - f * (a.bh * BW), by = r / BW, bx = r - by * BW;
+        const int f = ct_div(pix, a.inv_band), r = pix - f * (a.bh * BW), by = ct_div(r, a.inv_bw), bx = r - by * BW;
         g_rel[u] = ((f * H + by) * W + bx) * C + c * 8;
         const bool live = j < a.npieces && c < 8 && pix < a.band_px && bx >= 1 && bx <= W;
         g_yx[u] = live ? by : -1;
@@ -115,7 +133,7 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
 #pragma unroll
     for (int m = 0; m < MTW; ++m) {
         const int p = min(16 * (wm + MW * m) + li, tpix - 1);
-        const int f = p / (a.th * W), r = p - f * (a.th * W), py = r / W, px = r - py * W;
+        const int f = ct_div(p, a.inv_tw), r = p - f * (a.th * W), py = ct_div(r, a.inv_w), px = r - py * W;
         pbase[m] = (unsigned)(((f * a.bh + py) * BW + px) * CT_PIX + g * 16);
     }
     f32x4 bias4[NTW];
@@ -123,11 +141,12 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         bias4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (co0 + 16 * nt < K) bias4[nt] = *reinterpret_cast<const f32x4*>(a.bias + co0 + 16 * nt + 4 * g);
+        const int kt = min(co0 / 16 + nt, K / 16 - 1);     // (a tile past K: the last tile's weights, results never stored)
+        if (co0 + 16 * nt < K) bias4[nt] = *reinterpret_cast<const f32x4*>(a.bias + ct_channel(kt, 4 * g, a.perm));
         // PK: the weights were re-laid out by gdkvm_conv3x3_pack_weights as [K / 16][k-step][lane][8], a fragment = 1 KiB contiguous
         // (8 full cache lines per load instruction instead of 16 half-used ones: the vector-memory path is this kernel's bound)
-        if constexpr (PK) wrow[nt] = a.w + (size_t)min(co0 / 16 + nt, K / 16 - 1) * (9 * C * 16) + lane * 8;
-        else wrow[nt] = a.w + (size_t)min(co0 + 16 * nt + li, K - 1) * 9 * C + 8 * g;
+        if constexpr (PK) wrow[nt] = a.w + (size_t)kt * (9 * C * 16) + lane * 8;
+        else wrow[nt] = a.w + (size_t)ct_channel(kt, li, a.perm) * 9 * C + 8 * g;
     }
 
     // k-steps of one tile: chunk-major, then tap, then channel half: ks = (chunk * 9 + tap) * 2 + kh
@@ -242,32 +261,48 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
             for (int r0 = KU; r0 < 18; r0 += KU) trip(r0, std::false_type{});
             CT_STAMP(5);
         }
-        // epilogue: lane (li, g) holds channels co0 + 16nt + 4g .. +3 of pixel 16 (wm + MW m) + li
+        // epilogue: lane (li, g) holds rows 4g .. 4g+3 of each of the wave's output tiles for pixel 16 (wm + MW m) + li
 #ifndef CT_ABL_NOEPI
         {
             const int ty = tile % a.tiles_y, fg = tile / a.tiles_y;
+            auto bf4 = [](uint2 rr) { return f32x4{__uint_as_float(rr.x << 16), __uint_as_float(rr.x & 0xffff0000u), __uint_as_float(rr.y << 16), __uint_as_float(rr.y & 0xffff0000u)}; };
+            auto pk4 = [](const f32x4& v) { return make_uint2((unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16), (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16)); };
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < MTW; ++m) {
                 const int p = 16 * (wm + MW * m) + li;
                 if (p >= tpix) continue;
-                const int f = p / (a.th * W), r = p - f * (a.th * W), py = r / W, px = r - py * W;
+                const int f = ct_div(p, a.inv_tw), r = p - f * (a.th * W), py = ct_div(r, a.inv_w), px = r - py * W;
                 const int n = fg * a.fpt + f, yy = ty * a.th + py;
                 if (n >= a.N || yy >= H) continue;
+                const size_t opix = (((size_t)n * H + yy) * W + px) * K;
+                if (NTW == 2 && a.perm) {                  // 8 consecutive channels 32G + 8g .. +7 (co0 and K are multiples of 32)
+                    if (co0 >= K) continue;
+                    const size_t o = opix + co0 + 8 * g;
+                    f32x4 v0 = acc[m][0] + bias4[0], v1 = acc[m][NTW - 1] + bias4[NTW - 1];
+                    if (a.res) {
+                        const uint4 rr = *reinterpret_cast<const uint4*>(a.res + o);
+                        v0 += bf4(make_uint2(rr.x, rr.y)); v1 += bf4(make_uint2(rr.z, rr.w));
+                    }
+                    if (a.relu) { v0 = __builtin_elementwise_max(v0, zero4); v1 = __builtin_elementwise_max(v1, zero4); }
+                    const uint2 lo = pk4(v0), hi = pk4(v1);
+                    *reinterpret_cast<uint4*>(a.y + o) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    continue;
+                }
 #pragma unroll
                 for (int nt = 0; nt < NTW; ++nt) {
                     if (co0 + 16 * nt >= K) continue;
-                    const size_t o = (((size_t)n * H + yy) * W + px) * K + co0 + 16 * nt + 4 * g;
+                    const size_t o = opix + ct_channel(co0 / 16 + nt, 4 * g, a.perm);
                     f32x4 v = acc[m][nt] + bias4[nt];
-                    if (a.res) {
-                        const uint2 rr = *reinterpret_cast<const uint2*>(a.res + o);
-                        v += f32x4{__uint_as_float(rr.x << 16), __uint_as_float(rr.x & 0xffff0000u), __uint_as_float(rr.y << 16), __uint_as_float(rr.y & 0xffff0000u)};
-                    }
-                    if (a.relu) v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
-                    *reinterpret_cast<uint2*>(a.y + o) = make_uint2((unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16),
-                                                                    (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16));
+                    if (a.res) v += bf4(*reinterpret_cast<const uint2*>(a.res + o));
+                    if (a.relu) v = __builtin_elementwise_max(v, zero4);
+                    *reinterpret_cast<uint2*>(a.y + o) = pk4(v);
                 }
             }
         }
+#endif
+#ifdef CT_DIAG
+        { const int gcs = gc; { const int gc = gcs - 1; CT_STAMP(7); } }   // end of the tile's epilogue (slot 7 of its last chunk)
 #endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing may land in LDS after the workgroup is gone
@@ -276,7 +311,7 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
 // Shapes this kernel serves: 3x3 / stride 1 / pad 1, C a multiple of 64, K a multiple of 16, and a map that tiles into <= 208
 // pixels: whole frames of <= 208 pixels (several small frames per tile), or row bands of a wider frame.  Returns 0 when launched, 1
 // when the shape is not covered (the caller falls back to the framework convolution + epilogue pass).
-// weights [K][3][3][C] -> [K / 16][k-step = (chunk * 9 + tap) * 2 + kh][lane = 16 g + li][8]:  w[16 kt + li][tap][64 chunk + 32 kh + 8 g ..]
+// weights [K][3][3][C] -> [K / 16][k-step = (chunk * 9 + tap) * 2 + kh][lane = 16 g + li][8]:  w[ct_channel(kt, li)][tap][64 chunk + 32 kh + 8 g ..]
 __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const uint4* w, uint4* packed, int K, int C)
 {
     const int nks = C / CT_CK * 18;
@@ -286,7 +321,7 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const uint4* w, uint4
         const size_t f = i >> 6;
         const int ks = (int)(f % nks), kt = (int)(f / nks);
         const int chunk = ks / 18, r = ks - 18 * chunk, tap = r >> 1, kh = r & 1;
-        packed[i] = w[(((size_t)(16 * kt + li) * 9 + tap) * C + chunk * CT_CK + 32 * kh + 8 * g) / 8];
+        packed[i] = w[(((size_t)ct_channel(kt, li, K % 32 == 0) * 9 + tap) * C + chunk * CT_CK + 32 * kh + 8 * g) / 8];
     }
 }
 
@@ -342,6 +377,9 @@ int gdkvm_conv3x3_tile_launch(const void* x, const void* w, const float* bias, c
     while (pieces() > 56 && a.th > 1) { --a.th; a.bh = a.th + 2; a.tiles_y = (H + a.th - 1) / a.th; }
     a.npieces = pieces();
     if (a.npieces > 56) return 1;
+    a.inv_band = 1.0f / (float)(a.bh * a.bw); a.inv_bw = 1.0f / (float)a.bw;
+    a.inv_tw = 1.0f / (float)(a.th * W); a.inv_w = 1.0f / (float)W;
+    a.perm = K % 32 == 0;
     const long long groups = (N + a.fpt - 1) / a.fpt;
     const long long ntiles = groups * a.tiles_y;
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 1;

@@ -177,7 +177,8 @@ def test_stem_s2d_and_its_convolution(hip, dtype):
                                   (1, 64, 64, 64, 64, 1, True), (3, 64, 1, 1, 64, 1, False), (700, 64, 6, 5, 64, 1, True),
                                   (9, 128, 14, 14, 128, 1, True), (7, 256, 7, 7, 256, 1, True), (3, 384, 14, 14, 128, 1, False),
                                   (2, 192, 28, 28, 64, 1, False), (5, 128, 16, 10, 48, 1, True), (2, 64, 9, 70, 64, 1, False),
-                                  (20, 256, 4, 4, 256, 1, True), (3, 128, 64, 64, 64, 1, False), (33, 64, 2, 3, 128, 1, False)])
+                                  (20, 256, 4, 4, 256, 1, True), (3, 128, 64, 64, 64, 1, False), (33, 64, 2, 3, 128, 1, False), (4, 64, 14, 14, 160, 1, True),
+                                  (2, 128, 7, 9, 96, 1, False)])
 def test_conv_with_fused_epilogue(hip, kernel, case):
     """gdkvm_conv_bias_act (both hand-written kernels, and the choice by shape) == act(conv2d + bias (+ residual)) computed in fp32
     and rounded once; shapes neither kernel covers -- strided layers, channel counts that are no multiple of 64 / 16, rows wider

@@ -56,14 +56,17 @@ def stamps():
     lib.gdkvm_ct_diag_buffer.argtypes = [ctypes.c_void_p]
     lib.gdkvm_ct_diag_buffer(ctypes.c_void_p(buf.data_ptr()))
     for _ in range(3):
-        ops.conv_bias_act(x, w, b, None, 1, 1, True, 5)
+        ops.conv_bias_act(x, w, b, None, 1, 1, True, 5, ops.conv3x3_pack_weights(w))
     torch.cuda.synchronize()
     t = buf.cpu().reshape(8, 8, 8)                      # [chunk][wave][slot]
     t0 = t[0, :, 0].min()
     print(f"{C}->{K}@{H}: s_memtime cycles, workgroup 0; per chunk and wave: arrive | vmcnt wait | barrier wait | setup | trip 0 | trips 1-2 | (chunk total)")
+    print(f"  kernel entry -> first chunk: {int(t[0, 0, 0] - t[0, 0, 6])} cycles (wave 0), {int(t[0, 4, 0] - t[0, 4, 6])} (wave 4)")
     for c in range(8):
         if t[c, 0, 5] == 0:
             break
+        if t[c, 0, 7]:
+            print(f"  tile ends with chunk {c}: epilogue {int(t[c, 0, 7] - t[c, 0, 5])} cycles (wave 0), {int(t[c, 4, 7] - t[c, 4, 5])} (wave 4); since entry {int(t[c, 0, 7] - t[0, 0, 6])}")
         for wv in range(8):
             r = t[c, wv]
             print(f"  chunk {c} wave {wv}: at {int(r[0] - t0):7d} | {int(r[1] - r[0]):6d} | {int(r[2] - r[1]):6d} | {int(r[3] - r[2]):6d} | {int(r[4] - r[3]):6d} | {int(r[5] - r[4]):6d} | ({int(r[5] - r[0]):6d})")
@@ -79,7 +82,8 @@ def run_one(name):
         x = torch.randn(512, C, H, H, device="cuda").relu().bfloat16().contiguous(memory_format=torch.channels_last)
         w = (torch.randn(K, C, 3, 3, device="cuda") / (C * 9) ** 0.5).bfloat16().contiguous(memory_format=torch.channels_last)
         b = torch.randn(K, device="cuda")
-        out.append(f"{C}->{K}@{H}: {ev(lambda: ops.conv_bias_act(x, w, b, None, 1, 1, True, 5)):6.1f} us")
+        pk = ops.conv3x3_pack_weights(w)
+        out.append(f"{C}->{K}@{H}: {ev(lambda: ops.conv_bias_act(x, w, b, None, 1, 1, True, 5, pk)):6.1f} us")
     print(f"{name:26s} " + " | ".join(out), flush=True)
 
 
