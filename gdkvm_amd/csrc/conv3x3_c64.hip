@@ -29,9 +29,19 @@ constexpr int CV_PIX = 160;              // bytes between LDS pixels: 8 data chu
 
 __device__ const uint4 g_conv_zero16 = {0, 0, 0, 0};          // source of the zero padding
 
+#ifdef CV_DIAG
+// diagnostic builds (tools/abl_conv_tile.py c64stamps): s_memtime per wave of workgroup 0 at the phase boundaries of its first tiles
+__device__ unsigned long long* g_cv_diag = nullptr;
+#define CV_STAMP(slot) do { if (blockIdx.x == 0 && lane == 0 && nt_done < 8) { unsigned long long t__; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); g_cv_diag[(nt_done * 4 + w) * 8 + (slot)] = t__; } } while (0)
+#else
+#define CV_STAMP(slot) do {} while (0)
+#endif
+
 struct Conv64Args {
     const bf16_t* x; const bf16_t* w; const float* bias; const bf16_t* res; bf16_t* y;
     int N, H, W, tiles_x, tiles_y, relu;
+    int packed;                          // w is the gdkvm_conv3x3_pack_weights copy: fragment (kt, ks) = 1 KiB contiguous, rows in this kernel's channel order
 };
 
 template <int TW>
@@ -43,24 +53,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(Conv64Args a)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
     const int ntiles = a.N * a.tiles_y * a.tiles_x;
-
-    // weights of this wave's 32 output channels, all 18 k-steps, as A-operand fragments.  Which channel an MFMA row stands for is
-    // free: row rho = 4 g' + r of n-tile nt is channel 32wn + 8g' + 4nt + r, so that a lane's two accumulator tiles hold EIGHT
-    // consecutive channels of its pixel (one 16-byte store / residual load instead of two 8-byte ones).
-    bf16x8 wf[2][18];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int ks = 0; ks < 18; ++ks) {
-            const int tap = ks >> 1, kh = ks & 1, co = 32 * wn + 8 * (li >> 2) + 4 * nt + (li & 3);
-            wf[nt][ks] = *reinterpret_cast<const bf16x8*>(a.w + ((size_t)co * 9 + tap) * CV_C + 32 * kh + 8 * g);
-        }
-    float bia[2][4];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 32 * wn + 8 * g + 4 * nt);
-        bia[nt][0] = b4[0]; bia[nt][1] = b4[1]; bia[nt][2] = b4[2]; bia[nt][3] = b4[3];
-    }
+    int nt_done = 0;
+    (void)nt_done;
+    CV_STAMP(6);
 
     // band fetch by LDS-DMA: piece j = w + 4u (64 consecutive 16-byte LDS slots) is issued by wave w; slot d = 10 pix + c holds
     // channel chunk c of band pixel pix (c = 8, 9: padding).  The slot geometry does not depend on the tile: kept in registers.
@@ -105,11 +100,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(Conv64Args a)
     // | DMA of the tile after next into `cur` | this tile's epilogue.  The stores and the DMA are never waited for right
     // after being issued: the next wait is a tile of MFMAs later.
     int tile = blockIdx.x, cur = 0;
-    if (tile < ntiles) fetch(tile, 0);
+    if (tile < ntiles) fetch(tile, 0);                     // (the first band is on its way while the weights load)
+
+    // weights of this wave's 32 output channels, all 18 k-steps, as A-operand fragments.  Which channel an MFMA row stands for is
+    // free: row rho = 4 g' + r of n-tile nt is channel 32wn + 8g' + 4nt + r, so that a lane's two accumulator tiles hold EIGHT
+    // consecutive channels of its pixel (one 16-byte store / residual load instead of two 8-byte ones).
+    // (packed weights -- conv3x3_tile.hip's ct_channel order is this one -- make each of the 36 loads one contiguous KiB: the
+    // prologue was a quarter of the kernel's time with 16 half-used cache lines per load)
+    bf16x8 wf[2][18];
+    if (a.packed) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 18; ++ks)
+                wf[nt][ks] = *reinterpret_cast<const bf16x8*>(a.w + ((size_t)((2 * wn + nt) * 18 + ks) * 64 + lane) * 8);
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 18; ++ks) {
+                const int tap = ks >> 1, kh = ks & 1, co = 32 * wn + 8 * (li >> 2) + 4 * nt + (li & 3);
+                wf[nt][ks] = *reinterpret_cast<const bf16x8*>(a.w + ((size_t)co * 9 + tap) * CV_C + 32 * kh + 8 * g);
+            }
+    }
+    float bia[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + 32 * wn + 8 * g + 4 * nt);
+        bia[nt][0] = b4[0]; bia[nt][1] = b4[1]; bia[nt][2] = b4[2]; bia[nt][3] = b4[3];
+    }
+
     __syncthreads();                                       // (vmcnt(0) + barrier: the first band has landed)
     if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x, 1);
     for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
         const unsigned char* band = band2 + cur * BAND_BYTES;
+        CV_STAMP(0);
 
         f32x4 acc[4][2];
 #pragma unroll
@@ -146,9 +171,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(Conv64Args a)
         if (wm == 0 || NM1 == 4) compute(std::integral_constant<int, (NMT < 4 ? NMT : 4)>{});
         else if constexpr (NM1 > 0 && NM1 < 4) compute(std::integral_constant<int, (NM1 > 0 ? NM1 : 1)>{});
 
+        CV_STAMP(1);
         __syncthreads();                                   // everyone is done with this band; the next one has landed
+        CV_STAMP(2);
 
         if (tile + 2 * (int)gridDim.x < ntiles) fetch(tile + 2 * gridDim.x, cur);
+        CV_STAMP(3);
 
         // epilogue: lane (li, g) holds channels 32wn + 8g .. +7 of pixel 16(4wm+m) + li (tile nt: the four channels 4nt ..)
         const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
@@ -178,16 +206,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(Conv64Args a)
             }
             *reinterpret_cast<uint4*>(a.y + o) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
+        CV_STAMP(4);
+#ifdef CV_DIAG
+        ++nt_done;
+#endif
     }
 }
 
 }  // namespace
 
+#ifdef CV_DIAG
+extern "C" void gdkvm_cv_diag_buffer(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cv_diag), &p, sizeof(p)); }
+#endif
+
 // internal entry used by gdkvm_conv_bias_act (conv_dispatch.hip): returns 0 on launch
 int gdkvm_conv3x3_c64_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, int N, int H, int W,
-                             int relu, hipStream_t st)
+                             int relu, int packed, hipStream_t st)
 {
     Conv64Args a;
+    a.packed = packed;
     a.x = static_cast<const bf16_t*>(x); a.w = static_cast<const bf16_t*>(w); a.bias = bias;
     a.res = static_cast<const bf16_t*>(residual); a.y = static_cast<bf16_t*>(y);
     a.N = N; a.H = H; a.W = W; a.relu = relu;

@@ -6,7 +6,7 @@
 #include "gdkvm_common.hpp"
 
 int gdkvm_conv3x3_c64_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, int N, int H, int W,
-                             int relu, hipStream_t st);          // conv3x3_c64.hip
+                             int relu, int packed, hipStream_t st);   // conv3x3_c64.hip
 int gdkvm_conv3x3_tile_launch(const void* x, const void* w, const float* bias, const void* residual, void* y,
                               int N, int C, int H, int W, int K, int relu, int variant, int packed, hipStream_t st);   // conv3x3_tile.hip
 
@@ -22,8 +22,8 @@ extern "C" int gdkvm_conv_bias_act(const void* x, const void* w, const float* bi
     const bool packed = kernel & GDKVM_CONV_PACKED_WEIGHTS;
     kernel &= ~GDKVM_CONV_PACKED_WEIGHTS;
     if (kernel != 0 && (kernel < 4 || kernel > 8)) return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: kernel=%d (0 = by shape, 4, 5, 6..8)", kernel);
-    if (packed && (kernel < 5 || C % 64 || K % 16))
-        return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: packed weights go with kernel 5 (C a multiple of 64, K of 16), not kernel=%d C=%d K=%d", kernel, C, K);
+    if (packed && (C % 64 || K % 16))
+        return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: packed weights need C a multiple of 64 and K of 16 (C=%d K=%d)", C, K);
     if (!(R == 3 && S == 3 && stride == 1 && pad == 1))
         return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: %dx%d stride %d pad %d is not served by the hand-written kernels (3x3 / 1 / 1): "
                                            "use the framework convolution + gdkvm_bias_act", R, S, stride, pad);
@@ -38,7 +38,7 @@ extern "C" int gdkvm_conv_bias_act(const void* x, const void* w, const float* bi
     const bool c64 = C == 64 && K == 64;
     if (kernel == 4 && !c64) return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: kernel 4 serves 64 -> 64 channels only (C=%d K=%d)", C, K);
     if (kernel == 4 || (kernel == 0 && c64)) {
-        if (gdkvm_conv3x3_c64_launch(x, w, bias, residual, y, N, H, W, relu, st)) return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: too many tiles");
+        if (gdkvm_conv3x3_c64_launch(x, w, bias, residual, y, N, H, W, relu, packed ? 1 : 0, st)) return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: too many tiles");
         GDKVM_LAUNCH_CHECK("conv3x3_c64_kernel");
         return GDKVM_OK;
     }

@@ -221,7 +221,7 @@ class FusedConv(nn.Module):
             tile = self._tile(cv.in_channels, cv.out_channels, cv.stride[0], residual is not None, x.shape[-1])
             if tile is not None:                            # bias (+ residual) (+ ReLU) inside the implicit-GEMM kernel: one launch
                 packed = None
-                if tile == 5:                               # fragment-ordered weights, kept until the weights change (_wkey)
+                if tile in (4, 5):                          # fragment-ordered weights, kept until the weights change (_wkey)
                     key = _wkey(cv.weight) + (x.device,)
                     ent = self.__dict__.get("_wpack")
                     if ent is None or ent[0] != key:

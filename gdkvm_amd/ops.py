@@ -712,7 +712,7 @@ def conv_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, res
         if packed is not None:
             if packed.dtype != torch.bfloat16 or packed.numel() != weight.numel() or packed.device != x.device:
                 raise GdkvmError("conv_bias_act: packed must be conv3x3_pack_weights(weight)")
-            tile = (tile or 5) | CONV_PACKED_WEIGHTS
+            tile |= CONV_PACKED_WEIGHTS
         rc = lib.gdkvm_conv_bias_act(x.data_ptr(), (packed if packed is not None else weight).data_ptr(), bias.data_ptr(), _ptr(residual),
                                      y.data_ptr(), n, c, hh, ww, k, r, s, stride, padding, int(relu), tile, BF16, _stream(x.device))
     _check(rc, "gdkvm_conv_bias_act")

@@ -236,7 +236,7 @@ int gdkvm_gate_logits(const void* p, const float* w_gate, const float* b_gate, c
  * multiple of 64, K of 16, rows of <= 64 pixels (conv3x3_tile.hip: 64-channel LDS chunks, weights streamed); kernel 0 picks by
  * shape; 6, 7, 8 pin kernel 5's wave grid (4 channel groups x 1 tile, 4 x 2, 2 x 2: tuning; 5 picks by K).  Anything else
  * (strided, 1x1, odd channel counts) returns GDKVM_ERR_SHAPE: those stay on the framework convolution followed by gdkvm_bias_act.
- * kernel | GDKVM_CONV_PACKED_WEIGHTS (kernel 5..8): w is the fragment-ordered copy gdkvm_conv3x3_pack_weights made of the
+ * kernel | GDKVM_CONV_PACKED_WEIGHTS: w is the fragment-ordered copy gdkvm_conv3x3_pack_weights made of the
  * [K, 3, 3, C] weights (same size) -- each 1 KiB weight fragment is then one contiguous read; same result bit for bit. */
 enum { GDKVM_CONV_PACKED_WEIGHTS = 32 };
 int gdkvm_conv3x3_pack_weights(const void* w, void* packed, int K, int C, int io_dtype, void* stream);

@@ -42,6 +42,41 @@ def build(only):
         print("built", so, flush=True)
 
 
+def c64stamps():
+    """conv3x3_c64.hip built with -DCV_DIAG: where a tile's time goes (workgroup 0, its first tiles)."""
+    import ctypes
+    import torch
+    from gdkvm_amd import ops
+    ops._SO = os.path.join(OUT, "c64_stamps.so")
+    lib = ops.load()
+    x = torch.randn(512, 64, 28, 28, device="cuda").relu().bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 64, 3, 3, device="cuda") / 24.0).bfloat16().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(64, device="cuda")
+    buf = torch.zeros(8 * 4 * 8, dtype=torch.int64, device="cuda")
+    lib.gdkvm_cv_diag_buffer.argtypes = [ctypes.c_void_p]
+    lib.gdkvm_cv_diag_buffer(ctypes.c_void_p(buf.data_ptr()))
+    for _ in range(3):
+        ops.conv_bias_act(x, w, b, None, 1, 1, True, 4)
+    torch.cuda.synchronize()
+    t = buf.cpu().reshape(8, 4, 8)
+    print(f"64->64@28: entry -> first tile {int(t[0, 0, 0] - t[0, 0, 6])} cycles; per tile and wave: MFMAs | barrier | fetch issue | epilogue | (tile)")
+    for c in range(7):
+        for wv in range(4):
+            r = t[c, wv]
+            print(f"  tile {c} wave {wv}: {int(r[1] - r[0]):6d} | {int(r[2] - r[1]):6d} | {int(r[3] - r[2]):6d} | {int(r[4] - r[3]):6d} | ({int(r[4] - r[0]):6d})")
+
+
+def build_c64():
+    os.makedirs(OUT, exist_ok=True)
+    others = [o for o in sorted(glob.glob(os.path.join(CSRC, "_obj", "*.o"))) if not o.endswith("conv3x3_c64.o")]
+    obj, so = os.path.join(OUT, "c64_stamps.o"), os.path.join(OUT, "c64_stamps.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-DCV_DIAG",
+                           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, os.path.join(CSRC, "conv3x3_c64.hip"), "-o", obj])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, obj] + others)
+    os.remove(obj)
+    print("built", so, flush=True)
+
+
 def stamps():
     import ctypes
     import torch
@@ -90,6 +125,10 @@ def run_one(name):
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build(sys.argv[2:])
+    elif sys.argv[1] == "build_c64":
+        build_c64()
+    elif sys.argv[1] == "c64stamps":
+        c64stamps()
     elif sys.argv[1] == "stamps":
         stamps()
     elif sys.argv[1] == "run":
