@@ -12,6 +12,7 @@
 // accumulator tiles, reads its weight rows straight from L2 with 16-byte loads (each weight element is
 // fetched once per workgroup), and fuses bias, sigmoid, gating and the residual into the epilogue.
 #include <atomic>
+#include <type_traits>
 #include "gdkvm_common.hpp"
 
 namespace {
@@ -193,11 +194,26 @@ __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c)
 // One software-pipelined pass of `n` k-steps (32 inputs each, starting at k-step ks0 of the LDS tile) against NS weight
 // streams in fragment order, for MT token tiles.  The WEIGHTS are the A operand and the tokens the B operand, so an
 // accumulator register holds D[channel 4g+r][token i]: a lane ends up with 4 consecutive channels of one token (8-byte
-// stores, one 8-byte LDS read for the residual) instead of one channel of 4 tokens (four 2-byte stores).  Weight
-// fragments are prefetched three k-steps ahead (L2 latency ~600-800 cycles vs ~130-400 cycles of MFMA per step); the
-// rotation is done with register copies, which only ever wait on the OLDEST fetch.
+// stores, one 8-byte LDS read for the residual) instead of one channel of 4 tokens (four 2-byte stores).
+// Weight fragments are prefetched KPFF_WD k-steps ahead (L2 latency ~600-800 cycles vs ~130-400 cycles of MFMA per step) into
+// a ring of KPFF_WD register sets with STATIC indices: k-step i uses set i % KPFF_WD and refills it for k-step i + KPFF_WD.
+// (Until round 2 the sets were rotated with register copies -- b[0] = b[1]; ...; b[3] = load -- and the copy of the freshly
+// loaded set made the compiler wait for the newest fetch every k-step: s_waitcnt vmcnt(0) / vmcnt(1) inside the loop.)
 // OT output tiles at once: a token fragment read from LDS feeds NS*OT MFMAs (the kernel is LDS-read-bound at OT = 1: every
 // 32-deep k-step re-reads MT KiB of tokens for MT*NS MFMAs); ot_stride = elements between consecutive output tiles' packs.
+#ifndef KPFF_WD_STEPS
+#define KPFF_WD_STEPS 4
+#endif
+constexpr int KPFF_WD = KPFF_WD_STEPS;               // ring depth = k-steps per unrolled trip
+template <int I, int E, class F>
+__device__ __forceinline__ void kpff_static_for(F&& f)
+{
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        kpff_static_for<I + 1, E>(f);
+    }
+}
+
 template <int NS, int MT, int OT>
 __device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, int n, const bf16_t* w0, const bf16_t* w1, size_t ot_stride,
                                             f32x4 (&acc0)[OT][MT], f32x4 (&acc1)[OT][MT])
@@ -208,49 +224,46 @@ __device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, i
 #else
 #define KPFF_WOFF(x) (x)
 #endif
-    bf16x8 b0[OT][4], b1[OT][4];                           // [0] = current, [1..3] = the next three k-steps
-#pragma unroll
-    for (int d = 1; d < 4; ++d) {
-        const size_t off = KPFF_WOFF((size_t)min(d - 1, n - 1) * 512);
+    bf16x8 b0[KPFF_WD][OT], b1[KPFF_WD][OT];
+    auto wload = [&](int slot_ks, bf16x8 (&d0)[OT], bf16x8 (&d1)[OT]) __attribute__((always_inline)) {
+        const size_t off = KPFF_WOFF((size_t)min(slot_ks, n - 1) * 512);
 #pragma unroll
         for (int o = 0; o < OT; ++o) {
-            b0[o][d] = *reinterpret_cast<const bf16x8*>(w0 + o * ot_stride + off);
-            if constexpr (NS == 2) b1[o][d] = *reinterpret_cast<const bf16x8*>(w1 + o * ot_stride + off);
+            d0[o] = *reinterpret_cast<const bf16x8*>(w0 + o * ot_stride + off);
+            if constexpr (NS == 2) d1[o] = *reinterpret_cast<const bf16x8*>(w1 + o * ot_stride + off);
         }
-    }
-    // Token fragments are double-buffered in registers, a whole k-step at a time: with one fragment register re-used per token
-    // tile (what a plain loop compiles to) every ds_read_b128 is followed by a full lgkmcnt(0) wait -- eight exposed LDS
-    // latencies per k-step, about four times the step's MFMA time.
-    auto ldx = [&](int i, bf16x8 (&x)[MT]) __attribute__((always_inline)) {
-        const int ks = ks0 + min(i, n - 1);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) x[mt] = *reinterpret_cast<const bf16x8*>(xb + (size_t)mt * 16 * ld + 32 * ks);
     };
-    auto body = [&](int i, const bf16x8 (&x)[MT], bf16x8 (&xnext)[MT]) __attribute__((always_inline)) {
-        const size_t off = KPFF_WOFF((size_t)min(i + 3, n - 1) * 512);
 #pragma unroll
-        for (int o = 0; o < OT; ++o) {
-            b0[o][0] = b0[o][1]; b0[o][1] = b0[o][2]; b0[o][2] = b0[o][3];
-            if constexpr (NS == 2) { b1[o][0] = b1[o][1]; b1[o][1] = b1[o][2]; b1[o][2] = b1[o][3]; }
-            b0[o][3] = *reinterpret_cast<const bf16x8*>(w0 + o * ot_stride + off);
-            if constexpr (NS == 2) b1[o][3] = *reinterpret_cast<const bf16x8*>(w1 + o * ot_stride + off);
-        }
-        ldx(i + 1, xnext);                                 // next k-step's fragments: in flight behind this step's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
+    for (int d = 0; d < KPFF_WD; ++d) wload(d, b0[d], b1[d]);
+    bf16x8 xa[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xa[mt] = *reinterpret_cast<const bf16x8*>(xb + (size_t)mt * 16 * ld + 32 * ks0);
+    // One register set of token fragments, refilled fragment by fragment: tile mt's fragment for the NEXT k-step is requested
+    // right behind the MFMAs that consumed this k-step's -- MT - 1 tiles of MFMAs (>= the LDS latency) before it is needed, and
+    // LDS returns in order, so the wait in front of each tile's MFMAs is a counted lgkmcnt(MT - 1), never a drain.  (A second
+    // full set -- a k-step ahead -- cost 32 more registers and spilled; a plain loop over one set waited lgkmcnt(0) per read.)
+    auto body = [&](int i, auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value % KPFF_WD;   // ring set of k-step i
+        const int ksn = ks0 + min(i + 1, n - 1);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int o = 0; o < OT; ++o) {
-                acc0[o][mt] = mfma_bf16(b0[o][0], x[mt], acc0[o][mt]);
-                if constexpr (NS == 2) acc1[o][mt] = mfma_bf16(b1[o][0], x[mt], acc1[o][mt]);
+                acc0[o][mt] = mfma_bf16(b0[j][o], xa[mt], acc0[o][mt]);
+                if constexpr (NS == 2) acc1[o][mt] = mfma_bf16(b1[j][o], xa[mt], acc1[o][mt]);
             }
+            xa[mt] = *reinterpret_cast<const bf16x8*>(xb + (size_t)mt * 16 * ld + 32 * ksn);
         }
+        wload(i + KPFF_WD, b0[j], b1[j]);                  // refill the weight set just used
+        __builtin_amdgcn_sched_barrier(0);
     };
-    bf16x8 xa[MT], xc[MT];
-    ldx(0, xa);
     int i = 0;
-    for (; i + 2 <= n; i += 2) { body(i, xa, xc); body(i + 1, xc, xa); }
-    if (i < n) body(i, xa, xc);
+    for (; i + KPFF_WD <= n; i += KPFF_WD)                 // (i stays a multiple of KPFF_WD: the set ids are static)
+        kpff_static_for<0, KPFF_WD>([&](auto jc) { body(i + decltype(jc)::value, jc); });
+    const int rem = n - i;
+    kpff_static_for<0, KPFF_WD - 1>([&](auto jc) {
+        if (decltype(jc)::value < rem) body(i + decltype(jc)::value, jc);
+    });
 }
 
 // NT = 64-token tiles per workgroup (4*NT waves).  NT = 2 halves the weight traffic per token: at 64 tokens per
