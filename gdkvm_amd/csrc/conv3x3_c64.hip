@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(Conv64Args a)
     }
 
     // Per tile: MFMAs from buffer `cur` | barrier (+ vmcnt(0): the other buffer's band, issued a whole tile ago, has landed)
-    // | DMA of the tile after next into `cur` | this tile's epilogue.  The stores and the DMA are never waited for right
+    // | this tile's epilogue | DMA of the tile after next into `cur`.  The stores and the DMA are never waited for right
     // after being issued: the next wait is a tile of MFMAs later.
     int tile = blockIdx.x, cur = 0;
     if (tile < ntiles) fetch(tile, 0);                     // (the first band is on its way while the weights load)
@@ -175,7 +175,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(Conv64Args a)
         __syncthreads();                                   // everyone is done with this band; the next one has landed
         CV_STAMP(2);
 
-        if (tile + 2 * (int)gridDim.x < ntiles) fetch(tile + 2 * gridDim.x, cur);
         CV_STAMP(3);
 
         // epilogue: lane (li, g) holds channels 32wn + 8g .. +7 of pixel 16(4wm+m) + li (tile nt: the four channels 4nt ..)
@@ -206,6 +205,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_kernel(Conv64Args a)
             }
             *reinterpret_cast<uint4*>(a.y + o) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
         }
+        // the band of the tile after next, into the buffer just consumed.  Issued BEHIND the epilogue: the compiler cannot order
+        // LDS-DMA against register loads and waits with vmcnt(0) for the residual -- ahead of the epilogue that wait also covered
+        // the band just requested from HBM (+9 us per residual layer); the band still has a whole tile of MFMAs to land.
+        if (tile + 2 * (int)gridDim.x < ntiles) fetch(tile + 2 * gridDim.x, cur);
         CV_STAMP(4);
 #ifdef CV_DIAG
         ++nt_done;

@@ -233,13 +233,16 @@ __device__ __forceinline__ void unpack8(const uint4& a, float (&v)[8])
 // copied vectors; all loads of a row are issued before the first blend.
 __global__ __launch_bounds__(256) void upsample_cat_bf16_kernel(const bf16_t* lo, const bf16_t* skip, bf16_t* out,
                                                                 int Nimg, int hl, int wl, int H, int W, int C1, int C2,
-                                                                float sy, float sx)
+                                                                float sy, float sx, float inv_c1n, float inv_c2n, float inv_h)
 {
+    // floor(n / d) for the small non-negative indices below (n < 2^20), inv = 1.0f / d: exact, 3 instructions instead of ~40 for
+    // an integer division by a run-time divisor -- there were four to six of those per thread and row, as many as useful work
+    auto qdiv = [](int n, float inv) { return (int)(((float)n + 0.5f) * inv); };
     const int C = C1 + C2, c1n = C1 / 8, c2n = C2 / 8, n1 = W * c1n, n2 = W * c2n, tid = threadIdx.x;
     constexpr int MAXV = 2;                                // interpolated vectors per thread per trip (W*C1/8 <= 512 in one trip)
     const bool exact2x = H == 2 * hl && W == 2 * wl;
     for (int row = blockIdx.x; row < Nimg * H; row += gridDim.x) {
-        const int n = row / H, y = row - n * H;
+        const int n = qdiv(row, inv_h), y = row - n * H;
         const float fy = fmaxf(sy * ((float)y + 0.5f) - 0.5f, 0.f);
         const int y0 = (int)fy, y1 = min(y0 + 1, hl - 1);
         const float ly = fy - (float)y0, hy = 1.f - ly;
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void upsample_cat_bf16_kernel(const bf16_t* lo
             const int nu = (wl + 1) * c1n;
             for (int u0 = 0; u0 < nu; u0 += 256) {
                 const int u = min(u0 + tid, nu - 1);
-                const int jq = u / c1n, c = (u - jq * c1n) * 8, jp = jq - 1;
+                const int jq = qdiv(u, inv_c1n), c = (u - jq * c1n) * 8, jp = jq - 1;
                 const int x0 = max(jp, 0), x1 = min(jp + 1, wl - 1);
                 const uint4 t00 = *reinterpret_cast<const uint4*>(lo0 + x0 * C1 + c), t01 = *reinterpret_cast<const uint4*>(lo0 + x1 * C1 + c);
                 const uint4 t10 = *reinterpret_cast<const uint4*>(lo1 + x0 * C1 + c), t11 = *reinterpret_cast<const uint4*>(lo1 + x1 * C1 + c);
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256) void upsample_cat_bf16_kernel(const bf16_t* lo
 #pragma unroll
             for (int u = 0; u < MAXV; ++u) {
                 const int j = min(j0 + u * 256 + tid, n1 - 1);
-                const int x = j / c1n, c = (j - x * c1n) * 8;
+                const int x = qdiv(j, inv_c1n), c = (j - x * c1n) * 8;
                 const float fx = fmaxf(sx * ((float)x + 0.5f) - 0.5f, 0.f);
                 const int x0 = (int)fx, x1 = min(x0 + 1, wl - 1);
                 lx[u] = fx - (float)x0;
@@ -316,12 +319,12 @@ __global__ __launch_bounds__(256) void upsample_cat_bf16_kernel(const bf16_t* lo
         for (int u = 0; u < MAXV; ++u) {
             const int jc = u * 256 + tid;
             if (jc < n2) {
-                const int x = jc / c2n;
+                const int x = qdiv(jc, inv_c2n);
                 *reinterpret_cast<uint4*>(orow + x * C + C1 + (jc - x * c2n) * 8) = cp[u];
             }
         }
         for (int jc = MAXV * 256 + tid; jc < n2; jc += 256) {                 // wider rows: the rest of the copy half
-            const int x = jc / c2n;
+            const int x = qdiv(jc, inv_c2n);
             *reinterpret_cast<uint4*>(orow + x * C + C1 + (jc - x * c2n) * 8) = *reinterpret_cast<const uint4*>(sk + jc * 8);
         }
     }
@@ -551,12 +554,12 @@ extern "C" int gdkvm_upsample_cat(const void* lo, const void* skip, void* out,
     if (!lo || !skip || !out || !gdkvm_aligned16(lo) || !gdkvm_aligned16(skip) || !gdkvm_aligned16(out))
         return gdkvm_fail(GDKVM_ERR_ARG, "upsample_cat: null or misaligned pointer");
     if (int rc = gdkvm_check_device()) return rc;
-    if ((size_t)W * (C1 + C2) >= (1u << 30)) return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_cat: row too long");
+    if ((size_t)W * (C1 + C2) >= (1u << 20) || (size_t)Nimg * H >= (1u << 20)) return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_cat: row too long or too many rows");
     size_t blocks = (size_t)Nimg * H;
     if (blocks > 256 * 16) blocks = 256 * 16;
     hipLaunchKernelGGL(upsample_cat_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const bf16_t*>(lo), static_cast<const bf16_t*>(skip), static_cast<bf16_t*>(out),
-                       Nimg, hl, wl, H, W, C1, C2, (float)hl / (float)H, (float)wl / (float)W);
+                       Nimg, hl, wl, H, W, C1, C2, (float)hl / (float)H, (float)wl / (float)W, 8.0f / (float)C1, 8.0f / (float)C2, 1.0f / (float)H);
     GDKVM_LAUNCH_CHECK("upsample_cat_bf16_kernel");
     return GDKVM_OK;
 }
