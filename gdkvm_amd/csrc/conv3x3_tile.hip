@@ -54,6 +54,8 @@ __device__ __forceinline__ void static_for_ct(F&& f)
 
 struct ConvTileArgs {
     const bf16_t* x; const bf16_t* w; const float* bias; const bf16_t* res; bf16_t* y;
+    const bf16_t* x2; int C1;            // x2 != NULL: the input is the channel concatenation [x (C1 channels) ; x2 (C - C1)], never
+                                         // materialised: a 64-channel chunk is fetched from the tensor it lies in (C1 % 64 == 0)
     int N, H, W, C, K;                   // frames, map, input / output channels
     int fpt, th, tiles_y, ntiles;        // frames per tile, rows per tile, row tiles per frame, tiles in all
     int bw, bh, band_px, npieces;        // band geometry: (th + 2) x (W + 2) pixels per frame; 1 KiB DMA pieces per chunk
@@ -97,20 +99,22 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
 
     // DMA piece geometry (tile-invariant): piece j = w + 8u, slot d = 64 j + lane = CT_SLOTS pix + c; c >= 8 is padding
     constexpr int PP = 7;                                  // pieces per wave: npieces <= 56
-    int g_rel[PP], g_yx[PP], g_fr[PP];
+    int g_pix[PP], g_yx[PP], g_fr[PP];                     // source pixel offset from the band's (0, 0); band row or -1; frame | 8c << 8
 #pragma unroll
     for (int u = 0; u < PP; ++u) {
         const int j = w + 8 * u, d = 64 * j + lane, pix = d / CT_SLOTS, c = d - CT_SLOTS * pix;
         const int f = ct_div(pix, a.inv_band), r = pix - f * (a.bh * BW), by = ct_div(r, a.inv_bw), bx = r - by * BW;
-        g_rel[u] = ((f * H + by) * W + bx) * C + c * 8;
+        g_pix[u] = (f * H + by) * W + bx;
         const bool live = j < a.npieces && c < 8 && pix < a.band_px && bx >= 1 && bx <= W;
         g_yx[u] = live ? by : -1;
-        g_fr[u] = f;
+        g_fr[u] = f | (c * 8) << 8;
     }
     auto fetch = [&](int tile, int chunk, int buf) __attribute__((always_inline)) {
         const int ty = tile % a.tiles_y, fg = tile / a.tiles_y;          // row tile, frame group
         const int y0 = ty * a.th - 1;
-        const bf16_t* origin = a.x + (((long long)fg * a.fpt * H + y0) * W - 1) * C + chunk * CT_CK;
+        const bool second = a.x2 != nullptr && chunk * CT_CK >= a.C1;   // which tensor of a concatenated input holds this chunk
+        const int cs = a.x2 ? (second ? C - a.C1 : a.C1) : C;           // its channel count = pixel pitch
+        const bf16_t* origin = (second ? a.x2 : a.x) + (((long long)fg * a.fpt * H + y0) * W - 1) * cs + chunk * CT_CK - (second ? a.C1 : 0);
         const int nfr = min(a.fpt, a.N - fg * a.fpt);                   // frames that exist in the last group
         // straight-line on purpose (always PP pieces: surplus ones land in a dump slot): a branch would make the compiler's vmcnt
         // counting conservative for the weight fragments in flight around it
@@ -121,8 +125,8 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
         for (int u = 0; u < PP; ++u) {
             const int j = w + 8 * u;
             const int yy = y0 + g_yx[u];
-            const bool ok = g_yx[u] >= 0 && (unsigned)yy < (unsigned)H && g_fr[u] < nfr;
-            const bf16_t* src = ok ? origin + g_rel[u] : reinterpret_cast<const bf16_t*>(&g_ct_zero16);
+            const bool ok = g_yx[u] >= 0 && (unsigned)yy < (unsigned)H && (g_fr[u] & 255) < nfr;
+            const bf16_t* src = ok ? origin + g_pix[u] * cs + (g_fr[u] >> 8) : reinterpret_cast<const bf16_t*>(&g_ct_zero16);
             unsigned char* dst = j < a.npieces ? ct_band + buf * band_bytes + 1024 * j : ct_band + 2 * band_bytes;
             __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
         }
@@ -359,11 +363,13 @@ bool setattr_tile()
 extern "C" void gdkvm_ct_diag_buffer(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ct_diag), &p, sizeof(p)); }
 #endif
 
-int gdkvm_conv3x3_tile_launch(const void* x, const void* w, const float* bias, const void* residual, void* y,
+int gdkvm_conv3x3_tile_launch(const void* x, const void* x2, int C1, const void* w, const float* bias, const void* residual, void* y,
                               int N, int C, int H, int W, int K, int relu, int variant, int packed, hipStream_t st)
 {
     if (C % CT_CK || K % 16 || W > 64 || W < 1 || H < 1 || N < 1 || variant < 0 || variant > 3) return 1;
+    if (x2 && (C1 <= 0 || C1 >= C || C1 % CT_CK)) return 1;
     ConvTileArgs a;
+    a.x2 = static_cast<const bf16_t*>(x2); a.C1 = x2 ? C1 : C;
     a.x = static_cast<const bf16_t*>(x); a.w = static_cast<const bf16_t*>(w); a.bias = bias;
     a.res = static_cast<const bf16_t*>(residual); a.y = static_cast<bf16_t*>(y);
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.relu = relu;

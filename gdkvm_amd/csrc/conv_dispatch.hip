@@ -7,7 +7,7 @@
 
 int gdkvm_conv3x3_c64_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, int N, int H, int W,
                              int relu, int packed, hipStream_t st);   // conv3x3_c64.hip
-int gdkvm_conv3x3_tile_launch(const void* x, const void* w, const float* bias, const void* residual, void* y,
+int gdkvm_conv3x3_tile_launch(const void* x, const void* x2, int C1, const void* w, const float* bias, const void* residual, void* y,
                               int N, int C, int H, int W, int K, int relu, int variant, int packed, hipStream_t st);   // conv3x3_tile.hip
 
 extern "C" int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y,
@@ -42,9 +42,35 @@ extern "C" int gdkvm_conv_bias_act(const void* x, const void* w, const float* bi
         GDKVM_LAUNCH_CHECK("conv3x3_c64_kernel");
         return GDKVM_OK;
     }
-    if (gdkvm_conv3x3_tile_launch(x, w, bias, residual, y, N, C, H, W, K, relu, kernel >= 6 ? kernel - 5 : 0, packed ? 1 : 0, st))
+    if (gdkvm_conv3x3_tile_launch(x, nullptr, 0, w, bias, residual, y, N, C, H, W, K, relu, kernel >= 6 ? kernel - 5 : 0, packed ? 1 : 0, st))
         return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: C=%d K=%d %dx%d is not served by the hand-written kernels (C a multiple of 64, K of "
                                            "16, rows of at most 64 pixels): use the framework convolution + gdkvm_bias_act", C, K, H, W);
+    GDKVM_LAUNCH_CHECK("conv3x3_tile_kernel");
+    return GDKVM_OK;
+}
+
+// The same convolution over the channel concatenation [x1 (C1 channels) ; x2 (C2)] of two NHWC tensors, which is never
+// materialised (the decoder's "upsampled feature ; skip feature" input): the chunked kernel fetches every 64-channel chunk from
+// the tensor it lies in.  C1 and C2 multiples of 64; w [K, 3, 3, C1 + C2] (or its packed copy); kernel 0 / 5..8 as above.
+extern "C" int gdkvm_conv_cat_bias_act(const void* x1, const void* x2, const void* w, const float* bias, const void* residual, void* y,
+                                       int N, int C1, int C2, int H, int W, int K, int relu, int kernel, int io_dtype, void* stream)
+{
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "conv_cat_bias_act: only bf16 is implemented");
+    const bool packed = kernel & GDKVM_CONV_PACKED_WEIGHTS;
+    kernel &= ~GDKVM_CONV_PACKED_WEIGHTS;
+    if (kernel != 0 && (kernel < 5 || kernel > 8)) return gdkvm_fail(GDKVM_ERR_ARG, "conv_cat_bias_act: kernel=%d (0, 5..8)", kernel);
+    if (N < 0 || C1 <= 0 || C2 <= 0 || C1 % 64 || C2 % 64 || H <= 0 || W <= 0 || K <= 0 || K % 16)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_cat_bias_act: N=%d C1=%d C2=%d H=%d W=%d K=%d (C1, C2 multiples of 64, K of 16)", N, C1, C2, H, W, K);
+    if (N == 0) return GDKVM_OK;
+    if (!x1 || !x2 || !w || !bias || !y) return gdkvm_fail(GDKVM_ERR_ARG, "conv_cat_bias_act: null pointer");
+    if (!gdkvm_aligned16(x1) || !gdkvm_aligned16(x2) || !gdkvm_aligned16(w) || !gdkvm_aligned16(y) || !gdkvm_aligned16(bias) || (residual && !gdkvm_aligned16(residual)))
+        return gdkvm_fail(GDKVM_ERR_ARG, "conv_cat_bias_act: pointers must be 16-byte aligned");
+    if ((size_t)N * H * W * (C1 + C2) >= (1ull << 31) || (size_t)N * H * W * K >= (1ull << 31))
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_cat_bias_act: tensor too large for 32-bit offsets");
+    if (int rc = gdkvm_check_device()) return rc;
+    if (gdkvm_conv3x3_tile_launch(x1, x2, C1, w, bias, residual, y, N, C1 + C2, H, W, K, relu, kernel >= 6 ? kernel - 5 : 0, packed ? 1 : 0,
+                                  static_cast<hipStream_t>(stream)))
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_cat_bias_act: %dx%d is not served (rows of at most 64 pixels)", H, W);
     GDKVM_LAUNCH_CHECK("conv3x3_tile_kernel");
     return GDKVM_OK;
 }

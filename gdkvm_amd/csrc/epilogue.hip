@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void upsample_cat_bf16_kernel(const bf16_t* lo
         bf16_t* orow = out + (size_t)row * W * C;
         uint4 cp[MAXV];                                    // this thread's first copy vectors, in flight behind the taps
 #pragma unroll
-        for (int u = 0; u < MAXV; ++u) cp[u] = *reinterpret_cast<const uint4*>(sk + min(u * 256 + tid, n2 - 1) * 8);
+        for (int u = 0; u < MAXV; ++u) cp[u] = n2 ? *reinterpret_cast<const uint4*>(sk + min(u * 256 + tid, n2 - 1) * 8) : make_uint4(0u, 0u, 0u, 0u);
         if (exact2x) {
             // exactly 2x: output columns 2jp+1 and 2jp+2 share the horizontal taps jp and jp+1 (weights 1/4 and 3/4), so a
             // thread owns one such pair per trip -- four tap loads for two outputs; jp = -1 and jp = wl-1 are the borders
@@ -546,12 +546,12 @@ __global__ __launch_bounds__(256) void upsample_cat_bwd_bf16_kernel(const bf16_t
 extern "C" int gdkvm_upsample_cat(const void* lo, const void* skip, void* out,
                                   int Nimg, int hl, int wl, int H, int W, int C1, int C2, int io_dtype, void* stream)
 {
-    if (Nimg < 0 || hl <= 0 || wl <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 <= 0)
-        return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_cat: bad shape");
+    if (Nimg < 0 || hl <= 0 || wl <= 0 || H <= 0 || W <= 0 || C1 <= 0 || C2 < 0 || (C2 == 0) != (skip == nullptr))
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_cat: bad shape (C2 == 0 goes with skip == NULL: the enlargement alone)");
     if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "upsample_cat: only bf16 (inference build) is implemented");
     if (C1 % 8 || C2 % 8) return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_cat: channel counts must be multiples of 8");
     if (Nimg == 0) return GDKVM_OK;
-    if (!lo || !skip || !out || !gdkvm_aligned16(lo) || !gdkvm_aligned16(skip) || !gdkvm_aligned16(out))
+    if (!lo || !out || !gdkvm_aligned16(lo) || (skip && !gdkvm_aligned16(skip)) || !gdkvm_aligned16(out))
         return gdkvm_fail(GDKVM_ERR_ARG, "upsample_cat: null or misaligned pointer");
     if (int rc = gdkvm_check_device()) return rc;
     if ((size_t)W * (C1 + C2) >= (1u << 20) || (size_t)Nimg * H >= (1u << 20)) return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_cat: row too long or too many rows");

@@ -137,6 +137,15 @@ class UpBlock(nn.Module):
 
     def forward(self, x, skip):
         c = self.conv
+        if (isinstance(c[0], FusedConv) and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.bfloat16
+                and skip.dtype == torch.bfloat16 and c[0].cat_served(x.shape[1], skip.shape[1], skip.shape[-1])):
+            # inference build: only the enlarged feature is written; the first convolution reads it and the skip feature where they
+            # lie (no concatenated copy: 154 MB less traffic per forward at cfg2)
+            u = ops.upsample_bilinear(x.contiguous(memory_format=torch.channels_last), skip.shape[2:])
+            y = c[0].forward_cat(u, skip)
+            for m in list(c)[1:]:
+                y = m(y)
+            return y
         if (x.is_cuda and x.dtype == torch.bfloat16 and skip.dtype == torch.bfloat16
                 and x.shape[1] % 8 == 0 and skip.shape[1] % 8 == 0):            # one fused HIP pass (differentiable)
             x = ops.upsample_cat(x.contiguous(memory_format=torch.channels_last),
@@ -212,6 +221,29 @@ class FusedConv(nn.Module):
             return 4
         return 5 if width <= 64 else None                   # (the chunked kernel tiles rows of at most 64 pixels)
 
+    def _packed(self, device):
+        """The fragment-ordered copy of the weights (ops.conv3x3_pack_weights), kept until the weights change (_wkey)."""
+        key = _wkey(self.conv.weight) + (device,)
+        ent = self.__dict__.get("_wpack")
+        if ent is None or ent[0] != key:
+            ent = (key, ops.conv3x3_pack_weights(self.conv.weight))
+            self.__dict__["_wpack"] = ent
+        return ent[1]
+
+    def cat_served(self, c1: int, c2: int, width: int) -> bool:
+        """Can forward_cat run this layer on [x1 (c1 channels) ; x2 (c2)] without the concatenated tensor (gdkvm_conv_cat_bias_act)?"""
+        cv = self.conv
+        return (not getattr(self, "bias_folded_downstream", False) and cv.kernel_size == (3, 3) and cv.groups == 1
+                and cv.dilation == (1, 1) and cv.stride == (1, 1) and cv.padding == (1, 1) and cv.weight.is_cuda
+                and cv.weight.dtype == torch.bfloat16 and cv.weight.is_contiguous(memory_format=torch.channels_last)
+                and c1 % 64 == 0 and c2 % 64 == 0 and c1 + c2 == cv.in_channels and cv.out_channels % 16 == 0 and width <= 64)
+
+    def forward_cat(self, x1, x2):
+        """forward(torch.cat([x1, x2], 1)) with every 64-channel chunk read from the tensor it lies in."""
+        cl = torch.channels_last
+        return ops.conv_cat_bias_act(x1.contiguous(memory_format=cl), x2.contiguous(memory_format=cl), self.conv.weight, self.epi.bias,
+                                     None, self.relu, 0, self._packed(x1.device))
+
     def forward(self, x, residual=None):
         cv = self.conv
         folded = getattr(self, "bias_folded_downstream", False)
@@ -220,14 +252,7 @@ class FusedConv(nn.Module):
                 and cv.in_channels % 8 == 0 and cv.out_channels % 8 == 0 and cv.weight.is_contiguous(memory_format=torch.channels_last)):
             tile = self._tile(cv.in_channels, cv.out_channels, cv.stride[0], residual is not None, x.shape[-1])
             if tile is not None:                            # bias (+ residual) (+ ReLU) inside the implicit-GEMM kernel: one launch
-                packed = None
-                if tile in (4, 5):                          # fragment-ordered weights, kept until the weights change (_wkey)
-                    key = _wkey(cv.weight) + (x.device,)
-                    ent = self.__dict__.get("_wpack")
-                    if ent is None or ent[0] != key:
-                        ent = (key, ops.conv3x3_pack_weights(cv.weight))
-                        self.__dict__["_wpack"] = ent
-                    packed = ent[1]
+                packed = self._packed(x.device) if tile in (4, 5) else None
                 return ops.conv_bias_act(x.contiguous(memory_format=torch.channels_last), cv.weight, self.epi.bias, residual,
                                          cv.stride[0], 1, self.relu, tile, packed)
         y = self.conv(x)

@@ -58,6 +58,7 @@ SIGNATURES = {
     "gdkvm_gate_logits": (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     "gdkvm_conv_bias_act": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
     "gdkvm_conv3x3_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "gdkvm_conv_cat_bias_act": (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
     "gdkvm_upsample_cat": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_upsample_cat_bwd": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_bias_relu_maxpool": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
@@ -757,6 +758,55 @@ def stem_s2d(x: torch.Tensor, cpad: int) -> torch.Tensor:
         rc = lib.gdkvm_stem_s2d(x.data_ptr(), out.data_ptr(), n, c, hh, ww, cpad, _io_dtype(x), _stream(x.device))
     _check(rc, "gdkvm_stem_s2d")
     return out
+
+
+def upsample_bilinear(lo: torch.Tensor, size) -> torch.Tensor:
+    """F.interpolate(lo, size, mode="bilinear", align_corners=False) on a channels_last bf16 [N,C,h,w] device tensor
+    (gdkvm_upsample_cat without a skip tensor): what conv_cat_bias_act reads next to the skip feature."""
+    lib = load()
+    if lo.dim() != 4 or not lo.is_cuda or lo.dtype != torch.bfloat16 or not lo.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("upsample_bilinear needs a channels_last bf16 [N,C,h,w] device tensor (no CPU path)")
+    n, c1, hl, wl = lo.shape
+    H, W = int(size[0]), int(size[1])
+    out = torch.empty((n, c1, H, W), dtype=lo.dtype, device=lo.device, memory_format=torch.channels_last)
+    with torch.cuda.device(lo.device):
+        rc = lib.gdkvm_upsample_cat(lo.data_ptr(), None, out.data_ptr(), n, hl, wl, H, W, c1, 0, BF16, _stream(lo.device))
+    _check(rc, "gdkvm_upsample_cat")
+    return out
+
+
+def conv_cat_bias_act(x1: torch.Tensor, x2: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor,
+                      residual: Optional[torch.Tensor] = None, relu: bool = True, tile: int = 0,
+                      packed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv_bias_act(torch.cat([x1, x2], 1), weight, ...) for a 3x3 / stride 1 / pad 1 layer WITHOUT the concatenated tensor
+    (gdkvm_conv_cat_bias_act): channel counts in multiples of 64, same result bit for bit."""
+    lib = load()
+    for t in (x1, x2):
+        if t.dim() != 4 or not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous(memory_format=torch.channels_last):
+            raise GdkvmError("conv_cat_bias_act needs channels_last bf16 [N,C,H,W] device tensors (no CPU path)")
+    n, c1, hh, ww = x1.shape
+    c2 = x2.shape[1]
+    if tuple(x2.shape) != (n, c2, hh, ww):
+        raise GdkvmError("conv_cat_bias_act: x1 and x2 must agree in batch and size")
+    if weight.dim() != 4 or weight.dtype != torch.bfloat16 or tuple(weight.shape[1:]) != (c1 + c2, 3, 3) or \
+            not weight.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("conv_cat_bias_act: weight must be channels_last bf16 [K,C1+C2,3,3]")
+    k = weight.shape[0]
+    if bias.dtype != torch.float32 or bias.numel() != k:
+        raise GdkvmError("bias must be float32 [K]")
+    y = torch.empty((n, k, hh, ww), dtype=x1.dtype, device=x1.device, memory_format=torch.channels_last)
+    if residual is not None and (residual.shape != y.shape or residual.dtype != y.dtype or
+                                 not residual.is_contiguous(memory_format=torch.channels_last)):
+        raise GdkvmError("residual must match the output (shape, dtype, channels_last)")
+    if packed is not None:
+        if packed.dtype != torch.bfloat16 or packed.numel() != weight.numel() or packed.device != x1.device:
+            raise GdkvmError("conv_cat_bias_act: packed must be conv3x3_pack_weights(weight)")
+        tile |= CONV_PACKED_WEIGHTS
+    with torch.cuda.device(x1.device):
+        rc = lib.gdkvm_conv_cat_bias_act(x1.data_ptr(), x2.data_ptr(), (packed if packed is not None else weight).data_ptr(), bias.data_ptr(),
+                                         _ptr(residual), y.data_ptr(), n, c1, c2, hh, ww, k, int(relu), tile, BF16, _stream(x1.device))
+    _check(rc, "gdkvm_conv_cat_bias_act")
+    return y
 
 
 def _upsample_cat_fwd(lo: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:

@@ -243,6 +243,12 @@ int gdkvm_conv3x3_pack_weights(const void* w, void* packed, int K, int C, int io
 int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y,
                         int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, int kernel,
                         int io_dtype, void* stream);
+/* The same 3x3 / 1 / 1 convolution over the channel concatenation [x1 (C1 channels) ; x2 (C2)] of two NHWC tensors, which is
+ * never materialised -- the decoder's  conv(cat(upsample(feature), skip))  without the concatenated copy.  C1, C2 multiples of
+ * 64, K of 16, rows of <= 64 pixels; w [K, 3, 3, C1 + C2] or its packed copy (kernel | GDKVM_CONV_PACKED_WEIGHTS); kernel 0 or
+ * 5..8.  Bit-identical to gdkvm_conv_bias_act on the concatenated tensor. */
+int gdkvm_conv_cat_bias_act(const void* x1, const void* x2, const void* w, const float* bias, const void* residual, void* y,
+                            int N, int C1, int C2, int H, int W, int K, int relu, int kernel, int io_dtype, void* stream);
 
 /* Row n1, the stem: bias + ReLU + 3x3 / stride 2 / pad 1 max-pool in one pass over the NHWC conv output
  * x [N, H, W, C] -> y [N, (H-1)/2+1, (W-1)/2+1, C]:  y = relu(max_window(x) + bias)  (== max_window(relu(x + bias)), the
@@ -291,7 +297,8 @@ int gdkvm_bn_bwd(const void* x, const void* y, const void* dy, const float* gamm
                  long long rows, int C, int relu, int io_dtype, void* stream);
 
 /* decoder glue, out = concat(bilinear_upsample(lo -> H x W), skip) over
- * NHWC tensors  lo [N,hl,wl,C1], skip [N,H,W,C2], out [N,H,W,C1+C2]; align_corners = false; bf16 only. */
+ * NHWC tensors  lo [N,hl,wl,C1], skip [N,H,W,C2], out [N,H,W,C1+C2]; align_corners = false; bf16 only.  skip == NULL with
+ * C2 == 0: the enlargement alone (its consumer, gdkvm_conv_cat_bias_act, reads the skip tensor where it lies). */
 int gdkvm_upsample_cat(const void* lo, const void* skip, void* out,
                        int Nimg, int hl, int wl, int H, int W, int C1, int C2, int io_dtype, void* stream);
 /* Backward of gdkvm_upsample_cat (training): dlo [Nimg, hl, wl, C1] = transpose of the bilinear enlargement applied to

@@ -218,6 +218,30 @@ def test_conv_with_fused_epilogue(hip, kernel, case):
             assert torch.equal(hip.conv_bias_act(x, wt, b, r, stride, 1, True, 4, pk), hip.conv_bias_act(x, wt, b, r, stride, 1, True, 4))
 
 
+@pytest.mark.parametrize("case", [(5, 256, 128, 14, 14, 128), (3, 128, 64, 28, 28, 64), (9, 64, 64, 7, 5, 48), (2, 192, 64, 10, 33, 160)])
+def test_conv_over_a_concatenation_that_is_never_built(hip, case):
+    """gdkvm_conv_cat_bias_act([x1 ; x2]) == gdkvm_conv_bias_act(cat(x1, x2)) bit for bit (plain and packed weights), and the
+    enlargement alone (gdkvm_upsample_cat without a skip tensor) == the first C1 channels of upsample_cat."""
+    n, c1, c2, h, w, k = case
+    torch.manual_seed(sum(case))
+    cl = dict(memory_format=torch.channels_last)
+    lo = torch.randn(n, c1, (h + 1) // 2, (w + 1) // 2, device="cuda").bfloat16().contiguous(**cl)
+    x2 = torch.randn(n, c2, h, w, device="cuda").bfloat16().contiguous(**cl)
+    both = hip.upsample_cat(lo, x2)
+    x1 = hip.upsample_bilinear(lo, (h, w))
+    assert x1.is_contiguous(**cl) and torch.equal(x1, both[:, :c1]) and torch.equal(both[:, c1:], x2)
+    wt = (torch.randn(k, c1 + c2, 3, 3, device="cuda") / (9 * (c1 + c2)) ** 0.5).bfloat16().contiguous(**cl)
+    b = torch.randn(k, device="cuda")
+    r = torch.randn(n, k, h, w, device="cuda").bfloat16().contiguous(**cl)
+    pk = hip.conv3x3_pack_weights(wt)
+    for res in (None, r):
+        want = hip.conv_bias_act(both, wt, b, res, 1, 1, True, 5)
+        assert torch.equal(hip.conv_cat_bias_act(x1, x2, wt, b, res, True), want)
+        assert torch.equal(hip.conv_cat_bias_act(x1, x2, wt, b, res, True, 0, pk), want)
+    with pytest.raises(hip.GdkvmError):
+        hip.conv_cat_bias_act(x1[:, :c1 - 8].contiguous(**cl), x2, wt[:, :c1 + c2 - 8].contiguous(**cl), b)     # (chunks of 64 channels)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [(6, 49, 256, 1), (3, 256, 256, 2), (2, 7, 64, 1), (5, 1, 32, 3)])
 def test_gate_logits_one_pass(hip, dtype, case):
