@@ -453,6 +453,19 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
         d1 = *reinterpret_cast<const uint4*>(vp + ((bt + min(32 + (lane >> 1), N - 1)) * Hh + h) * Dv);
     };
 
+    // bf16 I/O: the Gram blocks of phase 1 run on the bf16 MFMA straight from the key rows -- token tile X as an operand image is
+    // 16 rows x 16 bytes per k-step, the A image of K_X and the B image of K_X^T at once, and products of bf16 are exact in fp32 --
+    // 2 MFMAs of 16 cycles per block instead of 16 exact-fp32 ones of 32 fed from the LDS staging tile.  Rows past N are clamped
+    // duplicates, not zeros: every Gram entry that involves one is multiplied by its kinv = 0 / beta = 0 below.
+    bf16x8 kimg[IO == GDKVM_BF16 ? NB : 1][2];
+    if constexpr (IO == GDKVM_BF16) {
+#pragma unroll
+        for (int X = 0; X < NB; ++X)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                kimg[X][ks] = *reinterpret_cast<const bf16x8*>(static_cast<const bf16_t*>(a.k) + ((bt + min(16 * X + li, N - 1)) * Hh + h) * GDKVM_DK + 32 * ks + 8 * g);
+    }
+
     // ---- phase 0 (a5 prologue): ONE pass over the k and q rows by all 256 threads (4 threads per token, 16 channels each):
     //      K staged in LDS as fp32 for the Gram blocks and the Kn tiles, inverse norms by a 4-lane reduction, gates
 #pragma unroll
@@ -506,13 +519,32 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
             const int J = p - I * (I + 1) / 2;                                  // J <= I
             const int nI = 16 * I + li, nJ = 16 * J + li;
             f32x4 kI[4], kJ[4];
+            if constexpr (IO != GDKVM_BF16) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                kI[m] = *reinterpret_cast<const f32x4*>(s_K + nI * KLD + 16 * m + 4 * g);
-                kJ[m] = *reinterpret_cast<const f32x4*>(s_K + nJ * KLD + 16 * m + 4 * g);
+                for (int m = 0; m < 4; ++m) {
+                    kI[m] = *reinterpret_cast<const f32x4*>(s_K + nI * KLD + 16 * m + 4 * g);
+                    kJ[m] = *reinterpret_cast<const f32x4*>(s_K + nJ * KLD + 16 * m + 4 * g);
+                }
             }
+            // (bf16 I/O: block images picked by a compile-time index -- a run-time one would put the register array in scratch)
+            auto gram16 = [&](int A, int B) __attribute__((always_inline)) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                static_for<0, NB>([&](auto ac) {
+                    static_for<0, NB>([&](auto bc) {
+                        if (decltype(ac)::value == A && decltype(bc)::value == B) {
+#pragma unroll
+                            for (int ks = 0; ks < 2; ++ks)
+                                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg[IO == GDKVM_BF16 ? decltype(ac)::value : 0][ks],
+                                                                              kimg[IO == GDKVM_BF16 ? decltype(bc)::value : 0][ks], acc, 0, 0, 0);
+                        }
+                    });
+                });
+                return acc;
+            };
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
             if (J == I) {                      // lane (g,li) reg r = k_{I,4g+r} . k_{I,li}: the image of L_II[li][4g+r]
+                if constexpr (IO == GDKVM_BF16) acc0 = gram16(J, I);
+                else {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -520,6 +552,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
                         if (m & 1) acc1 = mfma4(kJ[m][r], kI[m][r], acc1);
                         else acc0 = mfma4(kJ[m][r], kI[m][r], acc0);
                     }
+                }
                 f32x4 acc = acc0 + acc1;
                 const float rowscale = s_kinv[nI] * s_beta[nI];
                 const f32x4 kinvJ = *reinterpret_cast<const f32x4*>(s_kinv + 16 * J + 4 * g);
@@ -527,6 +560,8 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
                 for (int r = 0; r < 4; ++r) acc[r] = (4 * g + r >= li) ? 0.f : acc[r] * rowscale * kinvJ[r];
                 s_Ld[I * 64 + lane] = acc;
             } else {                           // lane (g,li) reg r = L_IJ[4g+r][li] = b_{I,4g+r} kn_{I,4g+r} . kn_{J,li}  (I > J)
+                if constexpr (IO == GDKVM_BF16) acc0 = gram16(I, J);
+                else {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -534,6 +569,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
                         if (m & 1) acc1 = mfma4(kI[m][r], kJ[m][r], acc1);
                         else acc0 = mfma4(kI[m][r], kJ[m][r], acc0);
                     }
+                }
                 f32x4 acc = acc0 + acc1;
                 const f32x4 kiI = *reinterpret_cast<const f32x4*>(s_kinv + 16 * I + 4 * g);
                 const f32x4 btI = *reinterpret_cast<const f32x4*>(s_beta + 16 * I + 4 * g);
