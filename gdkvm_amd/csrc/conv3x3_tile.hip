@@ -329,7 +329,41 @@ __global__ __launch_bounds__(256) void conv3x3_pack_kernel(const uint4* w, uint4
     }
 }
 
+// The pack of the DATA-GRADIENT convolution of the same layer, straight from the forward weights w [K][3][3][C]:
+// dx = conv3x3(dy, w') with w'[c][ty][tx][k] = w[k][2 - ty][2 - tx][c]  (input channels K, output channels C), laid out as
+// [C / 16][k-step = (chunk * 9 + tap) * 2 + kh][lane][8]:  w'[ct_channel(ct, li)][tap][64 chunk + 32 kh + 8 g + e]
+__global__ __launch_bounds__(256) void conv3x3_pack_dgrad_kernel(const bf16_t* w, uint4* packed, int K, int C)
+{
+    const int nks = K / CT_CK * 18;
+    const size_t total = (size_t)(C / 16) * nks * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63), li = lane & 15, g = lane >> 4;
+        const size_t f = i >> 6;
+        const int ks = (int)(f % nks), ct = (int)(f / nks);
+        const int chunk = ks / 18, r = ks - 18 * chunk, tap = r >> 1, kh = r & 1;
+        const int c = ct_channel(ct, li, C % 32 == 0), ftap = 8 - tap;                 // (2 - ty) * 3 + (2 - tx)
+        const bf16_t* src = w + ((size_t)(chunk * CT_CK + 32 * kh + 8 * g) * 9 + ftap) * C + c;
+        unsigned short e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = src[(size_t)j * 9 * C];
+        packed[i] = make_uint4(e[0] | (unsigned)e[1] << 16, e[2] | (unsigned)e[3] << 16, e[4] | (unsigned)e[5] << 16, e[6] | (unsigned)e[7] << 16);
+    }
+}
+
 }  // namespace
+
+extern "C" int gdkvm_conv3x3_pack_weights_dgrad(const void* w, void* packed, int K, int C, int io_dtype, void* stream)
+{
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "conv3x3_pack_weights_dgrad: only bf16 is implemented");
+    if (K <= 0 || C <= 0 || K % CT_CK || C % 16) return gdkvm_fail(GDKVM_ERR_SHAPE, "conv3x3_pack_weights_dgrad: K=%d C=%d (K a multiple of 64, C of 16)", K, C);
+    if (!w || !packed || !gdkvm_aligned16(w) || !gdkvm_aligned16(packed)) return gdkvm_fail(GDKVM_ERR_ARG, "conv3x3_pack_weights_dgrad: null or unaligned pointer");
+    if (int rc = gdkvm_check_device()) return rc;
+    const size_t total = (size_t)(C / 16) * (K / CT_CK * 18) * 64;
+    hipLaunchKernelGGL(conv3x3_pack_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const bf16_t*>(w), static_cast<uint4*>(packed), K, C);
+    GDKVM_LAUNCH_CHECK("conv3x3_pack_dgrad_kernel");
+    return GDKVM_OK;
+}
 
 extern "C" int gdkvm_conv3x3_pack_weights(const void* w, void* packed, int K, int C, int io_dtype, void* stream)
 {

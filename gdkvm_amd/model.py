@@ -80,6 +80,15 @@ def _bn_act(bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, residual: Optional[
     return F.relu(y, inplace=True) if relu else y
 
 
+def _conv(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """A training-build convolution: the stride-1 3x3 layers with channel counts in multiples of 64 run their forward and data
+    gradient on the hand-written kernels (ops.conv3x3; the weight gradient stays the framework's), everything else is conv(x)."""
+    if (torch.is_grad_enabled() and isinstance(conv, nn.Conv2d) and conv.bias is None and conv.padding_mode == "zeros"
+            and ops.conv3x3_train_served(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
+        return ops.conv3x3(x, conv.weight)
+    return conv(x)
+
+
 class BasicBlock(nn.Module):
     def __init__(self, cin, cout, stride):
         super().__init__()
@@ -95,9 +104,9 @@ class BasicBlock(nn.Module):
         if isinstance(self.conv1, FusedConv):              # inference build: conv -> one fused epilogue pass
             skip = x if self.down is None else self.down(x)
             return self.conv2(self.conv1(x), skip.contiguous(memory_format=torch.channels_last) if skip.is_cuda else skip)
-        y = _bn_act(self.bn1, self.conv1(x), True)
+        y = _bn_act(self.bn1, _conv(self.conv1, x), True)
         skip = x if self.down is None else _bn_act(self.down[1], self.down[0](x), False)
-        return _bn_act(self.bn2, self.conv2(y), True, skip)
+        return _bn_act(self.bn2, _conv(self.conv2, y), True, skip)
 
 
 class Encoder(nn.Module):
@@ -153,7 +162,7 @@ class UpBlock(nn.Module):
         else:
             x = torch.cat([F.interpolate(x, size=skip.shape[-2:], mode="bilinear", align_corners=False), skip], 1)
         if len(c) == 6 and isinstance(c[1], nn.BatchNorm2d):                    # training build
-            return _bn_act(c[4], c[3](_bn_act(c[1], c[0](x), True)), True)
+            return _bn_act(c[4], _conv(c[3], _bn_act(c[1], _conv(c[0], x), True)), True)
         return c(x)
 
 

@@ -59,6 +59,7 @@ SIGNATURES = {
     "gdkvm_conv_bias_act": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
     "gdkvm_conv3x3_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "gdkvm_conv_cat_bias_act": (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
+    "gdkvm_conv3x3_pack_weights_dgrad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "gdkvm_upsample_cat": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_upsample_cat_bwd": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_bias_relu_maxpool": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
@@ -686,6 +687,76 @@ def conv3x3_pack_weights(weight: torch.Tensor) -> torch.Tensor:
         rc = lib.gdkvm_conv3x3_pack_weights(weight.data_ptr(), packed.data_ptr(), k, c, BF16, _stream(weight.device))
     _check(rc, "gdkvm_conv3x3_pack_weights")
     return packed
+
+
+def _conv3x3_packed(x: torch.Tensor, packed: torch.Tensor, k_out: int, bias: torch.Tensor) -> torch.Tensor:
+    """conv3x3 / stride 1 / pad 1 of channels_last bf16 x with weights given ONLY as a pack (no epilogue beyond the bias)."""
+    n, c, hh, ww = x.shape
+    y = torch.empty((n, k_out, hh, ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = load().gdkvm_conv_bias_act(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), None, y.data_ptr(), n, c, hh, ww, k_out, 3, 3, 1, 1,
+                                        0, CONV_PACKED_WEIGHTS, BF16, _stream(x.device))
+    _check(rc, "gdkvm_conv_bias_act")
+    return y
+
+
+_ZERO_BIAS = {}
+
+
+def _zero_bias(k: int, device) -> torch.Tensor:
+    key = (k, str(device))
+    if key not in _ZERO_BIAS:
+        _ZERO_BIAS[key] = torch.zeros(k, dtype=torch.float32, device=device)
+    return _ZERO_BIAS[key]
+
+
+class _Conv3x3Function(torch.autograd.Function):
+    """Training-mode 3x3 / stride 1 / pad 1 convolution (no bias) on the hand-written kernels: forward and the data gradient
+    (the same kernel on the flipped, transposed weights: gdkvm_conv3x3_pack_weights_dgrad); the weight gradient stays the
+    framework's.  bf16 activations (autocast), fp32 master weights."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        lib = load()
+        xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        k, c = wb.shape[:2]
+        packed = torch.empty(k * 9 * c, dtype=torch.bfloat16, device=xb.device)
+        with torch.cuda.device(xb.device):
+            _check(lib.gdkvm_conv3x3_pack_weights(wb.data_ptr(), packed.data_ptr(), k, c, BF16, _stream(xb.device)), "gdkvm_conv3x3_pack_weights")
+        ctx.save_for_backward(xb, wb)
+        ctx.wdtype, ctx.xdtype = weight.dtype, x.dtype
+        return _conv3x3_packed(xb, packed, k, _zero_bias(k, xb.device))
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, wb = ctx.saved_tensors
+        k, c = wb.shape[:2]
+        dyb = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            packed = torch.empty(k * 9 * c, dtype=torch.bfloat16, device=dyb.device)
+            with torch.cuda.device(dyb.device):
+                _check(load().gdkvm_conv3x3_pack_weights_dgrad(wb.data_ptr(), packed.data_ptr(), k, c, BF16, _stream(dyb.device)),
+                       "gdkvm_conv3x3_pack_weights_dgrad")
+            dx = _conv3x3_packed(dyb, packed, c, _zero_bias(c, dyb.device)).to(ctx.xdtype)
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(dyb, xb, wb, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
+            dw = dw.to(ctx.wdtype)
+        return dx, dw
+
+
+def conv3x3_train_served(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups) -> bool:
+    """Does conv3x3 (forward + data gradient on the hand-written kernels) serve this layer and input?"""
+    k, c = weight.shape[:2]
+    return (x.is_cuda and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
+            and tuple(dilation) == (1, 1) and groups == 1 and c % 64 == 0 and k % 64 == 0 and x.shape[-1] <= 64
+            and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)))
+
+
+def conv3x3(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """conv2d(x, weight, padding=1) for a 3x3 / stride-1 layer with channel counts in multiples of 64, differentiable, bf16."""
+    return _Conv3x3Function.apply(x, weight)
 
 
 def conv_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tensor] = None,

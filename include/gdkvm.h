@@ -240,6 +240,10 @@ int gdkvm_gate_logits(const void* p, const float* w_gate, const float* b_gate, c
  * [K, 3, 3, C] weights (same size) -- each 1 KiB weight fragment is then one contiguous read; same result bit for bit. */
 enum { GDKVM_CONV_PACKED_WEIGHTS = 32 };
 int gdkvm_conv3x3_pack_weights(const void* w, void* packed, int K, int C, int io_dtype, void* stream);
+/* The pack of the same layer's DATA-GRADIENT convolution, from the forward weights w [K, 3, 3, C]:  dx = conv3x3(dy, w'),
+ * w'[c][ty][tx][k] = w[k][2 - ty][2 - tx][c] -- K input channels (a multiple of 64), C output channels (of 16).  Use it as
+ * gdkvm_conv_bias_act(dy, packed, zero bias, NULL, dx, N, K, H, W, C, 3, 3, 1, 1, 0, kernel | GDKVM_CONV_PACKED_WEIGHTS, ...). */
+int gdkvm_conv3x3_pack_weights_dgrad(const void* w, void* packed, int K, int C, int io_dtype, void* stream);
 int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y,
                         int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, int kernel,
                         int io_dtype, void* stream);

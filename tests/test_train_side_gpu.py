@@ -237,6 +237,31 @@ def test_fused_objective_matches_the_torch_loss(hip, case, dtype):
     assert (za.grad.double().cpu() - zb.grad).abs().max() <= tol * zb.grad.abs().max().item()
 
 
+@pytest.mark.parametrize("case", [(6, 64, 64, 28, 28), (3, 128, 128, 14, 14), (5, 256, 256, 7, 7), (2, 384, 128, 14, 14), (2, 192, 64, 28, 28),
+                                  (3, 64, 192, 9, 13), (1, 128, 64, 64, 64)])
+def test_training_convolution_forward_and_data_gradient(hip, case):
+    """ops.conv3x3 (hand-written forward and data gradient, framework weight gradient) against conv2d autograd in fp64 on the
+    same bf16-rounded operands; the data gradient is the SAME kernel on the flipped, transposed weights."""
+    n, c, k, h, w = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(n, c, h, w, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wt = (torch.randn(k, c, 3, 3, device="cuda") / (9 * c) ** 0.5).requires_grad_(True)          # fp32 master weights
+    dy = torch.randn(n, k, h, w, device="cuda").bfloat16()
+    assert hip.conv3x3_train_served(x, wt, (1, 1), (1, 1), (1, 1), 1)
+    y = hip.conv3x3(x, wt)
+    y.backward(dy)
+    x64 = x.detach().double().requires_grad_(True)
+    w64 = wt.detach().bfloat16().double().requires_grad_(True)
+    y64 = F.conv2d(x64, w64, None, 1, 1)
+    y64.backward(dy.double())
+    tol = 2.0 ** -7
+    assert y.dtype == torch.bfloat16 and (y.double() - y64).abs().max() <= tol * max(1.0, y64.abs().max().item())
+    assert x.grad.dtype == torch.bfloat16 and (x.grad.double() - x64.grad).abs().max() <= tol * max(1.0, x64.grad.abs().max().item())
+    assert wt.grad.dtype == torch.float32 and (wt.grad.double() - w64.grad).abs().max() <= 2 * tol * max(1.0, w64.grad.abs().max().item())
+    assert not hip.conv3x3_train_served(x, wt[:, :, :1, :1], (1, 1), (0, 0), (1, 1), 1)
+    assert not hip.conv3x3_train_served(x, wt, (2, 2), (1, 1), (1, 1), 1)
+
+
 def test_fused_objective_ignores_unlabelled_pixels(hip):
     """Labels outside [0, C) (255 in uint8 annotation masks) carry no class: the cross-entropy averages over the labelled pixels
     only, as F.cross_entropy(ignore_index=...) does; the Dice sums see them as 'no class'.  The host-side loss agrees."""
