@@ -60,6 +60,8 @@ SIGNATURES = {
     "gdkvm_conv3x3_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "gdkvm_conv_cat_bias_act": (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
     "gdkvm_conv3x3_pack_weights_dgrad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "gdkvm_conv3x3_wgrad_workspace_bytes": (_sz, [_i] * 5),
+    "gdkvm_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _sz] + [_i] * 6 + [_vp]),
     "gdkvm_upsample_cat": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_upsample_cat_bwd": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_bias_relu_maxpool": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
@@ -711,9 +713,9 @@ def _zero_bias(k: int, device) -> torch.Tensor:
 
 
 class _Conv3x3Function(torch.autograd.Function):
-    """Training-mode 3x3 / stride 1 / pad 1 convolution (no bias) on the hand-written kernels: forward and the data gradient
-    (the same kernel on the flipped, transposed weights: gdkvm_conv3x3_pack_weights_dgrad); the weight gradient stays the
-    framework's.  bf16 activations (autocast), fp32 master weights."""
+    """Training-mode 3x3 / stride 1 / pad 1 convolution (no bias) on the hand-written kernels: forward, the data gradient (the
+    same kernel on the flipped, transposed weights: gdkvm_conv3x3_pack_weights_dgrad) and the weight gradient
+    (gdkvm_conv3x3_wgrad).  bf16 activations (autocast), fp32 master weights."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -741,9 +743,39 @@ class _Conv3x3Function(torch.autograd.Function):
                        "gdkvm_conv3x3_pack_weights_dgrad")
             dx = _conv3x3_packed(dyb, packed, c, _zero_bias(c, dyb.device)).to(ctx.xdtype)
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(dyb, xb, wb, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1]
-            dw = dw.to(ctx.wdtype)
+            if os.environ.get("GDKVM_CONV_WGRAD") == "framework":          # (A/B switch for tools: the framework's weight gradient)
+                dw = torch.ops.aten.convolution_backward(dyb, xb, wb, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1].to(ctx.wdtype)
+            else:
+                dw = conv3x3_wgrad(xb, dyb).to(ctx.wdtype)  # (fp32 sums over all pixels, deterministic)
         return dx, dw
+
+
+_WGRAD_WS = {}
+
+
+def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """dW [K,C,3,3] fp32 of a 3x3 / stride 1 / pad 1 convolution from channels_last bf16 x [N,C,H,W] and dy [N,K,H,W]
+    (gdkvm_conv3x3_wgrad): C, K multiples of 64, rows of at most 64 pixels; deterministic."""
+    lib = load()
+    for t in (x, dy):
+        if t.dim() != 4 or not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous(memory_format=torch.channels_last):
+            raise GdkvmError("conv3x3_wgrad needs channels_last bf16 [N,C,H,W] device tensors (no CPU path)")
+    n, c, hh, ww = x.shape
+    k = dy.shape[1]
+    if tuple(dy.shape) != (n, k, hh, ww):
+        raise GdkvmError("conv3x3_wgrad: x and dy must agree in batch and size")
+    dw = torch.empty((k, c, 3, 3), dtype=torch.float32, device=x.device)
+    # one workspace per device and stream, grown to the largest layer (up to 75 MB of partial blocks): calls on a stream are
+    # ordered, so the next layer's gradient may overwrite it
+    need = max(16, int(lib.gdkvm_conv3x3_wgrad_workspace_bytes(n, c, hh, ww, k)))
+    key = (x.device, _stream(x.device))
+    ws = _WGRAD_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _WGRAD_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.gdkvm_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), n, c, hh, ww, k, BF16, _stream(x.device))
+    _check(rc, "gdkvm_conv3x3_wgrad")
+    return dw
 
 
 def conv3x3_train_served(x: torch.Tensor, weight: torch.Tensor, stride, padding, dilation, groups) -> bool:

@@ -244,6 +244,12 @@ int gdkvm_conv3x3_pack_weights(const void* w, void* packed, int K, int C, int io
  * w'[c][ty][tx][k] = w[k][2 - ty][2 - tx][c] -- K input channels (a multiple of 64), C output channels (of 16).  Use it as
  * gdkvm_conv_bias_act(dy, packed, zero bias, NULL, dx, N, K, H, W, C, 3, 3, 1, 1, 0, kernel | GDKVM_CONV_PACKED_WEIGHTS, ...). */
 int gdkvm_conv3x3_pack_weights_dgrad(const void* w, void* packed, int K, int C, int io_dtype, void* stream);
+/* Weight gradient of the same layers (training):  dw [K, C, 3, 3] fp32 = sum over pixels dy[n,y,x,k] * x[n,y+ty-1,x+tx-1,c]  for
+ * NHWC bf16 x [N,H,W,C] and dy [N,H,W,K]; C and K multiples of 64, rows of <= 64 pixels.  Deterministic (per-workgroup partial
+ * blocks in the workspace, added in a fixed order).  workspace: gdkvm_conv3x3_wgrad_workspace_bytes. */
+size_t gdkvm_conv3x3_wgrad_workspace_bytes(int N, int C, int H, int W, int K);
+int gdkvm_conv3x3_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
+                        int N, int C, int H, int W, int K, int io_dtype, void* stream);
 int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y,
                         int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, int kernel,
                         int io_dtype, void* stream);

@@ -262,6 +262,22 @@ def test_training_convolution_forward_and_data_gradient(hip, case):
     assert not hip.conv3x3_train_served(x, wt, (2, 2), (1, 1), (1, 1), 1)
 
 
+@pytest.mark.parametrize("case", [(6, 64, 64, 28, 28), (3, 128, 128, 14, 14), (9, 256, 256, 7, 7), (2, 384, 128, 14, 14), (2, 192, 64, 28, 28),
+                                  (3, 64, 192, 9, 13), (1, 128, 64, 64, 64), (5, 64, 64, 3, 2)])
+def test_convolution_weight_gradient(hip, case):
+    """gdkvm_conv3x3_wgrad == the weight gradient of conv2d(x, w, padding=1) in fp64 on the same bf16 operands; deterministic."""
+    n, c, k, h, w = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(n, c, h, w, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(n, k, h, w, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    dw = hip.conv3x3_wgrad(x, dy)
+    w64 = torch.zeros(k, c, 3, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w64, None, 1, 1).backward(dy.double())
+    assert dw.dtype == torch.float32 and dw.shape == w64.shape and dw.is_contiguous()
+    assert (dw.double() - w64.grad).abs().max() <= 1e-5 * (n * h * w) ** 0.5 * max(1.0, w64.grad.abs().max().item() / (n * h * w) ** 0.5)
+    assert torch.equal(dw, hip.conv3x3_wgrad(x, dy))
+
+
 def test_fused_objective_ignores_unlabelled_pixels(hip):
     """Labels outside [0, C) (255 in uint8 annotation masks) carry no class: the cross-entropy averages over the labelled pixels
     only, as F.cross_entropy(ignore_index=...) does; the Dice sums see them as 'no class'.  The host-side loss agrees."""
