@@ -12,6 +12,7 @@
 //   * every workgroup writes its partial block (fp32) to the workspace; a second kernel adds the partials in a fixed order
 //     (deterministic) into dW [K][C][3][3].
 #include <atomic>
+#include <type_traits>
 
 #include "gdkvm_common.hpp"
 
@@ -110,21 +111,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a)
                 for (int hf = 0; hf < 2; ++hf)
                     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=&v"(fb[t][hf]) : "v"(xa[hf] + (dyy * BW + dxx) * WG_PIX) : "memory");
             }
-            asm volatile("s_waitcnt lgkmcnt(0)"
+            // LDS returns in order: with the reads of taps 5 .. 8 (the last 8) still in flight everything before them has landed
+            asm volatile("s_waitcnt lgkmcnt(8)"
                          : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]),
                            "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]), "+v"(fb[3][0]), "+v"(fb[3][1]),
-                           "+v"(fb[4][0]), "+v"(fb[4][1]), "+v"(fb[5][0]), "+v"(fb[5][1]), "+v"(fb[6][0]), "+v"(fb[6][1]), "+v"(fb[7][0]), "+v"(fb[7][1]),
-                           "+v"(fb[8][0]), "+v"(fb[8][1])
+                           "+v"(fb[4][0]), "+v"(fb[4][1])
                          :: "memory");
             bf16x8 af[4];                                  // dy^T: A operand, output-channel tile kt (rows), 32 pixels (k)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) af[kt] = __builtin_bit_cast(bf16x8, make_uint4(fa[kt][0].x, fa[kt][0].y, fa[kt][1].x, fa[kt][1].y));
+            auto taps = [&](auto t0c, auto t1c) __attribute__((always_inline)) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const bf16x8 bf = __builtin_bit_cast(bf16x8, make_uint4(fb[t][0].x, fb[t][0].y, fb[t][1].x, fb[t][1].y));   // x^T window of tap t
+                for (int t = decltype(t0c)::value; t < decltype(t1c)::value; ++t) {
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, make_uint4(fb[t][0].x, fb[t][0].y, fb[t][1].x, fb[t][1].y));   // x^T window of tap t
 #pragma unroll
-                for (int kt = 0; kt < 4; ++kt) acc[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kt], bf, acc[kt][t], 0, 0, 0);
-            }
+                    for (int kt = 0; kt < 4; ++kt) acc[kt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kt], bf, acc[kt][t], 0, 0, 0);
+                }
+            };
+            taps(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fb[5][0]), "+v"(fb[5][1]), "+v"(fb[6][0]), "+v"(fb[6][1]), "+v"(fb[7][0]), "+v"(fb[7][1]), "+v"(fb[8][0]), "+v"(fb[8][1])
+                         :: "memory");
+            taps(std::integral_constant<int, 5>{}, std::integral_constant<int, 9>{});
         }
     }
     (void)s_dump;
