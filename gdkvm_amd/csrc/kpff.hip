@@ -25,6 +25,7 @@ struct KpffArgs {
     void* out;
     int Ck, Cv, Cp, h, w, rows_per_tile, tiles_per_frame;
     KpffSave sv;
+    int cols_per_tile, col_tiles;     // grids wider than 16 columns: a tile is a row band x a block of 16 columns
 };
 
 constexpr int KPFF_TM = 64;       // tokens per workgroup tile
@@ -37,11 +38,14 @@ __global__ __launch_bounds__(256) void kpff_kernel(KpffArgs a)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Ck = a.Ck, Cv = a.Cv, Cp = a.Cp, Cin = Cp + Ck + Cv, ld = Cin + KPFF_PAD;
-    const int f = blockIdx.x / a.tiles_per_frame, rt = blockIdx.x % a.tiles_per_frame;
-    const int N = a.h * a.w, W = a.w;
-    const int row0 = rt * a.rows_per_tile;
-    const int nrows = min(a.rows_per_tile, a.h - row0);
-    const int n0 = row0 * W, ntok = nrows * W;
+    const int f = blockIdx.x / a.tiles_per_frame, tf = blockIdx.x % a.tiles_per_frame;
+    const int rt = tf / a.col_tiles, ct = tf - rt * a.col_tiles;
+    const int N = a.h * a.w;
+    const int row0 = rt * a.rows_per_tile, col0 = ct * a.cols_per_tile;
+    const int nrows = min(a.rows_per_tile, a.h - row0), W = min(a.cols_per_tile, a.w - col0);      // W: the TILE's width
+    const int ntok = nrows * W;
+    // token tok of the tile (row-major inside the tile) -> token of the frame
+    auto gtok = [&](int tok) { const int ty = tok / W; return (row0 + ty) * a.w + col0 + (tok - ty * W); };
 
     // ---- stage [P ; L ; G] rows (4 channels per thread, 16-byte LDS stores) -------------------------
     {
@@ -50,7 +54,7 @@ __global__ __launch_bounds__(256) void kpff_kernel(KpffArgs a)
             const int tok = idx / q4, c = (idx - tok * q4) * 4;
             f32x4 x = {0.f, 0.f, 0.f, 0.f};
             if (tok < ntok) {
-                const size_t row = (size_t)f * N + n0 + tok;
+                const size_t row = (size_t)f * N + gtok(tok);
                 if (c < Cp) x = load4<IO>(a.P, row * Cp + c);
                 else if (c < Cp + Ck) x = load4<IO>(a.L, row * Ck + (c - Cp));
                 else x = load4<IO>(a.G, row * Cv + (c - Cp - Ck));
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void kpff_kernel(KpffArgs a)
     if (a.sv.gms) {                                            // training: keep the pooled feature for the backward
         for (int idx = tid; idx < ntok * Cv; idx += 256) {
             const int tok = idx / Cv, c = idx - tok * Cv;
-            store1<IO>(a.sv.gms, ((size_t)f * N + n0 + tok) * Cv + c, s_x[(size_t)tok * ld + Cp + Ck + c]);
+            store1<IO>(a.sv.gms, ((size_t)f * N + gtok(tok)) * Cv + c, s_x[(size_t)tok * ld + Cp + Ck + c]);
         }
     }
 
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(256) void kpff_kernel(KpffArgs a)
                     const float sl = 1.0f / (1.0f + expf(-(gl[mt][r] + bl)));
                     const float sg = 1.0f / (1.0f + expf(-(gg[mt][r] + bg)));
                     const float y = s_x[(size_t)tok * ld + o] + sl * lp[mt][r] + sg * gp[mt][r];
-                    const size_t grow = (size_t)f * N + n0 + tok;
+                    const size_t grow = (size_t)f * N + gtok(tok);
                     store1<IO>(a.out, grow * Cp + o, y);
                     if (a.sv.gates) {
                         store1<IO>(a.sv.gates, grow * 2 * Cp + o, sl);
@@ -162,6 +166,7 @@ struct KpffBf16Args {
     bf16_t* out;
     int Ck, Cv, Cp, h, w, rows_per_tile, tiles_per_frame;
     KpffSave sv;
+    int cols_per_tile, col_tiles;
 };
 
 constexpr int KPFF_PAD16 = 8;     // bf16 elements (16 B) of row padding
@@ -281,18 +286,22 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w_id = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Ck = a.Ck, Cv = a.Cv, Cp = a.Cp, Cin = Cp + Ck + Cv, ld = Cin + KPFF_PAD16;
-    const int N = a.h * a.w, W = a.w;
-    // sub-tile s of this workgroup = global tile NT*blockIdx.x + s  ->  (frame, row band)
-    int t_f[NT], t_n0[NT], t_ntok[NT], t_nrows[NT];
+    const int N = a.h * a.w;
+    // sub-tile s of this workgroup = global tile NT*blockIdx.x + s  ->  (frame, row band, block of 16 columns)
+    int t_f[NT], t_n0[NT], t_ntok[NT], t_nrows[NT], t_w[NT];
 #pragma unroll
     for (int sb = 0; sb < NT; ++sb) {
         const int tile = NT * blockIdx.x + sb;
         const bool valid = tile < total_tiles;
-        const int f = valid ? tile / a.tiles_per_frame : 0, rt = valid ? tile % a.tiles_per_frame : 0;
-        const int row0 = rt * a.rows_per_tile;
+        const int f = valid ? tile / a.tiles_per_frame : 0, tf = valid ? tile % a.tiles_per_frame : 0;
+        const int rt = tf / a.col_tiles, ct = tf - rt * a.col_tiles;
+        const int row0 = rt * a.rows_per_tile, col0 = ct * a.cols_per_tile;
         t_nrows[sb] = valid ? min(a.rows_per_tile, a.h - row0) : 0;
-        t_f[sb] = f; t_n0[sb] = row0 * W; t_ntok[sb] = t_nrows[sb] * W;
+        t_w[sb] = min(a.cols_per_tile, a.w - col0);                       // the tile's width
+        t_f[sb] = f; t_n0[sb] = row0 * a.w + col0; t_ntok[sb] = t_nrows[sb] * t_w[sb];
     }
+    // token tok of sub-tile sb (row-major inside the tile) -> token of the frame
+    auto gtok = [&](int sb, int tok) { const int ty = tok / t_w[sb]; return t_n0[sb] + ty * a.w + (tok - ty * t_w[sb]); };
 
     // ---- stage [P ; L ; G] rows as they are (8 channels = 16 bytes per thread, 4 loads in flight) -----------
     {
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
                 dst[u] = idx < total ? trow * ld + c : -1;
                 x[u] = make_uint4(0u, 0u, 0u, 0u);
                 if (idx < total && tok < t_ntok[sb < NT ? sb : 0]) {
-                    const size_t row = (size_t)t_f[sb] * N + t_n0[sb] + tok;
+                    const size_t row = (size_t)t_f[sb] * N + gtok(sb, tok);
                     const bf16_t* src = c < Cp ? a.P + row * Cp + c : (c < Cp + Ck ? a.L + row * Ck + (c - Cp) : a.G + row * Cv + (c - Cp - Ck));
                     x[u] = *reinterpret_cast<const uint4*>(src);
                 }
@@ -324,7 +333,7 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
     //      independent predicated LDS loads (a runtime-bounded loop serialises on the ~100-cycle LDS latency)
 #pragma unroll
     for (int sb = 0; sb < NT; ++sb) {
-        const int nrows = t_nrows[sb];
+        const int nrows = t_nrows[sb], W = t_w[sb];
         const int cw = (W + 3) / 4, chh = (nrows + 3) / 4, cv2 = Cv / 2;
         bf16_t* gx = s_xb + (size_t)sb * 64 * ld + Cp + Ck;
         for (int idx = tid; idx < cw * chh * cv2; idx += NTHR) {
@@ -366,7 +375,7 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
         for (int sb = 0; sb < NT; ++sb)
             for (int idx = tid; idx < t_ntok[sb] * Cv; idx += NTHR) {
                 const int tok = idx / Cv, c = idx - tok * Cv;
-                gms[((size_t)t_f[sb] * N + t_n0[sb] + tok) * Cv + c] = s_xb[(size_t)(sb * 64 + tok) * ld + Cp + Ck + c];
+                gms[((size_t)t_f[sb] * N + gtok(sb, tok)) * Cv + c] = s_xb[(size_t)(sb * 64 + tok) * ld + Cp + Ck + c];
             }
     }
 
@@ -418,7 +427,7 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
                     return make_uint2((unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16),
                                       (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16));
                 };
-                const size_t grow = (size_t)t_f[sb] * N + t_n0[sb] + tok;
+                const size_t grow = (size_t)t_f[sb] * N + gtok(sb, tok);
                 *reinterpret_cast<uint2*>(a.out + grow * Cp + oc) = pack4(y);
                 if (a.sv.gates) {
                     bf16_t* sg_ = static_cast<bf16_t*>(a.sv.gates);
@@ -580,7 +589,7 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
     if (BT < 0 || Ck <= 0 || Cv <= 0 || Cp <= 0 || h <= 0 || w <= 0)
         return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: bad shape BT=%d Ck=%d Cv=%d Cp=%d h=%d w=%d", BT, Ck, Cv, Cp, h, w);
     if (Ck % 16 || Cv % 16 || Cp % 16) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: channels must be multiples of 16");
-    if ((long)h * w > GDKVM_MAX_N || w > 64) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: grid %dx%d unsupported", h, w);
+    if ((long)h * w > GDKVM_MAX_N) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: grid %dx%d exceeds %d tokens", h, w, GDKVM_MAX_N);
     if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "kpff_fwd: io_dtype=%d", io_dtype);
     if (BT == 0) return GDKVM_OK;
     const void* ptrs[] = {local, global, pixel, wa, ba, wl, wg, out};
@@ -588,14 +597,14 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
         if (!p) return gdkvm_fail(GDKVM_ERR_ARG, "kpff_fwd: null pointer");
         if (!gdkvm_aligned16(p)) return gdkvm_fail(GDKVM_ERR_ARG, "kpff_fwd: pointer %p is not 16-byte aligned", p);
     }
-    // tile = whole frame if it fits 64 tokens, else the largest multiple of 4 grid rows that does
-    int rows;
+    // tile = whole frame if it fits 64 tokens, else the largest multiple of 4 grid rows that does; a grid wider than 16 columns is
+    // cut into 4-row x 16-column tiles (every 2x2 / 4x4 pooling cell stays inside one tile: both cuts are multiples of 4)
+    int rows, cols = w;
     if (h * w <= KPFF_TM) rows = h;
-    else {
-        rows = (KPFF_TM / w) & ~3;
-        if (rows < 4) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: grid width %d too large for a 4-row tile", w);
-    }
-    const int tiles = (h + rows - 1) / rows;
+    else if (w <= 16) rows = (KPFF_TM / w) & ~3;
+    else { rows = 4; cols = 16; }
+    const int col_tiles = (w + cols - 1) / cols;
+    const int tiles = ((h + rows - 1) / rows) * col_tiles;
     const int Cin = Cp + Ck + Cv;
     if (int rc = gdkvm_check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -617,7 +626,7 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
             GDKVM_LAUNCH_CHECK("kpff_pack_weights_kernel");
         }
         KpffBf16Args b{static_cast<const bf16_t*>(local), static_cast<const bf16_t*>(global), static_cast<const bf16_t*>(pixel),
-                       wab, ba, wab + na, wab + na + nl, static_cast<bf16_t*>(out), Ck, Cv, Cp, h, w, rows, tiles, sv};
+                       wab, ba, wab + na, wab + na + nl, static_cast<bf16_t*>(out), Ck, Cv, Cp, h, w, rows, tiles, sv, cols, col_tiles};
         const size_t lds = pair ? 2 * lds1 : lds1;
         const void* fn = pair ? reinterpret_cast<const void*>(kpff_bf16_kernel<2, KPFF_OT>) : reinterpret_cast<const void*>(kpff_bf16_kernel<1, 1>);
         if (lds > 64 * 1024) {
@@ -632,7 +641,7 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
 
     const size_t lds = (size_t)KPFF_TM * (Cin + KPFF_PAD) * sizeof(float);
     if (lds > 160 * 1024) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: Cp+Ck+Cv=%d exceeds the LDS tile", Cin);
-    KpffArgs a{local, global, pixel, wa, ba, wl, wg, out, Ck, Cv, Cp, h, w, rows, tiles, sv};
+    KpffArgs a{local, global, pixel, wa, ba, wl, wg, out, Ck, Cv, Cp, h, w, rows, tiles, sv, cols, col_tiles};
     const void* fn = io_dtype == GDKVM_F32 ? reinterpret_cast<const void*>(kpff_kernel<GDKVM_F32>)
                                            : reinterpret_cast<const void*>(kpff_kernel<GDKVM_BF16>);
     if (lds > 64 * 1024) {

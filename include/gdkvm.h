@@ -157,7 +157,7 @@ int gdkvm_gemm_tn(const void* a, const void* b, float* c, void* workspace, size_
  * bf16 MFMA with fp32 accumulation (weights and the pooled feature are rounded to bf16, i.e. bf16-autocast
  * accuracy); other bf16 shapes use the exact fp32 arm.  `workspace` (gdkvm_kpff_workspace_bytes) holds the bf16
  * copy of the weights, rebuilt on every call; it may be NULL for io_dtype f32.
- * Supported: Ck, Cv, Cp multiples of 16; h*w <= 256, w <= 16 when h*w > 64. */
+ * Supported: Ck, Cv, Cp multiples of 16; h*w <= 4096 (grids wider than 16 columns are processed as 4-row x 16-column tiles). */
 size_t gdkvm_kpff_workspace_bytes(int Ck, int Cv, int Cp, int io_dtype);
 int gdkvm_kpff_fwd(const void* local, const void* global, const void* pixel,
                    const float* wa, const float* ba, const float* wl, const float* wg, void* out,

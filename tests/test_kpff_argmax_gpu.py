@@ -18,7 +18,7 @@ def _dev(x, dtype=None):
 
 @pytest.mark.parametrize("case", [(3, 7, 7, 64, 256, 256), (2, 16, 16, 64, 256, 256), (2, 4, 4, 16, 32, 64),
                                   (1, 5, 3, 32, 16, 16), (2, 14, 14, 64, 64, 128), (1, 1, 1, 16, 16, 16),
-                                  (1, 6, 16, 16, 48, 80)])
+                                  (1, 6, 16, 16, 48, 80), (2, 8, 32, 16, 32, 48), (1, 5, 21, 16, 16, 32), (1, 32, 32, 16, 16, 16)])
 def test_kpff_fp32(hip, case):
     BT, h, w, Ck, Cv, Cp = case
     L, G, P, Wa, ba, Wl, Wg = make_kpff_inputs(BT, h, w, Ck, Cv, Cp, seed=sum(case))
@@ -27,7 +27,8 @@ def test_kpff_fp32(hip, case):
     assert np.abs(F - Fo).max() <= 1e-4
 
 
-@pytest.mark.parametrize("case", [(4, 7, 7, 64, 256, 256), (2, 16, 16, 64, 256, 256), (3, 4, 4, 32, 32, 64), (2, 14, 14, 64, 64, 128)])
+@pytest.mark.parametrize("case", [(4, 7, 7, 64, 256, 256), (2, 16, 16, 64, 256, 256), (3, 4, 4, 32, 32, 64), (2, 14, 14, 64, 64, 128),
+                                  (2, 8, 32, 32, 64, 64), (3, 6, 19, 32, 32, 64), (1, 32, 32, 64, 256, 256)])
 def test_kpff_bf16_mfma_arm(hip, case):
     """bf16 I/O, channels % 32 == 0 -> bf16 MFMA arm: weights and the pooled feature are rounded to bf16 (bf16
     autocast accuracy).  Checked against the oracle fed the same bf16-rounded inputs AND weights; what is left is

@@ -49,6 +49,22 @@ def test_module_fp32_matches_cpu_reference(hip):
     assert disagree.float().mean() <= 1e-3 and (margin[disagree] <= 1e-3).all()
 
 
+def test_module_fp32_on_a_grid_wider_than_16_tokens(hip):
+    """320x320 frames: a 20x20 token grid (400 tokens per frame: chunked scan, KPFF tiles of 4 rows x 16 columns)."""
+    ref, model = _pair(seed=3)
+    frames = torch.rand(1, 2, 3, 320, 320)
+    _balance(ref, model, frames)
+    with torch.no_grad():
+        lr, sr = ref(frames, return_state=True)
+        lg, sg = model(frames.cuda(), return_state=True)
+    lg = lg.cpu(); sg = sg.cpu()
+    assert (lg - lr).abs().max() <= 1e-3 and (sg - sr).abs().max() <= 1e-3
+    mr, mg = lr.argmax(2), lg.argmax(2)
+    margin = (lr[:, :, 0] - lr[:, :, 1]).abs()
+    disagree = (mr != mg)
+    assert disagree.float().mean() <= 1e-3 and (margin[disagree] <= 1e-3).all()
+
+
 def test_module_state_carry_and_mask0(hip):
     ref, model = _pair(seed=1)
     frames = torch.rand(1, 6, 3, 112, 112).cuda()
