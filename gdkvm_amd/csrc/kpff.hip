@@ -28,6 +28,15 @@ struct KpffArgs {
     int cols_per_tile, col_tiles;     // grids wider than 16 columns: a tile is a row band x a block of 16 columns
 };
 
+template <int I, int E, class F>
+__device__ __forceinline__ void kpff_static_for(F&& f)
+{
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        kpff_static_for<I + 1, E>(f);
+    }
+}
+
 constexpr int KPFF_TM = 64;       // tokens per workgroup tile
 constexpr int KPFF_PAD = 4;       // row padding in floats: stride % 64 == 4 -> 16 rows cover all 64 banks
 
@@ -109,25 +118,49 @@ __global__ __launch_bounds__(256) void kpff_kernel(KpffArgs a)
         const float* wag = a.wa + (size_t)(Cp + o) * Cin + 4 * g;
         const float* xa = s_x + (size_t)li * ld + 4 * g;
 
-        auto step = [&](int kb, const float* wmix, f32x4* mix) {
-            const f32x4 bl = *reinterpret_cast<const f32x4*>(wal + 16 * kb);
-            const f32x4 bg = *reinterpret_cast<const f32x4*>(wag + 16 * kb);
-            f32x4 bm = {0.f, 0.f, 0.f, 0.f};
-            if (wmix) bm = *reinterpret_cast<const f32x4*>(wmix);
+        // The weight fragments (16 bytes per lane and stream, row-major rows of Wa / Wl / Wg in L2) are fetched THREE k-blocks
+        // ahead into a ring of register sets with static indices: round 1 loaded them right in front of the MFMAs that use them,
+        // one exposed L2 round trip per k-block -- 36 of them per 64 output channels, most of the arm's 390 us.
+        auto run = [&](int kb0, int n, const float* wmix, f32x4* mix, auto hasmix) __attribute__((always_inline)) {
+            constexpr bool MIX = decltype(hasmix)::value;
+            constexpr int WD = 3;
+            if (n <= 0) return;
+            f32x4 rb[WD][3];
+            auto wl3 = [&](int j, f32x4 (&d)[3]) __attribute__((always_inline)) {
+                j = min(j, n - 1);
+                d[0] = *reinterpret_cast<const f32x4*>(wal + 16 * (kb0 + j));
+                d[1] = *reinterpret_cast<const f32x4*>(wag + 16 * (kb0 + j));
+                if constexpr (MIX) d[2] = *reinterpret_cast<const f32x4*>(wmix + 16 * j);
+            };
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const f32x4 av = *reinterpret_cast<const f32x4*>(xa + (size_t)mt * 16 * ld + 16 * kb);
+            for (int d = 0; d < WD; ++d) wl3(d, rb[d]);
+            // token fragments: one set, tile mt's fragment for the next k-block requested right behind the MFMAs that used this one's
+            f32x4 av[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    gl[mt] = mfma4(av[r], bl[r], gl[mt]);
-                    gg[mt] = mfma4(av[r], bg[r], gg[mt]);
-                    if (wmix) mix[mt] = mfma4(av[r], bm[r], mix[mt]);
+            for (int mt = 0; mt < 4; ++mt) av[mt] = *reinterpret_cast<const f32x4*>(xa + (size_t)mt * 16 * ld + 16 * kb0);
+            auto body = [&](int i, auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                const int kbn = kb0 + min(i + 1, n - 1);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gl[mt] = mfma4(av[mt][r], rb[j][0][r], gl[mt]);
+                        gg[mt] = mfma4(av[mt][r], rb[j][1][r], gg[mt]);
+                        if constexpr (MIX) mix[mt] = mfma4(av[mt][r], rb[j][2][r], mix[mt]);
+                    }
+                    av[mt] = *reinterpret_cast<const f32x4*>(xa + (size_t)mt * 16 * ld + 16 * kbn);
                 }
-            }
+                wl3(i + WD, rb[j]);
+            };
+            int i = 0;
+            for (; i + WD <= n; i += WD) kpff_static_for<0, WD>([&](auto jc) { body(i + decltype(jc)::value, jc); });
+            const int rem = n - i;
+            kpff_static_for<0, WD - 1>([&](auto jc) { if (decltype(jc)::value < rem) body(i + decltype(jc)::value, jc); });
         };
-        for (int kb = 0; kb < kbP; ++kb) step(kb, nullptr, nullptr);
-        for (int kb = 0; kb < kbL; ++kb) step(kbP + kb, a.wl + (size_t)o * Ck + 16 * kb + 4 * g, lp);
-        for (int kb = 0; kb < kbG; ++kb) step(kbP + kbL + kb, a.wg + (size_t)o * Cv + 16 * kb + 4 * g, gp);
+        run(0, kbP, nullptr, nullptr, std::false_type{});
+        run(kbP, kbL, a.wl + (size_t)o * Ck + 4 * g, lp, std::true_type{});
+        run(kbP + kbL, kbG, a.wg + (size_t)o * Cv + 4 * g, gp, std::true_type{});
 
         const float bl = a.ba[o], bg = a.ba[Cp + o];
 #pragma unroll
@@ -210,14 +243,6 @@ __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c)
 #define KPFF_WD_STEPS 4
 #endif
 constexpr int KPFF_WD = KPFF_WD_STEPS;               // ring depth = k-steps per unrolled trip
-template <int I, int E, class F>
-__device__ __forceinline__ void kpff_static_for(F&& f)
-{
-    if constexpr (I < E) {
-        f(std::integral_constant<int, I>{});
-        kpff_static_for<I + 1, E>(f);
-    }
-}
 
 template <int NS, int MT, int OT>
 __device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, int n, const bf16_t* w0, const bf16_t* w1, size_t ot_stride,
