@@ -6,13 +6,17 @@
 //   * a workgroup (8 waves) owns a tile of up to 208 output pixels -- a whole 14x14 frame, four 7x7 frames, or a 7-row band of a
 //     28x28 frame -- and 64 or 128 output channels;
 //   * the input is walked in chunks of 64 channels: the chunk's halo band ((rows + 2) x (W + 2) pixels per frame, 128 B of
-//     channels + 16 B of padding per pixel: a ds_read_b128 of 16 consecutive pixels is conflict-free and every operand
-//     address is base + immediate) is staged in LDS by LDS-DMA, double-buffered: chunk c+1 streams in while chunk c computes;
+//     channels + padding per pixel: a ds_read_b128 of 16 consecutive pixels is conflict-free and every operand
+//     address is base + immediate -- 128 B + 32 B in fact: CT_PIX = 160) is staged in LDS by LDS-DMA, double-buffered: chunk c+1
+//     streams in while chunk c computes; the input may be the channel concatenation of TWO tensors (x2 / C1), fetched in place;
 //     pixels outside the frame and the padding slots are fetched from a 16-byte zero constant;
 //   * the nine taps are nine SHIFTED READS of that image; the weights never touch LDS: a wave owns one or two 16-channel output
 //     tiles and streams their weight fragments (one 16-byte load each per k-step, three k-steps ahead, straight from L2) -- each
 //     is used for all the wave's pixel tiles (7 MFMAs per load);
-//   * weights are the A operand, so a lane ends with 4 consecutive output channels of one pixel (8-byte stores / residual loads).
+//     with weights packed in fragment order (gdkvm_conv3x3_pack_weights) such a load is one contiguous KiB;
+//   * weights are the A operand, so a lane ends with 4 consecutive output channels of one pixel -- 8 with the channel permutation
+//     ct_channel (16-byte stores / residual loads);
+//   * the same kernel computes the training-mode data gradient (weights packed flipped and transposed).
 // Arithmetic: fp32 accumulation over the same 9 C products as a library convolution, one rounding after the epilogue.
 #include <atomic>
 #include <type_traits>
