@@ -541,6 +541,68 @@ extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* p
                                  : launch_affine_any<GDKVM_BF16>(wide, false, false, sa, grid, st);
 }
 
+// gdr_stitch_kernel -- the sequential part of the time-segmented scan (row n3): with Phi_c and S_loc_c of every segment known,
+//     start_0 = S_in,   start_{c+1} = Phi_c start_c + S_loc_c,
+// one workgroup per (clip, head, 16-column slice), wave w owning row tile w; exact fp32 MFMA.  The four accumulator tiles are
+// exchanged through LDS as lane-linear images, which ARE the B operand under the k permutation "register r of lane (li, g) of
+// image m is k = 16m + 4g + r" (the same trick as the scan's exact read-out); double-buffered by segment parity: one barrier each.
+__global__ __launch_bounds__(256) void gdr_stitch_kernel(const float* phi, const float* s_loc, const float* s_in, float* starts, float* s_end,
+                                                          int S, int Hh, int Dv)
+{
+    __shared__ f32x4 s_img[2][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nsl = Dv / 16, sl = blockIdx.x % nsl, bh = blockIdx.x / nsl, b = bh / Hh, h = bh % Hh;
+    auto tile_ptr = [&](const float* base, size_t mat) { return base + mat * GDKVM_DK * Dv + (size_t)(16 * w + 4 * g) * Dv + 16 * sl + li; };
+    f32x4 cur = {0.f, 0.f, 0.f, 0.f};
+    if (s_in) {
+        const float* p = tile_ptr(s_in, (size_t)bh);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cur[r] = p[(size_t)r * Dv];
+    }
+    for (int c = 0; c < S; ++c) {
+        const size_t mat = ((size_t)b * S + c) * Hh + h;
+        float* st = const_cast<float*>(tile_ptr(starts, mat));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st[(size_t)r * Dv] = cur[r];
+        s_img[c & 1][w][lane] = cur;
+        const float* lp = tile_ptr(s_loc, mat);
+        f32x4 nxt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nxt[r] = lp[(size_t)r * Dv];
+        f32x4 pa[4];                                       // Phi_c[row 16w + li][16m + 4g .. +3]
+#pragma unroll
+        for (int m = 0; m < 4; ++m) pa[m] = *reinterpret_cast<const f32x4*>(phi + mat * GDKVM_DK * GDKVM_DK + (size_t)(16 * w + li) * GDKVM_DK + 16 * m + 4 * g);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const f32x4 bv = s_img[c & 1][m][lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nxt = mfma4(pa[m][r], bv[r], nxt);
+        }
+        cur = nxt;
+    }
+    if (s_end) {
+        float* p = const_cast<float*>(tile_ptr(s_end, (size_t)bh));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[(size_t)r * Dv] = cur[r];
+    }
+}
+
+extern "C" int gdkvm_scan_stitch(const float* phi, const float* s_loc, const float* s_in, float* starts, float* s_end,
+                                 int B, int S, int Hh, int Dk, int Dv, void* stream)
+{
+    if (B < 0 || S <= 0 || Hh <= 0 || Dv <= 0 || Dv % 16) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_stitch: B=%d S=%d Hh=%d Dv=%d", B, S, Hh, Dv);
+    if (Dk != GDKVM_DK) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_stitch: Dk=%d unsupported (kernels are built for Dk=%d)", Dk, GDKVM_DK);
+    if (B == 0) return GDKVM_OK;
+    if (int rc = check_ptrs("scan_stitch", {phi, s_loc, starts}, {s_in, s_end})) return rc;
+    if (int rc = gdkvm_check_device()) return rc;
+    hipLaunchKernelGGL(gdr_stitch_kernel, dim3((unsigned)(B * Hh * (Dv / 16))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       phi, s_loc, s_in, starts, s_end, S, Hh, Dv);
+    GDKVM_LAUNCH_CHECK("gdr_stitch_kernel");
+    return GDKVM_OK;
+}
+
 extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
                               const float* s_in, void* r_out, float* s_out, float* s_hist, void* workspace, size_t workspace_bytes,
                               int B, int T, int Hh, int N, int Dk, int Dv,

@@ -36,6 +36,7 @@ SIGNATURES = {
     "gdkvm_scan_prep": (_i, [_vp] * 5 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_apply": (_i, [_vp] * 7 + [_sz] + [_i] * 8 + [_vp]),
     "gdkvm_scan_transition": (_i, [_vp] * 4 + [_sz] + [_i] * 8 + [_vp]),
+    "gdkvm_scan_stitch": (_i, [_vp] * 5 + [_i] * 5 + [_vp]),
     "gdkvm_scan_bwd_workspace_bytes": (_sz, [_i] * 6),
     "gdkvm_scan_state_bwd": (_i, [_vp] * 6 + [_sz] + [_vp] * 8 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_bwd": (_i, [_vp] * 7 + [_sz] + [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
@@ -407,6 +408,22 @@ def scan_transition(q, alpha, workspace, Dv, flags=0):
     return phi
 
 
+def scan_stitch(phi: torch.Tensor, s_loc: torch.Tensor, state: Optional[torch.Tensor] = None):
+    """starts [B,S,Hh,Dk,Dv] and the end state of S consecutive segments from their transition matrices phi [B,S,Hh,Dk,Dk] and
+    zero-start end states s_loc [B,S,Hh,Dk,Dv] (gdkvm_scan_stitch): starts[:,0] = state, starts[:,c+1] = phi[:,c] starts[:,c] + s_loc[:,c]."""
+    B, S, Hh, Dk, Dv = s_loc.shape
+    if tuple(phi.shape) != (B, S, Hh, Dk, Dk) or phi.dtype != torch.float32 or s_loc.dtype != torch.float32:
+        raise GdkvmError("scan_stitch: phi [B,S,Hh,Dk,Dk] and s_loc [B,S,Hh,Dk,Dv] in float32")
+    dev = _dev(phi, s_loc, state)
+    phi, s_loc = phi.contiguous(), s_loc.contiguous()
+    starts = torch.empty_like(s_loc)
+    end = torch.empty((B, Hh, Dk, Dv), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = load().gdkvm_scan_stitch(phi.data_ptr(), s_loc.data_ptr(), _ptr(state), starts.data_ptr(), end.data_ptr(), B, S, Hh, Dk, Dv, _stream(dev))
+    _check(rc, "gdkvm_scan_stitch")
+    return starts, end
+
+
 def scan_fwd_segmented(q, k, v, alpha, beta, state=None, segments: int = 8, rule: int = RULE_DELTA_SEQUENTIAL, flags: int = 0):
     """Long-clip scan with the time axis cut into ``segments`` equal pieces that run concurrently (inside one
     GPU): per segment the transition matrix Phi_c and the zero-start end state S_loc_c, a tiny sequential stitch
@@ -426,12 +443,7 @@ def scan_fwd_segmented(q, k, v, alpha, beta, state=None, segments: int = 8, rule
     phi = scan_transition(qs, als, ws, Dv, flags=flags).reshape(B, segments, Hh, Dk, Dk)
     s_loc = torch.empty((BS, Hh, Dk, Dv), dtype=torch.float32, device=dev)
     scan_apply(qs, als, ws, Dv, flags=flags, state_out=s_loc, want_readout=False)
-    s_loc = s_loc.reshape(B, segments, Hh, Dk, Dv)
-    starts = torch.empty_like(s_loc)
-    cur = state if state is not None else torch.zeros((B, Hh, Dk, Dv), dtype=torch.float32, device=dev)
-    for c in range(segments):                                          # the stitch: segments-1 tiny [Dk,Dk]x[Dk,Dv] products
-        starts[:, c] = cur
-        cur = torch.matmul(phi[:, c], cur) + s_loc[:, c]
+    starts, _ = scan_stitch(phi, s_loc.reshape(B, segments, Hh, Dk, Dv), state)      # one kernel, sequential over the segments
     r, s_seg = scan_apply(qs, als, ws, Dv, state=starts.reshape(BS, Hh, Dk, Dv), flags=flags)
     return r.reshape(B, T, N, Hh, Dv), s_seg.reshape(B, segments, Hh, Dk, Dv)[:, -1].contiguous()
 

@@ -99,6 +99,13 @@ int gdkvm_scan_apply(const void* q, const float* alpha, const float* s_in, void*
  * in time -- can then be scanned independently and stitched with one small exchange. */
 int gdkvm_scan_transition(const void* q, const float* alpha, float* phi_out, const void* workspace, size_t workspace_bytes,
                           int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int flags, void* stream);
+/* Row n3, the sequential stitch of a time-segmented scan: phi [B,S,Hh,Dk,Dk] and s_loc [B,S,Hh,Dk,Dv] are the transition matrix
+ * and the zero-start end state of each of S consecutive segments (gdkvm_scan_transition / gdkvm_scan_apply on the clip viewed as
+ * B*S clips of T/S frames); starts [B,S,Hh,Dk,Dv] receives the state every segment really starts from,
+ *   starts[:,0] = s_in (zero if NULL),  starts[:,c+1] = phi[:,c] starts[:,c] + s_loc[:,c],
+ * and s_end (optional) the state after the last segment.  All fp32; exact fp32 arithmetic. */
+int gdkvm_scan_stitch(const float* phi, const float* s_loc, const float* s_in, float* starts, float* s_end,
+                      int B, int S, int Hh, int Dk, int Dv, void* stream);
 
 /* Row a7: backward of gdkvm_scan_fwd.  Inputs: the forward's inputs, its s_hist, its workspace exactly as the
  * forward left it, the gradients d_r [B,T,N,Hh,Dv] (io_dtype) and d_s_out [B,Hh,Dk,Dv] (fp32, may be NULL = 0).

@@ -147,3 +147,18 @@ def test_context_parallel_scan_single_rank_hip_backend(hip):
     R, S = hip.scan_fwd(*t, flags=3)
     R2, S2 = context_parallel_scan(*t, flags=3)
     assert torch.equal(R, R2) and torch.equal(S, S2)
+
+
+def test_segment_stitch_kernel(hip):
+    """gdkvm_scan_stitch: starts[c+1] = phi[c] starts[c] + s_loc[c] against fp64, with and without an initial state."""
+    torch.manual_seed(4)
+    B, S, Hh, Dv = 3, 9, 2, 48
+    phi = 0.3 * torch.randn(B, S, Hh, 64, 64, device="cuda")
+    s_loc = torch.randn(B, S, Hh, 64, Dv, device="cuda")
+    for s0 in (None, torch.randn(B, Hh, 64, Dv, device="cuda")):
+        starts, end = hip.scan_stitch(phi, s_loc, s0)
+        cur = torch.zeros(B, Hh, 64, Dv, device="cuda", dtype=torch.float64) if s0 is None else s0.double()
+        for c in range(S):
+            assert (starts[:, c].double() - cur).abs().max() <= 1e-4 * max(1.0, cur.abs().max().item())
+            cur = phi[:, c].double() @ cur + s_loc[:, c].double()
+        assert (end.double() - cur).abs().max() <= 1e-4 * max(1.0, cur.abs().max().item())
