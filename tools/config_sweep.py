@@ -49,6 +49,10 @@ def main():
             tk = ev_time(lambda: ops.kpff_fwd(L, r.reshape(B * T, N, Dv), P, wa, ba, wl, wg, h, w, out=f))
             gbs = alg / (tf * 1e-6) / 1e9
             print(f"{name:22s} {'bf16' if dt == torch.bfloat16 else 'f32':5s} {tp:9.1f} {ta:9.1f} {tf:9.1f} {alg / 1e6:8.1f} {gbs:8.1f} {gbs / 8000:7.4f} {tk:9.1f}")
+            if T >= 256:                        # long clips: the opt-in time-segmented scan (not bit-identical to chunked calls)
+                ts = ev_time(lambda: ops.scan_fwd_segmented(q, k, v, al, be, segments=16, flags=3), iters=5)
+                gs = alg / (ts * 1e-6) / 1e9
+                print(f"{name + ' /16 seg':22s} {'bf16' if dt == torch.bfloat16 else 'f32':5s} {'':>9s} {'':>9s} {ts:9.1f} {alg / 1e6:8.1f} {gs:8.1f} {gs / 8000:7.4f}")
 
 
 if __name__ == "__main__":
