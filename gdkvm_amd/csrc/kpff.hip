@@ -207,7 +207,8 @@ constexpr int KPFF_PAD16 = 8;     // bf16 elements (16 B) of row padding
 // Weights are re-packed to bf16 in MFMA-fragment order: for output tile ot (16 channels) and k-step ks (32 inputs) the
 // 64 lanes' B fragments (lane 16g+i = W[16ot+i][32ks+8g .. +7]) are contiguous, so a wave's B load is one 1 KiB access.
 // (Reading the row-major matrix directly makes each wave-instruction touch 16 rows x 64 B: measured 9 B/clk/CU.)
-__global__ void kpff_pack_weights_kernel(const float* wa, const float* wl, const float* wg, bf16_t* dst,
+// dst_lo (fp32 arm on splits, below): a second pack of the same layout with the bf16 remainders w - bf16(w).
+__global__ void kpff_pack_weights_kernel(const float* wa, const float* wl, const float* wg, bf16_t* dst, bf16_t* dst_lo,
                                          int Cp, int Ck, int Cv)
 {
     const int Cin = Cp + Ck + Cv;
@@ -220,7 +221,10 @@ __global__ void kpff_pack_weights_kernel(const float* wa, const float* wl, const
         const int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
         const size_t blk = e >> 9;                          // = ot * (K/32) + ks
         const int KS = K / 32, ks = (int)(blk % KS), ot = (int)(blk / KS);
-        dst[i] = f32_to_bf16(src[(size_t)(16 * ot + (lane & 15)) * K + 32 * ks + 8 * (lane >> 4) + j]);
+        const float v = src[(size_t)(16 * ot + (lane & 15)) * K + 32 * ks + 8 * (lane >> 4) + j];
+        const bf16_t hi = f32_to_bf16(v);
+        dst[i] = hi;
+        if (dst_lo) dst_lo[i] = f32_to_bf16(v - bf16_to_f32(hi));
     }
 }
 
@@ -470,6 +474,221 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
 
 
 // ---------------------------------------------------------------------------------------------------------
+// fp32 arm on 16-bit splits: fp32 I/O, every operand carried as two bf16 terms x = x_h + x_l (x_h = bf16(x), x_l = bf16(x - x_h):
+// 16 significant bits, the full fp32 exponent range), every product as the three bf16 MFMAs x_h w_h + x_l w_h + x_h w_l with
+// fp32 accumulation -- the dropped x_l w_l and the two truncations leave a relative error of about 2^-16 per product (measured
+// against the fp64 oracle: see tests), at 3/16 of the exact arm's MFMA time (v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate).
+// One workgroup of 8 waves owns one 64-token tile; LDS holds the tile's two bf16 images ([64][Cin + 8] each: 146 KB at
+// Cin = 576), the pooled feature is produced straight from global memory in fp32 (one thread per 4x4 cell and channel pair, 16
+// independent loads) and split afterwards, the residual P and the outputs stay fp32 end to end.
+struct KpffSplitArgs {
+    const float* L; const float* G; const float* P;
+    const bf16_t* wpack; size_t lo_off;        // fragment-order packs (kpff_pack_weights_kernel): high terms, low terms lo_off elements on
+    const float* ba;
+    float* out;
+    int Ck, Cv, Cp, h, w, rows_per_tile, tiles_per_frame;
+    KpffSave sv;
+    int cols_per_tile, col_tiles;
+};
+
+__device__ __forceinline__ void kpff_split2(float v, bf16_t& hi, bf16_t& lo)
+{
+    hi = f32_to_bf16(v);
+    lo = f32_to_bf16(v - bf16_to_f32(hi));
+}
+
+// `n` k-steps of NS weight streams (each a high and a low pack) against the MT token tiles of the two LDS images; ring of WD
+// register sets with static indices as in kpff_stream.
+template <int NS, int MT>
+__device__ __forceinline__ void kpff_stream_split(const bf16_t* xh, const bf16_t* xl, int ld, int ks0, int n,
+                                                  const bf16_t* w0, const bf16_t* w1, size_t lo_off,
+                                                  f32x4 (&acc0)[MT], f32x4 (&acc1)[MT])
+{
+    if (n <= 0) return;
+    constexpr int WD = 3;
+    bf16x8 bh0[WD], bl0[WD], bh1[WD], bl1[WD];
+    auto wload = [&](int slot_ks, bf16x8& h0, bf16x8& l0, bf16x8& h1, bf16x8& l1) __attribute__((always_inline)) {
+        const size_t off = (size_t)min(slot_ks, n - 1) * 512;
+        h0 = *reinterpret_cast<const bf16x8*>(w0 + off);
+        l0 = *reinterpret_cast<const bf16x8*>(w0 + lo_off + off);
+        if constexpr (NS == 2) {
+            h1 = *reinterpret_cast<const bf16x8*>(w1 + off);
+            l1 = *reinterpret_cast<const bf16x8*>(w1 + lo_off + off);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < WD; ++d) wload(d, bh0[d], bl0[d], bh1[d], bl1[d]);
+    bf16x8 ah[MT], al[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        ah[mt] = *reinterpret_cast<const bf16x8*>(xh + (size_t)mt * 16 * ld + 32 * ks0);
+        al[mt] = *reinterpret_cast<const bf16x8*>(xl + (size_t)mt * 16 * ld + 32 * ks0);
+    }
+    auto body = [&](int i, auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value % WD;
+        const int ksn = ks0 + min(i + 1, n - 1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            acc0[mt] = mfma_bf16(bh0[j], ah[mt], acc0[mt]);
+            if constexpr (NS == 2) acc1[mt] = mfma_bf16(bh1[j], ah[mt], acc1[mt]);
+            acc0[mt] = mfma_bf16(bl0[j], ah[mt], acc0[mt]);
+            if constexpr (NS == 2) acc1[mt] = mfma_bf16(bl1[j], ah[mt], acc1[mt]);
+            acc0[mt] = mfma_bf16(bh0[j], al[mt], acc0[mt]);
+            if constexpr (NS == 2) acc1[mt] = mfma_bf16(bh1[j], al[mt], acc1[mt]);
+            ah[mt] = *reinterpret_cast<const bf16x8*>(xh + (size_t)mt * 16 * ld + 32 * ksn);
+            al[mt] = *reinterpret_cast<const bf16x8*>(xl + (size_t)mt * 16 * ld + 32 * ksn);
+        }
+        wload(i + WD, bh0[j], bl0[j], bh1[j], bl1[j]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int i = 0;
+    for (; i + WD <= n; i += WD) kpff_static_for<0, WD>([&](auto jc) { body(i + decltype(jc)::value, jc); });
+    const int rem = n - i;
+    kpff_static_for<0, WD - 1>([&](auto jc) { if (decltype(jc)::value < rem) body(i + decltype(jc)::value, jc); });
+}
+
+__global__ __launch_bounds__(512) void kpff_split_kernel(KpffSplitArgs a)
+{
+    constexpr int NTHR = 512, MT = 4;
+    extern __shared__ __attribute__((aligned(16))) bf16_t s_sp[];     // [2][KPFF_TM][Cin + PAD16]: high image, low image
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Ck = a.Ck, Cv = a.Cv, Cp = a.Cp, Cin = Cp + Ck + Cv, ld = Cin + KPFF_PAD16;
+    bf16_t* s_hi = s_sp;
+    bf16_t* s_lo = s_sp + (size_t)KPFF_TM * ld;
+    const int N = a.h * a.w;
+    const int f = blockIdx.x / a.tiles_per_frame, tf = blockIdx.x - f * a.tiles_per_frame;
+    const int rt = tf / a.col_tiles, ct = tf - rt * a.col_tiles;
+    const int row0 = rt * a.rows_per_tile, col0 = ct * a.cols_per_tile;
+    const int nrows = min(a.rows_per_tile, a.h - row0), W = min(a.cols_per_tile, a.w - col0);
+    const int ntok = nrows * W, n0 = row0 * a.w + col0;
+    auto gtok = [&](int tok) { const int ty = tok / W; return n0 + ty * a.w + (tok - ty * W); };
+    const size_t frow = (size_t)f * N;
+
+    // ---- stage [P ; L]: 4 channels per thread (16-byte loads, 4 in flight), split, two 8-byte LDS stores ------------
+    {
+        const int cpl = Cp + Ck, q4 = cpl / 4, total = KPFF_TM * q4;
+        for (int base = tid; base < total; base += 4 * NTHR) {
+            f32x4 x[4];
+            int dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * NTHR;
+                const int tok = idx / q4, c = (idx - tok * q4) * 4;
+                dst[u] = idx < total ? tok * ld + c : -1;
+                x[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (idx < total && tok < ntok) {
+                    const size_t row = frow + gtok(tok);
+                    x[u] = *reinterpret_cast<const f32x4*>(c < Cp ? a.P + row * Cp + c : a.L + row * Ck + (c - Cp));
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (dst[u] >= 0) {
+                    bf16_t hi[4], lo[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) kpff_split2(x[u][r], hi[r], lo[r]);
+                    *reinterpret_cast<uint2*>(s_hi + dst[u]) = make_uint2((unsigned)hi[0] | ((unsigned)hi[1] << 16), (unsigned)hi[2] | ((unsigned)hi[3] << 16));
+                    *reinterpret_cast<uint2*>(s_lo + dst[u]) = make_uint2((unsigned)lo[0] | ((unsigned)lo[1] << 16), (unsigned)lo[2] | ((unsigned)lo[3] << 16));
+                }
+        }
+    }
+    // ---- multi-scale pooling of G from global memory in fp32: one thread per (4x4 cell, channel pair) -------------------
+    {
+        const int cw = (W + 3) / 4, chh = (nrows + 3) / 4, cv2 = Cv / 2;
+        float* gms = static_cast<float*>(a.sv.gms);
+        for (int idx = tid; idx < cw * chh * cv2; idx += NTHR) {
+            const int cell = idx / cv2, c = (idx - cell * cv2) * 2;
+            const int cy = cell / cw, y0 = cy * 4, x0 = (cell - cy * cw) * 4;
+            float2 u[16];
+            bool ok[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                const int y = y0 + (p >> 2), x = x0 + (p & 3);
+                ok[p] = y < nrows && x < W;
+                u[p] = ok[p] ? *reinterpret_cast<const float2*>(a.G + (frow + n0 + y * a.w + x) * Cv + c) : make_float2(0.f, 0.f);
+            }
+            float s2[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, s4[2] = {0.f, 0.f};
+            int n2[4] = {0, 0, 0, 0}, n4 = 0;
+            // (row-major sums inside the cell, as the oracle and the exact arm: the pooled feature is bit-identical to theirs)
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+                if (ok[p]) {
+                    const int q = ((p >> 3) << 1) | ((p >> 1) & 1);
+                    s2[q][0] += u[p].x; s2[q][1] += u[p].y; n2[q] += 1; s4[0] += u[p].x; s4[1] += u[p].y; n4 += 1;
+                }
+            const float m4[2] = {s4[0] / (float)n4, s4[1] / (float)n4};
+#pragma unroll
+            for (int p = 0; p < 16; ++p)
+                if (ok[p]) {
+                    const int q = ((p >> 3) << 1) | ((p >> 1) & 1);
+                    const float r0 = (u[p].x + s2[q][0] / (float)n2[q] + m4[0]) * (1.0f / 3.0f);
+                    const float r1 = (u[p].y + s2[q][1] / (float)n2[q] + m4[1]) * (1.0f / 3.0f);
+                    const int y = y0 + (p >> 2), x = x0 + (p & 3);
+                    bf16_t h0, l0, h1, l1;
+                    kpff_split2(r0, h0, l0);
+                    kpff_split2(r1, h1, l1);
+                    const int o = (y * W + x) * ld + Cp + Ck + c;
+                    *reinterpret_cast<unsigned*>(s_hi + o) = (unsigned)h0 | ((unsigned)h1 << 16);
+                    *reinterpret_cast<unsigned*>(s_lo + o) = (unsigned)l0 | ((unsigned)l1 << 16);
+                    if (gms) *reinterpret_cast<float2*>(gms + (frow + n0 + y * a.w + x) * Cv + c) = make_float2(r0, r1);
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- fused channel mixes: wave w owns output channels 16*(8*chunk + w) .. +15 for the 64 tokens -------------------
+    const int ksP = Cp / 32, ksL = Ck / 32, ksG = Cv / 32, KSa = Cin / 32;
+    const bf16_t* wa = a.wpack;
+    const bf16_t* wl = wa + (size_t)2 * Cp * Cin;
+    const bf16_t* wg = wl + (size_t)Cp * Ck;
+    const bf16_t* xh = s_hi + (size_t)li * ld + 8 * g;
+    const bf16_t* xl = s_lo + (size_t)li * ld + 8 * g;
+    for (int ob = 16 * w_id; ob < Cp; ob += 16 * (NTHR / 64)) {
+        f32x4 gl[MT], gg[MT], lp[MT], gp[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) gl[mt] = gg[mt] = lp[mt] = gp[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        kpff_stream_split<2, MT>(xh, xl, ld, 0, KSa, wa + ((size_t)(ob / 16) * KSa * 64 + lane) * 8,
+                                 wa + ((size_t)((Cp + ob) / 16) * KSa * 64 + lane) * 8, a.lo_off, gl, gg);
+        kpff_stream_split<1, MT>(xh, xl, ld, ksP, ksL, wl + ((size_t)(ob / 16) * ksL * 64 + lane) * 8, nullptr, a.lo_off, lp, lp);
+        kpff_stream_split<1, MT>(xh, xl, ld, ksP + ksL, ksG, wg + ((size_t)(ob / 16) * ksG * 64 + lane) * 8, nullptr, a.lo_off, gp, gp);
+        // epilogue: this lane holds channels oc..oc+3 of token 16mt+li
+        const int oc = ob + 4 * g;
+        const f32x4 bl4 = *reinterpret_cast<const f32x4*>(a.ba + oc), bg4 = *reinterpret_cast<const f32x4*>(a.ba + Cp + oc);
+        f32x4 pv[MT];
+        size_t grow[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int tok = 16 * mt + li;
+            grow[mt] = frow + gtok(min(tok, ntok - 1));
+            pv[mt] = *reinterpret_cast<const f32x4*>(a.P + grow[mt] * Cp + oc);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int tok = 16 * mt + li;
+            if (tok < ntok) {
+                f32x4 y, sl, sg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sl[r] = 1.0f / (1.0f + expf(-(gl[mt][r] + bl4[r])));
+                    sg[r] = 1.0f / (1.0f + expf(-(gg[mt][r] + bg4[r])));
+                    y[r] = pv[mt][r] + sl[r] * lp[mt][r] + sg[r] * gp[mt][r];
+                }
+                *reinterpret_cast<f32x4*>(a.out + grow[mt] * Cp + oc) = y;
+                if (a.sv.gates) {
+                    float* sgt = static_cast<float*>(a.sv.gates);
+                    *reinterpret_cast<f32x4*>(sgt + grow[mt] * 2 * Cp + oc) = sl;
+                    *reinterpret_cast<f32x4*>(sgt + grow[mt] * 2 * Cp + Cp + oc) = sg;
+                    *reinterpret_cast<f32x4*>(static_cast<float*>(a.sv.lp) + grow[mt] * Cp + oc) = lp[mt];
+                    *reinterpret_cast<f32x4*>(static_cast<float*>(a.sv.gp) + grow[mt] * Cp + oc) = gp[mt];
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
 // Backward (row a7) pieces that are not plain GEMMs.  With g = (g_l | g_g), Lp = L Wl^T, Gp = Gms Wg^T:
 //   pre :  dz = (dF * Lp * g_l (1-g_l) | dF * Gp * g_g (1-g_g)),  dLp = dF * g_l,  dGp = dF * g_g     (elementwise)
 //   ...    dX = dz Wa,  dL += dLp Wl,  dGms += dGp Wg,  dWa = dz^T [P;L;Gms], dWl = dLp^T L, dWg = dGp^T Gms   (library GEMMs)
@@ -596,8 +815,10 @@ __global__ __launch_bounds__(512) void proj_rows_kernel(ProjArgs a)
 
 extern "C" size_t gdkvm_kpff_workspace_bytes(int Ck, int Cv, int Cp, int io_dtype)
 {
-    if (io_dtype != GDKVM_BF16 || Ck <= 0 || Cv <= 0 || Cp <= 0) return 16;
-    return ((size_t)2 * Cp * (Cp + Ck + Cv) + (size_t)Cp * Ck + (size_t)Cp * Cv) * sizeof(bf16_t) + 16;
+    if ((io_dtype != GDKVM_BF16 && io_dtype != GDKVM_F32) || Ck <= 0 || Cv <= 0 || Cp <= 0) return 16;
+    const size_t pack = ((size_t)2 * Cp * (Cp + Ck + Cv) + (size_t)Cp * Ck + (size_t)Cp * Cv) * sizeof(bf16_t);
+    if (io_dtype == GDKVM_F32) return (Ck % 32 || Cv % 32 || Cp % 32) ? 16 : 2 * pack + 16;      // split arm: high and low packs
+    return pack + 16;
 }
 
 static thread_local int g_kpff_skip_pack = 0;            // set by gdkvm_kpff_fwd_packed around its call
@@ -647,7 +868,7 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
         bf16_t* wab = static_cast<bf16_t*>(workspace);
         const size_t na = (size_t)2 * Cp * Cin, nl = (size_t)Cp * Ck;
         if (!g_kpff_skip_pack) {
-            hipLaunchKernelGGL(kpff_pack_weights_kernel, dim3(256), dim3(256), 0, st, wa, wl, wg, wab, Cp, Ck, Cv);
+            hipLaunchKernelGGL(kpff_pack_weights_kernel, dim3(256), dim3(256), 0, st, wa, wl, wg, wab, static_cast<bf16_t*>(nullptr), Cp, Ck, Cv);
             GDKVM_LAUNCH_CHECK("kpff_pack_weights_kernel");
         }
         KpffBf16Args b{static_cast<const bf16_t*>(local), static_cast<const bf16_t*>(global), static_cast<const bf16_t*>(pixel),
@@ -661,6 +882,37 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
         if (pair) hipLaunchKernelGGL((kpff_bf16_kernel<2, KPFF_OT>), dim3((unsigned)((total_tiles + 1) / 2)), dim3(512 / KPFF_OT), lds, st, b, total_tiles);
         else hipLaunchKernelGGL((kpff_bf16_kernel<1, 1>), dim3((unsigned)total_tiles), dim3(256), lds, st, b, total_tiles);
         GDKVM_LAUNCH_CHECK("kpff_bf16_kernel");
+        return GDKVM_OK;
+    }
+
+    // fp32 I/O with 32-aligned channel counts and a workspace for the two packs: the arm on bf16 splits (without a workspace the
+    // exact fp32-MFMA arm below runs: that is also the way to ask for it)
+    const size_t lds_split = (size_t)2 * KPFF_TM * (Cin + KPFF_PAD16) * sizeof(bf16_t);
+    if (io_dtype == GDKVM_F32 && Ck % 32 == 0 && Cv % 32 == 0 && Cp % 32 == 0 && workspace && lds_split <= 160 * 1024) {
+        const size_t need = gdkvm_kpff_workspace_bytes(Ck, Cv, Cp, io_dtype) - 16;
+        if (!gdkvm_aligned16(workspace)) return gdkvm_fail(GDKVM_ERR_ARG, "kpff_fwd: workspace misaligned");
+        if (workspace_bytes < need) return gdkvm_fail(GDKVM_ERR_WORKSPACE, "kpff_fwd: workspace %zu < %zu bytes", workspace_bytes, need + 16);
+        bf16_t* wpk = static_cast<bf16_t*>(workspace);
+        const size_t lo_off = need / (2 * sizeof(bf16_t));
+        if (!g_kpff_skip_pack) {
+            hipLaunchKernelGGL(kpff_pack_weights_kernel, dim3(256), dim3(256), 0, st, wa, wl, wg, wpk, wpk + lo_off, Cp, Ck, Cv);
+            GDKVM_LAUNCH_CHECK("kpff_pack_weights_kernel");
+        }
+        {
+            static std::atomic<unsigned long long> done_mask{0};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "kpff_fwd: hipGetDevice");
+            const unsigned long long bit = 1ull << (dev & 63);
+            if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kpff_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "kpff_fwd: LDS attribute: %s", hipGetErrorString(e));
+                done_mask.fetch_or(bit, std::memory_order_relaxed);
+            }
+        }
+        KpffSplitArgs b{static_cast<const float*>(local), static_cast<const float*>(global), static_cast<const float*>(pixel), wpk, lo_off, ba,
+                        static_cast<float*>(out), Ck, Cv, Cp, h, w, rows, tiles, sv, cols, col_tiles};
+        hipLaunchKernelGGL(kpff_split_kernel, grid, dim3(512), lds_split, st, b);
+        GDKVM_LAUNCH_CHECK("kpff_split_kernel");
         return GDKVM_OK;
     }
 

@@ -472,9 +472,11 @@ def scan_apply(q, alpha, workspace, Dv, state=None, flags=0, out=None, state_out
 
 def kpff_fwd(local: torch.Tensor, glob: torch.Tensor, pixel: torch.Tensor, wa: torch.Tensor, ba: torch.Tensor,
              wl: torch.Tensor, wg: torch.Tensor, h: int, w: int, out: Optional[torch.Tensor] = None,
-             workspace: Optional[torch.Tensor] = None, packed: bool = False) -> torch.Tensor:
+             workspace: Optional[torch.Tensor] = None, packed: bool = False, exact: bool = False) -> torch.Tensor:
     """Key-Pixel Feature Fusion (gdkvm_kpff_fwd).  local [BT,N,Ck] glob [BT,N,Cv] pixel [BT,N,Cp], N=h*w;
-    wa [2Cp,Cp+Ck+Cv] ba [2Cp] wl [Cp,Ck] wg [Cp,Cv] float32.  Returns F [BT,N,Cp] in the io dtype."""
+    wa [2Cp,Cp+Ck+Cv] ba [2Cp] wl [Cp,Ck] wg [Cp,Cv] float32.  Returns F [BT,N,Cp] in the io dtype.
+    exact (float32 features only): no workspace is handed over, which selects the exact fp32-MFMA arm instead of the arm on
+    bf16 splits (include/gdkvm.h)."""
     lib = load()
     BT, N, Ck = local.shape
     Cv, Cp = glob.shape[-1], pixel.shape[-1]
@@ -491,12 +493,16 @@ def kpff_fwd(local: torch.Tensor, glob: torch.Tensor, pixel: torch.Tensor, wa: t
     dev = _dev(local, glob, pixel, wa, ba, wl, wg, out, workspace)
     io = _io_dtype(local)
     f = out if out is not None else torch.empty((BT, N, Cp), dtype=local.dtype, device=dev)
-    if workspace is None:
+    if exact:
+        if local.dtype != torch.float32 or workspace is not None or packed:
+            raise GdkvmError("kpff_fwd(exact=True) is the float32 arm without a workspace")
+    elif workspace is None:
         workspace = torch.empty(int(lib.gdkvm_kpff_workspace_bytes(Ck, Cv, Cp, io)), dtype=torch.uint8, device=dev)
     fn = lib.gdkvm_kpff_fwd_packed if packed else lib.gdkvm_kpff_fwd     # packed: `workspace` already holds these weights
     with torch.cuda.device(dev):
         rc = fn(_ptr(local), _ptr(glob), _ptr(pixel), _ptr(wa), _ptr(ba), _ptr(wl), _ptr(wg), _ptr(f),
-                workspace.data_ptr(), workspace.numel(), BT, Ck, Cv, Cp, h, w, io, _stream(dev))
+                workspace.data_ptr() if workspace is not None else None, workspace.numel() if workspace is not None else 0,
+                BT, Ck, Cv, Cp, h, w, io, _stream(dev))
     _check(rc, "gdkvm_kpff_fwd")
     return f
 

@@ -160,10 +160,13 @@ int gdkvm_gemm_tn(const void* a, const void* b, float* c, void* workspace, size_
  *   wa [2Cp, Cp+Ck+Cv]  ba [2Cp]  wl [Cp,Ck]  wg [Cp,Cv]                 (fp32)
  *   Gms = mean_{s in 1,2,4} cellmean_s(global);  g = sigmoid([P;L;Gms] wa^T + ba) = (g_l | g_g)
  *   out = P + g_l * (L wl^T) + g_g * (Gms wg^T)
- * Arithmetic: io_dtype f32 -> exact fp32 MFMA.  io_dtype bf16 with channel counts that are multiples of 32 ->
- * bf16 MFMA with fp32 accumulation (weights and the pooled feature are rounded to bf16, i.e. bf16-autocast
- * accuracy); other bf16 shapes use the exact fp32 arm.  `workspace` (gdkvm_kpff_workspace_bytes) holds the bf16
- * copy of the weights, rebuilt on every call; it may be NULL for io_dtype f32.
+ * Arithmetic: io_dtype f32 with channel counts that are multiples of 32 and a workspace -> operands as two bf16 terms
+ * (16 significant bits, the fp32 exponent range), three bf16 MFMAs per product, fp32 accumulation / pooling / residual /
+ * epilogue: about 2^-16 relative per product (3e-5 absolute against the fp64 oracle at unit-variance features).  io_dtype f32
+ * otherwise -- other channel counts, or workspace == NULL, which is how a caller asks for it -> exact fp32 MFMA (3x slower).
+ * io_dtype bf16 with channel counts that are multiples of 32 -> bf16 MFMA with fp32 accumulation (weights and the pooled
+ * feature are rounded to bf16, i.e. bf16-autocast accuracy); other bf16 shapes use the exact fp32 arm.  `workspace`
+ * (gdkvm_kpff_workspace_bytes) holds the bf16 copies of the weights (high and low terms for f32), rebuilt on every call.
  * Supported: Ck, Cv, Cp multiples of 16; h*w <= 4096 (grids wider than 16 columns are processed as 4-row x 16-column tiles). */
 size_t gdkvm_kpff_workspace_bytes(int Ck, int Cv, int Cp, int io_dtype);
 int gdkvm_kpff_fwd(const void* local, const void* global, const void* pixel,

@@ -25,6 +25,42 @@ def test_kpff_fp32(hip, case):
     F = hip.kpff_fwd(_dev(L), _dev(G), _dev(P), _dev(Wa), _dev(ba), _dev(Wl), _dev(Wg), h, w).cpu().numpy()
     Fo = c_oracle.kpff(L, G, P, Wa, ba, Wl, Wg, h, w)
     assert np.abs(F - Fo).max() <= 1e-4
+    # without a workspace: the exact fp32-MFMA arm (the default above is the arm on bf16 splits when all channel counts are
+    # multiples of 32, and this same kernel otherwise)
+    Fe = hip.kpff_fwd(_dev(L), _dev(G), _dev(P), _dev(Wa), _dev(ba), _dev(Wl), _dev(Wg), h, w, exact=True).cpu().numpy()
+    assert np.abs(Fe - Fo).max() <= 2e-5
+    if Ck % 32 or Cv % 32 or Cp % 32:
+        assert np.array_equal(F, Fe)
+
+
+@pytest.mark.parametrize("case", [(4, 7, 7, 64, 256, 256), (2, 16, 16, 64, 256, 256), (3, 4, 4, 32, 32, 64), (2, 8, 32, 32, 64, 64),
+                                  (3, 6, 19, 32, 32, 64), (1, 32, 32, 64, 256, 256), (5, 1, 1, 32, 32, 32)])
+def test_kpff_fp32_on_bf16_splits(hip, case):
+    """fp32 I/O, channels % 32 == 0, workspace given -> every product is x_h w_h + x_l w_h + x_h w_l on the bf16 MFMA (16
+    significant bits per operand), fp32 accumulation, fp32 pooling / residual / epilogue.  Against the fp64-accumulating
+    oracle: 3e-5 absolute at unit-variance features (the exact arm: 2e-5 of accumulation-order noise alone), inputs scaled by 2^20
+    and 2^-20 keep the same RELATIVE error (bf16 terms carry the whole fp32 exponent range), and weights that are exact in bf16
+    with bf16-exact features reproduce the exact arm to its accumulation order."""
+    BT, h, w, Ck, Cv, Cp = case
+    L, G, P, Wa, ba, Wl, Wg = make_kpff_inputs(BT, h, w, Ck, Cv, Cp, seed=sum(case) + 1)
+    run = lambda *t, **kw: hip.kpff_fwd(*(_dev(x) for x in t), h, w, **kw).cpu().numpy()
+    F = run(L, G, P, Wa, ba, Wl, Wg)
+    Fo = c_oracle.kpff(L, G, P, Wa, ba, Wl, Wg, h, w)
+    assert np.abs(F - Fo).max() <= 3e-5, np.abs(F - Fo).max()
+    # a cached pack (gdkvm_kpff_fwd_packed) computes the same bits
+    ws = torch.empty(int(hip.load().gdkvm_kpff_workspace_bytes(Ck, Cv, Cp, 0)), dtype=torch.uint8, device="cuda")
+    F1 = hip.kpff_fwd(*(_dev(x) for x in (L, G, P, Wa, ba, Wl, Wg)), h, w, workspace=ws).cpu().numpy()
+    F2 = hip.kpff_fwd(*(_dev(x) for x in (L, G, P, Wa, ba, Wl, Wg)), h, w, workspace=ws, packed=True).cpu().numpy()
+    assert np.array_equal(F, F1) and np.array_equal(F, F2)
+    # exponent range: the mixes scale with the features (gates saturate identically under the same pre-activations: scale
+    # the features up and the gate weights down by the same power of two)
+    for sc in (2.0 ** 20, 2.0 ** -20):
+        Fs = run(L * sc, G * sc, P * sc, Wa / sc, ba, Wl, Wg)
+        assert np.abs(Fs / sc - Fo).max() <= 3e-5
+    # operands with at most 8 significant bits: their low terms vanish
+    Lb, Gb, Pb, Wab, Wlb, Wgb = (O.to_bf16_f32(x) for x in (L, G, P, Wa, Wl, Wg))
+    Fb, Fbe = run(Lb, Gb, Pb, Wab, ba, Wlb, Wgb), run(Lb, Gb, Pb, Wab, ba, Wlb, Wgb, exact=True)
+    assert np.abs(Fb - Fbe).max() <= 2e-5                     # (the pooled feature is a mean: it keeps its low term)
 
 
 @pytest.mark.parametrize("case", [(4, 7, 7, 64, 256, 256), (2, 16, 16, 64, 256, 256), (3, 4, 4, 32, 32, 64), (2, 14, 14, 64, 64, 128),
