@@ -384,7 +384,7 @@ static int scan_bwd_impl(const void* q, const void* k, const void* v, const floa
     if (rule < 0 || rule > 2) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_bwd: rule=%d", rule);
     if (B == 0) return GDKVM_OK;
     if (T == 0 || N == 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_bwd: T and N must be positive");
-    if (N > 64) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_bwd: N=%d > 64 tokens per frame is not supported yet", N);
+    if (N > 64) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_bwd: N=%d > 64 tokens per frame: use gdkvm_scan_train_fwd / gdkvm_scan_train_bwd", N);
     if (int rc = check_ptrs("scan_bwd", {k, v, alpha, beta, s_hist, fwd_workspace, d_k, d_v, d_alpha, d_beta, bwd_workspace},
                             {q, d_r, d_q, d_hist, d_s_out, d_s_in})) return rc;
     if ((d_r != nullptr) != (d_q != nullptr) || (d_q && !q))

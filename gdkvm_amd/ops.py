@@ -40,6 +40,9 @@ SIGNATURES = {
     "gdkvm_scan_bwd_workspace_bytes": (_sz, [_i] * 6),
     "gdkvm_scan_state_bwd": (_i, [_vp] * 6 + [_sz] + [_vp] * 8 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_bwd": (_i, [_vp] * 7 + [_sz] + [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
+    "gdkvm_scan_train_workspace_bytes": (_sz, [_i] * 7),
+    "gdkvm_scan_train_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
+    "gdkvm_scan_train_bwd": (_i, [_vp] * 14 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_readout_fwd": (_i, [_vp] * 3 + [_i] * 9 + [_vp]),
     "gdkvm_readout_bwd": (_i, [_vp] * 5 + [_i] * 9 + [_vp]),
     "gdkvm_gemm_nt": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
@@ -279,35 +282,11 @@ def scan_state_bwd(k, v, alpha, beta, state_hist, workspace, d_hist=None, d_stat
     return dk, dv, da, db, ds
 
 
-class _StateScanFunction(torch.autograd.Function):
-    """The state recurrence alone, differentiable: (k, v, alpha, beta, S_0) -> (the state before every frame, S_T).  The forward
-    is gdkvm_scan_fwd without a read-out, the backward gdkvm_scan_state_bwd fed with the gradient of the state history."""
-
-    @staticmethod
-    def forward(ctx, k, v, alpha, beta, state, rule, flags):
-        B, T, N, Hh, Dk = k.shape
-        Dv = v.shape[-1]
-        ws = torch.empty(scan_workspace_bytes(B, T, Hh, N, Dk, Dv), dtype=torch.uint8, device=k.device)
-        hist = torch.empty((B, T, Hh, Dk, Dv), dtype=torch.float32, device=k.device)
-        _, s = scan_fwd(k, k, v, alpha, beta, state, rule=rule, flags=flags, workspace=ws, state_hist=hist, readout=False)
-        ctx.save_for_backward(k, v, alpha, beta, hist, ws)
-        ctx.rule, ctx.flags, ctx.has_state = rule, flags, state is not None
-        return hist, s
-
-    @staticmethod
-    def backward(ctx, d_hist, d_s):
-        k, v, alpha, beta, hist, ws = ctx.saved_tensors
-        d_hist = None if d_hist is None else d_hist.contiguous().float()
-        d_s = None if d_s is None else d_s.contiguous().float()
-        dk, dv, da, db, ds = scan_state_bwd(k, v, alpha, beta, hist, ws, d_hist, d_s, ctx.rule, ctx.flags,
-                                            need_d_state_in=ctx.has_state)
-        return dk, dv, da, db, ds, None, None
-
-
 class _ReadoutFunction(torch.autograd.Function):
     """The LKVA read-out of frames of more than 64 tokens from the saved state history (gdkvm_readout_fwd), differentiable:
     the backward (gdkvm_readout_bwd) returns d_q and the gradient with respect to the states the frames read, in the history's
-    own layout, which autograd hands on to _StateScanFunction.backward -> gdkvm_scan_state_bwd.  No framework op computes."""
+    own layout (what gdkvm_scan_state_bwd takes as d_hist).  gdkvm_scan_train_fwd / _bwd compose the same calls in C; this
+    autograd node exposes the read-out on its own."""
 
     @staticmethod
     def forward(ctx, q, hist, chunks, flags):
@@ -341,31 +320,51 @@ class _ReadoutFunction(torch.autograd.Function):
         return dq, d_hist, None, None
 
 
-_BIG_LOGIT = 1.0e30           # sigmoid(+-1e30) is exactly 1 / 0 in the kernels' formulas
+class _ScanTrainFunction(torch.autograd.Function):
+    """Differentiable scan for frames of any token count: gdkvm_scan_train_fwd / gdkvm_scan_train_bwd, with ONE workspace carrying
+    the state history, the WY factors and (N > 64) the frame re-cut into 64-token pseudo-frames from the forward to the backward
+    call.  No framework op between the HIP calls."""
 
+    @staticmethod
+    def forward(ctx, q, k, v, alpha, beta, state, rule, flags):
+        lib = load()
+        B, T, N, Hh, Dk = q.shape
+        Dv = v.shape[-1]
+        q, k, v, alpha, beta = (t.contiguous() for t in (q, k, v, alpha, beta))
+        dev = _dev(q, k, v, alpha, beta, state)
+        io = _io_dtype(q)
+        ws = torch.empty(int(lib.gdkvm_scan_train_workspace_bytes(B, T, Hh, N, Dk, Dv, io)), dtype=torch.uint8, device=dev)
+        r = torch.empty((B, T, N, Hh, Dv), dtype=q.dtype, device=dev)
+        s = torch.empty((B, Hh, Dk, Dv), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.gdkvm_scan_train_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(alpha), _ptr(beta), _ptr(state), _ptr(r), _ptr(s),
+                                          ws.data_ptr(), ws.numel(), B, T, Hh, N, Dk, Dv, io, rule, flags, _stream(dev))
+        _check(rc, "gdkvm_scan_train_fwd")
+        ctx.save_for_backward(q, k, v, alpha, beta, ws)
+        ctx.rule, ctx.flags, ctx.has_state = rule, flags, state is not None
+        return r, s
 
-def _scan_chunked(q, k, v, alpha, beta, state, rule, flags):
-    """Training path for frames of more than 64 tokens.  The tokens of a frame act on the state in order, so a frame is a
-    sequence of 64-token pseudo-frames: the first carries the frame's gate, the others gate 1, padding tokens beta = 0; the
-    state recurrence and its backward run on the 64-token kernels over T * chunks steps.  The read-out of ALL the frame's tokens
-    uses the state before the frame, i.e. before its first pseudo-frame: gdkvm_readout_fwd on the saved state history, whose
-    backward (gdkvm_readout_bwd) sends the state gradients into the reverse recurrence through gdkvm_scan_state_bwd's d_hist."""
-    if rule == RULE_DELTA_PARALLEL:
-        raise GdkvmError("training with rule delta_parallel is limited to 64 tokens per frame (its chunks combine additively)")
-    B, T, N, Hh, Dk = q.shape
-    Dv = v.shape[-1]
-    C = (N + 63) // 64
-    pad = 64 * C - N
-    logits = bool(flags & FLAG_GATE_LOGITS)
-    Fn = torch.nn.functional
-    k_p = Fn.pad(k, (0, 0, 0, 0, 0, pad)).reshape(B, T * C, 64, Hh, Dk)
-    v_p = Fn.pad(v, (0, 0, 0, 0, 0, pad)).reshape(B, T * C, 64, Hh, Dv)
-    beta_p = Fn.pad(beta, (0, 0, 0, pad), value=-_BIG_LOGIT if logits else 0.0).reshape(B, T * C, 64, Hh)
-    one = torch.full((B, T, C - 1, Hh), _BIG_LOGIT if logits else 1.0, dtype=alpha.dtype, device=alpha.device)
-    alpha_p = torch.cat([alpha.unsqueeze(2), one], 2).reshape(B, T * C, Hh)
-    hist, s_T = _StateScanFunction.apply(k_p.contiguous(), v_p.contiguous(), alpha_p.contiguous(), beta_p.contiguous(), state, rule, flags)
-    r = _ReadoutFunction.apply(q.contiguous(), hist, C, flags & FLAG_NORMALIZE_QK)   # every frame reads the state before its first chunk
-    return r, s_T
+    @staticmethod
+    def backward(ctx, d_r, d_s):
+        lib = load()
+        q, k, v, alpha, beta, ws = ctx.saved_tensors
+        B, T, N, Hh, Dk = q.shape
+        Dv = v.shape[-1]
+        dev = q.device
+        d_r = d_r.contiguous()
+        if d_r.dtype != q.dtype:
+            d_r = d_r.to(q.dtype)
+        d_s = None if d_s is None else d_s.contiguous().float()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        da = torch.empty((B, T, Hh), dtype=torch.float32, device=dev)
+        db = torch.empty((B, T, N, Hh), dtype=torch.float32, device=dev)
+        ds = torch.empty((B, Hh, Dk, Dv), dtype=torch.float32, device=dev) if ctx.has_state else None
+        with torch.cuda.device(dev):
+            rc = lib.gdkvm_scan_train_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(alpha), _ptr(beta), _ptr(d_r), _ptr(d_s), _ptr(dq), _ptr(dk),
+                                          _ptr(dv), _ptr(da), _ptr(db), _ptr(ds), ws.data_ptr(), ws.numel(), B, T, Hh, N, Dk, Dv,
+                                          _io_dtype(q), ctx.rule, ctx.flags, _stream(dev))
+        _check(rc, "gdkvm_scan_train_bwd")
+        return dq, dk, dv, da, db, ds, None, None
 
 
 def scan(q, k, v, alpha, beta, state=None, rule: int = RULE_DELTA_SEQUENTIAL, flags: int = 0):
@@ -375,7 +374,7 @@ def scan(q, k, v, alpha, beta, state=None, rule: int = RULE_DELTA_SEQUENTIAL, fl
         r, s = scan(qp, kp, v, alpha, beta, sp, rule, flags)
         return r, s[:, :, :q.shape[-1]]
     if q.shape[2] > 64:
-        return _scan_chunked(q, k, v, alpha, beta, state, rule, flags)
+        return _ScanTrainFunction.apply(q, k, v, alpha, beta, state, rule, flags)
     return _ScanFunction.apply(q, k, v, alpha, beta, state, rule, flags)
 
 

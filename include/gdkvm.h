@@ -111,7 +111,8 @@ int gdkvm_scan_stitch(const float* phi, const float* s_loc, const float* s_in, f
  * forward left it, the gradients d_r [B,T,N,Hh,Dv] (io_dtype) and d_s_out [B,Hh,Dk,Dv] (fp32, may be NULL = 0).
  * Outputs: d_q, d_k [B,T,N,Hh,Dk], d_v [B,T,N,Hh,Dv] (io_dtype), d_alpha [B,T,Hh], d_beta [B,T,N,Hh] (fp32; with
  * GDKVM_FLAG_GATE_LOGITS they are gradients w.r.t. the logits), d_s_in [B,Hh,Dk,Dv] (fp32, may be NULL).
- * bwd_workspace (gdkvm_scan_bwd_workspace_bytes) holds the per-frame state gradients.  Supported: N <= 64. */
+ * bwd_workspace (gdkvm_scan_bwd_workspace_bytes) holds the per-frame state gradients.  Supported: N <= 64 (any N: gdkvm_scan_train_fwd /
+ * gdkvm_scan_train_bwd below). */
 size_t gdkvm_scan_bwd_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv);
 int gdkvm_scan_bwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
                    const float* s_hist, const void* fwd_workspace, size_t fwd_workspace_bytes,
@@ -119,6 +120,24 @@ int gdkvm_scan_bwd(const void* q, const void* k, const void* v, const float* alp
                    void* d_q, void* d_k, void* d_v, float* d_alpha, float* d_beta, float* d_s_in,
                    void* bwd_workspace, size_t bwd_workspace_bytes,
                    int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream);
+
+/* Row a7 for frames of ANY token count in two calls.  gdkvm_scan_train_fwd is gdkvm_scan_fwd that keeps what the backward needs
+ * in ONE opaque workspace (gdkvm_scan_train_workspace_bytes: state history, WY factors, and for N > 64 the frame re-cut into
+ * ceil(N/64) pseudo-frames of 64 tokens -- the first with the frame's gate, the others with gate 1, padding tokens with beta = 0 --
+ * on which the state recurrence runs; the read-out of all N tokens uses the state before the frame).  gdkvm_scan_train_bwd takes
+ * the same inputs, that workspace untouched, d_r and d_s_out (may be NULL = 0), and returns the gradients of gdkvm_scan_bwd.
+ * N <= 64 is exactly gdkvm_scan_fwd (s_hist inside the workspace) + gdkvm_scan_bwd; N > 64 composes gdkvm_scan_fwd without a
+ * read-out, gdkvm_readout_fwd / _bwd and gdkvm_scan_state_bwd below.  GDKVM_RULE_DELTA_PARALLEL: N <= 64 only (its chunks
+ * combine additively, not in sequence).  Supported: Dk == 64, Dv % 16 == 0, 1 <= N <= 4096. */
+size_t gdkvm_scan_train_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype);
+int gdkvm_scan_train_fwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta, const float* s_in,
+                         void* r_out, float* s_out, void* train_workspace, size_t train_workspace_bytes,
+                         int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream);
+int gdkvm_scan_train_bwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
+                         const void* d_r, const float* d_s_out,
+                         void* d_q, void* d_k, void* d_v, float* d_alpha, float* d_beta, float* d_s_in,
+                         void* train_workspace, size_t train_workspace_bytes,
+                         int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream);
 
 /* Row a7 for frames of more than 64 tokens (and any caller that does its own read-out): the backward of the STATE recurrence
  * alone.  No q / d_r / d_q; instead d_hist [B,T,Hh,Dk,Dv] fp32 (may be NULL) is the gradient with respect to the state before

@@ -77,8 +77,9 @@ def test_scan_backward_randomized_sweep(hip):
 
 @pytest.mark.parametrize("case", [(2, 3, 100, 1, 32, 2, 3), (1, 2, 130, 2, 48, 2, 3), (1, 3, 256, 1, 64, 2, 0), (2, 2, 65, 1, 16, 0, 3)])
 def test_scan_backward_more_than_64_tokens(hip, case):
-    """Frames of more than 64 tokens train through 64-token pseudo-frames (ops._scan_chunked): gradients of the whole op --
-    incl. the read-out's path back into the state recurrence (gdkvm_scan_state_bwd's d_hist) -- against fp64 autograd."""
+    """Frames of more than 64 tokens train through 64-token pseudo-frames (gdkvm_scan_train_fwd / gdkvm_scan_train_bwd: two C calls
+    and one workspace, no framework op in between): gradients of the whole op -- incl. the read-out's path back into the state
+    recurrence (gdkvm_scan_state_bwd's d_hist) -- against fp64 autograd."""
     B, T, N, Hh, Dv, rule, flags = case
     q, k, v, a, b = make_scan_inputs(B, T, N, Hh, 64, Dv, seed=sum(case), normalized=not flags, logits=bool(flags), corr=0.5)
     rng = np.random.default_rng(47)
@@ -98,6 +99,37 @@ def test_scan_forward_values_through_the_chunked_training_path(hip):
     R0, S0 = hip.scan_fwd(*t, flags=3)
     R1, S1 = hip.scan(*(x.clone().requires_grad_() for x in t), None, 2, 3)
     assert torch.allclose(R1, R0, atol=2e-5) and torch.allclose(S1, S0, atol=2e-5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_train_entries_at_64_tokens_or_fewer_are_the_direct_pair(hip, dtype):
+    """N <= 64: gdkvm_scan_train_fwd / _bwd == gdkvm_scan_fwd (history inside the workspace) + gdkvm_scan_bwd, bit for bit; and the
+    limits that remain fail loudly (delta_parallel with more than 64 tokens; a workspace that is too small)."""
+    from gdkvm_amd import ops
+    q, k, v, a, b = make_scan_inputs(2, 4, 49, 1, 64, 32, seed=12, normalized=False, logits=True, corr=0.5)
+    dev = lambda x, dt=None: torch.from_numpy(x).cuda().to(dt or torch.float32)
+    mk = lambda: [dev(q, dtype).requires_grad_(), dev(k, dtype).requires_grad_(), dev(v, dtype).requires_grad_(), dev(a).requires_grad_(), dev(b).requires_grad_()]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    dR = torch.randn(2, 4, 49, 1, 32, device="cuda", generator=g).to(dtype)
+    outs = []
+    for fn in (ops._ScanFunction, ops._ScanTrainFunction):
+        t = mk()
+        R, S = fn.apply(*t, None, 2, 3)
+        (R.float() * dR.float()).sum().backward()
+        outs.append([R, S] + [x.grad for x in t])
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    big = make_scan_inputs(1, 2, 100, 1, 64, 16, seed=13, normalized=False, logits=True)
+    with pytest.raises(hip.GdkvmError, match="delta_parallel"):
+        ops._ScanTrainFunction.apply(*(dev(x) for x in big), None, 1, 3)
+    lib = hip.load()
+    need = int(lib.gdkvm_scan_train_workspace_bytes(1, 2, 1, 100, 64, 16, 0))
+    assert need > int(lib.gdkvm_scan_workspace_bytes(1, 2, 1, 100, 64, 16))
+    t = [dev(x) for x in big]
+    ws = torch.empty(need // 2, dtype=torch.uint8, device="cuda")
+    r = torch.empty(1, 2, 100, 1, 16, device="cuda")
+    rc = lib.gdkvm_scan_train_fwd(*(x.data_ptr() for x in t), None, r.data_ptr(), None, ws.data_ptr(), ws.numel(), 1, 2, 1, 100, 64, 16, 0, 2, 3, None)
+    assert rc == -5 and "workspace" in lib.gdkvm_last_error().decode()          # GDKVM_ERR_WORKSPACE
 
 
 def test_scan_backward_bf16_io(hip):
