@@ -40,6 +40,9 @@ SIGNATURES = {
     "gdkvm_scan_bwd_workspace_bytes": (_sz, [_i] * 6),
     "gdkvm_scan_state_bwd": (_i, [_vp] * 6 + [_sz] + [_vp] * 8 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_bwd": (_i, [_vp] * 7 + [_sz] + [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
+    "gdkvm_scan_segments": (_i, [_i] * 5),
+    "gdkvm_scan_segmented_workspace_bytes": (_sz, [_i] * 7),
+    "gdkvm_scan_fwd_segmented": (_i, [_vp] * 9 + [_sz] + [_i] * 10 + [_vp]),
     "gdkvm_scan_train_workspace_bytes": (_sz, [_i] * 7),
     "gdkvm_scan_train_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_train_bwd": (_i, [_vp] * 14 + [_sz] + [_i] * 9 + [_vp]),
@@ -423,28 +426,36 @@ def scan_stitch(phi: torch.Tensor, s_loc: torch.Tensor, state: Optional[torch.Te
     return starts, end
 
 
-def scan_fwd_segmented(q, k, v, alpha, beta, state=None, segments: int = 8, rule: int = RULE_DELTA_SEQUENTIAL, flags: int = 0):
-    """Long-clip scan with the time axis cut into ``segments`` equal pieces that run concurrently (inside one
-    GPU): per segment the transition matrix Phi_c and the zero-start end state S_loc_c, a tiny sequential stitch
-    S_start_{c+1} = Phi_c S_start_c + S_loc_c, then every segment is scanned from its true start state.  2.25x the
-    recurrence work on `segments`x the workgroups.  Equal to scan_fwd up to fp32 re-association (not bit-identical)."""
+def scan_fwd_segmented(q, k, v, alpha, beta, state=None, segments: int = 0, rule: int = RULE_DELTA_SEQUENTIAL, flags: int = 0,
+                       workspace: Optional[torch.Tensor] = None):
+    """Long-clip scan with the time axis cut into ``segments`` equal pieces that run concurrently (gdkvm_scan_fwd_segmented; SURVEY
+    §8f n3 inside one GPU): per segment the transition matrix Phi_c and the zero-start end state S_loc_c, a tiny sequential
+    stitch S_start_{c+1} = Phi_c S_start_c + S_loc_c, then every segment is scanned from its true start state.  2.25x the
+    recurrence work on `segments`x the workgroups.  ``segments`` = 0: chosen by shape (gdkvm_scan_segments; 1 = the serial scan).
+    Equal to scan_fwd up to fp32 re-association (not bit-identical)."""
+    lib = load()
     B, T, N, Hh, Dk = q.shape
     Dv = v.shape[-1]
-    if segments <= 1 or T % segments:
-        return scan_fwd(q, k, v, alpha, beta, state, rule=rule, flags=flags)
-    flags = recurrence_flags(rule, flags)
-    Ts, BS = T // segments, B * segments
-    seg = lambda x: x.reshape(BS, Ts, *x.shape[2:])                    # [B,T,...] -> [B*segments, T/segments, ...] (a view)
-    qs, ks, vs, als, bes = seg(q), seg(k), seg(v), seg(alpha), seg(beta)
-    dev = q.device
-    ws = torch.empty(scan_workspace_bytes(BS, Ts, Hh, N, Dk, Dv), dtype=torch.uint8, device=dev)
-    scan_prep(qs, ks, vs, bes, ws, rule=rule, flags=flags)
-    phi = scan_transition(qs, als, ws, Dv, flags=flags).reshape(B, segments, Hh, Dk, Dk)
-    s_loc = torch.empty((BS, Hh, Dk, Dv), dtype=torch.float32, device=dev)
-    scan_apply(qs, als, ws, Dv, flags=flags, state_out=s_loc, want_readout=False)
-    starts, _ = scan_stitch(phi, s_loc.reshape(B, segments, Hh, Dk, Dv), state)      # one kernel, sequential over the segments
-    r, s_seg = scan_apply(qs, als, ws, Dv, state=starts.reshape(BS, Hh, Dk, Dv), flags=flags)
-    return r.reshape(B, T, N, Hh, Dv), s_seg.reshape(B, segments, Hh, Dk, Dv)[:, -1].contiguous()
+    if segments < 0 or (segments and T % segments):
+        raise GdkvmError(f"segments={segments} must divide T={T}")
+    if k.shape != q.shape or tuple(v.shape[:4]) != (B, T, N, Hh) or tuple(alpha.shape) != (B, T, Hh) or tuple(beta.shape) != (B, T, N, Hh):
+        raise GdkvmError("bad scan shapes")
+    if k.dtype != q.dtype or v.dtype != q.dtype or alpha.dtype != torch.float32 or beta.dtype != torch.float32:
+        raise GdkvmError("q, k, v share one dtype; alpha / beta are float32")
+    if state is not None and (tuple(state.shape) != (B, Hh, Dk, Dv) or state.dtype != torch.float32):
+        raise GdkvmError("state must be float32 [B,Hh,Dk,Dv]")
+    dev = _dev(q, k, v, alpha, beta, state, workspace)
+    q, k, v, alpha, beta = (t.contiguous() for t in (q, k, v, alpha, beta))
+    with torch.cuda.device(dev):                           # (the choice by shape asks the current device for its CU count)
+        if workspace is None:
+            workspace = torch.empty(int(lib.gdkvm_scan_segmented_workspace_bytes(B, T, Hh, N, Dk, Dv, segments)), dtype=torch.uint8, device=dev)
+        r = torch.empty((B, T, N, Hh, Dv), dtype=q.dtype, device=dev)
+        s = torch.empty((B, Hh, Dk, Dv), dtype=torch.float32, device=dev)
+        rc = lib.gdkvm_scan_fwd_segmented(_ptr(q), _ptr(k), _ptr(v), _ptr(alpha), _ptr(beta), _ptr(state), _ptr(r), _ptr(s),
+                                          workspace.data_ptr(), workspace.numel(), B, T, Hh, N, Dk, Dv, segments, _io_dtype(q), rule,
+                                          flags, _stream(dev))
+    _check(rc, "gdkvm_scan_fwd_segmented")
+    return r, s
 
 
 def scan_apply(q, alpha, workspace, Dv, state=None, flags=0, out=None, state_out=None, want_readout=True):

@@ -107,6 +107,21 @@ int gdkvm_scan_transition(const void* q, const float* alpha, float* phi_out, con
 int gdkvm_scan_stitch(const float* phi, const float* s_loc, const float* s_in, float* starts, float* s_end,
                       int B, int S, int Hh, int Dk, int Dv, void* stream);
 
+/* Row n3 as one call: gdkvm_scan_fwd with the time axis cut into `segments` equal pieces that run concurrently (prep of the clip
+ * viewed as B*segments clips, gdkvm_scan_transition + a read-out-free gdkvm_scan_apply per segment, gdkvm_scan_stitch, then
+ * gdkvm_scan_apply from the true start states).  For long clips on few clips / heads / columns, where the serial recurrence leaves
+ * CUs idle: 2x512 frames, Dv = 256 (32 serial workgroups) 397 us with 16 segments against 516 us.  segments must divide T;
+ * segments == 0 chooses by shape (gdkvm_scan_segments returns the choice: a power of two >= 4, or 1 = plain gdkvm_scan_fwd).
+ * Equal to gdkvm_scan_fwd up to fp32 re-association through Phi -- NOT bit-identical, which is why gdkvm_scan_fwd, whose contract
+ * is bit-identity under chunked calls, never takes this path by itself.  No s_hist (inference).  workspace:
+ * gdkvm_scan_segmented_workspace_bytes with the same `segments` argument. */
+int gdkvm_scan_segments(int B, int T, int Hh, int Dv, int segments);
+size_t gdkvm_scan_segmented_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv, int segments);
+int gdkvm_scan_fwd_segmented(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
+                             const float* s_in, void* r_out, float* s_out, void* workspace, size_t workspace_bytes,
+                             int B, int T, int Hh, int N, int Dk, int Dv, int segments,
+                             int io_dtype, int rule, int flags, void* stream);
+
 /* Row a7: backward of gdkvm_scan_fwd.  Inputs: the forward's inputs, its s_hist, its workspace exactly as the
  * forward left it, the gradients d_r [B,T,N,Hh,Dv] (io_dtype) and d_s_out [B,Hh,Dk,Dv] (fp32, may be NULL = 0).
  * Outputs: d_q, d_k [B,T,N,Hh,Dk], d_v [B,T,N,Hh,Dv] (io_dtype), d_alpha [B,T,Hh], d_beta [B,T,N,Hh] (fp32; with

@@ -139,6 +139,37 @@ def test_segmented_scan_cfg5_shape_bf16(hip):
     assert ((R.float() - R2.float()).abs() <= 1e-4 + R.float().abs() * 2.0 ** -7).all()
 
 
+def test_segmented_scan_choice_by_shape(hip):
+    """segments = 0: gdkvm_scan_segments picks a power of two >= 4 for long clips on few workgroups and 1 (= gdkvm_scan_fwd, bit for
+    bit) when the serial grid keeps the device busy; every rule runs; a segment count that does not divide T fails loudly."""
+    lib = hip.load()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert lib.gdkvm_scan_segments(16, 32, 1, 256, 0) == 1                     # cfg2: 256 serial workgroups
+    assert lib.gdkvm_scan_segments(8, 20, 1, 256, 0) == 1                      # cfg3: T = 20 leaves no 4 segments of >= 8 frames
+    if cus == 256:
+        assert lib.gdkvm_scan_segments(2, 512, 1, 256, 0) == 16                # cfg5
+    assert lib.gdkvm_scan_segments(2, 512, 1, 256, 8) == 8
+    B, T, N, Hh, Dk, Dv = 1, 64, 49, 1, 64, 32
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=21, normalized=False, logits=True, corr=0.5)
+    t = [_dev(x) for x in (q, k, v, a, b)]
+    S = lib.gdkvm_scan_segments(B, T, Hh, Dv, 0)
+    assert S == 8                                                               # 2 serial workgroups -> segments of 8 frames
+    for rule in (0, 1, 2):
+        Ro, So = c_oracle.scan(q, k, v, a, b, None, rule, 3, math="f64")
+        R, Sg = hip.scan_fwd_segmented(*t, rule=rule, flags=3)
+        lim = 1e-4 * max(1.0, np.abs(Ro).max(), np.abs(So).max())     # (delta_parallel is not contractive: its values grow over 64 frames)
+        assert np.abs(R.cpu().numpy() - Ro).max() <= lim and np.abs(Sg.cpu().numpy() - So).max() <= lim, rule
+    wide = [_dev(x) for x in make_scan_inputs(16, 16, 49, 1, 64, 256, seed=22, normalized=False, logits=True)]
+    R1, S1 = hip.scan_fwd_segmented(*wide, flags=3)
+    R0, S0 = hip.scan_fwd(*wide, flags=3)
+    assert torch.equal(R1, R0) and torch.equal(S1, S0)
+    with pytest.raises(hip.GdkvmError):
+        hip.scan_fwd_segmented(*t, segments=5, flags=3)
+    ws = torch.empty(1024, dtype=torch.uint8, device="cuda")
+    with pytest.raises(hip.GdkvmError, match="workspace"):
+        hip.scan_fwd_segmented(*t, segments=8, flags=3, workspace=ws)
+
+
 def test_context_parallel_scan_single_rank_hip_backend(hip):
     """The cross-GPU stitch with the HIP backend and a world of one degenerates to a plain scan (bit for bit)."""
     from gdkvm_amd.distributed import context_parallel_scan
