@@ -16,6 +16,7 @@
 #include <initializer_list>
 #include <type_traits>
 
+#include <cstdlib>
 #include "gdkvm_common.hpp"
 #include "gdr_device.hpp"
 #include "gdr_ws.hpp"
@@ -377,23 +378,27 @@ struct PrepMArgs {
     float* qinv; float* pp; float* gg;
     float* x0; float* ppc; float* ggc;                  // frames of more than 64 tokens: chunk 0 -> x0, chunk c >= 1 -> ppc/ggc[c-1]
     int T, Hh, N, Dv, rule, flags, np_total;            // N = tokens of the frame, np_total = its padded count (qinv row length)
+    int nchunk;                                         // FUSE: 64-token chunks per frame, walked by ONE workgroup (else gridDim.y)
 #ifdef GDKVM_DIAG
     unsigned long long* diag;
 #endif
 };
 
 __host__ __device__ constexpr bool prepm_split(int NB, int IO) { return NB == 4 && IO == GDKVM_BF16; }
-__host__ __device__ constexpr size_t prepm_lds_bytes(int NB, int IO)
+__host__ __device__ constexpr size_t prepm_lds_bytes(int NB, int IO, bool fuse = false)
 {   // kinv beta qinv pad | negB pairs | Ld | TmT | kni [4][NB] | mt [4][NB]   (images of 64 x f32x4) | m3 [3][4][NB/2] (bf16 arm)
-    return (size_t)(4 * 16 * NB + (NB * (NB - 1) / 2 + 2 * NB + 8 * NB + (prepm_split(NB, IO) ? 3 * 4 * (NB / 2) : 0)) * 256) * sizeof(float);
+    // | fused chunk walk: wave 3's column tile (two term images)
+    return (size_t)(4 * 16 * NB + (NB * (NB - 1) / 2 + 2 * NB + 8 * NB + (prepm_split(NB, IO) ? 3 * 4 * (NB / 2) : 0)) * 256) * sizeof(float)
+           + (fuse ? 2 * SPLIT_IMG * 8 : 0);
 }
 
 
 
-template <int NB, int IO, int FMT>
+template <int NB, int IO, int FMT, bool FUSE = false>
 __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(1, 2))) void gdr_prepm_kernel(PrepMArgs a)
 {
     constexpr int NP = 16 * NB, NT = fmt_terms(FMT);
+    static_assert(!FUSE || (prepm_split(NB, IO) && FMT == FMT_PAIR16), "the fused chunk walk is built for bf16 I/O on pair16 operands");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_kinv = smem;
     float* s_beta = smem + NP;
@@ -423,7 +428,22 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
         }
     }
     const int h = fh % a.Hh;
-    const int Ntot = a.N, chunk = blockIdx.y, nchunk = gridDim.y, tok0 = chunk * NP;
+    const int Ntot = a.N, nchunk = FUSE ? a.nchunk : (int)gridDim.y;
+    // FUSE (frames of more than 64 tokens, many frames): this workgroup walks the frame's chunks itself and carries the frame's
+    // running map [P | G] <- P_c [P | G] + [0 | G_c] in accumulators -- wave w owns COLUMN tile w of P and column tiles w, w+4, ..
+    // of G (all four row tiles of each: X[m][j]), which is the layout the chunk's own P tiles and G tiles are born in, and a
+    // column's four row tiles are exactly the rows a B image of that column needs: the re-split never leaves the wave.  The chunk
+    // maps P_c, G_c (80 KB per chunk) are never written: gdr_compose_kernel re-read them from HBM (cfg5: 2 x 328 MB).
+    constexpr int XJ = FUSE ? 5 : 1;
+    f32x4 X[FUSE ? 4 : 1][XJ];
+    const int tid_k = tid;
+    for (int chunk = FUSE ? 0 : (int)blockIdx.y, chunk_end = FUSE ? nchunk : chunk + 1; chunk < chunk_end; ++chunk) {
+    // FUSE: the lane ids are re-derived per chunk from an opaque copy -- otherwise every lane-dependent address of the body is
+    // hoisted out of the chunk loop as an invariant and held (then spilled) across it: ~100 registers the running map needs
+    int tid_o = tid_k;
+    if constexpr (FUSE) asm volatile("" : "+v"(tid_o));
+    const int tid = tid_o, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int tok0 = chunk * NP;
     const size_t bt = (size_t)(fh / a.Hh) * Ntot + tok0;   // row of this chunk's first token; rows are addressed bt*1 + n below
     const int N = min(NP, Ntot - tok0), Hh = a.Hh, Dv = a.Dv, nsl = Dv / 16;
     const bool seq = a.rule == GDKVM_RULE_DELTA_SEQUENTIAL;
@@ -665,7 +685,14 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
     // chunk 0 of a chunked frame starts the composition as [P | G] accumulator tiles; under delta_parallel (every token sees
     // the frame's old state) the chunks combine additively, P = I - sum_c (I - P_c), so all of them are written as tiles
     const bool first_of_many = nchunk > 1 && chunk == 0;
-    const bool p_tiles = nchunk > 1 && (chunk == 0 || a.rule == GDKVM_RULE_DELTA_PARALLEL);
+    const bool p_tiles = nchunk > 1 && (chunk == 0 || (!FUSE && a.rule == GDKVM_RULE_DELTA_PARALLEL));
+    // FUSE: P_c of a later chunk goes to LDS as A images (over the M^T tiles, which every wave holds in registers by then), and
+    // each wave re-splits its columns of the running map through a private 4 KB tile (waves 0-2: over the Gram / T blocks, which
+    // phase 3 is done with; wave 3: 4 KB appended to the allocation)
+    uint2* s_pc = reinterpret_cast<uint2*>(s_mt);
+    uint2* s_wx = w < 3 ? reinterpret_cast<uint2*>(s_negB) + w * (NT * SPLIT_IMG) : s_m3 + 3 * 4 * KS * 128;
+    static_assert(!FUSE || 3 * NT * SPLIT_IMG * 8 <= (NB * (NB - 1) / 2 + 2 * NB) * 1024, "three wave tiles fit the Gram / T blocks");
+    if constexpr (FUSE) __syncthreads();                  // every wave has its M^T tiles in registers: their LDS is free
     uint2* pp = (chunk == 0 ? reinterpret_cast<uint2*>(a.pp) + (size_t)fh * (4 * 3 * SPLIT_IMG)
                             : reinterpret_cast<uint2*>(a.ppc) + ((size_t)fh * (nchunk - 1) + chunk - 1) * (4 * 3 * SPLIT_IMG));
     f32x4* x0 = reinterpret_cast<f32x4*>(a.x0) + (size_t)fh * (4 + nsl) * 4 * 64;
@@ -701,7 +728,8 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
             f32x4 o;
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = ((16 * m + 4 * g + r == 16 * w + li) ? 1.f : 0.f) - (b0[r] + b1[r]);
-            ptile[(w * 4 + m) * 64 + lane] = o;
+            if constexpr (FUSE) X[m][0] = o;
+            else ptile[(w * 4 + m) * 64 + lane] = o;
             continue;
         }
         // lane (g,li) reg r = P[16m + li][k = 16w + 4g + r]: four consecutive k of row li of row tile m -> its term images
@@ -712,9 +740,46 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
         OpFmt<FMT>::split4(pv, tt);
         const int e = split_slot(w, g, li);
 #pragma unroll
-        for (int sp = 0; sp < NT; ++sp) pp[(m * NT + sp) * SPLIT_IMG + e] = tt[sp];
+        for (int sp = 0; sp < NT; ++sp) {
+            if constexpr (FUSE) s_pc[(m * NT + sp) * SPLIT_IMG + e] = tt[sp];
+            else pp[(m * NT + sp) * SPLIT_IMG + e] = tt[sp];
+        }
     }
     DIAG_STAMP(5);
+    // FUSE, chunk c >= 1: column tile j of the running map as B images (this wave's private tile), then row tile m of
+    // P_c X[:, j] (+ the chunk's own G tile) -- gdr_compose_kernel's step, without leaving the workgroup
+    auto col_images = [&](auto jc, uint4 (&xb)[NT][2]) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value < XJ ? decltype(jc)::value : 0;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            uint2 tt[3];
+            OpFmt<FMT>::split4(X[FUSE ? m : 0][j] * OpFmt<FMT>::STATE, tt);
+            const int e = split_slot(m, g, li);
+#pragma unroll
+            for (int sp = 0; sp < NT; ++sp) s_wx[sp * SPLIT_IMG + e] = tt[sp];
+        }
+#pragma unroll
+        for (int sp = 0; sp < NT; ++sp)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) xb[sp][ks] = *reinterpret_cast<const uint4*>(&s_wx[sp * SPLIT_IMG + (ks * 64 + lane) * 2]);
+    };
+    auto pc_times = [&](int m, const uint4 (&xb)[NT][2]) __attribute__((always_inline)) {
+        uint4 pa[NT][2];
+#pragma unroll
+        for (int sp = 0; sp < NT; ++sp)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) pa[sp][ks] = *reinterpret_cast<const uint4*>(&s_pc[(m * NT + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
+        return OpFmt<FMT>::STATE_INV * OpFmt<FMT>::product(pa, xb);
+    };
+    if constexpr (FUSE) {
+        if (chunk > 0) {
+            __syncthreads();                               // P_c complete in LDS
+            uint4 xb[NT][2];
+            col_images(std::integral_constant<int, 0>{}, xb);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) X[m][0] = pc_times(m, xb);
+        }
+    }
     f32x4* gg = first_of_many ? x0 + 4 * 4 * 64
               : (chunk == 0 ? reinterpret_cast<f32x4*>(a.gg) + (size_t)fh * nsl * 4 * 64
                             : reinterpret_cast<f32x4*>(a.ggc) + ((size_t)fh * (nchunk - 1) + chunk - 1) * nsl * 4 * 64);
@@ -740,29 +805,38 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
         }
     };
     if constexpr (SPLIT) {
-        bf16x8 am[4][KS][3];
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
+        // the A images of M: resident for all four row tiles (96 registers), or -- FUSE, where the running map takes 80 -- re-read
+        // per row tile (six 16-byte LDS reads against twelve MFMAs)
+        bf16x8 am[FUSE ? 1 : 4][KS][3];
+        auto am_load = [&](int m, bf16x8 (&d)[KS][3]) __attribute__((always_inline)) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int sp = 0; sp < 3; ++sp)
-                    am[m][ks][sp] = *reinterpret_cast<const bf16x8*>(&s_m3[sp * 4 * KS * 128 + ((m * KS + ks) * 64 + lane) * 2]);
-        auto g_tiles3 = [&](int cV, const bf16x8 (&x)[KS]) __attribute__((always_inline)) {
+                    d[ks][sp] = *reinterpret_cast<const bf16x8*>(&s_m3[sp * 4 * KS * 128 + ((m * KS + ks) * 64 + lane) * 2]);
+        };
+        if constexpr (!FUSE) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) am_load(m, am[m]);
+        }
+        // emit(m, tile): what becomes of G tile (m, cV) -- stored (one chunk, or a chunk map), or folded into the running map
+        auto g_tiles3 = [&](int cV, const bf16x8 (&x)[KS], auto&& emit) __attribute__((always_inline)) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
+                if constexpr (FUSE) am_load(m, am[0]);
+                const bf16x8 (&amm)[KS][3] = am[FUSE ? 0 : m];
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {          // smallest terms first
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m][ks][2], x[ks], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m][ks][1], x[ks], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(amm[ks][2], x[ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(amm[ks][1], x[ks], acc1, 0, 0, 0);
                 }
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) {
-                    if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m][ks][0], x[ks], acc1, 0, 0, 0);
-                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[m][ks][0], x[ks], acc0, 0, 0, 0);
+                    if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(amm[ks][0], x[ks], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(amm[ks][0], x[ks], acc0, 0, 0, 0);
                 }
-                if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = (acc0 + acc1) * gscale;
+                emit(m, acc0 + acc1);
             }
         };
         char* vst = reinterpret_cast<char*>(s_kni) + w * 4096;          // two wave-private 2 KiB tiles (the K staging area is free)
@@ -785,15 +859,77 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
             x[1] = __builtin_bit_cast(bf16x8, make_uint4(r10.x, r10.y, r11.x, r11.y));
         };
         bf16x8 xb[KS];
-        for (int cV = w; cV < nsl; cV += 8) {
-            load_vraw(cV + 4, vB0, vB1);
-            stage(0, vA0, vA1);
-            read_b(0, xb);
-            g_tiles3(cV, xb);
-            load_vraw(cV + 8, vA0, vA1);
-            stage(1, vB0, vB1);
-            read_b(1, xb);
-            g_tiles3(cV + 4, xb);
+        if constexpr (!FUSE) {
+            for (int cV = w; cV < nsl; cV += 8) {
+                load_vraw(cV + 4, vB0, vB1);
+                stage(0, vA0, vA1);
+                read_b(0, xb);
+                g_tiles3(cV, xb, [&](int m, const f32x4& t) { if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = t * gscale; });
+                load_vraw(cV + 8, vA0, vA1);
+                stage(1, vB0, vB1);
+                read_b(1, xb);
+                g_tiles3(cV + 4, xb, [&](int m, const f32x4& t) { if (cV + 4 < nsl) gg[((size_t)(cV + 4) * 4 + m) * 64 + lane] = t * gscale; });
+            }
+        } else {
+            // column tile cV = w + 4 (j - 1) of G is X[.][j], j = 1 .. 4 (Dv <= 256): compile-time indices, run-time bounds.
+            // Two column tiles per trip share every row tile's operand fetch -- M's term images (6 reads) and P_c's (4): with one
+            // column per fetch the walk read 4x the chunk-parallel kernel's LDS bytes and two co-resident workgroups got in each
+            // other's way (measured: 69 us for 256 frames, 107 us for 512).
+            auto gtile = [&](const bf16x8 (&amm)[KS][3], const bf16x8 (&x)[KS]) __attribute__((always_inline)) {
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {          // smallest terms first
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(amm[ks][2], x[ks], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(amm[ks][1], x[ks], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(amm[ks][0], x[ks], acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(amm[ks][0], x[ks], acc0, 0, 0, 0);
+                }
+                return acc0 + acc1;
+            };
+            static_for<0, 2>([&](auto tc) {
+                constexpr int t2 = decltype(tc)::value, jA = 1 + 2 * t2, jB = 2 + 2 * t2;
+                const int cV = w + 8 * t2;
+                if (cV < nsl) {
+                    const bool twoB = cV + 4 < nsl;
+                    bf16x8 xbB[KS];
+                    stage(0, vA0, vA1);
+                    if (t2 == 0) {                          // (the first trip's second tile is not in flight yet)
+                        load_vraw(cV + 4, vB0, vB1);
+                        load_vraw(cV + 8, vA0, vA1);
+                        stage(1, vB0, vB1);
+                        load_vraw(cV + 12, vB0, vB1);
+                    } else {
+                        stage(1, vB0, vB1);
+                    }
+                    read_b(0, xb);
+                    read_b(1, xbB);
+                    uint4 xiA[NT][2], xiB[NT][2];
+                    if (chunk > 0) {
+                        col_images(std::integral_constant<int, jA>{}, xiA);
+                        col_images(std::integral_constant<int, jB>{}, xiB);
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        am_load(m, am[0]);
+                        const f32x4 tA = gtile(am[0], xb), tB = gtile(am[0], xbB);
+                        if (chunk == 0) {
+                            X[m][jA] = tA;
+                            X[m][jB] = tB;
+                        } else {
+                            uint4 pa[NT][2];
+#pragma unroll
+                            for (int sp = 0; sp < NT; ++sp)
+#pragma unroll
+                                for (int ks = 0; ks < 2; ++ks) pa[sp][ks] = *reinterpret_cast<const uint4*>(&s_pc[(m * NT + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
+                            X[m][jA] = OpFmt<FMT>::STATE_INV * OpFmt<FMT>::product(pa, xiA) + tA;
+                            if (twoB) X[m][jB] = OpFmt<FMT>::STATE_INV * OpFmt<FMT>::product(pa, xiB) + tB;
+                        }
+                    }
+                }
+            });
         }
     } else {
         for (int cV = w; cV < nsl; cV += 8) {     // two V tiles per trip: the next tile's loads are in flight behind the MFMAs
@@ -804,12 +940,40 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
         }
     }
     DIAG_STAMP(6);
+    if constexpr (FUSE) __syncthreads();                  // the next chunk's staging tile overwrites what this one's phase 4 read
+    }   // chunks
+    if constexpr (FUSE) {
+        // the frame's map in the formats the scan consumes (as gdr_compose_kernel's last step): P tile (m, w) -> the term images of
+        // row tile m, G tiles in the scan's scale
+        const int nsl = a.Dv / 16;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            unsigned short* img = reinterpret_cast<unsigned short*>(a.pp) + (size_t)fh * (4 * 3 * SPLIT_IMG * 4) + m * (NT * SPLIT_IMG * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                unsigned short tt[3];
+                OpFmt<FMT>::split1(X[m][0][r], tt);
+                const int e = split_slot(w, li >> 2, 4 * g + r) * 4 + (li & 3);
+#pragma unroll
+                for (int sp = 0; sp < NT; ++sp) img[sp * SPLIT_IMG * 4 + e] = tt[sp];
+            }
+        }
+        f32x4* gout = reinterpret_cast<f32x4*>(a.gg) + (size_t)fh * nsl * 4 * 64;
+        static_for<1, 5>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int cV = w + 4 * (j - 1);
+            if (cV < nsl) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) gout[((size_t)cV * 4 + m) * 64 + lane] = X[m][j] * OpFmt<FMT>::STATE;
+            }
+        });
+    }
 }
 
-template <int NB, int IO, int FMT>
+template <int NB, int IO, int FMT, bool FUSE = false>
 int launch_prepm_fmt(const PrepMArgs& pa, int FH, int nchunk, hipStream_t st)
 {
-    const size_t lds = prepm_lds_bytes(NB, IO);
+    const size_t lds = prepm_lds_bytes(NB, IO, FUSE);
     if (lds > 64 * 1024) {
         // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device; lock-free cache as in gdr_scan.hip
         static std::atomic<unsigned long long> done_mask{0};
@@ -817,19 +981,22 @@ int launch_prepm_fmt(const PrepMArgs& pa, int FH, int nchunk, hipStream_t st)
         if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_prepm: hipGetDevice");
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_prepm_kernel<NB, IO, FMT>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_prepm_kernel<NB, IO, FMT, FUSE>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_prepm: LDS attribute: %s", hipGetErrorString(e));
             done_mask.fetch_or(bit, std::memory_order_relaxed);
         }
     }
-    hipLaunchKernelGGL((gdr_prepm_kernel<NB, IO, FMT>), dim3(FH, nchunk), dim3(256), lds, st, pa);
+    hipLaunchKernelGGL((gdr_prepm_kernel<NB, IO, FMT, FUSE>), dim3(FH, FUSE ? 1 : nchunk), dim3(256), lds, st, pa);
     GDKVM_LAUNCH_CHECK("gdr_prepm_kernel");
     return GDKVM_OK;
 }
 template <int NB, int IO>
-int launch_prepm(const PrepMArgs& pa, int FH, int nchunk, bool wide, hipStream_t st)
+int launch_prepm(const PrepMArgs& pa, int FH, int nchunk, bool wide, bool fuse, hipStream_t st)
 {
+    if constexpr (prepm_split(NB, IO)) {
+        if (fuse && !wide) return launch_prepm_fmt<NB, IO, FMT_PAIR16, true>(pa, FH, nchunk, st);
+    }
     return wide ? launch_prepm_fmt<NB, IO, FMT_SPLIT3>(pa, FH, nchunk, st) : launch_prepm_fmt<NB, IO, FMT_PAIR16>(pa, FH, nchunk, st);
 }
 
@@ -959,14 +1126,28 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
     if (int rc = gdkvm_check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!(flags & GDKVM_FLAG_TRAIN) || ws.nchunk > 1) {  // P and G directly (frames of > 64 tokens: per 64-token chunk, then composed)
-        PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, ws.x0, ws.ppc, ws.ggc, T, Hh, N, Dv, rule, flags, 16 * ws.nb};
+        PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, ws.x0, ws.ppc, ws.ggc, T, Hh, N, Dv, rule, flags, 16 * ws.nb, ws.nchunk};
 #ifdef GDKVM_DIAG
         pm.diag = g_gdkvm_diag_buf;
 #endif
         const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
-        if (int rc = io_dtype == GDKVM_F32 ? launch_prepm<4, GDKVM_F32>(pm, B * T * Hh, ws.nchunk, wide, st)
-                                           : launch_prepm<4, GDKVM_BF16>(pm, B * T * Hh, ws.nchunk, wide, st)) return rc;
-        if (ws.nchunk > 1) {
+        // Frames of more than 64 tokens: with enough frames to fill the device on their own, ONE workgroup walks a frame's chunks and
+        // composes its map in registers (no chunk maps through HBM, no compose kernel); with few frames the chunks run as separate
+        // workgroups (4x the parallelism) and gdr_compose_kernel stitches them.  bf16 I/O on pair16 operands, Dv <= 256 in
+        // multiples of 64 (five column tiles of accumulators per wave), not delta_parallel (its chunks add up instead).
+        bool fuse = false;
+        if (ws.nchunk > 1 && io_dtype == GDKVM_BF16 && !wide && rule != GDKVM_RULE_DELTA_PARALLEL && Dv % 64 == 0 && Dv <= 256) {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) {
+                int n = 0;
+                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+            }
+            fuse = (long)B * T * Hh >= cus;               // measured crossover at N = 256, Dv = 256: 256 frames (54 us either way)
+            if (const char* e = getenv("GDKVM_PREP_FUSE")) fuse = e[0] == '1';     // "0" / "1": overrides the choice by frame count (tests, A/B)
+        }
+        if (int rc = io_dtype == GDKVM_F32 ? launch_prepm<4, GDKVM_F32>(pm, B * T * Hh, ws.nchunk, wide, false, st)
+                                           : launch_prepm<4, GDKVM_BF16>(pm, B * T * Hh, ws.nchunk, wide, fuse, st)) return rc;
+        if (ws.nchunk > 1 && !fuse) {
             ComposeArgs ca{ws.x0, ws.ppc, ws.ggc, ws.pp, ws.gg, Dv, ws.nchunk, rule == GDKVM_RULE_DELTA_PARALLEL};
             const dim3 cgrid((unsigned)(B * T * Hh), (unsigned)((4 + Dv / 16 + 3) / 4));
             if (wide) hipLaunchKernelGGL(gdr_compose_kernel<FMT_SPLIT3>, cgrid, dim3(256), 0, st, ca);

@@ -50,6 +50,35 @@ def test_scan_fp32_ragged_shapes(hip, shape):
     assert np.abs(Rg - Ro).max() <= TOL and np.abs(Sg - So).max() <= TOL
 
 
+@pytest.mark.parametrize("case", [(2, 3, 65, 1, 64), (1, 4, 100, 2, 128), (3, 2, 130, 1, 192), (2, 2, 250, 1, 256), (1, 3, 256, 1, 256), (1, 2, 1024, 1, 64)])
+@pytest.mark.parametrize("rule", [0, 2])
+def test_fused_chunk_walk_is_the_chunk_parallel_path_bit_for_bit(hip, case, rule, monkeypatch):
+    """Frames of more than 64 tokens, bf16: gdr_prepm_kernel walking a frame's chunks in ONE workgroup with the running map in
+    registers (chosen when there are at least as many frames as CUs; forced here with GDKVM_PREP_FUSE=1) computes the same sums in
+    the same order as chunk-parallel workgroups + gdr_compose_kernel (=0): read-outs and states are bit-identical, and right
+    against the oracle.  Shapes the walk does not serve (fp32 I/O, Dv not a multiple of 64, delta_parallel) keep the other path."""
+    B, T, N, Hh, Dv = case
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, 64, Dv, seed=sum(case) + rule, normalized=False, logits=True, corr=0.5)
+    t = [_dev(x, torch.bfloat16) for x in (q, k, v)] + [_dev(a), _dev(b)]
+    s0 = _dev((0.3 * np.random.default_rng(3).standard_normal((B, Hh, 64, Dv))).astype(np.float32))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GDKVM_PREP_FUSE", mode)
+        out[mode] = hip.scan_fwd(*t, s0, rule=rule, flags=3)
+    assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])
+    if N <= 256:
+        Ro, So = c_oracle.scan(*(O.to_bf16_f32(x) for x in (q, k, v)), a, b, s0.cpu().numpy(), rule, 3)
+        assert np.abs(out["1"][1].cpu().numpy() - So).max() <= 1e-4
+        assert np.all(np.abs(out["1"][0].float().cpu().numpy() - Ro) <= 1e-4 + np.abs(Ro) * 2.0 ** -7)
+    monkeypatch.setenv("GDKVM_PREP_FUSE", "1")
+    for alt in ([x.float() for x in t[:3]] + t[3:], [t[0], t[1], t[2][..., :48].contiguous(), t[3], t[4]]):     # fp32 I/O; Dv = 48
+        monkeypatch.setenv("GDKVM_PREP_FUSE", "1")
+        r1, s1 = hip.scan_fwd(*alt, rule=rule, flags=3)
+        monkeypatch.setenv("GDKVM_PREP_FUSE", "0")
+        r0, s0_ = hip.scan_fwd(*alt, rule=rule, flags=3)
+        assert torch.equal(r0, r1) and torch.equal(s0_, s1)
+
+
 @pytest.mark.parametrize("rule", [0, 1, 2])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_scan_chunked_frames_every_rule(hip, rule, dtype):

@@ -25,6 +25,8 @@ def run():
     import torch
     lib = ctypes.CDLL(SO)
     B, T, N, Hh, Dk, Dv = 16, 32, 49, 1, 64, 256
+    if len(sys.argv) > 4:                                  # run B T N  (frames of more than 64 tokens: GDKVM_PREP_FUSE=0/1 picks the path;
+        B, T, N = (int(x) for x in sys.argv[2:5])          #  the fused walk re-stamps per chunk, so the last chunk's phases are shown)
     dev = torch.device("cuda")
     q, k = (torch.randn(B, T, N, Hh, Dk, device=dev).bfloat16() for _ in range(2))
     v = torch.randn(B, T, N, Hh, Dv, device=dev).bfloat16()
