@@ -1,0 +1,94 @@
+"""plain_forward -- the whole module restated as ONE function of a state_dict, sharing no code with gdkvm_amd.
+
+TEST INFRASTRUCTURE ONLY (tests/ and smoke()).  oracle/model_ref.GDKVMRef subclasses the product's nn.Module and swaps the memory
+path for the oracle: handy (same parameters, same autograd), but the layer wiring -- which block feeds which, which skip tensor a
+decoder stage concatenates, where the residual enters -- is then the product's own code on both sides of every comparison, and a
+wiring error is invisible.  This file writes the architecture of SURVEY.md Appendix A / DESIGN.md §1 down a second time, from the
+parameter names alone, as torch.nn.functional calls in float64 on the CPU (eval-mode BatchNorm from the running statistics), with
+the memory path on the numpy oracle (oracle/gdkvm_oracle.py, float64).  tests/test_model_plain_cpu.py pins GDKVMRef to it; the GPU
+parity tests compare the product's fused inference build with it directly.
+
+    frames [B,T,C,H,W] -> encoder (ResNet-18-style trunk to stride 16: f4, f8, f16)
+      f16 -> key / query / value / gate 1x1 projections per token, decay gate from the token mean
+      LKVA read + GDR write over the T frames (oracle.scan), KPFF (oracle.kpff) on (key feature, read-out, f16)
+      decoder: [upsample x2 ; f8] -> two 3x3 convs -> [upsample x2 ; f4] -> two 3x3 convs -> 1x1 head -> bilinear to HxW
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import gdkvm_oracle as O
+
+_RULE_IDS = {"gated_linear": 0, "delta_parallel": 1, "delta_sequential": 2}
+
+
+def _t(sd, name):
+    return sd[name].detach().to("cpu", torch.float64)
+
+
+def _bn(sd, prefix, x, eps=1e-5):
+    return F.batch_norm(x, _t(sd, prefix + ".running_mean"), _t(sd, prefix + ".running_var"), _t(sd, prefix + ".weight"),
+                        _t(sd, prefix + ".bias"), False, 0.0, eps)
+
+
+def _block(sd, p, x, stride):
+    """conv3x3(stride) - bn - relu - conv3x3 - bn, plus the input (through a strided 1x1 conv + bn when the shape changes), relu."""
+    y = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, _t(sd, p + ".conv1.weight"), None, stride, 1)))
+    y = _bn(sd, p + ".bn2", F.conv2d(y, _t(sd, p + ".conv2.weight"), None, 1, 1))
+    if (p + ".down.0.weight") in sd:
+        x = _bn(sd, p + ".down.1", F.conv2d(x, _t(sd, p + ".down.0.weight"), None, stride, 0))
+    return F.relu(y + x)
+
+
+def _up(sd, p, x, skip):
+    x = torch.cat([F.interpolate(x, size=skip.shape[-2:], mode="bilinear", align_corners=False), skip], 1)
+    x = F.relu(_bn(sd, p + ".conv.1", F.conv2d(x, _t(sd, p + ".conv.0.weight"), None, 1, 1)))
+    return F.relu(_bn(sd, p + ".conv.4", F.conv2d(x, _t(sd, p + ".conv.3.weight"), None, 1, 1)))
+
+
+def _tokens(x):
+    return x.permute(0, 2, 3, 1).reshape(x.shape[0], x.shape[2] * x.shape[3], x.shape[1])
+
+
+@torch.no_grad()
+def plain_forward(sd, frames, heads=1, key_dim=64, value_dim=256, rule="delta_sequential", mask0=None, state=None, lowres=False):
+    """sd: state_dict of the un-fused module (gdkvm_amd.model.GDKVM(...).state_dict()); frames [B,T,C,H,W].
+    Returns (logits [B,T,ncls,H,W] float64 -- stride-4 logits if lowres --, final state [B,Hh,Dk,Dv] float64)."""
+    B, T, C, H, W = frames.shape
+    Hh, Dk, Dv = heads, key_dim, value_dim
+    x = frames.detach().to("cpu", torch.float64).reshape(B * T, C, H, W)
+    # encoder
+    x = F.relu(_bn(sd, "encoder.stem.1", F.conv2d(x, _t(sd, "encoder.stem.0.weight"), None, 2, 3)))
+    x = F.max_pool2d(x, 3, 2, 1)
+    f4 = _block(sd, "encoder.layer1.1", _block(sd, "encoder.layer1.0", x, 1), 1)
+    f8 = _block(sd, "encoder.layer2.1", _block(sd, "encoder.layer2.0", f4, 2), 1)
+    f16 = _block(sd, "encoder.layer3.1", _block(sd, "encoder.layer3.0", f8, 2), 1)
+    h, w = f16.shape[-2:]
+    N = h * w
+    # per-token projections of the stride-16 feature
+    p_tok = _tokens(f16)                                                   # [BT, N, Cp]
+    lin = lambda name: p_tok @ _t(sd, name + ".weight").reshape(sd[name + ".weight"].shape[0], -1).T + _t(sd, name + ".bias")
+    k_tok = lin("key_proj")                                                # [BT, N, Hh*Dk]: also KPFF's local key feature
+    q = lin("query_proj")
+    v = lin("value_proj").reshape(B, T, N, Hh * Dv)
+    if mask0 is not None:
+        m = F.adaptive_avg_pool2d(mask0.detach().to("cpu", torch.float64), (h, w))
+        me = _tokens(F.conv2d(m, _t(sd, "mask_embed.weight")))             # [B, N, Hh*Dv]: joins the first frame's values
+        v = torch.cat([v[:, :1] + me.unsqueeze(1), v[:, 1:]], 1)
+    beta = lin("gate_proj").reshape(B, T, N, Hh)                           # logits, per token and head
+    alpha = (p_tok.mean(1) @ _t(sd, "decay_proj.weight").T + _t(sd, "decay_proj.bias")).reshape(B, T, Hh)   # per frame and head
+    # memory: LKVA read + GDR write (flags 3: L2-normalised q / k, gates given as logits), then KPFF
+    s0 = None if state is None else state.detach().cpu().double().numpy()
+    r, s = O.scan(q.reshape(B, T, N, Hh, Dk).numpy(), k_tok.reshape(B, T, N, Hh, Dk).numpy(), v.reshape(B, T, N, Hh, Dv).numpy(),
+                  alpha.numpy(), beta.numpy(), s0, _RULE_IDS[rule], 3)
+    fused = O.kpff(k_tok.numpy(), np.asarray(r, np.float64).reshape(B * T, N, Hh * Dv), p_tok.numpy(),
+                   *(_t(sd, "kpff." + n).numpy() for n in ("wa", "ba", "wl", "wg")), h, w)
+    fmap = torch.from_numpy(np.asarray(fused, np.float64)).reshape(B * T, h, w, -1).permute(0, 3, 1, 2)
+    # decoder
+    y = _up(sd, "decoder.up4", _up(sd, "decoder.up8", fmap, f8), f4)
+    logits = F.conv2d(y, _t(sd, "decoder.head.weight"), _t(sd, "decoder.head.bias"))
+    if not lowres:
+        logits = F.interpolate(logits, size=(H, W), mode="bilinear", align_corners=False)
+    return logits.reshape(B, T, -1, *logits.shape[-2:]), torch.from_numpy(np.asarray(s, np.float64))

@@ -49,6 +49,29 @@ def test_module_fp32_matches_cpu_reference(hip):
     assert disagree.float().mean() <= 1e-3 and (margin[disagree] <= 1e-3).all()
 
 
+def test_module_against_the_independent_restatement(hip):
+    """The product on the GPU -- fp32 module, and the fused bf16 inference build -- against oracle/model_plain.plain_forward, which
+    shares no code with gdkvm_amd (float64, torch.nn.functional + the numpy oracle, from the state_dict alone): layer wiring included."""
+    from oracle.model_plain import plain_forward
+    ref, model = _pair(seed=4)
+    frames = torch.rand(2, 3, 3, 112, 112)
+    _balance(ref, model, frames)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    lp, sp = plain_forward(sd, frames)
+    with torch.no_grad():
+        lg, sg = model(frames.cuda(), return_state=True)
+    assert (lg.cpu().double() - lp).abs().max() <= 1e-3 and (sg.cpu().double() - sp).abs().max() <= 1e-3
+    frac = lp.argmax(2).float().mean().item()
+    assert 0.2 < frac < 0.8, f"degenerate mask ({frac})"
+    with torch.no_grad():
+        fused = model.fuse_for_inference().to(torch.bfloat16)
+        lb = fused(frames.cuda()).float().cpu().double()
+    err = (lb - lp).abs()
+    assert err.max() <= 0.05 * max(1.0, lp.abs().max().item()) and err.mean() <= 0.01, (err.max().item(), err.mean().item())
+    agree = (lb.argmax(2) == lp.argmax(2)).float().mean().item()
+    assert agree >= 0.97, agree
+
+
 def test_module_fp32_on_a_grid_wider_than_16_tokens(hip):
     """320x320 frames: a 20x20 token grid (400 tokens per frame: chunked scan, KPFF tiles of 4 rows x 16 columns)."""
     ref, model = _pair(seed=3)
