@@ -380,10 +380,14 @@ __global__ __launch_bounds__(256) void gdr_readout_kernel(ReadoutArgs a)
     const float* qinv = a.qinv + fh * a.NP;
     char* rbase = static_cast<char*>(a.r_out) + ((bt * N * a.Hh + h) * (size_t)Dv + 16 * c0 + 4 * g) * ESZ;
     const size_t rowq = (size_t)a.Hh * GDKVM_DK * ESZ, rowr = (size_t)a.Hh * Dv * ESZ;
-    const int ntt = (N + 15) / 16;
+    // token tiles [tt0, tt1) of the frame: with few frames the tokens are split over gridDim.z workgroups (cfg3: 160 frames x 2
+    // column groups left half the CUs idle on a 16-tile latency chain; the state images are re-read from L2 per split)
+    const int ntt_all = (N + 15) / 16, per_z = (ntt_all + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int tt0 = (int)blockIdx.z * per_z, ntt = min(ntt_all, tt0 + per_z);
+    if (tt0 >= ntt) return;
     struct QT { uint4 q[IO == GDKVM_F32 ? 4 : 2]; float qi; };
     auto load_q = [&](int tt, QT& d) __attribute__((always_inline)) {
-        const int nq = min(16 * min(tt, ntt - 1) + li, N - 1);
+        const int nq = min(16 * min(tt, ntt_all - 1) + li, N - 1);
         const char* p = qbase + (size_t)nq * rowq;
         if constexpr (IO == GDKVM_F32 && PAIR) {           // channels 32ks + 8g .. +7 as q[2ks], q[2ks + 1]
 #pragma unroll
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(256) void gdr_readout_kernel(ReadoutArgs a)
 #pragma unroll
             for (int i = 0; i < (IO == GDKVM_F32 ? 4 : 2); ++i) d.q[i] = *reinterpret_cast<const uint4*>(p + 64 * i + 16 * g);
         }
-        d.qi = qinv[min(16 * min(tt, ntt - 1) + li, a.NP - 1)];
+        d.qi = qinv[min(16 * min(tt, ntt_all - 1) + li, a.NP - 1)];
     };
     auto tile = [&](int tt, const QT& d) __attribute__((always_inline)) {
         float rscale = d.qi * OpFmt<FMT>::STATE_INV;         // (the dumped images are those of S * STATE)
@@ -451,8 +455,8 @@ __global__ __launch_bounds__(256) void gdr_readout_kernel(ReadoutArgs a)
         }
     };
     QT qa, qb;
-    load_q(0, qa);
-    for (int tt = 0; tt < ntt; tt += 2) {
+    load_q(tt0, qa);
+    for (int tt = tt0; tt < ntt; tt += 2) {
         load_q(tt + 1, qb);
         tile(tt, qa);
         load_q(tt + 2, qa);
@@ -510,7 +514,18 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
                                        : launch_affine_any<GDKVM_BF16>(wide, defer, s_hist != nullptr, sa, grid, st)) return rc;
     if (defer) {
         ReadoutArgs ra{q, ws.qinv, ws.simg, r_out, Hh, N, Dv, 16 * ws.nb};
-        const dim3 rgrid((unsigned)(B * T * Hh), (unsigned)((Dv / 16 + 7) / 8));
+        // enough workgroups for two per CU: split the frame's token tiles when frames x column groups alone do not give them
+        unsigned ny = (unsigned)((Dv / 16 + 7) / 8), nz = 1;
+        {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) {
+                int n = 0;
+                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+            }
+            const long wg = (long)B * T * Hh * ny, ntt = (N + 15) / 16;
+            while (wg * nz < 2L * cus && 2 * nz <= (unsigned)(ntt / 2)) nz *= 2;       // (at least two token tiles per workgroup)
+        }
+        const dim3 rgrid((unsigned)(B * T * Hh), ny, nz);
         if (io_dtype == GDKVM_F32 && wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
         else if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
         else if (wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
