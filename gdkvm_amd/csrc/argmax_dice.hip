@@ -95,6 +95,7 @@ struct UpArgs {
     const void* logits; const uint8_t* target; uint8_t* mask; int32_t* counts;
     int ncls, hl, wl, H, W;
     float sy, sx;
+    int staged;                                          // the frame's low-resolution logits fit in LDS (fp32): taps are LDS reads
 };
 
 __device__ __forceinline__ float up_src(float scale, int dst)
@@ -103,16 +104,26 @@ __device__ __forceinline__ float up_src(float scale, int dst)
     return s < 0.f ? 0.f : s;
 }
 
-template <int IO>
+// NC = number of classes when it is 2..4 (loops unrolled, the Dice counters of a thread in registers and reduced once per
+// block), 0 = any (per-pixel wave ballots).
+template <int IO, int NC>
 __global__ __launch_bounds__(256) void upsample_argmax_dice_kernel(UpArgs a)
 {
-    extern __shared__ int s_cnt[];                       // [ncls][3]
-    const int f = blockIdx.y, ncls = a.ncls, HW = a.H * a.W, hw = a.hl * a.wl;
+    extern __shared__ int s_cnt[];                       // [ncls][3] counters, then (staged) [ncls][hl*wl] fp32 logits of the frame
+    const int f = blockIdx.y, ncls = NC ? NC : a.ncls, HW = a.H * a.W, hw = a.hl * a.wl;
     const bool dice = a.target != nullptr;
-    if (dice) {
+    int cnt[NC ? NC : 1][3];
+#pragma unroll
+    for (int c = 0; c < (NC ? NC : 1); ++c) cnt[c][0] = cnt[c][1] = cnt[c][2] = 0;
+    // Every output pixel blends four taps per class; as 2-byte global loads that is 32 vector-memory instructions per thread and the
+    // kernel is bound by their issue (20 us at 512 frames of 112x112 for 14 MB of traffic).  The frame's low-resolution planes are a
+    // few KB: staged once per block, widened to fp32, the taps become LDS reads -- same values, same arithmetic, same bits.
+    float* s_log = reinterpret_cast<float*>(s_cnt + ((ncls * 3 + 3) & ~3));
+    if (a.staged)
+        for (int i = threadIdx.x; i < ncls * hw; i += 256) s_log[i] = load1<IO>(a.logits, (size_t)f * ncls * hw + i);
+    if (dice)
         for (int i = threadIdx.x; i < ncls * 3; i += 256) s_cnt[i] = 0;
-        __syncthreads();
-    }
+    if (dice || a.staged) __syncthreads();
     // PX consecutive pixels of a row per thread (4 when W % 4 == 0): one 4-byte mask store and one 4-byte target load
     // instead of four 1-byte ones, and the vertical taps / weights computed once per thread
     const int PX = (a.W % 4 == 0) ? 4 : 1, nq = HW / PX;
@@ -125,15 +136,24 @@ __global__ __launch_bounds__(256) void upsample_argmax_dice_kernel(UpArgs a)
             const float fy = up_src(a.sy, y);
             const int y0 = (int)fy, y1 = min(y0 + 1, a.hl - 1);
             const float ly = __fsub_rn(fy, (float)y0), hy = __fsub_rn(1.0f, ly);
-            for (int e = 0; e < PX; ++e) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e >= PX) break;
                 const float fx = up_src(a.sx, xb + e);
                 const int x0 = (int)fx, x1 = min(x0 + 1, a.wl - 1);
                 const float lx = __fsub_rn(fx, (float)x0), hx = __fsub_rn(1.0f, lx);
                 float best = 0.f;
+#pragma unroll
                 for (int c = 0; c < ncls; ++c) {
                     const size_t base = ((size_t)f * ncls + c) * hw;
-                    const float v00 = load1<IO>(a.logits, base + y0 * a.wl + x0), v01 = load1<IO>(a.logits, base + y0 * a.wl + x1);
-                    const float v10 = load1<IO>(a.logits, base + y1 * a.wl + x0), v11 = load1<IO>(a.logits, base + y1 * a.wl + x1);
+                    float v00, v01, v10, v11;
+                    if (a.staged) {
+                        const float* pl = s_log + c * hw;
+                        v00 = pl[y0 * a.wl + x0]; v01 = pl[y0 * a.wl + x1]; v10 = pl[y1 * a.wl + x0]; v11 = pl[y1 * a.wl + x1];
+                    } else {
+                        v00 = load1<IO>(a.logits, base + y0 * a.wl + x0); v01 = load1<IO>(a.logits, base + y0 * a.wl + x1);
+                        v10 = load1<IO>(a.logits, base + y1 * a.wl + x0); v11 = load1<IO>(a.logits, base + y1 * a.wl + x1);
+                    }
                     const float top = __fadd_rn(__fmul_rn(hx, v00), __fmul_rn(lx, v01));
                     const float bot = __fadd_rn(__fmul_rn(hx, v10), __fmul_rn(lx, v11));
                     const float v = __fadd_rn(__fmul_rn(hy, top), __fmul_rn(ly, bot));
@@ -146,8 +166,18 @@ __global__ __launch_bounds__(256) void upsample_argmax_dice_kernel(UpArgs a)
         if (dice) {
             unsigned tw = 0xffffffffu;
             if (act) tw = PX == 4 ? *reinterpret_cast<const unsigned*>(a.target + (size_t)f * HW + p0) : (0xffffff00u | a.target[(size_t)f * HW + p0]);
-            for (int e = 0; e < PX; ++e) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (e >= PX) break;
                 const int tc = act ? (int)((tw >> (8 * e)) & 0xff) : -1;
+                if constexpr (NC > 0) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        const int ip = (act && arg[e] == c) ? 1 : 0, it = (tc == c) ? 1 : 0;
+                        cnt[c][0] += ip & it; cnt[c][1] += ip; cnt[c][2] += it;
+                    }
+                    continue;
+                }
                 for (int c = 0; c < ncls; ++c) {
                     const unsigned long long mp = __ballot(act && arg[e] == c), mt = __ballot(tc == c);
                     if ((threadIdx.x & 63) == 0 && (mp | mt)) {
@@ -161,6 +191,17 @@ __global__ __launch_bounds__(256) void upsample_argmax_dice_kernel(UpArgs a)
         }
     }
     if (dice) {
+        if constexpr (NC > 0) {                            // one wave reduction per counter, one LDS atomic per wave
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    int v = cnt[c][k];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                    if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_cnt[c * 3 + k], v);
+                }
+        }
         __syncthreads();
         for (int i = threadIdx.x; i < ncls * 3; i += 256)
             if (s_cnt[i]) atomicAdd(&a.counts[(size_t)f * ncls * 3 + i], s_cnt[i]);
@@ -225,15 +266,24 @@ extern "C" int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* tar
         hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)BT * ncls * 3, st);
         if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "upsample_argmax_dice: memset: %s", hipGetErrorString(e));
     }
-    UpArgs a{logits, target, mask, counts, ncls, hl, wl, H, W, (float)hl / (float)H, (float)wl / (float)W};
+    const size_t cnt_bytes = sizeof(int) * (size_t)((ncls * 3 + 3) & ~3), log_bytes = sizeof(float) * (size_t)ncls * hl * wl;
+    const int staged = cnt_bytes + log_bytes <= 48 * 1024;
+    UpArgs a{logits, target, mask, counts, ncls, hl, wl, H, W, (float)hl / (float)H, (float)wl / (float)W, staged};
     const int nq = (W % 4 == 0) ? H * W / 4 : H * W;       // work items per frame (pixel quads when rows allow)
     int gx = (nq + 255) / 256;
     const int cap = BT >= 1024 ? 2 : (BT >= 256 ? 4 : 16);  // enough blocks to fill the chip, few enough that launch and the
     if (gx > cap) gx = cap;                                //   per-block count reduction do not dominate
     const dim3 grid((unsigned)gx, (unsigned)BT);
-    const size_t lds = sizeof(int) * (size_t)ncls * 3;
-    if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((upsample_argmax_dice_kernel<GDKVM_F32>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((upsample_argmax_dice_kernel<GDKVM_BF16>), grid, dim3(256), lds, st, a);
+    const size_t lds = cnt_bytes + (staged ? log_bytes : 0);
+#define GDKVM_UP_LAUNCH(IO)                                                                                                   \
+    switch (ncls) {                                                                                                           \
+        case 2: hipLaunchKernelGGL((upsample_argmax_dice_kernel<IO, 2>), grid, dim3(256), lds, st, a); break;                 \
+        case 3: hipLaunchKernelGGL((upsample_argmax_dice_kernel<IO, 3>), grid, dim3(256), lds, st, a); break;                 \
+        case 4: hipLaunchKernelGGL((upsample_argmax_dice_kernel<IO, 4>), grid, dim3(256), lds, st, a); break;                 \
+        default: hipLaunchKernelGGL((upsample_argmax_dice_kernel<IO, 0>), grid, dim3(256), lds, st, a);                       \
+    }
+    if (io_dtype == GDKVM_F32) { GDKVM_UP_LAUNCH(GDKVM_F32) } else { GDKVM_UP_LAUNCH(GDKVM_BF16) }
+#undef GDKVM_UP_LAUNCH
     GDKVM_LAUNCH_CHECK("upsample_argmax_dice_kernel");
     return GDKVM_OK;
 }

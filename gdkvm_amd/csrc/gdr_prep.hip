@@ -1098,9 +1098,8 @@ int launch_prep(const PrepArgs& pa, int FH, hipStream_t st)
 {
     const size_t lds = prep_lds_bytes(NB);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_prep_kernel<NB, IO, TPR>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_prep: LDS attribute: %s", hipGetErrorString(e));
+        static std::atomic<unsigned long long> done_mask{0};
+        if (int rc = gdr_lds_optin(reinterpret_cast<const void*>(gdr_prep_kernel<NB, IO, TPR>), done_mask, lds, "gdr_prep")) return rc;
     }
     hipLaunchKernelGGL((gdr_prep_kernel<NB, IO, TPR>), dim3(FH), dim3(256), lds, st, pa);
     GDKVM_LAUNCH_CHECK("gdr_prep_kernel");

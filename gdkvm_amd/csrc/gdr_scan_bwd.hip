@@ -419,8 +419,10 @@ static int scan_bwd_impl(const void* q, const void* k, const void* v, const floa
     const size_t lds = (size_t)(8 * BF_TILE + 3 * 64 + 8 + 4 * 256) * sizeof(float);
     const void* fn = io_dtype == GDKVM_F32 ? reinterpret_cast<const void*>(gdr_bwd_frame_kernel<GDKVM_F32>)
                                            : reinterpret_cast<const void*>(gdr_bwd_frame_kernel<GDKVM_BF16>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_bwd: LDS attribute: %s", hipGetErrorString(e));
+    {
+        static std::atomic<unsigned long long> done_mask[2];
+        if (int rc = gdr_lds_optin(fn, done_mask[io_dtype == GDKVM_F32 ? 0 : 1], lds, "scan_bwd")) return rc;
+    }
     const dim3 fgrid((unsigned)(B * T * Hh));
     if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_bwd_frame_kernel<GDKVM_F32>), fgrid, dim3(256), lds, st, fa);
     else hipLaunchKernelGGL((gdr_bwd_frame_kernel<GDKVM_BF16>), fgrid, dim3(256), lds, st, fa);

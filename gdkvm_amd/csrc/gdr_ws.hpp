@@ -1,5 +1,6 @@
 // gdr_ws.hpp -- workspace layout and argument checks shared by the forward and backward GDR scan entry points.
 #pragma once
+#include <atomic>
 #include <initializer_list>
 
 #include "gdkvm_common.hpp"
@@ -70,6 +71,21 @@ static inline int carve(const char* fn, void* workspace, size_t workspace_bytes,
     v->simg = p;  p += NP > 64 ? FH * ggf : 0;
     v->zero = p;                                         // 256 floats, zeroed by gdkvm_scan_transition
     v->trash = reinterpret_cast<char*>(v->zero + 256);   // write-only slot for read-out rows of padding tokens
+    return GDKVM_OK;
+}
+
+// > 64 KiB of dynamic LDS needs an opt-in per kernel and device: done once, remembered in the caller's lock-free mask (one
+// static mask per kernel instantiation) -- host threads may drive several devices concurrently.
+static inline int gdr_lds_optin(const void* fn, std::atomic<unsigned long long>& done_mask, size_t bytes, const char* who)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "%s: hipGetDevice", who);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "%s: LDS attribute: %s", who, hipGetErrorString(e));
+        done_mask.fetch_or(bit, std::memory_order_relaxed);
+    }
     return GDKVM_OK;
 }
 

@@ -813,6 +813,22 @@ __global__ __launch_bounds__(512) void proj_rows_kernel(ProjArgs a)
 
 }  // namespace
 
+// > 64 KiB of dynamic LDS needs an opt-in per kernel and device: done once (to the CU's 160 KiB), remembered in a lock-free mask per
+// kernel (`slot`), as in gdr_scan.hip -- host threads may drive several devices concurrently.
+static int kpff_lds_optin(const void* fn, int slot)
+{
+    static std::atomic<unsigned long long> done_mask[8];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "kpff_fwd: hipGetDevice");
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done_mask[slot].load(std::memory_order_relaxed) & bit)) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "kpff_fwd: LDS attribute: %s", hipGetErrorString(e));
+        done_mask[slot].fetch_or(bit, std::memory_order_relaxed);
+    }
+    return GDKVM_OK;
+}
+
 extern "C" size_t gdkvm_kpff_workspace_bytes(int Ck, int Cv, int Cp, int io_dtype)
 {
     if ((io_dtype != GDKVM_BF16 && io_dtype != GDKVM_F32) || Ck <= 0 || Cv <= 0 || Cp <= 0) return 16;
@@ -875,10 +891,8 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
                        wab, ba, wab + na, wab + na + nl, static_cast<bf16_t*>(out), Ck, Cv, Cp, h, w, rows, tiles, sv, cols, col_tiles};
         const size_t lds = pair ? 2 * lds1 : lds1;
         const void* fn = pair ? reinterpret_cast<const void*>(kpff_bf16_kernel<2, KPFF_OT>) : reinterpret_cast<const void*>(kpff_bf16_kernel<1, 1>);
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "kpff_fwd: LDS attribute: %s", hipGetErrorString(e));
-        }
+        if (lds > 64 * 1024)
+            if (int rc = kpff_lds_optin(fn, pair ? 0 : 1)) return rc;
         if (pair) hipLaunchKernelGGL((kpff_bf16_kernel<2, KPFF_OT>), dim3((unsigned)((total_tiles + 1) / 2)), dim3(512 / KPFF_OT), lds, st, b, total_tiles);
         else hipLaunchKernelGGL((kpff_bf16_kernel<1, 1>), dim3((unsigned)total_tiles), dim3(256), lds, st, b, total_tiles);
         GDKVM_LAUNCH_CHECK("kpff_bf16_kernel");
@@ -898,17 +912,7 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
             hipLaunchKernelGGL(kpff_pack_weights_kernel, dim3(256), dim3(256), 0, st, wa, wl, wg, wpk, wpk + lo_off, Cp, Ck, Cv);
             GDKVM_LAUNCH_CHECK("kpff_pack_weights_kernel");
         }
-        {
-            static std::atomic<unsigned long long> done_mask{0};
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "kpff_fwd: hipGetDevice");
-            const unsigned long long bit = 1ull << (dev & 63);
-            if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kpff_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "kpff_fwd: LDS attribute: %s", hipGetErrorString(e));
-                done_mask.fetch_or(bit, std::memory_order_relaxed);
-            }
-        }
+        if (int rc = kpff_lds_optin(reinterpret_cast<const void*>(kpff_split_kernel), 2)) return rc;
         KpffSplitArgs b{static_cast<const float*>(local), static_cast<const float*>(global), static_cast<const float*>(pixel), wpk, lo_off, ba,
                         static_cast<float*>(out), Ck, Cv, Cp, h, w, rows, tiles, sv, cols, col_tiles};
         hipLaunchKernelGGL(kpff_split_kernel, grid, dim3(512), lds_split, st, b);
@@ -921,10 +925,8 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
     KpffArgs a{local, global, pixel, wa, ba, wl, wg, out, Ck, Cv, Cp, h, w, rows, tiles, sv, cols, col_tiles};
     const void* fn = io_dtype == GDKVM_F32 ? reinterpret_cast<const void*>(kpff_kernel<GDKVM_F32>)
                                            : reinterpret_cast<const void*>(kpff_kernel<GDKVM_BF16>);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "kpff_fwd: LDS attribute: %s", hipGetErrorString(e));
-    }
+    if (lds > 64 * 1024)
+        if (int rc = kpff_lds_optin(fn, io_dtype == GDKVM_F32 ? 3 : 4)) return rc;
     if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((kpff_kernel<GDKVM_F32>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((kpff_kernel<GDKVM_BF16>), grid, dim3(256), lds, st, a);
     GDKVM_LAUNCH_CHECK("kpff_kernel");

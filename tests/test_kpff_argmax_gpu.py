@@ -114,7 +114,8 @@ def test_argmax_dice_bit_exact(hip, case, dtype):
     np.testing.assert_allclose(d, O.dice_from_counts(co[..., 0], co[..., 1], co[..., 2]), rtol=1e-12)
 
 
-@pytest.mark.parametrize("case", [(3, 2, 28, 28, 112, 112), (2, 4, 64, 64, 256, 256), (2, 3, 7, 5, 30, 17), (1, 2, 28, 28, 28, 28)])
+@pytest.mark.parametrize("case", [(3, 2, 28, 28, 112, 112), (2, 4, 64, 64, 256, 256), (2, 3, 7, 5, 30, 17), (1, 2, 28, 28, 28, 28), (2, 6, 9, 8, 36, 32),
+                                  (1, 5, 40, 40, 160, 160)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_upsample_argmax_dice_bit_exact(hip, case, dtype):
     """Fused bilinear upsample + argmax + Dice against the scalar oracle (same un-fused fp32 formula): bit-exact."""
