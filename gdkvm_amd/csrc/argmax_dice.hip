@@ -95,7 +95,11 @@ struct UpArgs {
     const void* logits; const uint8_t* target; uint8_t* mask; int32_t* counts;
     int ncls, hl, wl, H, W;
     float sy, sx;
-    int staged;                                          // the frame's low-resolution logits fit in LDS (fp32): taps are LDS reads
+    int staged;                                          // the block's low-resolution logit rows go through LDS (fp32): taps are LDS reads
+    // head fused in (gdkvm_head_upsample_argmax_dice): `logits` is the decoder feature [BT, hl, wl, C] (NHWC) and the class planes
+    // are computed into LDS by the block itself, with gdkvm_head_logits' arithmetic and its rounding to the io dtype
+    const float* hw_; const float* hb; int C;
+    int lr_cap;                                          // low-resolution rows the LDS tile holds
 };
 
 __device__ __forceinline__ float up_src(float scale, int dst)
@@ -119,16 +123,56 @@ __global__ __launch_bounds__(256) void upsample_argmax_dice_kernel(UpArgs a)
     // kernel is bound by their issue (20 us at 512 frames of 112x112 for 14 MB of traffic).  The frame's low-resolution planes are a
     // few KB: staged once per block, widened to fp32, the taps become LDS reads -- same values, same arithmetic, same bits.
     float* s_log = reinterpret_cast<float*>(s_cnt + ((ncls * 3 + 3) & ~3));
-    if (a.staged)
-        for (int i = threadIdx.x; i < ncls * hw; i += 256) s_log[i] = load1<IO>(a.logits, (size_t)f * ncls * hw + i);
+    // PX consecutive pixels of a row per thread (4 when W % 4 == 0): one 4-byte mask store and one 4-byte target load
+    // instead of four 1-byte ones, and the vertical taps / weights computed once per thread.  A block owns a contiguous range of
+    // them, hence a contiguous band of low-resolution rows [lr0, lr1].
+    const int PX = (a.W % 4 == 0) ? 4 : 1, nq = HW / PX;
+    const int per = (((nq + (int)gridDim.x - 1) / (int)gridDim.x + 255) / 256) * 256;
+    const int q_lo = blockIdx.x * per, q_hi = min(nq, q_lo + per);
+    int lr0 = 0, lr1 = a.hl - 1;
+    if (q_lo < q_hi) {
+        lr0 = (int)up_src(a.sy, (q_lo * PX) / a.W);
+        lr1 = min((int)up_src(a.sy, (q_hi * PX - 1) / a.W) + 1, a.hl - 1);
+    }
+    const int npl = (lr1 - lr0 + 1) * a.wl;              // low-resolution pixels of the band
+    const bool staged = a.staged && lr1 - lr0 + 1 <= a.lr_cap;
+    if (staged && a.hw_) {
+        // the head on the band: C/V lanes per pixel, lane cg keeps class cg (as head_logits_kernel; same sums, same rounding)
+        constexpr int V = IO == GDKVM_F32 ? 4 : 8;
+        const int G = a.C / V, ppw = 64 / G;
+        const int lane = threadIdx.x & 63, sub = lane / G, cg = lane % G, wv = threadIdx.x >> 6;
+        const uint4* xv = static_cast<const uint4*>(a.logits) + ((size_t)f * hw + (size_t)lr0 * a.wl) * G;
+        for (int p0 = wv * ppw; p0 < npl; p0 += 4 * ppw) {
+            const int p = p0 + sub;
+            const uint4 v4 = xv[(size_t)min(p, npl - 1) * G + cg];
+            const unsigned xw[4] = {v4.x, v4.y, v4.z, v4.w};
+            float v[V];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (IO == GDKVM_F32) v[j] = __uint_as_float(xw[j]);
+                else { v[2 * j] = __uint_as_float(xw[j] << 16); v[2 * j + 1] = __uint_as_float(xw[j] & 0xffff0000u); }
+            }
+            float mine = 0.f;
+            for (int c = 0; c < ncls; ++c) {
+                float d = 0.f;
+#pragma unroll
+                for (int j = 0; j < V; ++j) d = fmaf(v[j], a.hw_[(size_t)c * a.C + cg * V + j], d);
+                for (int o = G >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o);
+                if (cg == c) mine = d + a.hb[c];
+            }
+            if (p < npl && cg < ncls) s_log[cg * npl + p] = IO == GDKVM_F32 ? mine : bf16_to_f32(f32_to_bf16(mine));
+        }
+    } else if (staged) {
+        for (int i = threadIdx.x; i < ncls * npl; i += 256) {
+            const int c = i / npl, r = i - c * npl;
+            s_log[i] = load1<IO>(a.logits, ((size_t)f * ncls + c) * hw + (size_t)lr0 * a.wl + r);
+        }
+    }
     if (dice)
         for (int i = threadIdx.x; i < ncls * 3; i += 256) s_cnt[i] = 0;
-    if (dice || a.staged) __syncthreads();
-    // PX consecutive pixels of a row per thread (4 when W % 4 == 0): one 4-byte mask store and one 4-byte target load
-    // instead of four 1-byte ones, and the vertical taps / weights computed once per thread
-    const int PX = (a.W % 4 == 0) ? 4 : 1, nq = HW / PX;
-    for (int qd = blockIdx.x * 256 + threadIdx.x; qd < ((nq + 255) / 256) * 256; qd += gridDim.x * 256) {
-        const bool act = qd < nq;
+    if (dice || staged) __syncthreads();
+    for (int qd = q_lo + threadIdx.x; qd < q_lo + per; qd += 256) {
+        const bool act = qd < q_hi;
         int arg[4] = {0, 0, 0, 0};
         const int p0 = qd * PX;
         if (act) {
@@ -147,8 +191,8 @@ __global__ __launch_bounds__(256) void upsample_argmax_dice_kernel(UpArgs a)
                 for (int c = 0; c < ncls; ++c) {
                     const size_t base = ((size_t)f * ncls + c) * hw;
                     float v00, v01, v10, v11;
-                    if (a.staged) {
-                        const float* pl = s_log + c * hw;
+                    if (staged) {
+                        const float* pl = s_log + c * npl - lr0 * a.wl;
                         v00 = pl[y0 * a.wl + x0]; v01 = pl[y0 * a.wl + x1]; v10 = pl[y1 * a.wl + x0]; v11 = pl[y1 * a.wl + x1];
                     } else {
                         v00 = load1<IO>(a.logits, base + y0 * a.wl + x0); v01 = load1<IO>(a.logits, base + y0 * a.wl + x1);
@@ -248,31 +292,44 @@ extern "C" int gdkvm_argmax_dice(const void* logits, const uint8_t* target, uint
     return GDKVM_OK;
 }
 
-extern "C" int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* target, uint8_t* mask, int32_t* counts,
-                                          int BT, int ncls, int hl, int wl, int H, int W, int io_dtype, void* stream)
+static int upsample_launch(const char* who, const void* src, const float* head_w, const float* head_b, int C,
+                           const uint8_t* target, uint8_t* mask, int32_t* counts,
+                           int BT, int ncls, int hl, int wl, int H, int W, int io_dtype, void* stream)
 {
     if (BT < 0 || ncls <= 0 || ncls > 255 || hl <= 0 || wl <= 0 || H <= 0 || W <= 0)
-        return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_argmax_dice: bad shape BT=%d ncls=%d %dx%d -> %dx%d", BT, ncls, hl, wl, H, W);
-    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "upsample_argmax_dice: io_dtype=%d", io_dtype);
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: bad shape BT=%d ncls=%d %dx%d -> %dx%d", who, BT, ncls, hl, wl, H, W);
+    if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "%s: io_dtype=%d", who, io_dtype);
+    if (head_w) {
+        const int V = io_dtype == GDKVM_F32 ? 4 : 8, G = C > 0 ? C / V : 0;
+        if (C <= 0 || C % V || G > 64 || (G & (G - 1)) || ncls > G)
+            return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: C=%d classes=%d (C/%d a power of two <= 64, classes <= C/%d)", who, C, ncls, V, V);
+    }
     if (BT == 0) return GDKVM_OK;
-    if (!logits || !mask) return gdkvm_fail(GDKVM_ERR_ARG, "upsample_argmax_dice: null pointer");
-    if (target && !counts) return gdkvm_fail(GDKVM_ERR_ARG, "upsample_argmax_dice: counts required with a target");
-    if (!gdkvm_aligned16(logits) || !gdkvm_aligned16(mask) || (target && !gdkvm_aligned16(target)) || (counts && !gdkvm_aligned16(counts)))
-        return gdkvm_fail(GDKVM_ERR_ARG, "upsample_argmax_dice: pointers must be 16-byte aligned");
-    if ((size_t)H * W > 0x7fffffffu / 2) return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_argmax_dice: image too large");
+    if (!src || !mask || (head_w && !head_b)) return gdkvm_fail(GDKVM_ERR_ARG, "%s: null pointer", who);
+    if (target && !counts) return gdkvm_fail(GDKVM_ERR_ARG, "%s: counts required with a target", who);
+    if (!gdkvm_aligned16(src) || !gdkvm_aligned16(mask) || (target && !gdkvm_aligned16(target)) || (counts && !gdkvm_aligned16(counts)))
+        return gdkvm_fail(GDKVM_ERR_ARG, "%s: pointers must be 16-byte aligned", who);
+    if ((size_t)H * W > 0x7fffffffu / 2) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: image too large", who);
     if (int rc = gdkvm_check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (target) {
         hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)BT * ncls * 3, st);
-        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "upsample_argmax_dice: memset: %s", hipGetErrorString(e));
+        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "%s: memset: %s", who, hipGetErrorString(e));
     }
-    const size_t cnt_bytes = sizeof(int) * (size_t)((ncls * 3 + 3) & ~3), log_bytes = sizeof(float) * (size_t)ncls * hl * wl;
-    const int staged = cnt_bytes + log_bytes <= 48 * 1024;
-    UpArgs a{logits, target, mask, counts, ncls, hl, wl, H, W, (float)hl / (float)H, (float)wl / (float)W, staged};
     const int nq = (W % 4 == 0) ? H * W / 4 : H * W;       // work items per frame (pixel quads when rows allow)
     int gx = (nq + 255) / 256;
     const int cap = BT >= 1024 ? 2 : (BT >= 256 ? 4 : 16);  // enough blocks to fill the chip, few enough that launch and the
     if (gx > cap) gx = cap;                                //   per-block count reduction do not dominate
+    // low-resolution rows a block's contiguous output range can touch (+ slack: the kernel's own fp32 row arithmetic decides,
+    // and takes the unstaged path should a band ever exceed the tile)
+    const int per = (((nq + gx - 1) / gx + 255) / 256) * 256, PX = (W % 4 == 0) ? 4 : 1;
+    const int out_rows = (per * PX + W - 1) / W + 1;
+    int lr_cap = (int)((double)out_rows * hl / H) + 4;
+    if (lr_cap > hl) lr_cap = hl;
+    const size_t cnt_bytes = sizeof(int) * (size_t)((ncls * 3 + 3) & ~3), log_bytes = sizeof(float) * (size_t)ncls * lr_cap * wl;
+    const int staged = cnt_bytes + log_bytes <= 48 * 1024;
+    if (head_w && !staged) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: %d classes x %d x %d low-resolution rows do not fit the LDS tile", who, ncls, lr_cap, wl);
+    UpArgs a{src, target, mask, counts, ncls, hl, wl, H, W, (float)hl / (float)H, (float)wl / (float)W, staged, head_w, head_b, C, lr_cap};
     const dim3 grid((unsigned)gx, (unsigned)BT);
     const size_t lds = cnt_bytes + (staged ? log_bytes : 0);
 #define GDKVM_UP_LAUNCH(IO)                                                                                                   \
@@ -286,4 +343,20 @@ extern "C" int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* tar
 #undef GDKVM_UP_LAUNCH
     GDKVM_LAUNCH_CHECK("upsample_argmax_dice_kernel");
     return GDKVM_OK;
+}
+
+extern "C" int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* target, uint8_t* mask, int32_t* counts,
+                                          int BT, int ncls, int hl, int wl, int H, int W, int io_dtype, void* stream)
+{
+    return upsample_launch("upsample_argmax_dice", logits, nullptr, nullptr, 0, target, mask, counts, BT, ncls, hl, wl, H, W, io_dtype, stream);
+}
+
+// The decoder's head folded in: x [BT, hl, wl, C] is the stride-4 feature (NHWC), w [ncls, C] and b [ncls] the 1x1 head; the class
+// planes exist only as the LDS bands of the blocks -- bit-identical to gdkvm_head_logits followed by gdkvm_upsample_argmax_dice.
+extern "C" int gdkvm_head_upsample_argmax_dice(const void* x, const float* w, const float* b, const uint8_t* target, uint8_t* mask,
+                                               int32_t* counts, int BT, int C, int ncls, int hl, int wl, int H, int W, int io_dtype,
+                                               void* stream)
+{
+    if (!w) return gdkvm_fail(GDKVM_ERR_ARG, "head_upsample_argmax_dice: null pointer");
+    return upsample_launch("head_upsample_argmax_dice", x, w, b, C, target, mask, counts, BT, ncls, hl, wl, H, W, io_dtype, stream);
 }

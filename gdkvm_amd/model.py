@@ -14,7 +14,7 @@ or without libgdkvm_hip.so the forward raises.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import NamedTuple, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -166,6 +166,13 @@ class UpBlock(nn.Module):
         return c(x)
 
 
+class HeadFeature(NamedTuple):
+    """What Decoder.forward(head_fused=True) hands to GDKVM.segment: the stride-4 decoder feature (channels_last) and the 1x1 head."""
+    feature: torch.Tensor
+    weight: torch.Tensor
+    bias: torch.Tensor
+
+
 class Decoder(nn.Module):
     def __init__(self, cp, widths, ncls):
         super().__init__()
@@ -174,9 +181,10 @@ class Decoder(nn.Module):
         self.up4 = UpBlock(w8, w4, w4)
         self.head = nn.Conv2d(w4, ncls, 1)
 
-    def forward(self, f, f8, f4, size):
+    def forward(self, f, f8, f4, size, head_fused=False):
         """size = (H, W): full-resolution logits; size = None: the stride-4 logits (segment() upsamples them inside
-        the fused argmax kernel instead of materialising them)."""
+        the fused argmax kernel instead of materialising them); head_fused (with size None, inference on the GPU): the stride-4
+        FEATURE and the head's fp32 weights as a HeadFeature -- segment() folds the head into the argmax kernel too."""
         y = self.up4(self.up8(f, f8), f4)
         hd = self.head
         v = 8 if y.dtype == torch.bfloat16 else 4
@@ -190,6 +198,8 @@ class Decoder(nn.Module):
             if cache is None or cache[0] != key:
                 cache = (key, hd.weight.detach().reshape(hd.out_channels, -1).float().contiguous(), hd.bias.detach().float().contiguous())
                 self._head_w32 = cache
+            if head_fused and size is None:
+                return HeadFeature(y, cache[1], cache[2])
             x = ops.head_logits(y, cache[1], cache[2])
         else:
             x = hd(y)
@@ -433,7 +443,7 @@ class GDKVM(nn.Module):
         return x.permute(0, 2, 3, 1).reshape(x.shape[0], x.shape[2] * x.shape[3], x.shape[1]).contiguous()
 
     def forward(self, frames: torch.Tensor, mask0: Optional[torch.Tensor] = None,
-                state: Optional[torch.Tensor] = None, return_state: bool = False, _lowres: bool = False):
+                state: Optional[torch.Tensor] = None, return_state: bool = False, _lowres: bool = False, _head_fused: bool = False):
         if frames.dim() != 5:
             raise ValueError("frames must be [B,T,C,H,W]")
         cfg = self.cfg
@@ -455,11 +465,11 @@ class GDKVM(nn.Module):
         _BN_COUNTED_BY_MODEL[0] = counted
         try:
             f4, f8, f16 = self.encoder(x)
-            return self._after_encoder(f4, f8, f16, mask0, state, return_state, _lowres, (B, T, H, W))
+            return self._after_encoder(f4, f8, f16, mask0, state, return_state, _lowres, (B, T, H, W), _head_fused)
         finally:
             _BN_COUNTED_BY_MODEL[0] = False
 
-    def _after_encoder(self, f4, f8, f16, mask0, state, return_state, _lowres, dims):
+    def _after_encoder(self, f4, f8, f16, mask0, state, return_state, _lowres, dims, _head_fused=False):
         cfg = self.cfg
         B, T, H, W = dims
         Hh, Dk, Dv = cfg.heads, cfg.key_dim, cfg.value_dim
@@ -524,7 +534,9 @@ class GDKVM(nn.Module):
         r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state)
         fused = self._fuse(k_tok, r.reshape(B * T, N, Hh * Dv), p_tok, h, w)       # [BT,N,Cp]
         fmap = fused.reshape(B * T, h, w, -1).permute(0, 3, 1, 2)                  # channels_last view, no copy
-        logits = self.decoder(fmap, f8, f4, None if _lowres else (H, W))
+        logits = self.decoder(fmap, f8, f4, None if _lowres else (H, W), head_fused=_head_fused and _lowres and not return_state)
+        if isinstance(logits, HeadFeature):
+            return logits
         logits = logits.reshape(B, T, cfg.num_classes, *logits.shape[-2:])
         return (logits, s_out) if return_state else logits
 
@@ -574,9 +586,13 @@ class GDKVM(nn.Module):
     def segment(self, frames, target=None, **kw):
         """logits -> (mask uint8 [B,T,H,W], Dice counts int32 [B,T,ncls,3] | None) with the HIP argmax kernel."""
         B, T, _, H, W = frames.shape
-        lowres = self.forward(frames, _lowres=True, **kw)                     # [B,T,ncls,H/4,W/4]
-        ncls, hl, wl = lowres.shape[2:]
         tgt = None if target is None else target.reshape(B * T, H, W).contiguous()
+        lowres = self.forward(frames, _lowres=True, _head_fused=True, **kw)   # [B,T,ncls,H/4,W/4], or the feature under the head
+        if isinstance(lowres, HeadFeature):
+            # head + upsample + argmax + Dice in one kernel: the class planes never reach memory (bit-identical to the two-kernel form)
+            mask, counts = ops.head_upsample_argmax_dice(lowres.feature, lowres.weight, lowres.bias, H, W, tgt)
+            return mask.reshape(B, T, H, W), (None if counts is None else counts.reshape(B, T, lowres.weight.shape[0], 3))
+        ncls, hl, wl = lowres.shape[2:]
         mask, counts = ops.upsample_argmax_dice(lowres.reshape(B * T, ncls, hl, wl).contiguous(), H, W, tgt)
         return mask.reshape(B, T, H, W), (None if counts is None else counts.reshape(B, T, ncls, 3))
 

@@ -74,6 +74,7 @@ SIGNATURES = {
     "gdkvm_bias_relu_maxpool": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
     "gdkvm_stem_s2d": (_i, [_vp] * 2 + [_i] * 6 + [_vp]),
     "gdkvm_upsample_argmax_dice": (_i, [_vp] * 4 + [_i] * 7 + [_vp]),
+    "gdkvm_head_upsample_argmax_dice": (_i, [_vp] * 6 + [_i] * 8 + [_vp]),
     "gdkvm_maxpool_fwd": (_i, [_vp] * 3 + [_i] * 5 + [_vp]),
     "gdkvm_maxpool_bwd": (_i, [_vp] * 3 + [_i] * 5 + [_vp]),
     "gdkvm_seg_loss_workspace_bytes": (_sz, [_i]),
@@ -610,6 +611,33 @@ def upsample_argmax_dice(logits: torch.Tensor, H: int, W: int, target: Optional[
         rc = lib.gdkvm_upsample_argmax_dice(_ptr(logits), _ptr(target), _ptr(mask), _ptr(counts), BT, ncls, hl, wl, H, W,
                                             _io_dtype(logits), _stream(dev))
     _check(rc, "gdkvm_upsample_argmax_dice")
+    return mask, counts
+
+
+def head_upsample_argmax_dice(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, H: int, W: int,
+                              target: Optional[torch.Tensor] = None):
+    """The decoder's 1x1 head + bilinear upsample + argmax + Dice counts in one kernel (gdkvm_head_upsample_argmax_dice): x is the
+    channels_last stride-4 feature [BT,C,hl,wl], weight fp32 [classes, C], bias fp32 [classes]; the class planes never reach memory.
+    Bit-identical to head_logits followed by upsample_argmax_dice.  Returns (mask u8 [BT,H,W], counts i32 [BT,classes,3] | None)."""
+    lib = load()
+    if x.dim() != 4 or not x.is_cuda or not x.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("head_upsample_argmax_dice needs a channels_last [BT,C,hl,wl] device tensor (no CPU path)")
+    BT, C, hl, wl = x.shape
+    ncls = weight.shape[0]
+    if weight.dtype != torch.float32 or bias.dtype != torch.float32 or tuple(weight.shape) != (ncls, C) or bias.numel() != ncls \
+            or not weight.is_contiguous():
+        raise GdkvmError("head_upsample_argmax_dice: weight fp32 [classes, C] (contiguous), bias fp32 [classes]")
+    dev = _dev(weight, bias, target)                       # (x is channels_last: checked above)
+    if dev != x.device:
+        raise GdkvmError("all tensors must live on one device")
+    if target is not None and (target.dtype != torch.uint8 or tuple(target.shape) != (BT, H, W)):
+        raise GdkvmError("target must be uint8 [BT,H,W]")
+    mask = torch.empty((BT, H, W), dtype=torch.uint8, device=dev)
+    counts = torch.empty((BT, ncls, 3), dtype=torch.int32, device=dev) if target is not None else None
+    with torch.cuda.device(dev):
+        rc = lib.gdkvm_head_upsample_argmax_dice(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(target), _ptr(mask), _ptr(counts),
+                                                 BT, C, ncls, hl, wl, H, W, _io_dtype(x), _stream(dev))
+    _check(rc, "gdkvm_head_upsample_argmax_dice")
     return mask, counts
 
 

@@ -246,6 +246,13 @@ int gdkvm_argmax_dice(const void* logits, const uint8_t* target, uint8_t* mask, 
 int gdkvm_upsample_argmax_dice(const void* logits, const uint8_t* target, uint8_t* mask, int32_t* counts,
                                int BT, int ncls, int hl, int wl, int H, int W, int io_dtype, void* stream);
 
+/* ... and with the decoder's 1x1 head folded in as well: x [BT, hl, wl, C] is the stride-4 feature (NHWC, io_dtype), w [ncls, C] and
+ * b [ncls] (fp32) the head; every block computes the class planes of the low-resolution rows it needs into LDS, with
+ * gdkvm_head_logits' arithmetic and rounding -- masks and counts are bit-identical to gdkvm_head_logits followed by
+ * gdkvm_upsample_argmax_dice, and the class planes never reach memory.  C/8 (bf16) or C/4 (f32) a power of two <= 64, ncls <= it. */
+int gdkvm_head_upsample_argmax_dice(const void* x, const float* w, const float* b, const uint8_t* target, uint8_t* mask,
+                                    int32_t* counts, int BT, int C, int ncls, int hl, int wl, int H, int W, int io_dtype, void* stream);
+
 /* SURVEY.md §8(f) row n1 (inference build only): fused pointwise epilogue for the unchanged MIOpen convolutions,
  * y[r, c] = act(x[r, c] + bias[c] (+ residual[r, c])) over an NHWC tensor viewed as [rows, C]; relu != 0 applies ReLU.
  * x, residual, y in io_dtype (y may alias x), bias fp32.  C must be a multiple of 4 (f32) / 8 (bf16). */

@@ -132,6 +132,32 @@ def test_upsample_argmax_dice_bit_exact(hip, case, dtype):
     assert (ref.numpy() != mo).mean() <= 2e-3
 
 
+@pytest.mark.parametrize("case", [(5, 64, 2, 28, 28, 112, 112), (2, 32, 4, 64, 64, 256, 256), (3, 64, 3, 7, 5, 30, 17), (2, 128, 6, 9, 8, 36, 32),
+                                  (600, 64, 2, 28, 28, 112, 112)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_head_folded_into_the_argmax_kernel(hip, case, dtype):
+    """gdkvm_head_upsample_argmax_dice == gdkvm_head_logits then gdkvm_upsample_argmax_dice, bit for bit (masks and counts): every
+    block computes the class planes of the low-resolution rows it needs, with the head kernel's sums and its rounding."""
+    BT, C, ncls, hl, wl, H, W = case
+    g = torch.Generator().manual_seed(sum(case[1:]))
+    x = torch.randn(min(BT, 8), C, hl, wl, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    if BT > 8:
+        x = x.repeat(BT // 8, 1, 1, 1).contiguous(memory_format=torch.channels_last)
+    BT = x.shape[0]
+    w = (torch.randn(ncls, C, generator=g) / C ** 0.5).cuda()
+    b = torch.randn(ncls, generator=g).cuda()
+    target = torch.randint(0, ncls + 1, (BT, H, W), generator=g, dtype=torch.uint8).cuda()
+    lo = hip.head_logits(x, w, b)
+    m0, c0 = hip.upsample_argmax_dice(lo, H, W, target)
+    m1, c1 = hip.head_upsample_argmax_dice(x, w, b, H, W, target)
+    assert torch.equal(m0, m1) and torch.equal(c0, c1)
+    m2, c2 = hip.head_upsample_argmax_dice(x, w, b, H, W)
+    assert c2 is None and torch.equal(m2, m0)
+    assert len(torch.unique(m0)) >= 2                              # (a mixed mask: the comparison is not vacuous)
+    with pytest.raises(hip.GdkvmError):
+        hip.head_upsample_argmax_dice(x[:, :C - 8].contiguous(memory_format=torch.channels_last) if C > 8 else x, w, b, H, W)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(3, 64, 28, 28), (2, 8, 5, 7), (1, 256, 7, 7)])
 def test_bias_act_epilogue(hip, dtype, shape):
