@@ -170,6 +170,20 @@ def test_segmented_scan_choice_by_shape(hip):
         hip.scan_fwd_segmented(*t, segments=8, flags=3, workspace=ws)
 
 
+def test_segmented_scan_on_the_fused_chunk_walk(hip):
+    """Segments of a long clip of 130-token frames: B * segments = 8 pseudo-clips and 256 frames -- the frame-parallel side takes the
+    fused chunk walk with the XCD-aware frame order -- against the serial scan and the oracle."""
+    B, T, N, Hh, Dk, Dv = 2, 128, 130, 1, 64, 64
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=31, normalized=False, logits=True, corr=0.5)
+    t = [_dev(x, torch.bfloat16) for x in (q, k, v)] + [_dev(a), _dev(b)]
+    R, S = hip.scan_fwd(*t, flags=3)
+    R2, S2 = hip.scan_fwd_segmented(*t, segments=4, flags=3)
+    assert (S - S2).abs().max() <= 1e-4
+    assert ((R.float() - R2.float()).abs() <= 1e-4 + R.float().abs() * 2.0 ** -7).all()
+    _, So = c_oracle.scan(*(O.to_bf16_f32(x[:1]) for x in (q, k, v)), a[:1], b[:1], None, 2, 3)
+    assert np.abs(S2[:1].cpu().numpy() - So).max() <= 1e-4
+
+
 def test_context_parallel_scan_single_rank_hip_backend(hip):
     """The cross-GPU stitch with the HIP backend and a world of one degenerates to a plain scan (bit for bit)."""
     from gdkvm_amd.distributed import context_parallel_scan

@@ -50,7 +50,8 @@ def test_scan_fp32_ragged_shapes(hip, shape):
     assert np.abs(Rg - Ro).max() <= TOL and np.abs(Sg - So).max() <= TOL
 
 
-@pytest.mark.parametrize("case", [(2, 3, 65, 1, 64), (1, 4, 100, 2, 128), (3, 2, 130, 1, 192), (2, 2, 250, 1, 256), (1, 3, 256, 1, 256), (1, 2, 1024, 1, 64)])
+@pytest.mark.parametrize("case", [(2, 3, 65, 1, 64), (1, 4, 100, 2, 128), (3, 2, 130, 1, 192), (2, 2, 250, 1, 256), (1, 3, 256, 1, 256), (1, 2, 1024, 1, 64),
+                                  (8, 2, 130, 1, 64), (16, 17, 70, 1, 128)])      # (8 / 16 clips: the XCD-aware frame order; 272 frames: the default choice)
 @pytest.mark.parametrize("rule", [0, 2])
 def test_fused_chunk_walk_is_the_chunk_parallel_path_bit_for_bit(hip, case, rule, monkeypatch):
     """Frames of more than 64 tokens, bf16: gdr_prepm_kernel walking a frame's chunks in ONE workgroup with the running map in
