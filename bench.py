@@ -216,6 +216,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the scan timings at the other BASELINE shapes")
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU")
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--size", type=int, default=112)
@@ -368,6 +369,30 @@ def main():
             "upsample_argmax_dice_kernel": {"avg_ms": round(am_ms, 4), "algorithmic_bytes": am_bytes,
                                             "achieved_GBps": round(am_bytes / (am_ms * 1e-3) / 1e9, 1),
                                             "frac": round(am_bytes / (am_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
+        # the same fraction for the scan at the other BASELINE.json shapes that fit one GPU (informational, same timing method,
+        # a few launches each): configs[2] CAMUS 256x256x20 (N = 256 tokens per frame) and configs[4], the 512-frame 256x256 clip
+        # -- as one gdkvm_scan_fwd call, and as gdkvm_scan_fwd_segmented with the segment count it picks for that shape
+        if (B, T, S) == (16, 32, 112) and not args.no_other_configs:
+            other = {}
+            for name, b2, t2, n2 in (("configs[2] 8x20 frames, 256 tokens", 8, 20, 256), ("configs[4] 2x512 frames, 256 tokens", 2, 512, 256)):
+                q2, k2 = (torch.randn(b2, t2, n2, Hh, Dk, device=dev, generator=gq).bfloat16() for _ in range(2))
+                v2 = torch.randn(b2, t2, n2, Hh, Dv, device=dev, generator=gq).bfloat16()
+                al2 = 2 + torch.randn(b2, t2, Hh, device=dev, generator=gq)
+                be2 = torch.randn(b2, t2, n2, Hh, device=dev, generator=gq)
+                ws2 = torch.empty(ops.scan_workspace_bytes(b2, t2, Hh, n2, Dk, Dv), dtype=torch.uint8, device=dev)
+                r2 = torch.empty(b2, t2, n2, Hh, Dv, device=dev, dtype=torch.bfloat16)
+                s2 = torch.empty(b2, Hh, Dk, Dv, device=dev)
+                ms, _ = time_events(lambda: ops.scan_fwd(q2, k2, v2, al2, be2, flags=3, workspace=ws2, out=r2, state_out=s2), 5)
+                alg2 = scan_algorithmic_bytes(b2, t2, n2, Hh, Dk, Dv, 2)
+                ent = {"scan_fwd_ms": round(ms, 4), "algorithmic_bytes": alg2, "frac": round(alg2 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                nseg = int(ops.load().gdkvm_scan_segments(b2, t2, Hh, Dv, 0))
+                if nseg > 1:
+                    ms_s, _ = time_events(lambda: ops.scan_fwd_segmented(q2, k2, v2, al2, be2, flags=3), 5)
+                    ent["segmented"] = {"segments": nseg, "scan_fwd_ms": round(ms_s, 4),
+                                        "frac": round(alg2 / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                other[name] = ent
+                del q2, k2, v2, al2, be2, ws2, r2, s2
+            out["roofline"]["other_configs"] = other
         # ---- CPU baseline: the oracle module on a bounded sample of the same workload (N=1 only) -----------
         if world == 1 and not args.no_cpu_baseline:
             cores = host_cores()
