@@ -1110,6 +1110,8 @@ int launch_prep(const PrepArgs& pa, int FH, hipStream_t st)
 
 extern "C" size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
 {
+    if (gdr_narrow_keys(Dk) && B > 0 && T > 0 && Hh > 0 && N > 0 && Dv > 0 && N <= GDKVM_MAX_N)      // (gdkvm_scan_fwd's zero-extended copies)
+        return gdr_up256(gdr_workspace_bytes(B, T, Hh, N, GDKVM_DK, Dv)) + gdr_narrow_extra_bytes(B, T, Hh, N, Dv);
     return gdr_workspace_bytes(B, T, Hh, N, Dk, Dv);
 }
 

@@ -623,6 +623,31 @@ extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const
                               int B, int T, int Hh, int N, int Dk, int Dv,
                               int io_dtype, int rule, int flags, void* stream)
 {
+    if (gdr_narrow_keys(Dk) && B > 0 && T > 0 && N > 0) {
+        // key widths 8 .. 56: the Dk = 64 kernels on zero-extended copies of q, k and the state (gdr_ws.hpp)
+        if (s_hist) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: s_hist needs Dk=%d (training pads the keys itself)", GDKVM_DK);
+        if (io_dtype != GDKVM_F32 && io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "scan_fwd: io_dtype=%d", io_dtype);
+        if (Hh <= 0 || Dv <= 0 || Dv % 16 || N > GDKVM_MAX_N) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: Hh=%d N=%d Dv=%d", Hh, N, Dv);
+        if (int rc = check_ptrs("scan_fwd", {q, k, v, alpha, beta, workspace}, {s_in, r_out, s_out})) return rc;
+        const size_t base = gdr_up256(gdr_workspace_bytes(B, T, Hh, N, GDKVM_DK, Dv));
+        if (workspace_bytes < base + gdr_narrow_extra_bytes(B, T, Hh, N, Dv))
+            return gdkvm_fail(GDKVM_ERR_WORKSPACE, "scan_fwd: workspace %zu < %zu bytes", workspace_bytes, base + gdr_narrow_extra_bytes(B, T, Hh, N, Dv));
+        if (int rc = gdkvm_check_device()) return rc;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const size_t es = io_dtype == GDKVM_F32 ? 4 : 2, rows = (size_t)B * T * N * Hh, BH = (size_t)B * Hh;
+        char* p = static_cast<char*>(workspace) + base;
+        char* q_p = p;  p += gdr_up256(rows * GDKVM_DK * 4);
+        char* k_p = p;  p += gdr_up256(rows * GDKVM_DK * 4);
+        float* si_p = reinterpret_cast<float*>(p);  p += gdr_up256(BH * GDKVM_DK * Dv * 4);
+        float* so_p = reinterpret_cast<float*>(p);
+        const size_t rq = Dk * es / 16, rq64 = GDKVM_DK * es / 16, sq = (size_t)Dk * Dv * 4 / 16, sq64 = (size_t)GDKVM_DK * Dv * 4 / 16;
+        if (int rc = gdr_block_copy(q, q_p, rows, rq, rq64, rq, rq64, st)) return rc;
+        if (int rc = gdr_block_copy(k, k_p, rows, rq, rq64, rq, rq64, st)) return rc;
+        if (s_in) if (int rc = gdr_block_copy(s_in, si_p, BH, sq, sq64, sq, sq64, st)) return rc;
+        if (int rc = gdkvm_scan_fwd(q_p, k_p, v, alpha, beta, s_in ? si_p : nullptr, r_out, s_out ? so_p : nullptr, nullptr, workspace, base,
+                                    B, T, Hh, N, GDKVM_DK, Dv, io_dtype, rule, flags, stream)) return rc;
+        return s_out ? gdr_block_copy(so_p, s_out, BH, sq64, sq, sq, sq, st) : GDKVM_OK;
+    }
     if (s_hist) flags |= GDKVM_FLAG_TRAIN;              // the backward reads extra operand layouts from the workspace
     if (rule == GDKVM_RULE_DELTA_PARALLEL) flags |= GDKVM_FLAG_WIDE_RANGE;      // not contractive: full-range operands
     if (int rc = gdkvm_scan_prep(q, k, v, beta, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream)) return rc;

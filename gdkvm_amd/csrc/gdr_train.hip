@@ -58,7 +58,7 @@ __global__ void gdr_unpad_gates_kernel(const float* __restrict__ da_p, const flo
     }
 }
 
-inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline size_t up256(size_t x) { return gdr_up256(x); }
 
 struct TrainView {
     int C, Np, Tc;
@@ -115,6 +115,15 @@ int train_check(const char* fn, void* ws, size_t ws_bytes, int B, int T, int Hh,
 unsigned copy_grid(size_t n) { const size_t g = (n + 255) / 256; return (unsigned)(g > 16384 ? 16384 : (g ? g : 1)); }
 
 }  // namespace
+
+int gdr_block_copy(const void* src, void* dst, size_t nblk, size_t src_q, size_t dst_q, size_t copy_q, size_t fill_q, hipStream_t st)
+{
+    if (nblk == 0 || fill_q == 0) return GDKVM_OK;
+    hipLaunchKernelGGL(gdr_block_copy_kernel, dim3(copy_grid(nblk * fill_q)), dim3(256), 0, st, static_cast<const uint4*>(src),
+                       static_cast<uint4*>(dst), nblk, src_q, dst_q, copy_q, fill_q);
+    GDKVM_LAUNCH_CHECK("gdr_block_copy_kernel");
+    return GDKVM_OK;
+}
 
 extern "C" size_t gdkvm_scan_train_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype)
 {

@@ -42,6 +42,18 @@ static inline size_t gdr_workspace_bytes(int B, int T, int Hh, int N, int Dk, in
     return (size_t)B * T * Hh * gdr_ws_floats_per_fh(N, Dk, Dv) * sizeof(float) + GDKVM_WS_TAIL;
 }
 
+// Key widths below the kernels' 64 (multiples of 8): gdkvm_scan_fwd runs the Dk = 64 kernels on zero-extended copies of q, k and the
+// state kept behind the regular workspace -- norms, Gram matrices and read-outs are unchanged by zero channels, P stays the identity
+// on the extra rows and the extra rows of the state stay zero, so the result on the real rows is that of the narrower problem.
+static inline bool gdr_narrow_keys(int Dk) { return Dk >= 8 && Dk < GDKVM_DK && Dk % 8 == 0; }
+static inline size_t gdr_up256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline size_t gdr_narrow_extra_bytes(int B, int T, int Hh, int N, int Dv)
+{   // q and k rows at 64 channels (sized for fp32), state in and out at 64 rows
+    return 2 * gdr_up256((size_t)B * T * N * Hh * GDKVM_DK * 4) + 2 * gdr_up256((size_t)B * Hh * GDKVM_DK * Dv * 4);
+}
+// 16-byte units: block b of nblk copies copy_q units from src + b*src_q to dst + b*dst_q and zero-fills up to fill_q (gdr_train.hip)
+int gdr_block_copy(const void* src, void* dst, size_t nblk, size_t src_q, size_t dst_q, size_t copy_q, size_t fill_q, hipStream_t st);
+
 static inline int carve(const char* fn, void* workspace, size_t workspace_bytes, int B, int T, int Hh, int N, int Dk, int Dv, WsView* v)
 {
     const size_t need = gdr_workspace_bytes(B, T, Hh, N, Dk, Dv);

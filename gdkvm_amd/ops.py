@@ -183,8 +183,8 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
     lib = load()
     if q.dim() != 5 or k.shape != q.shape or v.dim() != 5 or v.shape[:4] != q.shape[:4]:
         raise GdkvmError(f"bad shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
-    if q.shape[-1] < KERNEL_DK and state_hist is None:      # narrower keys: exact through zero channels (see _pad_keys)
-        qp, kp, sp = _pad_keys(q, k, state)
+    if q.shape[-1] < KERNEL_DK and state_hist is None and q.shape[-1] % 8:      # key widths that are no multiple of 8: padded here
+        qp, kp, sp = _pad_keys(q, k, state)                # (multiples of 8 below 64: gdkvm_scan_fwd zero-extends them itself)
         r, s = scan_fwd(qp, kp, v, alpha, beta, sp, rule, flags, workspace, out, None, None, readout)
         s = s[:, :, :q.shape[-1]].contiguous()
         if state_out is not None:

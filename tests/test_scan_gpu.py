@@ -266,8 +266,8 @@ def test_scan_frames_of_more_than_256_tokens(hip, N, dtype):
 
 
 def test_scan_rejects_what_the_kernels_are_not_built_for(hip):
-    """The limits that remain fail loudly with a message (never a silent fallback): Dk other than 64 at the C ABI, Dv not a
-    multiple of 16, more than 4096 tokens per frame, unknown flags."""
+    """The limits that remain fail loudly with a message (never a silent fallback): Dk above 64 or no multiple of 8 at the C ABI, Dv
+    not a multiple of 16, more than 4096 tokens per frame, unknown flags."""
     from gdkvm_amd import ops
     def call(N=8, Dk=64, Dv=16, flags=0):
         lib = ops.load()
@@ -276,14 +276,43 @@ def test_scan_rejects_what_the_kernels_are_not_built_for(hip):
         return lib.gdkvm_scan_fwd(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.data_ptr(), z.data_ptr(), None,
                                   ws.data_ptr(), ws.numel(), 1, 1, 1, N, Dk, Dv, 0, 2, flags, None)
     assert call() == 0
-    for kw, msg in [(dict(Dk=32), "Dk=32"), (dict(Dk=128), "Dk=128"), (dict(Dv=24), "Dv=24"), (dict(N=4097), "N=4097"), (dict(flags=64), "flags")]:
+    for kw, msg in [(dict(Dk=36), "Dk=36"), (dict(Dk=128), "Dk=128"), (dict(Dv=24), "Dv=24"), (dict(N=4097), "N=4097"), (dict(flags=64), "flags")]:
         assert call(**kw) == -1 and msg in ops.load().gdkvm_last_error().decode(), kw
 
 
-@pytest.mark.parametrize("Dk", [32, 16, 48])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(32, 49, 32), (8, 7, 16), (56, 130, 64)])
+def test_scan_narrow_keys_at_the_c_abi(hip, case, dtype):
+    """gdkvm_scan_fwd with 8 <= Dk < 64 (multiples of 8): the call zero-extends q, k and the state inside its workspace -- the same
+    bits as the host-side padding (ops._pad_keys) onto the Dk = 64 kernels, and right against the oracle run at the narrow width;
+    s_hist (training) at a narrow width is refused."""
+    from gdkvm_amd import ops
+    Dk, N, Dv = case
+    q, k, v, a, b = make_scan_inputs(2, 3, N, 1, Dk, Dv, seed=Dk + N, normalized=False, logits=True, corr=0.4)
+    s0 = (0.2 * np.random.default_rng(Dk).standard_normal((2, 1, Dk, Dv))).astype(np.float32)
+    t = [_dev(x, dtype) for x in (q, k, v)] + [_dev(a), _dev(b)]
+    st = _dev(s0)
+    assert ops.scan_workspace_bytes(2, 3, 1, N, Dk, Dv) > ops.scan_workspace_bytes(2, 3, 1, N, 64, Dv)
+    R, S = hip.scan_fwd(*t, st, flags=3)
+    qp, kp, sp = ops._pad_keys(t[0], t[1], st)
+    R2, S2 = hip.scan_fwd(qp, kp, t[2], t[3], t[4], sp, flags=3)
+    assert S.shape == (2, 1, Dk, Dv) and torch.equal(R, R2) and torch.equal(S, S2[:, :, :Dk]) and not S2[:, :, Dk:].any()
+    inp = [O.to_bf16_f32(x) for x in (q, k, v)] if dtype == torch.bfloat16 else [q, k, v]
+    Ro, So = c_oracle.scan(*inp, a, b, s0, 2, 3, math="f64")
+    assert np.abs(S.cpu().numpy() - So).max() <= TOL
+    assert np.all(np.abs(R.float().cpu().numpy() - Ro) <= TOL + (np.abs(Ro) * 2.0 ** -8 if dtype == torch.bfloat16 else 0))
+    R3, S3 = hip.scan_fwd(*t, None, flags=3)              # no state in
+    Ro3, So3 = c_oracle.scan(*inp, a, b, None, 2, 3, math="f64")
+    assert np.abs(S3.cpu().numpy() - So3).max() <= TOL
+    hist = torch.empty(2, 3, 1, Dk, Dv, device="cuda")
+    with pytest.raises(hip.GdkvmError, match="s_hist"):
+        hip.scan_fwd(*t, st, flags=3, state_hist=hist)
+
+
+@pytest.mark.parametrize("Dk", [32, 16, 48, 20])
 def test_scan_narrower_key_dims_through_zero_channels(hip, Dk):
-    """Dk below 64 at the host seam (gdkvm_amd/ops.py pads zero key channels onto the Dk = 64 kernels): exact against the oracle
-    run at the narrow Dk, state carried in and out at [B,Hh,Dk,Dv]."""
+    """Dk below 64 (multiples of 8 inside gdkvm_scan_fwd, other widths padded at the host seam in gdkvm_amd/ops.py): exact against
+    the oracle run at the narrow Dk, state carried in and out at [B,Hh,Dk,Dv]."""
     q, k, v, a, b = make_scan_inputs(2, 4, 49, 1, Dk, 32, seed=Dk, normalized=False, logits=True, corr=0.4)
     s0 = np.random.default_rng(Dk).standard_normal((2, 1, Dk, 32)).astype(np.float32) * 0.2
     Rg, Sg = _run(hip, q, k, v, a, b, s0, 2, 3)
