@@ -9,6 +9,8 @@ int gdkvm_conv3x3_c64_launch(const void* x, const void* w, const float* bias, co
                              int relu, int packed, hipStream_t st);   // conv3x3_c64.hip
 int gdkvm_conv3x3_tile_launch(const void* x, const void* x2, int C1, const void* w, const float* bias, const void* residual, void* y,
                               int N, int C, int H, int W, int K, int relu, int variant, int packed, hipStream_t st);   // conv3x3_tile.hip
+int gdkvm_conv_igemm_launch(const void* x, const void* wpacked, const float* bias, const void* residual, void* y,
+                            int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, hipStream_t st);   // conv_igemm.hip
 
 extern "C" int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y,
                                    int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, int kernel,
@@ -21,12 +23,26 @@ extern "C" int gdkvm_conv_bias_act(const void* x, const void* w, const float* bi
                           N, C, H, W, K, R, S, stride, pad);
     const bool packed = kernel & GDKVM_CONV_PACKED_WEIGHTS;
     kernel &= ~GDKVM_CONV_PACKED_WEIGHTS;
-    if (kernel != 0 && (kernel < 4 || kernel > 8)) return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: kernel=%d (0 = by shape, 4, 5, 6..8)", kernel);
+    if (kernel != 0 && (kernel < 4 || kernel > 9)) return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: kernel=%d (0 = by shape, 4, 5, 6..8, 9)", kernel);
+    if (kernel == 9) {
+        // the general implicit-GEMM kernel: any R x S / stride / pad, weights as gdkvm_conv_igemm_pack_weights wrote them
+        if (!packed) return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: kernel 9 reads the gdkvm_conv_igemm_pack_weights copy of the weights (flag %d)", GDKVM_CONV_PACKED_WEIGHTS);
+        if (C % 32 || K % 128) return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: kernel 9 needs C a multiple of 32 and K of 128 (C=%d K=%d)", C, K);
+        if (N == 0) return GDKVM_OK;
+        if (!x || !w || !bias || !y) return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: null pointer");
+        if (!gdkvm_aligned16(x) || !gdkvm_aligned16(w) || !gdkvm_aligned16(y) || !gdkvm_aligned16(bias) || (residual && !gdkvm_aligned16(residual)))
+            return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: pointers must be 16-byte aligned");
+        if (int rc = gdkvm_check_device()) return rc;
+        if (gdkvm_conv_igemm_launch(x, w, bias, residual, y, N, C, H, W, K, R, S, stride, pad, relu, static_cast<hipStream_t>(stream)))
+            return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: N=%d C=%d H=%d W=%d K=%d %dx%d stride %d pad %d is too large for 32-bit offsets", N, C, H, W, K, R, S, stride, pad);
+        GDKVM_LAUNCH_CHECK("conv_igemm_kernel");
+        return GDKVM_OK;
+    }
     if (packed && (C % 64 || K % 16))
         return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: packed weights need C a multiple of 64 and K of 16 (C=%d K=%d)", C, K);
     if (!(R == 3 && S == 3 && stride == 1 && pad == 1))
-        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: %dx%d stride %d pad %d is not served by the hand-written kernels (3x3 / 1 / 1): "
-                                           "use the framework convolution + gdkvm_bias_act", R, S, stride, pad);
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: %dx%d stride %d pad %d is not served by the 3x3 / 1 / 1 kernels: kernel 9 (the "
+                                           "implicit-GEMM kernel, packed weights) or the framework convolution + gdkvm_bias_act", R, S, stride, pad);
     if (N == 0) return GDKVM_OK;
     if (!x || !w || !bias || !y) return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: null pointer");
     if (!gdkvm_aligned16(x) || !gdkvm_aligned16(w) || !gdkvm_aligned16(y) || !gdkvm_aligned16(bias) || (residual && !gdkvm_aligned16(residual)))

@@ -1,0 +1,238 @@
+// conv_igemm.hip -- SURVEY.md §8f row n1: the convolutions the two specialised kernels do not take -- strided layers, 1x1 layers,
+// rows wider than 64 pixels -- as ONE hand-written implicit-GEMM kernel (NHWC bf16, bias (+ residual) (+ ReLU) in the epilogue).
+// Until the end of round 2 these went to the framework convolution followed by a gdkvm_bias_act pass (four layers of an EchoNet
+// forward: the two 3x3 / stride-2 convolutions and the two 1x1 / stride-2 downsamples, 99 us of 1.04 ms).
+//
+//   out[p][k] = act(bias[k] + sum_{r, s, c} x[pixel(p) * stride + (r, s) - pad][c] w[k][r][s][c]),   M = N Ho Wo pixels, Kd = R S C
+//
+//   * a workgroup of 4 waves owns 256 output pixels x 128 output channels; wave (wm, wn) 128 pixels x 64 channels = 8 x 4
+//     accumulator tiles (the larger the wave tile, the fewer operand bytes per MFMA: at 64 x 64 both LDS and the vector-memory path
+//     of a CU would be over their rate at half the MFMA peak);
+//   * per k-step (32 of the Kd products: one tap, 32 channels -- C is a multiple of 32, so a k-step never straddles taps) the 256
+//     pixels' 64-byte channel runs are GATHERED into LDS, one pixel row 80 bytes apart (64 + 16: a ds_read_b128 of 16 consecutive
+//     pixels is conflict-free), double-buffered: the gather of k-step s+1 is in flight as register loads behind the MFMAs of s;
+//     out-of-image taps are zeros;
+//   * the weights never touch LDS: packed in MFMA-fragment order (gdkvm_conv_igemm_pack_weights: fragment (n-tile, k-step) = one
+//     contiguous KiB), streamed from L2 into a ring of register sets two k-steps ahead;
+//   * weights are the A operand, pixels the B operand: a lane ends with 4 consecutive output channels of one pixel (8-byte stores).
+// Arithmetic: fp32 accumulation over the same R S C products as a library convolution, one rounding after the epilogue.
+#include <atomic>
+#include <type_traits>
+
+#include "gdkvm_common.hpp"
+
+namespace {
+
+constexpr int IG_TN = 128;                       // workgroup tile: channels (pixels: the template parameter TM)
+constexpr int IG_GD = 2;                         // gather distance, k-steps (two register sets)
+
+struct IgArgs {
+    const bf16_t* x; const bf16_t* w; const float* bias; const bf16_t* res; bf16_t* y;
+    int N, H, W, C, K, R, S, stride, pad, Ho, Wo, relu;
+    int M, ksteps, cps;                          // output pixels; Kd / 32; k-steps per tap (C / 32)
+    float inv_cps, inv_s;                        // per-k-step index arithmetic without integer division (see conv3x3_tile.hip: ct_div)
+};
+
+__device__ __forceinline__ int ig_div(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
+
+template <int I, int E, class F>
+__device__ __forceinline__ void ig_static_for(F&& f)
+{
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        ig_static_for<I + 1, E>(f);
+    }
+}
+
+// TM = pixels per workgroup (128: wave (wm, wn) owns 64 pixels x 64 channels, 4 x 4 accumulator tiles); SUB = 32-deep MFMA k-steps
+// per barrier: with C a multiple of 64 a step gathers 128-byte channel runs (two MFMA k-steps: half the barriers, LDS round trips
+// and index arithmetic per MFMA); SUB = 1 serves channel counts that are only multiples of 32.
+template <int TM, int SUB>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
+{
+    constexpr int MT = TM / 32;                  // 16-pixel tiles per wave
+    constexpr int PITCH = SUB == 2 ? 160 : 80;   // bytes between pixel rows of the LDS tile: 128 + 32 or 64 + 16 (conflict-free ds_read_b128)
+    constexpr int PPP = 4 * SUB;                 // 16-byte pieces per pixel and step
+    constexpr int GP = TM * PPP / 256;           // pieces per thread and step
+    constexpr int WD = SUB == 2 ? 2 : 3;         // weight ring depth, steps
+    constexpr int UF = SUB == 2 ? 2 : 6;         // unroll: lcm(weight ring, two gather sets) -> static register indices
+    __shared__ __attribute__((aligned(16))) unsigned char s_a[2][TM * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * IG_TN;
+    const int nsteps = a.ksteps / SUB;           // steps of 32 SUB products
+
+    // ---- gather geometry: piece q = 256 u + tid is 16-byte part q % PPP of the channel run of tile pixel q / PPP: PPP lanes share a
+    //      run, a wave instruction touches 64 / PPP runs ----------------------------------------------------------------------------
+    int g_iy0[GP], g_ix0[GP];
+    const bf16_t* g_base[GP];
+    unsigned g_lds[GP];
+#pragma unroll
+    for (int u = 0; u < GP; ++u) {
+        const int q = 256 * u + tid, px = q / PPP, part = q % PPP;
+        const int gp = min(m0 + px, a.M - 1);
+        const int gn = gp / (a.Ho * a.Wo), grem = gp - gn * a.Ho * a.Wo, gyo = grem / a.Wo, gxo = grem - gyo * a.Wo;     // (once per thread)
+        g_iy0[u] = m0 + px < a.M ? gyo * a.stride - a.pad : -0x40000000;
+        g_ix0[u] = gxo * a.stride - a.pad;
+        g_base[u] = a.x + (size_t)gn * a.H * a.W * a.C + 8 * part;
+        g_lds[u] = (unsigned)(px * PITCH + 16 * part);
+    }
+    // (the loads are unconditional -- an out-of-image tap reads pixel (0, 0) of its frame and is zeroed when it goes to LDS: with
+    // loads under a branch the compiler gives up counting and every wait becomes vmcnt(0), i.e. for the youngest prefetch too)
+    uint4 ga[IG_GD][GP];
+    unsigned gok[IG_GD];
+    const int spt = a.cps / SUB;                 // steps per tap
+    const float inv_spt = a.inv_cps * (float)SUB;
+    auto gather = [&](int st, uint4 (&d)[GP], unsigned& okm) __attribute__((always_inline)) {
+        st = min(st, nsteps - 1);
+        const int tap = ig_div(st, inv_spt), c0 = (st - tap * spt) * 32 * SUB, r = ig_div(tap, a.inv_s), s = tap - r * a.S;
+        okm = 0;
+#pragma unroll
+        for (int u = 0; u < GP; ++u) {
+            const int iy = g_iy0[u] + r, ix = g_ix0[u] + s;
+            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            okm |= ok ? 1u << u : 0u;
+#ifdef IG_ABL_SAMEPIX                                          // ablation: every gather from one (cached) address
+            d[u] = *reinterpret_cast<const uint4*>(a.x + 8 * (tid & 7));
+#else
+            d[u] = *reinterpret_cast<const uint4*>(g_base[u] + ((size_t)(ok ? iy : 0) * a.W + (ok ? ix : 0)) * a.C + c0);
+#endif
+        }
+    };
+    auto put = [&](int buf, const uint4 (&d)[GP], unsigned okm) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < GP; ++u) {
+            const unsigned m = (okm >> u) & 1u ? 0xffffffffu : 0u;
+            *reinterpret_cast<uint4*>(&s_a[buf][g_lds[u]]) = make_uint4(d[u].x & m, d[u].y & m, d[u].z & m, d[u].w & m);
+        }
+    };
+
+    // ---- weights: fragment (n-tile, k-step) = 1 KiB contiguous; this wave's four n-tiles, SUB k-steps per step ---------------------
+    const bf16_t* wp = a.w + ((size_t)((n0 + 64 * wn) / 16) * a.ksteps * 64 + lane) * 8;
+    const size_t nt_stride = (size_t)a.ksteps * 512;
+    bf16x8 wr[WD][SUB][4];
+    auto wload = [&](int st, bf16x8 (&d)[SUB][4]) __attribute__((always_inline)) {
+        const size_t off = (size_t)min(st, nsteps - 1) * (512 * SUB);
+#pragma unroll
+        for (int sb = 0; sb < SUB; ++sb)
+#pragma unroll
+#ifdef IG_ABL_SAMEW                                            // ablation: every weight fragment from one (cached) KiB
+            for (int nt = 0; nt < 4; ++nt) d[sb][nt] = *reinterpret_cast<const bf16x8*>(wp + 0 * (nt * nt_stride + off + 512 * sb));
+#else
+            for (int nt = 0; nt < 4; ++nt) d[sb][nt] = *reinterpret_cast<const bf16x8*>(wp + nt * nt_stride + off + 512 * sb);
+#endif
+    };
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    gather(0, ga[0], gok[0]);
+    gather(1, ga[1], gok[1]);
+#pragma unroll
+    for (int d = 0; d < WD; ++d) wload(d, wr[d]);
+    put(0, ga[0], gok[0]);
+    gather(2, ga[0], gok[0]);
+    __syncthreads();
+
+    // step st: MFMAs from LDS buffer st & 1; the pixels of step st + 1 (requested a step and a half ago, set (st + 1) & 1) go to the
+    // other buffer behind them, and that set is refilled for step st + 3; weights of step st + WD refill ring set st % WD
+    const unsigned abase = (unsigned)(((TM / 2) * wm + li) * PITCH + 16 * g);      // this lane's B fragment of pixel tile 0: pixel li, k 8g..
+    auto step = [&](int st, auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value % WD, gs = (decltype(jc)::value + 1) & 1;   // (st and jc agree modulo UF)
+        const int buf = st & 1;
+#pragma unroll
+        for (int sb = 0; sb < SUB; ++sb)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bf16x8 xa = *reinterpret_cast<const bf16x8*>(&s_a[buf][abase + mt * 16 * PITCH + 64 * sb]);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[j][sb][nt], xa, acc[mt][nt], 0, 0, 0);
+            }
+        put(buf ^ 1, ga[gs], gok[gs]);                       // (everyone finished reading that buffer before the last barrier)
+        wload(st + WD, wr[j]);                               // refill the weight set just used
+        gather(st + 1 + IG_GD, ga[gs], gok[gs]);
+        __syncthreads();
+    };
+    int st = 0;
+    for (; st + UF <= nsteps; st += UF)
+        ig_static_for<0, UF>([&](auto jc) { step(st + decltype(jc)::value, jc); });
+    ig_static_for<0, UF - 1>([&](auto jc) { if (st + decltype(jc)::value < nsteps) step(st + decltype(jc)::value, jc); });
+
+    // ---- epilogue: lane (g, li) holds channels n + 4g .. +3 of pixel 16 mt + li ----------------------------------------------------
+    const float lo = a.relu ? 0.f : -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int ch = n0 + 64 * wn + 16 * nt + 4 * g;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + ch);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int p = m0 + (TM / 2) * wm + 16 * mt + li;
+            if (p >= a.M) continue;
+            f32x4 v = acc[mt][nt] + b4;
+            const size_t o = (size_t)p * a.K + ch;
+            if (a.res) {
+                const uint2 rr = *reinterpret_cast<const uint2*>(a.res + o);
+                v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lo);
+            *reinterpret_cast<uint2*>(a.y + o) = make_uint2((unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16),
+                                                            (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16));
+        }
+    }
+}
+
+// weights [K][R][S][C] (= [K][Kd]) -> [K / 16][Kd / 32][lane = 16 g + li][8]:  w[16 nt + li][32 ks + 8 g ..]
+__global__ __launch_bounds__(256) void conv_igemm_pack_kernel(const uint4* w, uint4* packed, int K, int Kd)
+{
+    const int nks = Kd / 32;
+    const size_t total = (size_t)(K / 16) * nks * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63), li = lane & 15, g = lane >> 4;
+        const size_t f = i >> 6;
+        const int ks = (int)(f % nks), nt = (int)(f / nks);
+        packed[i] = w[((size_t)(16 * nt + li) * Kd + 32 * ks + 8 * g) / 8];
+    }
+}
+
+}  // namespace
+
+extern "C" int gdkvm_conv_igemm_pack_weights(const void* w, void* packed, int K, int C, int R, int S, int io_dtype, void* stream)
+{
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "conv_igemm_pack_weights: only bf16 is implemented");
+    if (K <= 0 || C <= 0 || R <= 0 || S <= 0 || K % 16 || C % 32)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_igemm_pack_weights: K=%d C=%d %dx%d (K a multiple of 16, C of 32)", K, C, R, S);
+    if (!w || !packed || !gdkvm_aligned16(w) || !gdkvm_aligned16(packed)) return gdkvm_fail(GDKVM_ERR_ARG, "conv_igemm_pack_weights: null or unaligned pointer");
+    if (int rc = gdkvm_check_device()) return rc;
+    const int Kd = R * S * C;
+    const size_t total = (size_t)(K / 16) * (Kd / 32) * 64;
+    hipLaunchKernelGGL(conv_igemm_pack_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const uint4*>(w), static_cast<uint4*>(packed), K, Kd);
+    GDKVM_LAUNCH_CHECK("conv_igemm_pack_kernel");
+    return GDKVM_OK;
+}
+
+// internal entry used by gdkvm_conv_bias_act (conv_dispatch.hip): 0 = launched, 1 = shape not covered
+int gdkvm_conv_igemm_launch(const void* x, const void* wpacked, const float* bias, const void* residual, void* y,
+                            int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, hipStream_t st)
+{
+    if (C % 32 || K % IG_TN || N < 1 || R < 1 || S < 1 || stride < 1 || pad < 0) return 1;
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    if (Ho < 1 || Wo < 1) return 1;
+    const long long M = (long long)N * Ho * Wo;
+    if (M * (long long)(K > C ? K : C) > 0x7fffffffLL || (long long)N * H * W * C > 0x7fffffffLL || (long long)R * S * C / 32 > 65535) return 1;
+    IgArgs a;
+    a.x = static_cast<const bf16_t*>(x); a.w = static_cast<const bf16_t*>(wpacked); a.bias = bias;
+    a.res = static_cast<const bf16_t*>(residual); a.y = static_cast<bf16_t*>(y);
+    a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.Ho = Ho; a.Wo = Wo; a.relu = relu;
+    a.M = (int)M; a.cps = C / 32; a.ksteps = R * S * a.cps;
+    a.inv_cps = 1.0f / (float)a.cps; a.inv_s = 1.0f / (float)S;
+    const dim3 grid((unsigned)((M + 127) / 128), (unsigned)(K / IG_TN));
+    if (C % 64 == 0) hipLaunchKernelGGL((conv_igemm_kernel<128, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, 1>), grid, dim3(256), 0, st, a);
+    return 0;
+}

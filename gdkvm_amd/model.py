@@ -14,6 +14,7 @@ or without libgdkvm_hip.so the forward raises.
 from __future__ import annotations
 
 from dataclasses import dataclass
+import os
 from typing import NamedTuple, Optional, Tuple
 
 import torch
@@ -54,6 +55,10 @@ def _wkey(*tensors):
 
 
 _BN_COUNTED_BY_MODEL = [False]
+# The strided 3x3 layers of the inference build: gdkvm_conv_bias_act's general implicit-GEMM kernel with the epilogue inside
+# (default), or the library convolution + one epilogue pass (GDKVM_CONV_IGEMM=0).  Measured equal on the EchoNet shapes -- 1.013 /
+# 1.020 ms against 1.021 ms per cfg2 forward -- so the hand-written path is taken: no solver search, one launch.
+_IGEMM_STRIDED = os.environ.get("GDKVM_CONV_IGEMM", "1") != "0"
 
 
 def _bn_act(bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -240,12 +245,13 @@ class FusedConv(nn.Module):
             return 4
         return 5 if width <= 64 else None                   # (the chunked kernel tiles rows of at most 64 pixels)
 
-    def _packed(self, device):
-        """The fragment-ordered copy of the weights (ops.conv3x3_pack_weights), kept until the weights change (_wkey)."""
-        key = _wkey(self.conv.weight) + (device,)
+    def _packed(self, device, igemm: bool = False):
+        """The fragment-ordered copy of the weights (ops.conv3x3_pack_weights, or ops.conv_igemm_pack_weights for the general
+        kernel), kept until the weights change (_wkey)."""
+        key = _wkey(self.conv.weight) + (device, igemm)
         ent = self.__dict__.get("_wpack")
         if ent is None or ent[0] != key:
-            ent = (key, ops.conv3x3_pack_weights(self.conv.weight))
+            ent = (key, (ops.conv_igemm_pack_weights if igemm else ops.conv3x3_pack_weights)(self.conv.weight))
             self.__dict__["_wpack"] = ent
         return ent[1]
 
@@ -274,6 +280,10 @@ class FusedConv(nn.Module):
                 packed = self._packed(x.device) if tile in (4, 5) else None
                 return ops.conv_bias_act(x.contiguous(memory_format=torch.channels_last), cv.weight, self.epi.bias, residual,
                                          cv.stride[0], 1, self.relu, tile, packed)
+            if _IGEMM_STRIDED and cv.stride[0] == 2 and cv.in_channels % 64 == 0 and cv.out_channels % 128 == 0:
+                # the strided 3x3 layers on the general implicit-GEMM kernel, epilogue included (A/B switch: see _IGEMM_STRIDED)
+                return ops.conv_bias_act(x.contiguous(memory_format=torch.channels_last), cv.weight, self.epi.bias, residual,
+                                         2, 1, self.relu, ops.CONV_KERNEL_IGEMM, self._packed(x.device, igemm=True))
         y = self.conv(x)
         if folded:                                          # the bias was added to the consumer's epilogue bias: nothing to do here
             return y

@@ -65,6 +65,7 @@ SIGNATURES = {
     "gdkvm_gate_logits": (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     "gdkvm_conv_bias_act": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
     "gdkvm_conv3x3_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "gdkvm_conv_igemm_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gdkvm_conv_cat_bias_act": (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
     "gdkvm_conv3x3_pack_weights_dgrad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "gdkvm_conv3x3_wgrad_workspace_bytes": (_sz, [_i] * 5),
@@ -744,6 +745,23 @@ def conv3x3_pack_weights(weight: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(weight.device):
         rc = lib.gdkvm_conv3x3_pack_weights(weight.data_ptr(), packed.data_ptr(), k, c, BF16, _stream(weight.device))
     _check(rc, "gdkvm_conv3x3_pack_weights")
+    return packed
+
+
+CONV_KERNEL_IGEMM = 9         # gdkvm_conv_bias_act's general implicit-GEMM kernel (any R x S / stride / pad; packed weights only)
+
+
+def conv_igemm_pack_weights(weight: torch.Tensor) -> torch.Tensor:
+    """The fragment-ordered copy of channels_last bf16 [K,C,R,S] weights that conv_bias_act(..., tile=CONV_KERNEL_IGEMM, packed=...)
+    reads (gdkvm_conv_igemm_pack_weights): K a multiple of 16 (128 for the kernel), C of 32."""
+    lib = load()
+    if weight.dim() != 4 or weight.dtype != torch.bfloat16 or not weight.is_cuda or not weight.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("conv_igemm_pack_weights: weight must be a channels_last bf16 [K,C,R,S] device tensor")
+    k, c, r, s = weight.shape
+    packed = torch.empty(weight.numel(), dtype=torch.bfloat16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = lib.gdkvm_conv_igemm_pack_weights(weight.data_ptr(), packed.data_ptr(), k, c, r, s, BF16, _stream(weight.device))
+    _check(rc, "gdkvm_conv_igemm_pack_weights")
     return packed
 
 

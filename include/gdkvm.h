@@ -286,12 +286,17 @@ int gdkvm_gate_logits(const void* p, const float* w_gate, const float* b_gate, c
  * y / residual [N, H, W, K], bias fp32 [K]; bf16 only.  The fp32 accumulator is rounded ONCE (after the epilogue).  Both kernels
  * are hand-written: kernel 4 = 64 -> 64 channels (conv3x3_c64.hip: LDS halo band, weights resident in registers), kernel 5 = C a
  * multiple of 64, K of 16, rows of <= 64 pixels (conv3x3_tile.hip: 64-channel LDS chunks, weights streamed); kernel 0 picks by
- * shape; 6, 7, 8 pin kernel 5's wave grid (4 channel groups x 1 tile, 4 x 2, 2 x 2: tuning; 5 picks by K).  Anything else
- * (strided, 1x1, odd channel counts) returns GDKVM_ERR_SHAPE: those stay on the framework convolution followed by gdkvm_bias_act.
+ * shape; 6, 7, 8 pin kernel 5's wave grid (4 channel groups x 1 tile, 4 x 2, 2 x 2: tuning; 5 picks by K).
+ * kernel 9 | GDKVM_CONV_PACKED_WEIGHTS = the general implicit-GEMM kernel (conv_igemm.hip): any R x S, stride and padding, rows of
+ * any width -- the strided 3x3 layers, the 1x1 downsamples, 3x3 / 1 / 1 on maps wider than 64 pixels; C a multiple of 32, K of 128,
+ * w the gdkvm_conv_igemm_pack_weights copy of the [K, R, S, C] weights.  Shapes none of the three serves (odd channel counts)
+ * return GDKVM_ERR_SHAPE: those stay on the framework convolution followed by gdkvm_bias_act.
  * kernel | GDKVM_CONV_PACKED_WEIGHTS: w is the fragment-ordered copy gdkvm_conv3x3_pack_weights made of the
  * [K, 3, 3, C] weights (same size) -- each 1 KiB weight fragment is then one contiguous read; same result bit for bit. */
 enum { GDKVM_CONV_PACKED_WEIGHTS = 32 };
 int gdkvm_conv3x3_pack_weights(const void* w, void* packed, int K, int C, int io_dtype, void* stream);
+/* kernel 9's pack: w [K, R, S, C] bf16 -> the same bytes in MFMA-fragment order (K a multiple of 16, C of 32). */
+int gdkvm_conv_igemm_pack_weights(const void* w, void* packed, int K, int C, int R, int S, int io_dtype, void* stream);
 /* The pack of the same layer's DATA-GRADIENT convolution, from the forward weights w [K, 3, 3, C]:  dx = conv3x3(dy, w'),
  * w'[c][ty][tx][k] = w[k][2 - ty][2 - tx][c] -- K input channels (a multiple of 64), C output channels (of 16).  Use it as
  * gdkvm_conv_bias_act(dy, packed, zero bias, NULL, dx, N, K, H, W, C, 3, 3, 1, 1, 0, kernel | GDKVM_CONV_PACKED_WEIGHTS, ...). */

@@ -282,6 +282,39 @@ def test_conv_with_fused_epilogue(hip, kernel, case):
             assert torch.equal(hip.conv_bias_act(x, wt, b, r, stride, 1, True, 4, pk), hip.conv_bias_act(x, wt, b, r, stride, 1, True, 4))
 
 
+@pytest.mark.parametrize("case", [(9, 64, 28, 28, 128, 3, 2, 1, False), (5, 128, 14, 14, 256, 3, 2, 1, True), (7, 64, 28, 28, 128, 1, 2, 0, False),
+                                  (3, 128, 14, 14, 256, 1, 2, 0, True), (2, 64, 20, 80, 128, 3, 1, 1, True), (1, 32, 9, 11, 128, 5, 2, 2, False),
+                                  (3, 96, 7, 7, 128, 3, 1, 1, True), (1, 64, 70, 70, 256, 3, 2, 1, False), (2, 64, 5, 4, 128, 1, 1, 0, False)])
+def test_conv_implicit_gemm_kernel(hip, case):
+    """gdkvm_conv_bias_act kernel 9 (the general implicit-GEMM kernel: strided layers, 1x1 layers, rows wider than 64 pixels) ==
+    act(conv2d + bias (+ residual)) computed in fp64 and rounded once; where the 3x3 / 1 / 1 kernel also serves the shape the two
+    agree to a rounding of the sums' order; unpacked weights and channel counts it does not take fail loudly."""
+    n, c, h, w, k, rs, stride, pad, with_res = case
+    torch.manual_seed(sum(case[:8]))
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(n, c, h, w, device="cuda").bfloat16().contiguous(**cl)
+    wt = (torch.randn(k, c, rs, rs, device="cuda") / (rs * rs * c) ** 0.5).bfloat16().contiguous(**cl)
+    b = torch.randn(k, device="cuda")
+    ho, wo = (h + 2 * pad - rs) // stride + 1, (w + 2 * pad - rs) // stride + 1
+    r = torch.randn(n, k, ho, wo, device="cuda").bfloat16().contiguous(**cl) if with_res else None
+    pk = hip.conv_igemm_pack_weights(wt)
+    for relu in (True, False):
+        got = hip.conv_bias_act(x, wt, b, r, stride, pad, relu, hip.CONV_KERNEL_IGEMM, pk)
+        want = torch.nn.functional.conv2d(x.double(), wt.double(), b.double(), stride, pad)
+        want = want + r.double() if with_res else want
+        want = want.relu() if relu else want
+        assert got.shape == want.shape and got.is_contiguous(**cl) and got.dtype == torch.bfloat16
+        assert (got.double() - want).abs().max() <= 2.0 ** -7 * max(1.0, want.abs().max().item())
+    if rs == 3 and stride == 1 and pad == 1 and c % 64 == 0 and w <= 64:
+        other = hip.conv_bias_act(x, wt, b, r, 1, 1, True, 5)
+        assert (got.float() * 0 + hip.conv_bias_act(x, wt, b, r, 1, 1, True, hip.CONV_KERNEL_IGEMM, pk).float() - other.float()).abs().max() \
+            <= 2.0 ** -7 * max(1.0, other.float().abs().max().item())
+    with pytest.raises(hip.GdkvmError, match="pack"):
+        hip.conv_bias_act(x, wt, b, r, stride, pad, True, hip.CONV_KERNEL_IGEMM)
+    with pytest.raises(hip.GdkvmError):
+        hip.conv_bias_act(x, wt[:64].contiguous(**cl), b[:64], None, stride, pad, True, hip.CONV_KERNEL_IGEMM, hip.conv_igemm_pack_weights(wt[:64].contiguous(**cl)))
+
+
 @pytest.mark.parametrize("case", [(5, 256, 128, 14, 14, 128), (3, 128, 64, 28, 28, 64), (9, 64, 64, 7, 5, 48), (2, 192, 64, 10, 33, 160)])
 def test_conv_over_a_concatenation_that_is_never_built(hip, case):
     """gdkvm_conv_cat_bias_act([x1 ; x2]) == gdkvm_conv_bias_act(cat(x1, x2)) bit for bit (plain and packed weights), and the

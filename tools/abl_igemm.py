@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Diagnostic only: ablation builds of conv_igemm.hip (wrong results by design) and their timings on the strided layers.
+  python tools/abl_igemm.py build   (here)      python tools/abl_igemm.py run   (GPU box)"""
+import glob
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "gdkvm_amd", "csrc")
+OUT = os.path.join(ROOT, "tools", "_abl")
+VARIANTS = {"ig_base": [], "ig_samepix": ["-DIG_ABL_SAMEPIX"], "ig_samew": ["-DIG_ABL_SAMEW"], "ig_both": ["-DIG_ABL_SAMEPIX", "-DIG_ABL_SAMEW"]}
+
+if sys.argv[1] == "build":
+    os.makedirs(OUT, exist_ok=True)
+    others = [o for o in sorted(glob.glob(os.path.join(CSRC, "_obj", "*.o"))) if not o.endswith("conv_igemm.o")]
+    for name, flags in VARIANTS.items():
+        obj, so = os.path.join(OUT, name + ".o"), os.path.join(OUT, name + ".so")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c"] + flags +
+                              ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, os.path.join(CSRC, "conv_igemm.hip"), "-o", obj])
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so, obj] + others)
+        os.remove(obj)
+elif sys.argv[1] == "run":
+    for name in VARIANTS:
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), "one", name])
+else:
+    import torch
+    from gdkvm_amd import ops
+    ops._SO = os.path.join(OUT, sys.argv[2] + ".so")
+    from tools.config_sweep import ev_time
+    cl = dict(memory_format=torch.channels_last)
+    out = []
+    for n, c, h, k, rs, st, pad in ((512, 64, 28, 128, 3, 2, 1), (512, 128, 14, 256, 3, 2, 1), (512, 128, 14, 128, 3, 1, 1)):
+        x = torch.randn(n, c, h, h, device="cuda").bfloat16().contiguous(**cl)
+        w = (torch.randn(k, c, rs, rs, device="cuda") / (rs * rs * c) ** 0.5).bfloat16().contiguous(**cl)
+        b = torch.randn(k, device="cuda")
+        pk = ops.conv_igemm_pack_weights(w)
+        out.append(f"{ev_time(lambda: ops.conv_bias_act(x, w, b, None, st, pad, True, ops.CONV_KERNEL_IGEMM, pk)):6.1f}")
+    print(f"{sys.argv[2]:12s} " + " ".join(out) + " us", flush=True)
