@@ -280,10 +280,11 @@ class FusedConv(nn.Module):
                 packed = self._packed(x.device) if tile in (4, 5) else None
                 return ops.conv_bias_act(x.contiguous(memory_format=torch.channels_last), cv.weight, self.epi.bias, residual,
                                          cv.stride[0], 1, self.relu, tile, packed)
-            if _IGEMM_STRIDED and cv.stride[0] == 2 and cv.in_channels % 64 == 0 and cv.out_channels % 128 == 0:
-                # the strided 3x3 layers on the general implicit-GEMM kernel, epilogue included (A/B switch: see _IGEMM_STRIDED)
+            if _IGEMM_STRIDED and cv.in_channels % 32 == 0 and cv.out_channels % 128 == 0:
+                # what the two 3x3 / 1 / 1 kernels do not take -- the strided layers, rows wider than 64 pixels -- on the general
+                # implicit-GEMM kernel, epilogue included (A/B switch: see _IGEMM_STRIDED)
                 return ops.conv_bias_act(x.contiguous(memory_format=torch.channels_last), cv.weight, self.epi.bias, residual,
-                                         2, 1, self.relu, ops.CONV_KERNEL_IGEMM, self._packed(x.device, igemm=True))
+                                         cv.stride[0], 1, self.relu, ops.CONV_KERNEL_IGEMM, self._packed(x.device, igemm=True))
         y = self.conv(x)
         if folded:                                          # the bias was added to the consumer's epilogue bias: nothing to do here
             return y

@@ -72,6 +72,28 @@ def test_module_against_the_independent_restatement(hip):
     assert agree >= 0.97, agree
 
 
+def test_fused_build_on_maps_wider_than_64_pixels(hip):
+    """528x528 frames: the stride-8 map is 66 pixels wide, wider than the chunked 3x3 kernel tiles -- those layers and the strided ones
+    take the general implicit-GEMM kernel; 33x33 = 1089 tokens per frame.  The fused bf16 build against the independent restatement."""
+    from oracle.model_plain import plain_forward
+    ref, model = _pair(seed=6)
+    frames = torch.rand(1, 2, 3, 528, 528)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    lp, _ = plain_forward(sd, frames, lowres=True)
+    gap = (lp[:, :, 0] - lp[:, :, 1]).median()                    # balance the two classes (as _balance does, on the restatement)
+    sd["decoder.head.bias"][1] += gap.float()
+    lp[:, :, 1] += gap
+    with torch.no_grad():
+        model.decoder.head.bias[1] += gap.float().cuda()
+        fused = model.fuse_for_inference().to(torch.bfloat16)
+        lb = fused(frames.cuda(), _lowres=True).float().cpu().double()
+    err = (lb - lp).abs()
+    assert err.max() <= 0.05 * max(1.0, lp.abs().max().item()) and err.mean() <= 0.01, (err.max().item(), err.mean().item())
+    agree = (lb.argmax(2) == lp.argmax(2)).float().mean().item()
+    frac = lp.argmax(2).float().mean().item()
+    assert agree >= 0.97 and 0.2 < frac < 0.8, (agree, frac)
+
+
 def test_module_fp32_on_a_grid_wider_than_16_tokens(hip):
     """320x320 frames: a 20x20 token grid (400 tokens per frame: chunked scan, KPFF tiles of 4 rows x 16 columns)."""
     ref, model = _pair(seed=3)
