@@ -332,9 +332,9 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
     // token tok of sub-tile sb (row-major inside the tile) -> token of the frame
     auto gtok = [&](int sb, int tok) { const int ty = tok / t_w[sb]; return t_n0[sb] + ty * a.w + (tok - ty * t_w[sb]); };
 
-    // ---- stage [P ; L ; G] rows as they are (8 channels = 16 bytes per thread, 4 loads in flight) -----------
+    // ---- stage the [P ; L] rows as they are (8 channels = 16 bytes per thread, 4 loads in flight) -----------
     {
-        const int q8 = Cin / 8, total = TMW * q8;
+        const int q8 = (Cp + Ck) / 8, total = TMW * q8;
         for (int base = tid; base < total; base += 4 * NTHR) {
             uint4 x[4];
             int dst[4];
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
                 x[u] = make_uint4(0u, 0u, 0u, 0u);
                 if (idx < total && tok < t_ntok[sb < NT ? sb : 0]) {
                     const size_t row = (size_t)t_f[sb] * N + gtok(sb, tok);
-                    const bf16_t* src = c < Cp ? a.P + row * Cp + c : (c < Cp + Ck ? a.L + row * Ck + (c - Cp) : a.G + row * Cv + (c - Cp - Ck));
+                    const bf16_t* src = c < Cp ? a.P + row * Cp + c : a.L + row * Ck + (c - Cp);
                     x[u] = *reinterpret_cast<const uint4*>(src);
                 }
             }
@@ -356,15 +356,17 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
                 if (dst[u] >= 0) *reinterpret_cast<uint4*>(s_xb + dst[u]) = x[u];
         }
     }
-    __syncthreads();
 #ifndef KPFF_SKIP_POOL
-    // ---- multi-scale pooling of G in place: one thread per (4x4 cell, channel pair); the cell is read with 16
-    //      independent predicated LDS loads (a runtime-bounded loop serialises on the ~100-cycle LDS latency)
+    // ---- G: pooled (multi-scale) straight from global memory: one thread per (4x4 cell, channel pair), the cell's 16 tokens as 16
+    //      independent 4-byte loads (64 lanes = 256 contiguous bytes of a token row), fp32 math, one bf16 store per token into the
+    //      tile.  (Until the end of round 2 G was staged like P and L and pooled in place in a second pass over LDS, behind one
+    //      more barrier.)
 #pragma unroll
     for (int sb = 0; sb < NT; ++sb) {
         const int nrows = t_nrows[sb], W = t_w[sb];
         const int cw = (W + 3) / 4, chh = (nrows + 3) / 4, cv2 = Cv / 2;
         bf16_t* gx = s_xb + (size_t)sb * 64 * ld + Cp + Ck;
+        const bf16_t* gsrc = a.G + ((size_t)t_f[sb] * N + t_n0[sb]) * Cv;
         for (int idx = tid; idx < cw * chh * cv2; idx += NTHR) {
             const int cell = idx / cv2, c = (idx - cell * cv2) * 2;
             const int cy = cell / cw, y0 = cy * 4, x0 = (cell - cy * cw) * 4;
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
             for (int p = 0; p < 16; ++p) {
                 const int y = y0 + (p >> 2), x = x0 + (p & 3);
                 ok[p] = y < nrows && x < W;
-                u[p] = ok[p] ? *reinterpret_cast<const unsigned*>(gx + (size_t)(y * W + x) * ld + c) : 0u;
+                u[p] = ok[p] ? *reinterpret_cast<const unsigned*>(gsrc + (size_t)(y * a.w + x) * Cv + c) : 0u;
             }
             float s2[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, s4[2] = {0.f, 0.f};
             float n2[4] = {0.f, 0.f, 0.f, 0.f}, n4 = 0.f;
