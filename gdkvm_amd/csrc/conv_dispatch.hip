@@ -10,7 +10,8 @@ int gdkvm_conv3x3_c64_launch(const void* x, const void* w, const float* bias, co
 int gdkvm_conv3x3_tile_launch(const void* x, const void* x2, int C1, const void* w, const float* bias, const void* residual, void* y,
                               int N, int C, int H, int W, int K, int relu, int variant, int packed, hipStream_t st);   // conv3x3_tile.hip
 int gdkvm_conv_igemm_launch(const void* x, const void* wpacked, const float* bias, const void* residual, void* y,
-                            int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, hipStream_t st);   // conv_igemm.hip
+                            int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu,
+                            const void* w2packed, const float* bias2, void* y2, hipStream_t st);   // conv_igemm.hip
 
 extern "C" int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y,
                                    int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, int kernel,
@@ -33,7 +34,7 @@ extern "C" int gdkvm_conv_bias_act(const void* x, const void* w, const float* bi
         if (!gdkvm_aligned16(x) || !gdkvm_aligned16(w) || !gdkvm_aligned16(y) || !gdkvm_aligned16(bias) || (residual && !gdkvm_aligned16(residual)))
             return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: pointers must be 16-byte aligned");
         if (int rc = gdkvm_check_device()) return rc;
-        if (gdkvm_conv_igemm_launch(x, w, bias, residual, y, N, C, H, W, K, R, S, stride, pad, relu, static_cast<hipStream_t>(stream)))
+        if (gdkvm_conv_igemm_launch(x, w, bias, residual, y, N, C, H, W, K, R, S, stride, pad, relu, nullptr, nullptr, nullptr, static_cast<hipStream_t>(stream)))
             return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: N=%d C=%d H=%d W=%d K=%d %dx%d stride %d pad %d is too large for 32-bit offsets", N, C, H, W, K, R, S, stride, pad);
         GDKVM_LAUNCH_CHECK("conv_igemm_kernel");
         return GDKVM_OK;
@@ -88,5 +89,29 @@ extern "C" int gdkvm_conv_cat_bias_act(const void* x1, const void* x2, const voi
                                   static_cast<hipStream_t>(stream)))
         return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_cat_bias_act: %dx%d is not served (rows of at most 64 pixels)", H, W);
     GDKVM_LAUNCH_CHECK("conv3x3_tile_kernel");
+    return GDKVM_OK;
+}
+
+// A residual block's first convolution AND its downsample branch in one launch: y = act(conv_RxS(x, w) + bias) as kernel 9 above, and
+// y_down = conv_1x1(x, w_down) (+ bias_down, may be NULL) with the same stride and K output channels -- the 1x1's input pixel is the
+// centre of the R x S window (R = S odd, pad = R / 2), so the second result is one more pass over pixels the kernel has already
+// set up.  Both weight tensors as gdkvm_conv_igemm_pack_weights copies ([K, R, S, C] and [K, 1, 1, C]).
+extern "C" int gdkvm_conv_down_bias_act(const void* x, const void* w, const float* bias, void* y, int relu,
+                                        const void* w_down, const float* bias_down, void* y_down,
+                                        int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int io_dtype, void* stream)
+{
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "conv_down_bias_act: only bf16 is implemented");
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || R <= 0 || S != R || !(R & 1) || stride <= 0 || pad != R / 2 || C % 32 || K % 128)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_down_bias_act: N=%d C=%d H=%d W=%d K=%d %dx%d stride %d pad %d (odd square window, pad = R/2, "
+                                           "C a multiple of 32, K of 128)", N, C, H, W, K, R, S, stride, pad);
+    if (N == 0) return GDKVM_OK;
+    if (!x || !w || !bias || !y || !w_down || !y_down) return gdkvm_fail(GDKVM_ERR_ARG, "conv_down_bias_act: null pointer");
+    const void* ptrs[] = {x, w, bias, y, w_down, y_down};
+    for (const void* p : ptrs) if (!gdkvm_aligned16(p)) return gdkvm_fail(GDKVM_ERR_ARG, "conv_down_bias_act: pointers must be 16-byte aligned");
+    if (bias_down && !gdkvm_aligned16(bias_down)) return gdkvm_fail(GDKVM_ERR_ARG, "conv_down_bias_act: pointers must be 16-byte aligned");
+    if (int rc = gdkvm_check_device()) return rc;
+    if (gdkvm_conv_igemm_launch(x, w, bias, nullptr, y, N, C, H, W, K, R, S, stride, pad, relu, w_down, bias_down, y_down, static_cast<hipStream_t>(stream)))
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_down_bias_act: tensor too large for 32-bit offsets");
+    GDKVM_LAUNCH_CHECK("conv_igemm_kernel");
     return GDKVM_OK;
 }

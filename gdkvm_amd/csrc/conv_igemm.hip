@@ -30,6 +30,8 @@ struct IgArgs {
     const bf16_t* x; const bf16_t* w; const float* bias; const bf16_t* res; bf16_t* y;
     int N, H, W, C, K, R, S, stride, pad, Ho, Wo, relu;
     int M, ksteps, cps;                          // output pixels; Kd / 32; k-steps per tap (C / 32)
+    const bf16_t* w2; const float* bias2; bf16_t* y2; int centre;   // optional second output: the 1x1 convolution (same stride, K channels,
+                                                 // bias2 may be NULL) of the window's centre pixel -- tap index `centre` -- with pack w2
     float inv_cps, inv_s;                        // per-k-step index arithmetic without integer division (see conv3x3_tile.hip: ct_div)
 };
 
@@ -84,7 +86,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
     const int spt = a.cps / SUB;                 // steps per tap
     const float inv_spt = a.inv_cps * (float)SUB;
     auto gather = [&](int st, uint4 (&d)[GP], unsigned& okm) __attribute__((always_inline)) {
-        st = min(st, nsteps - 1);
         const int tap = ig_div(st, inv_spt), c0 = (st - tap * spt) * 32 * SUB, r = ig_div(tap, a.inv_s), s = tap - r * a.S;
         okm = 0;
 #pragma unroll
@@ -107,83 +108,91 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
         }
     };
 
-    // ---- weights: fragment (n-tile, k-step) = 1 KiB contiguous; this wave's four n-tiles, SUB k-steps per step ---------------------
-    const bf16_t* wp = a.w + ((size_t)((n0 + 64 * wn) / 16) * a.ksteps * 64 + lane) * 8;
-    const size_t nt_stride = (size_t)a.ksteps * 512;
-    bf16x8 wr[WD][SUB][4];
-    auto wload = [&](int st, bf16x8 (&d)[SUB][4]) __attribute__((always_inline)) {
-        const size_t off = (size_t)min(st, nsteps - 1) * (512 * SUB);
+    const unsigned abase = (unsigned)(((TM / 2) * wm + li) * PITCH + 16 * g);      // this lane's B fragment of pixel tile 0: pixel li, k 8g..
+
+    // One convolution over the gathered pixels: `L` steps starting at gather step g0, weights `wpk` packed for exactly those steps.
+    // The layer itself is (0, nsteps); a second pass over the CENTRE tap alone with another weight pack is the 1x1 / same-stride
+    // convolution of the same input (the residual block's downsample branch), computed here on the pixels' geometry already set up.
+    auto run_pass = [&](const bf16_t* wpk, int g0, int L, const float* bias, const bf16_t* res, bf16_t* y, int relu) __attribute__((always_inline)) {
+        // weights: fragment (n-tile, k-step) = 1 KiB contiguous; this wave's four n-tiles, SUB k-steps per step
+        const bf16_t* wp = wpk + ((size_t)((n0 + 64 * wn) / 16) * (L * SUB) * 64 + lane) * 8;
+        const size_t nt_stride = (size_t)(L * SUB) * 512;
+        bf16x8 wr[WD][SUB][4];
+        auto wload = [&](int l, bf16x8 (&d)[SUB][4]) __attribute__((always_inline)) {
+            const size_t off = (size_t)min(l, L - 1) * (512 * SUB);
 #pragma unroll
-        for (int sb = 0; sb < SUB; ++sb)
+            for (int sb = 0; sb < SUB; ++sb)
 #pragma unroll
 #ifdef IG_ABL_SAMEW                                            // ablation: every weight fragment from one (cached) KiB
-            for (int nt = 0; nt < 4; ++nt) d[sb][nt] = *reinterpret_cast<const bf16x8*>(wp + 0 * (nt * nt_stride + off + 512 * sb));
+                for (int nt = 0; nt < 4; ++nt) d[sb][nt] = *reinterpret_cast<const bf16x8*>(wp + 0 * (nt * nt_stride + off + 512 * sb));
 #else
-            for (int nt = 0; nt < 4; ++nt) d[sb][nt] = *reinterpret_cast<const bf16x8*>(wp + nt * nt_stride + off + 512 * sb);
+                for (int nt = 0; nt < 4; ++nt) d[sb][nt] = *reinterpret_cast<const bf16x8*>(wp + nt * nt_stride + off + 512 * sb);
 #endif
-    };
+        };
+        const int glast = g0 + L - 1;
+        f32x4 acc[MT][4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 acc[MT][4];
+        gather(min(g0, glast), ga[0], gok[0]);
+        gather(min(g0 + 1, glast), ga[1], gok[1]);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int d = 0; d < WD; ++d) wload(d, wr[d]);
+        put(0, ga[0], gok[0]);
+        gather(min(g0 + 2, glast), ga[0], gok[0]);
+        __syncthreads();
 
-    gather(0, ga[0], gok[0]);
-    gather(1, ga[1], gok[1]);
+        // step l: MFMAs from LDS buffer l & 1; the pixels of step l + 1 (requested a step and a half ago, set (l + 1) & 1) go to the
+        // other buffer behind them, and that set is refilled for step l + 3; weights of step l + WD refill ring set l % WD
+        auto step = [&](int l, auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value % WD, gs = (decltype(jc)::value + 1) & 1;   // (l and jc agree modulo UF)
+            const int buf = l & 1;
 #pragma unroll
-    for (int d = 0; d < WD; ++d) wload(d, wr[d]);
-    put(0, ga[0], gok[0]);
-    gather(2, ga[0], gok[0]);
-    __syncthreads();
+            for (int sb = 0; sb < SUB; ++sb)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bf16x8 xa = *reinterpret_cast<const bf16x8*>(&s_a[buf][abase + mt * 16 * PITCH + 64 * sb]);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[j][sb][nt], xa, acc[mt][nt], 0, 0, 0);
+                }
+            put(buf ^ 1, ga[gs], gok[gs]);                   // (everyone finished reading that buffer before the last barrier)
+            wload(l + WD, wr[j]);                            // refill the weight set just used
+            gather(min(g0 + l + 1 + IG_GD, glast), ga[gs], gok[gs]);
+            __syncthreads();
+        };
+        int l = 0;
+        for (; l + UF <= L; l += UF)
+            ig_static_for<0, UF>([&](auto jc) { step(l + decltype(jc)::value, jc); });
+        ig_static_for<0, UF - 1>([&](auto jc) { if (l + decltype(jc)::value < L) step(l + decltype(jc)::value, jc); });
 
-    // step st: MFMAs from LDS buffer st & 1; the pixels of step st + 1 (requested a step and a half ago, set (st + 1) & 1) go to the
-    // other buffer behind them, and that set is refilled for step st + 3; weights of step st + WD refill ring set st % WD
-    const unsigned abase = (unsigned)(((TM / 2) * wm + li) * PITCH + 16 * g);      // this lane's B fragment of pixel tile 0: pixel li, k 8g..
-    auto step = [&](int st, auto jc) __attribute__((always_inline)) {
-        constexpr int j = decltype(jc)::value % WD, gs = (decltype(jc)::value + 1) & 1;   // (st and jc agree modulo UF)
-        const int buf = st & 1;
+        // epilogue: lane (g, li) holds channels n + 4g .. +3 of pixel 16 mt + li
+        const float lo = relu ? 0.f : -INFINITY;
 #pragma unroll
-        for (int sb = 0; sb < SUB; ++sb)
+        for (int nt = 0; nt < 4; ++nt) {
+            const int ch = n0 + 64 * wn + 16 * nt + 4 * g;
+            const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const bf16x8 xa = *reinterpret_cast<const bf16x8*>(&s_a[buf][abase + mt * 16 * PITCH + 64 * sb]);
+                const int p = m0 + (TM / 2) * wm + 16 * mt + li;
+                if (p >= a.M) continue;
+                f32x4 v = acc[mt][nt] + b4;
+                const size_t o = (size_t)p * a.K + ch;
+                if (res) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(res + o);
+                    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                }
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[j][sb][nt], xa, acc[mt][nt], 0, 0, 0);
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lo);
+                *reinterpret_cast<uint2*>(y + o) = make_uint2((unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16),
+                                                              (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16));
             }
-        put(buf ^ 1, ga[gs], gok[gs]);                       // (everyone finished reading that buffer before the last barrier)
-        wload(st + WD, wr[j]);                               // refill the weight set just used
-        gather(st + 1 + IG_GD, ga[gs], gok[gs]);
-        __syncthreads();
-    };
-    int st = 0;
-    for (; st + UF <= nsteps; st += UF)
-        ig_static_for<0, UF>([&](auto jc) { step(st + decltype(jc)::value, jc); });
-    ig_static_for<0, UF - 1>([&](auto jc) { if (st + decltype(jc)::value < nsteps) step(st + decltype(jc)::value, jc); });
-
-    // ---- epilogue: lane (g, li) holds channels n + 4g .. +3 of pixel 16 mt + li ----------------------------------------------------
-    const float lo = a.relu ? 0.f : -INFINITY;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int ch = n0 + 64 * wn + 16 * nt + 4 * g;
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + ch);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int p = m0 + (TM / 2) * wm + 16 * mt + li;
-            if (p >= a.M) continue;
-            f32x4 v = acc[mt][nt] + b4;
-            const size_t o = (size_t)p * a.K + ch;
-            if (a.res) {
-                const uint2 rr = *reinterpret_cast<const uint2*>(a.res + o);
-                v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-                v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], lo);
-            *reinterpret_cast<uint2*>(a.y + o) = make_uint2((unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16),
-                                                            (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16));
         }
-    }
+    };
+    run_pass(a.w, 0, nsteps, a.bias, a.res, a.y, a.relu);
+    if (a.w2) run_pass(a.w2, a.centre * spt, spt, a.bias2, nullptr, a.y2, 0);
 }
 
 // weights [K][R][S][C] (= [K][Kd]) -> [K / 16][Kd / 32][lane = 16 g + li][8]:  w[16 nt + li][32 ks + 8 g ..]
@@ -218,9 +227,11 @@ extern "C" int gdkvm_conv_igemm_pack_weights(const void* w, void* packed, int K,
 
 // internal entry used by gdkvm_conv_bias_act (conv_dispatch.hip): 0 = launched, 1 = shape not covered
 int gdkvm_conv_igemm_launch(const void* x, const void* wpacked, const float* bias, const void* residual, void* y,
-                            int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, hipStream_t st)
+                            int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu,
+                            const void* w2packed, const float* bias2, void* y2, hipStream_t st)
 {
     if (C % 32 || K % IG_TN || N < 1 || R < 1 || S < 1 || stride < 1 || pad < 0) return 1;
+    if (w2packed && (!y2 || R != S || !(R & 1) || pad != R / 2)) return 1;        // (the 1x1's pixel must be the window's centre)
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     if (Ho < 1 || Wo < 1) return 1;
     const long long M = (long long)N * Ho * Wo;
@@ -228,6 +239,7 @@ int gdkvm_conv_igemm_launch(const void* x, const void* wpacked, const float* bia
     IgArgs a;
     a.x = static_cast<const bf16_t*>(x); a.w = static_cast<const bf16_t*>(wpacked); a.bias = bias;
     a.res = static_cast<const bf16_t*>(residual); a.y = static_cast<bf16_t*>(y);
+    a.w2 = static_cast<const bf16_t*>(w2packed); a.bias2 = bias2; a.y2 = static_cast<bf16_t*>(y2); a.centre = (R / 2) * S + S / 2;
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.Ho = Ho; a.Wo = Wo; a.relu = relu;
     a.M = (int)M; a.cps = C / 32; a.ksteps = R * S * a.cps;
     a.inv_cps = 1.0f / (float)a.cps; a.inv_s = 1.0f / (float)S;

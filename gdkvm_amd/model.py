@@ -107,6 +107,9 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         if isinstance(self.conv1, FusedConv):              # inference build: conv -> one fused epilogue pass
+            pair = self.conv1.with_down(x, self.down) if self.down is not None else None
+            if pair is not None:                            # first convolution and downsample branch in ONE launch
+                return self.conv2(pair[0], pair[1])
             skip = x if self.down is None else self.down(x)
             return self.conv2(self.conv1(x), skip.contiguous(memory_format=torch.channels_last) if skip.is_cuda else skip)
         y = _bn_act(self.bn1, _conv(self.conv1, x), True)
@@ -254,6 +257,25 @@ class FusedConv(nn.Module):
             ent = (key, (ops.conv_igemm_pack_weights if igemm else ops.conv3x3_pack_weights)(self.conv.weight))
             self.__dict__["_wpack"] = ent
         return ent[1]
+
+    def with_down(self, x, down):
+        """(self(x), down(x)) from one launch of the general kernel (ops.conv_down_bias_act) when this is a strided 3x3 layer and
+        `down` the block's folded 1x1 convolution of the same stride whose bias already sits in the consumer's epilogue; else None."""
+        cv = self.conv
+        d = down[0] if isinstance(down, nn.Sequential) and len(down) == 1 else None
+        if not (_IGEMM_STRIDED and isinstance(d, FusedConv) and getattr(d, "bias_folded_downstream", False) and not d.relu
+                and not getattr(self, "bias_folded_downstream", False) and x.is_cuda and x.dtype == torch.bfloat16
+                and cv.kernel_size == (3, 3) and cv.padding == (1, 1) and cv.dilation == (1, 1) and cv.groups == 1
+                and cv.stride[0] == cv.stride[1] and d.conv.kernel_size == (1, 1) and d.conv.stride == cv.stride
+                and d.conv.padding == (0, 0) and d.conv.groups == 1 and d.conv.in_channels == cv.in_channels
+                and d.conv.out_channels == cv.out_channels and cv.in_channels % 32 == 0 and cv.out_channels % 128 == 0
+                and cv.weight.dtype == torch.bfloat16 and d.conv.weight.dtype == torch.bfloat16
+                and cv.weight.is_contiguous(memory_format=torch.channels_last)
+                and self._tile(cv.in_channels, cv.out_channels, cv.stride[0], False, x.shape[-1]) is None):
+            return None
+        dw = d.conv.weight if d.conv.weight.is_contiguous(memory_format=torch.channels_last) else d.conv.weight.contiguous(memory_format=torch.channels_last)
+        return ops.conv_down_bias_act(x.contiguous(memory_format=torch.channels_last), cv.weight, self.epi.bias, self._packed(x.device, igemm=True),
+                                      dw, d._packed(x.device, igemm=True), None, cv.stride[0], self.relu)
 
     def cat_served(self, c1: int, c2: int, width: int) -> bool:
         """Can forward_cat run this layer on [x1 (c1 channels) ; x2 (c2)] without the concatenated tensor (gdkvm_conv_cat_bias_act)?"""

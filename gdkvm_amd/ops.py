@@ -66,6 +66,7 @@ SIGNATURES = {
     "gdkvm_conv_bias_act": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
     "gdkvm_conv3x3_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "gdkvm_conv_igemm_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "gdkvm_conv_down_bias_act": (_i, [_vp] * 4 + [_i] + [_vp] * 3 + [_i] * 10 + [_vp]),
     "gdkvm_conv_cat_bias_act": (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
     "gdkvm_conv3x3_pack_weights_dgrad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "gdkvm_conv3x3_wgrad_workspace_bytes": (_sz, [_i] * 5),
@@ -763,6 +764,32 @@ def conv_igemm_pack_weights(weight: torch.Tensor) -> torch.Tensor:
         rc = lib.gdkvm_conv_igemm_pack_weights(weight.data_ptr(), packed.data_ptr(), k, c, r, s, BF16, _stream(weight.device))
     _check(rc, "gdkvm_conv_igemm_pack_weights")
     return packed
+
+
+def conv_down_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, packed: torch.Tensor, down_weight: torch.Tensor,
+                       down_packed: torch.Tensor, down_bias: Optional[torch.Tensor] = None, stride: int = 2, relu: bool = True):
+    """A residual block's first convolution and its 1x1 downsample branch in one launch (gdkvm_conv_down_bias_act):
+    (act(conv(x, weight, stride, pad = R // 2) + bias), conv(x, down_weight, stride) (+ down_bias)); channels_last bf16, the packs as
+    conv_igemm_pack_weights made them."""
+    lib = load()
+    if x.dim() != 4 or not x.is_cuda or x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("conv_down_bias_act needs a channels_last bf16 [N,C,H,W] device tensor (no CPU path)")
+    n, c, hh, ww = x.shape
+    k, _, r, s = weight.shape
+    if tuple(down_weight.shape) != (k, c, 1, 1) or weight.shape[1] != c or packed.numel() != weight.numel() or down_packed.numel() != k * c \
+            or packed.dtype != torch.bfloat16 or down_packed.dtype != torch.bfloat16:
+        raise GdkvmError("conv_down_bias_act: weight [K,C,R,R], down_weight [K,C,1,1] and their conv_igemm_pack_weights copies")
+    if bias.dtype != torch.float32 or bias.numel() != k or (down_bias is not None and (down_bias.dtype != torch.float32 or down_bias.numel() != k)):
+        raise GdkvmError("biases must be float32 [K]")
+    pad = r // 2
+    ho, wo = (hh + 2 * pad - r) // stride + 1, (ww + 2 * pad - s) // stride + 1
+    y = torch.empty((n, k, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    yd = torch.empty_like(y)
+    with torch.cuda.device(x.device):
+        rc = lib.gdkvm_conv_down_bias_act(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), y.data_ptr(), int(relu), down_packed.data_ptr(),
+                                          _ptr(down_bias), yd.data_ptr(), n, c, hh, ww, k, r, s, stride, pad, BF16, _stream(x.device))
+    _check(rc, "gdkvm_conv_down_bias_act")
+    return y, yd
 
 
 def _conv3x3_packed(x: torch.Tensor, packed: torch.Tensor, k_out: int, bias: torch.Tensor) -> torch.Tensor:

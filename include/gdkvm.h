@@ -310,6 +310,13 @@ int gdkvm_conv3x3_wgrad(const void* x, const void* dy, float* dw, void* workspac
 int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y,
                         int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, int kernel,
                         int io_dtype, void* stream);
+/* A residual block's first convolution and its 1x1 downsample branch in ONE launch of kernel 9:  y = act(conv_RxS(x, w) + bias)  and
+ * y_down = conv_1x1(x, w_down) (+ bias_down, may be NULL), both with the same stride and K output channels -- the 1x1's input pixel
+ * is the centre of the R x S window (R = S odd, pad = R / 2).  w and w_down are gdkvm_conv_igemm_pack_weights copies of the
+ * [K, R, S, C] and [K, 1, 1, C] weights; C a multiple of 32, K of 128; bf16. */
+int gdkvm_conv_down_bias_act(const void* x, const void* w, const float* bias, void* y, int relu,
+                             const void* w_down, const float* bias_down, void* y_down,
+                             int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int io_dtype, void* stream);
 /* The same 3x3 / 1 / 1 convolution over the channel concatenation [x1 (C1 channels) ; x2 (C2)] of two NHWC tensors, which is
  * never materialised -- the decoder's  conv(cat(upsample(feature), skip))  without the concatenated copy.  C1, C2 multiples of
  * 64, K of 16, rows of <= 64 pixels; w [K, 3, 3, C1 + C2] or its packed copy (kernel | GDKVM_CONV_PACKED_WEIGHTS); kernel 0 or

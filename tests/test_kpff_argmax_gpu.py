@@ -315,6 +315,31 @@ def test_conv_implicit_gemm_kernel(hip, case):
         hip.conv_bias_act(x, wt[:64].contiguous(**cl), b[:64], None, stride, pad, True, hip.CONV_KERNEL_IGEMM, hip.conv_igemm_pack_weights(wt[:64].contiguous(**cl)))
 
 
+@pytest.mark.parametrize("case", [(9, 64, 28, 28, 128, 3, 2), (5, 128, 14, 14, 256, 3, 2), (2, 32, 9, 11, 128, 5, 2), (3, 96, 8, 8, 128, 3, 1), (1, 64, 31, 17, 128, 3, 2)])
+def test_conv_with_its_downsample_branch_in_one_launch(hip, case):
+    """gdkvm_conv_down_bias_act == (kernel 9 on the R x S layer, kernel 9 on the 1x1 layer of the same stride), bit for bit, and both
+    right against fp64; with and without a bias on the branch."""
+    n, c, h, w, k, rs, stride = case
+    torch.manual_seed(sum(case))
+    cl = dict(memory_format=torch.channels_last)
+    x = torch.randn(n, c, h, w, device="cuda").bfloat16().contiguous(**cl)
+    wt = (torch.randn(k, c, rs, rs, device="cuda") / (rs * rs * c) ** 0.5).bfloat16().contiguous(**cl)
+    wd = (torch.randn(k, c, 1, 1, device="cuda") / c ** 0.5).bfloat16().contiguous(**cl)
+    b, bd = torch.randn(k, device="cuda"), torch.randn(k, device="cuda")
+    pk, pkd = hip.conv_igemm_pack_weights(wt), hip.conv_igemm_pack_weights(wd)
+    zero = torch.zeros(k, device="cuda")
+    for dbias in (None, bd):
+        y, yd = hip.conv_down_bias_act(x, wt, b, pk, wd, pkd, dbias, stride, True)
+        y0 = hip.conv_bias_act(x, wt, b, None, stride, rs // 2, True, hip.CONV_KERNEL_IGEMM, pk)
+        yd0 = hip.conv_bias_act(x, wd, zero if dbias is None else dbias, None, stride, 0, False, hip.CONV_KERNEL_IGEMM, pkd)
+        assert torch.equal(y, y0) and torch.equal(yd, yd0)
+        want = torch.nn.functional.conv2d(x.double(), wd.double(), None if dbias is None else dbias.double(), stride, 0)
+        assert (yd.double() - want).abs().max() <= 2.0 ** -7 * max(1.0, want.abs().max().item())
+    with pytest.raises(hip.GdkvmError):
+        hip.conv_down_bias_act(x, wt[:64].contiguous(**cl), b[:64], hip.conv_igemm_pack_weights(wt[:64].contiguous(**cl)), wd[:64].contiguous(**cl),
+                               hip.conv_igemm_pack_weights(wd[:64].contiguous(**cl)))
+
+
 @pytest.mark.parametrize("case", [(5, 256, 128, 14, 14, 128), (3, 128, 64, 28, 28, 64), (9, 64, 64, 7, 5, 48), (2, 192, 64, 10, 33, 160)])
 def test_conv_over_a_concatenation_that_is_never_built(hip, case):
     """gdkvm_conv_cat_bias_act([x1 ; x2]) == gdkvm_conv_bias_act(cat(x1, x2)) bit for bit (plain and packed weights), and the
