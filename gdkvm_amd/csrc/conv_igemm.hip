@@ -26,6 +26,15 @@ namespace {
 constexpr int IG_TN = 128;                       // workgroup tile: channels (pixels: the template parameter TM)
 constexpr int IG_GD = 2;                         // gather distance, k-steps (two register sets)
 
+#ifdef IG_DIAG
+// diagnostic builds (tools/abl_igemm.py stamps): s_memtime of wave 0 of workgroup (0, 0) around the phases of its first steps
+__device__ unsigned long long* g_ig_diag = nullptr;
+#define IG_STAMP(row, slot) do { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && (row) < 16) { unsigned long long t__; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); g_ig_diag[(row) * 8 + (slot)] = t__; } } while (0)
+#else
+#define IG_STAMP(row, slot) do {} while (0)
+#endif
+
 struct IgArgs {
     const bf16_t* x; const bf16_t* w; const float* bias; const bf16_t* res; bf16_t* y;
     int N, H, W, C, K, R, S, stride, pad, Ho, Wo, relu;
@@ -136,6 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+        IG_STAMP(15, 0);
         gather(min(g0, glast), ga[0], gok[0]);
         gather(min(g0 + 1, glast), ga[1], gok[1]);
 #pragma unroll
@@ -143,12 +153,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
         put(0, ga[0], gok[0]);
         gather(min(g0 + 2, glast), ga[0], gok[0]);
         __syncthreads();
+        IG_STAMP(15, 1);
 
         // step l: MFMAs from LDS buffer l & 1; the pixels of step l + 1 (requested a step and a half ago, set (l + 1) & 1) go to the
         // other buffer behind them, and that set is refilled for step l + 3; weights of step l + WD refill ring set l % WD
         auto step = [&](int l, auto jc) __attribute__((always_inline)) {
             constexpr int j = decltype(jc)::value % WD, gs = (decltype(jc)::value + 1) & 1;   // (l and jc agree modulo UF)
             const int buf = l & 1;
+            IG_STAMP(l, 0);
 #pragma unroll
             for (int sb = 0; sb < SUB; ++sb)
 #pragma unroll
@@ -157,10 +169,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[j][sb][nt], xa, acc[mt][nt], 0, 0, 0);
                 }
+            IG_STAMP(l, 1);
             put(buf ^ 1, ga[gs], gok[gs]);                   // (everyone finished reading that buffer before the last barrier)
+            IG_STAMP(l, 2);
             wload(l + WD, wr[j]);                            // refill the weight set just used
             gather(min(g0 + l + 1 + IG_GD, glast), ga[gs], gok[gs]);
+            IG_STAMP(l, 3);
             __syncthreads();
+            IG_STAMP(l, 4);
         };
         int l = 0;
         for (; l + UF <= L; l += UF)
@@ -168,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
         ig_static_for<0, UF - 1>([&](auto jc) { if (l + decltype(jc)::value < L) step(l + decltype(jc)::value, jc); });
 
         // epilogue: lane (g, li) holds channels n + 4g .. +3 of pixel 16 mt + li
+        IG_STAMP(15, 2);
         const float lo = relu ? 0.f : -INFINITY;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -192,6 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
         }
     };
     run_pass(a.w, 0, nsteps, a.bias, a.res, a.y, a.relu);
+    IG_STAMP(15, 3);
     if (a.w2) run_pass(a.w2, a.centre * spt, spt, a.bias2, nullptr, a.y2, 0);
 }
 
@@ -209,6 +227,10 @@ __global__ __launch_bounds__(256) void conv_igemm_pack_kernel(const uint4* w, ui
 }
 
 }  // namespace
+
+#ifdef IG_DIAG
+extern "C" void gdkvm_ig_diag_buffer(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ig_diag), &p, sizeof(p)); }
+#endif
 
 extern "C" int gdkvm_conv_igemm_pack_weights(const void* w, void* packed, int K, int C, int R, int S, int io_dtype, void* stream)
 {
