@@ -1,8 +1,9 @@
-// conv_dispatch.hip -- C entry of the convolutions that carry their epilogue.  Both kernels behind it are
-// hand-written for gfx950: conv3x3_c64.hip (64 -> 64 channels: weights resident in registers) and conv3x3_tile.hip (input channels
-// in multiples of 64 walked in LDS chunks, weights streamed).  Shapes neither covers -- strided and 1x1 convolutions, channel
-// counts that are no multiple of 64 -- are NOT computed here: the caller keeps them on the framework convolution (north_star:
-// "PyTorch-ROCm for the unchanged encoder / decoder convs") followed by the gdkvm_bias_act epilogue pass.
+// conv_dispatch.hip -- C entry of the convolutions that carry their epilogue.  The three kernels behind it are
+// hand-written for gfx950: conv3x3_c64.hip (3x3 / 1 / 1, 64 -> 64 channels: weights resident in registers), conv3x3_tile.hip
+// (3x3 / 1 / 1, input channels in multiples of 64 walked in LDS chunks, weights streamed, rows of <= 64 pixels) and conv_igemm.hip
+// (kernel 9: any window / stride / padding / row width as an implicit GEMM; C a multiple of 32, K of 128).  Shapes none of them
+// covers (odd channel counts) are NOT computed here: the caller keeps them on the framework convolution followed by the
+// gdkvm_bias_act epilogue pass.
 #include "gdkvm_common.hpp"
 
 int gdkvm_conv3x3_c64_launch(const void* x, const void* w, const float* bias, const void* residual, void* y, int N, int H, int W,

@@ -240,8 +240,8 @@ class FusedConv(nn.Module):
     @staticmethod
     def _tile(cin: int, cout: int, stride: int, has_res: bool, width: int = 0) -> Optional[int]:
         """Which hand-written kernel of gdkvm_conv_bias_act serves a 3x3 layer (include/gdkvm.h): 4 = 64 -> 64 channels, 5 = input
-        channels in multiples of 64; None = none does (strided layers, odd channel counts): the framework convolution + one
-        epilogue pass.  Any choice computes the same result: this is speed only (tools/conv_probe.py)."""
+        channels in multiples of 64; None = neither does (strided layers, wide rows: the general kernel 9 takes those in forward();
+        odd channel counts: the framework convolution + one epilogue pass).  Any choice computes the same result: this is speed only (tools/conv_probe.py)."""
         if stride != 1 or cin % 64 or cout % 16:
             return None
         if cin == 64 and cout == 64:
