@@ -5,9 +5,9 @@
 //
 //   out[p][k] = act(bias[k] + sum_{r, s, c} x[pixel(p) * stride + (r, s) - pad][c] w[k][r][s][c]),   M = N Ho Wo pixels, Kd = R S C
 //
-//   * a workgroup of 4 waves owns 256 output pixels x 128 output channels; wave (wm, wn) 128 pixels x 64 channels = 8 x 4
-//     accumulator tiles (the larger the wave tile, the fewer operand bytes per MFMA: at 64 x 64 both LDS and the vector-memory path
-//     of a CU would be over their rate at half the MFMA peak);
+//   * a workgroup of 4 waves owns 128 output pixels x 128 output channels; every wave takes ALL the pixels and 32 of the channels
+//     (8 x 2 accumulator tiles): no weight fragment is fetched by two waves -- the kernel is bound by the CU's vector-memory path
+//     (weights + gathers), and a 2 x 2 wave grid, where two waves stream the same weights, measured 7-10 % slower;
 //   * per k-step (32 of the Kd products: one tap, 32 channels -- C is a multiple of 32, so a k-step never straddles taps) the 256
 //     pixels' 64-byte channel runs are GATHERED into LDS, one pixel row 80 bytes apart (64 + 16: a ds_read_b128 of 16 consecutive
 //     pixels is conflict-free), double-buffered: the gather of k-step s+1 is in flight as register loads behind the MFMAs of s;
@@ -24,6 +24,9 @@
 namespace {
 
 constexpr int IG_TN = 128;                       // workgroup tile: channels (pixels: the template parameter TM)
+#ifndef IG_WAVES_N
+#define IG_WAVES_N 4
+#endif
 constexpr int IG_GD = 2;                         // gather distance, k-steps (two register sets)
 
 #ifdef IG_DIAG
@@ -55,13 +58,15 @@ __device__ __forceinline__ void ig_static_for(F&& f)
     }
 }
 
-// TM = pixels per workgroup (128: wave (wm, wn) owns 64 pixels x 64 channels, 4 x 4 accumulator tiles); SUB = 32-deep MFMA k-steps
+// TM = pixels per workgroup (128); SUB = 32-deep MFMA k-steps
 // per barrier: with C a multiple of 64 a step gathers 128-byte channel runs (two MFMA k-steps: half the barriers, LDS round trips
 // and index arithmetic per MFMA); SUB = 1 serves channel counts that are only multiples of 32.
 template <int TM, int SUB>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
 {
-    constexpr int MT = TM / 32;                  // 16-pixel tiles per wave
+    constexpr int WN = IG_WAVES_N;               // waves along the channels (4 / WN along the pixels)
+    constexpr int NTW = IG_TN / 16 / WN;         // 16-channel tiles per wave
+    constexpr int MT = TM / 16 / (4 / WN);       // 16-pixel tiles per wave
     constexpr int PITCH = SUB == 2 ? 160 : 80;   // bytes between pixel rows of the LDS tile: 128 + 32 or 64 + 16 (conflict-free ds_read_b128)
     constexpr int PPP = 4 * SUB;                 // 16-byte pieces per pixel and step
     constexpr int GP = TM * PPP / 256;           // pieces per thread and step
@@ -69,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
     constexpr int UF = SUB == 2 ? 2 : 6;         // unroll: lcm(weight ring, two gather sets) -> static register indices
     __shared__ __attribute__((aligned(16))) unsigned char s_a[2][TM * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w / WN, wn = w % WN;
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * IG_TN;
     const int nsteps = a.ksteps / SUB;           // steps of 32 SUB products
 
@@ -117,33 +122,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
         }
     };
 
-    const unsigned abase = (unsigned)(((TM / 2) * wm + li) * PITCH + 16 * g);      // this lane's B fragment of pixel tile 0: pixel li, k 8g..
+    const unsigned abase = (unsigned)((16 * MT * wm + li) * PITCH + 16 * g);      // this lane's B fragment of pixel tile 0: pixel li, k 8g..
 
     // One convolution over the gathered pixels: `L` steps starting at gather step g0, weights `wpk` packed for exactly those steps.
     // The layer itself is (0, nsteps); a second pass over the CENTRE tap alone with another weight pack is the 1x1 / same-stride
     // convolution of the same input (the residual block's downsample branch), computed here on the pixels' geometry already set up.
     auto run_pass = [&](const bf16_t* wpk, int g0, int L, const float* bias, const bf16_t* res, bf16_t* y, int relu) __attribute__((always_inline)) {
         // weights: fragment (n-tile, k-step) = 1 KiB contiguous; this wave's four n-tiles, SUB k-steps per step
-        const bf16_t* wp = wpk + ((size_t)((n0 + 64 * wn) / 16) * (L * SUB) * 64 + lane) * 8;
+        const bf16_t* wp = wpk + ((size_t)((n0 + 16 * NTW * wn) / 16) * (L * SUB) * 64 + lane) * 8;
         const size_t nt_stride = (size_t)(L * SUB) * 512;
-        bf16x8 wr[WD][SUB][4];
-        auto wload = [&](int l, bf16x8 (&d)[SUB][4]) __attribute__((always_inline)) {
+        bf16x8 wr[WD][SUB][NTW];
+        auto wload = [&](int l, bf16x8 (&d)[SUB][NTW]) __attribute__((always_inline)) {
             const size_t off = (size_t)min(l, L - 1) * (512 * SUB);
 #pragma unroll
             for (int sb = 0; sb < SUB; ++sb)
 #pragma unroll
 #ifdef IG_ABL_SAMEW                                            // ablation: every weight fragment from one (cached) KiB
-                for (int nt = 0; nt < 4; ++nt) d[sb][nt] = *reinterpret_cast<const bf16x8*>(wp + 0 * (nt * nt_stride + off + 512 * sb));
+                for (int nt = 0; nt < NTW; ++nt) d[sb][nt] = *reinterpret_cast<const bf16x8*>(wp + 0 * (nt * nt_stride + off + 512 * sb));
 #else
-                for (int nt = 0; nt < 4; ++nt) d[sb][nt] = *reinterpret_cast<const bf16x8*>(wp + nt * nt_stride + off + 512 * sb);
+                for (int nt = 0; nt < NTW; ++nt) d[sb][nt] = *reinterpret_cast<const bf16x8*>(wp + nt * nt_stride + off + 512 * sb);
 #endif
         };
         const int glast = g0 + L - 1;
-        f32x4 acc[MT][4];
+        f32x4 acc[MT][NTW];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         IG_STAMP(15, 0);
         gather(min(g0, glast), ga[0], gok[0]);
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
                 for (int mt = 0; mt < MT; ++mt) {
                     const bf16x8 xa = *reinterpret_cast<const bf16x8*>(&s_a[buf][abase + mt * 16 * PITCH + 64 * sb]);
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[j][sb][nt], xa, acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[j][sb][nt], xa, acc[mt][nt], 0, 0, 0);
                 }
             IG_STAMP(l, 1);
             put(buf ^ 1, ga[gs], gok[gs]);                   // (everyone finished reading that buffer before the last barrier)
@@ -187,12 +192,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
         IG_STAMP(15, 2);
         const float lo = relu ? 0.f : -INFINITY;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int ch = n0 + 64 * wn + 16 * nt + 4 * g;
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int ch = n0 + 16 * NTW * wn + 16 * nt + 4 * g;
             const f32x4 b4 = bias ? *reinterpret_cast<const f32x4*>(bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int p = m0 + (TM / 2) * wm + 16 * mt + li;
+                const int p = m0 + 16 * MT * wm + 16 * mt + li;
                 if (p >= a.M) continue;
                 f32x4 v = acc[mt][nt] + b4;
                 const size_t o = (size_t)p * a.K + ch;

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "gdkvm_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "_abl")
 VARIANTS = {"ig_base": [], "ig_samepix": ["-DIG_ABL_SAMEPIX"], "ig_samew": ["-DIG_ABL_SAMEW"], "ig_both": ["-DIG_ABL_SAMEPIX", "-DIG_ABL_SAMEW"],
-            "ig_diag": ["-DIG_DIAG"]}
+            "ig_diag": ["-DIG_DIAG"], "ig_wn2": ["-DIG_WAVES_N=2"], "ig_wn1": ["-DIG_WAVES_N=1"]}
 
 if sys.argv[1] == "build":
     os.makedirs(OUT, exist_ok=True)
