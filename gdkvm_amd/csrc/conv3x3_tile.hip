@@ -33,8 +33,9 @@ constexpr int CT_PIX = CT_PIX_BYTES;              // bytes between LDS pixels: 8
                                          // conflict-free for ds_read_b128: its 16-lane groups mix two lane quarters)
 constexpr int CT_SLOTS = CT_PIX / 16;    // 16-byte LDS slots per pixel
 constexpr int CT_MAXMT = 13;             // 16-pixel tiles per workgroup tile (208 pixels)
-// wave grids <NWN, NTW>: 1 = <4, 1>, 2 = <4, 2>, 3 = <2, 2>; the defaults are the measured picks (tools/conv_probe.py)
-constexpr int CT_VARIANT_128 = 2, CT_VARIANT_64 = 1;
+// wave grids <NWN, NTW>: 1 = <4, 1>, 2 = <4, 2>, 3 = <2, 2>; the defaults are the measured picks (tools/conv_probe.py; K = 64: <2, 2> since the
+// weights are packed -- 121 against 129 us on the 192 -> 64 layer: half the LDS operand reads per MFMA, and the fourfold weight fetch is cheap now)
+constexpr int CT_VARIANT_128 = 2, CT_VARIANT_64 = 3;
 
 __device__ const uint4 g_ct_zero16 = {0, 0, 0, 0};
 
