@@ -10,6 +10,8 @@ Prints ONE JSON line on rank 0 (contract in the task prompt) with two extra obje
                 live with HIP events on the launch stream; achieved = SURVEY.md §8(d) algorithmic bytes / time
   cpu_baseline  the CPU oracle module (oracle/model_ref.py: PyTorch CPU convs + scalar C memory path) on a
                 bounded sample of the same workload, rank 0, N=1 only
+and a third, `train_step`: BASELINE.json configs[3]'s per-GPU training step (16 clips x 32 frames, bf16 autocast, AdamW; DDP
+over RCCL when N > 1), a few steps measured AFTER the headline's timed region -- it never enters `value`.
 Clips shard over GPUs with no data-path collective (inference): scaling is weak, per-GPU batch fixed.
 """
 from __future__ import annotations
@@ -25,12 +27,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# The convolutions either side of the memory path stay MIOpen (north_star); with fixed shapes let it search its solvers
-# once (MIOpen "find" through PyTorch's benchmark flag) instead of taking the immediate-mode pick: 2.71 -> 1.88 ms per
-# cfg2 step.  The search runs inside the untimed warm-up steps.
-torch.backends.cudnn.benchmark = True
+# (The inference forward has no library convolution left -- profiles/r02_p_bench_cfg2_steady_state.csv -- so MIOpen's solver
+# search, torch.backends.cudnn.benchmark, is switched on only by the training leg, whose strided / 1x1 / stem layers are MIOpen.)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_MEASURED_GBS = 6290.0      # same table: what a float4 copy reaches; quoted beside the spec fraction as frac_measured_peak
 BF16_MFMA_PEAK_TFS = 2500.0    # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA (spec)
 
 
@@ -160,13 +161,17 @@ def time_events(fn, iters, warmup=3):
     return sum(ms) / len(ms), ms[len(ms) // 2]
 
 
-def bench_train(args, world, rank, dev):
+def run_train(args, world, rank, dev, steps, warmup):
     """BASELINE configs[3]: EchoNet-Dynamic training, DDP over the GPUs of one node, 16 clips x 32 frames per GPU,
     bf16 autocast with fp32 master weights, AdamW lr 1e-4 (the reference guide's learning rate).  A step = forward,
-    loss, backward (HIP backward kernels + RCCL gradient all-reduce), optimiser update."""
+    loss, backward (HIP backward kernels + RCCL gradient all-reduce), optimiser update.  Returns the timing (max over
+    ranks) on every rank; the caller prints."""
     import torch.distributed as dist
     from gdkvm_amd.model import GDKVM, GDKVMConfig
     from gdkvm_amd.train import train_step, wrap_ddp
+    # the strided / 1x1 / stem layers of the TRAINING build are MIOpen in both directions: with fixed shapes let it search its
+    # solvers once (find mode) instead of taking the immediate-mode pick; the search runs in the untimed set-up step
+    torch.backends.cudnn.benchmark = True
     cfg = GDKVMConfig()
     torch.manual_seed(3)
     model = GDKVM(cfg).train().to(dev).to(memory_format=torch.channels_last)
@@ -183,12 +188,13 @@ def bench_train(args, world, rank, dev):
             dist.barrier()
         torch.cuda.synchronize()
 
-    loss = train_step(ddp, opt, frames, target, torch.bfloat16)      # set-up: MIOpen's solver search (find mode), not a step
-    for _ in range(args.warmup):
+    first = train_step(ddp, opt, frames, target, torch.bfloat16)     # set-up: MIOpen's solver search (find mode), not a step
+    loss = first
+    for _ in range(warmup):
         loss = train_step(ddp, opt, frames, target, torch.bfloat16)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = train_step(ddp, opt, frames, target, torch.bfloat16)
     barrier()
     dt = time.perf_counter() - t0
@@ -196,19 +202,58 @@ def bench_train(args, world, rank, dev):
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
+    return {"frames_per_s": round(world * B * T * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
+            "warmup": warmup, "first_loss": round(float(first), 5), "final_loss": round(float(loss), 5),
+            "wrapped": type(ddp).__name__,
+            "workload": "BASELINE.json configs[3]: EchoNet-Dynamic training, DDP, 16 clips/GPU (global batch 128 at 8 GPUs), "
+                        "bf16 autocast, AdamW lr 1e-4",
+            "clips_per_gpu": B, "frames_per_clip": T, "image": f"{S}x{S}",
+            "sharding": f"DDP over {world} GPU(s): one gradient all-reduce per step (RCCL)" if world > 1
+                        else "one GPU: no gradient exchange (the one-rank RCCL path is tests/test_nccl_gpu.py)"}
+
+
+def bench_train(args, world, rank, dev):
+    """`--mode train`: the configs[3] step as the headline of its own JSON line."""
+    import torch.distributed as dist
+    res = run_train(args, world, rank, dev, args.steps, args.warmup)
     if rank == 0:
         print(json.dumps({"metric": "training frames/sec (GDKVM forward+backward+AdamW), EchoNet 112x112x32 clips",
-                          "value": round(world * B * T * args.steps / dt, 1), "unit": "frames/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                          "value": res["frames_per_s"], "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                          "config": {"workload": "BASELINE.json configs[3]: EchoNet-Dynamic training, DDP, 16 clips/GPU "
-                                                 "(global batch 128 at 8 GPUs), bf16 autocast, AdamW lr 1e-4",
-                                     "clips_per_gpu": B, "frames_per_clip": T, "image": f"{S}x{S}",
-                                     "sharding": f"DDP over {world} GPU(s): one gradient all-reduce per step (RCCL)"},
-                          "final_loss": round(float(loss), 5)}), flush=True)
+                          "config": {"workload": res["workload"], "clips_per_gpu": res["clips_per_gpu"],
+                                     "frames_per_clip": res["frames_per_clip"], "image": res["image"], "sharding": res["sharding"]},
+                          "final_loss": res["final_loss"]}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+class Watchdog:
+    """Bounds a leg that contains collectives: if it has not been disarmed after `seconds`, `on_fire()` runs (rank 0 prints the
+    line it has) and the process leaves with os._exit -- a hung RCCL call cannot be interrupted from Python, and one rank
+    exiting normally would leave the others waiting.  Every rank arms its own."""
+
+    def __init__(self, seconds, on_fire):
+        import threading
+        self._t = threading.Timer(seconds, self._fire)
+        self._t.daemon = True
+        self._on_fire = on_fire
+
+    def _fire(self):
+        try:
+            self._on_fire()
+        finally:
+            sys.stdout.flush()
+            os._exit(0)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._t.cancel()
+        return False
 
 
 def main():
@@ -224,6 +269,10 @@ def main():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = BASELINE configs[1] (the headline metric); train = configs[3]: DDP training step")
     ap.add_argument("--kernel-iters", type=int, default=50)
+    ap.add_argument("--train-steps", type=int, default=5,
+                    help="infer mode: timed steps of the configs[3] training leg reported as `train_step` (0 = skip the leg)")
+    ap.add_argument("--train-warmup", type=int, default=2)
+    ap.add_argument("--train-leg-timeout", type=float, default=240.0, help="seconds before the training leg is given up (N > 1)")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU/gloo ranks, no kernels: exercises the --gpus N launch path only (tests)")
     args = ap.parse_args()
@@ -289,8 +338,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step()                                                  # set-up, not a step: MIOpen's solver search for these shapes (find
-    for _ in range(args.warmup):                            # mode) runs on the first call of every convolution
+    step()                                                  # set-up, not a step: weight packs, library load, first launches
+    for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
@@ -337,7 +386,8 @@ def main():
         mfma_busy, mfma_src = committed_mfma_busy() if (B, T, S) == (16, 32, 112) else (None, None)
         out["roofline"] = {"kernel": "gdr_prepm_kernel+gdr_affine_scan_kernel (one gdkvm_scan_fwd)", "bound": "hbm",
                            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+                           "frac": round(achieved / HBM_PEAK_GBS, 5), "frac_measured_peak": round(achieved / HBM_MEASURED_GBS, 5),
+                           "traffic": traffic, "traffic_source": traffic_src,
                            "mfma_busy_frac": mfma_busy, "mfma_busy_source": mfma_src,
                            "algorithmic_bytes": alg, "avg_ms": {"gdr_prepm_kernel": round(prep_ms, 4),
                                                                 "gdr_affine_scan_kernel": round(scan_ms, 4),
@@ -354,9 +404,14 @@ def main():
         kpff_ms, _ = time_events(lambda: ops.kpff_fwd(Lk, r.reshape(B * T, N, Hh * Dv), Pk, kp.wa, kp.ba, kp.wl, kp.wg, hw, hw,
                                                       out=fo, workspace=kws, packed=True), args.kernel_iters)
         kpff_bytes = 2 * B * T * N * (Hh * Dk + Hh * Dv + 2 * Cp) + 2 * (2 * Cp * (Cp + Hh * Dk + Hh * Dv) + Cp * Hh * Dk + Cp * Hh * Dv)
-        lowres = torch.randn(B * T, cfg.num_classes, S // 4, S // 4, device=dev, generator=gq).bfloat16()
-        am_ms, _ = time_events(lambda: ops.upsample_argmax_dice(lowres, S, S, None), args.kernel_iters)
-        am_bytes = lowres.numel() * 2 + B * T * S * S
+        # what the timed forward runs last: the decoder's 1x1 head + bilinear upsample + argmax in one kernel, on the stride-4
+        # feature (channels_last bf16) -- the class planes never reach memory
+        w4 = cfg.widths[0]
+        feat = torch.randn(B * T, w4, S // 4, S // 4, device=dev, generator=gq).bfloat16().contiguous(memory_format=torch.channels_last)
+        hw_ = torch.randn(cfg.num_classes, w4, device=dev, generator=gq) / w4 ** 0.5
+        hb_ = torch.zeros(cfg.num_classes, device=dev)
+        am_ms, _ = time_events(lambda: ops.head_upsample_argmax_dice(feat, hw_, hb_, S, S, None), args.kernel_iters)
+        am_bytes = feat.numel() * 2 + B * T * S * S
         ck_, cv_ = Hh * Dk, Hh * Dv
         kpff_flops = B * T * 2 * N * (2 * Cp * (Cp + ck_ + cv_) + Cp * ck_ + Cp * cv_)
         out["roofline"]["other_kernels"] = {
@@ -366,9 +421,9 @@ def main():
                                  "frac": round(kpff_bytes / (kpff_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                                  "flops": kpff_flops, "achieved_TFLOPs": round(kpff_flops / (kpff_ms * 1e-3) / 1e12, 1),
                                  "frac_bf16_mfma": round(kpff_flops / (kpff_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFS, 5)},
-            "upsample_argmax_dice_kernel": {"avg_ms": round(am_ms, 4), "algorithmic_bytes": am_bytes,
-                                            "achieved_GBps": round(am_bytes / (am_ms * 1e-3) / 1e9, 1),
-                                            "frac": round(am_bytes / (am_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
+            "head_upsample_argmax_dice_kernel": {"avg_ms": round(am_ms, 4), "algorithmic_bytes": am_bytes,
+                                                 "achieved_GBps": round(am_bytes / (am_ms * 1e-3) / 1e9, 1),
+                                                 "frac": round(am_bytes / (am_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
         # the same fraction for the scan at the other BASELINE.json shapes that fit one GPU (informational, same timing method,
         # a few launches each): configs[2] CAMUS 256x256x20 (N = 256 tokens per frame) and configs[4], the 512-frame 256x256 clip
         # -- as one gdkvm_scan_fwd call, and as gdkvm_scan_fwd_segmented with the segment count it picks for that shape
@@ -426,7 +481,31 @@ def main():
             else:                                            # a (nearly) constant mask says nothing about the kernels
                 out["dice_vs_cpu"] = None
                 out["dice_skipped"] = f"degenerate reference mask: foreground fraction {fg:.4f} outside (0.2, 0.8)"
-        print(json.dumps(out), flush=True)
+
+    # ---- BASELINE configs[3] beside the headline: a few training steps at the per-GPU shape, AFTER the timed region and the
+    # kernel timings above (every rank; DDP + RCCL all-reduce when N > 1).  It can only add a `train_step` object: a failure is
+    # reported inside it, and a hung collective is cut off by the watchdog with the line printed as it stands.
+    def emit():
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+
+    if args.train_steps > 0:
+        del model, frames
+        torch.cuda.empty_cache()
+
+        def gave_up():
+            out["train_step"] = {"error": f"no result after {args.train_leg_timeout:.0f} s (collective hung?)"}
+            emit()
+
+        try:
+            if world > 1:
+                with Watchdog(args.train_leg_timeout, gave_up):
+                    out["train_step"] = run_train(args, world, rank, dev, args.train_steps, args.train_warmup)
+            else:
+                out["train_step"] = run_train(args, world, rank, dev, args.train_steps, args.train_warmup)
+        except Exception as e:                               # noqa: BLE001 -- the headline must survive the extra leg
+            out["train_step"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+    emit()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

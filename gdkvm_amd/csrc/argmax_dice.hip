@@ -136,6 +136,10 @@ __global__ __launch_bounds__(256) void upsample_argmax_dice_kernel(UpArgs a)
     }
     const int npl = (lr1 - lr0 + 1) * a.wl;              // low-resolution pixels of the band
     const bool staged = a.staged && lr1 - lr0 + 1 <= a.lr_cap;
+    // Head fused in: `logits` is the NHWC decoder FEATURE, which the unstaged taps below would read as NCHW class planes (in bounds,
+    // wrong values).  The host sizes lr_cap as a proven bound on a block's band, so this never happens; if that bound is ever broken
+    // the launch must die, not return plausible masks.
+    if (a.hw_ && !staged) __builtin_trap();
     if (staged && a.hw_) {
         // the head on the band: C/V lanes per pixel, lane cg keeps class cg (as head_logits_kernel; same sums, same rounding)
         constexpr int V = IO == GDKVM_F32 ? 4 : 8;

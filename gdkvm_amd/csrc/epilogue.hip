@@ -1,5 +1,7 @@
-// epilogue.hip -- fused pointwise epilogue for the (unchanged, MIOpen) encoder/decoder convolutions in the
-// inference build: y = act(x + bias[c] (+ residual)), NHWC, in place or out of place.
+// epilogue.hip -- pointwise passes around the encoder/decoder convolutions: the fused epilogue
+// y = act(x + bias[c] (+ residual)), NHWC, in place or out of place -- what a LIBRARY convolution is followed by (the training
+// build's strided / 1x1 / stem layers, odd channel counts; the hand-written convolution kernels carry this epilogue inside) --
+// plus upsample(+concat), the stem's bias + ReLU + max-pool and space-to-depth passes, and the max-pool pair of the training build.
 // After BatchNorm folding every conv carries a bias; PyTorch then runs the bias add, the residual add and the ReLU as
 // three separate full-tensor passes (1.1 ms of a 3.6 ms cfg2 forward).  This is one pass: 16-byte loads/stores,
 // HBM-bound by construction.
@@ -554,12 +556,20 @@ extern "C" int gdkvm_upsample_cat(const void* lo, const void* skip, void* out,
     if (!lo || !out || !gdkvm_aligned16(lo) || (skip && !gdkvm_aligned16(skip)) || !gdkvm_aligned16(out))
         return gdkvm_fail(GDKVM_ERR_ARG, "upsample_cat: null or misaligned pointer");
     if (int rc = gdkvm_check_device()) return rc;
-    if ((size_t)W * (C1 + C2) >= (1u << 20) || (size_t)Nimg * H >= (1u << 20)) return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_cat: row too long or too many rows");
-    size_t blocks = (size_t)Nimg * H;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(upsample_cat_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const bf16_t*>(lo), static_cast<const bf16_t*>(skip), static_cast<bf16_t*>(out),
-                       Nimg, hl, wl, H, W, C1, C2, (float)hl / (float)H, (float)wl / (float)W, 8.0f / (float)C1, 8.0f / (float)C2, 1.0f / (float)H);
+    if ((size_t)W * (C1 + C2) >= (1u << 20) || (size_t)H >= (1u << 20)) return gdkvm_fail(GDKVM_ERR_SHAPE, "upsample_cat: row too long or image too tall");
+    // the kernel's float-reciprocal row -> (image, y) split is exact below 2^20 rows: larger batches go as several launches over
+    // image ranges (16384 frames x 64 rows used to be refused)
+    const int per = (int)(((1u << 20) - 1) / (unsigned)H);
+    for (int n0 = 0; n0 < Nimg; n0 += per) {
+        const int nn = Nimg - n0 < per ? Nimg - n0 : per;
+        size_t blocks = (size_t)nn * H;
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL(upsample_cat_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const bf16_t*>(lo) + (size_t)n0 * hl * wl * C1,
+                           skip ? static_cast<const bf16_t*>(skip) + (size_t)n0 * H * W * C2 : nullptr,
+                           static_cast<bf16_t*>(out) + (size_t)n0 * H * W * (C1 + C2),
+                           nn, hl, wl, H, W, C1, C2, (float)hl / (float)H, (float)wl / (float)W, 8.0f / (float)C1, 8.0f / (float)C2, 1.0f / (float)H);
+    }
     GDKVM_LAUNCH_CHECK("upsample_cat_bf16_kernel");
     return GDKVM_OK;
 }

@@ -5,12 +5,17 @@
 //   F   = P + g_l * (L Wl^T) + g_g * (Gms Wg^T)
 //
 // One workgroup owns a tile of <= 64 tokens made of whole 4-row bands of the h x w grid (or the whole
-// frame when it has <= 64 tokens), so every 2x2 and 4x4 pooling cell is tile-local.  The tile's [P;L;G]
-// rows are staged once in LDS (fp32, padded rows -> conflict-free 16-byte operand reads), G is pooled in
-// place, and the four channel mixes run as ONE pass of exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) over the
-// concatenated input: each wave owns 16 output channels x 64 tokens x {g_l, g_g, L Wl, Gms Wg} = 16
-// accumulator tiles, reads its weight rows straight from L2 with 16-byte loads (each weight element is
-// fetched once per workgroup), and fuses bias, sigmoid, gating and the residual into the epilogue.
+// frame when it has <= 64 tokens), so every 2x2 and 4x4 pooling cell is tile-local; the four channel mixes run as ONE
+// MFMA pass over the concatenated input [P ; L ; Gms] with bias, sigmoid, gating and the residual in the epilogue.
+// Three arms, chosen by gdkvm_kpff_fwd from the I/O type, the channel counts and the workspace:
+//   kpff_bf16_kernel<NT>  bf16 I/O, channels % 32 == 0: v_mfma_f32_16x16x32_bf16, NT 64-token tiles per 8-wave workgroup as
+//                         bf16 B images in LDS, weights re-packed in MFMA-fragment order and streamed through a static
+//                         register ring (the inference path; also gdkvm_proj_rows' machinery)
+//   kpff_split_kernel     fp32 I/O with a workspace: every operand as two bf16 terms, three bf16 MFMAs per product
+//   kpff_kernel<IO>       exact fp32 MFMA (v_mfma_f32_16x16x4_f32): rows staged in LDS as fp32 (padded rows -> conflict-free
+//                         16-byte operand reads), G pooled in place, weights read row-major from L2 with 16-byte loads; odd
+//                         channel counts, or a caller that hands over no workspace
+// plus the training forward (saves gates / mixes / pooled feature) and the elementwise halves of the backward.
 #include <atomic>
 #include <type_traits>
 #include "gdkvm_common.hpp"

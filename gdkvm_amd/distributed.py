@@ -53,7 +53,7 @@ def gather_clips(local: torch.Tensor, n_total: int) -> torch.Tensor:
     return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], 0)
 
 
-def context_parallel_scan(q, k, v, alpha, beta, state=None, rule: int = 2, flags: int = 0, backend=None):
+def context_parallel_scan(q, k, v, alpha, beta, state=None, rule: int = 2, flags: int = 0, backend=None, force_exchange: bool = False):
     """Sequence-parallel scan of clips whose TIME axis is sharded over the ranks of the default process group (rank r holds
     frames [r*T_local, (r+1)*T_local) of every clip) -- SURVEY.md §8f row n3.
 
@@ -62,7 +62,9 @@ def context_parallel_scan(q, k, v, alpha, beta, state=None, rule: int = 2, flags
     ([B,Hh,Dk,Dk+Dv] fp32 per rank: 80 KB per clip-head at Dk=64, Dv=256), every rank folds the maps of the ranks before it
     into its true start state, S_start_r = Phi_{r-1}(...Phi_0 S_0 + S_loc_0...) + S_loc_{r-1}, and scans its frames from
     there, reusing its prepared workspace.  Returns (R_local, S_final) with S_final identical on every rank.
-    ``backend`` defaults to gdkvm_amd.ops (HIP); tests inject a CPU implementation of the same three calls."""
+    ``backend`` defaults to gdkvm_amd.ops (HIP); tests inject a CPU implementation of the same three calls.
+    ``force_exchange`` takes the exchange branch on a one-rank group too (transition matrix, all-gather of device tensors, fold,
+    second pass): the one-GPU RCCL test of this path."""
     if backend is None:
         from . import ops as backend
     B, T, N, Hh, Dk = q.shape
@@ -74,7 +76,7 @@ def context_parallel_scan(q, k, v, alpha, beta, state=None, rule: int = 2, flags
         flags |= 8                                      # GDKVM_FLAG_WIDE_RANGE
     backend.scan_prep(q, k, v, beta, ws, rule=rule, flags=flags)
     cur = state if state is not None else torch.zeros((B, Hh, Dk, Dv), dtype=torch.float32, device=q.device)
-    if world > 1:
+    if world > 1 or (force_exchange and dist.is_initialized()):
         phi = backend.scan_transition(q, alpha, ws, Dv, flags=flags)
         _, s_loc = backend.scan_apply(q, alpha, ws, Dv, flags=flags, want_readout=False)
         mine = torch.cat([phi, s_loc], -1).contiguous()                      # [B,Hh,Dk,Dk+Dv]

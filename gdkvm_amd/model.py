@@ -6,10 +6,11 @@ return_state=False) -> logits[B,T,ncls,H,W] (, state)`` with parameters grouped 
 query_proj.* / value_proj.* / gate_proj.* / kpff.* / decoder.*`` and one ``_KEY_REMAP`` table applied in
 ``load_state_dict`` for the day real checkpoints are visible.
 
-Only the CNN encoder / decoder (unchanged PyTorch-ROCm convolutions, BASELINE.json north_star) run in
-torch.  The memory path between them -- LKVA read, GDR write, KPFF -- is ``ops.scan_fwd`` /
-``ops.kpff_fwd`` (hand-written HIP behind include/gdkvm.h).  There is no eager fallback: on a CPU tensor
-or without libgdkvm_hip.so the forward raises.
+The memory path between encoder and decoder -- LKVA read, GDR write, KPFF -- is ``ops.scan_fwd`` / ``ops.kpff_fwd``
+(hand-written HIP behind include/gdkvm.h).  The CNN either side of it is hand-written too in the
+inference build (``fuse_for_inference()``: every convolution runs on csrc/conv3x3_*.hip, conv_igemm.hip, stem_conv_pool.hip
+with its epilogue inside); the training build keeps torch / MIOpen for the strided, 1x1 and stem layers only.  There is no
+eager fallback for the memory path: on a CPU tensor or without libgdkvm_hip.so the forward raises.
 """
 from __future__ import annotations
 
@@ -86,8 +87,9 @@ def _bn_act(bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, residual: Optional[
 
 
 def _conv(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
-    """A training-build convolution: the stride-1 3x3 layers with channel counts in multiples of 64 run their forward and data
-    gradient on the hand-written kernels (ops.conv3x3; the weight gradient stays the framework's), everything else is conv(x)."""
+    """A training-build convolution: the stride-1 3x3 layers with channel counts in multiples of 64 run forward, data gradient
+    and weight gradient on the hand-written kernels (ops.conv3x3: csrc/conv3x3_tile.hip, conv3x3_wgrad.hip), everything else is
+    conv(x) (MIOpen)."""
     if (torch.is_grad_enabled() and isinstance(conv, nn.Conv2d) and conv.bias is None and conv.padding_mode == "zeros"
             and ops.conv3x3_train_served(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
         return ops.conv3x3(x, conv.weight)
@@ -226,8 +228,10 @@ def _fold_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d) -> nn.Conv2d:
 
 
 class FusedConv(nn.Module):
-    """Inference-only: a bias-free MIOpen convolution followed by ONE fused HIP epilogue pass (bias + optional residual +
-    optional ReLU, in place) instead of PyTorch's separate bias-add / add / clamp kernels.  The bias is kept in fp32."""
+    """Inference-only: a convolution with its folded-BatchNorm bias, optional residual add and optional ReLU.  On the GPU
+    in bf16 every 3x3 layer of the model runs as ONE hand-written kernel with the epilogue inside (forward(): kernels 4 / 5 /
+    9 of gdkvm_conv_bias_act); what those do not serve (odd channel counts, fp32) is a library convolution followed by ONE
+    fused HIP epilogue pass instead of PyTorch's separate bias-add / add / clamp kernels.  The bias is kept in fp32."""
 
     def __init__(self, conv: nn.Conv2d, relu: bool):
         super().__init__()
@@ -429,15 +433,20 @@ class GDKVM(nn.Module):
     # ------------------------------------------------------------------ packed-weight caches of the inference build
     def invalidate_packed_weights(self):
         """Drop the weight packs the inference forward keeps between calls (K/Q/V fragment pack, fp32 gate and head weights,
-        KPFF bf16 pack).  They are keyed on every source tensor's version counter and address (`_wkey`), which catches
+        KPFF bf16 pack, every FusedConv's fragment-ordered weight copy).  They are keyed on every source tensor's version counter and address (`_wkey`), which catches
         optimiser steps, ``load_state_dict`` and re-binding; an in-place write through ``.data`` changes neither, so code that
         does one must call this.  Called by load_state_dict(), _apply() (.to / .cuda / .half ...), train() and
         fuse_for_inference()."""
         for name in ("_qkv_pack", "_gate_w32", "_kpff_pack"):
             self.__dict__.pop(name, None)
-        dec = self._modules.get("decoder") if "_modules" in self.__dict__ else None
+        if "_modules" not in self.__dict__:
+            return
+        dec = self._modules.get("decoder")
         if dec is not None:
             dec.__dict__.pop("_head_w32", None)
+        for m in self.modules():                            # the fragment-ordered weight copies of the fused convolutions
+            if isinstance(m, FusedConv):
+                m.__dict__.pop("_wpack", None)
 
     def _apply(self, fn, recurse=True):
         self.invalidate_packed_weights()

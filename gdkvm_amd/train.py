@@ -22,7 +22,10 @@ def segmentation_loss(logits: torch.Tensor, target: torch.Tensor, dice_weight: f
     lg = logits.reshape(B * T, C, H, W).float()
     tg = target.reshape(B * T, H, W).long()
     labelled = (tg >= 0) & (tg < C)                 # anything else (255 in annotation masks) carries no class
-    ce = F.cross_entropy(lg, torch.where(labelled, tg, torch.full_like(tg, -100)), ignore_index=-100)
+    if bool(labelled.any()):
+        ce = F.cross_entropy(lg, torch.where(labelled, tg, torch.full_like(tg, -100)), ignore_index=-100)
+    else:                                           # no labelled pixel: the mean over none is 0 here, as in seg_loss_finalize_kernel
+        ce = lg.sum() * 0.0                         # (F.cross_entropy returns NaN, which would reach AdamW)
     p = lg.softmax(1)
     oh = (F.one_hot(torch.where(labelled, tg, torch.zeros_like(tg)), C) * labelled.unsqueeze(-1)).permute(0, 3, 1, 2).float()
     inter = (p * oh).sum((0, 2, 3))
@@ -38,12 +41,18 @@ def segmentation_loss_lowres(lowres_logits: torch.Tensor, target: torch.Tensor, 
     return ops.seg_loss(lowres_logits.reshape(B * T, C, h, w), target.reshape(B * T, *target.shape[-2:]), dice_weight, eps)
 
 
-def wrap_ddp(model: nn.Module, device: Optional[torch.device] = None, bucket_cap_mb: int = 25) -> nn.Module:
+def wrap_ddp(model: nn.Module, device: Optional[torch.device] = None, bucket_cap_mb: int = 25, force: bool = False) -> nn.Module:
     """DistributedDataParallel over the default process group (gradient all-reduce bucketed and overlapped with the
     backward).  xGMI is point-to-point, so buckets are kept large enough to amortise ring latency: the whole model is
-    ~16 MB of fp32 gradients, i.e. one or two buckets."""
+    ~16 MB of fp32 gradients, i.e. one or two buckets.  A single process needs no wrapper and gets the bare model back;
+    ``force`` wraps even at world size 1 (an initialised group is still required): the reducer's hooks, bucket views and
+    the RCCL all-reduce then run for real on a one-rank group, which is how the one-GPU tests exercise this path."""
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
+        if force:
+            raise RuntimeError("wrap_ddp(force=True) needs an initialised process group")
+        return model
+    if dist.get_world_size() == 1 and not force:
         return model
     ids = None if device is None or device.type != "cuda" else [device.index]
     return nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb,

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Child process of tests/test_nccl_gpu.py: BASELINE.json configs[3] (DDP training over RCCL) as far as ONE GPU allows.
+
+A one-rank ``nccl`` process group is legal on one GPU and runs the real RCCL code path: communicator set-up, DDP's reducer
+(bucket views, autograd hooks on the HIP autograd Functions, the all-reduce launch) and all_gather of device tensors.  The
+group is initialised before any other GPU call of this process, which is why this is a child and not a pytest function.
+
+    python tests/nccl_one_rank_child.py ddp [B T S]     three train steps, DDP-wrapped (forced) against the bare model
+    python tests/nccl_one_rank_child.py cp              context_parallel_scan's exchange branch against gdkvm_scan_fwd
+Prints ONE JSON line; the parent asserts on it.  (reprod/index.astro:238-249 of the reference's website is the recipe: a
+torch.distributed launcher, one process per GPU.)"""
+import copy
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def init_group():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    return dev
+
+
+def ddp(dev, B, T, S):
+    from gdkvm_amd import ops
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    from gdkvm_amd.train import train_step, wrap_ddp
+    ops.require_native()
+    torch.manual_seed(3)
+    bare = GDKVM(GDKVMConfig()).train().to(dev).to(memory_format=torch.channels_last)
+    twin = copy.deepcopy(bare)
+    wrapped = wrap_ddp(twin, dev, force=True)
+    assert isinstance(wrapped, torch.nn.parallel.DistributedDataParallel), type(wrapped)
+    g = torch.Generator(device="cpu").manual_seed(3000)
+    frames = torch.rand(B, T, 3, S, S, generator=g).to(dev)
+    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    target = ((((yy - S / 2) / (S * 0.3)) ** 2 + ((xx - S / 2) / (S * 0.2)) ** 2) < 1).long().expand(B, T, S, S).contiguous().to(dev)
+    opt_b = torch.optim.AdamW(bare.parameters(), lr=1.0e-4)
+    opt_w = torch.optim.AdamW(twin.parameters(), lr=1.0e-4)
+    losses_b, losses_w, rel, nograd = [], [], 0.0, []
+    for it in range(3):
+        lb = train_step(bare, opt_b, frames, target, torch.bfloat16)
+        lw = train_step(wrapped, opt_w, frames, target, torch.bfloat16)       # "unused parameter" would raise here on step 2
+        losses_b.append(float(lb)); losses_w.append(float(lw))
+        if it == 0:                                                            # same weights, same batch: same gradients
+            for (n, pb), pw in zip(bare.named_parameters(), twin.parameters()):
+                if pb.grad is None or pw.grad is None:
+                    nograd.append(n)
+                    continue
+                den = pb.grad.float().abs().max().item()
+                rel = max(rel, (pb.grad.float() - pw.grad.float()).abs().max().item() / max(den, 1e-30))
+    torch.cuda.synchronize()
+    wdiff = max((pb.detach().float() - pw.detach().float()).abs().max().item() for pb, pw in zip(bare.parameters(), twin.parameters()))
+    return {"mode": "ddp", "backend": dist.get_backend(), "world": dist.get_world_size(), "shape": [B, T, S, S],
+            "loss_bare": losses_b, "loss_ddp": losses_w, "grad_rel_diff_step1": rel, "params_without_grad": nograd,
+            "weight_abs_diff_after_3_steps": wdiff}
+
+
+def cp(dev):
+    from gdkvm_amd import ops
+    from gdkvm_amd.distributed import context_parallel_scan
+    ops.require_native()
+    out = {"mode": "cp", "backend": dist.get_backend(), "world": dist.get_world_size(), "cases": []}
+    gq = torch.Generator(device=dev).manual_seed(7)
+    for (B, T, N, Dv, dt, with_state) in ((2, 8, 49, 256, torch.bfloat16, False), (2, 8, 49, 256, torch.bfloat16, True),
+                                          (1, 4, 256, 64, torch.bfloat16, False), (2, 6, 49, 64, torch.float32, True)):
+        Hh, Dk = 1, 64
+        q, k = (torch.randn(B, T, N, Hh, Dk, device=dev, generator=gq).to(dt) for _ in range(2))
+        v = torch.randn(B, T, N, Hh, Dv, device=dev, generator=gq).to(dt)
+        al = 2 + torch.randn(B, T, Hh, device=dev, generator=gq)
+        be = torch.randn(B, T, N, Hh, device=dev, generator=gq)
+        st = 0.3 * torch.randn(B, Hh, Dk, Dv, device=dev, generator=gq) if with_state else None
+        r0, s0 = ops.scan_fwd(q, k, v, al, be, st, flags=3)
+        r1, s1 = context_parallel_scan(q, k, v, al, be, st, flags=3, force_exchange=True)
+        out["cases"].append({"shape": [B, T, N, Dv], "dtype": str(dt), "state": with_state,
+                             "readout_bit_equal": bool(torch.equal(r0, r1)),
+                             "state_bit_equal": bool(torch.equal(s0, s1)),
+                             "state_abs_diff": (s0 - s1).abs().max().item()})
+    return out
+
+
+def main():
+    mode = sys.argv[1]
+    dev = init_group()
+    try:
+        if mode == "ddp":
+            B, T, S = (int(x) for x in sys.argv[2:5]) if len(sys.argv) >= 5 else (16, 32, 112)
+            res = ddp(dev, B, T, S)
+        elif mode == "cp":
+            res = cp(dev)
+        else:
+            raise SystemExit(f"unknown mode {mode}")
+        print(json.dumps(res), flush=True)
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

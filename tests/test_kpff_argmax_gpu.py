@@ -187,6 +187,20 @@ def test_upsample_cat(hip, case):
     assert (got[:, :c1].float() - up).abs().max() <= 2.0 ** -7 * up.abs().max()     # one bf16 rounding of an fp32 blend
 
 
+def test_upsample_cat_more_than_2_20_output_rows(hip):
+    """The kernel's float-reciprocal row split is exact below 2^20 rows; a larger batch (16400 frames x 64 rows) goes as several
+    launches over image ranges and must equal the small-batch result frame for frame."""
+    n, c1, hl, wl, c2, H, W = 16400, 8, 32, 2, 8, 64, 4
+    torch.manual_seed(9)
+    lo = torch.randn(n, c1, hl, wl, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    sk = torch.randn(n, c2, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    got = hip.upsample_cat(lo, sk)
+    for sl in (slice(0, 3), slice(16380, 16384), slice(16384, 16400)):            # either side of the launch boundary
+        part = hip.upsample_cat(lo[sl].contiguous(memory_format=torch.channels_last), sk[sl].contiguous(memory_format=torch.channels_last))
+        assert torch.equal(got[sl], part)
+    assert torch.equal(got[:, c1:], sk)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(3, 16, 9, 11), (2, 64, 56, 56), (1, 8, 1, 1), (2, 24, 4, 7)])
 def test_bias_relu_maxpool(hip, dtype, shape):

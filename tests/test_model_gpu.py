@@ -142,6 +142,27 @@ def test_module_bf16_fused_dice_parity(hip):
     assert 0.2 < mr.float().mean() < 0.8
 
 
+def test_invalidate_packed_weights_reaches_the_fused_convolutions(hip):
+    """An in-place write through .data changes neither the version counter nor the address the weight packs are keyed on:
+    invalidate_packed_weights() must drop every FusedConv's fragment-ordered copy too, or the convolution kernels keep reading
+    the old weights."""
+    from gdkvm_amd.model import FusedConv
+    _, model = _pair(seed=5)
+    frames = torch.rand(1, 2, 3, 112, 112).cuda().bfloat16()
+    with torch.no_grad():
+        model = model.fuse_for_inference().to(torch.bfloat16)
+        before = model(frames, _lowres=True).float()
+        conv = model.encoder.layer2[1].conv1                       # a 128 -> 128 layer on the packed-weight kernel
+        assert isinstance(conv, FusedConv) and "_wpack" in conv.__dict__
+        conv.conv.weight.data.mul_(0)
+        stale = model(frames, _lowres=True).float()
+        assert torch.equal(stale, before)                          # (the hazard: the pack is still the old weights)
+        model.invalidate_packed_weights()
+        assert "_wpack" not in conv.__dict__
+        after = model(frames, _lowres=True).float()
+    assert not torch.equal(after, before)
+
+
 def test_module_gradients_match_cpu_reference(hip):
     """One training step's gradients: GDKVM (MIOpen convs + HIP forward/backward kernels) vs GDKVMRef (CPU convs +
     autograd through the fp64 torch restatement), same weights, same batch, train-mode BatchNorm."""

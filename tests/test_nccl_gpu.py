@@ -1,0 +1,59 @@
+"""BASELINE.json configs[3] on the one GPU a test box has: a ONE-rank ``nccl`` (= RCCL) process group.
+
+The children (tests/nccl_one_rank_child.py) initialise the group before any other GPU call, then
+  * wrap the training model in DistributedDataParallel although the world is 1 (wrap_ddp(force=True)) and run three
+    train steps at the full per-GPU shape of configs[3] (16 clips x 32 frames x 112 x 112, bf16 autocast, AdamW): the reducer's
+    hooks sit on the HIP autograd Functions, the gradient buckets go through a real RCCL all-reduce, and a parameter without
+    a gradient would raise on the second step;
+  * force gdkvm_amd.distributed.context_parallel_scan down its exchange branch (transition matrix, all_gather of DEVICE
+    tensors over RCCL, fold, second pass) and compare with gdkvm_scan_fwd.
+What stays unmeasured on hardware is the 8-GPU scaling itself (the driver's job)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = os.path.join(ROOT, "tests", "nccl_one_rank_child.py")
+
+
+def _run(*argv, timeout=600):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run([sys.executable, CHILD, *argv], env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert p.returncode == 0, f"child failed ({p.returncode}):\n{p.stdout[-2000:]}\n{p.stderr[-4000:]}"
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.gpu
+def test_ddp_wrapped_training_steps_on_a_one_rank_rccl_group(hip):
+    res = _run("ddp", "16", "32", "112")
+    print(res)
+    assert res["backend"] == "nccl" and res["world"] == 1 and res["shape"] == [16, 32, 112, 112]
+    assert res["params_without_grad"] == []
+    # same weights, same batch: the wrapped step's gradients are the bare step's (the all-reduce of one rank divides by 1)
+    assert res["grad_rel_diff_step1"] <= 1e-6, res
+    for ls in (res["loss_bare"], res["loss_ddp"]):
+        assert all(l == l and abs(l) < 1e4 for l in ls), ls           # finite
+        assert ls[2] < ls[0], ls                                       # and falling
+    assert res["weight_abs_diff_after_3_steps"] <= 1e-5, res
+
+
+@pytest.mark.gpu
+def test_context_parallel_scan_exchange_branch_on_rccl(hip):
+    res = _run("cp")
+    print(res)
+    assert res["backend"] == "nccl" and res["world"] == 1
+    for c in res["cases"]:
+        assert c["readout_bit_equal"], c                               # every frame is read from the state the serial scan reads
+        if not c["state"]:
+            assert c["state_bit_equal"], c                             # Phi 0 + S_loc = S_loc exactly
+        else:
+            assert c["state_abs_diff"] <= 2e-5, c                      # Phi S_0 + S_loc re-associates the recurrence (fp32)

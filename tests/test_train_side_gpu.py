@@ -306,6 +306,25 @@ def test_fused_objective_ignores_unlabelled_pixels(hip):
         assert abs(host.item() - ref.item()) <= 1e-4
 
 
+def test_fused_objective_with_no_labelled_pixel(hip):
+    """A batch whose every label is 255: the cross-entropy is a mean over no pixel -- 0 in the HIP loss and in the host loss
+    (F.cross_entropy would return NaN and hand it to AdamW); the Dice term sees empty targets.  Finite loss, finite gradient."""
+    from gdkvm_amd.train import segmentation_loss
+    ni, c, h, w, H, W = 2, 3, 16, 16, 64, 64
+    torch.manual_seed(6)
+    z = torch.randn(ni, c, h, w, device="cuda")
+    tgt = torch.full((ni, H, W), 255, dtype=torch.uint8, device="cuda")
+    za = z.clone().requires_grad_(True)
+    loss = hip.seg_loss(za, tgt, 1.0, 1.0)
+    loss.backward()
+    assert torch.isfinite(loss) and torch.isfinite(za.grad).all()
+    up = F.interpolate(z.cpu(), size=(H, W), mode="bilinear", align_corners=False).requires_grad_(True)
+    host = segmentation_loss(up.reshape(1, ni, c, H, W), tgt.cpu().reshape(1, ni, H, W), 1.0, 1.0)
+    host.backward()
+    assert torch.isfinite(host) and torch.isfinite(up.grad).all()
+    assert abs(loss.item() - host.item()) <= 1e-5
+
+
 def test_train_step_uses_the_fused_objective(hip):
     """train_step on the GPU (stride-4 logits + HIP loss) and the plain route (full-resolution logits + torch loss) give the
     same loss and the same parameter gradients (fp32, no autocast)."""
