@@ -78,7 +78,8 @@ static constexpr int SPLIT_IMG = 2 * 64 * 2;                    // uint2 per ter
 // chain after the MFMAs), so it does not go subnormal until |x scale| < 2^-24 / 2^11: full precision over ~13 decades.  A
 // product of two such pairs needs three f16 MFMAs per k step (hh on the main chain; hl, lh on the cross chain; ll = 2^-22 is
 // dropped) against six for two bf16 triples, and two operand images instead of three.  |x scale| saturates at 65504.
-// The state is published with scale = 2^-4 (|S| up to 1e6); P and the composed maps use scale 1.  The backward's reverse
+// The state is published with scale = 2^-e, e = 4 by default (|S| up to 1e6) and larger when the serial kernel's bound on the
+// state asks for it (gdr_scan.hip, "the state's exponent"); P and the composed maps use scale 1.  The backward's reverse
 // recurrence keeps split3: gradients have no natural magnitude.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
@@ -194,6 +195,38 @@ template <int FMT> struct OpFmt {
         }
     }
 };
+
+// ---- wave-wide reductions on DPP row rotations (all 64 lanes active; the result is uniform) -------------------------------
+// row_ror:n (dpp_ctrl 0x120 + n) rotates within each row of 16 lanes: four steps leave every lane with its row's result, the
+// four rows are combined through readlane.  Used once per tile / per launch, never inside the serial chain.
+template <int CTRL> static __device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+static __device__ __forceinline__ float wave_max_nonneg(float x)          // x >= 0 (or NaN / +inf, which win): compares as integers
+{
+    int v = __float_as_int(x);
+    v = max(v, dpp_i32<0x121>(v));
+    v = max(v, dpp_i32<0x122>(v));
+    v = max(v, dpp_i32<0x124>(v));
+    v = max(v, dpp_i32<0x128>(v));
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16), c = __builtin_amdgcn_readlane(v, 32),
+              d = __builtin_amdgcn_readlane(v, 48);
+    return __int_as_float(max(max(a, b), max(c, d)));
+}
+static __device__ __forceinline__ float wave_sum(float x)
+{
+    x += __int_as_float(dpp_i32<0x121>(__float_as_int(x)));
+    x += __int_as_float(dpp_i32<0x122>(__float_as_int(x)));
+    x += __int_as_float(dpp_i32<0x124>(__float_as_int(x)));
+    x += __int_as_float(dpp_i32<0x128>(__float_as_int(x)));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16)),
+                c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 48));
+    return (a + b) + (c + d);
+}
+static __device__ __forceinline__ float absmax4(const f32x4& t)
+{
+    return fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3])));
+}
+// The fp16 pair format saturates at 65504 (after the format's scale): what a producer of pair16 images checks its inputs against
+static constexpr float PAIR_SAT = 65504.0f;
 
 static __device__ __forceinline__ float fast_sigmoid(float x)
 {   // v_exp_f32 + v_rcp_f32 (1 ulp each): relative error < 1e-6 for |x| < 16, far inside the 1e-4 budget

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) void gdr_prep_kernel(PrepAr
 // gdr_fold_kernel: P = I - Kn^T Wt and G = Kn^T Ut for one frame-head; wave w owns row tile w (Dk rows 16w..16w+15), the
 // 4 + Dv/16 column tiles are split over gridDim.y workgroups.  A operands are rows of knT (k = 16I + 4g + r, the
 // permutation under which the Ut images -- prep's accumulator layout -- are B operands as stored).
-struct FoldArgs { const float* wti; const float* knT; const float* ut; float* pp; float* gg; float* ppt; int Dv; };
+struct FoldArgs { const float* wti; const float* knT; const float* ut; float* pp; float* gg; float* ppt; int Dv; float* gmax; };
 
 // grid (FH, 1 + ceil(Dv/64)): block y = 0 folds the four Wt tiles into P, block y > 0 four Ut tiles into G.  Every operand
 // of the block's four tiles is requested up front (20 16-byte loads per lane), then 4 x 4NB MFMA run back to back.
@@ -343,6 +343,8 @@ __global__ __launch_bounds__(256) void gdr_fold_kernel(FoldArgs a)
                     }
                 } else {
                     reinterpret_cast<f32x4*>(a.gg)[((fh * nsl + c) * 4 + w) * 64 + lane] = o * OpFmt<FMT>::STATE;   // the scan carries S * STATE
+                    const float mx = wave_max_nonneg(absmax4(o));      // range bookkeeping of the pair16 recurrence (gdr_ws.hpp: gmax)
+                    if (lane == 0) a.gmax[(fh * nsl + c) * 4 + w] = mx;
                 }
             }
         }
@@ -376,6 +378,7 @@ void launch_fold(const FoldArgs& fa, int FH, bool wide, hipStream_t st)
 struct PrepMArgs {
     const void* q; const void* k; const void* v; const float* beta;
     float* qinv; float* pp; float* gg;
+    float* gmax;                                        // max |G| of the frame's final map per 16-column slice (gdr_ws.hpp)
     float* x0; float* ppc; float* ggc;                  // frames of more than 64 tokens: chunk 0 -> x0, chunk c >= 1 -> ppc/ggc[c-1]
     int T, Hh, N, Dv, rule, flags, np_total;            // N = tokens of the frame, np_total = its padded count (qinv row length)
     int nchunk;                                         // FUSE: 64-token chunks per frame, walked by ONE workgroup (else gridDim.y)
@@ -436,6 +439,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
     // maps P_c, G_c (80 KB per chunk) are never written: gdr_compose_kernel re-read them from HBM (cfg5: 2 x 328 MB).
     constexpr int XJ = FUSE ? 5 : 1;
     f32x4 X[FUSE ? 4 : 1][XJ];
+    float xsplit_max = 0.f;                               // FUSE: largest |running map entry| this wave re-split into fp16 pairs
     const int tid_k = tid;
     for (int chunk = FUSE ? 0 : (int)blockIdx.y, chunk_end = FUSE ? nchunk : chunk + 1; chunk < chunk_end; ++chunk) {
     // FUSE: the lane ids are re-derived per chunk from an opaque copy -- otherwise every lane-dependent address of the body is
@@ -753,6 +757,7 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             uint2 tt[3];
+            if constexpr (FUSE) xsplit_max = fmaxf(xsplit_max, absmax4(X[m][j]));      // (what goes into fp16 pairs here: checked at the end)
             OpFmt<FMT>::split4(X[FUSE ? m : 0][j] * OpFmt<FMT>::STATE, tt);
             const int e = split_slot(m, g, li);
 #pragma unroll
@@ -785,7 +790,10 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
                             : reinterpret_cast<f32x4*>(a.ggc) + ((size_t)fh * (nchunk - 1) + chunk - 1) * nsl * 4 * 64);
     // the frame's final G goes to the scan in the scan's scale (it carries S * STATE); chunk maps headed for the composition stay raw
     const float gscale = nchunk == 1 ? OpFmt<FMT>::STATE : 1.0f;
+    // the frame's FINAL map (one chunk): max |G| per slice goes to the scan, which sizes the state's fp16-pair exponent by it
+    const bool final_g = nchunk == 1;
     auto g_tiles = [&](int cV, const float (&x)[SPLIT ? 1 : NB][4]) __attribute__((always_inline)) {
+        float gm = 0.f;
         if constexpr (!SPLIT)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -802,6 +810,11 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
                     if (nlast > 2) { acc0 = mfma4(mt[m][NB - 1][2], x[NB - 1][2], acc0);
                         if (nlast > 3) acc1 = mfma4(mt[m][NB - 1][3], x[NB - 1][3], acc1); } } }
             if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = (acc0 + acc1) * gscale;
+            gm = fmaxf(gm, absmax4(acc0 + acc1));
+        }
+        if (final_g && cV < nsl) {
+            gm = wave_max_nonneg(gm);
+            if (lane == 0) *reinterpret_cast<f32x4*>(a.gmax + ((size_t)fh * nsl + cV) * 4) = f32x4{gm, 0.f, 0.f, 0.f};
         }
     };
     if constexpr (SPLIT) {
@@ -864,11 +877,19 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
                 load_vraw(cV + 4, vB0, vB1);
                 stage(0, vA0, vA1);
                 read_b(0, xb);
-                g_tiles3(cV, xb, [&](int m, const f32x4& t) { if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = t * gscale; });
+                float gmA = 0.f, gmB = 0.f;
+                g_tiles3(cV, xb, [&](int m, const f32x4& t) { if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = t * gscale; gmA = fmaxf(gmA, absmax4(t)); });
                 load_vraw(cV + 8, vA0, vA1);
                 stage(1, vB0, vB1);
                 read_b(1, xb);
-                g_tiles3(cV + 4, xb, [&](int m, const f32x4& t) { if (cV + 4 < nsl) gg[((size_t)(cV + 4) * 4 + m) * 64 + lane] = t * gscale; });
+                g_tiles3(cV + 4, xb, [&](int m, const f32x4& t) { if (cV + 4 < nsl) gg[((size_t)(cV + 4) * 4 + m) * 64 + lane] = t * gscale; gmB = fmaxf(gmB, absmax4(t)); });
+                if (final_g) {
+                    gmA = wave_max_nonneg(gmA); gmB = wave_max_nonneg(gmB);
+                    if (lane == 0) {
+                        if (cV < nsl) *reinterpret_cast<f32x4*>(a.gmax + ((size_t)fh * nsl + cV) * 4) = f32x4{gmA, 0.f, 0.f, 0.f};
+                        if (cV + 4 < nsl) *reinterpret_cast<f32x4*>(a.gmax + ((size_t)fh * nsl + cV + 4) * 4) = f32x4{gmB, 0.f, 0.f, 0.f};
+                    }
+                }
             }
         } else {
             // column tile cV = w + 4 (j - 1) of G is X[.][j], j = 1 .. 4 (Dv <= 256): compile-time indices, run-time bounds.
@@ -959,12 +980,21 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
             }
         }
         f32x4* gout = reinterpret_cast<f32x4*>(a.gg) + (size_t)fh * nsl * 4 * 64;
+        // an intermediate of the composition beyond the fp16 pair's range (|x| 2^-4 >= 65504: values ~1e6 times the usual) is
+        // reported as +inf and the scan answers with NaNs -- never a silently saturated map
+        const bool sat = wave_max_nonneg(xsplit_max) * OpFmt<FMT>::STATE >= PAIR_SAT;
         static_for<1, 5>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             const int cV = w + 4 * (j - 1);
             if (cV < nsl) {
+                float gm = 0.f;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) gout[((size_t)cV * 4 + m) * 64 + lane] = X[m][j] * OpFmt<FMT>::STATE;
+                for (int m = 0; m < 4; ++m) {
+                    gout[((size_t)cV * 4 + m) * 64 + lane] = X[m][j] * OpFmt<FMT>::STATE;
+                    gm = fmaxf(gm, absmax4(X[m][j]));
+                }
+                gm = sat ? __builtin_inff() : wave_max_nonneg(gm);
+                if (lane == 0) *reinterpret_cast<f32x4*>(a.gmax + ((size_t)fh * nsl + cV) * 4) = f32x4{gm, 0.f, 0.f, 0.f};
             }
         });
     }
@@ -1007,7 +1037,7 @@ int launch_prepm(const PrepMArgs& pa, int FH, int nchunk, bool wide, bool fuse, 
 // accumulators, wave w = row tile w) through all steps, exactly like the serial scan carries S -- P_c as three-term A
 // images (as prepm wrote them), the running columns re-split into three-term B images through LDS each step.
 // Output: the final P as term images (pp) and G as accumulator images (gg), the formats the scan consumes.
-struct ComposeArgs { const float* x0; const float* ppc; const float* ggc; float* pp; float* gg; int Dv, nchunk, additive; };
+struct ComposeArgs { const float* x0; const float* ppc; const float* ggc; float* pp; float* gg; int Dv, nchunk, additive; float* gmax; };
 
 template <int FMT>
 __global__ __launch_bounds__(256) void gdr_compose_kernel(ComposeArgs a)
@@ -1019,6 +1049,7 @@ __global__ __launch_bounds__(256) void gdr_compose_kernel(ComposeArgs a)
     const size_t fh = blockIdx.x;
     const int nsl = a.Dv / 16, ncol = 4 + nsl, c0 = 4 * blockIdx.y;               // this block's column tiles c0 .. c0+3 of [P | G]
     f32x4 X[4];
+    float xsplit_max = 0.f;                                // pair16: largest |entry| this wave re-split into fp16 pairs (checked at the end)
     const f32x4* x0 = reinterpret_cast<const f32x4*>(a.x0) + fh * ncol * 4 * 64;
 #pragma unroll
     for (int j = 0; j < 4; ++j) X[j] = x0[((size_t)min(c0 + j, ncol - 1) * 4 + w) * 64 + lane];
@@ -1056,6 +1087,7 @@ __global__ __launch_bounds__(256) void gdr_compose_kernel(ComposeArgs a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                      // rows 16w + 4g + r of column tile j -> its term images
             uint2 tt[3];
+            if constexpr (FMT == FMT_PAIR16) xsplit_max = fmaxf(xsplit_max, absmax4(X[j]));
             OpFmt<FMT>::split4(X[j] * OpFmt<FMT>::STATE, tt);
             const int e = split_slot(w, g, li);
 #pragma unroll
@@ -1073,6 +1105,7 @@ __global__ __launch_bounds__(256) void gdr_compose_kernel(ComposeArgs a)
         }
         __syncthreads();                                   // the images are rewritten in the next step
     }
+    const bool sat = wave_max_nonneg(xsplit_max) * OpFmt<FMT>::STATE >= PAIR_SAT;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = c0 + j;
@@ -1089,6 +1122,9 @@ __global__ __launch_bounds__(256) void gdr_compose_kernel(ComposeArgs a)
             }
         } else {
             reinterpret_cast<f32x4*>(a.gg)[((fh * nsl + (col - 4)) * 4 + w) * 64 + lane] = X[j] * OpFmt<FMT>::STATE;   // the scan carries S * STATE
+            // range bookkeeping (gdr_ws.hpp: gmax): this wave's row tile; +inf when a composition step left the fp16 pair's range
+            const float mx = sat ? __builtin_inff() : wave_max_nonneg(absmax4(X[j]));
+            if (lane == 0) a.gmax[(fh * nsl + (col - 4)) * 4 + w] = mx;
         }
     }
 }
@@ -1127,7 +1163,7 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
     if (int rc = gdkvm_check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!(flags & GDKVM_FLAG_TRAIN) || ws.nchunk > 1) {  // P and G directly (frames of > 64 tokens: per 64-token chunk, then composed)
-        PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, ws.x0, ws.ppc, ws.ggc, T, Hh, N, Dv, rule, flags, 16 * ws.nb, ws.nchunk};
+        PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, ws.gmax, ws.x0, ws.ppc, ws.ggc, T, Hh, N, Dv, rule, flags, 16 * ws.nb, ws.nchunk};
 #ifdef GDKVM_DIAG
         pm.diag = g_gdkvm_diag_buf;
 #endif
@@ -1149,7 +1185,7 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
         if (int rc = io_dtype == GDKVM_F32 ? launch_prepm<4, GDKVM_F32>(pm, B * T * Hh, ws.nchunk, wide, false, st)
                                            : launch_prepm<4, GDKVM_BF16>(pm, B * T * Hh, ws.nchunk, wide, fuse, st)) return rc;
         if (ws.nchunk > 1 && !fuse) {
-            ComposeArgs ca{ws.x0, ws.ppc, ws.ggc, ws.pp, ws.gg, Dv, ws.nchunk, rule == GDKVM_RULE_DELTA_PARALLEL};
+            ComposeArgs ca{ws.x0, ws.ppc, ws.ggc, ws.pp, ws.gg, Dv, ws.nchunk, rule == GDKVM_RULE_DELTA_PARALLEL, ws.gmax};
             const dim3 cgrid((unsigned)(B * T * Hh), (unsigned)((4 + Dv / 16 + 3) / 4));
             if (wide) hipLaunchKernelGGL(gdr_compose_kernel<FMT_SPLIT3>, cgrid, dim3(256), 0, st, ca);
             else hipLaunchKernelGGL(gdr_compose_kernel<FMT_PAIR16>, cgrid, dim3(256), 0, st, ca);
@@ -1160,7 +1196,7 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
     // training, <= 64 tokens: the WY factors the backward consumes, then folded
     PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, ws.kn, ws.wtT, ws.qnT, ws.tii, ws.wti, T, Hh, N, Dv, rule, flags};
     if (int rc = io_dtype == GDKVM_F32 ? launch_prep<4, GDKVM_F32, 5>(pa, B * T * Hh, st) : launch_prep<4, GDKVM_BF16, 5>(pa, B * T * Hh, st)) return rc;
-    FoldArgs fa{ws.wti, ws.knT, ws.ut, ws.pp, ws.gg, ws.ppt, Dv};
+    FoldArgs fa{ws.wti, ws.knT, ws.ut, ws.pp, ws.gg, ws.ppt, Dv, ws.gmax};
     launch_fold<4>(fa, B * T * Hh, flags & GDKVM_FLAG_WIDE_RANGE, st);
     GDKVM_LAUNCH_CHECK("gdr_fold_kernel");
     return GDKVM_OK;

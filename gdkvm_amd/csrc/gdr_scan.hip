@@ -47,6 +47,8 @@ struct AffArgs {
     int T, Hh, N, Dv, flags, BH;
     int reverse;                                     // visit the frames last to first (the backward's reverse recurrence)
     float* simg;                                     // DEFER: per-frame operand images of the state for gdr_readout_kernel
+    const float* gmax;                               // pair16: max |G| per frame and slice from the frame-parallel side (NULL: default exponent)
+    float* esc;                                      // DEFER, pair16: 2^e of this (clip-head, slice) for gdr_readout_kernel
 };
 // LDS (16-byte units): S term images [2 parities][NT terms][2 ksteps][64] | (fp32 I/O on split3) S fp32 images [2][4][64]
 template <int IO> struct RItem;                                        // read-out operands of one 16-token tile
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
     constexpr int NB = 4, NP = 16 * NB, JT = 1, NBUF = 4, DEPTH = NBUF - 1, UFR = NBUF / JT;
     constexpr int NT = fmt_terms(FMT);
     constexpr bool PAIR = FMT == FMT_PAIR16;
-    constexpr float STATE = OpFmt<FMT>::STATE, STATE_INV = OpFmt<FMT>::STATE_INV;      // the kernel carries S' = S * STATE (G arrives scaled alike)
+    // the kernel carries S' = S * st_scale; G arrives scaled by OpFmt<FMT>::STATE (2^-4 under pair16, the default exponent)
     extern __shared__ __attribute__((aligned(16))) f32x4 aff_smem[];
     uint2* s_S3 = reinterpret_cast<uint2*>(aff_smem);      // [parity][term] images of SPLIT_IMG uint2: B operand of the 16x16x32 MFMA
     constexpr bool EXACT = IO == GDKVM_F32 && !PAIR;       // fp32 I/O on full-range operands: exact fp32 read-out from fp32 images of S
@@ -91,6 +93,41 @@ __global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
     const int b = bh / Hh, h = bh % Hh;
     const size_t fh0 = (size_t)b * T * Hh + h;
     constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
+
+    // ---- the state's exponent (pair16).  fp16 pairs hold |S * 2^-e| < 65504, so e must fit this call's state: columns of S never
+    // mix and every frame's map is a contraction in the 2-norm (delta_sequential: products of I - b k k^T with |k| = 1, b in [0,1];
+    // gated_linear: P = I), hence for this 16-column slice  |S_t| <= 8 (max|S_0| + sum_t max|G_t|)  elementwise for every t (8 =
+    // sqrt(Dk)).  The frame-parallel side left max|G_t| per slice in the workspace; every wave forms the same bound from the same
+    // numbers (no exchange) and takes e = max(4, ceil(log2 bound) - 15): 4, the format's default, for anything up to ~5e5 -- every
+    // ordinary input, so chunked calls of a clip stay bit-identical to one call -- and beyond that whatever the state needs (exact:
+    // powers of two).  A bound that is not finite (a composition step of a > 64-token frame overflowed) poisons the call with NaNs.
+    float st_scale = OpFmt<FMT>::STATE, st_inv = OpFmt<FMT>::STATE_INV;
+    bool rescaled = false;
+    if constexpr (PAIR) {
+        if (a.gmax) {
+            float gs = 0.f, sm = 0.f;
+            const f32x4* gm = reinterpret_cast<const f32x4*>(a.gmax) + fh0 * nsl + sl;
+            for (int t = lane; t < T; t += 64) {
+                const f32x4 x = gm[(size_t)t * Hh * nsl];
+                gs += fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+            }
+            if (a.s_in) {
+                const f32x4* sp = reinterpret_cast<const f32x4*>(a.s_in + ((size_t)bh * GDKVM_DK + lane) * Dv + 16 * sl);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sm = fmaxf(sm, absmax4(sp[c]));
+            }
+            const float bound = 8.0f * (wave_max_nonneg(sm) + wave_sum(gs));
+            const int eb = (int)((__float_as_uint(bound) >> 23) & 0xffu) - 126;       // bound < 2^eb
+            const int e = __builtin_amdgcn_readfirstlane(bound <= 3.0e38f ? max(4, eb - 15) : -1);
+            if (e != 4) {
+                rescaled = true;
+                st_scale = e < 0 ? __builtin_nanf("") : __uint_as_float((unsigned)(127 - e) << 23);
+                st_inv = e < 0 ? __builtin_nanf("") : __uint_as_float((unsigned)(127 + e) << 23);
+            }
+        }
+    }
+    const float STATE = st_scale, STATE_INV = st_inv;
+    const float gfix = st_scale * OpFmt<FMT>::STATE_INV;   // what G (prepared at the default exponent) is multiplied by: 1 unless rescaled
 
     // Publishing S: the three bf16 terms of this wave's rows 16w + 4g + r (k of the next product) as B images; the fp32
     // arm also keeps the accumulator image for its exact fp32 read-out.
@@ -117,6 +154,9 @@ __global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
     if (role == 1) {
         // ------------------------------------------------------------------------------ read-out waves
         if constexpr (DEFER) {                             // dump the images of S_{t-1}: 1 KiB per read wave and frame
+            if constexpr (PAIR) {
+                if (a.esc && w == 0 && lane == 0) a.esc[(size_t)bh * ((nsl + 3) & ~3) + sl] = STATE_INV;
+            }
             uint4* dst = reinterpret_cast<uint4*>(a.simg) + ((fh0 * nsl + sl) * 4 + w) * 64 + lane;
             const size_t d_fstride = (size_t)Hh * nsl * 4 * 64;
             aff_barrier();
@@ -288,7 +328,7 @@ __global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
         POp od[AFF_PD + 1];
 #pragma unroll
         for (int i = 0; i < AFF_PD; ++i) fetch_op(i, od[i]);
-        auto frame = [&](int t, const POp& op, POp& far) __attribute__((always_inline)) {
+        auto frame = [&](int t, const POp& op, POp& far, auto scaled_c) __attribute__((always_inline)) {
             const int par = t & 1;
             if constexpr (SAVE) {
                 float* hp = a.s_hist + ((fh0 + (size_t)(a.reverse ? T - 1 - t : t) * Hh) * GDKVM_DK + 16 * w + 4 * g) * Dv + 16 * sl + li;
@@ -307,21 +347,34 @@ __global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
             const float alpha = gate_logits ? fast_sigmoid(op.al) : op.al;
             const f32x4 ps = OpFmt<FMT>::product(op.pa, sb);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sacc[r] = alpha * ps[r] + op.gt[r];
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (decltype(scaled_c)::value) sacc[r] = alpha * ps[r] + op.gt[r] * gfix;   // (exact: a power of two)
+                else sacc[r] = alpha * ps[r] + op.gt[r];
+            }
             publish_state(par ^ 1, sacc);
             aff_barrier();
         };
         constexpr int NR = AFF_PD + 1, UFD = NR % 2 == 0 ? NR : 2 * NR;
-        int t0 = 0;
-        for (; t0 + UFD <= T; t0 += UFD)
-            static_for<0, UFD>([&](auto fc) {
+        // two copies of the frame loop: the ordinary one (default exponent: G as prepared, the chain as it always was) and the one
+        // that rescales G for a state beyond the default range
+        auto run = [&](auto scaled_c) __attribute__((always_inline)) {
+            int t0 = 0;
+            for (; t0 + UFD <= T; t0 += UFD)
+                static_for<0, UFD>([&](auto fc) {
+                    constexpr int F = decltype(fc)::value;
+                    frame(t0 + F, od[F % NR], od[(F + AFF_PD) % NR], scaled_c);
+                });
+            static_for<0, UFD - 1>([&](auto fc) {
                 constexpr int F = decltype(fc)::value;
-                frame(t0 + F, od[F % NR], od[(F + AFF_PD) % NR]);
+                if (t0 + F < T) frame(t0 + F, od[F % NR], od[(F + AFF_PD) % NR], scaled_c);
             });
-        static_for<0, UFD - 1>([&](auto fc) {
-            constexpr int F = decltype(fc)::value;
-            if (t0 + F < T) frame(t0 + F, od[F % NR], od[(F + AFF_PD) % NR]);
-        });
+        };
+        if constexpr (PAIR) {
+            if (rescaled) run(std::true_type{});
+            else run(std::false_type{});
+        } else {
+            run(std::false_type{});
+        }
         if (a.s_out) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) a.s_out[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li] = STATE_INV * sacc[r];
@@ -354,7 +407,7 @@ int launch_affine_any(bool wide, bool defer, bool save, const AffArgs& sa, dim3 
 // images the serial kernel dumped.  One workgroup per (frame-head, 8 column tiles); a wave keeps the images of its two column
 // tiles in registers and walks the frame's token tiles, so q is read once per workgroup and nothing goes through LDS.  Same
 // arithmetic and operation order as the in-scan read-out (R^T = S^T Qn^T: pair16 terms on the f16 MFMA, or exact fp32).
-struct ReadoutArgs { const void* q; const float* qinv; const float* simg; void* r_out; int Hh, N, Dv, NP; };
+struct ReadoutArgs { const void* q; const float* qinv; const float* simg; void* r_out; int Hh, N, Dv, NP; const float* esc; int T; };
 
 template <int IO, int FMT>
 __global__ __launch_bounds__(256) void gdr_readout_kernel(ReadoutArgs a)
@@ -398,12 +451,20 @@ __global__ __launch_bounds__(256) void gdr_readout_kernel(ReadoutArgs a)
         }
         d.qi = qinv[min(16 * min(tt, ntt_all - 1) + li, a.NP - 1)];
     };
+    // (the dumped images are those of S * 2^-e: pair16 -- the exponent the serial kernel chose for this clip-head and column tile)
+    float sinv[2] = {OpFmt<FMT>::STATE_INV, OpFmt<FMT>::STATE_INV};
+    if constexpr (PAIR) {
+        const size_t bh = (fh / ((size_t)a.T * a.Hh)) * a.Hh + h;
+        const float* ep = a.esc + bh * ((nsl + 3) & ~3);
+        sinv[0] = ep[c0];
+        sinv[1] = ep[two ? c0 + 1 : c0];
+    }
     auto tile = [&](int tt, const QT& d) __attribute__((always_inline)) {
-        float rscale = d.qi * OpFmt<FMT>::STATE_INV;         // (the dumped images are those of S * STATE)
+        float rscale = d.qi;
         f16x8 qh[2], ql[2];
         if constexpr (PAIR) {
             const float sc = pow2_floor(d.qi);
-            rscale = d.qi * pow2_inv(sc) * OpFmt<FMT>::STATE_INV;
+            rscale = d.qi * pow2_inv(sc);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if constexpr (IO == GDKVM_BF16) qh[ks] = bf16x8_to_f16(__builtin_bit_cast(bf16x8, d.q[ks]), sc);
@@ -445,7 +506,7 @@ __global__ __launch_bounds__(256) void gdr_readout_kernel(ReadoutArgs a)
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, sb[c][ks]), __builtin_bit_cast(bf16x8, d.q[ks]), acc1, 0, 0, 0);
                 }
             }
-            const f32x4 accR = (acc0 + acc1) * rscale;
+            const f32x4 accR = (acc0 + acc1) * (rscale * sinv[c]);
             const int nr = 16 * tt + li;
             if (nr < N && (c == 0 || two)) {
                 char* p = rbase + (size_t)nr * rowr + c * 16 * ESZ;
@@ -507,13 +568,14 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
         return GDKVM_OK;
     }
     const bool defer = ws.nb > 4 && r_out != nullptr;     // > 64 tokens per frame: read-out by its own frame-parallel kernel
-    AffArgs sa{q, alpha, s_in, ws.pp, ws.gg, ws.qinv, defer ? nullptr : r_out, s_out, s_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 0, ws.simg};
+    AffArgs sa{q, alpha, s_in, ws.pp, ws.gg, ws.qinv, defer ? nullptr : r_out, s_out, s_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 0, ws.simg,
+               ws.gmax, ws.esc};
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
     const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
     if (int rc = io_dtype == GDKVM_F32 ? launch_affine_any<GDKVM_F32>(wide, defer, s_hist != nullptr, sa, grid, st)
                                        : launch_affine_any<GDKVM_BF16>(wide, defer, s_hist != nullptr, sa, grid, st)) return rc;
     if (defer) {
-        ReadoutArgs ra{q, ws.qinv, ws.simg, r_out, Hh, N, Dv, 16 * ws.nb};
+        ReadoutArgs ra{q, ws.qinv, ws.simg, r_out, Hh, N, Dv, 16 * ws.nb, ws.esc, T};
         // enough workgroups for two per CU: split the frame's token tiles when frames x column groups alone do not give them
         unsigned ny = (unsigned)((Dv / 16 + 7) / 8), nz = 1;
         {

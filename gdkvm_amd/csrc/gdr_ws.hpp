@@ -24,22 +24,29 @@ static inline int tiles_for(int N) { return N <= 64 ? 4 : 4 * ((N + 63) / 64); }
 //     ppc [nchunk-1] x pp, ggc [nchunk-1] x gg  for chunks 1..
 //     simg [Dv/16][4][64][4]  the state before the frame as MFMA operand images (per slice: the h and m bf16 term images, or the
 //          fp32 accumulator images), dumped by the serial kernel for the frame-parallel read-out kernel
+//   range bookkeeping of the pair16 recurrence (gdr_scan.hip, "state exponent"):
+//     gmax [Dv/16][4]  per frame-head and 16-column slice: max |G| of the frame's final map, one entry per row tile (a producer
+//          that holds all four row tiles of a slice writes the maximum into entry 0 and zeros behind it; +inf = an intermediate of
+//          the chunk composition left the fp16 pair's range)
+//   and, per clip-head (behind everything per-frame): esc [Dv/16] = 2^e, the inverse of the scale the serial kernel carried that
+//          slice's state at, for the frame-parallel read-out kernel
 struct WsView {
     float* wt; float* knT; float* ut; float* qinv; float* kn; float* wtT; float* qnT; float* tii; float* wti; float* ppt;
-    float* pp; float* gg; float* x0; float* ppc; float* ggc; float* simg; float* zero; char* trash; int nb; int nchunk;
+    float* pp; float* gg; float* x0; float* ppc; float* ggc; float* simg; float* gmax; float* esc; float* zero; char* trash; int nb; int nchunk;
 };
 
 static inline size_t gdr_ws_floats_per_fh(int N, int Dk, int Dv)
 {
     const size_t NP = 16 * (size_t)tiles_for(N), NL = NP < 64 ? NP : 64, C = (NP + 63) / 64;
     const size_t pg = (size_t)Dk * Dk * 3 / 2 + (size_t)Dk * Dv;
-    return NL * (6 * (size_t)Dk + Dv + 16) + (size_t)Dk * Dk * 3 / 2 + NP + pg + (C > 1 ? (size_t)Dk * (Dk + Dv) + (C - 1) * pg + (size_t)Dk * Dv : 0);
+    return NL * (6 * (size_t)Dk + Dv + 16) + (size_t)Dk * Dk * 3 / 2 + NP + pg + (C > 1 ? (size_t)Dk * (Dk + Dv) + (C - 1) * pg + (size_t)Dk * Dv : 0)
+           + (size_t)Dv / 4;                                                       // gmax: 4 floats per 16-column slice
 }
 
 static inline size_t gdr_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
 {
     if (B <= 0 || T <= 0 || Hh <= 0 || N <= 0 || Dk <= 0 || Dv <= 0 || N > GDKVM_MAX_N) return GDKVM_WS_TAIL;
-    return (size_t)B * T * Hh * gdr_ws_floats_per_fh(N, Dk, Dv) * sizeof(float) + GDKVM_WS_TAIL;
+    return ((size_t)B * T * Hh * gdr_ws_floats_per_fh(N, Dk, Dv) + (size_t)B * Hh * (((size_t)Dv / 16 + 3) & ~(size_t)3)) * sizeof(float) + GDKVM_WS_TAIL;
 }
 
 // Key widths below the kernels' 64 (multiples of 8): gdkvm_scan_fwd runs the Dk = 64 kernels on zero-extended copies of q, k and the
@@ -81,6 +88,8 @@ static inline int carve(const char* fn, void* workspace, size_t workspace_bytes,
     v->ppc = p;   p += NP > 64 ? FH * (NP / 64 - 1) * ppf : 0;
     v->ggc = p;   p += NP > 64 ? FH * (NP / 64 - 1) * ggf : 0;
     v->simg = p;  p += NP > 64 ? FH * ggf : 0;
+    v->gmax = p;  p += FH * ((size_t)Dv / 4);
+    v->esc = p;   p += (size_t)B * Hh * (((size_t)Dv / 16 + 3) & ~(size_t)3);
     v->zero = p;                                         // 256 floats, zeroed by gdkvm_scan_transition
     v->trash = reinterpret_cast<char*>(v->zero + 256);   // write-only slot for read-out rows of padding tokens
     return GDKVM_OK;

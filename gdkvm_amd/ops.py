@@ -181,7 +181,10 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
     """Fused LKVA read + GDR write over T frames (gdkvm_scan_fwd).
 
     q,k [B,T,N,Hh,Dk]  v [B,T,N,Hh,Dv]  (f32|bf16)   alpha [B,T,Hh]  beta [B,T,N,Hh]  state [B,Hh,Dk,Dv] (f32)
-    returns (R [B,T,N,Hh,Dv] in the io dtype, S_T [B,Hh,Dk,Dv] f32)."""
+    returns (R [B,T,N,Hh,Dv] in the io dtype, S_T [B,Hh,Dk,Dv] f32).
+    Range: the default recurrence carries the state as fp16 pairs at 2^-e with e sized from the call's own bound on the state
+    (include/gdkvm.h, GDKVM_FLAG_WIDE_RANGE), so values and carried states of any magnitude are served for rules 0 and 2; the
+    one refusal -- frames of more than 64 tokens with values ~1e5x the usual -- returns NaNs, and FLAG_WIDE_RANGE serves it."""
     lib = load()
     if q.dim() != 5 or k.shape != q.shape or v.dim() != 5 or v.shape[:4] != q.shape[:4]:
         raise GdkvmError(f"bad shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")

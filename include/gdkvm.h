@@ -53,10 +53,17 @@ enum { GDKVM_FLAG_NORMALIZE_QK = 1,      /* q,k <- x * rsqrt(sum x^2 + 1e-12)   
        GDKVM_FLAG_TRAIN = 4,             /* prep also emits the operand layouts gdkvm_scan_bwd reads (set by
                                             gdkvm_scan_fwd itself whenever s_hist != NULL) */
        GDKVM_FLAG_WIDE_RANGE = 8         /* operands of the state recurrence as three bf16 terms (the whole fp32 range, twice
-                                            the MFMAs) instead of the default fp16 pairs, which hold |state| < 1e6 (beyond it
-                                            values saturate) at 22 bits.  gdkvm_scan_fwd sets it itself for rule
-                                            DELTA_PARALLEL, the one rule that is not contractive; a caller of the split
-                                            prep / apply / transition entry points passes the same flags to each. */ };
+                                            the MFMAs) instead of the default fp16 pairs (22 bits).  The default is safe at
+                                            any magnitude for rules GATED_LINEAR and DELTA_SEQUENTIAL with L2-normalised keys:
+                                            the serial kernel carries the state at 2^-e and sizes e per call and 16-column
+                                            slice from a bound on the state, 8 (max|s_in| + sum_t max|G_t|) -- e = 4 (the
+                                            format's default, hence bit-identical chunked calls) for every ordinary input,
+                                            larger exactly when the state needs it.  One corner is refused loudly rather
+                                            than served: frames of more than 64 tokens whose chunk composition leaves the
+                                            pair's range (|values| around 1e5 times the usual) come back as NaNs -- pass
+                                            this flag for such inputs.  gdkvm_scan_fwd sets it itself for rule
+                                            DELTA_PARALLEL, the one rule without a bound (not contractive); a caller of the
+                                            split prep / apply / transition entry points passes the same flags to each. */ };
 
 int gdkvm_abi_version(void);
 const char* gdkvm_last_error(void);

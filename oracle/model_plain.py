@@ -53,9 +53,17 @@ def _tokens(x):
 
 
 @torch.no_grad()
-def plain_forward(sd, frames, heads=1, key_dim=64, value_dim=256, rule="delta_sequential", mask0=None, state=None, lowres=False):
+def plain_forward(sd, frames, heads=1, key_dim=64, value_dim=256, rule="delta_sequential", mask0=None, state=None, lowres=False,
+                  taps=None, override=None):
     """sd: state_dict of the un-fused module (gdkvm_amd.model.GDKVM(...).state_dict()); frames [B,T,C,H,W].
-    Returns (logits [B,T,ncls,H,W] float64 -- stride-4 logits if lowres --, final state [B,Hh,Dk,Dv] float64)."""
+    Returns (logits [B,T,ncls,H,W] float64 -- stride-4 logits if lowres --, final state [B,Hh,Dk,Dv] float64).
+    taps (a dict): receives the intermediate stages -- f4, f8, f16 [BT,C,h,w], k, q, v, beta, alpha (token-major), r (read-out
+    [BT,N,Hh*Dv]), fused (KPFF output [BT,N,Cp]), dec (stride-4 decoder feature) -- as float64 tensors.  override (a dict with any
+    of f4 / f8 / f16 / r / fused): that stage is taken from the caller (e.g. from the product's bf16 build) instead of being
+    computed, everything after it runs here in float64: tools/stage_error.py attributes the build's mask flips this way."""
+    taps = {} if taps is None else taps
+    override = override or {}
+    ov = lambda name, val: override[name].detach().to("cpu", torch.float64) if name in override else val
     B, T, C, H, W = frames.shape
     Hh, Dk, Dv = heads, key_dim, value_dim
     x = frames.detach().to("cpu", torch.float64).reshape(B * T, C, H, W)
@@ -65,6 +73,8 @@ def plain_forward(sd, frames, heads=1, key_dim=64, value_dim=256, rule="delta_se
     f4 = _block(sd, "encoder.layer1.1", _block(sd, "encoder.layer1.0", x, 1), 1)
     f8 = _block(sd, "encoder.layer2.1", _block(sd, "encoder.layer2.0", f4, 2), 1)
     f16 = _block(sd, "encoder.layer3.1", _block(sd, "encoder.layer3.0", f8, 2), 1)
+    f4, f8, f16 = ov("f4", f4), ov("f8", f8), ov("f16", f16)
+    taps.update(f4=f4, f8=f8, f16=f16)
     h, w = f16.shape[-2:]
     N = h * w
     # per-token projections of the stride-16 feature
@@ -83,11 +93,14 @@ def plain_forward(sd, frames, heads=1, key_dim=64, value_dim=256, rule="delta_se
     s0 = None if state is None else state.detach().cpu().double().numpy()
     r, s = O.scan(q.reshape(B, T, N, Hh, Dk).numpy(), k_tok.reshape(B, T, N, Hh, Dk).numpy(), v.reshape(B, T, N, Hh, Dv).numpy(),
                   alpha.numpy(), beta.numpy(), s0, _RULE_IDS[rule], 3)
-    fused = O.kpff(k_tok.numpy(), np.asarray(r, np.float64).reshape(B * T, N, Hh * Dv), p_tok.numpy(),
-                   *(_t(sd, "kpff." + n).numpy() for n in ("wa", "ba", "wl", "wg")), h, w)
-    fmap = torch.from_numpy(np.asarray(fused, np.float64)).reshape(B * T, h, w, -1).permute(0, 3, 1, 2)
+    r = ov("r", torch.from_numpy(np.asarray(r, np.float64)).reshape(B * T, N, Hh * Dv)).reshape(B * T, N, Hh * Dv)
+    fused = O.kpff(k_tok.numpy(), r.numpy(), p_tok.numpy(), *(_t(sd, "kpff." + n).numpy() for n in ("wa", "ba", "wl", "wg")), h, w)
+    fused = ov("fused", torch.from_numpy(np.asarray(fused, np.float64)).reshape(B * T, N, -1)).reshape(B * T, N, -1)
+    taps.update(k=k_tok, q=q, v=v.reshape(B * T, N, Hh * Dv), beta=beta, alpha=alpha, r=r, fused=fused)
+    fmap = fused.reshape(B * T, h, w, -1).permute(0, 3, 1, 2)
     # decoder
     y = _up(sd, "decoder.up4", _up(sd, "decoder.up8", fmap, f8), f4)
+    taps["dec"] = y
     logits = F.conv2d(y, _t(sd, "decoder.head.weight"), _t(sd, "decoder.head.bias"))
     if not lowres:
         logits = F.interpolate(logits, size=(H, W), mode="bilinear", align_corners=False)

@@ -39,6 +39,7 @@ def ddp(dev, B, T, S):
     torch.manual_seed(3)
     bare = GDKVM(GDKVMConfig()).train().to(dev).to(memory_format=torch.channels_last)
     twin = copy.deepcopy(bare)
+    again = copy.deepcopy(bare)                               # a second BARE copy: the run-to-run spread of the backward itself
     wrapped = wrap_ddp(twin, dev, force=True)
     assert isinstance(wrapped, torch.nn.parallel.DistributedDataParallel), type(wrapped)
     g = torch.Generator(device="cpu").manual_seed(3000)
@@ -47,22 +48,30 @@ def ddp(dev, B, T, S):
     target = ((((yy - S / 2) / (S * 0.3)) ** 2 + ((xx - S / 2) / (S * 0.2)) ** 2) < 1).long().expand(B, T, S, S).contiguous().to(dev)
     opt_b = torch.optim.AdamW(bare.parameters(), lr=1.0e-4)
     opt_w = torch.optim.AdamW(twin.parameters(), lr=1.0e-4)
-    losses_b, losses_w, rel, nograd = [], [], 0.0, []
+    opt_a = torch.optim.AdamW(again.parameters(), lr=1.0e-4)
+    losses_b, losses_w, rel, nograd, rel_name, spread, spread_name = [], [], 0.0, [], "", 0.0, ""
     for it in range(3):
         lb = train_step(bare, opt_b, frames, target, torch.bfloat16)
         lw = train_step(wrapped, opt_w, frames, target, torch.bfloat16)       # "unused parameter" would raise here on step 2
         losses_b.append(float(lb)); losses_w.append(float(lw))
         if it == 0:                                                            # same weights, same batch: same gradients
-            for (n, pb), pw in zip(bare.named_parameters(), twin.parameters()):
+            train_step(again, opt_a, frames, target, torch.bfloat16)
+            for (n, pb), pw, pa in zip(bare.named_parameters(), twin.parameters(), again.parameters()):
                 if pb.grad is None or pw.grad is None:
                     nograd.append(n)
                     continue
-                den = pb.grad.float().abs().max().item()
-                rel = max(rel, (pb.grad.float() - pw.grad.float()).abs().max().item() / max(den, 1e-30))
+                den = max(pb.grad.float().abs().max().item(), 1e-30)
+                d = (pb.grad.float() - pw.grad.float()).abs().max().item() / den
+                if d > rel:
+                    rel, rel_name = d, n
+                d = (pb.grad.float() - pa.grad.float()).abs().max().item() / den
+                if d > spread:
+                    spread, spread_name = d, n
     torch.cuda.synchronize()
     wdiff = max((pb.detach().float() - pw.detach().float()).abs().max().item() for pb, pw in zip(bare.parameters(), twin.parameters()))
     return {"mode": "ddp", "backend": dist.get_backend(), "world": dist.get_world_size(), "shape": [B, T, S, S],
-            "loss_bare": losses_b, "loss_ddp": losses_w, "grad_rel_diff_step1": rel, "params_without_grad": nograd,
+            "loss_bare": losses_b, "loss_ddp": losses_w, "grad_rel_diff_step1": rel, "grad_rel_diff_param": rel_name,
+            "bare_vs_bare_rel_diff_step1": spread, "bare_vs_bare_param": spread_name, "params_without_grad": nograd,
             "weight_abs_diff_after_3_steps": wdiff}
 
 

@@ -70,6 +70,9 @@ def test_cfg5_full_size_long_clip_state_carry(hip):
     assert np.abs(S32.cpu().numpy() - So).max() <= 1e-4 and np.abs(R32.cpu().numpy() - Ro).max() <= 1e-4
 
 
+CFG3_DICE_BAR = 0.9      # raised to the measured value minus a margin once measured
+
+
 def test_cfg3_camus_module_fp32_vs_bf16_dice(hip):
     """configs[2] end to end: 4-class CAMUS-style head, 256x256, fp32 run vs bf16 run of the SAME GPU module -> Dice of
     the two masks (the fp32 run itself is tied to the CPU reference in tests/test_model_gpu.py)."""
@@ -87,7 +90,48 @@ def test_cfg3_camus_module_fp32_vs_bf16_dice(hip):
     assert len(torch.unique(m32)) >= 3, "degenerate mask"
     dice = ops.dice_from_counts(counts.sum((0, 1))).cpu().numpy()
     present = counts.sum((0, 1))[:, 2].cpu().numpy() > 500
-    assert (dice[present] >= 0.9).all(), dice
+    print("cfg3 fp32-vs-bf16 Dice per class:", dice, "agreement", (m32 == m16).float().mean().item())
+    assert (dice[present] >= CFG3_DICE_BAR).all(), dice
+
+
+def test_cfg3_module_against_the_independent_restatement(hip):
+    """configs[2]'s shape -- 256x256 frames (256 tokens per frame: chunked prep, deferred read-out), FOUR classes -- one clip x three
+    frames through the fp32 module and the fused bf16 build, against oracle/model_plain.plain_forward (float64, no product code):
+    fp32 logits within 1e-3 and every argmax flip a near-tie of the reference; bf16 masks agree on >= 97 % of the pixels."""
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    from oracle.model_plain import plain_forward
+    torch.manual_seed(12)
+    model = GDKVM(GDKVMConfig(num_classes=4)).eval()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.8, 1.25)
+    frames = torch.rand(1, 3, 3, 256, 256)
+    sd = {k_: v_.detach().clone() for k_, v_ in model.state_dict().items()}
+    lp, _ = plain_forward(sd, frames)
+    with torch.no_grad():                               # balance the random-init head so that all four classes appear
+        model.decoder.head.bias -= lp.flatten(3).median(-1).values.mean((0, 1)).float()
+    sd = {k_: v_.detach().clone() for k_, v_ in model.state_dict().items()}
+    lp, sp = plain_forward(sd, frames)
+    mp = lp.argmax(2)
+    shares = [(mp == c).float().mean().item() for c in range(4)]
+    assert min(shares) > 0.02, f"degenerate reference mask {shares}"
+    model = model.cuda().to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        lg, sg = model(frames.cuda(), return_state=True)
+    lg, sg = lg.cpu().double(), sg.cpu().double()
+    assert (lg - lp).abs().max() <= 1e-3 and (sg - sp).abs().max() <= 1e-3, ((lg - lp).abs().max().item(), (sg - sp).abs().max().item())
+    top = lp.sort(2, descending=True).values
+    margin = top[:, :, 0] - top[:, :, 1]
+    flip = lg.argmax(2) != mp
+    assert flip.float().mean() <= 1e-3 and (margin[flip] <= 1e-3).all(), (flip.float().mean().item(), margin[flip].max().item())
+    with torch.no_grad():
+        lb = model.fuse_for_inference().to(torch.bfloat16)(frames.cuda()).float().cpu().double()
+    err = (lb - lp).abs()
+    agree = (lb.argmax(2) == mp).float().mean().item()
+    print(f"cfg3 module vs plain_forward: fp32 max|dlogit| {(lg - lp).abs().max().item():.2e}; bf16 max {err.max().item():.3f} mean {err.mean().item():.4f} "
+          f"agreement {agree:.4f}; class shares {[round(x, 3) for x in shares]}")
+    assert err.max() <= 0.05 * max(1.0, lp.abs().max().item()) and err.mean() <= 0.01, (err.max().item(), err.mean().item())
+    assert agree >= 0.97, agree
 
 
 def test_cfg5_long_clip_chunked_state_carry(hip):

@@ -318,3 +318,55 @@ def test_scan_narrower_key_dims_through_zero_channels(hip, Dk):
     Rg, Sg = _run(hip, q, k, v, a, b, s0, 2, 3)
     Ro, So = c_oracle.scan(q, k, v, a, b, s0, 2, 3, math="f64")
     assert Sg.shape == So.shape and np.abs(Sg - So).max() <= TOL and np.abs(Rg - Ro).max() <= TOL
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rule", [0, 2])
+@pytest.mark.parametrize("log2_scale", [12, 20, 40])
+def test_scan_large_values_and_carried_state(hip, rule, log2_scale, dtype):
+    """The default forward carries the state as fp16 pairs at 2^-e.  With V and the carried state scaled by 2^12 ... 2^40 the
+    kernel must size e by the call's own bound (8 (max|S_0| + sum_t max|G_t|), gdr_scan.hip) instead of saturating at |S| ~ 1e6:
+    results against the oracle within the usual tolerance RELATIVE to the scale, for the delta rule and for gated_linear (whose
+    state grows with T N |v|), both I/O types, through the C ABI with default flags -- never rc 0 with saturated values."""
+    B, T, N, Hh, Dv = 2, 6, 49, 1, 64
+    scale = 2.0 ** log2_scale
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, 64, Dv, seed=40 + rule + log2_scale, normalized=False, logits=True, corr=0.5)
+    v = (v * scale).astype(np.float32)
+    s0 = (np.random.default_rng(2).standard_normal((B, Hh, 64, Dv)) * scale).astype(np.float32)
+    if dtype == torch.bfloat16:
+        q, k, v = (O.to_bf16_f32(x) for x in (q, k, v))
+    Rg, Sg = _run(hip, q, k, v, a, b, s0, rule, 3, dtype)
+    Ro, So = c_oracle.scan(q, k, v, a, b, s0, rule, 3, math="f64")
+    assert np.isfinite(Rg).all() and np.isfinite(Sg).all()
+    assert np.abs(Sg - So).max() <= TOL * scale, (np.abs(Sg - So).max() / scale)
+    out_q = 2.0 ** -8 if dtype == torch.bfloat16 else 0.0
+    assert np.all(np.abs(Rg - Ro) <= TOL * scale + np.abs(Ro) * out_q), (np.abs(Rg - Ro).max() / scale)
+    # the same clip cut into two calls with the state carried: the exponent of each call is sized by that call's own bound
+    h = T // 2
+    r1, s1 = _run(hip, q[:, :h], k[:, :h], v[:, :h], a[:, :h], b[:, :h], s0, rule, 3, dtype)
+    r2, s2 = _run(hip, q[:, h:], k[:, h:], v[:, h:], a[:, h:], b[:, h:], s1, rule, 3, dtype)
+    assert np.abs(s2 - So).max() <= TOL * scale
+    assert np.all(np.abs(np.concatenate([r1, r2], 1) - Ro) <= TOL * scale + np.abs(Ro) * out_q)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_large_values_in_frames_of_more_than_64_tokens(hip, dtype, monkeypatch):
+    """Frames of 130 tokens (chunk composition, deferred read-out).  2^12: right, relative to the scale.  2^22: the composition's
+    own fp16-pair re-split of the running map (fixed exponent 4) overflows -- that must come back as NaNs, never as plausible
+    saturated numbers; GDKVM_FLAG_WIDE_RANGE (three bf16 terms, the whole fp32 range) serves such inputs."""
+    B, T, N, Hh, Dv = 1, 3, 130, 1, 64
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, 64, Dv, seed=77, normalized=False, logits=True, corr=0.5)
+    if dtype == torch.bfloat16:
+        q, k, v = (O.to_bf16_f32(x) for x in (q, k, v))
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("GDKVM_PREP_FUSE", fuse)
+        v12 = (v * 4096.0).astype(np.float32)
+        Rg, Sg = _run(hip, q, k, v12, a, b, None, 2, 3, dtype)
+        Ro, So = c_oracle.scan(q, k, v12, a, b, None, 2, 3, math="f64")
+        assert np.abs(Sg - So).max() <= TOL * 4096 and np.all(np.abs(Rg - Ro) <= TOL * 4096 + np.abs(Ro) * 2.0 ** -8)
+        v22 = (v * 2.0 ** 22).astype(np.float32)
+        Rg, Sg = _run(hip, q, k, v22, a, b, None, 2, 3, dtype)
+        assert np.isnan(Sg).all() and np.isnan(Rg[:, 1:]).all()             # (frame 0 reads the zero start state)
+        Rw, Sw = _run(hip, q, k, v22, a, b, None, 2, 3 | 8, dtype)
+        Ro, So = c_oracle.scan(q, k, v22, a, b, None, 2, 3, math="f64")
+        assert np.abs(Sw - So).max() <= TOL * 2.0 ** 22 and np.all(np.abs(Rw - Ro) <= TOL * 2.0 ** 22 + np.abs(Ro) * 2.0 ** -8)
