@@ -379,6 +379,7 @@ struct PrepMArgs {
     const void* q; const void* k; const void* v; const float* beta;
     float* qinv; float* pp; float* gg;
     float* gmax;                                        // max |G| of the frame's final map per 16-column slice (gdr_ws.hpp)
+    const float* norms;                                 // [rows][Hh][2] inverse key / query norms from gdkvm_proj_gates, or NULL: computed here
     float* x0; float* ppc; float* ggc;                  // frames of more than 64 tokens: chunk 0 -> x0, chunk c >= 1 -> ppc/ggc[c-1]
     int T, Hh, N, Dv, rule, flags, np_total;            // N = tokens of the frame, np_total = its padded count (qinv row length)
     int nchunk;                                         // FUSE: 64-token chunks per frame, walked by ONE workgroup (else gridDim.y)
@@ -496,24 +497,30 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
     for (int rep = 0; rep < NP / 64; ++rep) {
         const int n = rep * 64 + (tid >> 2), qd = tid & 3;
         float sk = 0.f, sq = 0.f;
+        const bool given = a.norms != nullptr;            // (uniform) the norms came with the projections: q is not read here at all
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = {0.f, 0.f, 0.f, 0.f};
             if (n < N) {
                 x = load4<IO>(a.k, ((bt + n) * Hh + h) * GDKVM_DK + 16 * qd + 4 * j);
-                y = load4<IO>(a.q, ((bt + n) * Hh + h) * GDKVM_DK + 16 * qd + 4 * j);
+                if (!given) y = load4<IO>(a.q, ((bt + n) * Hh + h) * GDKVM_DK + 16 * qd + 4 * j);
             }
             *reinterpret_cast<f32x4*>(s_K + n * KLD + 16 * qd + 4 * j) = x;
             sk += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
             sq += y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
         }
-        sk += __shfl_xor(sk, 1); sq += __shfl_xor(sq, 1);
-        sk += __shfl_xor(sk, 2); sq += __shfl_xor(sq, 2);
+        if (!given) {
+            sk += __shfl_xor(sk, 1); sq += __shfl_xor(sq, 1);
+            sk += __shfl_xor(sk, 2); sq += __shfl_xor(sq, 2);
+        }
         if (qd == 0) {
             float kinv = 0.f, qinv = 0.f, bta = 0.f;
             if (n < N) {
                 kinv = qinv = 1.f;
-                if (a.flags & GDKVM_FLAG_NORMALIZE_QK) {
+                if (given) {
+                    const float2 nn = *reinterpret_cast<const float2*>(a.norms + ((bt + n) * Hh + h) * 2);
+                    kinv = nn.x; qinv = nn.y;
+                } else if (a.flags & GDKVM_FLAG_NORMALIZE_QK) {
                     kinv = 1.0f / sqrtf(sk + GDKVM_EPS_NORM);
                     qinv = 1.0f / sqrtf(sq + GDKVM_EPS_NORM);
                 }
@@ -1151,10 +1158,12 @@ extern "C" size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk
     return gdr_workspace_bytes(B, T, Hh, N, Dk, Dv);
 }
 
-extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, const float* beta, void* workspace, size_t workspace_bytes,
-                               int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
+static int scan_prep_impl(const void* q, const void* k, const void* v, const float* beta, const float* norms, void* workspace, size_t workspace_bytes,
+                          int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
 {
     if (int rc = check_common("scan_prep", B, T, Hh, N, Dk, Dv, io_dtype, flags)) return rc;
+    if (norms && (!(flags & GDKVM_FLAG_NORMALIZE_QK) || (flags & GDKVM_FLAG_TRAIN) || !gdkvm_aligned16(norms)))
+        return gdkvm_fail(GDKVM_ERR_ARG, "scan_prep_normed: norms go with GDKVM_FLAG_NORMALIZE_QK, inference (no GDKVM_FLAG_TRAIN), 16-byte aligned");
     if (rule < 0 || rule > 2) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_prep: rule=%d", rule);
     if (B == 0 || T == 0 || N == 0) return GDKVM_OK;
     if (int rc = check_ptrs("scan_prep", {q, k, v, beta, workspace}, {})) return rc;
@@ -1163,7 +1172,7 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
     if (int rc = gdkvm_check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!(flags & GDKVM_FLAG_TRAIN) || ws.nchunk > 1) {  // P and G directly (frames of > 64 tokens: per 64-token chunk, then composed)
-        PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, ws.gmax, ws.x0, ws.ppc, ws.ggc, T, Hh, N, Dv, rule, flags, 16 * ws.nb, ws.nchunk};
+        PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, ws.gmax, norms, ws.x0, ws.ppc, ws.ggc, T, Hh, N, Dv, rule, flags, 16 * ws.nb, ws.nchunk};
 #ifdef GDKVM_DIAG
         pm.diag = g_gdkvm_diag_buf;
 #endif
@@ -1202,3 +1211,26 @@ extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, cons
     return GDKVM_OK;
 }
 
+extern "C" int gdkvm_scan_prep(const void* q, const void* k, const void* v, const float* beta, void* workspace, size_t workspace_bytes,
+                               int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
+{
+    return scan_prep_impl(q, k, v, beta, nullptr, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream);
+}
+
+extern "C" int gdkvm_scan_prep_normed(const void* q, const void* k, const void* v, const float* beta, const float* norms,
+                                      void* workspace, size_t workspace_bytes,
+                                      int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
+{
+    if (!norms) return gdkvm_fail(GDKVM_ERR_ARG, "scan_prep_normed: null norms");
+    return scan_prep_impl(q, k, v, beta, norms, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream);
+}
+
+extern "C" int gdkvm_scan_fwd_normed(const void* q, const void* k, const void* v, const float* alpha, const float* beta, const float* norms,
+                                     const float* s_in, void* r_out, float* s_out, void* workspace, size_t workspace_bytes,
+                                     int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
+{
+    if (Dk != GDKVM_DK) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd_normed: Dk=%d (the norms path is built for Dk=%d)", Dk, GDKVM_DK);
+    if (rule == GDKVM_RULE_DELTA_PARALLEL) flags |= GDKVM_FLAG_WIDE_RANGE;      // as gdkvm_scan_fwd
+    if (int rc = gdkvm_scan_prep_normed(q, k, v, beta, norms, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream)) return rc;
+    return gdkvm_scan_apply(q, alpha, s_in, r_out, s_out, nullptr, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, flags, stream);
+}

@@ -764,6 +764,9 @@ __global__ __launch_bounds__(256) void kpff_bwd_post_kernel(const void* dF, cons
 // order as the A operand (kpff_stream) -- so the same machinery serves: a workgroup stages 128 token rows, its 8 waves walk the
 // 16-channel output tiles of all three projections, and the epilogue adds the bias and writes each tile into the tensor it
 // belongs to (contiguous [tokens, width] rows: exactly what gdkvm_scan_prep and gdkvm_kpff_fwd read).
+#ifndef PROJ_TM_SWITCH
+#define PROJ_TM_SWITCH (128 * 512)
+#endif
 struct ProjArgs {
     const bf16_t* x; const bf16_t* wpack; const float* bias;
     bf16_t* out[3];
@@ -815,6 +818,143 @@ __global__ __launch_bounds__(512) void proj_rows_kernel(ProjArgs a)
                 *reinterpret_cast<uint2*>(dst + row * wd + cbase) = o;
             }
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Row n4, one step further: EVERYTHING the memory path derives from the stride-16 pixel feature in ONE launch (inference) -- the
+// key / query / value projections (as proj_rows_kernel), the write-gate logit per token and the decay logit per frame (what
+// gdkvm_gate_logits computed in a launch of its own, from a second read of the same rows), and the inverse L2 norms of the key
+// and query rows (what gdkvm_scan_prep's first phase computed from a read of q it otherwise has no use for).
+//   workgroups [0, nproj)      a 64- or 128-token tile: rows staged once in LDS, gate logits from the staged rows (fp32 weights,
+//                              VALU), the projections' output tiles on the MFMA; the K and Q tiles leave per-token sums of squares
+//                              of the ROUNDED outputs (the values prep would read back) in LDS, one slot per tile, added up in a
+//                              fixed order after a barrier: deterministic, no atomics
+//   workgroups [nproj, ...)    the decay logit: one wave per frame walks the frame's rows (a frame's tokens straddle tiles, and a
+//                              sum over tiles would need atomics or a second launch); they run beside the tile workgroups
+struct ProjGateArgs {
+    ProjArgs p;
+    const float* w_gate; const float* b_gate; const float* w_decay; const float* b_decay;
+    float* beta; float* alpha; float* norms;
+    int frames, N, Hh, Dk, nproj;
+};
+
+template <int TM>
+__global__ __launch_bounds__(512) void proj_gates_kernel(ProjGateArgs ga)
+{
+    const ProjArgs& a = ga.p;
+    constexpr int MT = TM / 16;
+    extern __shared__ __attribute__((aligned(16))) bf16_t s_px[];       // [TM][K + PAD16] | per-tile sums of squares [ntile_norm][TM] fp32
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = a.K, ld = K + KPFF_PAD16, KS = K / 32, q8 = K / 8, Hh = ga.Hh;
+    if ((int)blockIdx.x >= ga.nproj) {
+        // ---- decay logits: alpha[f, h] = <mean_n x[f, n, :], w_decay[h, :]> + b_decay[h], one wave per frame
+        const int G = q8, tpw = 64 / G, sub = lane / G, cg = lane % G;   // lanes per token row (K / 8 <= 64, a power of two)
+        for (int f = ((int)blockIdx.x - ga.nproj) * 8 + w_id; f < ga.frames; f += ((int)gridDim.x - ga.nproj) * 8) {
+            const uint4* pv = reinterpret_cast<const uint4*>(a.x) + (size_t)f * ga.N * G;
+            for (int h = 0; h < Hh; ++h) {
+                float wd[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) wd[j] = ga.w_decay[(size_t)h * K + cg * 8 + j];
+                float dsum = 0.f;
+                constexpr int UNR = 8;
+                for (int n0 = 0; n0 < ga.N; n0 += tpw * UNR) {
+                    uint4 x[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) x[u] = pv[(size_t)min(n0 + tpw * u + sub, ga.N - 1) * G + cg];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const unsigned xw[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+                        float dd = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            dd = fmaf(__uint_as_float(xw[j] << 16), wd[2 * j], dd);
+                            dd = fmaf(__uint_as_float(xw[j] & 0xffff0000u), wd[2 * j + 1], dd);
+                        }
+                        dsum += (n0 + tpw * u + sub < ga.N) ? dd : 0.f;
+                    }
+                }
+                for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
+                if (lane == 0) ga.alpha[(size_t)f * Hh + h] = dsum / (float)ga.N + ga.b_decay[h];
+            }
+        }
+        return;
+    }
+    float* s_part = reinterpret_cast<float*>(s_px + (size_t)TM * ld);
+    const size_t row0 = (size_t)blockIdx.x * TM;
+    for (int base = tid; base < TM * q8; base += 4 * 512) {            // stage the token rows (zero beyond M), 4 loads in flight
+        uint4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 512, r = idx / q8, c = (idx - r * q8) * 8;
+            x[u] = (idx < TM * q8 && row0 + r < (size_t)a.M) ? *reinterpret_cast<const uint4*>(a.x + (row0 + r) * K + c) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 512, r = idx / q8, c = (idx - r * q8) * 8;
+            if (idx < TM * q8) *reinterpret_cast<uint4*>(s_px + (size_t)r * ld + c) = x[u];
+        }
+    }
+    __syncthreads();
+    {   // ---- write-gate logits from the staged rows: 512 / TM threads per token, 16-byte pieces interleaved over them
+        constexpr int TPT = 512 / TM;
+        const int tok = tid / TPT, part = tid % TPT;
+        for (int h = 0; h < Hh; ++h) {
+            float d = 0.f;
+            for (int pc = part; pc < q8; pc += TPT) {
+                const uint4 xv = *reinterpret_cast<const uint4*>(s_px + (size_t)tok * ld + pc * 8);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(ga.w_gate + (size_t)h * K + pc * 8);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(ga.w_gate + (size_t)h * K + pc * 8 + 4);
+                d = fmaf(__uint_as_float(xv.x << 16), w0[0], d); d = fmaf(__uint_as_float(xv.x & 0xffff0000u), w0[1], d);
+                d = fmaf(__uint_as_float(xv.y << 16), w0[2], d); d = fmaf(__uint_as_float(xv.y & 0xffff0000u), w0[3], d);
+                d = fmaf(__uint_as_float(xv.z << 16), w1[0], d); d = fmaf(__uint_as_float(xv.z & 0xffff0000u), w1[1], d);
+                d = fmaf(__uint_as_float(xv.w << 16), w1[2], d); d = fmaf(__uint_as_float(xv.w & 0xffff0000u), w1[3], d);
+            }
+#pragma unroll
+            for (int o = TPT >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o);
+            if (part == 0 && row0 + tok < (size_t)a.M) ga.beta[(row0 + tok) * Hh + h] = d + ga.b_gate[h];
+        }
+    }
+    const bf16_t* xb = s_px + (size_t)li * ld + 8 * g;
+    const int ntile_norm = (a.width[0] + a.width[1]) / 16;               // the key and query tiles
+    for (int ot = w_id; ot < a.ntile_out; ot += 8) {
+        f32x4 acc[1][MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[0][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        kpff_stream<1, MT, 1>(xb, ld, 0, KS, a.wpack + ((size_t)ot * KS * 64 + lane) * 8, nullptr, 0, acc, acc);
+        const int oc = 16 * ot + 4 * g;                               // this lane: channels oc .. oc+3 of token 16mt + li
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + oc);
+        const int seg = oc < a.width[0] ? 0 : (oc < a.width[0] + a.width[1] ? 1 : 2);
+        const int cbase = oc - (seg == 0 ? 0 : (seg == 1 ? a.width[0] : a.width[0] + a.width[1]));
+        bf16_t* dst = a.out[seg];
+        const int wd = a.width[seg];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const size_t row = row0 + 16 * mt + li;
+            const uint2 o = make_uint2((unsigned)f32_to_bf16(acc[0][mt][0] + b4[0]) | ((unsigned)f32_to_bf16(acc[0][mt][1] + b4[1]) << 16),
+                                       (unsigned)f32_to_bf16(acc[0][mt][2] + b4[2]) | ((unsigned)f32_to_bf16(acc[0][mt][3] + b4[3]) << 16));
+            if (row < (size_t)a.M) *reinterpret_cast<uint2*>(dst + row * wd + cbase) = o;
+            if (ot < ntile_norm) {                                    // sums of squares of the values as stored (bf16)
+                const float v0 = __uint_as_float(o.x << 16), v1 = __uint_as_float(o.x & 0xffff0000u);
+                const float v2 = __uint_as_float(o.y << 16), v3 = __uint_as_float(o.y & 0xffff0000u);
+                float ss = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+                ss += __shfl_xor(ss, 16);
+                ss += __shfl_xor(ss, 32);
+                if (g == 0) s_part[ot * TM + 16 * mt + li] = ss;
+            }
+        }
+    }
+    __syncthreads();
+    // inverse norms per (token, head): the Dk / 16 tile sums of a head in tile order; norms[row][head][0 = key, 1 = query]
+    const int tph = ga.Dk / 16;
+    for (int idx = tid; idx < TM * 2 * Hh; idx += 512) {
+        const int tok = idx % TM, hk = idx / TM, which = hk / Hh, h = hk % Hh;
+        const int t0 = (which ? a.width[0] / 16 : 0) + h * tph;
+        float ss = 0.f;
+        for (int t = 0; t < tph; ++t) ss += s_part[(t0 + t) * TM + tok];
+        if (row0 + tok < (size_t)a.M) ga.norms[((row0 + tok) * Hh + h) * 2 + which] = 1.0f / sqrtf(ss + GDKVM_EPS_NORM);
     }
 }
 
@@ -1017,9 +1157,6 @@ extern "C" int gdkvm_proj_rows(const void* x, const void* wpack, const float* bi
     a.width[0] = w0; a.width[1] = w1; a.width[2] = w2;
     a.M = (int)rows; a.K = K; a.ntile_out = (w0 + w1 + w2) / 16;
     // token rows per workgroup: 128 when that still gives every CU at least two workgroups, else 64 (cfg2: 25088 rows -> 392 x 64)
-#ifndef PROJ_TM_SWITCH
-#define PROJ_TM_SWITCH (128 * 512)
-#endif
     const int TM = rows >= PROJ_TM_SWITCH ? 128 : 64;
     const size_t lds = (size_t)TM * (K + KPFF_PAD16) * sizeof(bf16_t);
     {   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device; lock-free cache as in gdr_scan.hip
@@ -1039,5 +1176,57 @@ extern "C" int gdkvm_proj_rows(const void* x, const void* wpack, const float* bi
     if (TM == 128) hipLaunchKernelGGL(proj_rows_kernel<128>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
     else hipLaunchKernelGGL(proj_rows_kernel<64>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
     GDKVM_LAUNCH_CHECK("proj_rows_kernel");
+    return GDKVM_OK;
+}
+
+extern "C" int gdkvm_proj_gates(const void* x, const void* wpack, const float* bias, void* out_k, void* out_q, void* out_v,
+                                const float* w_gate, const float* b_gate, const float* w_decay, const float* b_decay,
+                                float* beta, float* alpha, float* norms,
+                                int frames, int N, int K, int Hh, int Dk, int Dv, int io_dtype, void* stream)
+{
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "proj_gates: only bf16 is implemented");
+    const int q8 = K > 0 ? K / 8 : 0;
+    if (frames < 0 || N <= 0 || K <= 0 || K % 32 || K > 512 || (q8 & (q8 - 1)) || Hh <= 0 || Dk <= 0 || Dk % 16 || Dv <= 0 || Dv % 16 ||
+        (long long)frames * N > 0x7fffffffLL)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "proj_gates: frames=%d N=%d K=%d Hh=%d Dk=%d Dv=%d (K a power of two times 8 up to 512, Dk and Dv multiples of 16)",
+                          frames, N, K, Hh, Dk, Dv);
+    if (frames == 0) return GDKVM_OK;
+    for (const void* p : {x, wpack, (const void*)bias, (const void*)out_k, (const void*)out_q, (const void*)out_v, (const void*)w_gate,
+                          (const void*)b_gate, (const void*)w_decay, (const void*)b_decay, (const void*)beta, (const void*)alpha, (const void*)norms})
+        if (!p) return gdkvm_fail(GDKVM_ERR_ARG, "proj_gates: null pointer");
+    for (const void* p : {x, wpack, (const void*)bias, (const void*)out_k, (const void*)out_q, (const void*)out_v, (const void*)w_gate, (const void*)w_decay})
+        if (!gdkvm_aligned16(p)) return gdkvm_fail(GDKVM_ERR_ARG, "proj_gates: pointers must be 16-byte aligned");
+    if (int rc = gdkvm_check_device()) return rc;
+    const long long rows = (long long)frames * N;
+    ProjGateArgs ga;
+    ProjArgs& a = ga.p;
+    a.x = static_cast<const bf16_t*>(x); a.wpack = static_cast<const bf16_t*>(wpack); a.bias = bias;
+    a.out[0] = static_cast<bf16_t*>(out_k); a.out[1] = static_cast<bf16_t*>(out_q); a.out[2] = static_cast<bf16_t*>(out_v);
+    a.width[0] = Hh * Dk; a.width[1] = Hh * Dk; a.width[2] = Hh * Dv;
+    a.M = (int)rows; a.K = K; a.ntile_out = (2 * Hh * Dk + Hh * Dv) / 16;
+    ga.w_gate = w_gate; ga.b_gate = b_gate; ga.w_decay = w_decay; ga.b_decay = b_decay;
+    ga.beta = beta; ga.alpha = alpha; ga.norms = norms; ga.frames = frames; ga.N = N; ga.Hh = Hh; ga.Dk = Dk;
+    const int TM = rows >= PROJ_TM_SWITCH ? 128 : 64;
+    const size_t lds = (size_t)TM * (K + KPFF_PAD16) * sizeof(bf16_t) + (size_t)(2 * Hh * Dk / 16) * TM * sizeof(float);
+    if (lds > 160 * 1024) return gdkvm_fail(GDKVM_ERR_SHAPE, "proj_gates: %zu bytes of LDS for Hh=%d Dk=%d", lds, Hh, Dk);
+    {   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device; lock-free cache as in gdr_scan.hip
+        static std::atomic<unsigned long long> done_mask{0};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "proj_gates: hipGetDevice");
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
+            const int cap = 160 * 1024;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_gates_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(proj_gates_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+            if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "proj_gates: %s", hipGetErrorString(e));
+            done_mask.fetch_or(bit, std::memory_order_relaxed);
+        }
+    }
+    ga.nproj = (int)((rows + TM - 1) / TM);
+    const unsigned nalpha = (unsigned)((frames + 7) / 8 < 256 ? (frames + 7) / 8 : 256);
+    const unsigned grid = (unsigned)ga.nproj + nalpha;
+    if (TM == 128) hipLaunchKernelGGL(proj_gates_kernel<128>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), ga);
+    else hipLaunchKernelGGL(proj_gates_kernel<64>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), ga);
+    GDKVM_LAUNCH_CHECK("proj_gates_kernel");
     return GDKVM_OK;
 }

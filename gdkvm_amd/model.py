@@ -60,6 +60,10 @@ _BN_COUNTED_BY_MODEL = [False]
 # (default), or the library convolution + one epilogue pass (GDKVM_CONV_IGEMM=0).  Measured equal on the EchoNet shapes -- 1.013 /
 # 1.020 ms against 1.021 ms per cfg2 forward -- so the hand-written path is taken: no solver search, one launch.
 _IGEMM_STRIDED = os.environ.get("GDKVM_CONV_IGEMM", "1") != "0"
+# SURVEY.md §8f row n4 in the inference build: key / query / value projections, both gate logits and the key / query norms in ONE
+# launch over the pixel feature (ops.proj_gates), the scan taking the norms as given -- or (GDKVM_PROJ_GATES=0, the A/B switch
+# behind DESIGN.md §8 n4's numbers) the three-launch form: ops.proj_rows, ops.gate_logits, norms inside gdkvm_scan_prep.
+_PROJ_GATES = os.environ.get("GDKVM_PROJ_GATES", "1") != "0"
 
 
 def _bn_act(bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -457,12 +461,13 @@ class GDKVM(nn.Module):
         return super().train(mode)
 
     # ------------------------------------------------------------------ memory path (HIP; overridable hooks)
-    def _memory_scan(self, q, k, v, alpha_logit, beta_logit, state):
-        """q,k [B,T,N,Hh,Dk] v [B,T,N,Hh,Dv] alpha [B,T,Hh] beta [B,T,N,Hh] -> (R [B,T,N,Hh,Dv], S_T)."""
+    def _memory_scan(self, q, k, v, alpha_logit, beta_logit, state, norms=None):
+        """q,k [B,T,N,Hh,Dk] v [B,T,N,Hh,Dv] alpha [B,T,Hh] beta [B,T,N,Hh] -> (R [B,T,N,Hh,Dv], S_T).  norms (inference): the
+        inverse key / query norms ops.proj_gates produced with the projections."""
         flags = ops.FLAG_NORMALIZE_QK | ops.FLAG_GATE_LOGITS
         if torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v, alpha_logit, beta_logit)):
             return ops.scan(q, k, v, alpha_logit, beta_logit, state, _RULES[self.cfg.rule], flags)   # saves history
-        return ops.scan_fwd(q, k, v, alpha_logit, beta_logit, state, rule=_RULES[self.cfg.rule], flags=flags)
+        return ops.scan_fwd(q, k, v, alpha_logit, beta_logit, state, rule=_RULES[self.cfg.rule], flags=flags, norms=norms)
 
     def _fuse(self, local, glob, pixel, h, w):
         p = self.kpff
@@ -532,8 +537,26 @@ class GDKVM(nn.Module):
             return F.linear(tok2d, w2, conv.bias)
 
         wk, wq, wv = Hh * Dk, Hh * Dk, Hh * Dv
-        if (tok2d.is_cuda and not train_gpu and not torch.is_grad_enabled() and tok2d.dtype == torch.bfloat16
-                and tok2d.shape[1] % 32 == 0 and tok2d.shape[1] <= 512 and wk % 16 == 0 and wv % 16 == 0):
+        norms = beta = alpha = None
+        cp8 = tok2d.shape[1] // 8
+        infer_bf16 = (tok2d.is_cuda and not train_gpu and not torch.is_grad_enabled() and tok2d.dtype == torch.bfloat16
+                      and tok2d.shape[1] % 32 == 0 and tok2d.shape[1] <= 512 and wk % 16 == 0 and wv % 16 == 0)
+        if infer_bf16 and _PROJ_GATES and Dk == ops.KERNEL_DK and cp8 & (cp8 - 1) == 0:
+            # ONE launch for everything derived from the pixel feature: K / Q / V, both gate logits, the key / query norms
+            projs = (self.key_proj, self.query_proj, self.value_proj)
+            gp, dp = self.gate_proj, self.decay_proj
+            key = _wkey(*(t for c in projs for t in (c.weight, c.bias)), gp.weight, gp.bias, dp.weight, dp.bias) + (tok2d.device,)
+            cache = getattr(self, "_qkv_pack", None)
+            if cache is None or cache[0] != key:
+                w_all = torch.cat([c.weight.detach().reshape(c.out_channels, -1).float() for c in projs], 0)
+                b_all = torch.cat([c.bias.detach().float() for c in projs], 0).contiguous()
+                gw = tuple(t.detach().float().contiguous() for t in (gp.weight.reshape(Hh, -1), gp.bias, dp.weight, dp.bias))
+                cache = (key, ops.pack_rows_weight(w_all), b_all, gw)
+                self._qkv_pack = cache
+            (k2d, q2d, v2d), (beta, alpha), norms = ops.proj_gates(p_tok, cache[1], cache[2], *cache[3], Hh, Dk, Dv)
+            beta, alpha = beta.reshape(B, T, N, Hh), alpha.reshape(B, T, Hh)
+            k_tok, q, v = k2d.reshape(B * T, N, wk), q2d.reshape(B, T, N, Hh, Dk), v2d.reshape(B, T, N, wv)
+        elif infer_bf16:
             # the three projections in ONE pass over the tokens (ops.proj_rows: token tile in LDS, weights streamed in MFMA
             # fragment order); the packed weight is rebuilt only when a projection's parameters change
             projs = (self.key_proj, self.query_proj, self.value_proj)
@@ -559,7 +582,9 @@ class GDKVM(nn.Module):
         v = v.reshape(B, T, N, Hh, Dv)
         v8 = 8 if p_tok.dtype == torch.bfloat16 else 4
         g_lanes = p_tok.shape[-1] // v8
-        if (p_tok.is_cuda and not train_gpu and not torch.is_grad_enabled() and p_tok.dtype in (torch.bfloat16, torch.float32)
+        if beta is not None:
+            pass                                                                 # (came with the projections)
+        elif (p_tok.is_cuda and not train_gpu and not torch.is_grad_enabled() and p_tok.dtype in (torch.bfloat16, torch.float32)
                 and p_tok.shape[-1] % v8 == 0 and g_lanes <= 64 and g_lanes & (g_lanes - 1) == 0):
             # both gate logits in one pass over the feature (token mean + two N = 1 projections + casts as framework ops: 6 launches)
             gp, dp = self.gate_proj, self.decay_proj
@@ -573,7 +598,10 @@ class GDKVM(nn.Module):
         else:
             beta = proj(self.gate_proj).float().reshape(B, T, N, Hh)
             alpha = self.decay_proj(p_tok.mean(1)).float().reshape(B, T, Hh)
-        r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state)
+        if norms is not None:
+            r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state, norms=norms)
+        else:
+            r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state)
         fused = self._fuse(k_tok, r.reshape(B * T, N, Hh * Dv), p_tok, h, w)       # [BT,N,Cp]
         fmap = fused.reshape(B * T, h, w, -1).permute(0, 3, 1, 2)                  # channels_last view, no copy
         logits = self.decoder(fmap, f8, f4, None if _lowres else (H, W), head_fused=_head_fused and _lowres and not return_state)

@@ -35,6 +35,8 @@ SIGNATURES = {
     "gdkvm_scan_fwd": (_i, [_vp] * 10 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_prep": (_i, [_vp] * 5 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_apply": (_i, [_vp] * 7 + [_sz] + [_i] * 8 + [_vp]),
+    "gdkvm_scan_prep_normed": (_i, [_vp] * 6 + [_sz] + [_i] * 9 + [_vp]),
+    "gdkvm_scan_fwd_normed": (_i, [_vp] * 10 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_transition": (_i, [_vp] * 4 + [_sz] + [_i] * 8 + [_vp]),
     "gdkvm_scan_stitch": (_i, [_vp] * 5 + [_i] * 5 + [_vp]),
     "gdkvm_scan_bwd_workspace_bytes": (_sz, [_i] * 6),
@@ -63,6 +65,7 @@ SIGNATURES = {
     "gdkvm_proj_rows": (_i, [_vp] * 6 + [ctypes.c_longlong] + [_i] * 5 + [_vp]),
     "gdkvm_stem_conv_pool": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
     "gdkvm_gate_logits": (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
+    "gdkvm_proj_gates": (_i, [_vp] * 13 + [_i] * 7 + [_vp]),
     "gdkvm_conv_bias_act": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
     "gdkvm_conv3x3_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "gdkvm_conv_igemm_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -177,14 +180,16 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
              state: Optional[torch.Tensor] = None, rule: int = RULE_DELTA_SEQUENTIAL, flags: int = 0,
              workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
              state_out: Optional[torch.Tensor] = None, state_hist: Optional[torch.Tensor] = None,
-             readout: bool = True) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+             readout: bool = True, norms: Optional[torch.Tensor] = None) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
     """Fused LKVA read + GDR write over T frames (gdkvm_scan_fwd).
 
     q,k [B,T,N,Hh,Dk]  v [B,T,N,Hh,Dv]  (f32|bf16)   alpha [B,T,Hh]  beta [B,T,N,Hh]  state [B,Hh,Dk,Dv] (f32)
     returns (R [B,T,N,Hh,Dv] in the io dtype, S_T [B,Hh,Dk,Dv] f32).
     Range: the default recurrence carries the state as fp16 pairs at 2^-e with e sized from the call's own bound on the state
     (include/gdkvm.h, GDKVM_FLAG_WIDE_RANGE), so values and carried states of any magnitude are served for rules 0 and 2; the
-    one refusal -- frames of more than 64 tokens with values ~1e5x the usual -- returns NaNs, and FLAG_WIDE_RANGE serves it."""
+    one refusal -- frames of more than 64 tokens with values ~1e5x the usual -- returns NaNs, and FLAG_WIDE_RANGE serves it.
+    norms [B*T*N, Hh, 2] fp32 (ops.proj_gates): the inverse key / query norms came with the projections (gdkvm_scan_fwd_normed:
+    the frame-parallel kernel neither reads q nor reduces anything in its first phase); needs FLAG_NORMALIZE_QK, Dk = 64."""
     lib = load()
     if q.dim() != 5 or k.shape != q.shape or v.dim() != 5 or v.shape[:4] != q.shape[:4]:
         raise GdkvmError(f"bad shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
@@ -213,6 +218,16 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
         workspace = torch.empty(need, dtype=torch.uint8, device=dev)
     r = None if not readout else (out if out is not None else torch.empty((B, T, N, Hh, Dv), dtype=q.dtype, device=dev))
     s = state_out if state_out is not None else torch.empty((B, Hh, Dk, Dv), dtype=torch.float32, device=dev)
+    if norms is not None:
+        if state_hist is not None or norms.dtype != torch.float32 or norms.numel() != B * T * N * Hh * 2 or not norms.is_contiguous() \
+                or norms.device != dev:
+            raise GdkvmError("scan_fwd: norms must be contiguous float32 [B*T*N, Hh, 2] on the inputs' device (inference: no state_hist)")
+        with torch.cuda.device(dev):
+            rc = lib.gdkvm_scan_fwd_normed(_ptr(q), _ptr(k), _ptr(v), _ptr(alpha), _ptr(beta), norms.data_ptr(), _ptr(state), _ptr(r), _ptr(s),
+                                           workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                           B, T, Hh, N, Dk, Dv, io, rule, flags, _stream(dev))
+        _check(rc, "gdkvm_scan_fwd_normed")
+        return r, s
     with torch.cuda.device(dev):
         rc = lib.gdkvm_scan_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(alpha), _ptr(beta), _ptr(state), _ptr(r), _ptr(s),
                                 _ptr(state_hist), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
@@ -732,6 +747,37 @@ def gate_logits(p_tok: torch.Tensor, w_gate: torch.Tensor, b_gate: torch.Tensor,
                                    beta.data_ptr(), alpha.data_ptr(), fr, n, cp, hh, _io_dtype(p_tok), _stream(p_tok.device))
     _check(rc, "gdkvm_gate_logits")
     return beta, alpha
+
+
+def proj_gates(p_tok: torch.Tensor, wpack: torch.Tensor, bias: torch.Tensor, w_gate: torch.Tensor, b_gate: torch.Tensor,
+               w_decay: torch.Tensor, b_decay: torch.Tensor, heads: int, key_dim: int, value_dim: int):
+    """Everything the memory path derives from the stride-16 pixel feature p_tok [frames, N, Cp] (bf16) in ONE launch
+    (gdkvm_proj_gates): returns (k [rows, Hh*Dk], q [rows, Hh*Dk], v [rows, Hh*Dv]) in bf16, (beta_logit [frames, N, Hh],
+    alpha_logit [frames, Hh]) in fp32, and norms [rows, Hh, 2] fp32 -- the inverse L2 norms of the stored key / query rows, which
+    scan_fwd(..., norms=norms) takes instead of computing them.  wpack / bias: pack_rows_weight of the stacked key, query, value
+    weights and their fp32 biases; gate weights fp32 [Hh, Cp]."""
+    lib = load()
+    if p_tok.dim() != 3 or not p_tok.is_cuda or p_tok.dtype != torch.bfloat16 or not p_tok.is_contiguous():
+        raise GdkvmError("proj_gates needs a contiguous bf16 [frames, N, Cp] device tensor (no CPU path)")
+    fr, n, cp = p_tok.shape
+    wk, wv = heads * key_dim, heads * value_dim
+    gw = [t.detach().float().contiguous() for t in (w_gate.reshape(heads, -1), b_gate, w_decay.reshape(heads, -1), b_decay)]
+    if gw[0].shape != (heads, cp) or gw[2].shape != (heads, cp) or gw[1].numel() != heads or gw[3].numel() != heads:
+        raise GdkvmError("proj_gates: gate weights must be [Hh, Cp], biases [Hh]")
+    if bias.dtype != torch.float32 or bias.numel() != 2 * wk + wv or wpack.dtype != torch.bfloat16 or wpack.numel() != (2 * wk + wv) * cp:
+        raise GdkvmError("proj_gates: packed bf16 weight [(2 Hh Dk + Hh Dv) * Cp] and fp32 bias [2 Hh Dk + Hh Dv]")
+    dev, rows = p_tok.device, fr * n
+    k, q = (torch.empty((rows, wk), dtype=p_tok.dtype, device=dev) for _ in range(2))
+    v = torch.empty((rows, wv), dtype=p_tok.dtype, device=dev)
+    beta = torch.empty((fr, n, heads), dtype=torch.float32, device=dev)
+    alpha = torch.empty((fr, heads), dtype=torch.float32, device=dev)
+    norms = torch.empty((rows, heads, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gdkvm_proj_gates(p_tok.data_ptr(), wpack.data_ptr(), bias.data_ptr(), k.data_ptr(), q.data_ptr(), v.data_ptr(),
+                                  gw[0].data_ptr(), gw[1].data_ptr(), gw[2].data_ptr(), gw[3].data_ptr(), beta.data_ptr(), alpha.data_ptr(),
+                                  norms.data_ptr(), fr, n, cp, heads, key_dim, value_dim, BF16, _stream(dev))
+    _check(rc, "gdkvm_proj_gates")
+    return (k, q, v), (beta, alpha), norms
 
 
 CONV_PACKED_WEIGHTS = 32

@@ -98,6 +98,18 @@ int gdkvm_scan_apply(const void* q, const float* alpha, const float* s_in, void*
                      float* s_hist, const void* workspace, size_t workspace_bytes,
                      int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int flags, void* stream);
 
+/* the same two calls for a caller that already holds the inverse L2 norms of the key and query rows --
+ * gdkvm_proj_gates, which produces q, k, v, the gate logits AND these norms in one launch.  norms [B*T*N, Hh, 2] fp32:
+ * 1 / sqrt(sum k^2 + 1e-12) and the same for q, of the rows AS STORED (io_dtype).  The frame-parallel kernel then neither reads q
+ * nor reduces anything in its first phase.  Requires GDKVM_FLAG_NORMALIZE_QK, Dk == 64, no s_hist (inference); everything else as
+ * gdkvm_scan_prep / gdkvm_scan_fwd, and the results agree with them to the last few ulp of the norms' summation order. */
+int gdkvm_scan_prep_normed(const void* q, const void* k, const void* v, const float* beta, const float* norms,
+                           void* workspace, size_t workspace_bytes,
+                           int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream);
+int gdkvm_scan_fwd_normed(const void* q, const void* k, const void* v, const float* alpha, const float* beta, const float* norms,
+                          const float* s_in, void* r_out, float* s_out, void* workspace, size_t workspace_bytes,
+                          int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream);
+
 /* SURVEY.md §8(f) row n3.  The effect of a block of frames on the state is affine, S_out = Phi S_in + S_loc, with the
  * state-transition matrix Phi = prod_t alpha_t (I - Kn_t^T Wt_t) ("Linear Key-Value Association defines frame-to-frame
  * causal relations as the state transition matrix", /root/reference/website/src/content/homepage/en.json:20).
@@ -287,6 +299,16 @@ int gdkvm_proj_rows(const void* x, const void* wpack, const float* bias, void* o
  * both fp32 (the dtype gdkvm_scan_prep / gdkvm_scan_apply read), weights fp32 [Hh, Cp], fp32 accumulation throughout. */
 int gdkvm_gate_logits(const void* p, const float* w_gate, const float* b_gate, const float* w_decay, const float* b_decay,
                       float* beta, float* alpha, int frames, int N, int Cp, int Hh, int io_dtype, void* stream);
+
+/* Row n4: gdkvm_proj_rows + gdkvm_gate_logits + the inverse norms of the key / query rows in ONE launch over the stride-16 pixel
+ * feature x [frames * N, K] (bf16): out_k, out_q [rows, Hh*Dk], out_v [rows, Hh*Dv] (bf16; wpack / bias as for gdkvm_proj_rows with
+ * the key, query and value weights stacked in that order), beta [rows, Hh] and alpha [frames, Hh] (fp32 logits, fp32 gate weights
+ * [Hh, K]), norms [rows, Hh, 2] (fp32: what gdkvm_scan_fwd_normed takes).  The tokens are read from HBM once; deterministic (no
+ * atomics).  K a power of two times 8 up to 512. */
+int gdkvm_proj_gates(const void* x, const void* wpack, const float* bias, void* out_k, void* out_q, void* out_v,
+                     const float* w_gate, const float* b_gate, const float* w_decay, const float* b_decay,
+                     float* beta, float* alpha, float* norms,
+                     int frames, int N, int K, int Hh, int Dk, int Dv, int io_dtype, void* stream);
 
 /* Row n1 (inference build): 3x3 / stride 1 / pad 1 convolution with the folded-BatchNorm bias, the residual add and the ReLU
  * in its epilogue,  y = act(conv(x, w) + bias[k] (+ residual)),  x [N, H, W, C] (NHWC), w [K, 3, 3, C] (channels_last weights),

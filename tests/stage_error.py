@@ -29,8 +29,8 @@ def product_taps(model, frames):
     hook = model.encoder.register_forward_hook(lambda m, i, o: taps.update(f4=o[0], f8=o[1], f16=o[2]))
     scan0, fuse0 = model._memory_scan, model._fuse
 
-    def scan(q, k, v, al, be, st):
-        r, s = scan0(q, k, v, al, be, st)
+    def scan(q, k, v, al, be, st, **kw):
+        r, s = scan0(q, k, v, al, be, st, **kw)
         B, T, N = q.shape[:3]
         taps.update(q=q.reshape(B * T, N, -1), k=k.reshape(B * T, N, -1), v=v.reshape(B * T, N, -1), r=r.reshape(B * T, N, -1),
                     beta=be, alpha=al)

@@ -433,6 +433,48 @@ def test_key_query_value_projections_in_one_pass(hip, case):
         hip.proj_rows(x.float(), hip.pack_rows_weight(w), b, widths)
 
 
+@pytest.mark.parametrize("case", [(512, 49, 256, 1, 64, 256), (40, 256, 256, 1, 64, 64), (7, 49, 256, 2, 64, 32), (3, 5, 64, 1, 64, 16),
+                                  (1400, 49, 128, 1, 64, 128)])       # (the last: 68600 rows -> 128-token tiles)
+def test_projections_gates_and_norms_in_one_launch(hip, case):
+    """gdkvm_proj_gates == gdkvm_proj_rows + gdkvm_gate_logits + the inverse norms of the stored key / query rows.
+    Projections bit-identical to gdkvm_proj_rows (same tile machinery), gate logits against fp64, norms against the rows as stored;
+    and gdkvm_scan_fwd_normed fed those norms agrees with gdkvm_scan_fwd computing its own."""
+    fr, n, cp, hh, dk, dv = case
+    torch.manual_seed(sum(case))
+    p = torch.randn(fr, n, cp, device="cuda").bfloat16()
+    wk, wv = hh * dk, hh * dv
+    w = torch.randn(2 * wk + wv, cp, device="cuda") / cp ** 0.5
+    b = torch.randn(2 * wk + wv, device="cuda")
+    wg, bg = torch.randn(hh, cp, device="cuda") / cp ** 0.5, torch.randn(hh, device="cuda")
+    wd, bd = torch.randn(hh, cp, device="cuda") / cp ** 0.5, torch.randn(hh, device="cuda")
+    pack = hip.pack_rows_weight(w)
+    (k, q, v), (beta, alpha), norms = hip.proj_gates(p, pack, b, wg, bg, wd, bd, hh, dk, dv)
+    k0, q0, v0 = hip.proj_rows(p.reshape(fr * n, cp), pack, b, (wk, wk, wv))
+    assert torch.equal(k, k0) and torch.equal(q, q0) and torch.equal(v, v0)
+    p64 = p.double()
+    beta_ref = p64 @ wg.double().t() + bg.double()
+    alpha_ref = p64.mean(1) @ wd.double().t() + bd.double()
+    assert beta.shape == (fr, n, hh) and alpha.shape == (fr, hh) and norms.shape == (fr * n, hh, 2)
+    assert (beta.double() - beta_ref).abs().max() <= 1e-5 * max(1.0, beta_ref.abs().max().item())
+    assert (alpha.double() - alpha_ref).abs().max() <= 1e-5 * max(1.0, alpha_ref.abs().max().item())
+    kn = 1.0 / (k.double().reshape(fr * n, hh, dk).pow(2).sum(-1) + 1e-12).sqrt()
+    qn = 1.0 / (q.double().reshape(fr * n, hh, dk).pow(2).sum(-1) + 1e-12).sqrt()
+    assert ((norms[..., 0].double() - kn).abs() <= 1e-6 * kn).all() and ((norms[..., 1].double() - qn).abs() <= 1e-6 * qn).all()
+    assert torch.equal(norms, hip.proj_gates(p, pack, b, wg, bg, wd, bd, hh, dk, dv)[2])          # deterministic
+    # the scan with the norms given against the scan computing them (B clips x T frames out of the rows)
+    B = 1 if fr % 2 else 2
+    T = fr // B
+    if T <= 64:
+        sh = lambda t, c: t.reshape(B, T, n, hh, c)
+        args = (sh(q, dk), sh(k, dk), sh(v, dv), alpha.reshape(B, T, hh), beta.reshape(B, T, n, hh))
+        r0, s0 = hip.scan_fwd(*args, flags=3)
+        r1, s1 = hip.scan_fwd(*args, flags=3, norms=norms)
+        assert (s1 - s0).abs().max() <= 1e-5 * max(1.0, s0.abs().max().item())
+        assert (r1.float() - r0.float()).abs().max() <= 2.0 ** -7 * max(1.0, r0.float().abs().max().item())
+        with pytest.raises(hip.GdkvmError):
+            hip.scan_fwd(*args, flags=2, norms=norms)                  # norms go with FLAG_NORMALIZE_QK
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", [(5, 64, 28, 28, 2), (2, 64, 64, 64, 4), (3, 32, 5, 7, 3), (1, 256, 3, 3, 8)])
 def test_head_logits_planes(hip, dtype, case):

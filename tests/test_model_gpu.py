@@ -67,7 +67,8 @@ def test_module_against_the_independent_restatement(hip):
         fused = model.fuse_for_inference().to(torch.bfloat16)
         lb = fused(frames.cuda()).float().cpu().double()
     err = (lb - lp).abs()
-    assert err.max() <= 0.05 * max(1.0, lp.abs().max().item()) and err.mean() <= 0.01, (err.max().item(), err.mean().item())
+    rms = lp.pow(2).mean().sqrt().item()                # errors relative to the logits' own scale (random-init logits are small)
+    assert err.mean() <= 0.05 * rms and err.max() <= 0.3 * rms, (err.max().item() / rms, err.mean().item() / rms)
     agree = (lb.argmax(2) == lp.argmax(2)).float().mean().item()
     assert agree >= 0.97, agree
 
@@ -88,7 +89,8 @@ def test_fused_build_on_maps_wider_than_64_pixels(hip):
         fused = model.fuse_for_inference().to(torch.bfloat16)
         lb = fused(frames.cuda(), _lowres=True).float().cpu().double()
     err = (lb - lp).abs()
-    assert err.max() <= 0.05 * max(1.0, lp.abs().max().item()) and err.mean() <= 0.01, (err.max().item(), err.mean().item())
+    rms = lp.pow(2).mean().sqrt().item()
+    assert err.mean() <= 0.05 * rms and err.max() <= 0.3 * rms, (err.max().item() / rms, err.mean().item() / rms)
     agree = (lb.argmax(2) == lp.argmax(2)).float().mean().item()
     frac = lp.argmax(2).float().mean().item()
     assert agree >= 0.97 and 0.2 < frac < 0.8, (agree, frac)
