@@ -1010,7 +1010,12 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
 template <int NB, int IO, int FMT, bool FUSE = false>
 int launch_prepm_fmt(const PrepMArgs& pa, int FH, int nchunk, hipStream_t st)
 {
-    const size_t lds = prepm_lds_bytes(NB, IO, FUSE);
+    size_t lds = prepm_lds_bytes(NB, IO, FUSE);
+    // diagnostics (tools/n4_bench.py fold): extra KiB of LDS per workgroup, to measure what a design that keeps more per frame
+    // resident -- the projections folded into this kernel need the frame's feature and value tiles: 104 KiB, one workgroup per CU --
+    // would pay in occupancy before any of its own work
+    static const int lds_pad_kb = [] { const char* e = getenv("GDKVM_PREP_LDS_PAD_KB"); return e ? atoi(e) : 0; }();
+    if (lds_pad_kb > 0 && lds + (size_t)lds_pad_kb * 1024 <= 160 * 1024) lds += (size_t)lds_pad_kb * 1024;
     if (lds > 64 * 1024) {
         // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device; lock-free cache as in gdr_scan.hip
         static std::atomic<unsigned long long> done_mask{0};

@@ -56,3 +56,9 @@ rows = [("gdkvm_proj_rows", lambda: ops.proj_rows(p.reshape(B * T * N, Cp), pack
         ("fused: proj_gates + scan_fwd_normed", fused)]
 for name, fn in rows:
     print(f"{name:55s} {ev_time(fn, iters=iters):8.1f} us")
+
+# The full fold (K / Q / V computed inside the frame-parallel kernel) must keep the frame's value tile (64 x 256 bf16 = 32 KiB) next to
+# the kernel's own 72 KiB: 104 KiB, ONE workgroup per CU instead of two.  What that occupancy alone costs, before any projection work:
+#     GDKVM_PREP_LDS_PAD_KB=32 python3 tools/n4_bench.py   (the gdkvm_scan_prep row)
+if os.environ.get("GDKVM_PREP_LDS_PAD_KB"):
+    print(f"(gdkvm_scan_prep above ran with {os.environ['GDKVM_PREP_LDS_PAD_KB']} KiB of extra LDS per workgroup)")
