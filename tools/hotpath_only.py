@@ -33,7 +33,12 @@ def main():
     f = torch.empty(B * T, N, Cp, device=dev, dtype=torch.bfloat16)
     logits = torch.randn(B * T, ncls, S, S, device=dev, generator=g).bfloat16()
     tgt = (torch.rand(B * T, S, S, device=dev, generator=g) > 0.5).to(torch.uint8)
+    wqkv = torch.randn(2 * Dk + Dv, Cp, device=dev, generator=g) / Cp ** 0.5
+    pack, bqkv = ops.pack_rows_weight(wqkv), torch.zeros(2 * Dk + Dv, device=dev)
+    wgt, wdc = (torch.randn(Hh, Cp, device=dev, generator=g) / Cp ** 0.5 for _ in range(2))
+    bg, bd = torch.zeros(Hh, device=dev), 2 + torch.zeros(Hh, device=dev)
     for _ in range(iters):
+        ops.proj_gates(P, pack, bqkv, wgt, bg, wdc, bd, Hh, Dk, Dv)        # row n4: projections + gates + norms, one launch
         ops.scan_fwd(q, k, v, al, be, flags=3, workspace=ws, out=r, state_out=s)
         ops.kpff_fwd(L, r.reshape(B * T, N, Dv), P, wa, ba, wl, wg, 7, 7, out=f)
         ops.argmax_dice(logits, tgt)
