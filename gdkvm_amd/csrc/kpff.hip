@@ -300,6 +300,18 @@ __device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, i
             xa[mt] = *reinterpret_cast<const bf16x8*>(xb + (size_t)mt * 16 * ld + 32 * ksn);
         }
         wload(i + KPFF_WD, b0[j], b1[j]);                  // refill the weight set just used
+#ifndef KPFF_NO_SCHED_GROUPS
+        // Pin the order written above.  Left alone, the machine scheduler clusters: all of the k-step's MFMAs first, then the MT
+        // LDS reads in one batch -- and the next k-step opens with s_waitcnt lgkmcnt(MT - 1) on a read issued a few cycles earlier:
+        // a full LDS round trip exposed per k-step (round 3 disassembly; the MFMA pipe was 40 % busy inside this loop).  One group
+        // per token tile: its NS * OT MFMAs, then its fragment read; the weight loads last.
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            __builtin_amdgcn_sched_group_barrier(0x008, NS * OT, 0);       // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);             // DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, NS * OT, 0);           // VMEM read
+#endif
         __builtin_amdgcn_sched_barrier(0);
     };
     int i = 0;
