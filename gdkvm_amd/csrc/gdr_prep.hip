@@ -389,9 +389,17 @@ struct PrepMArgs {
 };
 
 __host__ __device__ constexpr bool prepm_split(int NB, int IO) { return NB == 4 && IO == GDKVM_BF16; }
+// bf16 I/O, chunk-parallel (not the fused walk): the COMPACT layout -- two regions re-used along the kernel's phases, 40 KiB instead
+// of 72.7, so that THREE workgroups share a CU (cfg3: 640 chunk workgroups in one round instead of 1.25):
+//   R1 16 KiB   phases 0-3: kinv beta qinv pad | negB pairs | Ld | TmT (15 KiB)   end of phase 3: mt [4][NB]   phase 4b: V staging
+//   R2 24 KiB   phase 0: the raw K rows (17 KiB)                                   end of phase 3: m3 [3][4][NB/2]
+// (mt and m3 are written behind a barrier that follows every wave's last read of R1 / R2, and are read into registers once, at the
+// start of phase 4, behind which another barrier releases R1 for the V tiles.)
+__host__ __device__ constexpr bool prepm_compact(int NB, int IO, bool fuse) { return prepm_split(NB, IO) && !fuse; }
 __host__ __device__ constexpr size_t prepm_lds_bytes(int NB, int IO, bool fuse = false)
 {   // kinv beta qinv pad | negB pairs | Ld | TmT | kni [4][NB] | mt [4][NB]   (images of 64 x f32x4) | m3 [3][4][NB/2] (bf16 arm)
     // | fused chunk walk: wave 3's column tile (two term images)
+    if (prepm_compact(NB, IO, fuse)) return (size_t)(4 * NB * 256 + 3 * 4 * (NB / 2) * 256) * sizeof(float);
     return (size_t)(4 * 16 * NB + (NB * (NB - 1) / 2 + 2 * NB + 8 * NB + (prepm_split(NB, IO) ? 3 * 4 * (NB / 2) : 0)) * 256) * sizeof(float)
            + (fuse ? 2 * SPLIT_IMG * 8 : 0);
 }
@@ -399,25 +407,29 @@ __host__ __device__ constexpr size_t prepm_lds_bytes(int NB, int IO, bool fuse =
 
 
 template <int NB, int IO, int FMT, bool FUSE = false>
-__global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves_per_eu(1, 2))) void gdr_prepm_kernel(PrepMArgs a)
+__global__ __launch_bounds__(256, (NB == 4 ? (prepm_compact(NB, IO, FUSE) ? 3 : 2) : 1))
+__attribute__((amdgpu_waves_per_eu(1, (prepm_compact(NB, IO, FUSE) ? 3 : 2)))) void gdr_prepm_kernel(PrepMArgs a)
 {
     constexpr int NP = 16 * NB, NT = fmt_terms(FMT);
     static_assert(!FUSE || (prepm_split(NB, IO) && FMT == FMT_PAIR16), "the fused chunk walk is built for bf16 I/O on pair16 operands");
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool COMPACT = prepm_compact(NB, IO, FUSE);  // (layout: prepm_lds_bytes)
     float* s_kinv = smem;
     float* s_beta = smem + NP;
     float* s_qinv = smem + 2 * NP;
     f32x4* s_negB = reinterpret_cast<f32x4*>(smem + 4 * NP);
     f32x4* s_Ld = s_negB + (NB * (NB - 1) / 2) * 64;
     f32x4* s_TmT = s_Ld + NB * 64;
-    f32x4* s_kni = s_TmT + NB * 64;
-    f32x4* s_mt = s_kni + 4 * NB * 64;
+    f32x4* s_r2 = reinterpret_cast<f32x4*>(smem) + 4 * NB * 64;          // COMPACT: region R2, behind the 16 KiB of R1
+    f32x4* s_kni = COMPACT ? reinterpret_cast<f32x4*>(smem) : s_TmT + NB * 64;   // (V staging tiles of phase 4b)
+    f32x4* s_mt = COMPACT ? reinterpret_cast<f32x4*>(smem) : s_kni + 4 * NB * 64;
     constexpr bool SPLIT = prepm_split(NB, IO);
     constexpr int KS = NB / 2;                            // 32-token k-steps of the bf16 MFMA
-    uint2* s_m3 = reinterpret_cast<uint2*>(s_mt + 4 * NB * 64);   // [3 terms][4 m][KS][64 lanes][2 halves]: A images of M
-    float* s_K = reinterpret_cast<float*>(s_kni);         // raw K rows [NP][KLD] fp32 until phase 3 overwrites the region
+    uint2* s_m3 = reinterpret_cast<uint2*>(COMPACT ? s_r2 : s_mt + 4 * NB * 64);   // [3 terms][4 m][KS][64 lanes][2 halves]: A images of M
+    float* s_K = reinterpret_cast<float*>(COMPACT ? s_r2 : s_kni);   // raw K rows [NP][KLD] fp32 until the end of phase 3 overwrites the region
     constexpr int KLD = GDKVM_DK + 4;
-    static_assert(NP * KLD <= 8 * NB * 256, "the K staging tile aliases kni + mt");
+    static_assert(NP * KLD <= (COMPACT ? 3 * 4 * (NB / 2) : 8 * NB) * 256, "the K staging tile aliases kni + mt (COMPACT: m3)");
+    static_assert(4 * NP + (NB * (NB - 1) / 2 + 2 * NB) * 256 <= 4 * NB * 256, "COMPACT: the phase 0-3 scratch fits under mt");
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -471,11 +483,16 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
     // a wave-private LDS tile and read back TRANSPOSED (ds_read_b64_tr_b16: four rows x 16 columns per 16-lane group, column-
     // major) as the B operand -- 2 vector loads + 2 LDS writes + 4 LDS reads per tile instead of 16 two-byte gathers.
     uint4 vA0, vA1, vB0, vB1;                              // (scalars, not an array: an array of these ends up in scratch)
+    // (a uniform base and two 32-bit lane offsets: as 64-bit lane addresses they cost four registers across the G loop, which the
+    // three-workgroups-per-CU build of this kernel does not have)
+    const bf16_t* vrow = static_cast<const bf16_t*>(a.v) + (bt * Hh + h) * Dv;
+    const unsigned voff0 = (unsigned)min(lane >> 1, N - 1) * (unsigned)(Hh * Dv) + 8u * (lane & 1);
+    const unsigned voff1 = (unsigned)min(32 + (lane >> 1), N - 1) * (unsigned)(Hh * Dv) + 8u * (lane & 1);
     auto load_vraw = [&](int cV, uint4& d0, uint4& d1) __attribute__((always_inline)) {
         cV = min(cV, nsl - 1);
-        const bf16_t* vp = static_cast<const bf16_t*>(a.v) + 16 * cV + 8 * (lane & 1);
-        d0 = *reinterpret_cast<const uint4*>(vp + ((bt + min(lane >> 1, N - 1)) * Hh + h) * Dv);
-        d1 = *reinterpret_cast<const uint4*>(vp + ((bt + min(32 + (lane >> 1), N - 1)) * Hh + h) * Dv);
+        const bf16_t* vp = vrow + 16 * cV;
+        d0 = *reinterpret_cast<const uint4*>(vp + voff0);
+        d1 = *reinterpret_cast<const uint4*>(vp + voff1);
     };
 
     // bf16 I/O: the Gram blocks of phase 1 run on the bf16 MFMA straight from the key rows -- token tile X as an operand image is
@@ -668,9 +685,13 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
 #pragma unroll
         for (int I = 0; I < NB; ++I) Z[I] = KN[I];
     }
+    f32x4 btI[NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) btI[I] = *reinterpret_cast<const f32x4*>(s_beta + 16 * I + 4 * g);
+    if constexpr (COMPACT) __syncthreads();               // every wave is through with R1 (gates, Gram / T blocks) and R2 (K rows): mt / m3 take them over
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
-        const f32x4 bt4 = *reinterpret_cast<const f32x4*>(s_beta + 16 * I + 4 * g);
+        const f32x4 bt4 = btI[I];
         const f32x4 mtI = Z[I] * bt4;
         s_mt[(w * NB + I) * 64 + lane] = mtI;
         if constexpr (SPLIT) {             // this lane's 4 tokens 16I+4g+r of row 16w+li are half (g&1) of A lane (2(I&1)+(g>>1), li), ks = I>>1
@@ -821,7 +842,8 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
         }
         if (final_g && cV < nsl) {
             gm = wave_max_nonneg(gm);
-            if (lane == 0) *reinterpret_cast<f32x4*>(a.gmax + ((size_t)fh * nsl + cV) * 4) = f32x4{gm, 0.f, 0.f, 0.f};
+            const int gi = __builtin_amdgcn_readfirstlane((fh * nsl + cV) * 4);
+            if (lane == 0) *reinterpret_cast<f32x4*>(a.gmax + gi) = f32x4{gm, 0.f, 0.f, 0.f};
         }
     };
     if constexpr (SPLIT) {
@@ -835,6 +857,9 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
                 for (int sp = 0; sp < 3; ++sp)
                     d[ks][sp] = *reinterpret_cast<const bf16x8*>(&s_m3[sp * 4 * KS * 128 + ((m * KS + ks) * 64 + lane) * 2]);
         };
+        // COMPACT: every wave has consumed its copy of mt (the P tiles above): R1 now stages the V tiles.  (The barrier also keeps the
+        // 96 registers of M's term images from being fetched while the 64 of mt are still live.)
+        if constexpr (COMPACT) __syncthreads();
         if constexpr (!FUSE) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) am_load(m, am[m]);
@@ -892,9 +917,11 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 1)) __attribute__((amdgpu_waves
                 g_tiles3(cV + 4, xb, [&](int m, const f32x4& t) { if (cV + 4 < nsl) gg[((size_t)(cV + 4) * 4 + m) * 64 + lane] = t * gscale; gmB = fmaxf(gmB, absmax4(t)); });
                 if (final_g) {
                     gmA = wave_max_nonneg(gmA); gmB = wave_max_nonneg(gmB);
+                    // (the index as a scalar: as a vector expression its 64-bit address lived in registers across the loop and spilled)
+                    const int gi = __builtin_amdgcn_readfirstlane((fh * nsl + cV) * 4);
                     if (lane == 0) {
-                        if (cV < nsl) *reinterpret_cast<f32x4*>(a.gmax + ((size_t)fh * nsl + cV) * 4) = f32x4{gmA, 0.f, 0.f, 0.f};
-                        if (cV + 4 < nsl) *reinterpret_cast<f32x4*>(a.gmax + ((size_t)fh * nsl + cV + 4) * 4) = f32x4{gmB, 0.f, 0.f, 0.f};
+                        if (cV < nsl) *reinterpret_cast<f32x4*>(a.gmax + gi) = f32x4{gmA, 0.f, 0.f, 0.f};
+                        if (cV + 4 < nsl) *reinterpret_cast<f32x4*>(a.gmax + gi + 16) = f32x4{gmB, 0.f, 0.f, 0.f};
                     }
                 }
             }
