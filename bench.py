@@ -448,6 +448,26 @@ def main():
                 other[name] = ent
                 del q2, k2, v2, al2, be2, ws2, r2, s2
             out["roofline"]["other_configs"] = other
+            # configs[2]'s own figure of merit: Dice of the fused bf16 build's masks against the fp32 module's, same weights, 4 classes,
+            # 8 clips x 20 frames of 256 x 256 (random-init weights, head balanced so that every class is present; the fp32 module
+            # itself is tied to the float64 restatement in tests/test_configs_gpu.py)
+            try:
+                torch.manual_seed(2)
+                m3 = GDKVM(GDKVMConfig(num_classes=4)).eval().to(dev).to(memory_format=torch.channels_last)
+                f3 = torch.rand(8, 20, 3, 256, 256, device=dev)
+                with torch.no_grad():
+                    lg3 = m3(f3, _lowres=True)
+                    m3.decoder.head.bias -= lg3.float().flatten(3).median(-1).values.mean((0, 1))
+                    mask32, _ = m3.segment(f3)
+                    mask16, cnt3 = m3.fuse_for_inference().to(torch.bfloat16).segment(f3, target=mask32)
+                d3 = ops.dice_from_counts(cnt3.sum((0, 1))).tolist()
+                out["dice_configs2_fp32_vs_bf16"] = {
+                    "per_class": [round(x, 5) for x in d3], "mask_agreement": round((mask32 == mask16).float().mean().item(), 6),
+                    "class_fractions_fp32": [round((mask32 == c).float().mean().item(), 4) for c in range(4)],
+                    "compared": "fused bf16 build vs fp32 module on the GPU, same random-init weights (head balanced), 8x20x256x256, 4 classes"}
+                del m3, f3, lg3, mask32, mask16
+            except Exception as e:                              # noqa: BLE001 -- informational leg
+                out["dice_configs2_fp32_vs_bf16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         # ---- CPU baseline: the oracle module on a bounded sample of the same workload (N=1 only) -----------
         if world == 1 and not args.no_cpu_baseline:
             cores = host_cores()
