@@ -198,6 +198,23 @@ __global__ __launch_bounds__(256) void kpff_kernel(KpffArgs a)
 // fragment = 8 consecutive k of one output channel = one 16-byte load, a wave's 64 fragments contiguous).  Lane l = 16g + i:
 //   A = X[row i][k 8g..8g+7],  B = W[col i][k 8g..8g+7],  C/D reg r = D[row 4g + r][col i].
 
+#ifdef KPFF_STAMPS
+// Diagnostic build only (tools/stamp_kpff.py): lane 0 of every wave of the first 64 workgroups stamps s_memtime at the phase
+// boundaries of kpff_bf16_kernel into a buffer of its own ([block][wave][16]).  Never compiled into the product library.
+__device__ unsigned long long* g_kpff_stamps = nullptr;
+extern "C" void gdkvm_kpff_diag_set_buffer(unsigned long long* p) { hipMemcpyToSymbol(HIP_SYMBOL(g_kpff_stamps), &p, sizeof(p)); }
+#define KPFF_STAMP(slot)                                                                                           \
+    do {                                                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        unsigned long long t__;                                                                                     \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        if (g_kpff_stamps && blockIdx.x < 64 && (threadIdx.x & 63) == 0) g_kpff_stamps[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 16 + (slot)] = t__; \
+    } while (0)
+#else
+#define KPFF_STAMP(slot) do {} while (0)
+#endif
+
 struct KpffBf16Args {
     const bf16_t* L; const bf16_t* G; const bf16_t* P;
     const bf16_t* wa; const float* ba; const bf16_t* wl; const bf16_t* wg;
@@ -353,18 +370,38 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
         t_f[sb] = f; t_n0[sb] = row0 * a.w + col0; t_ntok[sb] = t_nrows[sb] * t_w[sb];
     }
     // token tok of sub-tile sb (row-major inside the tile) -> token of the frame
-    auto gtok = [&](int sb, int tok) { const int ty = tok / t_w[sb]; return t_n0[sb] + ty * a.w + (tok - ty * t_w[sb]); };
+    // (Integer divisions by run-time divisors cost ~30 vector instructions each and sat in every staged piece and every epilogue
+    // row: a tile as wide as the grid -- the usual case -- needs none, and the others use an exact float reciprocal, valid for the
+    // small non-negative indices here: floor(n / d) == (int)((n + 0.5f) * (1.0f / d)) for n < 2^20.)
+    const bool full_w = a.cols_per_tile >= a.w;               // uniform: the tile's tokens are consecutive tokens of the frame
+    float inv_tw[NT];
+#pragma unroll
+    for (int sb = 0; sb < NT; ++sb) inv_tw[sb] = 1.0f / (float)max(t_w[sb], 1);
+    auto gtok = [&](int sb, int tok) {
+#ifdef KPFF_ABL_INTDIV                                          // ablation: the integer divisions of rounds 1-2
+        { const int ty = tok / t_w[sb]; return t_n0[sb] + ty * a.w + (tok - ty * t_w[sb]); }
+#endif
+        if (full_w) return t_n0[sb] + tok;
+        const int ty = (int)(((float)tok + 0.5f) * inv_tw[sb]);
+        return t_n0[sb] + ty * a.w + (tok - ty * t_w[sb]);
+    };
 
+    KPFF_STAMP(0);
     // ---- stage the [P ; L] rows as they are (8 channels = 16 bytes per thread, 4 loads in flight) -----------
     {
         const int q8 = (Cp + Ck) / 8, total = TMW * q8;
+        const float inv_q8 = 1.0f / (float)q8;
         for (int base = tid; base < total; base += 4 * NTHR) {
             uint4 x[4];
             int dst[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = base + u * NTHR;
+#ifdef KPFF_ABL_INTDIV
                 const int trow = idx / q8, c = (idx - trow * q8) * 8;
+#else
+                const int trow = (int)(((float)idx + 0.5f) * inv_q8), c = (idx - trow * q8) * 8;
+#endif
                 const int sb = trow >> 6, tok = trow & 63;
                 dst[u] = idx < total ? trow * ld + c : -1;
                 x[u] = make_uint4(0u, 0u, 0u, 0u);
@@ -379,50 +416,89 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
                 if (dst[u] >= 0) *reinterpret_cast<uint4*>(s_xb + dst[u]) = x[u];
         }
     }
+    KPFF_STAMP(1);
 #ifndef KPFF_SKIP_POOL
-    // ---- G: pooled (multi-scale) straight from global memory: one thread per (4x4 cell, channel pair), the cell's 16 tokens as 16
-    //      independent 4-byte loads (64 lanes = 256 contiguous bytes of a token row), fp32 math, one bf16 store per token into the
-    //      tile.  (Until the end of round 2 G was staged like P and L and pooled in place in a second pass over LDS, behind one
-    //      more barrier.)
+    // ---- G: pooled (multi-scale) straight from global memory: one thread per (4x4 cell, group of four channels), the cell's 16 tokens
+    //      as 16 independent 8-byte loads, fp32 math (per channel the sums run over the cell's tokens in raster order), one 8-byte store
+    //      per token into the tile.  Both sub-tiles share one index space, so at 7x7 tokens and 256 channels every thread has exactly
+    //      one item.  (Until the end of round 2 G was staged like P and L and pooled in place in a second pass over LDS; until round 3
+    //      a thread took a channel PAIR -- twice the vector-memory instructions for the same bytes: 11.4 k of the kernel's 70 k cycles.)
+    const int cv4 = Cv / 4;
+    int items[NT], cwv[NT];
+    int itot = 0;
 #pragma unroll
     for (int sb = 0; sb < NT; ++sb) {
-        const int nrows = t_nrows[sb], W = t_w[sb];
-        const int cw = (W + 3) / 4, chh = (nrows + 3) / 4, cv2 = Cv / 2;
-        bf16_t* gx = s_xb + (size_t)sb * 64 * ld + Cp + Ck;
-        const bf16_t* gsrc = a.G + ((size_t)t_f[sb] * N + t_n0[sb]) * Cv;
-        for (int idx = tid; idx < cw * chh * cv2; idx += NTHR) {
-            const int cell = idx / cv2, c = (idx - cell * cv2) * 2;
-            const int cy = cell / cw, y0 = cy * 4, x0 = (cell - cy * cw) * 4;
-            unsigned u[16];
-            bool ok[16];
+        cwv[sb] = (t_w[sb] + 3) / 4;
+        items[sb] = cwv[sb] * ((t_nrows[sb] + 3) / 4) * cv4;
+        itot += items[sb];
+    }
+    struct PoolItem { int sb, c, y0, x0; };
+    auto pool_locate = [&](int it) __attribute__((always_inline)) {
+        int sb = 0, idx = it;
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const int y = y0 + (p >> 2), x = x0 + (p & 3);
-                ok[p] = y < nrows && x < W;
-                u[p] = ok[p] ? *reinterpret_cast<const unsigned*>(gsrc + (size_t)(y * a.w + x) * Cv + c) : 0u;
-            }
-            float s2[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, s4[2] = {0.f, 0.f};
-            float n2[4] = {0.f, 0.f, 0.f, 0.f}, n4 = 0.f;
+        for (int k = 0; k + 1 < NT; ++k)
+            if (idx >= items[k] && sb == k) { idx -= items[k]; sb = k + 1; }
+        const int cell = idx / cv4, cy = cell / cwv[sb];
+        return PoolItem{sb, (idx - cell * cv4) * 4, cy * 4, (cell - cy * cwv[sb]) * 4};
+    };
+    auto pool_issue = [&](const PoolItem& pi, uint2 (&u)[16], bool (&ok)[16]) __attribute__((always_inline)) {
+        const int nrows = t_nrows[pi.sb], W = t_w[pi.sb];
+        const bf16_t* gsrc = a.G + ((size_t)t_f[pi.sb] * N + t_n0[pi.sb]) * Cv;
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const int q = ((p >> 3) << 1) | ((p >> 1) & 1);
-                const float v0 = __uint_as_float(u[p] << 16), v1 = __uint_as_float(u[p] & 0xffff0000u), m = ok[p] ? 1.f : 0.f;
-                s2[q][0] += v0; s2[q][1] += v1; n2[q] += m; s4[0] += v0; s4[1] += v1; n4 += m;
-            }
-            const float i4 = 1.0f / n4;
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const int q = ((p >> 3) << 1) | ((p >> 1) & 1);
-                const float i2 = 1.0f / fmaxf(n2[q], 1.f);
-                const float r0 = (__uint_as_float(u[p] << 16) + s2[q][0] * i2 + s4[0] * i4) * (1.0f / 3.0f);
-                const float r1 = (__uint_as_float(u[p] & 0xffff0000u) + s2[q][1] * i2 + s4[1] * i4) * (1.0f / 3.0f);
-                const int y = y0 + (p >> 2), x = x0 + (p & 3);
-                if (ok[p]) *reinterpret_cast<unsigned*>(gx + (size_t)(y * W + x) * ld + c) = (unsigned)f32_to_bf16(r0) | ((unsigned)f32_to_bf16(r1) << 16);
-            }
+        for (int p = 0; p < 16; ++p) {
+            const int y = pi.y0 + (p >> 2), x = pi.x0 + (p & 3);
+            ok[p] = y < nrows && x < W;
+            u[p] = ok[p] ? *reinterpret_cast<const uint2*>(gsrc + (size_t)(y * a.w + x) * Cv + pi.c) : make_uint2(0u, 0u);
         }
+    };
+    auto pool_finish = [&](const PoolItem& pi, const uint2 (&u)[16], const bool (&ok)[16]) __attribute__((always_inline)) {
+        const int W = t_w[pi.sb];
+        bf16_t* gx = s_xb + (size_t)pi.sb * 64 * ld + Cp + Ck;
+        float s2[4][4], s4[4] = {0.f, 0.f, 0.f, 0.f};
+        float n2[4] = {0.f, 0.f, 0.f, 0.f}, n4 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s2[q][j] = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int q = ((p >> 3) << 1) | ((p >> 1) & 1);
+            const float v[4] = {__uint_as_float(u[p].x << 16), __uint_as_float(u[p].x & 0xffff0000u),
+                                __uint_as_float(u[p].y << 16), __uint_as_float(u[p].y & 0xffff0000u)};
+            const float m = ok[p] ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s2[q][j] += v[j]; s4[j] += v[j]; }
+            n2[q] += m; n4 += m;
+        }
+        const float i4 = 1.0f / n4;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int q = ((p >> 3) << 1) | ((p >> 1) & 1);
+            const float i2 = 1.0f / fmaxf(n2[q], 1.f);
+            const float v[4] = {__uint_as_float(u[p].x << 16), __uint_as_float(u[p].x & 0xffff0000u),
+                                __uint_as_float(u[p].y << 16), __uint_as_float(u[p].y & 0xffff0000u)};
+            float r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = (v[j] + s2[q][j] * i2 + s4[j] * i4) * (1.0f / 3.0f);
+            const int y = pi.y0 + (p >> 2), x = pi.x0 + (p & 3);
+            if (ok[p]) *reinterpret_cast<uint2*>(gx + (size_t)(y * W + x) * ld + pi.c) =
+                make_uint2((unsigned)f32_to_bf16(r[0]) | ((unsigned)f32_to_bf16(r[1]) << 16), (unsigned)f32_to_bf16(r[2]) | ((unsigned)f32_to_bf16(r[3]) << 16));
+        }
+    };
+    // (Measured and withdrawn in round 3: requesting the cell's loads here and doing the arithmetic behind the [P ; L] part of the first
+    // output tile's gate mixes.  vmcnt counts in order, so the first weight fragment of the mixes waits for the sixteen older pooling
+    // loads anyway: 37.6 -> 42.2 us.)
+    for (int it = tid; it < itot; it += NTHR) {
+        uint2 u[16];
+        bool ok[16];
+        const PoolItem pi = pool_locate(it);
+        pool_issue(pi, u, ok);
+        pool_finish(pi, u, ok);
     }
 #endif
+    KPFF_STAMP(2);
     __syncthreads();
+    KPFF_STAMP(3);
     if (a.sv.gms) {                                            // training: keep the pooled feature for the backward
         bf16_t* gms = static_cast<bf16_t*>(a.sv.gms);
 #pragma unroll
@@ -446,12 +522,14 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
         // fragment-order packs: k-step ks of output tile ot lives at ((ot*KS + ks)*64 + lane)*8
         kpff_stream<2, MT, OT>(xb, ld, 0, KSa, a.wa + ((size_t)(ob0 / 16) * KSa * 64 + lane) * 8,
                                a.wa + ((size_t)((Cp + ob0) / 16) * KSa * 64 + lane) * 8, (size_t)KSa * 512, gl, gg);                  // gates
+        KPFF_STAMP(ob0 < 16 * OT * (NTHR / 64) ? 4 : 8);
         kpff_stream<1, MT, OT>(xb, ld, ksP, ksL, a.wl + ((size_t)(ob0 / 16) * ksL * 64 + lane) * 8, nullptr, (size_t)ksL * 512, lp, lp);   // L Wl^T
         kpff_stream<1, MT, OT>(xb, ld, ksP + ksL, Cv / 32, a.wg + ((size_t)(ob0 / 16) * (Cv / 32) * 64 + lane) * 8, nullptr,
                                (size_t)(Cv / 32) * 512, gp, gp);
 #else
         gl[0][0][0] = xb[0]; (void)ksP; (void)ksL; (void)KSa;
 #endif
+        KPFF_STAMP(ob0 < 16 * OT * (NTHR / 64) ? 5 : 9);
 #pragma unroll
         for (int o = 0; o < OT; ++o) {
         const int ob = ob0 + 16 * o;
@@ -494,6 +572,7 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
             }
         }
         }
+        KPFF_STAMP(ob0 < 16 * OT * (NTHR / 64) ? 6 : 10);
     }
 }
 
