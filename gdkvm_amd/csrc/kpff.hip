@@ -347,10 +347,13 @@ __device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, i
 #ifndef KPFF_OT
 #define KPFF_OT 1
 #endif
-template <int NT, int OT>
+// SB = rows a sub-tile occupies in the workgroup's tile: 64, or 56 when both sub-tiles hold at most 56 tokens (two 7x7 frames:
+// 98 tokens in SEVEN 16-row token tiles instead of eight -- an eighth off the MFMA passes, the fragment reads and the epilogues).
+template <int NT, int OT, int SB = KPFF_TM>
 __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_kernel(KpffBf16Args a, int total_tiles)
 {
-    constexpr int NTHR = 256 * NT / OT, MT = 4 * NT, TMW = KPFF_TM * NT;
+    constexpr int NTHR = 256 * NT / OT, TMW = SB * NT, MT = (TMW + 15) / 16;
+    static_assert(SB == KPFF_TM || NT == 2, "packed sub-tiles: two per workgroup");
     extern __shared__ __attribute__((aligned(16))) bf16_t s_xb[];   // [TMW][Cin + PAD16]
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w_id = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
 #else
                 const int trow = (int)(((float)idx + 0.5f) * inv_q8), c = (idx - trow * q8) * 8;
 #endif
-                const int sb = trow >> 6, tok = trow & 63;
+                const int sb = trow >= SB ? 1 : 0, tok = trow - SB * sb;
                 dst[u] = idx < total ? trow * ld + c : -1;
                 x[u] = make_uint4(0u, 0u, 0u, 0u);
                 if (idx < total && tok < t_ntok[sb < NT ? sb : 0]) {
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
     };
     auto pool_finish = [&](const PoolItem& pi, const uint2 (&u)[16], const bool (&ok)[16]) __attribute__((always_inline)) {
         const int W = t_w[pi.sb];
-        bf16_t* gx = s_xb + (size_t)pi.sb * 64 * ld + Cp + Ck;
+        bf16_t* gx = s_xb + (size_t)pi.sb * SB * ld + Cp + Ck;
         float s2[4][4], s4[4] = {0.f, 0.f, 0.f, 0.f};
         float n2[4] = {0.f, 0.f, 0.f, 0.f}, n4 = 0.f;
 #pragma unroll
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
         for (int sb = 0; sb < NT; ++sb)
             for (int idx = tid; idx < t_ntok[sb] * Cv; idx += NTHR) {
                 const int tok = idx / Cv, c = idx - tok * Cv;
-                gms[((size_t)t_f[sb] * N + gtok(sb, tok)) * Cv + c] = s_xb[(size_t)(sb * 64 + tok) * ld + Cp + Ck + c];
+                gms[((size_t)t_f[sb] * N + gtok(sb, tok)) * Cv + c] = s_xb[(size_t)(sb * SB + tok) * ld + Cp + Ck + c];
             }
     }
 
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
         const f32x4 bl4 = *reinterpret_cast<const f32x4*>(a.ba + oc), bg4 = *reinterpret_cast<const f32x4*>(a.ba + Cp + oc);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int trow = 16 * mt + li, sb = trow >> 6, tok = trow & 63;
+            const int trow = 16 * mt + li, sb = (NT > 1 && trow >= SB) ? 1 : 0, tok = trow - SB * sb;
 #ifdef KPFF_SKIP_EPI
             if (tok < t_ntok[sb] && gl[o][mt][0] == 123.f) {
 #else
@@ -1133,11 +1136,19 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
         }
         KpffBf16Args b{static_cast<const bf16_t*>(local), static_cast<const bf16_t*>(global), static_cast<const bf16_t*>(pixel),
                        wab, ba, wab + na, wab + na + nl, static_cast<bf16_t*>(out), Ck, Cv, Cp, h, w, rows, tiles, sv, cols, col_tiles};
-        const size_t lds = pair ? 2 * lds1 : lds1;
-        const void* fn = pair ? reinterpret_cast<const void*>(kpff_bf16_kernel<2, KPFF_OT>) : reinterpret_cast<const void*>(kpff_bf16_kernel<1, 1>);
+        // two sub-tiles of at most 56 tokens each (two 7x7 frames): packed at 56 rows apiece, seven token tiles instead of eight
+#ifdef KPFF_ABL_NOPACK56                                        // ablation: eight token tiles as in rounds 1-2
+        const bool packed56 = false;
+#else
+        const bool packed56 = pair && rows * cols <= 56;
+#endif
+        const size_t lds = packed56 ? (size_t)112 * (Cin + KPFF_PAD16) * sizeof(bf16_t) : (pair ? 2 * lds1 : lds1);
+        const void* fn = packed56 ? reinterpret_cast<const void*>(kpff_bf16_kernel<2, KPFF_OT, 56>)
+                       : pair ? reinterpret_cast<const void*>(kpff_bf16_kernel<2, KPFF_OT>) : reinterpret_cast<const void*>(kpff_bf16_kernel<1, 1>);
         if (lds > 64 * 1024)
-            if (int rc = kpff_lds_optin(fn, pair ? 0 : 1)) return rc;
-        if (pair) hipLaunchKernelGGL((kpff_bf16_kernel<2, KPFF_OT>), dim3((unsigned)((total_tiles + 1) / 2)), dim3(512 / KPFF_OT), lds, st, b, total_tiles);
+            if (int rc = kpff_lds_optin(fn, packed56 ? 7 : (pair ? 0 : 1))) return rc;
+        if (packed56) hipLaunchKernelGGL((kpff_bf16_kernel<2, KPFF_OT, 56>), dim3((unsigned)((total_tiles + 1) / 2)), dim3(512 / KPFF_OT), lds, st, b, total_tiles);
+        else if (pair) hipLaunchKernelGGL((kpff_bf16_kernel<2, KPFF_OT>), dim3((unsigned)((total_tiles + 1) / 2)), dim3(512 / KPFF_OT), lds, st, b, total_tiles);
         else hipLaunchKernelGGL((kpff_bf16_kernel<1, 1>), dim3((unsigned)total_tiles), dim3(256), lds, st, b, total_tiles);
         GDKVM_LAUNCH_CHECK("kpff_bf16_kernel");
         return GDKVM_OK;
