@@ -276,27 +276,48 @@ __device__ __forceinline__ f32x4 mfma_bf16(bf16x8 a, bf16x8 b, f32x4 c)
 #endif
 constexpr int KPFF_WD = KPFF_WD_STEPS;               // ring depth = k-steps per unrolled trip
 
-template <int NS, int MT, int OT>
-__device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, int n, const bf16_t* w0, const bf16_t* w1, size_t ot_stride,
-                                            f32x4 (&acc0)[OT][MT], f32x4 (&acc1)[OT][MT])
-{
-    if (n <= 0) return;
+// The ring of weight register sets of one pass.  A caller may own it and PRIME it (kpff_prime: the pass's first KPFF_WD k-steps
+// requested) long before the pass runs -- at kernel entry, or right behind the previous output tile's pass of the same kind -- so that
+// the pass opens on fragments that have landed instead of on an L2 round trip (round 3 stamps: the two short passes of an output
+// tile took 4.9 k cycles against an MFMA floor of 2.6 k, the long one ~1 k over its floor: one exposed prologue each).
+template <int NS, int OT> struct KRing { bf16x8 b0[KPFF_WD][OT]; bf16x8 b1[KPFF_WD][OT]; };
+
 #ifdef KPFF_ABL_WSAME                                       // ablation: every weight fragment from one L1-resident KiB
 #define KPFF_WOFF(x) ((size_t)0 * (x))
 #else
 #define KPFF_WOFF(x) (x)
 #endif
-    bf16x8 b0[KPFF_WD][OT], b1[KPFF_WD][OT];
+template <int NS, int OT>
+__device__ __forceinline__ void kpff_wload(const bf16_t* w0, const bf16_t* w1, size_t ot_stride, int slot_ks, int n, bf16x8 (&d0)[OT], bf16x8 (&d1)[OT])
+{
+    const size_t off = KPFF_WOFF((size_t)min(slot_ks, n - 1) * 512);
+#pragma unroll
+    for (int o = 0; o < OT; ++o) {
+        d0[o] = *reinterpret_cast<const bf16x8*>(w0 + o * ot_stride + off);
+        if constexpr (NS == 2) d1[o] = *reinterpret_cast<const bf16x8*>(w1 + o * ot_stride + off);
+    }
+}
+template <int NS, int OT>
+__device__ __forceinline__ void kpff_prime(KRing<NS, OT>& r, const bf16_t* w0, const bf16_t* w1, size_t ot_stride, int n)
+{
+#pragma unroll
+    for (int d = 0; d < KPFF_WD; ++d) kpff_wload<NS, OT>(w0, w1, ot_stride, d, n, r.b0[d], r.b1[d]);
+}
+
+template <int NS, int MT, int OT, bool PRIMED = false>
+__device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, int n, const bf16_t* w0, const bf16_t* w1, size_t ot_stride,
+                                            f32x4 (&acc0)[OT][MT], f32x4 (&acc1)[OT][MT], KRing<NS, OT>& ring)
+{
+    if (n <= 0) return;
+    auto& b0 = ring.b0;
+    auto& b1 = ring.b1;
     auto wload = [&](int slot_ks, bf16x8 (&d0)[OT], bf16x8 (&d1)[OT]) __attribute__((always_inline)) {
-        const size_t off = KPFF_WOFF((size_t)min(slot_ks, n - 1) * 512);
-#pragma unroll
-        for (int o = 0; o < OT; ++o) {
-            d0[o] = *reinterpret_cast<const bf16x8*>(w0 + o * ot_stride + off);
-            if constexpr (NS == 2) d1[o] = *reinterpret_cast<const bf16x8*>(w1 + o * ot_stride + off);
-        }
+        kpff_wload<NS, OT>(w0, w1, ot_stride, slot_ks, n, d0, d1);
     };
+    if constexpr (!PRIMED) {
 #pragma unroll
-    for (int d = 0; d < KPFF_WD; ++d) wload(d, b0[d], b1[d]);
+        for (int d = 0; d < KPFF_WD; ++d) wload(d, b0[d], b1[d]);
+    }
     bf16x8 xa[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) xa[mt] = *reinterpret_cast<const bf16x8*>(xb + (size_t)mt * 16 * ld + 32 * ks0);
@@ -338,6 +359,14 @@ __device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, i
     kpff_static_for<0, KPFF_WD - 1>([&](auto jc) {
         if (decltype(jc)::value < rem) body(i + decltype(jc)::value, jc);
     });
+}
+
+template <int NS, int MT, int OT>
+__device__ __forceinline__ void kpff_stream(const bf16_t* xb, int ld, int ks0, int n, const bf16_t* w0, const bf16_t* w1, size_t ot_stride,
+                                            f32x4 (&acc0)[OT][MT], f32x4 (&acc1)[OT][MT])
+{
+    KRing<NS, OT> ring;
+    kpff_stream<NS, MT, OT, false>(xb, ld, ks0, n, w0, w1, ot_stride, acc0, acc1, ring);
 }
 
 // NT = 64-token tiles per workgroup (4*NT waves).  NT = 2 halves the weight traffic per token: at 64 tokens per
@@ -389,6 +418,17 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
         return t_n0[sb] + ty * a.w + (tok - ty * t_w[sb]);
     };
 
+    // The weight ring of the long pass (the gate mixes), primed for this wave's first output tile before anything else: the fragments
+    // travel while the tile is staged and pooled.
+    const int ksP = Cp / 32, ksL = Ck / 32, ksG = Cv / 32, KSa = Cin / 32;
+    constexpr int OB_STEP = 16 * OT * (NTHR / 64);
+    auto wa_g = [&](int ob) { return a.wa + ((size_t)(ob / 16) * KSa * 64 + lane) * 8; };
+    auto wl_g = [&](int ob) { return a.wl + ((size_t)(ob / 16) * ksL * 64 + lane) * 8; };
+    auto wg_g = [&](int ob) { return a.wg + ((size_t)(ob / 16) * ksG * 64 + lane) * 8; };
+    KRing<2, OT> ring_g;
+#ifndef KPFF_SKIP_GEMM
+    if (16 * OT * w_id < Cp) kpff_prime<2, OT>(ring_g, wa_g(16 * OT * w_id), wa_g(Cp + 16 * OT * w_id), (size_t)KSa * 512, KSa);
+#endif
     KPFF_STAMP(0);
     // ---- stage the [P ; L] rows as they are (8 channels = 16 bytes per thread, 4 loads in flight) -----------
     {
@@ -513,8 +553,7 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
     }
 
     // ---- fused channel mixes: wave owns output channels 16*(4*NT*chunk + wave) .. +15 for all TMW tokens ------
-    const int ksP = Cp / 32, ksL = Ck / 32, KSa = Cin / 32;
-    for (int ob0 = 16 * OT * w_id; ob0 < Cp; ob0 += 16 * OT * (NTHR / 64)) {
+    for (int ob0 = 16 * OT * w_id; ob0 < Cp; ob0 += OB_STEP) {
         f32x4 gl[OT][MT], gg[OT][MT], lp[OT][MT], gp[OT][MT];
 #pragma unroll
         for (int o = 0; o < OT; ++o)
@@ -522,13 +561,19 @@ __global__ __launch_bounds__(256 * NT / OT, (NT == 1 ? 2 : 1)) void kpff_bf16_ke
             for (int mt = 0; mt < MT; ++mt) gl[o][mt] = gg[o][mt] = lp[o][mt] = gp[o][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         const bf16_t* xb = s_xb + (size_t)li * ld + 8 * g;             // B fragment: token 16mt+li, k 8g..8g+7
 #ifndef KPFF_SKIP_GEMM
-        // fragment-order packs: k-step ks of output tile ot lives at ((ot*KS + ks)*64 + lane)*8
-        kpff_stream<2, MT, OT>(xb, ld, 0, KSa, a.wa + ((size_t)(ob0 / 16) * KSa * 64 + lane) * 8,
-                               a.wa + ((size_t)((Cp + ob0) / 16) * KSa * 64 + lane) * 8, (size_t)KSa * 512, gl, gg);                  // gates
+        // fragment-order packs: k-step ks of output tile ot lives at ((ot*KS + ks)*64 + lane)*8.  Every pass runs on a ring primed
+        // earlier (kernel entry for the first output tile); behind each pass its ring is primed for the wave's NEXT output tile.
+        const int obn = ob0 + OB_STEP;                             // the wave's next output tile (uniform)
+        // the two short passes' rings are primed in front of the long one (they are consumed right behind it and would otherwise be
+        // 32 more registers held across the epilogue), the long pass's ring for the NEXT output tile right behind it
+        KRing<1, OT> ring_l, ring_p;
+        kpff_prime<1, OT>(ring_l, wl_g(ob0), nullptr, (size_t)ksL * 512, ksL);
+        kpff_prime<1, OT>(ring_p, wg_g(ob0), nullptr, (size_t)ksG * 512, ksG);
+        kpff_stream<2, MT, OT, true>(xb, ld, 0, KSa, wa_g(ob0), wa_g(Cp + ob0), (size_t)KSa * 512, gl, gg, ring_g);                       // gates
+        if (obn < Cp) kpff_prime<2, OT>(ring_g, wa_g(obn), wa_g(Cp + obn), (size_t)KSa * 512, KSa);
         KPFF_STAMP(ob0 < 16 * OT * (NTHR / 64) ? 4 : 8);
-        kpff_stream<1, MT, OT>(xb, ld, ksP, ksL, a.wl + ((size_t)(ob0 / 16) * ksL * 64 + lane) * 8, nullptr, (size_t)ksL * 512, lp, lp);   // L Wl^T
-        kpff_stream<1, MT, OT>(xb, ld, ksP + ksL, Cv / 32, a.wg + ((size_t)(ob0 / 16) * (Cv / 32) * 64 + lane) * 8, nullptr,
-                               (size_t)(Cv / 32) * 512, gp, gp);
+        kpff_stream<1, MT, OT, true>(xb, ld, ksP, ksL, wl_g(ob0), nullptr, (size_t)ksL * 512, lp, lp, ring_l);                             // L Wl^T
+        kpff_stream<1, MT, OT, true>(xb, ld, ksP + ksL, ksG, wg_g(ob0), nullptr, (size_t)ksG * 512, gp, gp, ring_p);
 #else
         gl[0][0][0] = xb[0]; (void)ksP; (void)ksL; (void)KSa;
 #endif
