@@ -558,6 +558,29 @@ __attribute__((amdgpu_waves_per_eu(1, (prepm_compact(NB, IO, FUSE) ? 3 : 2)))) v
     for (int I = 0; I < NB; ++I)
 #pragma unroll
         for (int r = 0; r < 4; ++r) xk[I][r] = s_K[(16 * I + 4 * g + r) * KLD + 16 * w + li];
+    // bf16 I/O (round 3): the P tiles of phase 4 run on the bf16 MFMA too -- Kn^T (this wave's 16 key channels x 64 tokens) and M as
+    // three-term operands, six term products per 32-token k-step: 12 MFMAs of 16 cycles per tile instead of 16 exact-fp32 ones of
+    // 32, and the fp32 M^T tiles (16 KB of LDS, 64 registers) are not needed at all.  Here: the A images of Kn^T -- lane (g, li) holds
+    // tokens 32 ks + 8 g .. + 7 of channel 16 w + li, the other token grouping than xk's -- which are also the B images of Kn.
+    uint4 knT[SPLIT ? 3 : 1][SPLIT ? KS : 1];
+    if constexpr (SPLIT) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f32x4 ki0 = *reinterpret_cast<const f32x4*>(s_kinv + 32 * ks + 8 * g), ki1 = *reinterpret_cast<const f32x4*>(s_kinv + 32 * ks + 8 * g + 4);
+            f32x4 v0, v1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v0[j] = s_K[(32 * ks + 8 * g + j) * KLD + 16 * w + li] * ki0[j];
+                v1[j] = s_K[(32 * ks + 8 * g + 4 + j) * KLD + 16 * w + li] * ki1[j];
+            }
+            uint2 h0, m0, l0, h1, m1, l1;
+            split3x4(v0, h0, m0, l0);
+            split3x4(v1, h1, m1, l1);
+            knT[0][ks] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            knT[1][ks] = make_uint4(m0.x, m0.y, m1.x, m1.y);
+            knT[2][ks] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+    }
 
     if (seq) {
         // ---- phase 1
@@ -688,12 +711,13 @@ __attribute__((amdgpu_waves_per_eu(1, (prepm_compact(NB, IO, FUSE) ? 3 : 2)))) v
     f32x4 btI[NB];
 #pragma unroll
     for (int I = 0; I < NB; ++I) btI[I] = *reinterpret_cast<const f32x4*>(s_beta + 16 * I + 4 * g);
-    if constexpr (COMPACT) __syncthreads();               // every wave is through with R1 (gates, Gram / T blocks) and R2 (K rows): mt / m3 take them over
+    // (COMPACT: m3 below overwrites the K rows in R2 -- every wave took its copies right behind the phase 0 barrier and has passed
+    // the barriers of phases 1 and 2, or the one in front of phase 3, since)
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
         const f32x4 bt4 = btI[I];
         const f32x4 mtI = Z[I] * bt4;
-        s_mt[(w * NB + I) * 64 + lane] = mtI;
+        if constexpr (!SPLIT) s_mt[(w * NB + I) * 64 + lane] = mtI;      // (fp32 I/O: the exact fp32 products of phase 4 read M^T back)
         if constexpr (SPLIT) {             // this lane's 4 tokens 16I+4g+r of row 16w+li are half (g&1) of A lane (2(I&1)+(g>>1), li), ks = I>>1
             __bf16 hh[4], mm[4], ll[4];
 #pragma unroll
@@ -709,11 +733,21 @@ __attribute__((amdgpu_waves_per_eu(1, (prepm_compact(NB, IO, FUSE) ? 3 : 2)))) v
 
     // ---- phase 4: P images and G tiles
     const int nlast = N - 16 * (NB - 1);                  // real tokens in the last block (<= 0: none)
-    f32x4 mt[4][NB];
+    f32x4 mt[SPLIT ? 1 : 4][SPLIT ? 1 : NB];
+    if constexpr (!SPLIT) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int I = 0; I < NB; ++I) mt[m][I] = s_mt[(m * NB + I) * 64 + lane];
+            for (int I = 0; I < NB; ++I) mt[m][I] = s_mt[(m * NB + I) * 64 + lane];
+    }
+    // SPLIT: row tile m of M as three term images, [term][k step] (A images of M = B images of M^T)
+    auto m_terms = [&](int m, uint4 (&d)[3][SPLIT ? KS : 1]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+            for (int ks = 0; ks < (SPLIT ? KS : 1); ++ks)
+                d[sp][ks] = *reinterpret_cast<const uint4*>(&s_m3[sp * 4 * KS * 128 + ((m * KS + ks) * 64 + lane) * 2]);
+    };
     // chunk 0 of a chunked frame starts the composition as [P | G] accumulator tiles; under delta_parallel (every token sees
     // the frame's old state) the chunks combine additively, P = I - sum_c (I - P_c), so all of them are written as tiles
     const bool first_of_many = nchunk > 1 && chunk == 0;
@@ -732,7 +766,13 @@ __attribute__((amdgpu_waves_per_eu(1, (prepm_compact(NB, IO, FUSE) ? 3 : 2)))) v
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        if (!p_identity) {
+        uint4 mterm[3][SPLIT ? KS : 1];
+        if constexpr (SPLIT) {
+            if (!p_identity) {
+                m_terms(m, mterm);
+                if (!p_tiles) acc0 = OpFmt<FMT_SPLIT3>::product(knT, mterm);      // (Kn^T)_w (M^T)_m: rows = key channels, columns = rows of M
+            }
+        } else if (!p_identity) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -749,6 +789,8 @@ __attribute__((amdgpu_waves_per_eu(1, (prepm_compact(NB, IO, FUSE) ? 3 : 2)))) v
         if (p_tiles) {                         // the composition wants chunk 0 as [P | G] accumulator tiles: P tile (m, w),
             f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};          // the same product with the operands swapped
             if (!p_identity) {
+                if constexpr (SPLIT) b0 = OpFmt<FMT_SPLIT3>::product(mterm, knT);
+                else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -756,6 +798,7 @@ __attribute__((amdgpu_waves_per_eu(1, (prepm_compact(NB, IO, FUSE) ? 3 : 2)))) v
                         if (I & 1) b1 = mfma4(mt[m][I][r], KN[I][r], b1);
                         else b0 = mfma4(mt[m][I][r], KN[I][r], b0);
                     }
+                }
             }
             f32x4 o;
 #pragma unroll
@@ -857,9 +900,7 @@ __attribute__((amdgpu_waves_per_eu(1, (prepm_compact(NB, IO, FUSE) ? 3 : 2)))) v
                 for (int sp = 0; sp < 3; ++sp)
                     d[ks][sp] = *reinterpret_cast<const bf16x8*>(&s_m3[sp * 4 * KS * 128 + ((m * KS + ks) * 64 + lane) * 2]);
         };
-        // COMPACT: every wave has consumed its copy of mt (the P tiles above): R1 now stages the V tiles.  (The barrier also keeps the
-        // 96 registers of M's term images from being fetched while the 64 of mt are still live.)
-        if constexpr (COMPACT) __syncthreads();
+        // (COMPACT: R1 stages the V tiles from here on; every wave left its phase 0-3 scratch behind at the barrier that ends phase 3)
         if constexpr (!FUSE) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) am_load(m, am[m]);
