@@ -406,10 +406,14 @@ __host__ __device__ constexpr size_t prepm_lds_bytes(int NB, int IO, bool fuse =
 
 
 
-template <int NB, int IO, int FMT, bool FUSE = false>
-__global__ __launch_bounds__(256, (NB == 4 ? (prepm_compact(NB, IO, FUSE) ? 3 : 2) : 1))
-__attribute__((amdgpu_waves_per_eu(1, (prepm_compact(NB, IO, FUSE) ? 3 : 2)))) void gdr_prepm_kernel(PrepMArgs a)
+// W3: three workgroups per CU (the compact LDS layout allows it; 168 registers) -- chosen by the launch when there are more workgroups
+// than two per CU hold (cfg3: 640 chunk workgroups); with at most two per CU the kernel takes the registers instead (M's term images
+// fetched once for the P and the G tiles).
+template <int NB, int IO, int FMT, bool FUSE = false, bool W3 = false>
+__global__ __launch_bounds__(256, (NB == 4 ? (W3 ? 3 : 2) : 1))
+__attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(PrepMArgs a)
 {
+    static_assert(!W3 || prepm_compact(NB, IO, FUSE), "three workgroups per CU need the compact LDS layout");
     constexpr int NP = 16 * NB, NT = fmt_terms(FMT);
     static_assert(!FUSE || (prepm_split(NB, IO) && FMT == FMT_PAIR16), "the fused chunk walk is built for bf16 I/O on pair16 operands");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -763,13 +767,27 @@ __attribute__((amdgpu_waves_per_eu(1, (prepm_compact(NB, IO, FUSE) ? 3 : 2)))) v
                             : reinterpret_cast<uint2*>(a.ppc) + ((size_t)fh * (nchunk - 1) + chunk - 1) * (4 * 3 * SPLIT_IMG));
     f32x4* x0 = reinterpret_cast<f32x4*>(a.x0) + (size_t)fh * (4 + nsl) * 4 * 64;
     f32x4* ptile = chunk == 0 ? x0 : reinterpret_cast<f32x4*>(pp);      // P tiles of a later chunk take the place of its images
+    // chunk-parallel bf16 path: all four row tiles of M's term images are fetched ONCE, here, for the P tiles and for the G tiles of
+    // phase 4b (which kept them in 96 registers anyway): the four P products are then independent MFMA chains with no LDS round trip
+    // between them (stamps: the P phase took 4.3 k cycles for 0.8 k of MFMA issue with the images re-read per row tile)
+    constexpr bool MALL = SPLIT && !FUSE && !W3;
+    uint4 mall[MALL ? 4 : 1][3][SPLIT ? KS : 1];
+    if constexpr (MALL) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) m_terms(m, mall[m]);
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         uint4 mterm[3][SPLIT ? KS : 1];
         if constexpr (SPLIT) {
             if (!p_identity) {
-                m_terms(m, mterm);
+                if constexpr (MALL) {
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) mterm[sp][ks] = mall[m][sp][ks];
+                } else m_terms(m, mterm);
                 if (!p_tiles) acc0 = OpFmt<FMT_SPLIT3>::product(knT, mterm);      // (Kn^T)_w (M^T)_m: rows = key channels, columns = rows of M
             }
         } else if (!p_identity) {
@@ -901,7 +919,14 @@ __attribute__((amdgpu_waves_per_eu(1, (prepm_compact(NB, IO, FUSE) ? 3 : 2)))) v
                     d[ks][sp] = *reinterpret_cast<const bf16x8*>(&s_m3[sp * 4 * KS * 128 + ((m * KS + ks) * 64 + lane) * 2]);
         };
         // (COMPACT: R1 stages the V tiles from here on; every wave left its phase 0-3 scratch behind at the barrier that ends phase 3)
-        if constexpr (!FUSE) {
+        if constexpr (MALL) {                              // (the copies fetched in front of the P tiles)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int sp = 0; sp < 3; ++sp) am[m][ks][sp] = __builtin_bit_cast(bf16x8, mall[m][sp][ks]);
+        } else if constexpr (!FUSE) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) am_load(m, am[m]);
         }
@@ -1075,7 +1100,7 @@ __attribute__((amdgpu_waves_per_eu(1, (prepm_compact(NB, IO, FUSE) ? 3 : 2)))) v
     }
 }
 
-template <int NB, int IO, int FMT, bool FUSE = false>
+template <int NB, int IO, int FMT, bool FUSE = false, bool W3 = false>
 int launch_prepm_fmt(const PrepMArgs& pa, int FH, int nchunk, hipStream_t st)
 {
     size_t lds = prepm_lds_bytes(NB, IO, FUSE);
@@ -1091,13 +1116,13 @@ int launch_prepm_fmt(const PrepMArgs& pa, int FH, int nchunk, hipStream_t st)
         if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_prepm: hipGetDevice");
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_prepm_kernel<NB, IO, FMT, FUSE>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gdr_prepm_kernel<NB, IO, FMT, FUSE, W3>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_prepm: LDS attribute: %s", hipGetErrorString(e));
             done_mask.fetch_or(bit, std::memory_order_relaxed);
         }
     }
-    hipLaunchKernelGGL((gdr_prepm_kernel<NB, IO, FMT, FUSE>), dim3(FH, FUSE ? 1 : nchunk), dim3(256), lds, st, pa);
+    hipLaunchKernelGGL((gdr_prepm_kernel<NB, IO, FMT, FUSE, W3>), dim3(FH, FUSE ? 1 : nchunk), dim3(256), lds, st, pa);
     GDKVM_LAUNCH_CHECK("gdr_prepm_kernel");
     return GDKVM_OK;
 }
@@ -1106,6 +1131,16 @@ int launch_prepm(const PrepMArgs& pa, int FH, int nchunk, bool wide, bool fuse, 
 {
     if constexpr (prepm_split(NB, IO)) {
         if (fuse && !wide) return launch_prepm_fmt<NB, IO, FMT_PAIR16, true>(pa, FH, nchunk, st);
+        // more workgroups than two per CU hold: the three-per-CU build (fewer registers, M's images re-read per row tile)
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        }
+        bool w3 = (long)FH * nchunk > 2L * cus;
+        if (const char* e = getenv("GDKVM_PREP_W3")) w3 = e[0] == '1';           // "0" / "1": overrides the choice (A/B runs; same results)
+        if (w3)
+            return wide ? launch_prepm_fmt<NB, IO, FMT_SPLIT3, false, true>(pa, FH, nchunk, st) : launch_prepm_fmt<NB, IO, FMT_PAIR16, false, true>(pa, FH, nchunk, st);
     }
     return wide ? launch_prepm_fmt<NB, IO, FMT_SPLIT3>(pa, FH, nchunk, st) : launch_prepm_fmt<NB, IO, FMT_PAIR16>(pa, FH, nchunk, st);
 }

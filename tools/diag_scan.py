@@ -16,7 +16,7 @@ SO = os.path.join(ROOT, "tools", "_abl", "libgdkvm_hip_diag.so")
 
 def build(extra):
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in ("gdr_prep.hip", "gdr_scan.hip", "gdkvm_api.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("gdr_prep.hip", "gdr_scan.hip", "gdr_train.hip", "gdr_scan_bwd.hip", "gdr_readout_train.hip", "gdkvm_api.hip")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DGDKVM_DIAG"] + extra + [
                            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", SO] + srcs)
 
