@@ -17,8 +17,18 @@ extern unsigned long long* g_gdkvm_diag_buf;     // defined in gdr_scan.hip (gdk
         __builtin_amdgcn_sched_barrier(0);                                                    \
         if (a.diag && blockIdx.x == 0 && tid == 0) a.diag[(size_t)t * 8 + (slot)] = t__;      \
     } while (0)
+// a second row of stamps (row T - 1) for points inside a phase
+#define DIAG_STAMP2(slot)                                                                     \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        unsigned long long t__;                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");            \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (a.diag && blockIdx.x == 0 && tid == 0) a.diag[(size_t)(t - 1) * 8 + (slot)] = t__; \
+    } while (0)
 #else
 #define DIAG_STAMP(slot) do {} while (0)
+#define DIAG_STAMP2(slot) do {} while (0)
 #endif
 
 template <int I, int E, class F>

@@ -430,8 +430,18 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     constexpr bool SPLIT = prepm_split(NB, IO);
     constexpr int KS = NB / 2;                            // 32-token k-steps of the bf16 MFMA
     uint2* s_m3 = reinterpret_cast<uint2*>(COMPACT ? s_r2 : s_mt + 4 * NB * 64);   // [3 terms][4 m][KS][64 lanes][2 halves]: A images of M
-    float* s_K = reinterpret_cast<float*>(COMPACT ? s_r2 : s_kni);   // raw K rows [NP][KLD] fp32 until the end of phase 3 overwrites the region
     constexpr int KLD = GDKVM_DK + 4;
+    // the K rows [NP][KLD] as fp32 until the end of phase 3 overwrites the region (COMPACT: at the END of R2)
+    float* s_K = COMPACT ? smem + (prepm_lds_bytes(NB, IO, FUSE) / sizeof(float) - NP * KLD) : reinterpret_cast<float*>(s_kni);
+    // bf16 I/O: the same rows as they came, [NP][KRP bytes] (pitch 16 x odd: a b128 read of 16 rows touches every bank once) -- the Gram
+    // blocks' operand images are read from here by every wave, not fetched by every wave from memory (4 x 8 KB of the 72 KB a workgroup
+    // pulled through its CU's vector L1 at entry, where all eight waves of the CU queue).  Lives until the barrier that ends phase 1:
+    // over T^T and the gap in front of the fp32 rows (COMPACT), or inside the M^T tiles (behind the 2 KB tail of the fp32 rows)
+    constexpr int KRP = 2 * GDKVM_DK + 16;
+    char* s_Kraw = COMPACT ? reinterpret_cast<char*>(s_TmT) : reinterpret_cast<char*>(s_mt) + 2048;
+    static_assert(!COMPACT || (4 * NP + (NB * (NB - 1) / 2 + NB) * 256) * 4 + NP * KRP <= (int)prepm_lds_bytes(NB, IO, false) - NP * KLD * 4,
+                  "COMPACT: the raw key rows end in front of the fp32 ones");
+    static_assert(COMPACT || (NP * KLD * 4 - 4 * NB * 1024 <= 2048 && 2048 + NP * KRP <= 4 * NB * 1024), "the raw key rows fit the M^T tiles");
     static_assert(NP * KLD <= (COMPACT ? 3 * 4 * (NB / 2) : 8 * NB) * 256, "the K staging tile aliases kni + mt (COMPACT: m3)");
     static_assert(4 * NP + (NB * (NB - 1) / 2 + 2 * NB) * 256 <= 4 * NB * 256, "COMPACT: the phase 0-3 scratch fits under mt");
 
@@ -458,10 +468,21 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     f32x4 X[FUSE ? 4 : 1][XJ];
     float xsplit_max = 0.f;                               // FUSE: largest |running map entry| this wave re-split into fp16 pairs
     const int tid_k = tid;
+#if defined(GDKVM_DIAG) && defined(GDKVM_DIAG_TWICE)
+    // diagnostic: the whole body twice over the same frame (trip count opaque: one copy of the code), second pass stamped into row T - 1 --
+    // what the first pass pays for instructions and data met for the first time
+    int npass__ = 2;
+    asm volatile("" : "+s"(npass__));
+    for (int pass__ = 0; pass__ < npass__; ++pass__)
+#endif
     for (int chunk = FUSE ? 0 : (int)blockIdx.y, chunk_end = FUSE ? nchunk : chunk + 1; chunk < chunk_end; ++chunk) {
     // FUSE: the lane ids are re-derived per chunk from an opaque copy -- otherwise every lane-dependent address of the body is
     // hoisted out of the chunk loop as an invariant and held (then spilled) across it: ~100 registers the running map needs
     int tid_o = tid_k;
+#if defined(GDKVM_DIAG) && defined(GDKVM_DIAG_TWICE)
+    asm volatile("" : "+v"(tid_o));
+    __syncthreads();
+#endif
     if constexpr (FUSE) asm volatile("" : "+v"(tid_o));
     const int tid = tid_o, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int tok0 = chunk * NP;
@@ -469,9 +490,22 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     const int N = min(NP, Ntot - tok0), Hh = a.Hh, Dv = a.Dv, nsl = Dv / 16;
     const bool seq = a.rule == GDKVM_RULE_DELTA_SEQUENTIAL;
     const bool p_identity = a.rule == GDKVM_RULE_GATED_LINEAR;
+#if defined(GDKVM_DIAG) && defined(GDKVM_DIAG_TWICE)
+    const int t = a.T - pass__;
+#else
     const int t = a.T;                                    // diagnostic builds: stamps go to row T of the buffer
+#endif
     (void)t;
     DIAG_STAMP(0);
+#if defined(GDKVM_DIAG) && defined(GDKVM_DIAG_SPAN)
+    // diagnostic: every workgroup's entry and exit time (a chip-wide counter) behind the stamp rows -- when the workgroups of one launch
+    // start, how long each lives, what the launch adds around them
+    if (a.diag && tid == 0) {
+        unsigned long long t__;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");
+        a.diag[(size_t)(a.T + 1) * 8 + 2 * (blockIdx.x + gridDim.x * blockIdx.y)] = t__;
+    }
+#endif
 
     // this wave's first V tile, raw, in the accumulator layout: x[I][r] = V[token 16I+4g+r][16cV+li]
     float xk[NB][4], xv[SPLIT ? 1 : 2][SPLIT ? 1 : NB][4];
@@ -487,6 +521,11 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     // a wave-private LDS tile and read back TRANSPOSED (ds_read_b64_tr_b16: four rows x 16 columns per 16-lane group, column-
     // major) as the B operand -- 2 vector loads + 2 LDS writes + 4 LDS reads per tile instead of 16 two-byte gathers.
     uint4 vA0, vA1, vB0, vB1;                              // (scalars, not an array: an array of these ends up in scratch)
+    // the register-rich build fetches the wave's first FOUR V tiles (Dv <= 256: all of them) at kernel entry, behind the key rows: with
+    // one tile in flight ahead of the MFMAs, each of the wave's tiles exposed most of a memory round trip (stamps: 6.4 k cycles of G
+    // phase for 1.5 k of MFMA issue)
+    constexpr bool VPRE = SPLIT && !FUSE && !W3;
+    uint4 vC0, vC1, vD0, vD1;
     // (a uniform base and two 32-bit lane offsets: as 64-bit lane addresses they cost four registers across the G loop, which the
     // three-workgroups-per-CU build of this kernel does not have)
     const bf16_t* vrow = static_cast<const bf16_t*>(a.v) + (bt * Hh + h) * Dv;
@@ -503,14 +542,7 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     // 16 rows x 16 bytes per k-step, the A image of K_X and the B image of K_X^T at once, and products of bf16 are exact in fp32 --
     // 2 MFMAs of 16 cycles per block instead of 16 exact-fp32 ones of 32 fed from the LDS staging tile.  Rows past N are clamped
     // duplicates, not zeros: every Gram entry that involves one is multiplied by its kinv = 0 / beta = 0 below.
-    bf16x8 kimg[IO == GDKVM_BF16 ? NB : 1][2];
-    if constexpr (IO == GDKVM_BF16) {
-#pragma unroll
-        for (int X = 0; X < NB; ++X)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                kimg[X][ks] = *reinterpret_cast<const bf16x8*>(static_cast<const bf16_t*>(a.k) + ((bt + min(16 * X + li, N - 1)) * Hh + h) * GDKVM_DK + 32 * ks + 8 * g);
-    }
+    bf16x8 kimg[IO == GDKVM_BF16 ? NB : 1][2];            // (read from the raw rows in LDS behind the phase 0 barrier)
 
     // ---- phase 0 (a5 prologue): ONE pass over the k and q rows by all 256 threads (4 threads per token, 16 channels each):
     //      K staged in LDS as fp32 for the Gram blocks and the Kn tiles, inverse norms by a 4-lane reduction, gates
@@ -519,17 +551,54 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
         const int n = rep * 64 + (tid >> 2), qd = tid & 3;
         float sk = 0.f, sq = 0.f;
         const bool given = a.norms != nullptr;            // (uniform) the norms came with the projections: q is not read here at all
+        // every load of the phase is requested before the first is consumed (no branch in between: a conditional load starts its round
+        // trip only when the ones in front of it are back): gate, given norms, key (and query) rows, rows past N clamped and zeroed
+        const size_t rown = (bt + min(n, N - 1)) * Hh + h;
+        float bta_raw = a.beta[rown];
+        float2 nn = {1.f, 1.f};
+        if (given) nn = *reinterpret_cast<const float2*>(a.norms + rown * 2);
+        f32x4 xs[4], ys[4];
+        uint4 kraw0, kraw1;
+        if constexpr (IO == GDKVM_BF16) {
+            const uint4* kp = reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.k) + rown * GDKVM_DK + 16 * qd);
+            kraw0 = kp[0]; kraw1 = kp[1];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = {0.f, 0.f, 0.f, 0.f};
-            if (n < N) {
-                x = load4<IO>(a.k, ((bt + n) * Hh + h) * GDKVM_DK + 16 * qd + 4 * j);
-                if (!given) y = load4<IO>(a.q, ((bt + n) * Hh + h) * GDKVM_DK + 16 * qd + 4 * j);
+            if constexpr (IO != GDKVM_BF16) xs[j] = load4<IO>(a.k, rown * GDKVM_DK + 16 * qd + 4 * j);
+            ys[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (!given) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ys[j] = load4<IO>(a.q, rown * GDKVM_DK + 16 * qd + 4 * j);
+        }
+        if constexpr (VPRE) {
+            if (rep == 0) {
+                load_vraw(w, vA0, vA1);
+                load_vraw(w + 4, vB0, vB1);
+                load_vraw(w + 8, vC0, vC1);
+                load_vraw(w + 12, vD0, vD1);
             }
+        }
+        DIAG_STAMP2(0);                                    // every load of the phase requested
+        if constexpr (IO == GDKVM_BF16) {                  // (rows past N: the clamped duplicates, as fetched -- finite, and gated out below)
+            *reinterpret_cast<uint4*>(s_Kraw + n * KRP + 32 * qd) = kraw0;
+            *reinterpret_cast<uint4*>(s_Kraw + n * KRP + 32 * qd + 16) = kraw1;
+            const unsigned rw[8] = {kraw0.x, kraw0.y, kraw0.z, kraw0.w, kraw1.x, kraw1.y, kraw1.z, kraw1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                xs[j] = f32x4{__uint_as_float(rw[2 * j] << 16), __uint_as_float(rw[2 * j] & 0xffff0000u),
+                              __uint_as_float(rw[2 * j + 1] << 16), __uint_as_float(rw[2 * j + 1] & 0xffff0000u)};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 x = xs[j], y = ys[j];
+            if (n >= N) { x = f32x4{0.f, 0.f, 0.f, 0.f}; y = x; }
             *reinterpret_cast<f32x4*>(s_K + n * KLD + 16 * qd + 4 * j) = x;
             sk += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
             sq += y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
         }
+        DIAG_STAMP2(1);                                    // key rows arrived, converted, staged
         if (!given) {
             sk += __shfl_xor(sk, 1); sq += __shfl_xor(sq, 1);
             sk += __shfl_xor(sk, 2); sq += __shfl_xor(sq, 2);
@@ -539,13 +608,12 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
             if (n < N) {
                 kinv = qinv = 1.f;
                 if (given) {
-                    const float2 nn = *reinterpret_cast<const float2*>(a.norms + ((bt + n) * Hh + h) * 2);
                     kinv = nn.x; qinv = nn.y;
                 } else if (a.flags & GDKVM_FLAG_NORMALIZE_QK) {
                     kinv = 1.0f / sqrtf(sk + GDKVM_EPS_NORM);
                     qinv = 1.0f / sqrtf(sq + GDKVM_EPS_NORM);
                 }
-                bta = a.beta[(bt + n) * Hh + h];
+                bta = bta_raw;
                 if (a.flags & GDKVM_FLAG_GATE_LOGITS) bta = 1.0f / (1.0f + expf(-bta));
             }
             s_kinv[n] = kinv;
@@ -554,9 +622,18 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
             a.qinv[(size_t)fh * a.np_total + tok0 + n] = qinv;
         }
     }
+    DIAG_STAMP2(2);                                        // norms and gates done
     __syncthreads();
     DIAG_STAMP(1);
-    if constexpr (SPLIT) load_vraw(w, vA0, vA1);          // first V tile: in flight behind phases 1-3
+    if constexpr (IO == GDKVM_BF16) {
+#pragma unroll
+        for (int X = 0; X < NB; ++X)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                kimg[X][ks] = *reinterpret_cast<const bf16x8*>(s_Kraw + (16 * X + li) * KRP + 64 * ks + 16 * g);
+    }
+    if constexpr (VPRE) {}                                 // (fetched at entry)
+    else if constexpr (SPLIT) load_vraw(w, vA0, vA1);     // first V tile: in flight behind phases 1-3
     else load_v(w, xv[0]);
 #pragma unroll
     for (int I = 0; I < NB; ++I)
@@ -586,7 +663,82 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
         }
     }
 
-    if (seq) {
+    DIAG_STAMP2(3);                                        // Kn^T images built
+    constexpr bool WAVE_BLOCKS = IO == GDKVM_BF16 && NB == 4;
+    f32x4* s_T = WAVE_BLOCKS ? s_Ld : s_TmT;              // where phase 3 finds the T^T images
+    if (seq && WAVE_BLOCKS) {
+        // ---- phases 1 + 2, bf16 I/O: wave w takes diagonal block w -- its Gram block L_ww, then T_ww = (I + L_ww)^-1 right away, in the
+        //      same wave (no barrier between the two) -- and one or two of the six blocks below the diagonal, which fill the gaps of the
+        //      substitution's dependent chain.  Every block index is a compile-time constant of its wave's branch (the run-time loop
+        //      over blocks picked the operand images through sixteen predicated branches per block and took 2.7 k cycles for ten blocks
+        //      of two MFMAs; the substitution ran on sixteen lanes per block of wave 0 alone, the other waves waiting: 2.0 k).
+        //      Substitution on all 64 lanes: lane (jg, q, c) = (lane >> 4, (lane >> 2) & 3, lane & 3) works on column j = 4 jg + c of
+        //      T and holds its rows 4q .. 4q+3; row i is  delta_ij - sum_k L[i][k] T[k][j], each lane summing its own four k and the
+        //      four q-lanes of a column combined by two row rotations (DPP).
+        if constexpr (WAVE_BLOCKS) {
+        auto gram = [&](auto Ac, auto Bc) __attribute__((always_inline)) {
+            constexpr int A = decltype(Ac)::value, B = decltype(Bc)::value;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kimg[A][ks], kimg[B][ks], acc, 0, 0, 0);
+            return acc;
+        };
+        auto below = [&](auto Ic, auto Jc) __attribute__((always_inline)) {   // lane (g,li) reg r = -L_IJ[4g+r][li], I > J
+            constexpr int I = decltype(Ic)::value, J = decltype(Jc)::value;
+            f32x4 acc = gram(Ic, Jc);
+            const f32x4 kiI = *reinterpret_cast<const f32x4*>(s_kinv + 16 * I + 4 * g);
+            const f32x4 btI = *reinterpret_cast<const f32x4*>(s_beta + 16 * I + 4 * g);
+            const float colscale = s_kinv[16 * J + li];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] *= -(kiI[r] * btI[r] * colscale);
+            s_negB[pair_slot(I, J) * 64 + lane] = acc;
+        };
+        static_for<0, 4>([&](auto wc) {
+            constexpr int I = decltype(wc)::value;
+            if (w != I) return;
+            // L_II, row-major in this wave's 1 KB of Ld: lane (g,li) holds row li, columns 4g .. 4g+3 (zero on and above the diagonal)
+            f32x4 acc = gram(wc, wc);
+            {
+                const float rowscale = s_kinv[16 * I + li] * s_beta[16 * I + li];
+                const f32x4 kinvJ = *reinterpret_cast<const f32x4*>(s_kinv + 16 * I + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = (4 * g + r >= li) ? 0.f : acc[r] * rowscale * kinvJ[r];
+            }
+            s_Ld[I * 64 + li * 4 + g] = acc;
+            if constexpr (I == 0) { below(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); below(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}); }
+            if constexpr (I == 1) { below(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}); below(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{}); }
+            if constexpr (I == 2) below(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
+            if constexpr (I == 3) below(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+            const int q = (lane >> 2) & 3, j = 4 * (lane >> 4) + (lane & 3);
+            // (rows of L fetched LG at a time: all fifteen at once in the register-rich build, four where registers are short)
+            constexpr int LG = (W3 || FUSE) ? 4 : 15;
+            f32x4 tq = {0.f, 0.f, 0.f, 0.f};                                          // T[4q + r][j]
+            if (q == 0) tq[0] = (j == 0) ? 1.f : 0.f;
+#pragma unroll
+            for (int i0 = 1; i0 < 16; i0 += LG) {
+                f32x4 Lr[LG];
+#pragma unroll
+                for (int i = i0; i < i0 + LG && i < 16; ++i) Lr[i - i0] = s_Ld[I * 64 + i * 4 + q];   // L[i][4q .. 4q+3]  (written above by this wave's own lanes)
+#pragma unroll
+                for (int i = i0; i < i0 + LG && i < 16; ++i) {
+                    float sm = Lr[i - i0][0] * tq[0];
+                    sm = fmaf(Lr[i - i0][1], tq[1], sm);
+                    sm = fmaf(Lr[i - i0][2], tq[2], sm);
+                    sm = fmaf(Lr[i - i0][3], tq[3], sm);
+                    sm += __int_as_float(dpp_i32<0x124>(__float_as_int(sm)));
+                    sm += __int_as_float(dpp_i32<0x128>(__float_as_int(sm)));
+                    const float val = (i > j) ? -sm : ((i == j) ? 1.f : 0.f);
+                    if (q == (i >> 2)) tq[i & 3] = val;
+                }
+            }
+            // lane (q, j) reg r = T[4q + r][j]: the A image of T^T -- over this wave's own L block (every lane has its rows in registers),
+            // NOT in the T^T region: the raw key rows live there until the barrier below, and another wave may still be fetching its images
+            s_T[I * 64 + q * 16 + j] = tq;
+        });
+        }
+        DIAG_STAMP(2);
+        __syncthreads();
+    } else if (seq) {
         // ---- phase 1
         for (int p = w; p < NB * (NB + 1) / 2; p += 4) {
             int I = 0;
@@ -702,7 +854,7 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc = mfma4(nb[r], Z[J][r], acc);
             });
-            const f32x4 t4 = s_TmT[I * 64 + lane];
+            const f32x4 t4 = s_T[I * 64 + lane];
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) z = mfma4(t4[r], acc[r], z);
@@ -971,14 +1123,14 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
         };
         bf16x8 xb[KS];
         if constexpr (!FUSE) {
-            for (int cV = w; cV < nsl; cV += 8) {
-                load_vraw(cV + 4, vB0, vB1);
-                stage(0, vA0, vA1);
+            auto g_pair = [&](int cV, uint4& a0, uint4& a1, uint4& b0, uint4& b1, int nextA, int nextB) __attribute__((always_inline)) {
+                if (nextB >= 0) load_vraw(nextB, b0, b1);     // (one-ahead scheme: tile B is requested here, tile A of the next trip below)
+                stage(0, a0, a1);
                 read_b(0, xb);
                 float gmA = 0.f, gmB = 0.f;
                 g_tiles3(cV, xb, [&](int m, const f32x4& t) { if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = t * gscale; gmA = fmaxf(gmA, absmax4(t)); });
-                load_vraw(cV + 8, vA0, vA1);
-                stage(1, vB0, vB1);
+                if (nextA >= 0) load_vraw(nextA, a0, a1);
+                stage(1, b0, b1);
                 read_b(1, xb);
                 g_tiles3(cV + 4, xb, [&](int m, const f32x4& t) { if (cV + 4 < nsl) gg[((size_t)(cV + 4) * 4 + m) * 64 + lane] = t * gscale; gmB = fmaxf(gmB, absmax4(t)); });
                 if (final_g) {
@@ -990,6 +1142,19 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
                         if (cV + 4 < nsl) *reinterpret_cast<f32x4*>(a.gmax + gi + 16) = f32x4{gmB, 0.f, 0.f, 0.f};
                     }
                 }
+            };
+            if constexpr (VPRE) {
+                // tiles w, w+4 (A, B) and w+8, w+12 (C, D) are here or on their way; a wider V goes on in the same four registers pairs,
+                // each refilled as soon as its tile is staged
+                for (int cV = w; cV < nsl; cV += 16) {
+                    const bool more = cV + 16 < nsl;       // (uniform)
+                    g_pair(cV, vA0, vA1, vB0, vB1, -1, -1);
+                    if (more) { load_vraw(cV + 16, vA0, vA1); load_vraw(cV + 20, vB0, vB1); }
+                    if (cV + 8 < nsl) g_pair(cV + 8, vC0, vC1, vD0, vD1, -1, -1);
+                    if (more) { load_vraw(cV + 24, vC0, vC1); load_vraw(cV + 28, vD0, vD1); }
+                }
+            } else {
+                for (int cV = w; cV < nsl; cV += 8) g_pair(cV, vA0, vA1, vB0, vB1, cV + 8, cV + 4);
             }
         } else {
             // column tile cV = w + 4 (j - 1) of G is X[.][j], j = 1 .. 4 (Dv <= 256): compile-time indices, run-time bounds.
@@ -1061,6 +1226,14 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
         }
     }
     DIAG_STAMP(6);
+#if defined(GDKVM_DIAG) && defined(GDKVM_DIAG_SPAN)
+    __syncthreads();
+    if (a.diag && tid == 0) {
+        unsigned long long t__;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");
+        a.diag[(size_t)(a.T + 1) * 8 + 2 * (blockIdx.x + gridDim.x * blockIdx.y) + 1] = t__;
+    }
+#endif
     if constexpr (FUSE) __syncthreads();                  // the next chunk's staging tile overwrites what this one's phase 4 read
     }   // chunks
     if constexpr (FUSE) {
