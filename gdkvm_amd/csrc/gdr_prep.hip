@@ -581,22 +581,30 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
             }
         }
         DIAG_STAMP2(0);                                    // every load of the phase requested
-        if constexpr (IO == GDKVM_BF16) {                  // (rows past N: the clamped duplicates, as fetched -- finite, and gated out below)
+        if constexpr (IO == GDKVM_BF16) {
+            // the raw rows are all the later phases read (rows past N: the clamped duplicates, as fetched -- finite, and gated out by
+            // kinv = beta = 0); widened to fp32 only for the norms, and only when they did not come with the projections
             *reinterpret_cast<uint4*>(s_Kraw + n * KRP + 32 * qd) = kraw0;
             *reinterpret_cast<uint4*>(s_Kraw + n * KRP + 32 * qd + 16) = kraw1;
-            const unsigned rw[8] = {kraw0.x, kraw0.y, kraw0.z, kraw0.w, kraw1.x, kraw1.y, kraw1.z, kraw1.w};
+            if (!given) {
+                const unsigned rw[8] = {kraw0.x, kraw0.y, kraw0.z, kraw0.w, kraw1.x, kraw1.y, kraw1.z, kraw1.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                xs[j] = f32x4{__uint_as_float(rw[2 * j] << 16), __uint_as_float(rw[2 * j] & 0xffff0000u),
-                              __uint_as_float(rw[2 * j + 1] << 16), __uint_as_float(rw[2 * j + 1] & 0xffff0000u)};
-        }
+                for (int j = 0; j < 8; ++j) {
+                    const float lo = __uint_as_float(rw[j] << 16), hi = __uint_as_float(rw[j] & 0xffff0000u);
+                    sk += lo * lo + hi * hi;
+                }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 x = xs[j], y = ys[j];
-            if (n >= N) { x = f32x4{0.f, 0.f, 0.f, 0.f}; y = x; }
-            *reinterpret_cast<f32x4*>(s_K + n * KLD + 16 * qd + 4 * j) = x;
-            sk += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
-            sq += y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+                for (int j = 0; j < 4; ++j) sq += ys[j][0] * ys[j][0] + ys[j][1] * ys[j][1] + ys[j][2] * ys[j][2] + ys[j][3] * ys[j][3];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 x = xs[j], y = ys[j];
+                if (n >= N) { x = f32x4{0.f, 0.f, 0.f, 0.f}; y = x; }
+                *reinterpret_cast<f32x4*>(s_K + n * KLD + 16 * qd + 4 * j) = x;
+                sk += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+                sq += y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
+            }
         }
         DIAG_STAMP2(1);                                    // key rows arrived, converted, staged
         if (!given) {
@@ -635,10 +643,37 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     if constexpr (VPRE) {}                                 // (fetched at entry)
     else if constexpr (SPLIT) load_vraw(w, vA0, vA1);     // first V tile: in flight behind phases 1-3
     else load_v(w, xv[0]);
+    // bf16 I/O: this wave's 16 key channels of every token, TRANSPOSED out of the raw rows (ds_read_b64_tr_b16: a 16-lane group
+    // addresses four rows x 16 columns and lane i receives column i of the four rows): four tokens of channel 16w + li per read --
+    // the Kn tiles' grouping (tokens 16I + 4g + r) in four reads, the Kn^T images' (tokens 32ks + 8g + j) in four more, instead of
+    // thirty-two 4-byte reads of an fp32 copy of the rows (which bf16 I/O no longer writes)
+    uint2 ktr[IO == GDKVM_BF16 ? 8 : 1];
+    if constexpr (IO == GDKVM_BF16) {
+        const unsigned a0 = (unsigned)(uintptr_t)(s_Kraw + (4 * g + (li >> 2)) * KRP + (16 * w + 4 * (li & 3)) * 2);      // tokens 4g + q
+        const unsigned a1 = (unsigned)(uintptr_t)(s_Kraw + (8 * g + (li >> 2)) * KRP + (16 * w + 4 * (li & 3)) * 2);      // tokens 8g + q
+        static_assert(NB != 4 || (48 * KRP < 65536 && 36 * KRP < 65536), "offsets fit the instruction's 16 bits");
+        asm volatile("ds_read_b64_tr_b16 %0, %8\n\t"
+                     "ds_read_b64_tr_b16 %1, %8 offset:%c10\n\t"
+                     "ds_read_b64_tr_b16 %2, %8 offset:%c11\n\t"
+                     "ds_read_b64_tr_b16 %3, %8 offset:%c12\n\t"
+                     "ds_read_b64_tr_b16 %4, %9\n\t"
+                     "ds_read_b64_tr_b16 %5, %9 offset:%c13\n\t"
+                     "ds_read_b64_tr_b16 %6, %9 offset:%c14\n\t"
+                     "ds_read_b64_tr_b16 %7, %9 offset:%c15\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(ktr[0]), "=&v"(ktr[1]), "=&v"(ktr[2]), "=&v"(ktr[3]), "=&v"(ktr[4]), "=&v"(ktr[5]), "=&v"(ktr[6]), "=&v"(ktr[7])
+                     : "v"(a0), "v"(a1), "n"(16 * KRP), "n"(32 * KRP), "n"(48 * KRP), "n"(4 * KRP), "n"(32 * KRP), "n"(36 * KRP) : "memory");
 #pragma unroll
-    for (int I = 0; I < NB; ++I)
+        for (int I = 0; I < NB; ++I) {
+            xk[I][0] = __uint_as_float(ktr[I].x << 16); xk[I][1] = __uint_as_float(ktr[I].x & 0xffff0000u);
+            xk[I][2] = __uint_as_float(ktr[I].y << 16); xk[I][3] = __uint_as_float(ktr[I].y & 0xffff0000u);
+        }
+    } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) xk[I][r] = s_K[(16 * I + 4 * g + r) * KLD + 16 * w + li];
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xk[I][r] = s_K[(16 * I + 4 * g + r) * KLD + 16 * w + li];
+    }
     // bf16 I/O (round 3): the P tiles of phase 4 run on the bf16 MFMA too -- Kn^T (this wave's 16 key channels x 64 tokens) and M as
     // three-term operands, six term products per 32-token k-step: 12 MFMAs of 16 cycles per tile instead of 16 exact-fp32 ones of
     // 32, and the fp32 M^T tiles (16 KB of LDS, 64 registers) are not needed at all.  Here: the A images of Kn^T -- lane (g, li) holds
@@ -648,12 +683,11 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const f32x4 ki0 = *reinterpret_cast<const f32x4*>(s_kinv + 32 * ks + 8 * g), ki1 = *reinterpret_cast<const f32x4*>(s_kinv + 32 * ks + 8 * g + 4);
-            f32x4 v0, v1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v0[j] = s_K[(32 * ks + 8 * g + j) * KLD + 16 * w + li] * ki0[j];
-                v1[j] = s_K[(32 * ks + 8 * g + 4 + j) * KLD + 16 * w + li] * ki1[j];
-            }
+            // (ktr[4 + 2 ks], ktr[5 + 2 ks]: tokens 32 ks + 8 g + 0..3 and + 4..7 of channel 16 w + li)
+            const uint2 t0 = ktr[IO == GDKVM_BF16 ? 4 + 2 * ks : 0], t1 = ktr[IO == GDKVM_BF16 ? 5 + 2 * ks : 0];
+            f32x4 v0 = {__uint_as_float(t0.x << 16), __uint_as_float(t0.x & 0xffff0000u), __uint_as_float(t0.y << 16), __uint_as_float(t0.y & 0xffff0000u)};
+            f32x4 v1 = {__uint_as_float(t1.x << 16), __uint_as_float(t1.x & 0xffff0000u), __uint_as_float(t1.y << 16), __uint_as_float(t1.y & 0xffff0000u)};
+            v0 *= ki0; v1 *= ki1;
             uint2 h0, m0, l0, h1, m1, l1;
             split3x4(v0, h0, m0, l0);
             split3x4(v1, h1, m1, l1);
@@ -845,6 +879,9 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
         for (int r = 0; r < 4; ++r) KN[I][r] = xk[I][r] * ki4[r];
     }
     if (seq) {
+        // k-step r of a product with token block J covers its tokens 4g + r: in the LAST block only the steps r < N - 16 (NB - 1) meet a
+        // real token (rows of padding tokens are exactly zero in Kn, hence in Z) -- 49 tokens: one step of four, 12 of the 40 MFMAs less
+        const int rl = min(max(N - 16 * (NB - 1), 0), 4);
         static_for<0, NB>([&](auto ic) {
             constexpr int I = NB - 1 - decltype(ic)::value;
             f32x4 acc = KN[I];
@@ -852,12 +889,14 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
                 constexpr int J = decltype(jc)::value;
                 const f32x4 nb = s_negB[pair_slot(J, I) * 64 + lane];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc = mfma4(nb[r], Z[J][r], acc);
+                for (int r = 0; r < 4; ++r)
+                    if (J < NB - 1 || r < rl) acc = mfma4(nb[r], Z[J][r], acc);
             });
             const f32x4 t4 = s_T[I * 64 + lane];
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) z = mfma4(t4[r], acc[r], z);
+            for (int r = 0; r < 4; ++r)
+                if (I < NB - 1 || r < rl) z = mfma4(t4[r], acc[r], z);
             Z[I] = z;
         });
     } else {
