@@ -15,7 +15,7 @@ extern unsigned long long* g_gdkvm_diag_buf;     // defined in gdr_scan.hip (gdk
         unsigned long long t__;                                                               \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");            \
         __builtin_amdgcn_sched_barrier(0);                                                    \
-        if (a.diag && blockIdx.x == 0 && tid == 0) a.diag[(size_t)t * 8 + (slot)] = t__;      \
+        if (a.diag && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid == 0) a.diag[(size_t)t * 8 + (slot)] = t__;      \
     } while (0)
 // a second row of stamps (row T - 1) for points inside a phase
 #define DIAG_STAMP2(slot)                                                                     \
@@ -24,7 +24,7 @@ extern unsigned long long* g_gdkvm_diag_buf;     // defined in gdr_scan.hip (gdk
         unsigned long long t__;                                                               \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");            \
         __builtin_amdgcn_sched_barrier(0);                                                    \
-        if (a.diag && blockIdx.x == 0 && tid == 0) a.diag[(size_t)(t - 1) * 8 + (slot)] = t__; \
+        if (a.diag && (blockIdx.x | blockIdx.y | blockIdx.z) == 0 && tid == 0) a.diag[(size_t)(t - 1) * 8 + (slot)] = t__; \
     } while (0)
 #else
 #define DIAG_STAMP(slot) do {} while (0)
@@ -234,6 +234,12 @@ static __device__ __forceinline__ float wave_sum(float x)
 static __device__ __forceinline__ float absmax4(const f32x4& t)
 {
     return fmaxf(fmaxf(fabsf(t[0]), fabsf(t[1])), fmaxf(fabsf(t[2]), fabsf(t[3])));
+}
+// m = max(m, |t0|, .., |t3|) in two instructions (as fmaxf, a NaN in t is ignored; written out because the compiler quiets every
+// MFMA result with a max against itself before an fmaxf: five instructions per tile in a loop whose MFMAs leave few issue slots)
+static __device__ __forceinline__ void absmax4_into(float& m, const f32x4& t)
+{
+    asm("v_max3_f32 %0, |%1|, |%2|, %0\n\tv_max3_f32 %0, |%3|, |%4|, %0" : "+v"(m) : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
 }
 // The fp16 pair format saturates at 65504 (after the format's scale): what a producer of pair16 images checks its inputs against
 static constexpr float PAIR_SAT = 65504.0f;

@@ -383,6 +383,7 @@ struct PrepMArgs {
     float* x0; float* ppc; float* ggc;                  // frames of more than 64 tokens: chunk 0 -> x0, chunk c >= 1 -> ppc/ggc[c-1]
     int T, Hh, N, Dv, rule, flags, np_total;            // N = tokens of the frame, np_total = its padded count (qinv row length)
     int nchunk;                                         // FUSE: 64-token chunks per frame, walked by ONE workgroup (else gridDim.y)
+    int grid3;                                          // launched as (8, T, B / 8): frame = (x + 8 z) T + y, no division (one chunk, one head)
 #ifdef GDKVM_DIAG
     unsigned long long* diag;
 #endif
@@ -420,7 +421,11 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     constexpr bool COMPACT = prepm_compact(NB, IO, FUSE);  // (layout: prepm_lds_bytes)
     float* s_kinv = smem;
     float* s_beta = smem + NP;
-    float* s_qinv = smem + 2 * NP;
+    // bf16 I/O: beta * gs and kinv / gs, gs the power of two G is handed to the scan with (a single-chunk frame: the scan's state
+    // scale) -- M is formed as (M gs) and Kn^T as (Kn^T / gs), so P = I - (M gs)(Kn / gs) is unchanged to the bit and the G tiles
+    // leave the MFMA scaled, one multiply per element less in the kernel's busiest phase
+    float* s_beta_s = smem + 2 * NP;
+    float* s_kinv_s = smem + 3 * NP;
     f32x4* s_negB = reinterpret_cast<f32x4*>(smem + 4 * NP);
     f32x4* s_Ld = s_negB + (NB * (NB - 1) / 2) * 64;
     f32x4* s_TmT = s_Ld + NB * 64;
@@ -447,18 +452,29 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // every argument the prologue needs is fetched HERE, in one batch of scalar loads: left to the compiler they are fetched where first
+    // used, one basic block after the other -- four dependent round trips to the scalar cache before the first key row is requested
+    {
+        const unsigned gdx = gridDim.x, gdy = gridDim.y;
+        asm volatile("" :: "s"(a.q), "s"(a.k), "s"(a.v), "s"(a.beta), "s"(a.qinv), "s"(a.pp), "s"(a.gg), "s"(a.gmax), "s"(a.norms),
+                     "s"(a.T), "s"(a.Hh), "s"(a.N), "s"(a.Dv), "s"(a.rule), "s"(a.flags), "s"(a.np_total), "s"(a.nchunk), "s"(a.grid3), "s"(gdx), "s"(gdy));
+    }
     // XCD-aware: the serial kernel runs clip-head bh on XCD bh % 8 (when their count is a multiple of 8); fold the frames of
     // that clip-head on the same XCD so its P and G are read from the L2 they were written through (speed only)
     int fh = blockIdx.x;
-    {
+    if (a.grid3) {
+        // (the common case -- one head, frames of at most 64 tokens, clips a multiple of 8 -- comes as a 3-D grid whose x is the XCD:
+        // the integer divisions of the 1-D decoding stood between the kernel's entry and its first load)
+        fh = ((int)blockIdx.x + 8 * (int)blockIdx.z) * (int)gridDim.y + (int)blockIdx.y;
+    } else {
         const int BH = (int)(gridDim.x / a.T), per_clip = a.T * a.Hh;       // gridDim.x = B * T * Hh; BH = B * Hh clip-heads
         if (BH % 8 == 0 && a.Hh == 1) {
             const int x = blockIdx.x, xcd = x & 7, idx = x >> 3;
             fh = (xcd + 8 * (idx / per_clip)) * per_clip + idx % per_clip;
         }
     }
-    const int h = fh % a.Hh;
-    const int Ntot = a.N, nchunk = FUSE ? a.nchunk : (int)gridDim.y;
+    const int h = a.Hh == 1 ? 0 : fh % a.Hh;
+    const int Ntot = a.N, nchunk = FUSE ? a.nchunk : (a.grid3 ? 1 : (int)gridDim.y);
     // FUSE (frames of more than 64 tokens, many frames): this workgroup walks the frame's chunks itself and carries the frame's
     // running map [P | G] <- P_c [P | G] + [0 | G_c] in accumulators -- wave w owns COLUMN tile w of P and column tiles w, w+4, ..
     // of G (all four row tiles of each: X[m][j]), which is the layout the chunk's own P tiles and G tiles are born in, and a
@@ -475,7 +491,7 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     asm volatile("" : "+s"(npass__));
     for (int pass__ = 0; pass__ < npass__; ++pass__)
 #endif
-    for (int chunk = FUSE ? 0 : (int)blockIdx.y, chunk_end = FUSE ? nchunk : chunk + 1; chunk < chunk_end; ++chunk) {
+    for (int chunk = (FUSE || a.grid3) ? 0 : (int)blockIdx.y, chunk_end = FUSE ? nchunk : chunk + 1; chunk < chunk_end; ++chunk) {
     // FUSE: the lane ids are re-derived per chunk from an opaque copy -- otherwise every lane-dependent address of the body is
     // hoisted out of the chunk loop as an invariant and held (then spilled) across it: ~100 registers the running map needs
     int tid_o = tid_k;
@@ -486,10 +502,12 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     if constexpr (FUSE) asm volatile("" : "+v"(tid_o));
     const int tid = tid_o, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int tok0 = chunk * NP;
-    const size_t bt = (size_t)(fh / a.Hh) * Ntot + tok0;   // row of this chunk's first token; rows are addressed bt*1 + n below
+    const size_t bt = (size_t)(a.Hh == 1 ? fh : fh / a.Hh) * Ntot + tok0;   // row of this chunk's first token; rows are addressed bt*1 + n below
     const int N = min(NP, Ntot - tok0), Hh = a.Hh, Dv = a.Dv, nsl = Dv / 16;
     const bool seq = a.rule == GDKVM_RULE_DELTA_SEQUENTIAL;
     const bool p_identity = a.rule == GDKVM_RULE_GATED_LINEAR;
+    // the frame's final G goes to the scan in the scan's scale (it carries S * STATE); chunk maps headed for the composition stay raw
+    const float gscale = nchunk == 1 ? OpFmt<FMT>::STATE : 1.0f, gscale_inv = nchunk == 1 ? OpFmt<FMT>::STATE_INV : 1.0f;
 #if defined(GDKVM_DIAG) && defined(GDKVM_DIAG_TWICE)
     const int t = a.T - pass__;
 #else
@@ -503,7 +521,7 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     if (a.diag && tid == 0) {
         unsigned long long t__;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");
-        a.diag[(size_t)(a.T + 1) * 8 + 2 * (blockIdx.x + gridDim.x * blockIdx.y)] = t__;
+        a.diag[(size_t)(a.T + 1) * 8 + 2 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z))] = t__;
     }
 #endif
 
@@ -626,7 +644,10 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
             }
             s_kinv[n] = kinv;
             s_beta[n] = bta;
-            s_qinv[n] = qinv;
+            if constexpr (SPLIT) {
+                s_beta_s[n] = bta * gscale;
+                s_kinv_s[n] = kinv * gscale_inv;
+            }
             a.qinv[(size_t)fh * a.np_total + tok0 + n] = qinv;
         }
     }
@@ -682,7 +703,7 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     if constexpr (SPLIT) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const f32x4 ki0 = *reinterpret_cast<const f32x4*>(s_kinv + 32 * ks + 8 * g), ki1 = *reinterpret_cast<const f32x4*>(s_kinv + 32 * ks + 8 * g + 4);
+            const f32x4 ki0 = *reinterpret_cast<const f32x4*>(s_kinv_s + 32 * ks + 8 * g), ki1 = *reinterpret_cast<const f32x4*>(s_kinv_s + 32 * ks + 8 * g + 4);
             // (ktr[4 + 2 ks], ktr[5 + 2 ks]: tokens 32 ks + 8 g + 0..3 and + 4..7 of channel 16 w + li)
             const uint2 t0 = ktr[IO == GDKVM_BF16 ? 4 + 2 * ks : 0], t1 = ktr[IO == GDKVM_BF16 ? 5 + 2 * ks : 0];
             f32x4 v0 = {__uint_as_float(t0.x << 16), __uint_as_float(t0.x & 0xffff0000u), __uint_as_float(t0.y << 16), __uint_as_float(t0.y & 0xffff0000u)};
@@ -905,7 +926,7 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     }
     f32x4 btI[NB];
 #pragma unroll
-    for (int I = 0; I < NB; ++I) btI[I] = *reinterpret_cast<const f32x4*>(s_beta + 16 * I + 4 * g);
+    for (int I = 0; I < NB; ++I) btI[I] = *reinterpret_cast<const f32x4*>((SPLIT ? s_beta_s : s_beta) + 16 * I + 4 * g);
     // (COMPACT: m3 below overwrites the K rows in R2 -- every wave took its copies right behind the phase 0 barrier and has passed
     // the barriers of phases 1 and 2, or the one in front of phase 3, since)
 #pragma unroll
@@ -1068,8 +1089,6 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     f32x4* gg = first_of_many ? x0 + 4 * 4 * 64
               : (chunk == 0 ? reinterpret_cast<f32x4*>(a.gg) + (size_t)fh * nsl * 4 * 64
                             : reinterpret_cast<f32x4*>(a.ggc) + ((size_t)fh * (nchunk - 1) + chunk - 1) * nsl * 4 * 64);
-    // the frame's final G goes to the scan in the scan's scale (it carries S * STATE); chunk maps headed for the composition stay raw
-    const float gscale = nchunk == 1 ? OpFmt<FMT>::STATE : 1.0f;
     // the frame's FINAL map (one chunk): max |G| per slice goes to the scan, which sizes the state's fp16-pair exponent by it
     const bool final_g = nchunk == 1;
     auto g_tiles = [&](int cV, const float (&x)[SPLIT ? 1 : NB][4]) __attribute__((always_inline)) {
@@ -1167,13 +1186,13 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
                 stage(0, a0, a1);
                 read_b(0, xb);
                 float gmA = 0.f, gmB = 0.f;
-                g_tiles3(cV, xb, [&](int m, const f32x4& t) { if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = t * gscale; gmA = fmaxf(gmA, absmax4(t)); });
+                g_tiles3(cV, xb, [&](int m, const f32x4& t) { if (cV < nsl) gg[((size_t)cV * 4 + m) * 64 + lane] = t; absmax4_into(gmA, t); });
                 if (nextA >= 0) load_vraw(nextA, a0, a1);
                 stage(1, b0, b1);
                 read_b(1, xb);
-                g_tiles3(cV + 4, xb, [&](int m, const f32x4& t) { if (cV + 4 < nsl) gg[((size_t)(cV + 4) * 4 + m) * 64 + lane] = t * gscale; gmB = fmaxf(gmB, absmax4(t)); });
+                g_tiles3(cV + 4, xb, [&](int m, const f32x4& t) { if (cV + 4 < nsl) gg[((size_t)(cV + 4) * 4 + m) * 64 + lane] = t; absmax4_into(gmB, t); });
                 if (final_g) {
-                    gmA = wave_max_nonneg(gmA); gmB = wave_max_nonneg(gmB);
+                    gmA = wave_max_nonneg(gmA) * gscale_inv; gmB = wave_max_nonneg(gmB) * gscale_inv;   // (the tiles came out of the MFMA scaled)
                     // (the index as a scalar: as a vector expression its 64-bit address lived in registers across the loop and spilled)
                     const int gi = __builtin_amdgcn_readfirstlane((fh * nsl + cV) * 4);
                     if (lane == 0) {
@@ -1270,7 +1289,7 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     if (a.diag && tid == 0) {
         unsigned long long t__;
         asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");
-        a.diag[(size_t)(a.T + 1) * 8 + 2 * (blockIdx.x + gridDim.x * blockIdx.y) + 1] = t__;
+        a.diag[(size_t)(a.T + 1) * 8 + 2 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + 1] = t__;
     }
 #endif
     if constexpr (FUSE) __syncthreads();                  // the next chunk's staging tile overwrites what this one's phase 4 read
@@ -1334,7 +1353,14 @@ int launch_prepm_fmt(const PrepMArgs& pa, int FH, int nchunk, hipStream_t st)
             done_mask.fetch_or(bit, std::memory_order_relaxed);
         }
     }
-    hipLaunchKernelGGL((gdr_prepm_kernel<NB, IO, FMT, FUSE, W3>), dim3(FH, FUSE ? 1 : nchunk), dim3(256), lds, st, pa);
+    PrepMArgs la = pa;
+    dim3 grid(FH, FUSE ? 1 : nchunk);
+    la.grid3 = 0;
+    if (!FUSE && nchunk == 1 && pa.Hh == 1 && pa.T <= 65535 && FH % (8 * pa.T) == 0) {
+        la.grid3 = 1;
+        grid = dim3(8, pa.T, FH / (8 * pa.T));
+    }
+    hipLaunchKernelGGL((gdr_prepm_kernel<NB, IO, FMT, FUSE, W3>), grid, dim3(256), lds, st, la);
     GDKVM_LAUNCH_CHECK("gdr_prepm_kernel");
     return GDKVM_OK;
 }
