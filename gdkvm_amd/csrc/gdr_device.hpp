@@ -110,8 +110,13 @@ static __device__ __forceinline__ unsigned cvt_pkrtz_f16(float a, float b)
 static __device__ __forceinline__ void pair16x4(const f32x4& x, uint2& h, uint2& l)
 {
     h = make_uint2(cvt_pkrtz_f16(x[0], x[1]), cvt_pkrtz_f16(x[2], x[3]));
-    const f32x2_t b01 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, h.x), f32x2_t), b23 = __builtin_convertvector(__builtin_bit_cast(f16x2_t, h.y), f32x2_t);
-    l = make_uint2(cvt_pkrtz_f16((x[0] - b01[0]) * PAIR_LO, (x[1] - b01[1]) * PAIR_LO), cvt_pkrtz_f16((x[2] - b23[0]) * PAIR_LO, (x[3] - b23[1]) * PAIR_LO));
+    // l = (x - h) 2^11, formed as fma(h, -2^11, x 2^11): the same bits (x 2^11 and h 2^11 are exact, and so is x - h), but the half is
+    // read by the fma itself (v_fma_mix_f32) and x 2^11 is a packed multiply -- six instructions for four values instead of twelve
+    // (convert, subtract, multiply each), on the serial scan's dependent chain
+    const f16x2_t h01 = __builtin_bit_cast(f16x2_t, h.x), h23 = __builtin_bit_cast(f16x2_t, h.y);
+    const f32x2_t s01 = (f32x2_t){x[0], x[1]} * (f32x2_t){PAIR_LO, PAIR_LO}, s23 = (f32x2_t){x[2], x[3]} * (f32x2_t){PAIR_LO, PAIR_LO};
+    l = make_uint2(cvt_pkrtz_f16(__builtin_fmaf(static_cast<float>(h01[0]), -PAIR_LO, s01[0]), __builtin_fmaf(static_cast<float>(h01[1]), -PAIR_LO, s01[1])),
+                   cvt_pkrtz_f16(__builtin_fmaf(static_cast<float>(h23[0]), -PAIR_LO, s23[0]), __builtin_fmaf(static_cast<float>(h23[1]), -PAIR_LO, s23[1])));
 }
 static __device__ __forceinline__ void pair16(float x, _Float16& h, _Float16& l)
 {
@@ -184,6 +189,16 @@ template <int FMT> struct OpFmt {
     }
     // [16 x 64] x [64 x 16]: A term images a[term][k step], B term images b[term][k step]; every product term above 2^-22 (pair16:
     // hh on one chain, hl + lh on the chain carried at 2^11) or 2^-16 of split3 (six terms, smallest first, two chains)
+    // pair16: the two chains before they are combined (acc0 + 2^-11 acc1) -- the serial scan folds the combination into packed FMAs
+    static __device__ __forceinline__ void product_pair(const uint4 (&a)[NT][2], const uint4 (&b)[NT][2], f32x4& acc0, f32x4& acc1)
+    {
+        static_assert(PAIR, "pair16 only");
+        acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#define GDKVM_MM(ACC, AT, BT, KS) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[AT][KS]), __builtin_bit_cast(f16x8, b[BT][KS]), ACC, 0, 0, 0)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { GDKVM_MM(acc1, 1, 0, ks); GDKVM_MM(acc0, 0, 0, ks); GDKVM_MM(acc1, 0, 1, ks); }
+#undef GDKVM_MM
+    }
     static __device__ __forceinline__ f32x4 product(const uint4 (&a)[NT][2], const uint4 (&b)[NT][2])
     {
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};

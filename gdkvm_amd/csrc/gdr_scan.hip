@@ -60,7 +60,13 @@ __host__ __device__ constexpr size_t aff_lds_bytes(int IO, int NT)
 {
     return (size_t)(aff_s_f4(NT) + (IO == GDKVM_F32 && NT == 3 ? 2 * 4 * 64 : 0)) * 16;
 }
-constexpr int AFF_PD = 2;                            // operand prefetch distance of the state waves, in frames
+#ifndef AFF_PD_FRAMES
+#define AFF_PD_FRAMES 2
+#endif
+#ifndef AFF_NBUF
+#define AFF_NBUF 4
+#endif
+constexpr int AFF_PD = AFF_PD_FRAMES;                // operand prefetch distance of the state waves, in frames (read waves: AFF_NBUF - 1)
 constexpr int AFF_THREADS = 512;
 
 __device__ __forceinline__ void aff_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -71,7 +77,7 @@ __device__ __forceinline__ void aff_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <int IO, int FMT, bool DEFER, bool SAVE>
 __global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
 {
-    constexpr int NB = 4, NP = 16 * NB, JT = 1, NBUF = 4, DEPTH = NBUF - 1, UFR = NBUF / JT;
+    constexpr int NB = 4, NP = 16 * NB, JT = 1, NBUF = AFF_NBUF, DEPTH = NBUF - 1, UFR = NBUF / JT;
     constexpr int NT = fmt_terms(FMT);
     constexpr bool PAIR = FMT == FMT_PAIR16;
     // the kernel carries S' = S * st_scale; G arrives scaled by OpFmt<FMT>::STATE (2^-4 under pair16, the default exponent)
@@ -309,21 +315,31 @@ __global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
     struct POp { uint4 pa[NT][2]; f32x4 gt; float al; };
     {
         // (a frame-head's P slot is sized for three terms whatever the format; row tile w is 2 NT KiB contiguous, lane-linear)
-        const size_t pp_fstride = (size_t)Hh * (GDKVM_DK * GDKVM_DK * 3 / 2);
-        const float* pp_lane = a.pp + fh0 * (GDKVM_DK * GDKVM_DK * 3 / 2) + (w * (NT * 2 * 64) + lane) * 4;
-        const float* gg_lane = a.gg + ((a.zero_g ? 0 : ((fh0 * nsl + sl) * 4 + w) * 64) + lane) * 4;
-        const size_t gg_fstride = a.zero_g ? 0 : (size_t)Hh * nsl * 4 * 64 * 4;
-        const float* al_ptr = a.alpha + fh0;
-        auto fetch_op = [&](int f, POp& d) __attribute__((always_inline)) {
-            f = min(f, T - 1);
-            if (a.reverse) f = T - 1 - f;
-            const float* pr = pp_lane + f * pp_fstride;
+        // The three operand streams are walked by RUNNING pointers -- a uniform base per stream, advanced by one frame's stride after each
+        // fetch until the last frame is reached (further prefetches repeat it), plus a constant 32-bit lane offset: six scalar adds per
+        // frame where the index arithmetic (clamp, reversal, three 64-bit products) took 25 instructions between the S reads and the MFMAs
+        const long dir = a.reverse ? -1 : 1;
+        const size_t f_first = a.reverse ? (size_t)(T - 1) : 0;
+        long pp_step = dir * (long)Hh * (GDKVM_DK * GDKVM_DK * 3 / 2) * 4;                             // bytes
+        long gg_step = a.zero_g ? 0 : dir * (long)Hh * nsl * 4 * 64 * 4 * 4;
+        long al_step = dir * (long)Hh * 4;
+        const char* pp_cur = reinterpret_cast<const char*>(a.pp + (fh0 + f_first * Hh) * (GDKVM_DK * GDKVM_DK * 3 / 2) + (size_t)w * (NT * 2 * 64) * 4);
+        const char* gg_cur = reinterpret_cast<const char*>(a.gg + (a.zero_g ? 0 : ((fh0 + f_first * Hh) * nsl + sl) * 4 + w) * 64 * 4);
+        const char* al_cur = reinterpret_cast<const char*>(a.alpha + fh0 + f_first * Hh);
+        const unsigned lane16 = lane * 16;
+        int f_cur = 0;                                     // frames fetched so far - 1, clamped: the pointers address frame min(f_cur, T - 1)
+        auto fetch_op = [&](int, POp& d) __attribute__((always_inline)) {
 #pragma unroll
             for (int sp = 0; sp < NT; ++sp)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) d.pa[sp][ks] = *reinterpret_cast<const uint4*>(pr + 256 * (sp * 2 + ks));
-            d.gt = *reinterpret_cast<const f32x4*>(gg_lane + f * gg_fstride);
-            d.al = al_ptr[(size_t)f * Hh];
+                for (int ks = 0; ks < 2; ++ks) d.pa[sp][ks] = *reinterpret_cast<const uint4*>(pp_cur + lane16 + 1024 * (sp * 2 + ks));
+            d.gt = *reinterpret_cast<const f32x4*>(gg_cur + lane16);
+            d.al = *reinterpret_cast<const float*>(al_cur);
+            if (f_cur >= T - 1) pp_step = gg_step = al_step = 0;      // (uniform; taken at the clip's end only)
+            ++f_cur;
+            pp_cur += pp_step;
+            gg_cur += gg_step;
+            al_cur += al_step;
         };
         POp od[AFF_PD + 1];
 #pragma unroll
@@ -345,11 +361,25 @@ __global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
             fetch_op(t + AFF_PD, far);                     // issued behind the S reads: the issue overlaps their latency
             __builtin_amdgcn_sched_barrier(0);
             const float alpha = gate_logits ? fast_sigmoid(op.al) : op.al;
-            const f32x4 ps = OpFmt<FMT>::product(op.pa, sb);
+            if constexpr (PAIR) {
+                // S = alpha (acc0 + 2^-11 acc1) + G on PACKED fp32 FMAs (two values an instruction; the same two roundings as the scalar
+                // form): four instructions on the chain instead of eight
+                f32x4 acc0, acc1;
+                OpFmt<FMT>::product_pair(op.pa, sb, acc0, acc1);
+                const f32x2_t lo2 = {PAIR_LO_INV, PAIR_LO_INV}, al2 = {alpha, alpha};
+                f32x2_t g01 = {op.gt[0], op.gt[1]}, g23 = {op.gt[2], op.gt[3]};
+                if constexpr (decltype(scaled_c)::value) { g01 *= (f32x2_t){gfix, gfix}; g23 *= (f32x2_t){gfix, gfix}; }   // (exact: a power of two)
+                const f32x2_t c01 = __builtin_elementwise_fma((f32x2_t){acc1[0], acc1[1]}, lo2, (f32x2_t){acc0[0], acc0[1]});
+                const f32x2_t c23 = __builtin_elementwise_fma((f32x2_t){acc1[2], acc1[3]}, lo2, (f32x2_t){acc0[2], acc0[3]});
+                const f32x2_t s01 = __builtin_elementwise_fma(al2, c01, g01), s23 = __builtin_elementwise_fma(al2, c23, g23);
+                sacc = f32x4{s01[0], s01[1], s23[0], s23[1]};
+            } else {
+                const f32x4 ps = OpFmt<FMT>::product(op.pa, sb);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if constexpr (decltype(scaled_c)::value) sacc[r] = alpha * ps[r] + op.gt[r] * gfix;   // (exact: a power of two)
-                else sacc[r] = alpha * ps[r] + op.gt[r];
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (decltype(scaled_c)::value) sacc[r] = alpha * ps[r] + op.gt[r] * gfix;   // (exact: a power of two)
+                    else sacc[r] = alpha * ps[r] + op.gt[r];
+                }
             }
             publish_state(par ^ 1, sacc);
             aff_barrier();

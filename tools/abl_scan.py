@@ -15,6 +15,10 @@ CSRC = os.path.join(ROOT, "gdkvm_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "_abl")
 VARIANTS = {
     "baseline": [],
+    "r_honly": ["-DGDKVM_ABL_R_HONLY"],
+    "r_nostore": ["-DGDKVM_ABL_R_NOSTORE"],
+    "r_noprep": ["-DGDKVM_ABL_R_NOPREP"],
+    "r_all": ["-DGDKVM_ABL_R_HONLY", "-DGDKVM_ABL_R_NOSTORE", "-DGDKVM_ABL_R_NOPREP"],
 }
 
 
