@@ -146,6 +146,20 @@ __global__ __launch_bounds__(256) void upsample_argmax_dice_kernel(UpArgs a)
         const int G = a.C / V, ppw = 64 / G;
         const int lane = threadIdx.x & 63, sub = lane / G, cg = lane % G, wv = threadIdx.x >> 6;
         const uint4* xv = static_cast<const uint4*>(a.logits) + ((size_t)f * hw + (size_t)lr0 * a.wl) * G;
+        // 2..4 classes: this lane's V weights of every class and the biases live in registers for the whole band (they were fetched
+        // per pixel group: 8 ncls vector loads in front of 8 ncls FMAs), and eight lanes per pixel (bf16 I/O, C = 64) sum over DPP
+        // lane permutations in the butterfly's order (xor 4, 2, 1: the same additions in the same order, hence the same bits) instead
+        // of three LDS permutes per class
+        float wreg[NC ? NC : 1][V], breg[NC ? NC : 1];
+        if constexpr (NC > 0) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) wreg[c][j] = a.hw_[(size_t)c * a.C + cg * V + j];
+                breg[c] = a.hb[c];
+            }
+        }
+        const bool dpp8 = NC > 0 && G == 8;               // (uniform)
         for (int p0 = wv * ppw; p0 < npl; p0 += 4 * ppw) {
             const int p = p0 + sub;
             const uint4 v4 = xv[(size_t)min(p, npl - 1) * G + cg];
@@ -157,12 +171,31 @@ __global__ __launch_bounds__(256) void upsample_argmax_dice_kernel(UpArgs a)
                 else { v[2 * j] = __uint_as_float(xw[j] << 16); v[2 * j + 1] = __uint_as_float(xw[j] & 0xffff0000u); }
             }
             float mine = 0.f;
-            for (int c = 0; c < ncls; ++c) {
-                float d = 0.f;
+            if constexpr (NC > 0) {
 #pragma unroll
-                for (int j = 0; j < V; ++j) d = fmaf(v[j], a.hw_[(size_t)c * a.C + cg * V + j], d);
-                for (int o = G >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o);
-                if (cg == c) mine = d + a.hb[c];
+                for (int c = 0; c < NC; ++c) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int j = 0; j < V; ++j) d = fmaf(v[j], wreg[c][j], d);
+                    if (dpp8) {
+                        // lane i ^ 4: the half-row mirror (i -> 7 - i) followed by the quad reversal; i ^ 2, i ^ 1: quad permutations
+                        const int m = __builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x141, 0xf, 0xf, false);        // row_half_mirror
+                        d += __int_as_float(__builtin_amdgcn_update_dpp(0, m, 0x1b, 0xf, 0xf, false));                   // quad_perm [3,2,1,0]
+                        d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+                        d += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+                    } else {
+                        for (int o = G >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o);
+                    }
+                    if (cg == c) mine = d + breg[c];
+                }
+            } else {
+                for (int c = 0; c < ncls; ++c) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int j = 0; j < V; ++j) d = fmaf(v[j], a.hw_[(size_t)c * a.C + cg * V + j], d);
+                    for (int o = G >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o);
+                    if (cg == c) mine = d + a.hb[c];
+                }
             }
             if (p < npl && cg < ncls) s_log[cg * npl + p] = IO == GDKVM_F32 ? mine : bf16_to_f32(f32_to_bf16(mine));
         }
