@@ -1356,7 +1356,7 @@ int launch_prepm_fmt(const PrepMArgs& pa, int FH, int nchunk, hipStream_t st)
     PrepMArgs la = pa;
     dim3 grid(FH, FUSE ? 1 : nchunk);
     la.grid3 = 0;
-    if (!FUSE && nchunk == 1 && pa.Hh == 1 && pa.T <= 65535 && FH % (8 * pa.T) == 0) {
+    if (!FUSE && nchunk == 1 && pa.Hh == 1 && pa.T <= 65535 && FH % (8 * pa.T) == 0 && FH / (8 * pa.T) <= 65535) {
         la.grid3 = 1;
         grid = dim3(8, pa.T, FH / (8 * pa.T));
     }
