@@ -571,15 +571,20 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
         const bool given = a.norms != nullptr;            // (uniform) the norms came with the projections: q is not read here at all
         // every load of the phase is requested before the first is consumed (no branch in between: a conditional load starts its round
         // trip only when the ones in front of it are back): gate, given norms, key (and query) rows, rows past N clamped and zeroed
-        const size_t rown = (bt + min(n, N - 1)) * Hh + h;
-        float bta_raw = a.beta[rown];
+        // (a uniform row index plus a small lane part: addresses as scalar base + 32-bit lane offset -- as one 64-bit lane expression
+        // each cost a 64-bit multiply-add per load, in front of the loads everything else waits for)
+        const size_t row_u = bt * Hh + h;                  // (uniform)
+        const unsigned row_l = (unsigned)min(n, N - 1) * (unsigned)Hh;
+        const size_t rown = row_u + row_l;
+        float bta_raw = (a.beta + row_u)[row_l];
         float2 nn = {1.f, 1.f};
-        if (given) nn = *reinterpret_cast<const float2*>(a.norms + rown * 2);
+        if (given) nn = reinterpret_cast<const float2*>(a.norms + row_u * 2)[row_l];
         f32x4 xs[4], ys[4];
         uint4 kraw0, kraw1;
         if constexpr (IO == GDKVM_BF16) {
-            const uint4* kp = reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.k) + rown * GDKVM_DK + 16 * qd);
-            kraw0 = kp[0]; kraw1 = kp[1];
+            const char* kb = reinterpret_cast<const char*>(static_cast<const bf16_t*>(a.k) + row_u * GDKVM_DK);
+            const unsigned ko = row_l * (GDKVM_DK * 2) + 32u * qd;
+            kraw0 = *reinterpret_cast<const uint4*>(kb + ko); kraw1 = *reinterpret_cast<const uint4*>(kb + ko + 16);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1038,9 +1043,11 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
             continue;
         }
         // lane (g,li) reg r = P[16m + li][k = 16w + 4g + r]: four consecutive k of row li of row tile m -> its term images
-        f32x4 pv;
+        f32x4 pv = -(acc0 + acc1);
+        if (m == w) {                                      // (uniform: the identity meets only the diagonal tile)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pv[r] = ((16 * m + li == 16 * w + 4 * g + r) ? 1.f : 0.f) - (acc0[r] + acc1[r]);
+            for (int r = 0; r < 4; ++r) pv[r] = ((li == 4 * g + r) ? 1.f : 0.f) - (acc0[r] + acc1[r]);
+        }
         uint2 tt[3];
         OpFmt<FMT>::split4(pv, tt);
         const int e = split_slot(w, g, li);
