@@ -279,7 +279,7 @@ struct FoldArgs { const float* wti; const float* knT; const float* ut; float* pp
 // grid (FH, 1 + ceil(Dv/64)): block y = 0 folds the four Wt tiles into P, block y > 0 four Ut tiles into G.  Every operand
 // of the block's four tiles is requested up front (20 16-byte loads per lane), then 4 x 4NB MFMA run back to back.
 template <int NB, int FMT>
-__global__ __launch_bounds__(256) void gdr_fold_kernel(FoldArgs a)
+__global__ __launch_bounds__(256, 2) void gdr_fold_kernel(FoldArgs a)
 {
     constexpr int NP = 16 * NB, NT = fmt_terms(FMT);
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
@@ -1400,7 +1400,7 @@ int launch_prepm(const PrepMArgs& pa, int FH, int nchunk, bool wide, bool fuse, 
 struct ComposeArgs { const float* x0; const float* ppc; const float* ggc; float* pp; float* gg; int Dv, nchunk, additive; float* gmax; };
 
 template <int FMT>
-__global__ __launch_bounds__(256) void gdr_compose_kernel(ComposeArgs a)
+__global__ __launch_bounds__(256, 2) void gdr_compose_kernel(ComposeArgs a)       // (256 registers: MFMA results in VGPRs; with 512 they land in AGPRs and are copied out)
 {
     constexpr int NT = fmt_terms(FMT);
     __shared__ __attribute__((aligned(16))) uint2 s_X3[4 * NT * SPLIT_IMG];       // [col tile j][term] B images (pair16: at 2^-4)

@@ -440,7 +440,7 @@ int launch_affine_any(bool wide, bool defer, bool save, const AffArgs& sa, dim3 
 struct ReadoutArgs { const void* q; const float* qinv; const float* simg; void* r_out; int Hh, N, Dv, NP; const float* esc; int T; };
 
 template <int IO, int FMT>
-__global__ __launch_bounds__(256) void gdr_readout_kernel(ReadoutArgs a)
+__global__ __launch_bounds__(256, 2) void gdr_readout_kernel(ReadoutArgs a)       // (256 registers: MFMA results in VGPRs; with 512 they land in AGPRs and are copied out)
 {
     constexpr bool PAIR = FMT == FMT_PAIR16;
     constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;

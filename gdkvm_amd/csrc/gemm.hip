@@ -19,7 +19,7 @@ struct GemmArgs { const void* a; const void* b; void* c; float* part; const floa
 // product is computed transposed (C^T = B A^T: the weight rows are the A operand) so that a lane ends with four consecutive
 // columns of one output row (8/16-byte stores).
 template <int IO>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p)
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p)
 {
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
