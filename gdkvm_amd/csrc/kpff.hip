@@ -1029,6 +1029,7 @@ __global__ __launch_bounds__(512) void proj_gates_kernel(ProjGateArgs ga)
     }
     float* s_part = reinterpret_cast<float*>(s_px + (size_t)TM * ld);
     const size_t row0 = (size_t)blockIdx.x * TM;
+    KPFF_STAMP(0);
     for (int base = tid; base < TM * q8; base += 4 * 512) {            // stage the token rows (zero beyond M), 4 loads in flight
         uint4 x[4];
 #pragma unroll
@@ -1042,7 +1043,9 @@ __global__ __launch_bounds__(512) void proj_gates_kernel(ProjGateArgs ga)
             if (idx < TM * q8) *reinterpret_cast<uint4*>(s_px + (size_t)r * ld + c) = x[u];
         }
     }
+    KPFF_STAMP(1);
     __syncthreads();
+    KPFF_STAMP(2);
     {   // ---- write-gate logits from the staged rows: 512 / TM threads per token, 16-byte pieces interleaved over them
         constexpr int TPT = 512 / TM;
         const int tok = tid / TPT, part = tid % TPT;
@@ -1062,6 +1065,7 @@ __global__ __launch_bounds__(512) void proj_gates_kernel(ProjGateArgs ga)
             if (part == 0 && row0 + tok < (size_t)a.M) ga.beta[(row0 + tok) * Hh + h] = d + ga.b_gate[h];
         }
     }
+    KPFF_STAMP(3);
     const bf16_t* xb = s_px + (size_t)li * ld + 8 * g;
     const int ntile_norm = (a.width[0] + a.width[1]) / 16;               // the key and query tiles
     for (int ot = w_id; ot < a.ntile_out; ot += 8) {
@@ -1091,7 +1095,9 @@ __global__ __launch_bounds__(512) void proj_gates_kernel(ProjGateArgs ga)
             }
         }
     }
+    KPFF_STAMP(4);
     __syncthreads();
+    KPFF_STAMP(5);
     // inverse norms per (token, head): the Dk / 16 tile sums of a head in tile order; norms[row][head][0 = key, 1 = query]
     const int tph = ga.Dk / 16;
     for (int idx = tid; idx < TM * 2 * Hh; idx += 512) {
@@ -1101,6 +1107,7 @@ __global__ __launch_bounds__(512) void proj_gates_kernel(ProjGateArgs ga)
         for (int t = 0; t < tph; ++t) ss += s_part[(t0 + t) * TM + tok];
         if (row0 + tok < (size_t)a.M) ga.norms[((row0 + tok) * Hh + h) * 2 + which] = 1.0f / sqrtf(ss + GDKVM_EPS_NORM);
     }
+    KPFF_STAMP(6);
 }
 
 }  // namespace

@@ -15,8 +15,39 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "gdkvm_amd", "csrc")
 
 
+def proj(so):
+    """--proj: the stamps of proj_gates_kernel's tile workgroups (stage | barrier | gate logits | MFMA tiles + stores | barrier | norms)."""
+    from gdkvm_amd import ops
+    dev = torch.device("cuda"); B, T, N, Hh, Dk, Dv, Cp = 16, 32, 49, 1, 64, 256, 256
+    g = torch.Generator(device=dev).manual_seed(1)
+    p = torch.randn(B * T, N, Cp, device=dev, generator=g).bfloat16()
+    w = torch.randn(2 * Dk + Dv, Cp, device=dev, generator=g) / Cp ** 0.5
+    b = torch.randn(2 * Dk + Dv, device=dev, generator=g)
+    wg, bg = torch.randn(Hh, Cp, device=dev, generator=g) / Cp ** 0.5, torch.zeros(Hh, device=dev)
+    wd, bd = torch.randn(Hh, Cp, device=dev, generator=g) / Cp ** 0.5, 2 + torch.zeros(Hh, device=dev)
+    pack = ops.pack_rows_weight(w)
+    for _ in range(20):
+        ops.proj_gates(p, pack, b, wg, bg, wd, bd, Hh, Dk, Dv)
+    buf = torch.zeros(64 * 8 * 16, dtype=torch.int64, device=dev)
+    raw = ctypes.CDLL(so)
+    raw.gdkvm_kpff_diag_set_buffer.argtypes = [ctypes.c_void_p]
+    raw.gdkvm_kpff_diag_set_buffer(buf.data_ptr())
+    ops.proj_gates(p, pack, b, wg, bg, wd, bd, Hh, Dk, Dv)
+    torch.cuda.synchronize()
+    st = buf.cpu().reshape(64, 8, 16).double()
+    t0 = st[:, :, 0].min(1, keepdim=True).values
+    names = {1: "token rows requested and written to LDS", 2: "barrier", 3: "write-gate logits", 4: "output tiles (MFMA, bias, stores, norm partials)",
+             5: "barrier", 6: "inverse norms"}
+    last = 0
+    print("proj_gates_kernel<64>: median over 64 workgroups x 8 waves, cycles after the workgroup's start | phase cycles")
+    for slot in range(1, 7):
+        end = (st[:, :, slot] - t0).median().item()
+        print(f"{slot:4d}  {names[slot]:55s} {end:12.0f} {end - last:12.0f}")
+        last = end
+
+
 def main():
-    flags = ["-DKPFF_STAMPS"] + sys.argv[1:]
+    flags = ["-DKPFF_STAMPS"] + [a for a in sys.argv[1:] if a != "--proj"]
     so = os.path.join(ROOT, "gpurun_out", "libgdkvm_hip_stampk.so")
     os.makedirs(os.path.dirname(so), exist_ok=True)
     obj = os.path.join(ROOT, "gpurun_out", "kpff_stamp.o")
@@ -27,6 +58,8 @@ def main():
     from gdkvm_amd import ops
     ops._SO = so
     lib = ops.load()
+    if "--proj" in sys.argv:
+        return proj(so)
     dev = torch.device("cuda"); B, T, N, Dk, Dv, Cp = 16, 32, 49, 64, 256, 256
     g = torch.Generator(device=dev).manual_seed(1)
     L = torch.randn(B * T, N, Dk, device=dev, generator=g).bfloat16(); G = torch.randn(B * T, N, Dv, device=dev, generator=g).bfloat16()
