@@ -50,6 +50,22 @@ def test_scan_fp32_ragged_shapes(hip, shape):
     assert np.abs(Rg - Ro).max() <= TOL and np.abs(Sg - So).max() <= TOL
 
 
+@pytest.mark.parametrize("case", [(8, 3, 49, 1, 320), (3, 4, 49, 1, 512), (8, 2, 33, 2, 320), (16, 2, 64, 1, 64), (8, 2, 17, 1, 272)])
+def test_scan_bf16_wide_values_and_launch_forms(hip, case):
+    """bf16 I/O, frames of at most 64 tokens, MORE than sixteen 16-column value tiles: the frame-parallel kernel's register-rich build
+    requests a wave's first four V tiles at entry and refills the four register pairs for the tiles beyond (Dv 272 / 320 / 512) -- on both
+    launch forms of that kernel (clips a multiple of 8 with one head go out as a 3-D grid whose x is the XCD, everything else 1-D), with a
+    carried state, and at 64 tokens (no padding token: every k-step of the last block is kept)."""
+    B, T, N, Hh, Dv = case
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, 64, Dv, seed=sum(case), normalized=False, logits=True, corr=0.5)
+    t = [_dev(x, torch.bfloat16) for x in (q, k, v)] + [_dev(a), _dev(b)]
+    s0 = _dev((0.3 * np.random.default_rng(5).standard_normal((B, Hh, 64, Dv))).astype(np.float32))
+    R, S = hip.scan_fwd(*t, s0, rule=2, flags=3)
+    Ro, So = c_oracle.scan(*(O.to_bf16_f32(x) for x in (q, k, v)), a, b, s0.cpu().numpy(), 2, 3)
+    assert np.abs(S.cpu().numpy() - So).max() <= 1e-4
+    assert np.abs(R.float().cpu().numpy() - Ro).max() <= 2.0 ** -7 * max(1.0, float(np.abs(Ro).max()))      # bf16 read-out
+
+
 @pytest.mark.parametrize("case", [(2, 3, 65, 1, 64), (1, 4, 100, 2, 128), (3, 2, 130, 1, 192), (2, 2, 250, 1, 256), (1, 3, 256, 1, 256), (1, 2, 1024, 1, 64),
                                   (8, 2, 130, 1, 64), (16, 17, 70, 1, 128)])      # (8 / 16 clips: the XCD-aware frame order; 272 frames: the default choice)
 @pytest.mark.parametrize("rule", [0, 2])
