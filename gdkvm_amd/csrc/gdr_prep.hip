@@ -383,7 +383,8 @@ struct PrepMArgs {
     float* x0; float* ppc; float* ggc;                  // frames of more than 64 tokens: chunk 0 -> x0, chunk c >= 1 -> ppc/ggc[c-1]
     int T, Hh, N, Dv, rule, flags, np_total;            // N = tokens of the frame, np_total = its padded count (qinv row length)
     int nchunk;                                         // FUSE: 64-token chunks per frame, walked by ONE workgroup (else gridDim.y)
-    int grid3;                                          // launched as (8, T, B / 8): frame = (x + 8 z) T + y, no division (one chunk, one head)
+    int grid3;                                          // launched as (8, T, B / 8): frame = (x + 8 z) Tst + y, no division (one chunk, one head)
+    int Tst;                                            // frames between consecutive clips: T, or the whole clip's length for a window of T frames per clip
 #ifdef GDKVM_DIAG
     unsigned long long* diag;
 #endif
@@ -457,7 +458,7 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     {
         const unsigned gdx = gridDim.x, gdy = gridDim.y;
         asm volatile("" :: "s"(a.q), "s"(a.k), "s"(a.v), "s"(a.beta), "s"(a.qinv), "s"(a.pp), "s"(a.gg), "s"(a.gmax), "s"(a.norms),
-                     "s"(a.T), "s"(a.Hh), "s"(a.N), "s"(a.Dv), "s"(a.rule), "s"(a.flags), "s"(a.np_total), "s"(a.nchunk), "s"(a.grid3), "s"(gdx), "s"(gdy));
+                     "s"(a.T), "s"(a.Hh), "s"(a.N), "s"(a.Dv), "s"(a.rule), "s"(a.flags), "s"(a.np_total), "s"(a.nchunk), "s"(a.grid3), "s"(a.Tst), "s"(gdx), "s"(gdy));
     }
     // XCD-aware: the serial kernel runs clip-head bh on XCD bh % 8 (when their count is a multiple of 8); fold the frames of
     // that clip-head on the same XCD so its P and G are read from the L2 they were written through (speed only)
@@ -465,13 +466,14 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     if (a.grid3) {
         // (the common case -- one head, frames of at most 64 tokens, clips a multiple of 8 -- comes as a 3-D grid whose x is the XCD:
         // the integer divisions of the 1-D decoding stood between the kernel's entry and its first load)
-        fh = ((int)blockIdx.x + 8 * (int)blockIdx.z) * (int)gridDim.y + (int)blockIdx.y;
+        fh = ((int)blockIdx.x + 8 * (int)blockIdx.z) * a.Tst + (int)blockIdx.y;
     } else {
         const int BH = (int)(gridDim.x / a.T), per_clip = a.T * a.Hh;       // gridDim.x = B * T * Hh; BH = B * Hh clip-heads
         if (BH % 8 == 0 && a.Hh == 1) {
             const int x = blockIdx.x, xcd = x & 7, idx = x >> 3;
             fh = (xcd + 8 * (idx / per_clip)) * per_clip + idx % per_clip;
         }
+        if (a.Tst != a.T) fh += (fh / per_clip) * (a.Tst - a.T) * a.Hh;    // a window of T frames per clip: clips lie Tst frames apart
     }
     const int h = a.Hh == 1 ? 0 : fh % a.Hh;
     const int Ntot = a.N, nchunk = FUSE ? a.nchunk : (a.grid3 ? 1 : (int)gridDim.y);
@@ -1397,7 +1399,7 @@ int launch_prepm(const PrepMArgs& pa, int FH, int nchunk, bool wide, bool fuse, 
 // accumulators, wave w = row tile w) through all steps, exactly like the serial scan carries S -- P_c as three-term A
 // images (as prepm wrote them), the running columns re-split into three-term B images through LDS each step.
 // Output: the final P as term images (pp) and G as accumulator images (gg), the formats the scan consumes.
-struct ComposeArgs { const float* x0; const float* ppc; const float* ggc; float* pp; float* gg; int Dv, nchunk, additive; float* gmax; };
+struct ComposeArgs { const float* x0; const float* ppc; const float* ggc; float* pp; float* gg; int Dv, nchunk, additive; float* gmax; int per_clip, skip; };
 
 template <int FMT>
 __global__ __launch_bounds__(256, 2) void gdr_compose_kernel(ComposeArgs a)       // (256 registers: MFMA results in VGPRs; with 512 they land in AGPRs and are copied out)
@@ -1406,7 +1408,8 @@ __global__ __launch_bounds__(256, 2) void gdr_compose_kernel(ComposeArgs a)     
     __shared__ __attribute__((aligned(16))) uint2 s_X3[4 * NT * SPLIT_IMG];       // [col tile j][term] B images (pair16: at 2^-4)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t fh = blockIdx.x;
+    // (a window of frames per clip: per_clip frame-heads of the launch per clip, `skip` more between consecutive clips)
+    const size_t fh = blockIdx.x + (a.skip ? (size_t)(blockIdx.x / (unsigned)a.per_clip) * a.skip : 0);
     const int nsl = a.Dv / 16, ncol = 4 + nsl, c0 = 4 * blockIdx.y;               // this block's column tiles c0 .. c0+3 of [P | G]
     f32x4 X[4];
     float xsplit_max = 0.f;                                // pair16: largest |entry| this wave re-split into fp16 pairs (checked at the end)
@@ -1511,6 +1514,46 @@ extern "C" size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk
     return gdr_workspace_bytes(B, T, Hh, N, Dk, Dv);
 }
 
+// The inference-side fold (P and G per frame; frames of more than 64 tokens per 64-token chunk, then composed) over a window of Tb frames per
+// clip, clips Tst frames apart (gdr_ws.hpp).  fuse: GDR_FUSE_AUTO = by the window's frame count, 0 / 1 = the chunk-parallel workgroups /
+// the fused chunk walk where its conditions hold (the two are bit-identical; a caller that overlaps several windows knows the device is full).
+int gdr_prep_window(const void* q, const void* k, const void* v, const float* beta, const float* norms, const WsView& ws,
+                    int B, int Tb, int Tst, int Hh, int N, int Dv, int io_dtype, int rule, int flags, int fuse_req, hipStream_t st)
+{
+    const int T = Tb;
+    PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, ws.gmax, norms, ws.x0, ws.ppc, ws.ggc, T, Hh, N, Dv, rule, flags, 16 * ws.nb, ws.nchunk};
+    pm.Tst = Tst;
+#ifdef GDKVM_DIAG
+    pm.diag = g_gdkvm_diag_buf;
+#endif
+    const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
+    // Frames of more than 64 tokens: with enough frames to fill the device on their own, ONE workgroup walks a frame's chunks and
+    // composes its map in registers (no chunk maps through HBM, no compose kernel); with few frames the chunks run as separate
+    // workgroups (4x the parallelism) and gdr_compose_kernel stitches them.  bf16 I/O on pair16 operands, Dv <= 256 in
+    // multiples of 64 (five column tiles of accumulators per wave), not delta_parallel (its chunks add up instead).
+    bool fuse = false;
+    if (ws.nchunk > 1 && io_dtype == GDKVM_BF16 && !wide && rule != GDKVM_RULE_DELTA_PARALLEL && Dv % 64 == 0 && Dv <= 256) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        }
+        fuse = (long)B * T * Hh >= cus;               // measured crossover at N = 256, Dv = 256: 256 frames (54 us either way)
+        if (fuse_req != GDR_FUSE_AUTO) fuse = fuse_req != 0;
+        if (const char* e = getenv("GDKVM_PREP_FUSE")) fuse = e[0] == '1';     // "0" / "1": overrides the choice by frame count (tests, A/B)
+    }
+    if (int rc = io_dtype == GDKVM_F32 ? launch_prepm<4, GDKVM_F32>(pm, B * T * Hh, ws.nchunk, wide, false, st)
+                                       : launch_prepm<4, GDKVM_BF16>(pm, B * T * Hh, ws.nchunk, wide, fuse, st)) return rc;
+    if (ws.nchunk > 1 && !fuse) {
+        ComposeArgs ca{ws.x0, ws.ppc, ws.ggc, ws.pp, ws.gg, Dv, ws.nchunk, rule == GDKVM_RULE_DELTA_PARALLEL, ws.gmax, T * Hh, (Tst - T) * Hh};
+        const dim3 cgrid((unsigned)(B * T * Hh), (unsigned)((4 + Dv / 16 + 3) / 4));
+        if (wide) hipLaunchKernelGGL(gdr_compose_kernel<FMT_SPLIT3>, cgrid, dim3(256), 0, st, ca);
+        else hipLaunchKernelGGL(gdr_compose_kernel<FMT_PAIR16>, cgrid, dim3(256), 0, st, ca);
+        GDKVM_LAUNCH_CHECK("gdr_compose_kernel");
+    }
+    return GDKVM_OK;
+}
+
 static int scan_prep_impl(const void* q, const void* k, const void* v, const float* beta, const float* norms, void* workspace, size_t workspace_bytes,
                           int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
 {
@@ -1524,37 +1567,8 @@ static int scan_prep_impl(const void* q, const void* k, const void* v, const flo
     if (int rc = carve("scan_prep", workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
     if (int rc = gdkvm_check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!(flags & GDKVM_FLAG_TRAIN) || ws.nchunk > 1) {  // P and G directly (frames of > 64 tokens: per 64-token chunk, then composed)
-        PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, ws.gmax, norms, ws.x0, ws.ppc, ws.ggc, T, Hh, N, Dv, rule, flags, 16 * ws.nb, ws.nchunk};
-#ifdef GDKVM_DIAG
-        pm.diag = g_gdkvm_diag_buf;
-#endif
-        const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
-        // Frames of more than 64 tokens: with enough frames to fill the device on their own, ONE workgroup walks a frame's chunks and
-        // composes its map in registers (no chunk maps through HBM, no compose kernel); with few frames the chunks run as separate
-        // workgroups (4x the parallelism) and gdr_compose_kernel stitches them.  bf16 I/O on pair16 operands, Dv <= 256 in
-        // multiples of 64 (five column tiles of accumulators per wave), not delta_parallel (its chunks add up instead).
-        bool fuse = false;
-        if (ws.nchunk > 1 && io_dtype == GDKVM_BF16 && !wide && rule != GDKVM_RULE_DELTA_PARALLEL && Dv % 64 == 0 && Dv <= 256) {
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) == hipSuccess) {
-                int n = 0;
-                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-            }
-            fuse = (long)B * T * Hh >= cus;               // measured crossover at N = 256, Dv = 256: 256 frames (54 us either way)
-            if (const char* e = getenv("GDKVM_PREP_FUSE")) fuse = e[0] == '1';     // "0" / "1": overrides the choice by frame count (tests, A/B)
-        }
-        if (int rc = io_dtype == GDKVM_F32 ? launch_prepm<4, GDKVM_F32>(pm, B * T * Hh, ws.nchunk, wide, false, st)
-                                           : launch_prepm<4, GDKVM_BF16>(pm, B * T * Hh, ws.nchunk, wide, fuse, st)) return rc;
-        if (ws.nchunk > 1 && !fuse) {
-            ComposeArgs ca{ws.x0, ws.ppc, ws.ggc, ws.pp, ws.gg, Dv, ws.nchunk, rule == GDKVM_RULE_DELTA_PARALLEL, ws.gmax};
-            const dim3 cgrid((unsigned)(B * T * Hh), (unsigned)((4 + Dv / 16 + 3) / 4));
-            if (wide) hipLaunchKernelGGL(gdr_compose_kernel<FMT_SPLIT3>, cgrid, dim3(256), 0, st, ca);
-            else hipLaunchKernelGGL(gdr_compose_kernel<FMT_PAIR16>, cgrid, dim3(256), 0, st, ca);
-            GDKVM_LAUNCH_CHECK("gdr_compose_kernel");
-        }
-        return GDKVM_OK;
-    }
+    if (!(flags & GDKVM_FLAG_TRAIN) || ws.nchunk > 1)    // P and G directly (frames of > 64 tokens: per 64-token chunk, then composed)
+        return gdr_prep_window(q, k, v, beta, norms, ws, B, T, T, Hh, N, Dv, io_dtype, rule, flags, GDR_FUSE_AUTO, st);
     // training, <= 64 tokens: the WY factors the backward consumes, then folded
     PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, ws.kn, ws.wtT, ws.qnT, ws.tii, ws.wti, T, Hh, N, Dv, rule, flags};
     if (int rc = io_dtype == GDKVM_F32 ? launch_prep<4, GDKVM_F32, 5>(pa, B * T * Hh, st) : launch_prep<4, GDKVM_BF16, 5>(pa, B * T * Hh, st)) return rc;
@@ -1584,6 +1598,11 @@ extern "C" int gdkvm_scan_fwd_normed(const void* q, const void* k, const void* v
 {
     if (Dk != GDKVM_DK) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd_normed: Dk=%d (the norms path is built for Dk=%d)", Dk, GDKVM_DK);
     if (rule == GDKVM_RULE_DELTA_PARALLEL) flags |= GDKVM_FLAG_WIDE_RANGE;      // as gdkvm_scan_fwd
+    if (norms) {                                        // as gdkvm_scan_fwd: overlapping time blocks where that pays (gdr_pipeline.hip)
+        const int rc = gdr_scan_fwd_blocks(q, k, v, alpha, beta, norms, s_in, r_out, s_out, workspace, workspace_bytes, B, T, Hh, N, Dv,
+                                           io_dtype, rule, flags, static_cast<hipStream_t>(stream));
+        if (rc <= 0) return rc;
+    }
     if (int rc = gdkvm_scan_prep_normed(q, k, v, beta, norms, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream)) return rc;
     return gdkvm_scan_apply(q, alpha, s_in, r_out, s_out, nullptr, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, flags, stream);
 }

@@ -49,6 +49,8 @@ struct AffArgs {
     float* simg;                                     // DEFER: per-frame operand images of the state for gdr_readout_kernel
     const float* gmax;                               // pair16: max |G| per frame and slice from the frame-parallel side (NULL: default exponent)
     float* esc;                                      // DEFER, pair16: 2^e of this (clip-head, slice) for gdr_readout_kernel
+    int Tst;                                         // frames between consecutive clips in every [B, T, ...] tensor and workspace region: T, or the
+                                                     // whole clip's length when the call covers a window of T frames per clip (gdr_pipeline.hip)
 };
 // LDS (16-byte units): S term images [2 parities][NT terms][2 ksteps][64] | (fp32 I/O on split3) S fp32 images [2][4][64]
 template <int IO> struct RItem;                                        // read-out operands of one 16-token tile
@@ -97,7 +99,8 @@ __global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
         else { bh = x / nsl; sl = x % nsl; }
     }
     const int b = bh / Hh, h = bh % Hh;
-    const size_t fh0 = (size_t)b * T * Hh + h;
+    const int Tst = a.Tst;
+    const size_t fh0 = (size_t)b * Tst * Hh + h;
     constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
 
     // ---- the state's exponent (pair16).  fp16 pairs hold |S * 2^-e| < 65504, so e must fit this call's state: columns of S never
@@ -182,14 +185,14 @@ __global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
             return;
         }
         const int last_item = T * JT - 1;
-        const char* qbase = static_cast<const char*>(a.q) + (((size_t)b * T * N * Hh + h) * GDKVM_DK) * ESZ;
+        const char* qbase = static_cast<const char*>(a.q) + (((size_t)b * Tst * N * Hh + h) * GDKVM_DK) * ESZ;
         const size_t q_fstride = (size_t)N * Hh * GDKVM_DK * ESZ;
         const float* qinv_lane = a.qinv + fh0 * NP + li;
         // The read-out is computed TRANSPOSED, R^T = S^T Qn^T: the S images are also the A operand of S^T and the q rows as
         // loaded are also the B operand of Qn^T, so only the two MFMA arguments swap -- and lane (g, li) ends up with columns
         // 4g..4g+3 of token li: one 8- or 16-byte store per lane into the token's row instead of four scattered 2-byte ones
         // (the store issue made the read waves the slowest role of a frame).
-        char* rbase = static_cast<char*>(a.r_out) + ((size_t)b * T * N * Hh * Dv + h * Dv + 16 * sl + 4 * g) * ESZ;
+        char* rbase = static_cast<char*>(a.r_out) + ((size_t)b * Tst * N * Hh * Dv + h * Dv + 16 * sl + 4 * g) * ESZ;
         const size_t r_fstride = (size_t)N * Hh * Dv * ESZ;
         auto load_q = [&](int item, RItem<IO>& d) __attribute__((always_inline)) {
             item = min(item, last_item);
@@ -437,7 +440,7 @@ int launch_affine_any(bool wide, bool defer, bool save, const AffArgs& sa, dim3 
 // images the serial kernel dumped.  One workgroup per (frame-head, 8 column tiles); a wave keeps the images of its two column
 // tiles in registers and walks the frame's token tiles, so q is read once per workgroup and nothing goes through LDS.  Same
 // arithmetic and operation order as the in-scan read-out (R^T = S^T Qn^T: pair16 terms on the f16 MFMA, or exact fp32).
-struct ReadoutArgs { const void* q; const float* qinv; const float* simg; void* r_out; int Hh, N, Dv, NP; const float* esc; int T; };
+struct ReadoutArgs { const void* q; const float* qinv; const float* simg; void* r_out; int Hh, N, Dv, NP; const float* esc; int T, Tst; };
 
 template <int IO, int FMT>
 __global__ __launch_bounds__(256, 2) void gdr_readout_kernel(ReadoutArgs a)       // (256 registers: MFMA results in VGPRs; with 512 they land in AGPRs and are copied out)
@@ -446,9 +449,11 @@ __global__ __launch_bounds__(256, 2) void gdr_readout_kernel(ReadoutArgs a)     
     constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t fh = blockIdx.x;
-    const int h = (int)(fh % a.Hh), N = a.N, Dv = a.Dv, nsl = Dv / 16;
-    const size_t bt = fh / a.Hh;
+    // (blockIdx.x counts the launch's frame-heads, T frames per clip; clips lie Tst frames apart)
+    const int h = (int)(blockIdx.x % a.Hh), N = a.N, Dv = a.Dv, nsl = Dv / 16;
+    const unsigned btl = blockIdx.x / a.Hh, clip = btl / (unsigned)a.T;
+    const size_t bt = (size_t)clip * a.Tst + (btl - clip * (unsigned)a.T);
+    const size_t fh = bt * a.Hh + h;
     const int c0 = (blockIdx.y * 4 + w) * 2;
     if (c0 >= nsl) return;
     const bool two = c0 + 1 < nsl;
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void gdr_readout_kernel(ReadoutArgs a)     
     // (the dumped images are those of S * 2^-e: pair16 -- the exponent the serial kernel chose for this clip-head and column tile)
     float sinv[2] = {OpFmt<FMT>::STATE_INV, OpFmt<FMT>::STATE_INV};
     if constexpr (PAIR) {
-        const size_t bh = (fh / ((size_t)a.T * a.Hh)) * a.Hh + h;
+        const size_t bh = (size_t)clip * a.Hh + h;
         const float* ep = a.esc + bh * ((nsl + 3) & ~3);
         sinv[0] = ep[c0];
         sinv[1] = ep[two ? c0 + 1 : c0];
@@ -571,6 +576,44 @@ __global__ void gdr_decay_kernel(const float* alpha, const float* s_in, float* s
 
 }  // namespace
 
+// The serial recurrence (phases bit 0) and, for frames of more than 64 tokens, the frame-parallel read-out (bit 1) over a window of Tb
+// frames per clip, clips Tst frames apart (gdr_ws.hpp).  gdkvm_scan_apply is the whole clip with both phases on one stream.
+int gdr_apply_window(const void* q, const float* alpha, const float* s_in, void* r_out, float* s_out, float* s_hist, const WsView& ws,
+                     int B, int Tb, int Tst, int Hh, int N, int Dv, int io_dtype, int flags, int phases, hipStream_t st)
+{
+    const int T = Tb;
+    const bool defer = ws.nb > 4 && r_out != nullptr;     // > 64 tokens per frame: read-out by its own frame-parallel kernel
+    const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
+    if (phases & 1) {
+        AffArgs sa{q, alpha, s_in, ws.pp, ws.gg, ws.qinv, defer ? nullptr : r_out, s_out, s_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 0, ws.simg,
+                   ws.gmax, ws.esc, Tst};
+        const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
+        if (int rc = io_dtype == GDKVM_F32 ? launch_affine_any<GDKVM_F32>(wide, defer, s_hist != nullptr, sa, grid, st)
+                                           : launch_affine_any<GDKVM_BF16>(wide, defer, s_hist != nullptr, sa, grid, st)) return rc;
+    }
+    if (defer && (phases & 2)) {
+        ReadoutArgs ra{q, ws.qinv, ws.simg, r_out, Hh, N, Dv, 16 * ws.nb, ws.esc, T, Tst};
+        // enough workgroups for two per CU: split the frame's token tiles when frames x column groups alone do not give them
+        unsigned ny = (unsigned)((Dv / 16 + 7) / 8), nz = 1;
+        {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) {
+                int n = 0;
+                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+            }
+            const long wg = (long)B * T * Hh * ny, ntt = (N + 15) / 16;
+            while (wg * nz < 2L * cus && 2 * nz <= (unsigned)(ntt / 2)) nz *= 2;       // (at least two token tiles per workgroup)
+        }
+        const dim3 rgrid((unsigned)(B * T * Hh), ny, nz);
+        if (io_dtype == GDKVM_F32 && wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
+        else if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
+        else if (wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
+        else hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
+        GDKVM_LAUNCH_CHECK("gdr_readout_kernel");
+    }
+    return GDKVM_OK;
+}
+
 extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* s_in, void* r_out, float* s_out,
                                 float* s_hist, const void* workspace, size_t workspace_bytes,
                                 int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int flags, void* stream)
@@ -597,34 +640,7 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
         }
         return GDKVM_OK;
     }
-    const bool defer = ws.nb > 4 && r_out != nullptr;     // > 64 tokens per frame: read-out by its own frame-parallel kernel
-    AffArgs sa{q, alpha, s_in, ws.pp, ws.gg, ws.qinv, defer ? nullptr : r_out, s_out, s_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 0, ws.simg,
-               ws.gmax, ws.esc};
-    const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
-    const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
-    if (int rc = io_dtype == GDKVM_F32 ? launch_affine_any<GDKVM_F32>(wide, defer, s_hist != nullptr, sa, grid, st)
-                                       : launch_affine_any<GDKVM_BF16>(wide, defer, s_hist != nullptr, sa, grid, st)) return rc;
-    if (defer) {
-        ReadoutArgs ra{q, ws.qinv, ws.simg, r_out, Hh, N, Dv, 16 * ws.nb, ws.esc, T};
-        // enough workgroups for two per CU: split the frame's token tiles when frames x column groups alone do not give them
-        unsigned ny = (unsigned)((Dv / 16 + 7) / 8), nz = 1;
-        {
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) == hipSuccess) {
-                int n = 0;
-                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-            }
-            const long wg = (long)B * T * Hh * ny, ntt = (N + 15) / 16;
-            while (wg * nz < 2L * cus && 2 * nz <= (unsigned)(ntt / 2)) nz *= 2;       // (at least two token tiles per workgroup)
-        }
-        const dim3 rgrid((unsigned)(B * T * Hh), ny, nz);
-        if (io_dtype == GDKVM_F32 && wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
-        else if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
-        else if (wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
-        else hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
-        GDKVM_LAUNCH_CHECK("gdr_readout_kernel");
-    }
-    return GDKVM_OK;
+    return gdr_apply_window(q, alpha, s_in, r_out, s_out, s_hist, ws, B, T, T, Hh, N, Dv, io_dtype, flags, 3, st);
 }
 
 extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* phi_out, const void* workspace, size_t workspace_bytes,
@@ -642,6 +658,7 @@ extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* p
     hipError_t e = hipMemsetAsync(ws.zero, 0, 64 * 4 * sizeof(float), st);       // the one G tile every frame and slice reads
     if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_transition: memset: %s", hipGetErrorString(e));
     AffArgs sa{q, alpha, nullptr, ws.pp, ws.zero, ws.qinv, nullptr, phi_out, nullptr, ws.trash, 1, 1, T, Hh, N, GDKVM_DK, flags, B * Hh, 0, nullptr};
+    sa.Tst = T;
     const dim3 grid((unsigned)(B * Hh * (GDKVM_DK / 16)));
     const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
     return io_dtype == GDKVM_F32 ? launch_affine_any<GDKVM_F32>(wide, false, false, sa, grid, st)
@@ -742,6 +759,11 @@ extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const
     }
     if (s_hist) flags |= GDKVM_FLAG_TRAIN;              // the backward reads extra operand layouts from the workspace
     if (rule == GDKVM_RULE_DELTA_PARALLEL) flags |= GDKVM_FLAG_WIDE_RANGE;      // not contractive: full-range operands
+    if (!s_hist && Dk == GDKVM_DK) {                    // inference: the frames as overlapping time blocks where that pays (gdr_pipeline.hip)
+        const int rc = gdr_scan_fwd_blocks(q, k, v, alpha, beta, nullptr, s_in, r_out, s_out, workspace, workspace_bytes, B, T, Hh, N, Dv,
+                                           io_dtype, rule, flags, static_cast<hipStream_t>(stream));
+        if (rc <= 0) return rc;
+    }
     if (int rc = gdkvm_scan_prep(q, k, v, beta, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream)) return rc;
     return gdkvm_scan_apply(q, alpha, s_in, r_out, s_out, s_hist, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, flags, stream);
 }
@@ -794,6 +816,7 @@ int gdr_launch_reverse_scan(const WsView& ws, const float* alpha, const void* d_
         GDKVM_LAUNCH_CHECK("gdr_bwd_g_kernel");
     }
     AffArgs sa{nullptr, alpha, ds_out, ws.ppt, gb, nullptr, nullptr, ds_in, ds_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 1, nullptr};
+    sa.Tst = T;
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
     // gradients have no natural magnitude: the reverse recurrence keeps the full-range three-term bf16 operands (P^T images)
     return io_dtype == GDKVM_F32 ? launch_affine<GDKVM_F32, FMT_SPLIT3, false, true>(sa, grid, st)
