@@ -26,8 +26,8 @@ namespace {
 
 struct PipeRes {
     bool tried = false, ok = false;
-    hipStream_t sp = nullptr, sr = nullptr;
-    hipEvent_t fork = nullptr, join_r = nullptr, evp[GDR_MAX_BLOCKS] = {}, evs[GDR_MAX_BLOCKS] = {};
+    hipStream_t sp = nullptr, sr = nullptr, ss = nullptr;   // ss: the serial kernel of the concurrent form (highest priority)
+    hipEvent_t fork = nullptr, join_r = nullptr, join_s = nullptr, evp[GDR_MAX_BLOCKS] = {}, evs[GDR_MAX_BLOCKS] = {};
 };
 
 // helper streams and events per host thread and device (calls on different host threads never share them), created on first use and
@@ -48,6 +48,8 @@ PipeRes* pipe_res(hipStream_t user)
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
     bool ok = hipStreamCreateWithPriority(&r.sp, hipStreamNonBlocking, least) == hipSuccess
               && hipStreamCreateWithPriority(&r.sr, hipStreamNonBlocking, least) == hipSuccess
+              && hipStreamCreateWithPriority(&r.ss, hipStreamNonBlocking, greatest) == hipSuccess
+              && hipEventCreateWithFlags(&r.join_s, hipEventDisableTiming) == hipSuccess
               && hipEventCreateWithFlags(&r.fork, hipEventDisableTiming) == hipSuccess
               && hipEventCreateWithFlags(&r.join_r, hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < GDR_MAX_BLOCKS; ++i)
@@ -169,5 +171,68 @@ int gdr_scan_fwd_blocks(const void* q, const void* k, const void* v, const float
         PIPE_HIP(hipEventRecord(pr->join_r, pr->sr));
         PIPE_HIP(hipStreamWaitEvent(st, pr->join_r, 0));
     }
+    return GDKVM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The concurrent form (frames of more than 64 tokens, fp16-pair operands).  Event dependencies between the stages cost ~8-10 us each on
+// this system, more than any block of frames hides (profiles/r04_b_time_blocks_on_streams.txt), so here the stages are three kernels that
+// RUN AT THE SAME TIME and hand frames over through counters in the workspace (gdr_device.hpp, "flags"):
+//
+//     caller's stream   [clear counters] fold, time-major ........................ read-out, time-major (waits per frame group on `prog`)
+//     helper stream            serial recurrence (waits per frame group on `prep`, raises `prog`) ........|
+//
+// The fold never waits, the recurrence waits only for the fold, the read-out is launched behind the fold (stream order) and waits only for
+// the recurrence, which is resident by then: no cycle, and every wait is bounded anyway.  One event forks the helper stream at the start
+// (its latency hides behind the fold's first frames) and one joins it at the end (recorded behind the recurrence, which finishes before
+// the read-out does).  Per frame every kernel does what the plain sequence's kernel does, in the same order: the results are
+// bit-identical (tests/test_scan_gpu.py, tests/test_configs_gpu.py at cfg5's full size).
+int gdr_scan_fwd_pipe(const void* q, const void* k, const void* v, const float* alpha, const float* beta, const float* norms,
+                      const float* s_in, void* r_out, float* s_out, void* workspace, size_t workspace_bytes,
+                      int B, int T, int Hh, int N, int Dv, int io_dtype, int rule, int flags, hipStream_t st)
+{
+    if (B <= 0 || T < 2 || N <= 64 || Hh <= 0 || Dv <= 0 || !r_out || (flags & (GDKVM_FLAG_TRAIN | GDKVM_FLAG_WIDE_RANGE))) return 1;
+    // Opt-in (GDKVM_SCAN_PIPE=1), NOT taken by shape: measured at 2 x 512 frames of 256 tokens the form is bit-identical and no faster than
+    // the plain sequence (358 against 346 us) -- the serial kernel is bound by what its CU can fetch per frame, and beside kernels that load
+    // the memory system it slows from 390 to 460-750 ns per frame, which eats what the overlap saves (DESIGN.md §2.6,
+    // profiles/r04_i_pipe_timeline_cfg5.txt, r04_j_scan_alone.txt).
+    const char* take_e = getenv("GDKVM_SCAN_PIPE");
+    if (!take_e || take_e[0] != '1') return 1;
+    if (int rc = check_common("scan_fwd", B, T, Hh, N, GDKVM_DK, Dv, io_dtype, flags)) return rc;
+    if (rule < 0 || rule > 2) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: rule=%d", rule);
+    if (norms && (!(flags & GDKVM_FLAG_NORMALIZE_QK) || !gdkvm_aligned16(norms)))
+        return gdkvm_fail(GDKVM_ERR_ARG, "scan_fwd_normed: norms go with GDKVM_FLAG_NORMALIZE_QK, 16-byte aligned");
+    if (int rc = check_ptrs("scan_fwd", {q, k, v, alpha, beta, r_out, workspace}, {s_in, s_out})) return rc;
+    WsView ws;
+    if (int rc = carve("scan_fwd", workspace, workspace_bytes, B, T, Hh, N, GDKVM_DK, Dv, &ws)) return rc;
+    if (int rc = gdkvm_check_device()) return rc;
+    PipeRes* pr = pipe_res(st);
+    if (!pr) return 1;
+    ws.pipe.prep_per_frame = (unsigned)gdr_prep_producers(ws, B, T, Hh, Dv, io_dtype, rule, flags, GDR_FUSE_AUTO);
+    if (const char* e = getenv("GDKVM_PIPE_DBG")) ws.pipe.dbg = atoi(e);
+    // GDKVM_PIPE_STAGES (timing experiments; results are meaningless unless all three run): bit 0 the fold, bit 1 the recurrence, bit 2 the
+    // read-out; the counters of a stage that is left out are preset as "done"
+    int stages = 7;
+    if (const char* e = getenv("GDKVM_PIPE_STAGES")) stages = atoi(e) & 7;
+    const size_t fbytes = (size_t)B * Hh * ws.pipe.ngrp * sizeof(unsigned);
+    if (stages == 7) PIPE_HIP(hipMemsetAsync(ws.pipe.prep, 0, 2 * fbytes, st));      // prep and prog (adjacent)
+    else {
+        PIPE_HIP(hipMemsetAsync(ws.pipe.prep, (stages & 1) ? 0 : 0x7f, fbytes, st));
+        PIPE_HIP(hipMemsetAsync(ws.pipe.prog, (stages & 2) ? 0 : 0x7f, fbytes, st));
+    }
+    // the recurrence goes FIRST, on the caller's stream: its workgroups take their CUs while the device is empty (8 waves x 192 registers:
+    // beside two workgroups of the fold -- 2 x 232 registers per SIMD -- one never fits, and with the fold launched first the recurrence
+    // got its CUs only when the fold's last round drained: profiles/r04_e_pipe_probe.txt, S3 = the sum); the fold does not fit beside it
+    // either, so the serial chain has its CUs to itself.  The frame-parallel kernels follow on the helper stream.
+    PIPE_HIP(hipEventRecord(pr->fork, st));
+    PIPE_HIP(hipStreamWaitEvent(pr->sp, pr->fork, 0));
+    if (stages & 2)
+        if (int rc = gdr_apply_window(q, alpha, s_in, r_out, s_out, nullptr, ws, B, T, T, Hh, N, Dv, io_dtype, flags, GDR_PHASE_SCAN | GDR_PHASE_PIPE, st)) return rc;
+    if (stages & 1)
+        if (int rc = gdr_prep_window(q, k, v, beta, norms, ws, B, T, T, Hh, N, Dv, io_dtype, rule, flags, GDR_FUSE_AUTO, pr->sp, true)) return rc;
+    if (stages & 4)
+        if (int rc = gdr_apply_window(q, alpha, nullptr, r_out, nullptr, nullptr, ws, B, T, T, Hh, N, Dv, io_dtype, flags, GDR_PHASE_READOUT | GDR_PHASE_PIPE, pr->sp)) return rc;
+    PIPE_HIP(hipEventRecord(pr->join_r, pr->sp));
+    PIPE_HIP(hipStreamWaitEvent(st, pr->join_r, 0));
     return GDKVM_OK;
 }

@@ -11,13 +11,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gdkvm_amd import ops  # noqa: E402
 from tools.config_sweep import ev_time  # noqa: E402
 
-SHAPES = {"cfg2": (16, 32, 49), "cfg3": (8, 20, 256), "cfg5": (2, 512, 256), "cfg5c": (2, 32, 256), "cfg5h": (2, 128, 256)}
+SHAPES = {"cfg2": (16, 32, 49), "cfg3": (8, 20, 256), "cfg5": (2, 512, 256), "cfg5c": (2, 32, 256), "cfg5h": (2, 128, 256), "cfg5l": (1, 300, 200)}
 PLANS = {
     "cfg2": ["1", "2", "4", "L8", "L4,12", "L4,8,16"],
-    "cfg3": ["1", "2", "4", "5", "L4", "L2,6,12", "L2,8,14"],
-    "cfg5": ["1", "2", "4", "8", "16", "L32,128,256,384", "L16,64,192,320,448", "L64,192,320,448", "L32,96,224,352,480"],
-    "cfg5c": ["1", "2", "4", "L8"],
-    "cfg5h": ["1", "2", "4", "L16,48,80,112"],
+    "cfg3": ["1", "P", "P140", "S1", "S2", "S4", "S3", "S5", "S6"],
+    "cfg5": ["1", "P", "P140", "S1", "S2", "S4", "S3", "S5", "S6"],
+    "cfg5c": ["1", "P"],
+    "cfg5h": ["1", "P", "P140"],
+    "cfg5l": ["1", "P"],
 }
 
 
@@ -27,7 +28,17 @@ GRAPH = os.environ.get("BLOCK_PROBE_GRAPH", "1") == "1"
 def set_plan(p):
     os.environ.pop("GDKVM_SCAN_BLOCKS", None)
     os.environ.pop("GDKVM_SCAN_BLOCK_LIST", None)
-    if p.startswith("L"):
+    os.environ.pop("GDKVM_PIPE_SCAN_LDS_KB", None)
+    os.environ.pop("GDKVM_PIPE_STAGES", None)
+    os.environ["GDKVM_SCAN_PIPE"] = "0"
+    if p.startswith("S"):                                  # timing only: a subset of the concurrent form's stages (1 fold, 2 recurrence, 4 read-out)
+        os.environ["GDKVM_SCAN_PIPE"] = "1"
+        os.environ["GDKVM_PIPE_STAGES"] = p[1:]
+    elif p.startswith("P"):                                # the concurrent form (flags), optionally with the serial workgroups' LDS padded
+        os.environ["GDKVM_SCAN_PIPE"] = "1"
+        if len(p) > 1:
+            os.environ["GDKVM_PIPE_SCAN_LDS_KB"] = p[1:]
+    elif p.startswith("L"):
         os.environ["GDKVM_SCAN_BLOCK_LIST"] = p[1:]
     else:
         os.environ["GDKVM_SCAN_BLOCKS"] = p
@@ -39,7 +50,7 @@ def main():
     Dv = 256
     for name in names:
         B, T, N = SHAPES[name]
-        for dt in (torch.bfloat16,):
+        for dt in (torch.bfloat16, torch.float32) if os.environ.get("BLOCK_PROBE_F32") else (torch.bfloat16,):
             g = torch.Generator(device=dev).manual_seed(1)
             q, k = (torch.randn(B, T, N, 1, 64, device=dev, generator=g).to(dt) for _ in range(2))
             v = torch.randn(B, T, N, 1, Dv, device=dev, generator=g).to(dt)
@@ -56,13 +67,19 @@ def main():
                 ops.scan_fwd(q, k, v, al, be, s0, flags=3, workspace=ws, out=r, state_out=s)
 
             ref = None
-            for plan in PLANS[name]:
+            for plan in (os.environ["BLOCK_PROBE_PLANS"].split(";") if os.environ.get("BLOCK_PROBE_PLANS") else PLANS[name]):
                 set_plan(plan)
                 r.zero_(); s.zero_()
                 run(); torch.cuda.synchronize()
                 if ref is None:
                     ref = (r.clone(), s.clone())
                 same = torch.equal(r, ref[0]) and torch.equal(s, ref[1])
+                if not same and not plan.startswith("S"):                               # where: which frames' read-outs differ, and the final state
+                    d = (r.float() - ref[0].float()).abs().amax(dim=(2, 3, 4))                     # [B, T]
+                    bad_t = (d != 0).any(0).nonzero().flatten().tolist()
+                    print(f"   read-out: {int((r != ref[0]).sum())} of {r.numel()} differ, max |d| {float(d.max()):.3g}, nan {int(torch.isnan(r.float()).sum())}, "
+                          f"frames {bad_t[:12]}{'...' if len(bad_t) > 12 else ''} ({len(bad_t)} of {T});  state: {int((s != ref[1]).sum())} of {s.numel()} differ, "
+                          f"max |d| {float((s - ref[1]).abs().max()):.3g}", flush=True)
                 t = ev_time(run, iters=20 if T < 256 else 10)
                 tg = float("nan")
                 if GRAPH:                                  # the same call captured once and replayed: what the host's enqueue time hides
