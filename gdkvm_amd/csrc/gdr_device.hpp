@@ -264,54 +264,3 @@ static __device__ __forceinline__ float fast_sigmoid(float x)
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 
-// ---- flags between kernels that run AT THE SAME TIME on different streams (gdr_pipeline.hip) ----------------------------------
-// A producer workgroup writes its results with agent-scope stores (sc1: written through its XCD's L2, the eight L2s of the device are not
-// coherent with one another), waits for them (s_waitcnt vmcnt(0): gfx9 counts stores there), and only then adds to the consumer's counter;
-// the consumer polls the counter with agent-scope loads and reads the data with plain loads -- it has never touched those lines in this
-// launch, and a launch starts with its L2's non-local lines invalidated.  No fence on either side (an agent-scope release fence writes
-// back a whole L2: ~38 us; an acquire ~6 us -- tools/experiments/fence_probe.hip); measured across all eight XCDs over re-used buffers:
-// tools/experiments/xcd_flag_probe.hip, profiles/r04_c_xcd_flag_probe.txt.  Every wait gives up after a bounded number of polls (a
-// launch must drain whatever happened to its producer); the caller poisons its outputs with NaNs then.
-// (s_nop behind the wide store: the compiler's hazard recogniser does not see into the asm, and a VMEM store of more than 64 bits needs a
-// wait state before its data registers are overwritten)
-static __device__ __forceinline__ void st_agent(f32x4* p, const f32x4& v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 0" ::"v"(p), "v"(v) : "memory"); }
-static __device__ __forceinline__ void st_agent(uint4* p, const uint4& v) { st_agent(reinterpret_cast<f32x4*>(p), __builtin_bit_cast(f32x4, v)); }
-static __device__ __forceinline__ void st_agent(float* p, float v) { asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-static __device__ __forceinline__ void st_agent(unsigned short* p, unsigned short v) { asm volatile("global_store_short %0, %1, off sc1" ::"v"(p), "v"((unsigned)v) : "memory"); }
-template <bool AGENT, class P, class V> static __device__ __forceinline__ void st_out(P* p, const V& v)
-{
-    if constexpr (AGENT) st_agent(p, v);
-    else *p = v;
-}
-static __device__ __forceinline__ void stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-static __device__ __forceinline__ void flag_add(unsigned* f, unsigned n) { __hip_atomic_fetch_add(f, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-constexpr int GDR_FLAG_POLLS = 200000;               // polls that back off to ~4 us apart: ~0.5 s, then the wait gives up
-static __device__ __forceinline__ bool flag_wait_ge(const unsigned* f, unsigned target)
-{
-    int polls = 0;
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (++polls > GDR_FLAG_POLLS) return false;
-        // back off: every poll is a round trip to memory (agent scope), and a whole grid may be watching the same counter
-        if (polls < 8) __builtin_amdgcn_s_sleep(8);
-        else if (polls < 32) __builtin_amdgcn_s_sleep(32);
-        else __builtin_amdgcn_s_sleep(127);
-    }
-    asm volatile("" ::: "memory");                    // (the compiler keeps the data loads behind the poll)
-    return true;
-}
-
-// ---- diagnostic build only (-DGDKVM_PIPE_STAMPS, tools/pipe_timeline.py): wall-clock stamps (s_memrealtime, 100 MHz) of the concurrent
-// form's three kernels -- fold [frame-head][2] start / end, recurrence [clip-head x slice][64] start + the end of every group, read-out
-// [frame-head][3] start / counter seen / end; the buffers travel in the kernels' argument structs.  Never compiled into the product library.
-#ifdef GDKVM_PIPE_STAMPS
-extern unsigned long long* g_pipe_stamps_host[3];    // (host side; gdr_scan.hip: gdkvm_pipe_set_stamps)
-static __device__ __forceinline__ void pipe_stamp(unsigned long long* base, size_t idx)
-{
-    unsigned long long t;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    if (base) base[idx] = t;
-}
-#define PIPE_STAMP(base, idx, cond) do { if (cond) pipe_stamp(base, idx); } while (0)
-#else
-#define PIPE_STAMP(base, idx, cond) do {} while (0)
-#endif

@@ -383,14 +383,7 @@ struct PrepMArgs {
     float* x0; float* ppc; float* ggc;                  // frames of more than 64 tokens: chunk 0 -> x0, chunk c >= 1 -> ppc/ggc[c-1]
     int T, Hh, N, Dv, rule, flags, np_total;            // N = tokens of the frame, np_total = its padded count (qinv row length)
     int nchunk;                                         // FUSE: 64-token chunks per frame, walked by ONE workgroup (else gridDim.y)
-    int grid3;                                          // launched as (8, T, B / 8): frame = (x + 8 z) Tst + y, no division (one chunk, one head)
-    int Tst;                                            // frames between consecutive clips: T, or the whole clip's length for a window of T frames per clip
-    // FUSE only -- the producer side of the concurrent form (gdr_pipeline.hip; protocol: gdr_device.hpp): workgroups take the frames in
-    // time-major order, write the frame's map through (agent scope) and add 1 to pflag[clip-head][frame / pG]
-    unsigned* pflag; int pG, pngrp;
-#ifdef GDKVM_PIPE_STAMPS
-    unsigned long long* stamps;
-#endif
+    int grid3;                                          // launched as (8, T, B / 8): frame = (x + 8 z) T + y, no division (one chunk, one head)
 #ifdef GDKVM_DIAG
     unsigned long long* diag;
 #endif
@@ -464,31 +457,22 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     {
         const unsigned gdx = gridDim.x, gdy = gridDim.y;
         asm volatile("" :: "s"(a.q), "s"(a.k), "s"(a.v), "s"(a.beta), "s"(a.qinv), "s"(a.pp), "s"(a.gg), "s"(a.gmax), "s"(a.norms),
-                     "s"(a.T), "s"(a.Hh), "s"(a.N), "s"(a.Dv), "s"(a.rule), "s"(a.flags), "s"(a.np_total), "s"(a.nchunk), "s"(a.grid3), "s"(a.Tst), "s"(a.pflag), "s"(gdx), "s"(gdy));
+                     "s"(a.T), "s"(a.Hh), "s"(a.N), "s"(a.Dv), "s"(a.rule), "s"(a.flags), "s"(a.np_total), "s"(a.nchunk), "s"(a.grid3), "s"(gdx), "s"(gdy));
     }
     // XCD-aware: the serial kernel runs clip-head bh on XCD bh % 8 (when their count is a multiple of 8); fold the frames of
     // that clip-head on the same XCD so its P and G are read from the L2 they were written through (speed only)
-    int fh = blockIdx.x, pipe_t = 0, pipe_bh = 0;
+    int fh = blockIdx.x;
     if (a.grid3) {
         // (the common case -- one head, frames of at most 64 tokens, clips a multiple of 8 -- comes as a 3-D grid whose x is the XCD:
         // the integer divisions of the 1-D decoding stood between the kernel's entry and its first load)
-        fh = ((int)blockIdx.x + 8 * (int)blockIdx.z) * a.Tst + (int)blockIdx.y;
+        fh = ((int)blockIdx.x + 8 * (int)blockIdx.z) * (int)gridDim.y + (int)blockIdx.y;
     } else {
         const int BH = (int)(gridDim.x / a.T), per_clip = a.T * a.Hh;       // gridDim.x = B * T * Hh; BH = B * Hh clip-heads
         if (BH % 8 == 0 && a.Hh == 1) {
             const int x = blockIdx.x, xcd = x & 7, idx = x >> 3;
             fh = (xcd + 8 * (idx / per_clip)) * per_clip + idx % per_clip;
         }
-        if (a.Tst != a.T) fh += (fh / per_clip) * (a.Tst - a.T) * a.Hh;    // a window of T frames per clip: clips lie Tst frames apart
-        if constexpr (FUSE) {
-            if (a.pflag) {                                 // time-major: frame t of every clip-head, then frame t + 1
-                const int bh = (int)blockIdx.x % BH;
-                pipe_t = (int)blockIdx.x / BH; pipe_bh = bh;
-                fh = ((bh / a.Hh) * a.Tst + pipe_t) * a.Hh + bh % a.Hh;
-            }
-        }
     }
-    PIPE_STAMP(a.stamps, (size_t)fh * 2, FUSE && tid == 0);
     const int h = a.Hh == 1 ? 0 : fh % a.Hh;
     const int Ntot = a.N, nchunk = FUSE ? a.nchunk : (a.grid3 ? 1 : (int)gridDim.y);
     // FUSE (frames of more than 64 tokens, many frames): this workgroup walks the frame's chunks itself and carries the frame's
@@ -1319,50 +1303,38 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     }   // chunks
     if constexpr (FUSE) {
         // the frame's map in the formats the scan consumes (as gdr_compose_kernel's last step): P tile (m, w) -> the term images of
-        // row tile m, G tiles in the scan's scale.  AGENT: written through for a serial kernel that is already running (a.pflag)
+        // row tile m, G tiles in the scan's scale
         const int nsl = a.Dv / 16;
-        auto emit = [&](auto agent_c) __attribute__((always_inline)) {
-            constexpr bool AGENT = decltype(agent_c)::value;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                unsigned short* img = reinterpret_cast<unsigned short*>(a.pp) + (size_t)fh * (4 * 3 * SPLIT_IMG * 4) + m * (NT * SPLIT_IMG * 4);
+        for (int m = 0; m < 4; ++m) {
+            unsigned short* img = reinterpret_cast<unsigned short*>(a.pp) + (size_t)fh * (4 * 3 * SPLIT_IMG * 4) + m * (NT * SPLIT_IMG * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    unsigned short tt[3];
-                    OpFmt<FMT>::split1(X[m][0][r], tt);
-                    const int e = split_slot(w, li >> 2, 4 * g + r) * 4 + (li & 3);
+            for (int r = 0; r < 4; ++r) {
+                unsigned short tt[3];
+                OpFmt<FMT>::split1(X[m][0][r], tt);
+                const int e = split_slot(w, li >> 2, 4 * g + r) * 4 + (li & 3);
 #pragma unroll
-                    for (int sp = 0; sp < NT; ++sp) st_out<AGENT>(img + sp * SPLIT_IMG * 4 + e, tt[sp]);
-                }
+                for (int sp = 0; sp < NT; ++sp) img[sp * SPLIT_IMG * 4 + e] = tt[sp];
             }
-            f32x4* gout = reinterpret_cast<f32x4*>(a.gg) + (size_t)fh * nsl * 4 * 64;
-            // an intermediate of the composition beyond the fp16 pair's range (|x| 2^-4 >= 65504: values ~1e6 times the usual) is
-            // reported as +inf and the scan answers with NaNs -- never a silently saturated map
-            const bool sat = wave_max_nonneg(xsplit_max) * OpFmt<FMT>::STATE >= PAIR_SAT;
-            static_for<1, 5>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                const int cV = w + 4 * (j - 1);
-                if (cV < nsl) {
-                    float gm = 0.f;
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        st_out<AGENT>(gout + ((size_t)cV * 4 + m) * 64 + lane, X[m][j] * OpFmt<FMT>::STATE);
-                        gm = fmaxf(gm, absmax4(X[m][j]));
-                    }
-                    gm = sat ? __builtin_inff() : wave_max_nonneg(gm);
-                    if (lane == 0) st_out<AGENT>(reinterpret_cast<f32x4*>(a.gmax + ((size_t)fh * nsl + cV) * 4), f32x4{gm, 0.f, 0.f, 0.f});
-                }
-            });
-        };
-        if (a.pflag) {
-            emit(std::true_type{});
-            stores_done();
-            __syncthreads();
-            if (tid == 0) flag_add(a.pflag + (size_t)pipe_bh * a.pngrp + pipe_t / a.pG, 1u);
-        } else {
-            emit(std::false_type{});
         }
-        PIPE_STAMP(a.stamps, (size_t)fh * 2 + 1, tid == 0);
+        f32x4* gout = reinterpret_cast<f32x4*>(a.gg) + (size_t)fh * nsl * 4 * 64;
+        // an intermediate of the composition beyond the fp16 pair's range (|x| 2^-4 >= 65504: values ~1e6 times the usual) is
+        // reported as +inf and the scan answers with NaNs -- never a silently saturated map
+        const bool sat = wave_max_nonneg(xsplit_max) * OpFmt<FMT>::STATE >= PAIR_SAT;
+        static_for<1, 5>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int cV = w + 4 * (j - 1);
+            if (cV < nsl) {
+                float gm = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    gout[((size_t)cV * 4 + m) * 64 + lane] = X[m][j] * OpFmt<FMT>::STATE;
+                    gm = fmaxf(gm, absmax4(X[m][j]));
+                }
+                gm = sat ? __builtin_inff() : wave_max_nonneg(gm);
+                if (lane == 0) *reinterpret_cast<f32x4*>(a.gmax + ((size_t)fh * nsl + cV) * 4) = f32x4{gm, 0.f, 0.f, 0.f};
+            }
+        });
     }
 }
 
@@ -1425,11 +1397,7 @@ int launch_prepm(const PrepMArgs& pa, int FH, int nchunk, bool wide, bool fuse, 
 // accumulators, wave w = row tile w) through all steps, exactly like the serial scan carries S -- P_c as three-term A
 // images (as prepm wrote them), the running columns re-split into three-term B images through LDS each step.
 // Output: the final P as term images (pp) and G as accumulator images (gg), the formats the scan consumes.
-struct ComposeArgs {
-    const float* x0; const float* ppc; const float* ggc; float* pp; float* gg; int Dv, nchunk, additive; float* gmax; int per_clip, skip;
-    // the producer side of the concurrent form (as PrepMArgs): time-major frames, results written through, one count per workgroup
-    unsigned* pflag; int pG, pngrp, Hh, BH;
-};
+struct ComposeArgs { const float* x0; const float* ppc; const float* ggc; float* pp; float* gg; int Dv, nchunk, additive; float* gmax; };
 
 template <int FMT>
 __global__ __launch_bounds__(256, 2) void gdr_compose_kernel(ComposeArgs a)       // (256 registers: MFMA results in VGPRs; with 512 they land in AGPRs and are copied out)
@@ -1438,17 +1406,8 @@ __global__ __launch_bounds__(256, 2) void gdr_compose_kernel(ComposeArgs a)     
     __shared__ __attribute__((aligned(16))) uint2 s_X3[4 * NT * SPLIT_IMG];       // [col tile j][term] B images (pair16: at 2^-4)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // (a window of frames per clip: per_clip frame-heads of the launch per clip, `skip` more between consecutive clips)
-    size_t fh = blockIdx.x + (a.skip ? (size_t)(blockIdx.x / (unsigned)a.per_clip) * a.skip : 0);
-    unsigned by = blockIdx.y;
-    int pipe_t = 0, pipe_bh = 0;
-    if (a.pflag) {                                         // time-major: the column groups of frame t of every clip-head, then frame t + 1
-        const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, f = L / gridDim.y;
-        by = L % gridDim.y;
-        pipe_bh = (int)(f % (unsigned)a.BH); pipe_t = (int)(f / (unsigned)a.BH);
-        fh = (size_t)(pipe_bh / a.Hh) * (a.per_clip + a.skip) + (size_t)pipe_t * a.Hh + pipe_bh % a.Hh;      // (per_clip + skip = frame-heads between clips)
-    }
-    const int nsl = a.Dv / 16, ncol = 4 + nsl, c0 = 4 * by;                       // this block's column tiles c0 .. c0+3 of [P | G]
+    const size_t fh = blockIdx.x;
+    const int nsl = a.Dv / 16, ncol = 4 + nsl, c0 = 4 * blockIdx.y;               // this block's column tiles c0 .. c0+3 of [P | G]
     f32x4 X[4];
     float xsplit_max = 0.f;                                // pair16: largest |entry| this wave re-split into fp16 pairs (checked at the end)
     const f32x4* x0 = reinterpret_cast<const f32x4*>(a.x0) + fh * ncol * 4 * 64;
@@ -1507,37 +1466,26 @@ __global__ __launch_bounds__(256, 2) void gdr_compose_kernel(ComposeArgs a)     
         __syncthreads();                                   // the images are rewritten in the next step
     }
     const bool sat = wave_max_nonneg(xsplit_max) * OpFmt<FMT>::STATE >= PAIR_SAT;
-    auto emit = [&](auto agent_c) __attribute__((always_inline)) {
-        constexpr bool AGENT = decltype(agent_c)::value;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = c0 + j;
-            if (col >= ncol) continue;
-            if (col < 4) {                                 // P[16w + 4g + r][k = 16 col + li] -> term images of row tile w
+    for (int j = 0; j < 4; ++j) {
+        const int col = c0 + j;
+        if (col >= ncol) continue;
+        if (col < 4) {                                     // P[16w + 4g + r][k = 16 col + li] -> term images of row tile w
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    unsigned short tt[3];
-                    OpFmt<FMT>::split1(X[j][r], tt);
-                    unsigned short* img = reinterpret_cast<unsigned short*>(a.pp) + fh * (size_t)(4 * 3 * SPLIT_IMG * 4) + w * (NT * SPLIT_IMG * 4);
-                    const int e = split_slot(col, li >> 2, 4 * g + r) * 4 + (li & 3);
+            for (int r = 0; r < 4; ++r) {
+                unsigned short tt[3];
+                OpFmt<FMT>::split1(X[j][r], tt);
+                unsigned short* img = reinterpret_cast<unsigned short*>(a.pp) + fh * (size_t)(4 * 3 * SPLIT_IMG * 4) + w * (NT * SPLIT_IMG * 4);
+                const int e = split_slot(col, li >> 2, 4 * g + r) * 4 + (li & 3);
 #pragma unroll
-                    for (int sp = 0; sp < NT; ++sp) st_out<AGENT>(img + sp * SPLIT_IMG * 4 + e, tt[sp]);
-                }
-            } else {
-                st_out<AGENT>(reinterpret_cast<f32x4*>(a.gg) + ((fh * nsl + (col - 4)) * 4 + w) * 64 + lane, X[j] * OpFmt<FMT>::STATE);   // the scan carries S * STATE
-                // range bookkeeping (gdr_ws.hpp: gmax): this wave's row tile; +inf when a composition step left the fp16 pair's range
-                const float mx = sat ? __builtin_inff() : wave_max_nonneg(absmax4(X[j]));
-                if (lane == 0) st_out<AGENT>(a.gmax + (fh * nsl + (col - 4)) * 4 + w, mx);
+                for (int sp = 0; sp < NT; ++sp) img[sp * SPLIT_IMG * 4 + e] = tt[sp];
             }
+        } else {
+            reinterpret_cast<f32x4*>(a.gg)[((fh * nsl + (col - 4)) * 4 + w) * 64 + lane] = X[j] * OpFmt<FMT>::STATE;   // the scan carries S * STATE
+            // range bookkeeping (gdr_ws.hpp: gmax): this wave's row tile; +inf when a composition step left the fp16 pair's range
+            const float mx = sat ? __builtin_inff() : wave_max_nonneg(absmax4(X[j]));
+            if (lane == 0) a.gmax[(fh * nsl + (col - 4)) * 4 + w] = mx;
         }
-    };
-    if (a.pflag) {
-        emit(std::true_type{});
-        stores_done();
-        __syncthreads();
-        if (tid == 0) flag_add(a.pflag + (size_t)pipe_bh * a.pngrp + pipe_t / a.pG, 1u);
-    } else {
-        emit(std::false_type{});
     }
 }
 
@@ -1563,68 +1511,6 @@ extern "C" size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk
     return gdr_workspace_bytes(B, T, Hh, N, Dk, Dv);
 }
 
-static bool prep_fuse_choice(const WsView& ws, int B, int T, int Hh, int Dv, int io_dtype, int rule, int flags, int fuse_req)
-{
-    bool fuse = false;
-    if (ws.nchunk > 1 && io_dtype == GDKVM_BF16 && !(flags & GDKVM_FLAG_WIDE_RANGE) && rule != GDKVM_RULE_DELTA_PARALLEL && Dv % 64 == 0 && Dv <= 256) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            int n = 0;
-            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        }
-        fuse = (long)B * T * Hh >= cus;               // measured crossover at N = 256, Dv = 256: 256 frames (54 us either way)
-        if (fuse_req != GDR_FUSE_AUTO) fuse = fuse_req != 0;
-        if (const char* e = getenv("GDKVM_PREP_FUSE")) fuse = e[0] == '1';     // "0" / "1": overrides the choice by frame count (tests, A/B)
-    }
-    return fuse;
-}
-
-// counts one finished frame-head adds to its group's `prep` counter in the concurrent form: the fused walk is one workgroup per frame-head,
-// the composition one per four column tiles of [P | G]
-int gdr_prep_producers(const WsView& ws, int B, int Tb, int Hh, int Dv, int io_dtype, int rule, int flags, int fuse)
-{
-    return prep_fuse_choice(ws, B, Tb, Hh, Dv, io_dtype, rule, flags, fuse) ? 1 : (4 + Dv / 16 + 3) / 4;
-}
-
-// The inference-side fold (P and G per frame; frames of more than 64 tokens per 64-token chunk, then composed) over a window of Tb frames per
-// clip, clips Tst frames apart (gdr_ws.hpp).  fuse: GDR_FUSE_AUTO = by the window's frame count, 0 / 1 = the chunk-parallel workgroups /
-// the fused chunk walk where its conditions hold (the two are bit-identical; a caller that overlaps several windows knows the device is full).
-int gdr_prep_window(const void* q, const void* k, const void* v, const float* beta, const float* norms, const WsView& ws,
-                    int B, int Tb, int Tst, int Hh, int N, int Dv, int io_dtype, int rule, int flags, int fuse_req, hipStream_t st, bool pipe)
-{
-    const int T = Tb;
-    PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, ws.gmax, norms, ws.x0, ws.ppc, ws.ggc, T, Hh, N, Dv, rule, flags, 16 * ws.nb, ws.nchunk};
-    pm.Tst = Tst;
-    pm.pflag = nullptr; pm.pG = 1; pm.pngrp = 1;
-#ifdef GDKVM_PIPE_STAMPS
-    pm.stamps = pipe ? g_pipe_stamps_host[0] : nullptr;
-#endif
-#ifdef GDKVM_DIAG
-    pm.diag = g_gdkvm_diag_buf;
-#endif
-    const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
-    // Frames of more than 64 tokens: with enough frames to fill the device on their own, ONE workgroup walks a frame's chunks and
-    // composes its map in registers (no chunk maps through HBM, no compose kernel); with few frames the chunks run as separate
-    // workgroups (4x the parallelism) and gdr_compose_kernel stitches them.  bf16 I/O on pair16 operands, Dv <= 256 in
-    // multiples of 64 (five column tiles of accumulators per wave), not delta_parallel (its chunks add up instead).
-    const bool fuse = prep_fuse_choice(ws, B, T, Hh, Dv, io_dtype, rule, flags, fuse_req);
-    if (pipe) {                                            // the producer of a serial kernel that is already running (gdr_pipeline.hip)
-        if (ws.nchunk < 2 || wide) return gdkvm_fail(GDKVM_ERR_ARG, "scan prep: the concurrent form serves frames of more than 64 tokens on fp16-pair operands");
-        if (fuse) { pm.pflag = ws.pipe.prep; pm.pG = ws.pipe.G; pm.pngrp = ws.pipe.ngrp; }
-    }
-    if (int rc = io_dtype == GDKVM_F32 ? launch_prepm<4, GDKVM_F32>(pm, B * T * Hh, ws.nchunk, wide, false, st)
-                                       : launch_prepm<4, GDKVM_BF16>(pm, B * T * Hh, ws.nchunk, wide, fuse, st)) return rc;
-    if (ws.nchunk > 1 && !fuse) {
-        ComposeArgs ca{ws.x0, ws.ppc, ws.ggc, ws.pp, ws.gg, Dv, ws.nchunk, rule == GDKVM_RULE_DELTA_PARALLEL, ws.gmax, T * Hh, (Tst - T) * Hh,
-                       pipe ? ws.pipe.prep : nullptr, ws.pipe.G, ws.pipe.ngrp, Hh, B * Hh};
-        const dim3 cgrid((unsigned)(B * T * Hh), (unsigned)((4 + Dv / 16 + 3) / 4));
-        if (wide) hipLaunchKernelGGL(gdr_compose_kernel<FMT_SPLIT3>, cgrid, dim3(256), 0, st, ca);
-        else hipLaunchKernelGGL(gdr_compose_kernel<FMT_PAIR16>, cgrid, dim3(256), 0, st, ca);
-        GDKVM_LAUNCH_CHECK("gdr_compose_kernel");
-    }
-    return GDKVM_OK;
-}
-
 static int scan_prep_impl(const void* q, const void* k, const void* v, const float* beta, const float* norms, void* workspace, size_t workspace_bytes,
                           int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, void* stream)
 {
@@ -1638,8 +1524,37 @@ static int scan_prep_impl(const void* q, const void* k, const void* v, const flo
     if (int rc = carve("scan_prep", workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
     if (int rc = gdkvm_check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!(flags & GDKVM_FLAG_TRAIN) || ws.nchunk > 1)    // P and G directly (frames of > 64 tokens: per 64-token chunk, then composed)
-        return gdr_prep_window(q, k, v, beta, norms, ws, B, T, T, Hh, N, Dv, io_dtype, rule, flags, GDR_FUSE_AUTO, st);
+    if (!(flags & GDKVM_FLAG_TRAIN) || ws.nchunk > 1) {  // P and G directly (frames of > 64 tokens: per 64-token chunk, then composed)
+        PrepMArgs pm{q, k, v, beta, ws.qinv, ws.pp, ws.gg, ws.gmax, norms, ws.x0, ws.ppc, ws.ggc, T, Hh, N, Dv, rule, flags, 16 * ws.nb, ws.nchunk};
+#ifdef GDKVM_DIAG
+        pm.diag = g_gdkvm_diag_buf;
+#endif
+        const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
+        // Frames of more than 64 tokens: with enough frames to fill the device on their own, ONE workgroup walks a frame's chunks and
+        // composes its map in registers (no chunk maps through HBM, no compose kernel); with few frames the chunks run as separate
+        // workgroups (4x the parallelism) and gdr_compose_kernel stitches them.  bf16 I/O on pair16 operands, Dv <= 256 in
+        // multiples of 64 (five column tiles of accumulators per wave), not delta_parallel (its chunks add up instead).
+        bool fuse = false;
+        if (ws.nchunk > 1 && io_dtype == GDKVM_BF16 && !wide && rule != GDKVM_RULE_DELTA_PARALLEL && Dv % 64 == 0 && Dv <= 256) {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) {
+                int n = 0;
+                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+            }
+            fuse = (long)B * T * Hh >= cus;               // measured crossover at N = 256, Dv = 256: 256 frames (54 us either way)
+            if (const char* e = getenv("GDKVM_PREP_FUSE")) fuse = e[0] == '1';     // "0" / "1": overrides the choice by frame count (tests, A/B)
+        }
+        if (int rc = io_dtype == GDKVM_F32 ? launch_prepm<4, GDKVM_F32>(pm, B * T * Hh, ws.nchunk, wide, false, st)
+                                           : launch_prepm<4, GDKVM_BF16>(pm, B * T * Hh, ws.nchunk, wide, fuse, st)) return rc;
+        if (ws.nchunk > 1 && !fuse) {
+            ComposeArgs ca{ws.x0, ws.ppc, ws.ggc, ws.pp, ws.gg, Dv, ws.nchunk, rule == GDKVM_RULE_DELTA_PARALLEL, ws.gmax};
+            const dim3 cgrid((unsigned)(B * T * Hh), (unsigned)((4 + Dv / 16 + 3) / 4));
+            if (wide) hipLaunchKernelGGL(gdr_compose_kernel<FMT_SPLIT3>, cgrid, dim3(256), 0, st, ca);
+            else hipLaunchKernelGGL(gdr_compose_kernel<FMT_PAIR16>, cgrid, dim3(256), 0, st, ca);
+            GDKVM_LAUNCH_CHECK("gdr_compose_kernel");
+        }
+        return GDKVM_OK;
+    }
     // training, <= 64 tokens: the WY factors the backward consumes, then folded
     PrepArgs pa{q, k, v, beta, ws.wt, ws.knT, ws.ut, ws.qinv, ws.kn, ws.wtT, ws.qnT, ws.tii, ws.wti, T, Hh, N, Dv, rule, flags};
     if (int rc = io_dtype == GDKVM_F32 ? launch_prep<4, GDKVM_F32, 5>(pa, B * T * Hh, st) : launch_prep<4, GDKVM_BF16, 5>(pa, B * T * Hh, st)) return rc;
@@ -1669,14 +1584,6 @@ extern "C" int gdkvm_scan_fwd_normed(const void* q, const void* k, const void* v
 {
     if (Dk != GDKVM_DK) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd_normed: Dk=%d (the norms path is built for Dk=%d)", Dk, GDKVM_DK);
     if (rule == GDKVM_RULE_DELTA_PARALLEL) flags |= GDKVM_FLAG_WIDE_RANGE;      // as gdkvm_scan_fwd
-    if (norms) {                                        // as gdkvm_scan_fwd: overlapping time blocks where that pays (gdr_pipeline.hip)
-        int rc = gdr_scan_fwd_pipe(q, k, v, alpha, beta, norms, s_in, r_out, s_out, workspace, workspace_bytes, B, T, Hh, N, Dv,
-                                   io_dtype, rule, flags, static_cast<hipStream_t>(stream));
-        if (rc <= 0) return rc;
-        rc = gdr_scan_fwd_blocks(q, k, v, alpha, beta, norms, s_in, r_out, s_out, workspace, workspace_bytes, B, T, Hh, N, Dv,
-                                 io_dtype, rule, flags, static_cast<hipStream_t>(stream));
-        if (rc <= 0) return rc;
-    }
     if (int rc = gdkvm_scan_prep_normed(q, k, v, beta, norms, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream)) return rc;
     return gdkvm_scan_apply(q, alpha, s_in, r_out, s_out, nullptr, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, flags, stream);
 }

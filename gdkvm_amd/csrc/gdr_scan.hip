@@ -22,14 +22,6 @@
 #include "gdr_device.hpp"
 #include "gdr_ws.hpp"
 
-#ifdef GDKVM_PIPE_STAMPS
-unsigned long long* g_pipe_stamps_host[3] = {nullptr, nullptr, nullptr};
-extern "C" int gdkvm_pipe_set_stamps(unsigned long long* fold, unsigned long long* scan, unsigned long long* readout)
-{
-    g_pipe_stamps_host[0] = fold; g_pipe_stamps_host[1] = scan; g_pipe_stamps_host[2] = readout;
-    return 0;
-}
-#endif
 #ifdef GDKVM_DIAG
 unsigned long long* g_gdkvm_diag_buf = nullptr;
 extern "C" void gdkvm_diag_set_buffer(unsigned long long* p) { g_gdkvm_diag_buf = p; }
@@ -57,11 +49,6 @@ struct AffArgs {
     float* simg;                                     // DEFER: per-frame operand images of the state for gdr_readout_kernel
     const float* gmax;                               // pair16: max |G| per frame and slice from the frame-parallel side (NULL: default exponent)
     float* esc;                                      // DEFER, pair16: 2^e of this (clip-head, slice) for gdr_readout_kernel
-    int Tst;                                         // frames between consecutive clips in every [B, T, ...] tensor and workspace region: T, or the
-                                                     // whole clip's length when the call covers a window of T frames per clip (gdr_pipeline.hip)
-#ifdef GDKVM_PIPE_STAMPS
-    unsigned long long* stamps;
-#endif
 };
 // LDS (16-byte units): S term images [2 parities][NT terms][2 ksteps][64] | (fp32 I/O on split3) S fp32 images [2][4][64]
 template <int IO> struct RItem;                                        // read-out operands of one 16-token tile
@@ -110,8 +97,7 @@ __global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
         else { bh = x / nsl; sl = x % nsl; }
     }
     const int b = bh / Hh, h = bh % Hh;
-    const int Tst = a.Tst;
-    const size_t fh0 = (size_t)b * Tst * Hh + h;
+    const size_t fh0 = (size_t)b * T * Hh + h;
     constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
 
     // ---- the state's exponent (pair16).  fp16 pairs hold |S * 2^-e| < 65504, so e must fit this call's state: columns of S never
@@ -196,14 +182,14 @@ __global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
             return;
         }
         const int last_item = T * JT - 1;
-        const char* qbase = static_cast<const char*>(a.q) + (((size_t)b * Tst * N * Hh + h) * GDKVM_DK) * ESZ;
+        const char* qbase = static_cast<const char*>(a.q) + (((size_t)b * T * N * Hh + h) * GDKVM_DK) * ESZ;
         const size_t q_fstride = (size_t)N * Hh * GDKVM_DK * ESZ;
         const float* qinv_lane = a.qinv + fh0 * NP + li;
         // The read-out is computed TRANSPOSED, R^T = S^T Qn^T: the S images are also the A operand of S^T and the q rows as
         // loaded are also the B operand of Qn^T, so only the two MFMA arguments swap -- and lane (g, li) ends up with columns
         // 4g..4g+3 of token li: one 8- or 16-byte store per lane into the token's row instead of four scattered 2-byte ones
         // (the store issue made the read waves the slowest role of a frame).
-        char* rbase = static_cast<char*>(a.r_out) + ((size_t)b * Tst * N * Hh * Dv + h * Dv + 16 * sl + 4 * g) * ESZ;
+        char* rbase = static_cast<char*>(a.r_out) + ((size_t)b * T * N * Hh * Dv + h * Dv + 16 * sl + 4 * g) * ESZ;
         const size_t r_fstride = (size_t)N * Hh * Dv * ESZ;
         auto load_q = [&](int item, RItem<IO>& d) __attribute__((always_inline)) {
             item = min(item, last_item);
@@ -447,257 +433,11 @@ int launch_affine_any(bool wide, bool defer, bool save, const AffArgs& sa, dim3 
     return wide ? launch_affine_fmt<IO, FMT_SPLIT3>(defer, save, sa, grid, st) : launch_affine_fmt<IO, FMT_PAIR16>(defer, save, sa, grid, st);
 }
 
-// gdr_scan_pipe_kernel -- the serial recurrence of frames of more than 64 tokens (pair16 operands, deferred read-out) as the CONSUMER of a
-// frame-parallel kernel that is still running and the PRODUCER of a read-out kernel that already is (gdr_pipeline.hip; the flag protocol:
-// gdr_device.hpp).  Per frame it is gdr_affine_scan_kernel<IO, FMT_PAIR16, true, false> -- the same loads, products, roundings and
-// barrier, hence the same bits -- with three differences around the frames:
-//   * frames are taken in groups of pf.G; at the start of group g the state waves wait for the fold of group g + 1 (their operand
-//     prefetch runs two frames ahead, into the next group);
-//   * the read waves write the state images through (agent scope) and, behind the last frame of a group, raise its `prog` counter;
-//   * the state's exponent is sized group by group from the same bound, 8 (max|s_in| + sum_t max|G_t|) over the frames SO FAR plus the
-//     next group's (gdr_affine_scan_kernel sums the whole call up front, which would make it wait for the last frame's fold): e = 4 for
-//     every ordinary input, exactly as there; when a group needs more, the last frame of the group before it rescales the state by the
-//     exact power of two (folded into that frame's gate) and the group's 2^e goes to the read-out kernel through escg.
-// PD: operand prefetch distance of the state waves in frames (deeper than the plain kernel's 2: beside kernels that load the memory system
-// a fetch takes longer to come back); HOG: claim every vector register of the CU, so that no workgroup of the read-out kernel (96
-// registers, no LDS: it would fit) settles beside the serial chain -- the fold's workgroups never fit anyway.
-template <int PD, bool HOG>
-__global__ __launch_bounds__(AFF_THREADS) void gdr_scan_pipe_kernel(AffArgs a, PipeFlags pf)
-{
-    constexpr int FMT = FMT_PAIR16, NT = 2;
-    if constexpr (HOG) asm volatile("v_mov_b32 v255, 0" ::: "v255");
-    extern __shared__ __attribute__((aligned(16))) f32x4 aff_smem[];
-    uint2* s_S3 = reinterpret_cast<uint2*>(aff_smem);      // [parity][term] images, as in gdr_affine_scan_kernel
-    float* s_einv = reinterpret_cast<float*>(aff_smem + aff_s_f4(NT));       // [group & 3] 2^e of the group's images
-
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w = wave & 3, role = wave >> 2;
-    const int nsl = a.Dv / 16, Hh = a.Hh, Dv = a.Dv, T = a.T, G = pf.G, ngrp = pf.ngrp;
-    int bh, sl;
-    {
-        const int x = blockIdx.x;
-        if (a.BH % 8 == 0) { bh = (x & 7) + 8 * ((x >> 3) / nsl); sl = (x >> 3) % nsl; }
-        else { bh = x / nsl; sl = x % nsl; }
-    }
-    const int b = bh / Hh, h = bh % Hh;
-    const size_t fh0 = (size_t)b * a.Tst * Hh + h;
-
-    auto publish_state = [&](int par, const f32x4& sv) __attribute__((always_inline)) {
-        uint2 t3[3];
-        OpFmt<FMT>::split4(sv, t3);
-        const int e = split_slot(w, g, li);
-#pragma unroll
-        for (int sp = 0; sp < NT; ++sp) s_S3[(par * NT + sp) * SPLIT_IMG + e] = t3[sp];
-    };
-
-    if (role == 1) {
-        // ------------------------------------------------------------------------------ read waves: dump the images of S_{t-1}, group by group
-        uint4* dst = reinterpret_cast<uint4*>(a.simg) + ((fh0 * nsl + sl) * 4 + w) * 64 + lane;
-        const size_t d_fstride = (size_t)Hh * nsl * 4 * 64;
-        unsigned* prog = pf.prog + (size_t)bh * ngrp;
-        float* escg = pf.escg + ((size_t)bh * nsl + sl) * ngrp;
-        aff_barrier();                                     // (group 0 folded and sized by state wave 0)
-        aff_barrier();                                     // (S_0 published)
-        int t = 0;
-        for (int gi = 0; gi < ngrp; ++gi) {
-            const int tend = min(T, (gi + 1) * G);
-            for (; t < tend; ++t) {
-                const int par = t & 1;
-                const uint4 img = *reinterpret_cast<const uint4*>(&s_S3[(par * NT + (w >> 1)) * SPLIT_IMG + ((w & 1) * 64 + lane) * 2]);
-                if (pf.dbg & 1) dst[(size_t)t * d_fstride] = img;          // (experiments: plain stores / no stores -- wrong results)
-                else if (!(pf.dbg & 2)) st_agent(dst + (size_t)t * d_fstride, img);
-                aff_barrier();
-            }
-            if (w == 0 && lane == 0) st_agent(escg + gi, s_einv[gi & 3]);
-            stores_done();
-            if (lane == 0) flag_add(prog + gi, 1u);
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------------------- state waves
-    // Only wave 0 polls and keeps the bound (one poller per workgroup: every workgroup of the grid watches the same few counters); it
-    // leaves the next group's 2^e -- NaN when a wait gave up or the bound is not finite -- in s_einv before the group's first barrier,
-    // and every state wave picks it up one trip of six frames later, in front of the group's last trip.
-    __builtin_amdgcn_s_setprio(2);
-    const bool gate_logits = a.flags & GDKVM_FLAG_GATE_LOGITS;
-    const unsigned* pflag = pf.prep + (size_t)bh * ngrp;
-    const f32x4* gm = reinterpret_cast<const f32x4*>(a.gmax) + fh0 * nsl + sl;
-    bool alive = true;                                     // (wave 0) false: a wait gave up -- nothing waits any more
-    auto group_gsum = [&](int gi) __attribute__((always_inline)) {     // sum over the frames of group gi of max|G_t| of this slice
-        const int t = gi * G + lane;
-        float x = 0.f;
-        if (lane < G && t < T) {
-            const f32x4 v = gm[(size_t)t * Hh * nsl];
-            x = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-        }
-        return wave_sum(x);
-    };
-    auto group_target = [&](int gi) { return (unsigned)(min(T, (gi + 1) * G) - gi * G) * pf.prep_per_frame; };
-    auto exp_of = [&](float bound) {                       // as gdr_affine_scan_kernel: e = max(4, ceil(log2 bound) - 15); -1 = not finite
-        const int eb = (int)((__float_as_uint(bound) >> 23) & 0xffu) - 126;
-        return __builtin_amdgcn_readfirstlane(bound <= 3.0e38f ? max(4, eb - 15) : -1);
-    };
-    auto pow2 = [](int e) { return __uint_as_float((unsigned)(127 + e) << 23); };
-    auto exp_field = [](float p) { return (int)((__float_as_uint(p) >> 23) & 0xffu) - 127; };
-    const f32x4 nan4 = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-    float bound = 0.f;
-    int e_w0 = 4;                                          // (wave 0) the exponent announced last
-    auto announce = [&](int gi) __attribute__((always_inline)) {       // wave 0: wait for the fold of group gi, size its exponent, leave it in s_einv
-        if (alive) alive = flag_wait_ge(pflag + gi, group_target(gi));
-        bound += 8.0f * group_gsum(gi);
-        const int en = exp_of(bound);
-        if (en < 0) alive = false;
-        e_w0 = max(e_w0, en);
-        if (lane == 0) s_einv[gi & 3] = alive ? pow2(e_w0) : __builtin_nanf("");
-    };
-    PIPE_STAMP(a.stamps, (size_t)blockIdx.x * 64, w == 0 && lane == 0);
-    if (w == 0) {
-        float sm = 0.f;
-        if (a.s_in) {
-            const f32x4* sp = reinterpret_cast<const f32x4*>(a.s_in + ((size_t)bh * GDKVM_DK + lane) * Dv + 16 * sl);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) sm = fmaxf(sm, absmax4(sp[c]));
-        }
-        bound = 8.0f * wave_max_nonneg(sm);
-        announce(0);
-    }
-    aff_barrier();                                         // (group 0 is folded and sized)
-    int e_cur = 4;
-    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
-    {
-        const float einv = s_einv[0];
-        if (einv == einv) {
-            e_cur = exp_field(einv);
-            if (a.s_in) {
-                const float sc = pow2(-e_cur);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sacc[r] = sc * a.s_in[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li];
-            }
-        } else sacc = nan4;
-    }
-    publish_state(0, sacc);
-    aff_barrier();
-
-    struct POp { uint4 pa[NT][2]; f32x4 gt; float al; };
-    long pp_step = (long)Hh * (GDKVM_DK * GDKVM_DK * 3 / 2) * 4, gg_step = (long)Hh * nsl * 4 * 64 * 4 * 4, al_step = (long)Hh * 4;      // bytes
-    const char* pp_cur = reinterpret_cast<const char*>(a.pp + fh0 * (GDKVM_DK * GDKVM_DK * 3 / 2) + (size_t)w * (NT * 2 * 64) * 4);
-    const char* gg_cur = reinterpret_cast<const char*>(a.gg + ((fh0 * nsl + sl) * 4 + w) * 64 * 4);
-    const char* al_cur = reinterpret_cast<const char*>(a.alpha + fh0);
-    const unsigned lane16 = lane * 16;
-    int f_cur = 0;
-    auto fetch_op = [&](POp& d) __attribute__((always_inline)) {
-#pragma unroll
-        for (int sp = 0; sp < NT; ++sp)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) d.pa[sp][ks] = *reinterpret_cast<const uint4*>(pp_cur + lane16 + 1024 * (sp * 2 + ks));
-        d.gt = *reinterpret_cast<const f32x4*>(gg_cur + lane16);
-        d.al = *reinterpret_cast<const float*>(al_cur);
-        if (f_cur >= T - 1) pp_step = gg_step = al_step = 0;
-        ++f_cur;
-        pp_cur += pp_step;
-        gg_cur += gg_step;
-        al_cur += al_step;
-    };
-    POp od[PD + 1];
-    // (the first PD frames lie in group 0 -- G > PD -- or, beyond the call's last frame, repeat it)
-#pragma unroll
-    for (int i = 0; i < PD; ++i) fetch_op(od[i]);
-    // one frame; SC: the state is (or is about to be) carried beyond the default exponent -- G, prepared at 2^-4, is rescaled, and the
-    // frame in front of a group that needs a larger exponent takes the step in its gate
-    float gfix = pow2(4 - e_cur), gfix_last = gfix, arat_last = 1.f;
-    int t_last = -1;
-    auto frame = [&](int t, const POp& op, POp& far, auto scaled_c) __attribute__((always_inline)) {
-        const int par = t & 1;
-        uint4 sb[NT][2];
-#pragma unroll
-        for (int sp = 0; sp < NT; ++sp)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                sb[sp][ks] = *reinterpret_cast<const uint4*>(&s_S3[(par * NT + sp) * SPLIT_IMG + (ks * 64 + lane) * 2]);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch_op(far);
-        __builtin_amdgcn_sched_barrier(0);
-        float alpha = gate_logits ? fast_sigmoid(op.al) : op.al;
-        f32x4 acc0, acc1;
-        OpFmt<FMT>::product_pair(op.pa, sb, acc0, acc1);
-        const f32x2_t lo2 = {PAIR_LO_INV, PAIR_LO_INV};
-        f32x2_t g01 = {op.gt[0], op.gt[1]}, g23 = {op.gt[2], op.gt[3]};
-        if constexpr (decltype(scaled_c)::value) {
-            const float gf = t == t_last ? gfix_last : gfix;
-            g01 *= (f32x2_t){gf, gf}; g23 *= (f32x2_t){gf, gf};                  // (exact: powers of two)
-            if (t == t_last) alpha *= arat_last;
-        }
-        const f32x2_t al2 = {alpha, alpha};
-        const f32x2_t c01 = __builtin_elementwise_fma((f32x2_t){acc1[0], acc1[1]}, lo2, (f32x2_t){acc0[0], acc0[1]});
-        const f32x2_t c23 = __builtin_elementwise_fma((f32x2_t){acc1[2], acc1[3]}, lo2, (f32x2_t){acc0[2], acc0[3]});
-        const f32x2_t s01 = __builtin_elementwise_fma(al2, c01, g01), s23 = __builtin_elementwise_fma(al2, c23, g23);
-        sacc = f32x4{s01[0], s01[1], s23[0], s23[1]};
-        publish_state(par ^ 1, sacc);
-        aff_barrier();
-    };
-    constexpr int NR = PD + 1, UFD = NR % 2 == 0 ? NR : 2 * NR;
-    static_assert(GDR_PIPE_G % UFD == 0 && GDR_PIPE_G >= 2 * UFD && GDR_PIPE_G > PD, "a group of frames is at least two whole unrolled trips");
-    int t = 0;
-    bool scaled = e_cur != 4;
-    auto trips = [&](int limit) __attribute__((always_inline)) {       // whole trips of UFD frames up to `limit`
-        if (scaled) {
-            for (; t + UFD <= limit; t += UFD)
-                static_for<0, UFD>([&](auto fc) { constexpr int F = decltype(fc)::value; frame(t + F, od[F % NR], od[(F + PD) % NR], std::true_type{}); });
-        } else {
-            for (; t + UFD <= limit; t += UFD)
-                static_for<0, UFD>([&](auto fc) { constexpr int F = decltype(fc)::value; frame(t + F, od[F % NR], od[(F + PD) % NR], std::false_type{}); });
-        }
-    };
-    for (int gi = 0; gi + 1 < ngrp; ++gi) {                // whole groups: there is a next group to wait for and to size
-        const int tend = (gi + 1) * G;
-        if (w == 0) announce(gi + 1);
-        gfix = pow2(4 - e_cur); gfix_last = gfix; arat_last = 1.f; t_last = -1;
-        trips(tend - UFD);
-        int e_next = e_cur;
-        {
-            const float einv = s_einv[(gi + 1) & 3];       // (written in front of this group's first barrier; rewritten three groups on)
-            if (einv == einv) e_next = max(e_cur, exp_field(einv));
-            else publish_state(t & 1, nan4);               // NaNs into the images this frame multiplies: every later state is one
-        }
-        if (e_next != 4) scaled = true;
-        t_last = tend - 1;
-        gfix_last = pow2(4 - e_next); arat_last = pow2(e_cur - e_next);
-        trips(tend);
-        e_cur = e_next;
-        PIPE_STAMP(a.stamps, (size_t)blockIdx.x * 64 + 1 + min(gi, 61), w == 0 && lane == 0);
-    }
-    gfix = pow2(4 - e_cur); gfix_last = gfix; arat_last = 1.f; t_last = -1;
-    trips(T);                                              // the last group: nothing to wait for, no step
-    static_for<0, UFD - 1>([&](auto fc) {
-        constexpr int F = decltype(fc)::value;
-        if (t + F < T) {
-            if (scaled) frame(t + F, od[F % NR], od[(F + PD) % NR], std::true_type{});
-            else frame(t + F, od[F % NR], od[(F + PD) % NR], std::false_type{});
-        }
-    });
-    PIPE_STAMP(a.stamps, (size_t)blockIdx.x * 64 + 63, w == 0 && lane == 0);
-    if (a.s_out) {
-        const float inv = pow2(e_cur);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a.s_out[((size_t)bh * GDKVM_DK + 16 * w + 4 * g + r) * Dv + 16 * sl + li] = inv * sacc[r];
-    }
-}
-
 // gdr_readout_kernel -- LKVA read-out for frames of more than 64 tokens, frame-parallel: R_t = (Qn_t S_{t-1}) from the operand
 // images the serial kernel dumped.  One workgroup per (frame-head, 8 column tiles); a wave keeps the images of its two column
 // tiles in registers and walks the frame's token tiles, so q is read once per workgroup and nothing goes through LDS.  Same
 // arithmetic and operation order as the in-scan read-out (R^T = S^T Qn^T: pair16 terms on the f16 MFMA, or exact fp32).
-struct ReadoutArgs {
-    const void* q; const float* qinv; const float* simg; void* r_out; int Hh, N, Dv, NP; const float* esc; int T, Tst;
-    // the consumer of a serial kernel that is still running (gdr_pipeline.hip): workgroups in time-major order, each waits for its frame's
-    // group in `prog` and takes the group's 2^e from escg (all NULL / 0: the plain kernel behind a finished scan)
-    const unsigned* prog; const float* escg; unsigned prog_target; int G, ngrp;
-#ifdef GDKVM_PIPE_STAMPS
-    unsigned long long* stamps;
-#endif
-};
+struct ReadoutArgs { const void* q; const float* qinv; const float* simg; void* r_out; int Hh, N, Dv, NP; const float* esc; int T; };
 
 template <int IO, int FMT>
 __global__ __launch_bounds__(256, 2) void gdr_readout_kernel(ReadoutArgs a)       // (256 registers: MFMA results in VGPRs; with 512 they land in AGPRs and are copied out)
@@ -706,27 +446,10 @@ __global__ __launch_bounds__(256, 2) void gdr_readout_kernel(ReadoutArgs a)     
     constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // (blockIdx.x counts the launch's frame-heads, T frames per clip; clips lie Tst frames apart)
-    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    int tq = 0;                                            // (prog: the frame's index in its clip)
-    if (a.prog) {
-        // time-major: consecutive workgroups (x fastest, then y, z) take the (y, z) parts of ONE frame, then the same frame of the next clip-head
-        const unsigned L = bx + gridDim.x * (by + gridDim.y * bz), nyz = gridDim.y * gridDim.z, BH = gridDim.x / (unsigned)a.T;
-        const unsigned yz = L % nyz, f = L / nyz, bh = f % BH;
-        tq = (int)(f / BH);
-        by = yz % gridDim.y; bz = yz / gridDim.y;
-        bx = ((bh / (unsigned)a.Hh) * (unsigned)a.T + (unsigned)tq) * (unsigned)a.Hh + bh % (unsigned)a.Hh;
-    }
-    const int h = (int)(bx % a.Hh), N = a.N, Dv = a.Dv, nsl = Dv / 16;
-    const unsigned btl = bx / a.Hh, clip = btl / (unsigned)a.T;
-    const size_t bt = (size_t)clip * a.Tst + (btl - clip * (unsigned)a.T);
-    const size_t fh = bt * a.Hh + h;
-    bool dead = false;                                     // the serial kernel never got there: the frame's rows become NaNs
-    PIPE_STAMP(a.stamps, fh * 3, tid == 0 && by == 0 && bz == 0);
-    if (a.prog)                                            // (one poller per workgroup)
-        dead = __syncthreads_or(w == 0 && !flag_wait_ge(a.prog + (size_t)(clip * a.Hh + h) * a.ngrp + tq / a.G, a.prog_target));
-    PIPE_STAMP(a.stamps, fh * 3 + 1, tid == 0 && by == 0 && bz == 0);
-    const int c0 = (by * 4 + w) * 2;
+    const size_t fh = blockIdx.x;
+    const int h = (int)(fh % a.Hh), N = a.N, Dv = a.Dv, nsl = Dv / 16;
+    const size_t bt = fh / a.Hh;
+    const int c0 = (blockIdx.y * 4 + w) * 2;
     if (c0 >= nsl) return;
     const bool two = c0 + 1 < nsl;
     constexpr bool EXACT = IO == GDKVM_F32 && !PAIR;       // (as in the scan: fp32 images + exact fp32 MFMA only on full-range operands)
@@ -743,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void gdr_readout_kernel(ReadoutArgs a)     
     // token tiles [tt0, tt1) of the frame: with few frames the tokens are split over gridDim.z workgroups (cfg3: 160 frames x 2
     // column groups left half the CUs idle on a 16-tile latency chain; the state images are re-read from L2 per split)
     const int ntt_all = (N + 15) / 16, per_z = (ntt_all + (int)gridDim.z - 1) / (int)gridDim.z;
-    const int tt0 = (int)bz * per_z, ntt = min(ntt_all, tt0 + per_z);
+    const int tt0 = (int)blockIdx.z * per_z, ntt = min(ntt_all, tt0 + per_z);
     if (tt0 >= ntt) return;
     struct QT { uint4 q[IO == GDKVM_F32 ? 4 : 2]; float qi; };
     auto load_q = [&](int tt, QT& d) __attribute__((always_inline)) {
@@ -761,17 +484,10 @@ __global__ __launch_bounds__(256, 2) void gdr_readout_kernel(ReadoutArgs a)     
     // (the dumped images are those of S * 2^-e: pair16 -- the exponent the serial kernel chose for this clip-head and column tile)
     float sinv[2] = {OpFmt<FMT>::STATE_INV, OpFmt<FMT>::STATE_INV};
     if constexpr (PAIR) {
-        const size_t bh = (size_t)clip * a.Hh + h;
-        if (a.escg) {                                      // per group of frames (gdr_scan_pipe_kernel)
-            const float* ep = a.escg + (bh * nsl + c0) * a.ngrp + tq / a.G;
-            sinv[0] = ep[0];
-            sinv[1] = ep[two ? a.ngrp : 0];
-        } else {
-            const float* ep = a.esc + bh * ((nsl + 3) & ~3);
-            sinv[0] = ep[c0];
-            sinv[1] = ep[two ? c0 + 1 : c0];
-        }
-        if (dead) sinv[0] = sinv[1] = __builtin_nanf("");
+        const size_t bh = (fh / ((size_t)a.T * a.Hh)) * a.Hh + h;
+        const float* ep = a.esc + bh * ((nsl + 3) & ~3);
+        sinv[0] = ep[c0];
+        sinv[1] = ep[two ? c0 + 1 : c0];
     }
     auto tile = [&](int tt, const QT& d) __attribute__((always_inline)) {
         float rscale = d.qi;
@@ -837,7 +553,6 @@ __global__ __launch_bounds__(256, 2) void gdr_readout_kernel(ReadoutArgs a)     
         load_q(tt + 2, qa);
         if (tt + 1 < ntt) tile(tt + 1, qb);
     }
-    PIPE_STAMP(a.stamps, fh * 3 + 2, tid == 0 && by == 0 && bz == 0);
 }
 
 // N == 0: no tokens -> the state only decays, S_T = S_0 * prod_t alpha_t (no read-out rows exist)
@@ -855,80 +570,6 @@ __global__ void gdr_decay_kernel(const float* alpha, const float* s_in, float* s
 }
 
 }  // namespace
-
-// The serial recurrence (phases bit 0) and, for frames of more than 64 tokens, the frame-parallel read-out (bit 1) over a window of Tb
-// frames per clip, clips Tst frames apart (gdr_ws.hpp).  gdkvm_scan_apply is the whole clip with both phases on one stream.
-int gdr_apply_window(const void* q, const float* alpha, const float* s_in, void* r_out, float* s_out, float* s_hist, const WsView& ws,
-                     int B, int Tb, int Tst, int Hh, int N, int Dv, int io_dtype, int flags, int phases, hipStream_t st)
-{
-    const int T = Tb;
-    const bool defer = ws.nb > 4 && r_out != nullptr;     // > 64 tokens per frame: read-out by its own frame-parallel kernel
-    const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
-    const bool pipe = phases & GDR_PHASE_PIPE;             // consumer / producer of kernels that run at the same time (gdr_pipeline.hip)
-    if (pipe && (!defer || wide || s_hist)) return gdkvm_fail(GDKVM_ERR_ARG, "scan apply: the concurrent form serves deferred read-outs on fp16-pair operands");
-    if ((phases & 1) && pipe) {
-        AffArgs sa{q, alpha, s_in, ws.pp, ws.gg, ws.qinv, nullptr, s_out, nullptr, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 0, ws.simg,
-                   ws.gmax, nullptr, Tst};
-#ifdef GDKVM_PIPE_STAMPS
-        sa.stamps = g_pipe_stamps_host[1];
-#endif
-        const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
-        // experiments: GDKVM_PIPE_SCAN_LDS_KB extra LDS per serial workgroup; GDKVM_PIPE_SCAN_PD prefetch distance 2 / 3 / 5; GDKVM_PIPE_SCAN_HOG 0 / 1
-        const char* pad_e = getenv("GDKVM_PIPE_SCAN_LDS_KB");
-        const int pad_kb = pad_e ? atoi(pad_e) : 0;
-        size_t lds = aff_lds_bytes(io_dtype, 2) + 16;
-        if (pad_kb > 0 && pad_kb <= 150) lds += (size_t)pad_kb * 1024;
-        const char* pd_e = getenv("GDKVM_PIPE_SCAN_PD");
-        const int pd = pd_e ? atoi(pd_e) : 3;
-        const char* hog_e = getenv("GDKVM_PIPE_SCAN_HOG");
-        const bool hog = hog_e ? hog_e[0] == '1' : true;
-        auto go = [&](auto kern) -> int {
-            if (lds > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "gdr_scan_pipe: LDS attribute: %s", hipGetErrorString(e));
-            }
-            hipLaunchKernelGGL(kern, grid, dim3(AFF_THREADS), lds, st, sa, ws.pipe);
-            return GDKVM_OK;
-        };
-        int rc = GDKVM_OK;
-        if (pd == 2) rc = hog ? go(gdr_scan_pipe_kernel<2, true>) : go(gdr_scan_pipe_kernel<2, false>);
-        else if (pd == 5) rc = hog ? go(gdr_scan_pipe_kernel<5, true>) : go(gdr_scan_pipe_kernel<5, false>);
-        else rc = hog ? go(gdr_scan_pipe_kernel<3, true>) : go(gdr_scan_pipe_kernel<3, false>);
-        if (rc) return rc;
-        GDKVM_LAUNCH_CHECK("gdr_scan_pipe_kernel");
-    } else if (phases & 1) {
-        AffArgs sa{q, alpha, s_in, ws.pp, ws.gg, ws.qinv, defer ? nullptr : r_out, s_out, s_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 0, ws.simg,
-                   ws.gmax, ws.esc, Tst};
-        const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
-        if (int rc = io_dtype == GDKVM_F32 ? launch_affine_any<GDKVM_F32>(wide, defer, s_hist != nullptr, sa, grid, st)
-                                           : launch_affine_any<GDKVM_BF16>(wide, defer, s_hist != nullptr, sa, grid, st)) return rc;
-    }
-    if (defer && (phases & 2)) {
-        ReadoutArgs ra{q, ws.qinv, ws.simg, r_out, Hh, N, Dv, 16 * ws.nb, ws.esc, T, Tst, nullptr, nullptr, 0, 1, 1};
-#ifdef GDKVM_PIPE_STAMPS
-        ra.stamps = pipe ? g_pipe_stamps_host[2] : nullptr;
-#endif
-        if (pipe) { ra.prog = ws.pipe.prog; ra.escg = ws.pipe.escg; ra.prog_target = 4u * (unsigned)(Dv / 16); ra.G = ws.pipe.G; ra.ngrp = ws.pipe.ngrp; }
-        // enough workgroups for two per CU: split the frame's token tiles when frames x column groups alone do not give them
-        unsigned ny = (unsigned)((Dv / 16 + 7) / 8), nz = 1;
-        {
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) == hipSuccess) {
-                int n = 0;
-                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-            }
-            const long wg = (long)B * T * Hh * ny, ntt = (N + 15) / 16;
-            while (wg * nz < 2L * cus && 2 * nz <= (unsigned)(ntt / 2)) nz *= 2;       // (at least two token tiles per workgroup)
-        }
-        const dim3 rgrid((unsigned)(B * T * Hh), ny, nz);
-        if (io_dtype == GDKVM_F32 && wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
-        else if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
-        else if (wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
-        else hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
-        GDKVM_LAUNCH_CHECK("gdr_readout_kernel");
-    }
-    return GDKVM_OK;
-}
 
 extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* s_in, void* r_out, float* s_out,
                                 float* s_hist, const void* workspace, size_t workspace_bytes,
@@ -956,7 +597,34 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
         }
         return GDKVM_OK;
     }
-    return gdr_apply_window(q, alpha, s_in, r_out, s_out, s_hist, ws, B, T, T, Hh, N, Dv, io_dtype, flags, 3, st);
+    const bool defer = ws.nb > 4 && r_out != nullptr;     // > 64 tokens per frame: read-out by its own frame-parallel kernel
+    AffArgs sa{q, alpha, s_in, ws.pp, ws.gg, ws.qinv, defer ? nullptr : r_out, s_out, s_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 0, ws.simg,
+               ws.gmax, ws.esc};
+    const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
+    const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
+    if (int rc = io_dtype == GDKVM_F32 ? launch_affine_any<GDKVM_F32>(wide, defer, s_hist != nullptr, sa, grid, st)
+                                       : launch_affine_any<GDKVM_BF16>(wide, defer, s_hist != nullptr, sa, grid, st)) return rc;
+    if (defer) {
+        ReadoutArgs ra{q, ws.qinv, ws.simg, r_out, Hh, N, Dv, 16 * ws.nb, ws.esc, T};
+        // enough workgroups for two per CU: split the frame's token tiles when frames x column groups alone do not give them
+        unsigned ny = (unsigned)((Dv / 16 + 7) / 8), nz = 1;
+        {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) {
+                int n = 0;
+                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+            }
+            const long wg = (long)B * T * Hh * ny, ntt = (N + 15) / 16;
+            while (wg * nz < 2L * cus && 2 * nz <= (unsigned)(ntt / 2)) nz *= 2;       // (at least two token tiles per workgroup)
+        }
+        const dim3 rgrid((unsigned)(B * T * Hh), ny, nz);
+        if (io_dtype == GDKVM_F32 && wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
+        else if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
+        else if (wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
+        else hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
+        GDKVM_LAUNCH_CHECK("gdr_readout_kernel");
+    }
+    return GDKVM_OK;
 }
 
 extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* phi_out, const void* workspace, size_t workspace_bytes,
@@ -974,7 +642,6 @@ extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* p
     hipError_t e = hipMemsetAsync(ws.zero, 0, 64 * 4 * sizeof(float), st);       // the one G tile every frame and slice reads
     if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_transition: memset: %s", hipGetErrorString(e));
     AffArgs sa{q, alpha, nullptr, ws.pp, ws.zero, ws.qinv, nullptr, phi_out, nullptr, ws.trash, 1, 1, T, Hh, N, GDKVM_DK, flags, B * Hh, 0, nullptr};
-    sa.Tst = T;
     const dim3 grid((unsigned)(B * Hh * (GDKVM_DK / 16)));
     const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;
     return io_dtype == GDKVM_F32 ? launch_affine_any<GDKVM_F32>(wide, false, false, sa, grid, st)
@@ -1075,14 +742,6 @@ extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const
     }
     if (s_hist) flags |= GDKVM_FLAG_TRAIN;              // the backward reads extra operand layouts from the workspace
     if (rule == GDKVM_RULE_DELTA_PARALLEL) flags |= GDKVM_FLAG_WIDE_RANGE;      // not contractive: full-range operands
-    if (!s_hist && Dk == GDKVM_DK) {                    // inference: the frames as overlapping time blocks where that pays (gdr_pipeline.hip)
-        int rc = gdr_scan_fwd_pipe(q, k, v, alpha, beta, nullptr, s_in, r_out, s_out, workspace, workspace_bytes, B, T, Hh, N, Dv,
-                                   io_dtype, rule, flags, static_cast<hipStream_t>(stream));
-        if (rc <= 0) return rc;
-        rc = gdr_scan_fwd_blocks(q, k, v, alpha, beta, nullptr, s_in, r_out, s_out, workspace, workspace_bytes, B, T, Hh, N, Dv,
-                                 io_dtype, rule, flags, static_cast<hipStream_t>(stream));
-        if (rc <= 0) return rc;
-    }
     if (int rc = gdkvm_scan_prep(q, k, v, beta, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, stream)) return rc;
     return gdkvm_scan_apply(q, alpha, s_in, r_out, s_out, s_hist, workspace, workspace_bytes, B, T, Hh, N, Dk, Dv, io_dtype, flags, stream);
 }
@@ -1135,7 +794,6 @@ int gdr_launch_reverse_scan(const WsView& ws, const float* alpha, const void* d_
         GDKVM_LAUNCH_CHECK("gdr_bwd_g_kernel");
     }
     AffArgs sa{nullptr, alpha, ds_out, ws.ppt, gb, nullptr, nullptr, ds_in, ds_hist, ws.trash, 0, 0, T, Hh, N, Dv, flags, B * Hh, 1, nullptr};
-    sa.Tst = T;
     const dim3 grid((unsigned)(B * Hh * (Dv / 16)));
     // gradients have no natural magnitude: the reverse recurrence keeps the full-range three-term bf16 operands (P^T images)
     return io_dtype == GDKVM_F32 ? launch_affine<GDKVM_F32, FMT_SPLIT3, false, true>(sa, grid, st)

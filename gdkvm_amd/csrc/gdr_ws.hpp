@@ -30,21 +30,9 @@ static inline int tiles_for(int N) { return N <= 64 ? 4 : 4 * ((N + 63) / 64); }
 //          the chunk composition left the fp16 pair's range)
 //   and, per clip-head (behind everything per-frame): esc [Dv/16] = 2^e, the inverse of the scale the serial kernel carried that
 //          slice's state at, for the frame-parallel read-out kernel
-// gdkvm_scan_fwd may walk a call's frames as up to GDR_MAX_BLOCKS time blocks whose kernels overlap on helper streams (gdr_pipeline.hip):
-// every block's serial kernel leaves its own esc row (the read-out of block c runs beside the serial kernel of block c + 1), and the
-// state is carried from block to block in `carry` [B, Hh, Dk, Dv] when the caller did not ask for s_out.
-constexpr int GDR_MAX_BLOCKS = 16;
-// The same three stages as kernels that run AT THE SAME TIME and hand frames over through counters in the workspace (gdr_pipeline.hip,
-// gdr_device.hpp "flags"): frames are counted in groups of GDR_PIPE_G (a multiple of the serial kernel's unroll of 6).
-//   prep [clip-head][group]   += 1 by every frame-parallel workgroup that has finished a frame-head of the group
-//   prog [clip-head][group]   += 1 by every read wave of the serial kernel that has dumped the group's state images
-//   escg [clip-head][slice][group]  2^e of the group's state images (the serial kernel sizes the state's exponent group by group)
-constexpr int GDR_PIPE_G = 12;
-static inline int gdr_pipe_groups(int T) { return (T + GDR_PIPE_G - 1) / GDR_PIPE_G; }
-struct PipeFlags { unsigned* prep; unsigned* prog; float* escg; int G, ngrp; unsigned prep_per_frame; int dbg; };   // dbg: timing experiments (GDKVM_PIPE_DBG)
 struct WsView {
     float* wt; float* knT; float* ut; float* qinv; float* kn; float* wtT; float* qnT; float* tii; float* wti; float* ppt;
-    float* pp; float* gg; float* x0; float* ppc; float* ggc; float* simg; float* gmax; float* esc; float* carry; PipeFlags pipe; float* zero; char* trash; int nb; int nchunk;
+    float* pp; float* gg; float* x0; float* ppc; float* ggc; float* simg; float* gmax; float* esc; float* zero; char* trash; int nb; int nchunk;
 };
 
 static inline size_t gdr_ws_floats_per_fh(int N, int Dk, int Dv)
@@ -58,8 +46,7 @@ static inline size_t gdr_ws_floats_per_fh(int N, int Dk, int Dv)
 static inline size_t gdr_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv)
 {
     if (B <= 0 || T <= 0 || Hh <= 0 || N <= 0 || Dk <= 0 || Dv <= 0 || N > GDKVM_MAX_N) return GDKVM_WS_TAIL;
-    return ((size_t)B * T * Hh * gdr_ws_floats_per_fh(N, Dk, Dv) + (size_t)B * Hh * (((size_t)Dv / 16 + 3) & ~(size_t)3) * GDR_MAX_BLOCKS
-            + (size_t)B * Hh * Dk * Dv + (size_t)B * Hh * gdr_pipe_groups(T) * (2 + (size_t)Dv / 16)) * sizeof(float) + GDKVM_WS_TAIL;
+    return ((size_t)B * T * Hh * gdr_ws_floats_per_fh(N, Dk, Dv) + (size_t)B * Hh * (((size_t)Dv / 16 + 3) & ~(size_t)3)) * sizeof(float) + GDKVM_WS_TAIL;
 }
 
 // Key widths below the kernels' 64 (multiples of 8): gdkvm_scan_fwd runs the Dk = 64 kernels on zero-extended copies of q, k and the
@@ -102,63 +89,11 @@ static inline int carve(const char* fn, void* workspace, size_t workspace_bytes,
     v->ggc = p;   p += NP > 64 ? FH * (NP / 64 - 1) * ggf : 0;
     v->simg = p;  p += NP > 64 ? FH * ggf : 0;
     v->gmax = p;  p += FH * ((size_t)Dv / 4);
-    v->esc = p;   p += (size_t)B * Hh * (((size_t)Dv / 16 + 3) & ~(size_t)3) * GDR_MAX_BLOCKS;     // [block][clip-head][slice]
-    v->carry = p; p += (size_t)B * Hh * GDKVM_DK * Dv;
-    {
-        const size_t ng = (size_t)gdr_pipe_groups(T), BH = (size_t)B * Hh;
-        v->pipe.prep = reinterpret_cast<unsigned*>(p);  p += BH * ng;
-        v->pipe.prog = reinterpret_cast<unsigned*>(p);  p += BH * ng;      // (prep and prog are adjacent: one memset clears both)
-        v->pipe.escg = p;                               p += BH * ng * ((size_t)Dv / 16);
-        v->pipe.G = GDR_PIPE_G; v->pipe.ngrp = (int)ng; v->pipe.prep_per_frame = 1; v->pipe.dbg = 0;
-    }
+    v->esc = p;   p += (size_t)B * Hh * (((size_t)Dv / 16 + 3) & ~(size_t)3);
     v->zero = p;                                         // 256 floats, zeroed by gdkvm_scan_transition
     v->trash = reinterpret_cast<char*>(v->zero + 256);   // write-only slot for read-out rows of padding tokens
     return GDKVM_OK;
 }
-
-// A window of the call's frames, [t0, t0 + Tb) of every clip: every per-frame region of the view moved to frame t0 of clip 0 (all of them
-// are linear in the frame-head index, so a kernel that strides clips by the FULL clip length addresses the window's frames; esc / carry /
-// zero / trash are per call).  `esc_block` selects the window's esc row.
-static inline WsView gdr_ws_window(const WsView& f, int B, int Hh, int N, int Dv, int t0, int esc_block)
-{
-    WsView v = f;
-    const size_t NP = 16 * (size_t)f.nb, NL = NP < 64 ? NP : 64, o = (size_t)t0 * Hh;
-    const size_t ppf = (size_t)GDKVM_DK * GDKVM_DK * 3 / 2, ggf = (size_t)GDKVM_DK * Dv;
-    v.wt += o * NL * GDKVM_DK;   v.knT += o * NL * GDKVM_DK;  v.ut += o * NL * Dv;        v.kn += o * NL * GDKVM_DK;
-    v.wtT += o * NL * GDKVM_DK;  v.qnT += o * NL * GDKVM_DK;  v.tii += o * NL * 16;       v.wti += o * NL * GDKVM_DK;
-    v.ppt += o * ppf;            v.qinv += o * NP;            v.pp += o * ppf;            v.gg += o * ggf;
-    if (NP > 64) {
-        v.x0 += o * (size_t)GDKVM_DK * (GDKVM_DK + Dv);
-        v.ppc += o * (NP / 64 - 1) * ppf;
-        v.ggc += o * (NP / 64 - 1) * ggf;
-        v.simg += o * ggf;
-    }
-    v.gmax += o * ((size_t)Dv / 4);
-    v.esc += (size_t)esc_block * B * Hh * (((size_t)Dv / 16 + 3) & ~(size_t)3);
-    return v;
-}
-
-// The stages of gdkvm_scan_fwd on a window of Tb frames per clip inside clips of Tst frames (gdr_prep.hip, gdr_scan.hip); `ws` is the
-// window's view (gdr_ws_window) and every tensor pointer is already moved to the window's first frame.  gdr_apply_window: phases bit 0 =
-// the serial kernel, bit 1 = the frame-parallel read-out of frames of more than 64 tokens (a no-op for shorter frames).
-enum { GDR_FUSE_AUTO = -1 };
-enum { GDR_PHASE_SCAN = 1, GDR_PHASE_READOUT = 2, GDR_PHASE_PIPE = 4 };     // gdr_apply_window `phases`; PIPE: the concurrent form, flags in ws.pipe
-int gdr_prep_window(const void* q, const void* k, const void* v, const float* beta, const float* norms, const WsView& ws,
-                    int B, int Tb, int Tst, int Hh, int N, int Dv, int io_dtype, int rule, int flags, int fuse, hipStream_t st, bool pipe = false);
-// (pipe: the frame-parallel side as the producer of a serial kernel that is already running; gdr_prep_producers: how many counts one
-// finished frame-head adds to its group's `prep` counter)
-int gdr_prep_producers(const WsView& ws, int B, int Tb, int Hh, int Dv, int io_dtype, int rule, int flags, int fuse);
-int gdr_apply_window(const void* q, const float* alpha, const float* s_in, void* r_out, float* s_out, float* s_hist, const WsView& ws,
-                     int B, int Tb, int Tst, int Hh, int N, int Dv, int io_dtype, int flags, int phases, hipStream_t st);
-// gdr_pipeline.hip: gdkvm_scan_fwd's frames as time blocks on helper streams (prep of block c + 1 beside the serial kernel of block c
-// beside the read-out of block c - 1); returns GDKVM_OK having enqueued everything, or 1 = "not taken, run the plain sequence"
-// the same three stages as kernels running at the same time, frames handed over through counters; same return convention
-int gdr_scan_fwd_pipe(const void* q, const void* k, const void* v, const float* alpha, const float* beta, const float* norms,
-                      const float* s_in, void* r_out, float* s_out, void* workspace, size_t workspace_bytes,
-                      int B, int T, int Hh, int N, int Dv, int io_dtype, int rule, int flags, hipStream_t st);
-int gdr_scan_fwd_blocks(const void* q, const void* k, const void* v, const float* alpha, const float* beta, const float* norms,
-                        const float* s_in, void* r_out, float* s_out, void* workspace, size_t workspace_bytes,
-                        int B, int T, int Hh, int N, int Dv, int io_dtype, int rule, int flags, hipStream_t st);
 
 // > 64 KiB of dynamic LDS needs an opt-in per kernel and device: done once, remembered in the caller's lock-free mask (one
 // static mask per kernel instantiation) -- host threads may drive several devices concurrently.

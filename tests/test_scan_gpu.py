@@ -386,82 +386,3 @@ def test_scan_large_values_in_frames_of_more_than_64_tokens(hip, dtype, monkeypa
         Rw, Sw = _run(hip, q, k, v22, a, b, None, 2, 3 | 8, dtype)
         Ro, So = c_oracle.scan(q, k, v22, a, b, None, 2, 3, math="f64")
         assert np.abs(Sw - So).max() <= TOL * 2.0 ** 22 and np.all(np.abs(Rw - Ro) <= TOL * 2.0 ** 22 + np.abs(Ro) * 2.0 ** -8)
-
-
-@pytest.mark.parametrize("case", [(2, 30, 49, 1, 64, "3"), (16, 9, 49, 1, 32, "L2,5"), (2, 26, 100, 1, 64, "4"), (3, 14, 130, 2, 128, "L1,2,9")])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_scan_as_time_blocks_on_helper_streams_is_bit_identical(hip, case, dtype, monkeypatch):
-    """csrc/gdr_pipeline.hip, first form: the call's frames as time blocks whose fold / recurrence / read-out overlap on helper streams
-    (event dependencies; every kernel on a window of the same tensors and workspace regions, clips strided by the whole clip's length).
-    Opt-in (GDKVM_SCAN_BLOCKS / GDKVM_SCAN_BLOCK_LIST): measured slower than the plain sequence.  Whatever the block plan -- equal blocks,
-    ragged boundaries, blocks of one frame -- read-outs and final state equal the plain call's bit for bit, with and without a carried
-    state, frames of at most and of more than 64 tokens, several heads, clips a multiple of 8 (the XCD-aware launch forms)."""
-    B, T, N, Hh, Dv, plan = case
-    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, 64, Dv, seed=sum(case[:5]), normalized=False, logits=True, corr=0.5)
-    t = [_dev(x, dtype) for x in (q, k, v)] + [_dev(a), _dev(b)]
-    s0 = _dev((0.3 * np.random.default_rng(5).standard_normal((B, Hh, 64, Dv))).astype(np.float32))
-    for state in (None, s0):
-        monkeypatch.delenv("GDKVM_SCAN_BLOCKS", raising=False)
-        monkeypatch.delenv("GDKVM_SCAN_BLOCK_LIST", raising=False)
-        ref = hip.scan_fwd(*t, state, flags=3)
-        monkeypatch.setenv("GDKVM_SCAN_BLOCK_LIST" if plan.startswith("L") else "GDKVM_SCAN_BLOCKS", plan.lstrip("L"))
-        got = hip.scan_fwd(*t, state, flags=3)
-        torch.cuda.synchronize()
-        assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1])
-    Ro, So = c_oracle.scan(*(x.float().cpu().numpy() for x in t[:3]), a, b, s0.cpu().numpy(), 2, 3, math="f64")
-    assert np.abs(got[1].cpu().numpy() - So).max() <= TOL
-
-
-@pytest.mark.parametrize("case", [(2, 40, 130, 1, 64), (1, 25, 100, 2, 128), (8, 13, 256, 1, 64), (2, 140, 70, 1, 256)])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_scan_as_concurrent_kernels_is_bit_identical(hip, case, dtype, monkeypatch):
-    """csrc/gdr_pipeline.hip, second form (GDKVM_SCAN_PIPE=1; frames of more than 64 tokens, fp16-pair operands): fold, recurrence and
-    read-out as three kernels that run at the same time and hand groups of 12 frames over through counters in the workspace -- agent-scope
-    write-through stores, relaxed flags, no fences.  Same kernels' arithmetic in the same order: read-outs and final state equal the plain
-    call's bit for bit, on a workspace that held OTHER results before (a stale line anywhere in the hand-over would show), with the fused
-    chunk walk and with chunk-parallel workgroups + composition as the producer, one and several heads, 1 ... 12 groups, a ragged last group."""
-    B, T, N, Hh, Dv = case
-    dev = torch.device("cuda")
-    ws = hip.new_workspace(B, T, Hh, N, 64, Dv, dev)
-    ws.random_(0, 255)
-    for seed, fuse in ((0, "0"), (1, "1"), (2, "1"), (3, "0")):
-        q, k, v, a, b = make_scan_inputs(B, T, N, Hh, 64, Dv, seed=sum(case) + seed, normalized=False, logits=True, corr=0.5)
-        t = [_dev(x, dtype) for x in (q, k, v)] + [_dev(a), _dev(b)]
-        s0 = _dev(((seed + 1) * 0.3 * np.random.default_rng(seed).standard_normal((B, Hh, 64, Dv))).astype(np.float32)) if seed else None
-        monkeypatch.setenv("GDKVM_PREP_FUSE", fuse)
-        monkeypatch.setenv("GDKVM_SCAN_PIPE", "1")
-        got = hip.scan_fwd(*t, s0, flags=3, workspace=ws)
-        monkeypatch.setenv("GDKVM_SCAN_PIPE", "0")
-        ref = hip.scan_fwd(*t, s0, flags=3)
-        torch.cuda.synchronize()
-        assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]), (seed, fuse)
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_scan_as_concurrent_kernels_sizes_the_exponent_group_by_group(hip, dtype, monkeypatch):
-    """The concurrent form cannot sum max|G_t| over the whole call before its first frame (it would wait for the last frame's fold): the
-    serial kernel sizes the state's exponent group by group from the bound so far, and steps it -- exactly, by a power of two folded into
-    the gate of the group's last frame -- when the next group needs more.  Values that grow by 2^14 in mid-clip, a carried state at 2^10:
-    finite everywhere and right against the oracle relative to the scale; a non-finite bound (the composition's own overflow) still
-    poisons the call with NaNs from that group on."""
-    B, T, N, Hh, Dv = 1, 40, 130, 1, 64
-    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, 64, Dv, seed=91, normalized=False, logits=True, corr=0.5)
-    v = v.copy()
-    v[:, 17:] *= 2.0 ** 14                                     # (group 1 ends at frame 23: the step lands inside the clip)
-    s0 = (np.random.default_rng(4).standard_normal((B, Hh, 64, Dv)) * 2.0 ** 10).astype(np.float32)
-    if dtype == torch.bfloat16:
-        q, k, v = (O.to_bf16_f32(x) for x in (q, k, v))
-    monkeypatch.setenv("GDKVM_SCAN_PIPE", "1")
-    for fuse in ("0", "1"):
-        monkeypatch.setenv("GDKVM_PREP_FUSE", fuse)
-        Rg, Sg = _run(hip, q, k, v, a, b, s0, 2, 3, dtype)
-        Ro, So = c_oracle.scan(q, k, v, a, b, s0, 2, 3, math="f64")
-        assert np.isfinite(Rg).all() and np.isfinite(Sg).all()
-        assert np.abs(Sg - So).max() <= TOL * 2.0 ** 14
-        early, late = slice(0, 17), slice(18, T)                 # (frame 17 reads the state before the jump, writes after it)
-        assert np.all(np.abs(Rg[:, early] - Ro[:, early]) <= TOL * 2.0 ** 10 + np.abs(Ro[:, early]) * 2.0 ** -8)
-        assert np.all(np.abs(Rg[:, late] - Ro[:, late]) <= TOL * 2.0 ** 14 + np.abs(Ro[:, late]) * 2.0 ** -8)
-        v22 = v.copy()
-        v22[:, 30:] *= 2.0 ** 10                                 # 2^24 from frame 30 on: the chunk composition overflows its fixed fp16 pairs
-        Rn, Sn = _run(hip, q, k, v22.astype(np.float32), a, b, s0, 2, 3, dtype)
-        assert np.isnan(Sn).all() and np.isnan(Rn[:, 36:]).all() and np.isfinite(Rn[:, :12]).all()
