@@ -231,8 +231,10 @@ def bench_train(args, world, rank, dev):
 
 class Watchdog:
     """Bounds a leg that contains collectives: if it has not been disarmed after `seconds`, `on_fire()` runs (rank 0 prints the
-    line it has) and the process leaves with os._exit -- a hung RCCL call cannot be interrupted from Python, and one rank
-    exiting normally would leave the others waiting.  Every rank arms its own."""
+    line it has) and the process leaves with os._exit(3) -- a hung RCCL call cannot be interrupted from Python, and one rank
+    exiting normally would leave the others waiting.  Every rank arms its own.  The exit code is NON-ZERO: the headline figure of the
+    printed line was measured before the leg and is valid, but the run never reached its last barrier / destroy_process_group and
+    counts as failed (`train_step.error` says why); nothing is retried in-process -- a retry is a fresh launch by the caller."""
 
     def __init__(self, seconds, on_fire):
         import threading
@@ -245,7 +247,7 @@ class Watchdog:
             self._on_fire()
         finally:
             sys.stdout.flush()
-            os._exit(0)
+            os._exit(3)
 
     def __enter__(self):
         self._t.start()
@@ -347,10 +349,14 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    ranks_seen = 1
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
+        ones = torch.ones(1, device=dev, dtype=torch.int64)   # every rank adds one: the line itself shows that RCCL reached `world` ranks
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
     value = world * B * T * args.steps / dt
 
     out = {"metric": "frames/sec (GDKVM forward + argmax mask), EchoNet 112x112x32 clips", "value": round(value, 1),
@@ -362,7 +368,7 @@ def main():
                       "heads": cfg.heads, "key_dim": cfg.key_dim, "value_dim": cfg.value_dim, "rule": cfg.rule,
                       "input": "frames resident in HBM as bf16 before the timed region (host-to-device copy and cast untimed)",
                       "sharding": f"clips over {world} GPU(s), no data-path collective",
-                      "world_size": (dist.get_world_size() if world > 1 else 1),
+                      "world_size": (dist.get_world_size() if world > 1 else 1), "ranks_seen": ranks_seen,
                       "collective_backend": ("nccl (RCCL)" if world > 1 else None)}}
 
     if rank == 0:
@@ -465,7 +471,30 @@ def main():
                     "per_class": [round(x, 5) for x in d3], "mask_agreement": round((mask32 == mask16).float().mean().item(), 6),
                     "class_fractions_fp32": [round((mask32 == c).float().mean().item(), 4) for c in range(4)],
                     "compared": "fused bf16 build vs fp32 module on the GPU, same random-init weights (head balanced), 8x20x256x256, 4 classes"}
+                # the same two configs as WHOLE-MODULE workloads (frames/s of segment(): encoder, memory path, decoder, argmax mask),
+                # informational, a few calls each after one warm-up: configs[2] as one call; configs[4] (2 clips x 512 frames of 256x256)
+                # as 16 chunks of 32 frames with the memory state carried (GDKVM.segment_clip: bit-identical to any other chunking) and
+                # as ONE call with the scan's time axis cut into the segments gdkvm_scan_segments picks (scan_segments = 0)
+                def module_rate(fn, nframes, iters=3):
+                    fn(); torch.cuda.synchronize()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(iters):
+                        fn()
+                    e1.record(); torch.cuda.synchronize()
+                    ms = e0.elapsed_time(e1) / iters
+                    return {"ms_per_call": round(ms, 3), "frames_per_s": round(nframes / (ms * 1e-3), 1)}
+                wl = {"configs[2] 8x20x256x256, 4 classes, one call": module_rate(lambda: m3.segment(f3), 160)}
                 del m3, f3, lg3, mask32, mask16
+                f5 = torch.rand(2, 512, 3, 256, 256, device=dev).to(torch.bfloat16)
+                wl["configs[4] 2x512x256x256, 16 chunks of 32 frames, state carried"] = module_rate(lambda: model.segment_clip(f5, 32), 1024)
+                model.cfg.scan_segments = 0
+                try:
+                    wl["configs[4] 2x512x256x256, one call, scan in 16 time segments"] = module_rate(lambda: model.segment(f5), 1024)
+                finally:
+                    model.cfg.scan_segments = 1
+                del f5
+                out["module_workloads"] = wl
             except Exception as e:                              # noqa: BLE001 -- informational leg
                 out["dice_configs2_fp32_vs_bf16"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         # ---- CPU baseline: the oracle module on a bounded sample of the same workload (N=1 only) -----------

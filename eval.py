@@ -37,7 +37,8 @@ def main(argv=None):
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     torch.manual_seed(cfg.seed)
-    mcfg = GDKVMConfig(num_classes=cfg.data.num_classes, heads=cfg.model.heads, value_dim=cfg.model.value_dim, rule=cfg.model.rule)
+    mcfg = GDKVMConfig(num_classes=cfg.data.num_classes, heads=cfg.model.heads, value_dim=cfg.model.value_dim, rule=cfg.model.rule,
+                       scan_segments=cfg.model.scan_segments)
     model = GDKVM(mcfg).eval()
     if args.weights:
         model.load_state_dict(torch.load(args.weights, map_location="cpu")["model"])

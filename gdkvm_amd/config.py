@@ -30,6 +30,7 @@ class ModelCfg:
     heads: int = 1
     value_dim: int = 256
     rule: str = "delta_sequential"
+    scan_segments: int = 1           # evaluation of long clips: GDKVMConfig.scan_segments (1 = serial scan, bit-identical under chunking)
 
 
 @dataclass

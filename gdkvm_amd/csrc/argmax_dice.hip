@@ -107,6 +107,14 @@ __device__ __forceinline__ float up_src(float scale, int dst)
     const float s = __fsub_rn(__fmul_rn(scale, __fadd_rn((float)dst, 0.5f)), 0.5f);
     return s < 0.f ? 0.f : s;
 }
+// the same three roundings on the host (volatile: no contraction into an fma, no excess precision)
+static float up_src_host(float scale, int dst)
+{
+    volatile float t = (float)dst + 0.5f;
+    volatile float m = scale * t;
+    volatile float s = m - 0.5f;
+    return s < 0.f ? 0.f : s;
+}
 
 // NC = number of classes when it is 2..4 (loops unrolled, the Dice counters of a thread in registers and reduced once per
 // block), 0 = any (per-pixel wave ballots).
@@ -137,9 +145,15 @@ __global__ __launch_bounds__(256) void upsample_argmax_dice_kernel(UpArgs a)
     const int npl = (lr1 - lr0 + 1) * a.wl;              // low-resolution pixels of the band
     const bool staged = a.staged && lr1 - lr0 + 1 <= a.lr_cap;
     // Head fused in: `logits` is the NHWC decoder FEATURE, which the unstaged taps below would read as NCHW class planes (in bounds,
-    // wrong values).  The host sizes lr_cap as a proven bound on a block's band, so this never happens; if that bound is ever broken
-    // the launch must die, not return plausible masks.
-    if (a.hw_ && !staged) __builtin_trap();
+    // wrong values).  The host computes lr_cap with THIS arithmetic for every block of the launch (up_src_host: the same fp32
+    // operations) and refuses the call with GDKVM_ERR_SHAPE when a band does not fit the LDS tile, so the condition cannot hold here;
+    // a block that met it anyway writes nothing (GDKVM_DEBUG_TRAPS builds: it faults).
+    if (a.hw_ && !staged) {
+#ifdef GDKVM_DEBUG_TRAPS
+        __builtin_trap();
+#endif
+        return;
+    }
     if (staged && a.hw_) {
         // the head on the band: C/V lanes per pixel, lane cg keeps class cg (as head_logits_kernel; same sums, same rounding)
         constexpr int V = IO == GDKVM_F32 ? 4 : 8;
@@ -357,12 +371,19 @@ static int upsample_launch(const char* who, const void* src, const float* head_w
     int gx = (nq + 255) / 256;
     const int cap = BT >= 1024 ? 2 : (BT >= 256 ? 4 : 16);  // enough blocks to fill the chip, few enough that launch and the
     if (gx > cap) gx = cap;                                //   per-block count reduction do not dominate
-    // low-resolution rows a block's contiguous output range can touch (+ slack: the kernel's own fp32 row arithmetic decides,
-    // and takes the unstaged path should a band ever exceed the tile)
+    // low-resolution rows a block's contiguous output range touches: the kernel's own arithmetic (band of block bx = rows
+    // up_src(q_lo) .. up_src(q_hi - 1) + 1), evaluated here for every block of the launch -- lr_cap is the largest band, exactly
     const int per = (((nq + gx - 1) / gx + 255) / 256) * 256, PX = (W % 4 == 0) ? 4 : 1;
-    const int out_rows = (per * PX + W - 1) / W + 1;
-    int lr_cap = (int)((double)out_rows * hl / H) + 4;
-    if (lr_cap > hl) lr_cap = hl;
+    const float sy_f = (float)hl / (float)H;
+    int lr_cap = 1;
+    for (int bx = 0; bx < gx; ++bx) {
+        const int q_lo = bx * per, q_hi = nq < q_lo + per ? nq : q_lo + per;
+        if (q_lo >= q_hi) continue;
+        const int lr0 = (int)up_src_host(sy_f, (q_lo * PX) / W);
+        int lr1 = (int)up_src_host(sy_f, (q_hi * PX - 1) / W) + 1;
+        if (lr1 > hl - 1) lr1 = hl - 1;
+        if (lr1 - lr0 + 1 > lr_cap) lr_cap = lr1 - lr0 + 1;
+    }
     const size_t cnt_bytes = sizeof(int) * (size_t)((ncls * 3 + 3) & ~3), log_bytes = sizeof(float) * (size_t)ncls * lr_cap * wl;
     const int staged = cnt_bytes + log_bytes <= 48 * 1024;
     if (head_w && !staged) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: %d classes x %d x %d low-resolution rows do not fit the LDS tile", who, ncls, lr_cap, wl);

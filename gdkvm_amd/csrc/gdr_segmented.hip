@@ -5,7 +5,7 @@
 // frames is prepared once (gdkvm_scan_prep), every segment's transition matrix Phi_c (gdkvm_scan_transition) and zero-start end
 // state S_loc_c (gdkvm_scan_apply without a read-out) are computed in parallel, one small kernel stitches the true start states
 // (gdkvm_scan_stitch: start_{c+1} = Phi_c start_c + S_loc_c, exact fp32), and every segment is scanned again from its start state
-// with the read-out.  2.25x the recurrence work on S times the workgroups: cfg5 397 us against 516 us serial.
+// with the read-out.  2.25x the recurrence work on S times the workgroups: cfg5 269 us against 346 us serial (round 3).
 // NOT bit-identical to gdkvm_scan_fwd (fp32 re-association through Phi), which is why gdkvm_scan_fwd -- whose contract is "a clip
 // processed as consecutive calls is bit-identical to one call" -- never switches to this path by itself.
 #include "gdkvm_common.hpp"

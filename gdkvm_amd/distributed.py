@@ -82,11 +82,19 @@ def context_parallel_scan(q, k, v, alpha, beta, state=None, rule: int = 2, flags
         mine = torch.cat([phi, s_loc], -1).contiguous()                      # [B,Hh,Dk,Dk+Dv]
         every = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)                                         # the only exchange of the whole scan
-        start = None
-        for r in range(world):
-            if r == rank:
-                start = cur
-            cur = torch.matmul(every[r][..., :Dk], cur) + every[r][..., Dk:]
+        stitch = getattr(backend, "scan_stitch", None)
+        if stitch is not None:
+            # the ranks' maps folded by ONE launch (gdkvm_scan_stitch: the serial stitch of the time-segmented scan, exact fp32 MFMA):
+            # starts[:, r] is the state rank r's frames begin with, `end` the state after the last rank's -- identical on every rank
+            both = torch.stack(every, 1)                                     # [B, world, Hh, Dk, Dk+Dv]
+            starts, end = stitch(both[..., :Dk].contiguous(), both[..., Dk:].contiguous(), cur if state is not None else None)
+            start, cur = starts[:, rank], end
+        else:                                                                # (a test backend without the kernel: the same fold, rank by rank)
+            start = None
+            for r in range(world):
+                if r == rank:
+                    start = cur
+                cur = torch.matmul(every[r][..., :Dk], cur) + every[r][..., Dk:]
         r_local, _ = backend.scan_apply(q, alpha, ws, Dv, state=start.contiguous(), flags=flags)
         return r_local, cur
     return backend.scan_apply(q, alpha, ws, Dv, state=cur if state is not None else None, flags=flags)

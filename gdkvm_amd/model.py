@@ -42,6 +42,13 @@ class GDKVMConfig:
     widths: Tuple[int, int, int] = (64, 128, 256)
     rule: str = "delta_sequential"
     stride: int = 16
+    # Inference on long clips (BASELINE.json configs[4]): how the memory scan treats the time axis of ONE forward call.
+    #   1 (default)  the serial recurrence, gdkvm_scan_fwd: a clip processed as consecutive calls with the state carried
+    #                (GDKVM.segment_clip) is bit-identical to one call;
+    #   0            gdkvm_scan_fwd_segmented with the segment count it picks for the shape (a power of two >= 4 when the serial grid
+    #                leaves more than half the CUs idle -- 2 clips x 512 frames: 16 -- else the serial scan); n > 1: that many.
+    #                Equal to the serial scan up to fp32 re-association through the segments' transition matrices, NOT bit for bit.
+    scan_segments: int = 1
 
 
 def _bn(c):
@@ -467,6 +474,13 @@ class GDKVM(nn.Module):
         flags = ops.FLAG_NORMALIZE_QK | ops.FLAG_GATE_LOGITS
         if torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v, alpha_logit, beta_logit)):
             return ops.scan(q, k, v, alpha_logit, beta_logit, state, _RULES[self.cfg.rule], flags)   # saves history
+        seg = self.cfg.scan_segments
+        if seg != 1 and q.is_cuda and q.shape[1] > 1:
+            # time segments of one long call run concurrently (SURVEY §8f n3 inside one GPU); segments = 0 lets the library choose and
+            # falls back to the serial scan where segmenting cannot pay
+            if seg > 1 and q.shape[1] % seg:
+                raise ValueError(f"scan_segments={seg} must divide the call's {q.shape[1]} frames")
+            return ops.scan_fwd_segmented(q, k, v, alpha_logit, beta_logit, state, segments=seg, rule=_RULES[self.cfg.rule], flags=flags)
         return ops.scan_fwd(q, k, v, alpha_logit, beta_logit, state, rule=_RULES[self.cfg.rule], flags=flags, norms=norms)
 
     def _fuse(self, local, glob, pixel, h, w):
@@ -604,9 +618,9 @@ class GDKVM(nn.Module):
             r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state)
         fused = self._fuse(k_tok, r.reshape(B * T, N, Hh * Dv), p_tok, h, w)       # [BT,N,Cp]
         fmap = fused.reshape(B * T, h, w, -1).permute(0, 3, 1, 2)                  # channels_last view, no copy
-        logits = self.decoder(fmap, f8, f4, None if _lowres else (H, W), head_fused=_head_fused and _lowres and not return_state)
+        logits = self.decoder(fmap, f8, f4, None if _lowres else (H, W), head_fused=_head_fused and _lowres)
         if isinstance(logits, HeadFeature):
-            return logits
+            return (logits, s_out) if return_state else logits
         logits = logits.reshape(B, T, cfg.num_classes, *logits.shape[-2:])
         return (logits, s_out) if return_state else logits
 
@@ -653,18 +667,43 @@ class GDKVM(nn.Module):
         return self
 
     @torch.no_grad()
-    def segment(self, frames, target=None, **kw):
-        """logits -> (mask uint8 [B,T,H,W], Dice counts int32 [B,T,ncls,3] | None) with the HIP argmax kernel."""
+    def segment(self, frames, target=None, return_state: bool = False, **kw):
+        """logits -> (mask uint8 [B,T,H,W], Dice counts int32 [B,T,ncls,3] | None) with the HIP argmax kernel
+        (return_state: plus the memory state after the last frame, [B,Hh,Dk,Dv] fp32)."""
         B, T, _, H, W = frames.shape
         tgt = None if target is None else target.reshape(B * T, H, W).contiguous()
-        lowres = self.forward(frames, _lowres=True, _head_fused=True, **kw)   # [B,T,ncls,H/4,W/4], or the feature under the head
+        lowres = self.forward(frames, _lowres=True, _head_fused=True, return_state=return_state, **kw)   # [B,T,ncls,H/4,W/4], or the feature under the head
+        s_out = None
+        if return_state:
+            lowres, s_out = lowres
         if isinstance(lowres, HeadFeature):
             # head + upsample + argmax + Dice in one kernel: the class planes never reach memory (bit-identical to the two-kernel form)
             mask, counts = ops.head_upsample_argmax_dice(lowres.feature, lowres.weight, lowres.bias, H, W, tgt)
-            return mask.reshape(B, T, H, W), (None if counts is None else counts.reshape(B, T, lowres.weight.shape[0], 3))
-        ncls, hl, wl = lowres.shape[2:]
-        mask, counts = ops.upsample_argmax_dice(lowres.reshape(B * T, ncls, hl, wl).contiguous(), H, W, tgt)
-        return mask.reshape(B, T, H, W), (None if counts is None else counts.reshape(B, T, ncls, 3))
+            ncls = lowres.weight.shape[0]
+        else:
+            ncls, hl, wl = lowres.shape[2:]
+            mask, counts = ops.upsample_argmax_dice(lowres.reshape(B * T, ncls, hl, wl).contiguous(), H, W, tgt)
+        out = (mask.reshape(B, T, H, W), (None if counts is None else counts.reshape(B, T, ncls, 3)))
+        return out + (s_out,) if return_state else out
+
+    @torch.no_grad()
+    def segment_clip(self, frames, chunk_frames: int, target=None, mask0=None, state=None):
+        """A long clip as consecutive chunks of ``chunk_frames`` frames with the memory state carried from chunk to chunk
+        ("GDR memory-state carry across chunks", BASELINE.json configs[4]): activations are held for one chunk at a time, and -- with
+        the default ``scan_segments = 1`` -- masks, Dice counts and the final state are those of ONE call over the whole clip, and of
+        any other chunk length, bit for bit (every kernel of the inference build is deterministic and works frame by frame; the scan is
+        chunk-invariant by gdkvm_scan_fwd's contract).  Returns (mask [B,T,H,W] uint8, counts [B,T,ncls,3] | None, final state)."""
+        B, T = frames.shape[:2]
+        if chunk_frames <= 0:
+            raise ValueError("chunk_frames must be positive")
+        masks, counts = [], []
+        for t0 in range(0, T, chunk_frames):
+            t1 = min(T, t0 + chunk_frames)
+            m, c, state = self.segment(frames[:, t0:t1], None if target is None else target[:, t0:t1], return_state=True,
+                                       mask0=mask0 if t0 == 0 else None, state=state)
+            masks.append(m)
+            counts.append(c)
+        return torch.cat(masks, 1), (None if target is None else torch.cat(counts, 1)), state
 
     # -------------------------------------------------------------------------------------- checkpoints
     def load_state_dict(self, state_dict, strict: bool = True, **kw):

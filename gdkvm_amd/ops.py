@@ -186,7 +186,7 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
     q,k [B,T,N,Hh,Dk]  v [B,T,N,Hh,Dv]  (f32|bf16)   alpha [B,T,Hh]  beta [B,T,N,Hh]  state [B,Hh,Dk,Dv] (f32)
     returns (R [B,T,N,Hh,Dv] in the io dtype, S_T [B,Hh,Dk,Dv] f32).
     Range: the default recurrence carries the state as fp16 pairs at 2^-e with e sized from the call's own bound on the state
-    (include/gdkvm.h, GDKVM_FLAG_WIDE_RANGE), so values and carried states of any magnitude are served for rules 0 and 2; the
+    (include/gdkvm.h, GDKVM_FLAG_WIDE_RANGE), so values and carried states of any magnitude are served for rules 0 and 2 (with unit-norm keys and gates in [0, 1]: flags=3, or inputs the caller normalised); the
     one refusal -- frames of more than 64 tokens with values ~1e5x the usual -- returns NaNs, and FLAG_WIDE_RANGE serves it.
     norms [B*T*N, Hh, 2] fp32 (ops.proj_gates): the inverse key / query norms came with the projections (gdkvm_scan_fwd_normed:
     the frame-parallel kernel neither reads q nor reduces anything in its first phase); needs FLAG_NORMALIZE_QK, Dk = 64."""

@@ -22,10 +22,11 @@ def segmentation_loss(logits: torch.Tensor, target: torch.Tensor, dice_weight: f
     lg = logits.reshape(B * T, C, H, W).float()
     tg = target.reshape(B * T, H, W).long()
     labelled = (tg >= 0) & (tg < C)                 # anything else (255 in annotation masks) carries no class
-    if bool(labelled.any()):
-        ce = F.cross_entropy(lg, torch.where(labelled, tg, torch.full_like(tg, -100)), ignore_index=-100)
-    else:                                           # no labelled pixel: the mean over none is 0 here, as in seg_loss_finalize_kernel
-        ce = lg.sum() * 0.0                         # (F.cross_entropy returns NaN, which would reach AdamW)
+    # sum over the labelled pixels / their count, with the count clamped to 1: a batch without a labelled pixel gives 0 (as
+    # seg_loss_finalize_kernel does; F.cross_entropy's own mean would be NaN and reach AdamW) -- and no host branch, i.e. no
+    # device-to-host synchronisation in front of the backward
+    ce = F.cross_entropy(lg, torch.where(labelled, tg, torch.full_like(tg, -100)), ignore_index=-100, reduction="sum") \
+        / labelled.sum().clamp_min(1)
     p = lg.softmax(1)
     oh = (F.one_hot(torch.where(labelled, tg, torch.zeros_like(tg)), C) * labelled.unsqueeze(-1)).permute(0, 3, 1, 2).float()
     inter = (p * oh).sum((0, 2, 3))

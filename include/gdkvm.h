@@ -53,10 +53,15 @@ enum { GDKVM_FLAG_NORMALIZE_QK = 1,      /* q,k <- x * rsqrt(sum x^2 + 1e-12)   
        GDKVM_FLAG_TRAIN = 4,             /* prep also emits the operand layouts gdkvm_scan_bwd reads (set by
                                             gdkvm_scan_fwd itself whenever s_hist != NULL) */
        GDKVM_FLAG_WIDE_RANGE = 8         /* operands of the state recurrence as three bf16 terms (the whole fp32 range, twice
-                                            the MFMAs) instead of the default fp16 pairs (22 bits).  The default is safe at
-                                            any magnitude for rules GATED_LINEAR and DELTA_SEQUENTIAL with L2-normalised keys:
-                                            the serial kernel carries the state at 2^-e and sizes e per call and 16-column
-                                            slice from a bound on the state, 8 (max|s_in| + sum_t max|G_t|) -- e = 4 (the
+                                            the MFMAs) instead of the default fp16 pairs (22 bits).  The default serves
+                                            values and carried states of any magnitude for rules GATED_LINEAR and
+                                            DELTA_SEQUENTIAL PROVIDED every frame's map is a contraction -- keys of unit norm,
+                                            alpha and beta in [0, 1]: guaranteed by the kernels themselves when both
+                                            GDKVM_FLAG_NORMALIZE_QK and GDKVM_FLAG_GATE_LOGITS are set, and the caller's
+                                            promise when it passes keys / gates it normalised itself (raw gates above 1 or
+                                            un-normalised keys without the flags void the bound below: pass this flag then).
+                                            The serial kernel carries the state at 2^-e and sizes e per call and 16-column
+                                            slice from that bound, 8 (max|s_in| + sum_t max|G_t|) -- e = 4 (the
                                             format's default, hence bit-identical chunked calls) for every ordinary input,
                                             larger exactly when the state needs it.  One corner is refused loudly rather
                                             than served: frames of more than 64 tokens whose chunk composition leaves the
@@ -130,7 +135,7 @@ int gdkvm_scan_stitch(const float* phi, const float* s_loc, const float* s_in, f
 /* Row n3 as one call: gdkvm_scan_fwd with the time axis cut into `segments` equal pieces that run concurrently (prep of the clip
  * viewed as B*segments clips, gdkvm_scan_transition + a read-out-free gdkvm_scan_apply per segment, gdkvm_scan_stitch, then
  * gdkvm_scan_apply from the true start states).  For long clips on few clips / heads / columns, where the serial recurrence leaves
- * CUs idle: 2x512 frames, Dv = 256 (32 serial workgroups) 397 us with 16 segments against 516 us.  segments must divide T;
+ * CUs idle: 2x512 frames, Dv = 256 (32 serial workgroups) 269 us with 16 segments against 346 us (round 3).  segments must divide T;
  * segments == 0 chooses by shape (gdkvm_scan_segments returns the choice: a power of two >= 4, or 1 = plain gdkvm_scan_fwd).
  * Equal to gdkvm_scan_fwd up to fp32 re-association through Phi -- NOT bit-identical, which is why gdkvm_scan_fwd, whose contract
  * is bit-identity under chunked calls, never takes this path by itself.  No s_hist (inference).  workspace:
@@ -239,7 +244,8 @@ int gdkvm_kpff_fwd_packed(const void* local, const void* global, const void* pix
  * gates after the sigmoid [M,2Cp], L wl^T [M,Cp], Gms wg^T [M,Cp] and the pooled feature Gms [M,Cv].  The backward is
  *   gdkvm_kpff_bwd_pre   d_z = (d_out*Lp*g_l(1-g_l) | d_out*Gp*g_g(1-g_g)), d_lp = d_out*g_l, d_gp = d_out*g_g
  *   six plain GEMMs      d_x = d_z wa, d_l_add = d_lp wl, d_g_add = d_gp wg, d_wa = d_z^T [P;L;Gms], d_wl = d_lp^T L,
- *                        d_wg = d_gp^T Gms  (and d_ba = column sums of d_z) -- library GEMMs on the caller's side
+ *                        d_wg = d_gp^T Gms  (and d_ba = column sums of d_z) -- on the caller's side: gdkvm_gemm_nt for the
+ *                        products against weights, gdkvm_gemm_tn (split over the token rows, deterministic) for the weight gradients
  *   gdkvm_kpff_bwd_post  d_pixel = d_out + d_x[:, :Cp], d_local = d_x[:, Cp:Cp+Ck] + d_l_add,
  *                        d_global = pool(d_x[:, Cp+Ck:] + d_g_add)   (the multi-scale pooling operator is symmetric) */
 int gdkvm_kpff_fwd_train(const void* local, const void* global, const void* pixel,

@@ -68,7 +68,9 @@ def test_module_against_the_independent_restatement(hip):
         lb = fused(frames.cuda()).float().cpu().double()
     err = (lb - lp).abs()
     rms = lp.pow(2).mean().sqrt().item()                # errors relative to the logits' own scale (random-init logits are small)
-    assert err.mean() <= 0.05 * rms and err.max() <= 0.3 * rms, (err.max().item() / rms, err.mean().item() / rms)
+    # (mean relative to the logits' rms; the largest single error by the tighter of the rms-relative bound and the absolute one the test
+    #  used before -- for logits of rms >= 1 a 30 %-of-rms outlier would otherwise pass)
+    assert err.mean() <= 0.05 * rms and err.max() <= min(0.3 * rms, 0.05 * max(1.0, lp.abs().max().item())), (err.max().item() / rms, err.mean().item() / rms)
     agree = (lb.argmax(2) == lp.argmax(2)).float().mean().item()
     assert agree >= 0.97, agree
 
@@ -90,7 +92,9 @@ def test_fused_build_on_maps_wider_than_64_pixels(hip):
         lb = fused(frames.cuda(), _lowres=True).float().cpu().double()
     err = (lb - lp).abs()
     rms = lp.pow(2).mean().sqrt().item()
-    assert err.mean() <= 0.05 * rms and err.max() <= 0.3 * rms, (err.max().item() / rms, err.mean().item() / rms)
+    # (mean relative to the logits' rms; the largest single error by the tighter of the rms-relative bound and the absolute one the test
+    #  used before -- for logits of rms >= 1 a 30 %-of-rms outlier would otherwise pass)
+    assert err.mean() <= 0.05 * rms and err.max() <= min(0.3 * rms, 0.05 * max(1.0, lp.abs().max().item())), (err.max().item() / rms, err.mean().item() / rms)
     agree = (lb.argmax(2) == lp.argmax(2)).float().mean().item()
     frac = lp.argmax(2).float().mean().item()
     assert agree >= 0.97 and 0.2 < frac < 0.8, (agree, frac)
