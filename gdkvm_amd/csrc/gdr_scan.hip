@@ -48,7 +48,8 @@ struct AffArgs {
     int reverse;                                     // visit the frames last to first (the backward's reverse recurrence)
     float* simg;                                     // DEFER: per-frame operand images of the state for gdr_readout_kernel
     const float* gmax;                               // pair16: max |G| per frame and slice from the frame-parallel side (NULL: default exponent)
-    float* esc;                                      // DEFER, pair16: 2^e of this (clip-head, slice) for gdr_readout_kernel
+    float* esc;                                      // pair16: 2^e of this (clip-head, slice) -- NaN when the call's bound is not finite -- for
+                                                     // gdr_readout_kernel (DEFER) and for gdkvm_scan_status
 };
 // LDS (16-byte units): S term images [2 parities][NT terms][2 ksteps][64] | (fp32 I/O on split3) S fp32 images [2][4][64]
 template <int IO> struct RItem;                                        // read-out operands of one 16-token tile
@@ -133,6 +134,9 @@ __global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
         }
     }
     const float STATE = st_scale, STATE_INV = st_inv;
+    if constexpr (PAIR) {                                  // every workgroup leaves its slice's 2^e (gdr_ws.hpp: esc)
+        if (a.esc && wave == 0 && lane == 0) a.esc[(size_t)bh * ((nsl + 3) & ~3) + sl] = STATE_INV;
+    }
     const float gfix = st_scale * OpFmt<FMT>::STATE_INV;   // what G (prepared at the default exponent) is multiplied by: 1 unless rescaled
 
     // Publishing S: the three bf16 terms of this wave's rows 16w + 4g + r (k of the next product) as B images; the fp32
@@ -160,9 +164,6 @@ __global__ __launch_bounds__(AFF_THREADS) void gdr_affine_scan_kernel(AffArgs a)
     if (role == 1) {
         // ------------------------------------------------------------------------------ read-out waves
         if constexpr (DEFER) {                             // dump the images of S_{t-1}: 1 KiB per read wave and frame
-            if constexpr (PAIR) {
-                if (a.esc && w == 0 && lane == 0) a.esc[(size_t)bh * ((nsl + 3) & ~3) + sl] = STATE_INV;
-            }
             uint4* dst = reinterpret_cast<uint4*>(a.simg) + ((fh0 * nsl + sl) * 4 + w) * 64 + lane;
             const size_t d_fstride = (size_t)Hh * nsl * 4 * 64;
             aff_barrier();
@@ -624,6 +625,38 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
         else hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
         GDKVM_LAUNCH_CHECK("gdr_readout_kernel");
     }
+    return GDKVM_OK;
+}
+
+// The one SYNCHRONISING entry point of the scan: did the last gdkvm_scan_fwd / gdkvm_scan_apply on this workspace stay inside the range
+// of its fp16-pair operands?  Every call is asynchronous, so a range failure cannot come back as its return code; it is loud in the data
+// (NaNs) and visible here: the serial kernel leaves 2^e per (clip-head, 16-column slice) in the workspace, NaN where the bound on the state
+// -- or a chunk composition on the way to it -- was not finite.  Copies those words back on `stream`, waits for it, and returns
+// GDKVM_ERR_RANGE (with the remedy in gdkvm_last_error) or GDKVM_OK.
+extern "C" int gdkvm_scan_status(const void* workspace, size_t workspace_bytes, int B, int T, int Hh, int N, int Dk, int Dv, int flags, void* stream)
+{
+    if (gdr_narrow_keys(Dk)) Dk = GDKVM_DK;                // (gdkvm_scan_fwd ran the Dk = 64 kernels on the same base layout)
+    if (int rc = check_common("scan_status", B, T, Hh, N, Dk, Dv, GDKVM_F32, flags)) return rc;
+    if (B == 0 || T == 0 || N == 0 || (flags & GDKVM_FLAG_WIDE_RANGE)) return GDKVM_OK;        // nothing ran / full-range operands: no bound to break
+    if (int rc = check_ptrs("scan_status", {workspace}, {})) return rc;
+    WsView ws;
+    if (int rc = carve("scan_status", const_cast<void*>(workspace), workspace_bytes, B, T, Hh, N, Dk, Dv, &ws)) return rc;
+    const int nsl = Dv / 16, nsl4 = (nsl + 3) & ~3;
+    const size_t words = (size_t)B * Hh * nsl4;
+    float* host = static_cast<float*>(malloc(words * sizeof(float)));
+    if (!host) return gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_status: out of host memory");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemcpyAsync(host, ws.esc, words * sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    int bad = -1;
+    if (e == hipSuccess)
+        for (size_t i = 0; i < words && bad < 0; ++i)
+            if ((int)(i % nsl4) < nsl && host[i] != host[i]) bad = (int)(i / nsl4);
+    free(host);
+    if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_status: %s", hipGetErrorString(e));
+    if (bad >= 0)
+        return gdkvm_fail(GDKVM_ERR_RANGE, "scan: the state of clip-head %d left the range of the fp16-pair operands (a bound that is not finite, or a "
+                                           "chunk composition of a frame of more than 64 tokens beyond it); the results are NaNs -- pass GDKVM_FLAG_WIDE_RANGE", bad);
     return GDKVM_OK;
 }
 

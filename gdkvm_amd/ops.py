@@ -39,6 +39,7 @@ SIGNATURES = {
     "gdkvm_scan_fwd_normed": (_i, [_vp] * 10 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_transition": (_i, [_vp] * 4 + [_sz] + [_i] * 8 + [_vp]),
     "gdkvm_scan_stitch": (_i, [_vp] * 5 + [_i] * 5 + [_vp]),
+    "gdkvm_scan_status": (_i, [_vp, _sz] + [_i] * 7 + [_vp]),
     "gdkvm_scan_bwd_workspace_bytes": (_sz, [_i] * 6),
     "gdkvm_scan_state_bwd": (_i, [_vp] * 6 + [_sz] + [_vp] * 8 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_bwd": (_i, [_vp] * 7 + [_sz] + [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
@@ -180,7 +181,7 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
              state: Optional[torch.Tensor] = None, rule: int = RULE_DELTA_SEQUENTIAL, flags: int = 0,
              workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
              state_out: Optional[torch.Tensor] = None, state_hist: Optional[torch.Tensor] = None,
-             readout: bool = True, norms: Optional[torch.Tensor] = None) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+             readout: bool = True, norms: Optional[torch.Tensor] = None, check: bool = False) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
     """Fused LKVA read + GDR write over T frames (gdkvm_scan_fwd).
 
     q,k [B,T,N,Hh,Dk]  v [B,T,N,Hh,Dv]  (f32|bf16)   alpha [B,T,Hh]  beta [B,T,N,Hh]  state [B,Hh,Dk,Dv] (f32)
@@ -188,6 +189,7 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
     Range: the default recurrence carries the state as fp16 pairs at 2^-e with e sized from the call's own bound on the state
     (include/gdkvm.h, GDKVM_FLAG_WIDE_RANGE), so values and carried states of any magnitude are served for rules 0 and 2 (with unit-norm keys and gates in [0, 1]: flags=3, or inputs the caller normalised); the
     one refusal -- frames of more than 64 tokens with values ~1e5x the usual -- returns NaNs, and FLAG_WIDE_RANGE serves it.
+    check=True: wait for the call and raise GdkvmError if the data left that range (gdkvm_scan_status; synchronises the stream).
     norms [B*T*N, Hh, 2] fp32 (ops.proj_gates): the inverse key / query norms came with the projections (gdkvm_scan_fwd_normed:
     the frame-parallel kernel neither reads q nor reduces anything in its first phase); needs FLAG_NORMALIZE_QK, Dk = 64."""
     lib = load()
@@ -227,13 +229,26 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
                                            workspace.data_ptr(), workspace.numel() * workspace.element_size(),
                                            B, T, Hh, N, Dk, Dv, io, rule, flags, _stream(dev))
         _check(rc, "gdkvm_scan_fwd_normed")
+        if check:
+            scan_status(workspace, B, T, Hh, N, Dk, Dv, flags | (FLAG_WIDE_RANGE if rule == RULE_DELTA_PARALLEL else 0))
         return r, s
     with torch.cuda.device(dev):
         rc = lib.gdkvm_scan_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(alpha), _ptr(beta), _ptr(state), _ptr(r), _ptr(s),
                                 _ptr(state_hist), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
                                 B, T, Hh, N, Dk, Dv, io, rule, flags, _stream(dev))
     _check(rc, "gdkvm_scan_fwd")
+    if check:
+        scan_status(workspace, B, T, Hh, N, Dk, Dv, flags | (FLAG_WIDE_RANGE if rule == RULE_DELTA_PARALLEL else 0))
     return r, s
+
+
+def scan_status(workspace: torch.Tensor, B: int, T: int, Hh: int, N: int, Dk: int, Dv: int, flags: int = 0) -> None:
+    """Raises GdkvmError (GDKVM_ERR_RANGE) if the last scan_fwd / scan_apply on ``workspace`` left the range of its fp16-pair operands
+    (its results are NaNs then); returns None otherwise.  Waits for the current stream (gdkvm_scan_status)."""
+    dev = _dev(workspace)
+    with torch.cuda.device(dev):
+        rc = load().gdkvm_scan_status(workspace.data_ptr(), workspace.numel() * workspace.element_size(), B, T, Hh, N, Dk, Dv, flags, _stream(dev))
+    _check(rc, "gdkvm_scan_status")
 
 
 def scan_bwd(q, k, v, alpha, beta, state_hist, workspace, d_r, d_state_out=None, rule=RULE_DELTA_SEQUENTIAL, flags=0,

@@ -17,6 +17,7 @@
  *       GDKVM_ERR_SHAPE (-1) bad / unsupported shape    GDKVM_ERR_DTYPE (-2) unsupported io_dtype
  *       GDKVM_ERR_ARCH  (-3) device is not gfx950       GDKVM_ERR_LAUNCH(-4) HIP launch failure
  *       GDKVM_ERR_WORKSPACE (-5) workspace too small    GDKVM_ERR_ARG (-6) null / misaligned pointer
+ *     (a return code speaks about the ARGUMENTS of an asynchronous call, never about its data: see gdkvm_scan_status, GDKVM_ERR_RANGE)
  *     gdkvm_last_error() returns a thread-local message for the most recent failure on this thread;
  *   - re-entrant; concurrent calls are safe iff their output / workspace buffers are distinct.
  *
@@ -38,7 +39,8 @@ extern "C" {
 #define GDKVM_ABI_VERSION 1
 
 enum { GDKVM_OK = 0, GDKVM_ERR_SHAPE = -1, GDKVM_ERR_DTYPE = -2, GDKVM_ERR_ARCH = -3,
-       GDKVM_ERR_LAUNCH = -4, GDKVM_ERR_WORKSPACE = -5, GDKVM_ERR_ARG = -6 };
+       GDKVM_ERR_LAUNCH = -4, GDKVM_ERR_WORKSPACE = -5, GDKVM_ERR_ARG = -6,
+       GDKVM_ERR_RANGE = -7 /* gdkvm_scan_status only: the data left the numeric range of the default operand format */ };
 
 enum { GDKVM_F32 = 0, GDKVM_BF16 = 1 };                       /* io_dtype */
 
@@ -90,6 +92,14 @@ int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const float* alp
                    const float* s_in, void* r_out, float* s_out, float* s_hist, void* workspace, size_t workspace_bytes,
                    int B, int T, int Hh, int N, int Dk, int Dv,
                    int io_dtype, int rule, int flags, void* stream);
+
+/* Did the last gdkvm_scan_fwd / gdkvm_scan_fwd_normed / gdkvm_scan_apply on `workspace` (same shape arguments and flags) stay inside the
+ * range of the default fp16-pair operands?  Those calls are asynchronous and return before a kernel has seen the data; where the bound
+ * on the state is not finite -- or a chunk composition of a frame of more than 64 tokens overflowed on the way -- the results are NaNs
+ * (never saturated numbers), and this call says so: it copies the per-slice exponents the serial kernel left in the workspace back on
+ * `stream`, WAITS for the stream (the one synchronising entry point of the library), and returns GDKVM_ERR_RANGE or GDKVM_OK.
+ * GDKVM_FLAG_WIDE_RANGE serves such inputs.  Optional: nothing else in the library depends on it being called. */
+int gdkvm_scan_status(const void* workspace, size_t workspace_bytes, int B, int T, int Hh, int N, int Dk, int Dv, int flags, void* stream);
 
 /* The two stages of gdkvm_scan_fwd as separate entry points (gdkvm_scan_fwd == prep then apply on one stream).
  * `prep` is state-independent and parallel over frames: the a5 prologue incl. the query norms, and every frame folded

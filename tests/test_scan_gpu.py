@@ -354,6 +354,7 @@ def test_scan_large_values_and_carried_state(hip, rule, log2_scale, dtype):
     Rg, Sg = _run(hip, q, k, v, a, b, s0, rule, 3, dtype)
     Ro, So = c_oracle.scan(q, k, v, a, b, s0, rule, 3, math="f64")
     assert np.isfinite(Rg).all() and np.isfinite(Sg).all()
+    hip.scan_fwd(_dev(q, dtype), _dev(k, dtype), _dev(v, dtype), _dev(a), _dev(b), _dev(s0), rule=rule, flags=3, check=True)    # (in range: no exception)
     assert np.abs(Sg - So).max() <= TOL * scale, (np.abs(Sg - So).max() / scale)
     out_q = 2.0 ** -8 if dtype == torch.bfloat16 else 0.0
     assert np.all(np.abs(Rg - Ro) <= TOL * scale + np.abs(Ro) * out_q), (np.abs(Rg - Ro).max() / scale)
@@ -383,6 +384,17 @@ def test_scan_large_values_in_frames_of_more_than_64_tokens(hip, dtype, monkeypa
         v22 = (v * 2.0 ** 22).astype(np.float32)
         Rg, Sg = _run(hip, q, k, v22, a, b, None, 2, 3, dtype)
         assert np.isnan(Sg).all() and np.isnan(Rg[:, 1:]).all()             # (frame 0 reads the zero start state)
+        # the call itself returned 0 (asynchronous: no kernel had seen the data); gdkvm_scan_status reports it as GDKVM_ERR_RANGE, the
+        # ordinary call and the full-range one as fine, and check=True turns it into an exception
+        ws = hip.new_workspace(B, T, Hh, N, 64, Dv, torch.device("cuda"))
+        t22 = [_dev(x, dtype) for x in (q, k, v22)] + [_dev(a), _dev(b)]
+        hip.scan_fwd(*t22, flags=3, workspace=ws)
+        with pytest.raises(hip.GdkvmError, match=r"\(-7\).*GDKVM_FLAG_WIDE_RANGE"):
+            hip.scan_status(ws, B, T, Hh, N, 64, Dv, 3)
+        with pytest.raises(hip.GdkvmError, match="range"):
+            hip.scan_fwd(*t22, flags=3, check=True)
+        hip.scan_fwd(*t22, flags=3 | 8, workspace=ws, check=True)
+        hip.scan_fwd(_dev(q, dtype), _dev(k, dtype), _dev(v12, dtype), _dev(a), _dev(b), flags=3, workspace=ws, check=True)
         Rw, Sw = _run(hip, q, k, v22, a, b, None, 2, 3 | 8, dtype)
         Ro, So = c_oracle.scan(q, k, v22, a, b, None, 2, 3, math="f64")
         assert np.abs(Sw - So).max() <= TOL * 2.0 ** 22 and np.all(np.abs(Rw - Ro) <= TOL * 2.0 ** 22 + np.abs(Ro) * 2.0 ** -8)
