@@ -530,6 +530,41 @@ def main():
             else:                                            # a (nearly) constant mask says nothing about the kernels
                 out["dice_vs_cpu"] = None
                 out["dice_skipped"] = f"degenerate reference mask: foreground fraction {fg:.4f} outside (0.2, 0.8)"
+            # The same comparison on a head that separates its classes by real margins: a short fit on the synthetic echo clips (60 AdamW steps of
+            # 8 clips x 8 frames, the HIP training step), then held-out clips through the fp32 module, the fused bf16 build and the CPU reference
+            # with the same weights.  (The random-init figures above measure bf16 rounding against logit gaps of ~1e-3.)
+            try:
+                from gdkvm_amd import train as gtrain
+                from gdkvm_amd.data import SyntheticEchoClips
+                torch.manual_seed(21)
+                mfit = GDKVM(cfg).to(dev).to(memory_format=torch.channels_last)
+                losses = gtrain.fit_synthetic(mfit, steps=60, clips=8, frames=8, size=S, num_classes=cfg.num_classes, seed=5)
+                held = SyntheticEchoClips(4, 8, S, cfg.num_classes, seed=99)
+                hx = torch.stack([held[i][0] for i in range(4)])
+                hy = torch.stack([held[i][1] for i in range(4)]).to(torch.uint8)
+                sdf = {k_: v_.detach().cpu().clone() for k_, v_ in mfit.state_dict().items()}
+                reff = GDKVMRef(cfg).eval()
+                reff.load_state_dict(sdf)
+                with torch.no_grad():
+                    mref, _ = reff.segment(hx[:2])
+                    m32f, c32f = mfit.segment(hx.to(dev), target=hy.to(dev))
+                    ffit = GDKVM(cfg).eval()
+                    ffit.load_state_dict(sdf)
+                    ffit = ffit.to(dev).to(memory_format=torch.channels_last).fuse_for_inference().to(torch.bfloat16)
+                    m16f, c16f = ffit.segment(hx.to(dev), target=m32f)
+                    _, c16y = ffit.segment(hx.to(dev), target=hy.to(dev))
+                out["dice_fitted_model"] = {
+                    "fit": f"60 AdamW steps x 8 synthetic clips x 8 frames {S}x{S}, loss {losses[0]:.3f} -> {losses[-1]:.3f}",
+                    "dice_vs_labels_fp32": [round(x, 5) for x in ops.dice_from_counts(c32f.sum((0, 1))).tolist()],
+                    "dice_vs_labels_bf16": [round(x, 5) for x in ops.dice_from_counts(c16y.sum((0, 1))).tolist()],
+                    "dice_bf16_build_vs_fp32_module": [round(x, 5) for x in ops.dice_from_counts(c16f.sum((0, 1))).tolist()],
+                    "mask_agreement_fp32_gpu_vs_cpu_reference": round((m32f[:2].cpu() == mref).float().mean().item(), 6),
+                    "mask_agreement_bf16_vs_fp32": round((m16f == m32f).float().mean().item(), 6),
+                    "foreground_fraction": round((m32f != 0).float().mean().item(), 4),
+                    "held_out": "4 clips x 8 frames (2 of them through the CPU reference)"}
+                del mfit, ffit, reff
+            except Exception as e:                              # noqa: BLE001 -- informational leg
+                out["dice_fitted_model"] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- BASELINE configs[3] beside the headline: a few training steps at the per-GPU shape, AFTER the timed region and the
     # kernel timings above (every rank; DDP + RCCL all-reduce when N > 1).  It can only add a `train_step` object: a failure is

@@ -75,3 +75,24 @@ def train_step(model: nn.Module, opt: torch.optim.Optimizer, frames: torch.Tenso
     loss.backward()
     opt.step()
     return loss.detach()
+
+
+def fit_synthetic(model: nn.Module, steps: int, clips: int = 8, frames: int = 8, size: int = 112, num_classes: int = 2, lr: float = 2e-3,
+                  seed: int = 0, device: Optional[torch.device] = None, autocast_dtype: Optional[torch.dtype] = torch.bfloat16):
+    """A short fit on the seeded synthetic echo clips (gdkvm_amd.data.SyntheticEchoClips): `steps` AdamW steps of `clips` fresh clips
+    each.  Not a training recipe -- it exists so that parity figures (Dice of one build's masks against another's, against the CPU
+    reference's, against the labels) are measured on a head that separates its classes by real margins instead of a random-init one
+    whose logits differ by 1e-3.  Returns the list of losses."""
+    from .data import SyntheticEchoClips
+    dev = device or next(model.parameters()).device
+    ds = SyntheticEchoClips(steps * clips, frames, size, num_classes, seed=seed)
+    opt = torch.optim.AdamW(model.parameters(), lr=lr)
+    model.train()
+    losses = []
+    for s in range(steps):
+        items = [ds[s * clips + j] for j in range(clips)]
+        x = torch.stack([a for a, _ in items]).to(dev)
+        y = torch.stack([b for _, b in items]).to(dev)
+        losses.append(float(train_step(model, opt, x, y, autocast_dtype if dev.type == "cuda" else None)))
+    model.eval()
+    return losses

@@ -76,6 +76,7 @@ def test_kpff_bf16_mfma_arm(hip, case):
     Fo = c_oracle.kpff(O.to_bf16_f32(L), O.to_bf16_f32(G), O.to_bf16_f32(P), O.to_bf16_f32(Wa), ba, O.to_bf16_f32(Wl),
                        O.to_bf16_f32(Wg), h, w)
     err = np.abs(F - Fo)
+    print(f"kpff bf16 arm {case}: max err {err.max():.3e} (|F| there {np.abs(Fo).flat[err.argmax()]:.2f}), mean {err.mean():.3e}, max of err - |F| 2^-8: {(err - np.abs(Fo) * 2.0 ** -8).max():.3e}, rms F {np.sqrt((Fo ** 2).mean()):.2f}")
     assert np.all(err <= 1e-2 + np.abs(Fo) * 2.0 ** -7), err.max()
     assert err.mean() <= 2e-3
 
