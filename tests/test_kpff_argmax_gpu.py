@@ -68,7 +68,7 @@ def test_kpff_fp32_on_bf16_splits(hip, case):
 def test_kpff_bf16_mfma_arm(hip, case):
     """bf16 I/O, channels % 32 == 0 -> bf16 MFMA arm: weights and the pooled feature are rounded to bf16 (bf16
     autocast accuracy).  Checked against the oracle fed the same bf16-rounded inputs AND weights; what is left is
-    the bf16 rounding of the pooled feature and of the output: 1e-2 absolute + 2^-7 relative."""
+    the bf16 rounding of the pooled feature and of the output: 4e-3 absolute + half an output ulp (|F| 2^-8)."""
     BT, h, w, Ck, Cv, Cp = case
     L, G, P, Wa, ba, Wl, Wg = make_kpff_inputs(BT, h, w, Ck, Cv, Cp, seed=sum(case))
     F = hip.kpff_fwd(_dev(L, torch.bfloat16), _dev(G, torch.bfloat16), _dev(P, torch.bfloat16),
@@ -76,9 +76,11 @@ def test_kpff_bf16_mfma_arm(hip, case):
     Fo = c_oracle.kpff(O.to_bf16_f32(L), O.to_bf16_f32(G), O.to_bf16_f32(P), O.to_bf16_f32(Wa), ba, O.to_bf16_f32(Wl),
                        O.to_bf16_f32(Wg), h, w)
     err = np.abs(F - Fo)
-    print(f"kpff bf16 arm {case}: max err {err.max():.3e} (|F| there {np.abs(Fo).flat[err.argmax()]:.2f}), mean {err.mean():.3e}, max of err - |F| 2^-8: {(err - np.abs(Fo) * 2.0 ** -8).max():.3e}, rms F {np.sqrt((Fo ** 2).mean()):.2f}")
-    assert np.all(err <= 1e-2 + np.abs(Fo) * 2.0 ** -7), err.max()
-    assert err.mean() <= 2e-3
+    # Measured over these cases (round 4): the largest error beyond the output's own bf16 rounding (half an ulp <= |F| 2^-8) is 3.1e-3
+    # -- the bf16 rounding of the pooled feature through the 256-deep global mix -- and the mean error 1.34e-3 .. 1.41e-3; the bounds are
+    # those figures plus a third (the round-1 bound, 1e-2 + |F| 2^-7 and a mean of 2e-3, would have passed a kernel twice as wrong)
+    assert np.all(err <= 4e-3 + np.abs(Fo) * 2.0 ** -8), (err - np.abs(Fo) * 2.0 ** -8).max()
+    assert err.mean() <= 1.8e-3, err.mean()
 
 
 def test_kpff_bf16_io_exact_arm(hip):
