@@ -357,6 +357,69 @@ __global__ __launch_bounds__(256) void conv3x3_pack_dgrad_kernel(const bf16_t* w
 
 }  // namespace
 
+// ---- training: the forward pack AND the data-gradient pack of up to GDKVM_PACK_MAX_LAYERS layers in ONE launch, straight from the
+// fp32 master weights.  Per layer and step the training step ran a cast to bf16 (a framework kernel), conv3x3_pack_kernel and, in the
+// backward, conv3x3_pack_dgrad_kernel: 3 x 14 launches of ~5 us that move < 1 MB each (profiles/r04_n_train_cfg4_steady_state.csv:
+// 0.19 ms of a 7.4 ms step).  Same bytes as those three: the fp32 -> bf16 conversion rounds to nearest even like the framework's cast.
+struct PackTrainLayer { const float* w; uint4* fwd; uint4* dgrad; int K, C; long long sK, sC, sR, sS; };   // element strides of w[k][c][r][s]
+struct PackTrainArgs { PackTrainLayer l[GDKVM_PACK_MAX_LAYERS]; };
+
+namespace {
+__global__ __launch_bounds__(256) void conv3x3_pack_train_kernel(PackTrainArgs a)
+{
+    const PackTrainLayer L = a.l[blockIdx.y];
+    if (!L.w) return;
+    const int K = L.K, C = L.C;
+    const size_t nf = (size_t)(K / 16) * (C / CT_CK * 18) * 64, nd = (size_t)(C / 16) * (K / CT_CK * 18) * 64;
+    auto bf = [](float x) { return (unsigned)f32_to_bf16(x); };
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nf + nd; i += (size_t)gridDim.x * 256) {
+        const bool fwd = i < nf;
+        const size_t ii = fwd ? i : i - nf;
+        const int lane = (int)(ii & 63), li = lane & 15, g = lane >> 4;
+        const size_t f = ii >> 6;
+        float e[8];
+        if (fwd) {                                          // w[ct_channel(kt, li)][tap][64 chunk + 32 kh + 8 g ..]   (conv3x3_pack_kernel)
+            const int nks = C / CT_CK * 18, ks = (int)(f % nks), kt = (int)(f / nks);
+            const int chunk = ks / 18, r = ks - 18 * chunk, tap = r >> 1, kh = r & 1;
+            const float* src = L.w + (long long)ct_channel(kt, li, K % 32 == 0) * L.sK + (long long)(tap / 3) * L.sR + (long long)(tap % 3) * L.sS
+                               + (long long)(chunk * CT_CK + 32 * kh + 8 * g) * L.sC;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = src[(long long)j * L.sC];
+        } else {                                            // w'[c][tap][k] = w[k][8 - tap][c]   (conv3x3_pack_dgrad_kernel)
+            const int nks = K / CT_CK * 18, ks = (int)(f % nks), ct = (int)(f / nks);
+            const int chunk = ks / 18, r = ks - 18 * chunk, tap = r >> 1, kh = r & 1, ftap = 8 - tap;
+            const float* src = L.w + (long long)ct_channel(ct, li, C % 32 == 0) * L.sC + (long long)(ftap / 3) * L.sR + (long long)(ftap % 3) * L.sS
+                               + (long long)(chunk * CT_CK + 32 * kh + 8 * g) * L.sK;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = src[(long long)j * L.sK];
+        }
+        const uint4 o = make_uint4(bf(e[0]) | bf(e[1]) << 16, bf(e[2]) | bf(e[3]) << 16, bf(e[4]) | bf(e[5]) << 16, bf(e[6]) | bf(e[7]) << 16);
+        (fwd ? L.fwd : L.dgrad)[ii] = o;
+    }
+}
+}  // namespace
+
+extern "C" int gdkvm_conv3x3_pack_weights_train(int nlayers, const void* const* w, void* const* packed_fwd, void* const* packed_dgrad,
+                                                const int* K, const int* C, const long long* strides, void* stream)
+{
+    if (nlayers < 0 || nlayers > GDKVM_PACK_MAX_LAYERS) return gdkvm_fail(GDKVM_ERR_SHAPE, "conv3x3_pack_weights_train: %d layers (at most %d per call)", nlayers, GDKVM_PACK_MAX_LAYERS);
+    if (nlayers == 0) return GDKVM_OK;
+    if (!w || !packed_fwd || !packed_dgrad || !K || !C || !strides) return gdkvm_fail(GDKVM_ERR_ARG, "conv3x3_pack_weights_train: null pointer");
+    PackTrainArgs a{};
+    for (int i = 0; i < nlayers; ++i) {
+        if (K[i] <= 0 || C[i] <= 0 || K[i] % CT_CK || C[i] % CT_CK)
+            return gdkvm_fail(GDKVM_ERR_SHAPE, "conv3x3_pack_weights_train: layer %d K=%d C=%d (multiples of 64)", i, K[i], C[i]);
+        if (!w[i] || !packed_fwd[i] || !packed_dgrad[i] || !gdkvm_aligned16(packed_fwd[i]) || !gdkvm_aligned16(packed_dgrad[i]))
+            return gdkvm_fail(GDKVM_ERR_ARG, "conv3x3_pack_weights_train: layer %d: null or unaligned pointer", i);
+        a.l[i] = PackTrainLayer{static_cast<const float*>(w[i]), static_cast<uint4*>(packed_fwd[i]), static_cast<uint4*>(packed_dgrad[i]), K[i], C[i],
+                                strides[4 * i], strides[4 * i + 1], strides[4 * i + 2], strides[4 * i + 3]};
+    }
+    if (int rc = gdkvm_check_device()) return rc;
+    hipLaunchKernelGGL(conv3x3_pack_train_kernel, dim3(48, (unsigned)nlayers), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    GDKVM_LAUNCH_CHECK("conv3x3_pack_train_kernel");
+    return GDKVM_OK;
+}
+
 extern "C" int gdkvm_conv3x3_pack_weights_dgrad(const void* w, void* packed, int K, int C, int io_dtype, void* stream)
 {
     if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "conv3x3_pack_weights_dgrad: only bf16 is implemented");

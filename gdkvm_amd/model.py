@@ -450,6 +450,8 @@ class GDKVM(nn.Module):
         fuse_for_inference()."""
         for name in ("_qkv_pack", "_gate_w32", "_kpff_pack"):
             self.__dict__.pop(name, None)
+        for w in self.__dict__.pop("_train_pack_weights", None) or ():     # (the training step's per-weight packs, ops.conv3x3_train_packs)
+            ops._TRAIN_PACKS.pop(id(w), None)
         if "_modules" not in self.__dict__:
             return
         dec = self._modules.get("decoder")
@@ -518,6 +520,15 @@ class GDKVM(nn.Module):
             x = x.to(dt)                                                         # (the space-to-depth stem reads NCHW frames itself)
         else:
             x = x.to(dtype=dt, memory_format=torch.channels_last)                # cast + NHWC in one pass
+        if self.training and x.is_cuda and torch.is_grad_enabled() and dt == torch.bfloat16:
+            # the forward and data-gradient packs of every stride-1 3x3 layer's weights, ONE launch for the step (ops.conv3x3 finds them;
+            # per layer it was a cast, a pack and, in the backward, a second pack)
+            ws = getattr(self, "_train_pack_weights", None)
+            if ws is None:
+                ws = self._train_pack_weights = [m.weight for m in self.modules() if isinstance(m, nn.Conv2d) and m.bias is None
+                                                 and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.groups == 1
+                                                 and m.weight.shape[0] % 64 == 0 and m.weight.shape[1] % 64 == 0]
+            ops.conv3x3_train_packs([w for w in ws if w.is_cuda and w.dtype == torch.float32])
         counted = self.training and x.is_cuda
         if counted:                                                              # BatchNorm step counters: one launch, not 19
             nbt = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.track_running_stats]

@@ -73,6 +73,7 @@ SIGNATURES = {
     "gdkvm_conv_down_bias_act": (_i, [_vp] * 4 + [_i] + [_vp] * 3 + [_i] * 10 + [_vp]),
     "gdkvm_conv_cat_bias_act": (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
     "gdkvm_conv3x3_pack_weights_dgrad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "gdkvm_conv3x3_pack_weights_train": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gdkvm_conv3x3_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "gdkvm_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _sz] + [_i] * 6 + [_vp]),
     "gdkvm_upsample_cat": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
@@ -877,6 +878,53 @@ def _zero_bias(k: int, device) -> torch.Tensor:
     return _ZERO_BIAS[key]
 
 
+_TRAIN_PACKS = {}            # id(weight) -> (key, forward pack, data-gradient pack): filled by conv3x3_train_packs, read by conv3x3
+
+
+def conv3x3_train_packs(weights) -> int:
+    """Both packs (forward, data gradient) of every listed fp32 [K,C,3,3] weight in ONE launch (gdkvm_conv3x3_pack_weights_train),
+    kept until the weight changes (version counter / storage) -- call once per training step, before the forward; ops.conv3x3 then finds
+    its layer's packs here instead of casting and packing per layer (three launches per layer and step).  Weights whose packs are current
+    are skipped.  Returns the number of layers packed."""
+    lib = load()
+    todo = []
+    for w in weights:
+        k, c = w.shape[:2]
+        if not (w.is_cuda and w.dtype == torch.float32 and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and k % 64 == 0 and c % 64 == 0):
+            continue
+        key = (w._version, w.data_ptr(), tuple(w.stride()))
+        ent = _TRAIN_PACKS.get(id(w))
+        if ent is None or ent[0] != key:
+            if ent is None or ent[1].numel() != k * 9 * c or ent[1].device != w.device:
+                ent = (None, torch.empty(k * 9 * c, dtype=torch.bfloat16, device=w.device), torch.empty(k * 9 * c, dtype=torch.bfloat16, device=w.device))
+            _TRAIN_PACKS[id(w)] = (key, ent[1], ent[2])
+            todo.append(w)
+    for i0 in range(0, len(todo), 24):
+        part = todo[i0:i0 + 24]
+        n = len(part)
+        P = ctypes.c_void_p * n
+        wp = P(*[w.data_ptr() for w in part])
+        fp = P(*[_TRAIN_PACKS[id(w)][1].data_ptr() for w in part])
+        dp = P(*[_TRAIN_PACKS[id(w)][2].data_ptr() for w in part])
+        ks = (ctypes.c_int * n)(*[w.shape[0] for w in part])
+        cs = (ctypes.c_int * n)(*[w.shape[1] for w in part])
+        st = (ctypes.c_longlong * (4 * n))(*[x for w in part for x in w.stride()])
+        dev = part[0].device
+        with torch.cuda.device(dev):
+            rc = lib.gdkvm_conv3x3_pack_weights_train(n, ctypes.cast(wp, ctypes.c_void_p), ctypes.cast(fp, ctypes.c_void_p), ctypes.cast(dp, ctypes.c_void_p),
+                                                      ctypes.cast(ks, ctypes.c_void_p), ctypes.cast(cs, ctypes.c_void_p), ctypes.cast(st, ctypes.c_void_p),
+                                                      _stream(dev))
+        _check(rc, "gdkvm_conv3x3_pack_weights_train")
+    return len(todo)
+
+
+def _train_packs_of(weight):
+    ent = _TRAIN_PACKS.get(id(weight))
+    if ent is not None and ent[0] == (weight._version, weight.data_ptr(), tuple(weight.stride())):
+        return ent[1], ent[2]
+    return None
+
+
 class _Conv3x3Function(torch.autograd.Function):
     """Training-mode 3x3 / stride 1 / pad 1 convolution (no bias) on the hand-written kernels: forward, the data gradient (the
     same kernel on the flipped, transposed weights: gdkvm_conv3x3_pack_weights_dgrad) and the weight gradient
@@ -886,26 +934,43 @@ class _Conv3x3Function(torch.autograd.Function):
     def forward(ctx, x, weight):
         lib = load()
         xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        k, c = weight.shape[:2]
+        packs = _train_packs_of(weight)                    # (conv3x3_train_packs ran for this version of the weight: nothing to cast or pack here)
+        ctx.kc, ctx.wdtype, ctx.xdtype = (k, c), weight.dtype, x.dtype
+        if packs is not None and os.environ.get("GDKVM_CONV_WGRAD") != "framework":
+            # the data-gradient pack belongs to THIS version of the weight: a copy would cost what the pre-pack saves, so the backward
+            # checks that the weight has not been written since (an optimiser step between forward and backward is not a thing)
+            ctx.dgrad_pack, ctx.pack_key = packs[1], (weight._version, weight.data_ptr())
+            ctx.weight_ref = weight
+            ctx.save_for_backward(xb)
+            return _conv3x3_packed(xb, packs[0], k, _zero_bias(k, xb.device))
         wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        k, c = wb.shape[:2]
         packed = torch.empty(k * 9 * c, dtype=torch.bfloat16, device=xb.device)
         with torch.cuda.device(xb.device):
             _check(lib.gdkvm_conv3x3_pack_weights(wb.data_ptr(), packed.data_ptr(), k, c, BF16, _stream(xb.device)), "gdkvm_conv3x3_pack_weights")
+        ctx.dgrad_pack = None
         ctx.save_for_backward(xb, wb)
-        ctx.wdtype, ctx.xdtype = weight.dtype, x.dtype
         return _conv3x3_packed(xb, packed, k, _zero_bias(k, xb.device))
 
     @staticmethod
     def backward(ctx, dy):
-        xb, wb = ctx.saved_tensors
-        k, c = wb.shape[:2]
+        k, c = ctx.kc
         dyb = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         dx = dw = None
+        if ctx.dgrad_pack is not None:
+            (xb,), wb = ctx.saved_tensors, None
+            w = ctx.weight_ref
+            if (w._version, w.data_ptr()) != ctx.pack_key:
+                raise RuntimeError("conv3x3: the weight was modified between forward and backward (its pre-packed data-gradient copy is stale)")
+        else:
+            xb, wb = ctx.saved_tensors
         if ctx.needs_input_grad[0]:
-            packed = torch.empty(k * 9 * c, dtype=torch.bfloat16, device=dyb.device)
-            with torch.cuda.device(dyb.device):
-                _check(load().gdkvm_conv3x3_pack_weights_dgrad(wb.data_ptr(), packed.data_ptr(), k, c, BF16, _stream(dyb.device)),
-                       "gdkvm_conv3x3_pack_weights_dgrad")
+            packed = ctx.dgrad_pack
+            if packed is None:
+                packed = torch.empty(k * 9 * c, dtype=torch.bfloat16, device=dyb.device)
+                with torch.cuda.device(dyb.device):
+                    _check(load().gdkvm_conv3x3_pack_weights_dgrad(wb.data_ptr(), packed.data_ptr(), k, c, BF16, _stream(dyb.device)),
+                           "gdkvm_conv3x3_pack_weights_dgrad")
             dx = _conv3x3_packed(dyb, packed, c, _zero_bias(c, dyb.device)).to(ctx.xdtype)
         if ctx.needs_input_grad[1]:
             if os.environ.get("GDKVM_CONV_WGRAD") == "framework":          # (A/B switch for tools: the framework's weight gradient)

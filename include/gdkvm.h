@@ -346,6 +346,14 @@ int gdkvm_conv_igemm_pack_weights(const void* w, void* packed, int K, int C, int
  * w'[c][ty][tx][k] = w[k][2 - ty][2 - tx][c] -- K input channels (a multiple of 64), C output channels (of 16).  Use it as
  * gdkvm_conv_bias_act(dy, packed, zero bias, NULL, dx, N, K, H, W, C, 3, 3, 1, 1, 0, kernel | GDKVM_CONV_PACKED_WEIGHTS, ...). */
 int gdkvm_conv3x3_pack_weights_dgrad(const void* w, void* packed, int K, int C, int io_dtype, void* stream);
+/* Training: both packs of up to GDKVM_PACK_MAX_LAYERS 3x3 layers in ONE launch, straight from the fp32 master weights (the per-layer
+ * sequence "cast to bf16, gdkvm_conv3x3_pack_weights, gdkvm_conv3x3_pack_weights_dgrad" is three launches of ~5 us per layer and step).
+ * w[i]: fp32 [K_i, C_i, 3, 3] with element strides strides[4i .. 4i+3] = (k, c, r, s) -- any memory format; packed_fwd[i] /
+ * packed_dgrad[i]: 18 K_i C_i bytes each, the copies the two calls above produce from the bf16-rounded weights, bit for bit.
+ * K_i, C_i multiples of 64.  The five arrays are HOST arrays. */
+#define GDKVM_PACK_MAX_LAYERS 24
+int gdkvm_conv3x3_pack_weights_train(int nlayers, const void* const* w, void* const* packed_fwd, void* const* packed_dgrad,
+                                     const int* K, const int* C, const long long* strides, void* stream);
 /* Weight gradient of the same layers (training):  dw [K, C, 3, 3] fp32 = sum over pixels dy[n,y,x,k] * x[n,y+ty-1,x+tx-1,c]  for
  * NHWC bf16 x [N,H,W,C] and dy [N,H,W,K]; C and K multiples of 64, rows of <= 64 pixels.  Deterministic (per-workgroup partial
  * blocks in the workspace, added in a fixed order).  workspace: gdkvm_conv3x3_wgrad_workspace_bytes. */

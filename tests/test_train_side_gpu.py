@@ -349,3 +349,40 @@ def test_train_step_uses_the_fused_objective(hip):
             continue
         scale = max(p.grad.abs().max().item(), 1e-6)
         assert (ga[n] - p.grad).abs().max().item() <= 2e-3 * scale, n
+
+
+def test_training_weight_packs_in_one_launch(hip):
+    """ops.conv3x3_train_packs: the forward and the data-gradient pack of several layers from their fp32 master weights in ONE launch
+    (gdkvm_conv3x3_pack_weights_train) are, bit for bit, what the per-layer sequence produces -- cast to bf16, gdkvm_conv3x3_pack_weights,
+    gdkvm_conv3x3_pack_weights_dgrad -- for contiguous and channels_last weights; ops.conv3x3 with the packs in place gives the same output
+    and the same gradients as without them; a changed weight is re-packed, an unchanged one is not."""
+    import ctypes
+    from gdkvm_amd import ops
+    lib = ops.load()
+    torch.manual_seed(3)
+    shapes = [(64, 64), (128, 64), (64, 192), (256, 256), (128, 384)]
+    ws = [torch.randn(k, c, 3, 3, device="cuda") / (c * 9) ** 0.5 for k, c in shapes]
+    ws[1] = ws[1].contiguous(memory_format=torch.channels_last)
+    ws[3] = ws[3].contiguous(memory_format=torch.channels_last)
+    ws = [torch.nn.Parameter(w) for w in ws]
+    assert ops.conv3x3_train_packs(ws) == len(ws) and ops.conv3x3_train_packs(ws) == 0
+    for w in ws:
+        k, c = w.shape[:2]
+        wb = w.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        f0 = torch.empty(k * 9 * c, dtype=torch.bfloat16, device="cuda"); d0 = torch.empty_like(f0)
+        assert lib.gdkvm_conv3x3_pack_weights(wb.data_ptr(), f0.data_ptr(), k, c, ops.BF16, None) == 0
+        assert lib.gdkvm_conv3x3_pack_weights_dgrad(wb.data_ptr(), d0.data_ptr(), k, c, ops.BF16, None) == 0
+        f1, d1 = ops._train_packs_of(w)
+        torch.cuda.synchronize()
+        assert torch.equal(f0.view(torch.int16), f1.view(torch.int16)) and torch.equal(d0.view(torch.int16), d1.view(torch.int16)), (k, c)
+    # the differentiable op with and without the packs
+    w = ws[1]
+    x = torch.randn(4, 64, 14, 14, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_()
+    gy = torch.randn(4, 128, 14, 14, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    y1 = ops.conv3x3(x, w); g1 = torch.autograd.grad(y1, (x, w), gy)
+    ops._TRAIN_PACKS.pop(id(w))
+    y0 = ops.conv3x3(x, w); g0 = torch.autograd.grad(y0, (x, w), gy)
+    assert torch.equal(y0, y1) and torch.equal(g0[0], g1[0]) and torch.equal(g0[1], g1[1])
+    with torch.no_grad():
+        ws[0].mul_(0.5)
+    assert ops.conv3x3_train_packs(ws) == 2                        # the rescaled one and the one dropped above
