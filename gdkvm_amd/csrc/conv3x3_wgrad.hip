@@ -151,7 +151,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a)
 // dW[k][c][ty][tx] (the framework's contiguous [K, C, 3, 3]) = sum over the gx partial blocks, in index order (deterministic).
 // Threads walk the PARTIAL layout ([block][k 64][tap 9][c 64], c fastest: coalesced reads of gx x 147 KB); the transposition to
 // [k][c][tap] happens on the (small) write.
-__global__ __launch_bounds__(512) void conv3x3_wgrad_reduce_kernel(const float* part, float* dw, int gx, int gy, int cblocks, int C, int K)
+// krsc: write dW as [k][ty][tx][c] instead -- the memory order of a channels_last [K, C, 3, 3] parameter, whose gradient the framework
+// otherwise re-lays out with a copy per layer and step (and the order the partials come in: the write is coalesced too).
+__global__ __launch_bounds__(512) void conv3x3_wgrad_reduce_kernel(const float* part, float* dw, int gx, int gy, int cblocks, int C, int K, int krsc)
 {
     // a block = 64 consecutive elements x 8 slices of the partial index (thread = element e, slice ch): coalesced 256-byte reads,
     // eight times the threads of one-thread-per-element (which ran 119 us on 36864 threads for 512 partials), fixed summation order
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_reduce_kernel(const float* 
             const int by = (int)(i / blk), r = (int)(i % blk);
             const int c = r & 63, t = (r >> 6) % 9, kk = (r >> 6) / 9;
             const int k = (by / cblocks) * 64 + kk, cc = (by % cblocks) * 64 + c;
-            dw[((size_t)k * C + cc) * 9 + t] = t8;
+            dw[krsc ? ((size_t)k * 9 + t) * C + cc : ((size_t)k * C + cc) * 9 + t] = t8;
         }
         __syncthreads();
     }
@@ -221,8 +223,8 @@ extern "C" size_t gdkvm_conv3x3_wgrad_workspace_bytes(int N, int C, int H, int W
     return (size_t)p.gx * p.gy * (64 * 9 * 64) * sizeof(float);
 }
 
-extern "C" int gdkvm_conv3x3_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
-                                   int N, int C, int H, int W, int K, int io_dtype, void* stream)
+static int conv3x3_wgrad_impl(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
+                              int N, int C, int H, int W, int K, int io_dtype, int krsc, void* stream)
 {
     if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "conv3x3_wgrad: only bf16 operands are implemented");
     WgradPlan p;
@@ -250,7 +252,19 @@ extern "C" int gdkvm_conv3x3_wgrad(const void* x, const void* dy, float* dw, voi
     GDKVM_LAUNCH_CHECK("conv3x3_wgrad_kernel");
     const size_t n = (size_t)K * 9 * C;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)(n / 64 > 4096 ? 4096 : n / 64)), dim3(512), 0, st,
-                       static_cast<const float*>(workspace), dw, p.gx, p.gy, p.a.cblocks, C, K);
+                       static_cast<const float*>(workspace), dw, p.gx, p.gy, p.a.cblocks, C, K, krsc);
     GDKVM_LAUNCH_CHECK("conv3x3_wgrad_reduce_kernel");
     return GDKVM_OK;
+}
+
+extern "C" int gdkvm_conv3x3_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
+                                   int N, int C, int H, int W, int K, int io_dtype, void* stream)
+{
+    return conv3x3_wgrad_impl(x, dy, dw, workspace, workspace_bytes, N, C, H, W, K, io_dtype, 0, stream);
+}
+
+extern "C" int gdkvm_conv3x3_wgrad_krsc(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
+                                        int N, int C, int H, int W, int K, int io_dtype, void* stream)
+{
+    return conv3x3_wgrad_impl(x, dy, dw, workspace, workspace_bytes, N, C, H, W, K, io_dtype, 1, stream);
 }

@@ -76,6 +76,7 @@ SIGNATURES = {
     "gdkvm_conv3x3_pack_weights_train": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gdkvm_conv3x3_wgrad_workspace_bytes": (_sz, [_i] * 5),
     "gdkvm_conv3x3_wgrad": (_i, [_vp, _vp, _vp, _vp, _sz] + [_i] * 6 + [_vp]),
+    "gdkvm_conv3x3_wgrad_krsc": (_i, [_vp, _vp, _vp, _vp, _sz] + [_i] * 6 + [_vp]),
     "gdkvm_upsample_cat": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_upsample_cat_bwd": (_i, [_vp] * 3 + [_i] * 8 + [_vp]),
     "gdkvm_bias_relu_maxpool": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
@@ -603,7 +604,7 @@ class _KpffFunction(torch.autograd.Function):
         d_wa = torch.cat([wgrad(dz, P2), wgrad(dz, L2), wgrad(dz, gms)], 1)       # K = B*T*N tokens: split over workgroups, fp32 partials
         d_wl = wgrad(dlp, L2)
         d_wg = wgrad(dgp, gms)
-        d_ba = dz.float().sum(0)
+        d_ba = dz.sum(0, dtype=torch.float32)               # (fp32 accumulation straight from the bf16 rows: no fp32 copy of dz)
         d_p, d_l, d_g = torch.empty_like(pixel), torch.empty_like(local), torch.empty((BT, N, Cv), dtype=dt, device=dev)
         with torch.cuda.device(dev):
             _check(lib.gdkvm_kpff_bwd_post(_ptr(d_f), _ptr(dx), _ptr(dl_add), _ptr(dg_add), _ptr(d_p), _ptr(d_l), _ptr(d_g),
@@ -937,6 +938,8 @@ class _Conv3x3Function(torch.autograd.Function):
         k, c = weight.shape[:2]
         packs = _train_packs_of(weight)                    # (conv3x3_train_packs ran for this version of the weight: nothing to cast or pack here)
         ctx.kc, ctx.wdtype, ctx.xdtype = (k, c), weight.dtype, x.dtype
+        ctx.w_cl = (weight.is_contiguous(memory_format=torch.channels_last) and not weight.is_contiguous()
+                    and os.environ.get("GDKVM_WGRAD_KRSC", "1") != "0")          # ("0": A/B switch for tools)
         if packs is not None and os.environ.get("GDKVM_CONV_WGRAD") != "framework":
             # the data-gradient pack belongs to THIS version of the weight: a copy would cost what the pre-pack saves, so the backward
             # checks that the weight has not been written since (an optimiser step between forward and backward is not a thing)
@@ -976,16 +979,18 @@ class _Conv3x3Function(torch.autograd.Function):
             if os.environ.get("GDKVM_CONV_WGRAD") == "framework":          # (A/B switch for tools: the framework's weight gradient)
                 dw = torch.ops.aten.convolution_backward(dyb, xb, wb, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1].to(ctx.wdtype)
             else:
-                dw = conv3x3_wgrad(xb, dyb).to(ctx.wdtype)  # (fp32 sums over all pixels, deterministic)
+                dw = conv3x3_wgrad(xb, dyb, channels_last=ctx.w_cl).to(ctx.wdtype)  # (fp32 sums over all pixels, deterministic; in the weight's own memory order)
         return dx, dw
 
 
 _WGRAD_WS = {}
 
 
-def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor, channels_last: bool = False) -> torch.Tensor:
     """dW [K,C,3,3] fp32 of a 3x3 / stride 1 / pad 1 convolution from channels_last bf16 x [N,C,H,W] and dy [N,K,H,W]
-    (gdkvm_conv3x3_wgrad): C, K multiples of 64, rows of at most 64 pixels; deterministic."""
+    (gdkvm_conv3x3_wgrad): C, K multiples of 64, rows of at most 64 pixels; deterministic.  channels_last: the result in the memory
+    order of a channels_last parameter (gdkvm_conv3x3_wgrad_krsc) -- the same numbers, no re-layout copy when it becomes that
+    parameter's .grad."""
     lib = load()
     for t in (x, dy):
         if t.dim() != 4 or not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous(memory_format=torch.channels_last):
@@ -994,7 +999,7 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     k = dy.shape[1]
     if tuple(dy.shape) != (n, k, hh, ww):
         raise GdkvmError("conv3x3_wgrad: x and dy must agree in batch and size")
-    dw = torch.empty((k, c, 3, 3), dtype=torch.float32, device=x.device)
+    dw = torch.empty((k, c, 3, 3), dtype=torch.float32, device=x.device, memory_format=torch.channels_last if channels_last else torch.contiguous_format)
     # one workspace per device and stream, grown to the largest layer (up to 75 MB of partial blocks): calls on a stream are
     # ordered, so the next layer's gradient may overwrite it
     need = max(16, int(lib.gdkvm_conv3x3_wgrad_workspace_bytes(n, c, hh, ww, k)))
@@ -1003,7 +1008,8 @@ def conv3x3_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     if ws is None or ws.numel() < need:
         ws = _WGRAD_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
     with torch.cuda.device(x.device):
-        rc = lib.gdkvm_conv3x3_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), n, c, hh, ww, k, BF16, _stream(x.device))
+        fn = lib.gdkvm_conv3x3_wgrad_krsc if channels_last else lib.gdkvm_conv3x3_wgrad
+        rc = fn(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws.numel(), n, c, hh, ww, k, BF16, _stream(x.device))
     _check(rc, "gdkvm_conv3x3_wgrad")
     return dw
 
@@ -1395,7 +1401,8 @@ class _TokenLinear(torch.autograd.Function):
         dy = dy.contiguous()
         dx = gemm_nt(dy, w.t().contiguous()) if ctx.needs_input_grad[0] else None
         dw = wgrad(dy, x2d).to(ctx.wdtype) if ctx.needs_input_grad[1] else None
-        db = dy.float().sum(0).to(ctx.wdtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        # (column sums with fp32 accumulation straight from the rows: .float().sum(0) wrote and re-read an fp32 copy of dy first)
+        db = dy.sum(0, dtype=torch.float32).to(ctx.wdtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 

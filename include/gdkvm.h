@@ -360,6 +360,10 @@ int gdkvm_conv3x3_pack_weights_train(int nlayers, const void* const* w, void* co
 size_t gdkvm_conv3x3_wgrad_workspace_bytes(int N, int C, int H, int W, int K);
 int gdkvm_conv3x3_wgrad(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
                         int N, int C, int H, int W, int K, int io_dtype, void* stream);
+/* The same gradient written as [K, 3, 3, C] -- the memory order of a channels_last [K, C, 3, 3] parameter (the framework re-lays a
+ * contiguous gradient out with one copy per layer and step). */
+int gdkvm_conv3x3_wgrad_krsc(const void* x, const void* dy, float* dw, void* workspace, size_t workspace_bytes,
+                        int N, int C, int H, int W, int K, int io_dtype, void* stream);
 int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const void* residual, void* y,
                         int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int relu, int kernel,
                         int io_dtype, void* stream);

@@ -276,6 +276,9 @@ def test_convolution_weight_gradient(hip, case):
     assert dw.dtype == torch.float32 and dw.shape == w64.shape and dw.is_contiguous()
     assert (dw.double() - w64.grad).abs().max() <= 1e-5 * (n * h * w) ** 0.5 * max(1.0, w64.grad.abs().max().item() / (n * h * w) ** 0.5)
     assert torch.equal(dw, hip.conv3x3_wgrad(x, dy))
+    # the same numbers in the memory order of a channels_last parameter (no re-layout copy when they become its .grad)
+    dwc = hip.conv3x3_wgrad(x, dy, channels_last=True)
+    assert dwc.is_contiguous(memory_format=torch.channels_last) and torch.equal(dwc, dw)
 
 
 def test_fused_objective_ignores_unlabelled_pixels(hip):
