@@ -589,6 +589,22 @@ def main():
                 out["train_step"] = run_train(args, world, rank, dev, args.train_steps, args.train_warmup)
         except Exception as e:                               # noqa: BLE001 -- the headline must survive the extra leg
             out["train_step"] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        # where the step's time goes: the five largest kernels of the newest committed steady-state trace of this workload
+        # (profiles/*_train_cfg4_steady_state.csv: rocprofv3 --kernel-trace of `bench.py --mode train`; tools/profile_train.sh) -- a record of
+        # that run, quoted with its file name, not a measurement of this one
+        try:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_train_cfg4_steady_state.csv")), key=os.path.getmtime)
+            if files and isinstance(out.get("train_step"), dict) and "error" not in out["train_step"]:
+                with open(files[-1]) as f:
+                    lines = f.read().splitlines()
+                rows = [ln.split(",") for ln in lines if ln and not ln.startswith("#") and not ln.startswith("Name,")]
+                out["train_step"]["top_kernels"] = {
+                    "source": os.path.relpath(files[-1], ROOT), "note": lines[1].lstrip("# ") if len(lines) > 1 else "",
+                    "kernels": [{"name": ",".join(r[:-3])[:80], "calls_per_step": float(r[-3]), "us_per_step": float(r[-2]), "share_pct": float(r[-1])}
+                                for r in rows[:5]]}
+        except Exception:                                    # noqa: BLE001
+            pass
     emit()
     if world > 1:
         dist.barrier()
