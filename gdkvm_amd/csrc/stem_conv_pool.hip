@@ -34,8 +34,14 @@ __device__ const uint4 g_stem_zero16 = {0, 0, 0, 0};
 struct StemArgs {
     const bf16_t* xs; const bf16_t* w; const float* bias; bf16_t* y;
     int N, Hs, Ws, Hp, Wp, tiles_x, tiles_y;
+    const bf16_t* xf; int Cf;            // NCHW: the frames themselves [N, Cf <= 4, 2 Hs, 2 Ws] (xs unused)
 };
 
+// NCHW (round 4): the band is built from the NCHW frames by the workgroup itself -- a 16-byte slot of the space-to-depth image is four
+// 4-byte column pairs (channel c, row parity p: x[c][2Y + p][2X .. 2X + 1]) -- so the space-to-depth pass (gdkvm_stem_s2d: 38 MB read,
+// 51 MB written and read back, 20 us of a 1 ms forward) disappears.  The pieces the LDS-DMA fetched are fetched into registers a tile
+// ahead (16 dwords per lane) and written to the other band buffer behind the tile's MFMAs; same bytes in LDS, hence the same results.
+template <bool NCHW>
 __global__ __launch_bounds__(512, 1) void stem_conv_pool_kernel(StemArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -79,13 +85,49 @@ __global__ __launch_bounds__(512, 1) void stem_conv_pool_kernel(StemArgs a)
         }
     };
 
+    // NCHW: the same slots from the frames: slot d = 2 pix + half holds channel pairs (2 half, 2 half + 1) x row parity (0, 1)
+    unsigned stage[PP][4];
+    auto fetch_nchw = [&](int tile) __attribute__((always_inline)) {
+        const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
+        const int y0 = 2 * SP_TPY * ty - 3, x0 = 2 * SP_TPX * tx - 3;
+        const int H = 2 * a.Hs, W = 2 * a.Ws;
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            const int j = w + 8 * u, d = 64 * j + lane, pix = d >> 1, half = d & 1;
+            const int by = pix / SP_BC, bx = pix - by * SP_BC, yy = y0 + by, xx = x0 + bx;
+            const bool ok = j < SP_PIECES && pix < SP_BR * SP_BC && yy >= 0 && yy < a.Hs && xx >= 0 && xx < a.Ws;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                   // e = 2 (channel within the half) + row parity
+                const int c = 2 * half + (e >> 1);
+                const bool live = ok && c < a.Cf;
+                const bf16_t* src = live ? a.xf + ((((size_t)n * a.Cf + c) * H + 2 * yy + (e & 1)) * W + 2 * xx) : reinterpret_cast<const bf16_t*>(&g_stem_zero16);
+                stage[u][e] = *reinterpret_cast<const unsigned*>(src);
+            }
+        }
+    };
+    auto put_nchw = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            const int j = w + 8 * u;
+            if (j < SP_PIECES)
+                *reinterpret_cast<uint4*>(band2 + buf * SP_BAND_BYTES + 1024 * j + 16 * lane) = make_uint4(stage[u][0], stage[u][1], stage[u][2], stage[u][3]);
+        }
+    };
+
     const unsigned xoff = (unsigned)((16 * wm + li) * 32 + g * 16);          // this lane's pixel column / K group inside a band row
     int tile = blockIdx.x, cur = 0;
-    if (tile < ntiles) fetch(tile, 0);
+    if (tile < ntiles) {
+        if constexpr (NCHW) { fetch_nchw(tile); put_nchw(0); }
+        else fetch(tile, 0);
+    }
     __syncthreads();
     for (; tile < ntiles; tile += gridDim.x, cur ^= 1) {
+        const bool more = tile + (int)gridDim.x < ntiles;
 #ifndef STEM_ABL_NODMA
-        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x, cur ^ 1);          // lands behind this tile's MFMAs
+        if (more) {                                                                      // lands behind this tile's MFMAs
+            if constexpr (NCHW) fetch_nchw(tile + gridDim.x);
+            else fetch(tile + gridDim.x, cur ^ 1);
+        }
 #endif
         const unsigned char* band = band2 + cur * SP_BAND_BYTES;
         const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
@@ -137,6 +179,7 @@ __global__ __launch_bounds__(512, 1) void stem_conv_pool_kernel(StemArgs a)
                 *reinterpret_cast<uint4*>(ctile + (cr * SP_CC + 16 * wm + li) * SP_CPIX + (32 * wn + 8 * g) * 2) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
             }
         }
+        if constexpr (NCHW) { if (more) put_nchw(cur ^ 1); }   // (the other buffer was last read a tile ago, two barriers back)
         __syncthreads();                                   // the convolution tile is complete (and the next band has landed)
 
         // ---- 3x3 / stride 2 max-pool out of LDS: item = (pooled row q, pooled column px, 8-channel group) ------------------
@@ -171,31 +214,34 @@ __global__ __launch_bounds__(512, 1) void stem_conv_pool_kernel(StemArgs a)
 
 }  // namespace
 
-extern "C" int gdkvm_stem_conv_pool(const void* xs, const void* w, const float* bias, void* y, int N, int Hs, int Ws,
-                                    int io_dtype, void* stream)
+static int stem_conv_pool_impl(const char* who, const void* xs, const void* xf, int Cf, const void* w, const float* bias, void* y,
+                               int N, int Hs, int Ws, int io_dtype, void* stream)
 {
-    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "stem_conv_pool: only bf16 is implemented");
-    if (N < 0 || Hs <= 0 || Ws <= 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "stem_conv_pool: N=%d Hs=%d Ws=%d", N, Hs, Ws);
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "%s: only bf16 is implemented", who);
+    if (N < 0 || Hs <= 0 || Ws <= 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: N=%d Hs=%d Ws=%d", who, N, Hs, Ws);
     if (N == 0) return GDKVM_OK;
-    if (!xs || !w || !bias || !y) return gdkvm_fail(GDKVM_ERR_ARG, "stem_conv_pool: null pointer");
-    if (!gdkvm_aligned16(xs) || !gdkvm_aligned16(w) || !gdkvm_aligned16(y) || !gdkvm_aligned16(bias))
-        return gdkvm_fail(GDKVM_ERR_ARG, "stem_conv_pool: pointers must be 16-byte aligned");
+    const void* x = xf ? xf : xs;
+    if (!x || !w || !bias || !y) return gdkvm_fail(GDKVM_ERR_ARG, "%s: null pointer", who);
+    if (!gdkvm_aligned16(x) || !gdkvm_aligned16(w) || !gdkvm_aligned16(y) || !gdkvm_aligned16(bias))
+        return gdkvm_fail(GDKVM_ERR_ARG, "%s: pointers must be 16-byte aligned", who);
     if (int rc = gdkvm_check_device()) return rc;
     StemArgs a;
     a.xs = static_cast<const bf16_t*>(xs); a.w = static_cast<const bf16_t*>(w); a.bias = bias; a.y = static_cast<bf16_t*>(y);
+    a.xf = static_cast<const bf16_t*>(xf); a.Cf = Cf;
     a.N = N; a.Hs = Hs; a.Ws = Ws; a.Hp = (Hs - 1) / 2 + 1; a.Wp = (Ws - 1) / 2 + 1;
     a.tiles_x = (a.Wp + SP_TPX - 1) / SP_TPX; a.tiles_y = (a.Hp + SP_TPY - 1) / SP_TPY;
     const long long ntiles = (long long)N * a.tiles_x * a.tiles_y;
-    if (ntiles > 0x7fffffffLL) return gdkvm_fail(GDKVM_ERR_SHAPE, "stem_conv_pool: too many tiles");
+    if (ntiles > 0x7fffffffLL) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: too many tiles", who);
     const size_t lds = 2 * (size_t)SP_BAND_BYTES + SP_CONV_BYTES;
     {   // > 64 KiB of dynamic LDS needs the opt-in once per kernel and device; lock-free cache as in gdr_scan.hip
         static std::atomic<unsigned long long> done_mask{0};
         int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "stem_conv_pool: hipGetDevice");
+        if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "%s: hipGetDevice", who);
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "stem_conv_pool: %s", hipGetErrorString(e));
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_pool_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_pool_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "%s: %s", who, hipGetErrorString(e));
             done_mask.fetch_or(bit, std::memory_order_relaxed);
         }
     }
@@ -203,7 +249,22 @@ extern "C" int gdkvm_stem_conv_pool(const void* xs, const void* w, const float* 
 #define STEM_GRID 256                                      // persistent, one workgroup per CU
 #endif
     const int grid = (int)(ntiles < STEM_GRID ? ntiles : STEM_GRID);
-    hipLaunchKernelGGL(stem_conv_pool_kernel, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+    if (xf) hipLaunchKernelGGL(stem_conv_pool_kernel<true>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+    else hipLaunchKernelGGL(stem_conv_pool_kernel<false>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
     GDKVM_LAUNCH_CHECK("stem_conv_pool_kernel");
     return GDKVM_OK;
+}
+
+extern "C" int gdkvm_stem_conv_pool(const void* xs, const void* w, const float* bias, void* y, int N, int Hs, int Ws,
+                                    int io_dtype, void* stream)
+{
+    return stem_conv_pool_impl("stem_conv_pool", xs, nullptr, 0, w, bias, y, N, Hs, Ws, io_dtype, stream);
+}
+
+extern "C" int gdkvm_stem_conv_pool_nchw(const void* x, const void* w, const float* bias, void* y, int N, int C, int H, int W,
+                                         int io_dtype, void* stream)
+{
+    if (C <= 0 || C > 4 || H <= 0 || W <= 0 || (H & 1) || (W & 1))
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "stem_conv_pool_nchw: C=%d H=%d W=%d (at most 4 channels, H and W even)", C, H, W);
+    return stem_conv_pool_impl("stem_conv_pool_nchw", nullptr, x, C, w, bias, y, N, H / 2, W / 2, io_dtype, stream);
 }

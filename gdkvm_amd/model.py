@@ -71,6 +71,9 @@ _IGEMM_STRIDED = os.environ.get("GDKVM_CONV_IGEMM", "1") != "0"
 # launch over the pixel feature (ops.proj_gates), the scan taking the norms as given -- or (GDKVM_PROJ_GATES=0, the A/B switch
 # behind DESIGN.md §8 n4's numbers) the three-launch form: ops.proj_rows, ops.gate_logits, norms inside gdkvm_scan_prep.
 _PROJ_GATES = os.environ.get("GDKVM_PROJ_GATES", "1") != "0"
+# The inference stem reading the NCHW frames itself (round 4: ops.stem_conv_pool_nchw), or (GDKVM_STEM_NCHW=0, the A/B switch) the
+# space-to-depth pass followed by the stem kernel; bit-identical.
+_STEM_NCHW = os.environ.get("GDKVM_STEM_NCHW", "1") != "0"
 
 
 def _bn_act(bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -363,6 +366,10 @@ class FusedConvPool(FusedConv):
 
     def forward(self, x, residual=None):
         if x.is_cuda and getattr(self, "w_s2d", None) is not None and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+            if (_STEM_NCHW and x.dtype == torch.bfloat16 and x.shape[1] <= 4 and self.w_s2d.dtype == torch.bfloat16
+                    and tuple(self.w_s2d.shape) == (64, 16, 4, 4) and self.w_s2d.is_contiguous(memory_format=torch.channels_last)):
+                # the stem kernel builds its space-to-depth band from the NCHW frames itself: one kernel, no 16-channel copy of the input
+                return ops.stem_conv_pool_nchw(x.contiguous(), self.w_s2d, self.epi.bias)
             xs = ops.stem_s2d(x.contiguous(), self.S2D_CH)                       # NCHW frames -> NHWC space-to-depth, one pass
             if (xs.dtype == torch.bfloat16 and self.w_s2d.dtype == torch.bfloat16 and tuple(self.w_s2d.shape) == (64, 16, 4, 4)
                     and self.w_s2d.is_contiguous(memory_format=torch.channels_last)):

@@ -65,6 +65,7 @@ SIGNATURES = {
     "gdkvm_head_logits": (_i, [_vp] * 4 + [_i] * 6 + [_vp]),
     "gdkvm_proj_rows": (_i, [_vp] * 6 + [ctypes.c_longlong] + [_i] * 5 + [_vp]),
     "gdkvm_stem_conv_pool": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
+    "gdkvm_stem_conv_pool_nchw": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "gdkvm_gate_logits": (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     "gdkvm_proj_gates": (_i, [_vp] * 13 + [_i] * 7 + [_vp]),
     "gdkvm_conv_bias_act": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
@@ -1180,6 +1181,25 @@ def stem_conv_pool(xs: torch.Tensor, w_s2d: torch.Tensor, bias: torch.Tensor) ->
     with torch.cuda.device(xs.device):
         rc = lib.gdkvm_stem_conv_pool(xs.data_ptr(), w_s2d.data_ptr(), bias.data_ptr(), y.data_ptr(), n, hs, ws, BF16, _stream(xs.device))
     _check(rc, "gdkvm_stem_conv_pool")
+    return y
+
+
+def stem_conv_pool_nchw(x: torch.Tensor, w_s2d: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """stem_conv_pool(stem_s2d(x, 16), w_s2d, bias) without the space-to-depth copy (gdkvm_stem_conv_pool_nchw): x contiguous NCHW bf16
+    [N, C <= 4, H, W] with H, W even; bit-identical to the two-kernel form."""
+    lib = load()
+    if x.dim() != 4 or not x.is_cuda or x.dtype != torch.bfloat16 or not x.is_contiguous() or x.shape[1] > 4 or x.shape[2] % 2 or x.shape[3] % 2:
+        raise GdkvmError("stem_conv_pool_nchw needs a contiguous NCHW bf16 [N, C <= 4, H, W] device tensor with even H, W (no CPU path)")
+    if tuple(w_s2d.shape) != (64, 16, 4, 4) or w_s2d.dtype != torch.bfloat16 or not w_s2d.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("stem_conv_pool: weight must be channels_last bf16 [64,16,4,4]")
+    if bias.dtype != torch.float32 or bias.numel() != 64:
+        raise GdkvmError("bias must be float32 [64]")
+    n, c, hh, ww = x.shape
+    hs, ws = hh // 2, ww // 2
+    y = torch.empty((n, 64, (hs - 1) // 2 + 1, (ws - 1) // 2 + 1), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        rc = lib.gdkvm_stem_conv_pool_nchw(x.data_ptr(), w_s2d.data_ptr(), bias.data_ptr(), y.data_ptr(), n, c, hh, ww, BF16, _stream(x.device))
+    _check(rc, "gdkvm_stem_conv_pool_nchw")
     return y
 
 

@@ -394,6 +394,11 @@ int gdkvm_bias_relu_maxpool(const void* x, const float* bias, void* y, int N, in
  * channels.  The full-resolution activation exists only as an LDS tile (csrc/stem_conv_pool.hip). */
 int gdkvm_stem_conv_pool(const void* xs, const void* w, const float* bias, void* y, int N, int Hs, int Ws,
                          int io_dtype, void* stream);
+/* The same kernel reading the NCHW frames x [N, C <= 4, H, W] themselves (H, W even; Hs = H/2, Ws = W/2): the workgroup builds its band of
+ * the space-to-depth image on the way into LDS, so gdkvm_stem_s2d and its 16-channel copy of the input are not needed.  Bit-identical to
+ * gdkvm_stem_s2d followed by gdkvm_stem_conv_pool. */
+int gdkvm_stem_conv_pool_nchw(const void* x, const void* w, const float* bias, void* y, int N, int C, int H, int W,
+                              int io_dtype, void* stream);
 
 /* Row n1, the training stem: 3x3 / stride 2 / pad 1 max-pool of an NHWC tensor x [N, H, W, C] -> y [N, Ho, Wo, C]
  * (Ho = (H-1)/2+1) recording the winning tap of every output element in idx (one byte each, [N, Ho, Wo, C]: 3*dy + dx in

@@ -415,6 +415,21 @@ def test_stem_conv_pool_in_one_kernel(hip, case):
     assert (got.double() - want).abs().max() <= 2.0 ** -7 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("case", [(3, 3, 112, 112), (2, 3, 256, 256), (1, 1, 16, 16), (2, 4, 60, 88), (5, 3, 4, 4), (1, 2, 114, 46), (17, 3, 112, 112)])
+def test_stem_reads_the_nchw_frames_itself(hip, case):
+    """gdkvm_stem_conv_pool_nchw (the workgroup builds its band of the space-to-depth image from the NCHW frames on the way into LDS) is
+    gdkvm_stem_s2d followed by gdkvm_stem_conv_pool, bit for bit: 1 .. 4 input channels, ragged sizes, more tiles than workgroups."""
+    n, c, hh, ww = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(n, c, hh, ww, device="cuda").bfloat16()
+    w = (torch.randn(64, 16, 4, 4, device="cuda") / 16).bfloat16().contiguous(memory_format=torch.channels_last)
+    b = torch.randn(64, device="cuda")
+    two = hip.stem_conv_pool(hip.stem_s2d(x, 16), w, b)
+    one = hip.stem_conv_pool_nchw(x, w, b)
+    torch.cuda.synchronize()
+    assert one.shape == two.shape and torch.equal(one, two)
+
+
 @pytest.mark.parametrize("case", [(25088, 256, (64, 64, 256)), (1000, 256, (64, 64, 256)), (77, 64, (16, 32)), (5, 512, (48,)), (129, 32, (16, 16, 16))])
 def test_key_query_value_projections_in_one_pass(hip, case):
     """gdkvm_proj_rows == x W^T + b per projection, fp32 accumulation over the bf16-rounded weights, one rounding."""
