@@ -41,7 +41,10 @@ struct StemArgs {
 // 4-byte column pairs (channel c, row parity p: x[c][2Y + p][2X .. 2X + 1]) -- so the space-to-depth pass (gdkvm_stem_s2d: 38 MB read,
 // 51 MB written and read back, 20 us of a 1 ms forward) disappears.  The pieces the LDS-DMA fetched are fetched into registers a tile
 // ahead (16 dwords per lane) and written to the other band buffer behind the tile's MFMAs; same bytes in LDS, hence the same results.
-template <bool NCHW>
+// POOL = false (round 4, the TRAINING stem's forward): the raw convolution -- no bias, no ReLU, no pooling -- written to memory as bf16
+// [N, Hs, Ws, 64], in non-overlapping tiles of 9 x 57 outputs (BatchNorm needs the full-resolution activation; the library's implicit
+// GEMM took 183 us for it behind a 46 us zero-fill of its output).
+template <bool NCHW, bool POOL = true>
 __global__ __launch_bounds__(512, 1) void stem_conv_pool_kernel(StemArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(512, 1) void stem_conv_pool_kernel(StemArgs a)
     constexpr int PP = (SP_PIECES + 7) / 8;
     auto fetch = [&](int tile, int buf) __attribute__((always_inline)) {
         const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
-        const int y0 = 2 * SP_TPY * ty - 3, x0 = 2 * SP_TPX * tx - 3;       // input row / column of band pixel (0, 0)
+        const int y0 = (POOL ? 2 * SP_TPY * ty - 1 : SP_CR * ty) - 2, x0 = (POOL ? 2 * SP_TPX * tx - 1 : (SP_CC - 7) * tx) - 2;       // input row / column of band pixel (0, 0)
 #pragma unroll
         for (int u = 0; u < PP; ++u) {
             const int j = w + 8 * u;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(512, 1) void stem_conv_pool_kernel(StemArgs a)
     unsigned stage[PP][4];
     auto fetch_nchw = [&](int tile) __attribute__((always_inline)) {
         const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
-        const int y0 = 2 * SP_TPY * ty - 3, x0 = 2 * SP_TPX * tx - 3;
+        const int y0 = (POOL ? 2 * SP_TPY * ty - 1 : SP_CR * ty) - 2, x0 = (POOL ? 2 * SP_TPX * tx - 1 : (SP_CC - 7) * tx) - 2;
         const int H = 2 * a.Hs, W = 2 * a.Ws;
 #pragma unroll
         for (int u = 0; u < PP; ++u) {
@@ -131,9 +134,9 @@ __global__ __launch_bounds__(512, 1) void stem_conv_pool_kernel(StemArgs a)
 #endif
         const unsigned char* band = band2 + cur * SP_BAND_BYTES;
         const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
-        const int cy0 = 2 * SP_TPY * ty - 1, cx0 = 2 * SP_TPX * tx - 1;                 // convolution row / column of tile position (0, 0)
+        const int cy0 = POOL ? 2 * SP_TPY * ty - 1 : SP_CR * ty, cx0 = POOL ? 2 * SP_TPX * tx - 1 : (SP_CC - 7) * tx;   // convolution row / column of tile position (0, 0)
         const int cx = cx0 + 16 * wm + li;                                                // this lane's convolution column
-        const bool col_ok = cx >= 0 && cx < a.Ws;
+        const bool col_ok = cx >= 0 && cx < a.Ws && (POOL || 16 * wm + li < SP_CC - 7);   // (conv only: 57 columns per tile, no overlap)
 
         // ---- convolution rows in three groups of three: acc[row in group][nt] ---------------------------------------------
 #pragma unroll
@@ -162,6 +165,20 @@ __global__ __launch_bounds__(512, 1) void stem_conv_pool_kernel(StemArgs a)
 #endif
                 }
             }
+            if constexpr (!POOL) {                          // the raw convolution, straight to memory
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int cy = cy0 + 3 * grp + r;
+                    if (col_ok && cy < a.Hs) {
+                        unsigned ow[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            ow[q] = (unsigned)f32_to_bf16(acc[r][q >> 1][2 * (q & 1)]) | ((unsigned)f32_to_bf16(acc[r][q >> 1][2 * (q & 1) + 1]) << 16);
+                        *reinterpret_cast<uint4*>(a.y + (((size_t)n * a.Hs + cy) * a.Ws + cx) * 64 + 32 * wn + 8 * g) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                    }
+                }
+                continue;
+            }
             // bias + ReLU (+ zero outside the image) -> bf16 -> LDS tile; lane (li, g): channels 32wn + 8g .. +7 of column 16wm + li
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -184,7 +201,7 @@ __global__ __launch_bounds__(512, 1) void stem_conv_pool_kernel(StemArgs a)
 
         // ---- 3x3 / stride 2 max-pool out of LDS: item = (pooled row q, pooled column px, 8-channel group) ------------------
 #ifndef STEM_ABL_NOPOOL
-        for (int it = tid; it < SP_TPY * SP_TPX * 8; it += 512) {
+        for (int it = tid; POOL && it < SP_TPY * SP_TPX * 8; it += 512) {
             const int cg = it & 7, pp = it >> 3, q = pp / SP_TPX, px = pp - q * SP_TPX;
             const int py_g = SP_TPY * ty + q, px_g = SP_TPX * tx + px;
             // post-ReLU bf16 values are non-negative, so their order is the order of their bit patterns as unsigned 16-bit
@@ -208,21 +225,35 @@ __global__ __launch_bounds__(512, 1) void stem_conv_pool_kernel(StemArgs a)
             }
         }
 #endif
-        __syncthreads();                                   // the tile may be overwritten
+        if constexpr (POOL) __syncthreads();               // the tile may be overwritten
     }
+}
+
+// The 4 x 4 x 16 kernel of the space-to-depth form from the 7 x 7 kernel of the stride-2 stem (model.FusedConvPool.enable_s2d's
+// arithmetic as one kernel, for weights that change every step): w4[k][a + 2][b + 2][4c + 2p + q] = w7[k][c][2a + p + 3][2b + q + 3]
+// where that tap exists, 0 elsewhere; w7 fp32 [64, C, 7, 7] with element strides (sk, sc, sr, ss), w4 bf16 [64][4][4][16].
+__global__ __launch_bounds__(256) void stem_pack_s2d_kernel(const float* w7, bf16_t* w4, int C, long long sk, long long sc, long long sr, long long ss)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;          // (k, a, b, ch)
+    if (i >= 64 * 256) return;
+    const int ch = i & 15, b = (i >> 4) & 3, a = (i >> 6) & 3, k = i >> 8;
+    const int c = ch >> 2, p = (ch >> 1) & 1, q = ch & 1, u = 2 * (a - 2) + p + 3, v = 2 * (b - 2) + q + 3;
+    float x = 0.f;
+    if (c < C && u >= 0 && u <= 6 && v >= 0 && v <= 6) x = w7[k * sk + c * sc + u * sr + v * ss];
+    w4[i] = f32_to_bf16(x);
 }
 
 }  // namespace
 
 static int stem_conv_pool_impl(const char* who, const void* xs, const void* xf, int Cf, const void* w, const float* bias, void* y,
-                               int N, int Hs, int Ws, int io_dtype, void* stream)
+                               int N, int Hs, int Ws, int io_dtype, void* stream, bool pool = true)
 {
     if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "%s: only bf16 is implemented", who);
     if (N < 0 || Hs <= 0 || Ws <= 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: N=%d Hs=%d Ws=%d", who, N, Hs, Ws);
     if (N == 0) return GDKVM_OK;
     const void* x = xf ? xf : xs;
-    if (!x || !w || !bias || !y) return gdkvm_fail(GDKVM_ERR_ARG, "%s: null pointer", who);
-    if (!gdkvm_aligned16(x) || !gdkvm_aligned16(w) || !gdkvm_aligned16(y) || !gdkvm_aligned16(bias))
+    if (!x || !w || (pool && !bias) || !y) return gdkvm_fail(GDKVM_ERR_ARG, "%s: null pointer", who);
+    if (!gdkvm_aligned16(x) || !gdkvm_aligned16(w) || !gdkvm_aligned16(y) || (bias && !gdkvm_aligned16(bias)))
         return gdkvm_fail(GDKVM_ERR_ARG, "%s: pointers must be 16-byte aligned", who);
     if (int rc = gdkvm_check_device()) return rc;
     StemArgs a;
@@ -230,6 +261,7 @@ static int stem_conv_pool_impl(const char* who, const void* xs, const void* xf, 
     a.xf = static_cast<const bf16_t*>(xf); a.Cf = Cf;
     a.N = N; a.Hs = Hs; a.Ws = Ws; a.Hp = (Hs - 1) / 2 + 1; a.Wp = (Ws - 1) / 2 + 1;
     a.tiles_x = (a.Wp + SP_TPX - 1) / SP_TPX; a.tiles_y = (a.Hp + SP_TPY - 1) / SP_TPY;
+    if (!pool) { a.tiles_x = (Ws + SP_CC - 8) / (SP_CC - 7); a.tiles_y = (Hs + SP_CR - 1) / SP_CR; }       // 9 x 57 convolution outputs per tile
     const long long ntiles = (long long)N * a.tiles_x * a.tiles_y;
     if (ntiles > 0x7fffffffLL) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: too many tiles", who);
     const size_t lds = 2 * (size_t)SP_BAND_BYTES + SP_CONV_BYTES;
@@ -241,6 +273,7 @@ static int stem_conv_pool_impl(const char* who, const void* xs, const void* xf, 
         if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_pool_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_pool_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_pool_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "%s: %s", who, hipGetErrorString(e));
             done_mask.fetch_or(bit, std::memory_order_relaxed);
         }
@@ -249,7 +282,8 @@ static int stem_conv_pool_impl(const char* who, const void* xs, const void* xf, 
 #define STEM_GRID 256                                      // persistent, one workgroup per CU
 #endif
     const int grid = (int)(ntiles < STEM_GRID ? ntiles : STEM_GRID);
-    if (xf) hipLaunchKernelGGL(stem_conv_pool_kernel<true>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+    if (!pool) hipLaunchKernelGGL((stem_conv_pool_kernel<true, false>), dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
+    else if (xf) hipLaunchKernelGGL(stem_conv_pool_kernel<true>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
     else hipLaunchKernelGGL(stem_conv_pool_kernel<false>, dim3(grid), dim3(512), lds, static_cast<hipStream_t>(stream), a);
     GDKVM_LAUNCH_CHECK("stem_conv_pool_kernel");
     return GDKVM_OK;
@@ -267,4 +301,23 @@ extern "C" int gdkvm_stem_conv_pool_nchw(const void* x, const void* w, const flo
     if (C <= 0 || C > 4 || H <= 0 || W <= 0 || (H & 1) || (W & 1))
         return gdkvm_fail(GDKVM_ERR_SHAPE, "stem_conv_pool_nchw: C=%d H=%d W=%d (at most 4 channels, H and W even)", C, H, W);
     return stem_conv_pool_impl("stem_conv_pool_nchw", nullptr, x, C, w, bias, y, N, H / 2, W / 2, io_dtype, stream);
+}
+
+// Training: the raw 7x7 / stride 2 / pad 3 convolution of NCHW frames x [N, C <= 4, H, W] (H, W even) -> y [N, H/2, W/2, 64] bf16 (NHWC),
+// no bias, with the kernel given in the space-to-depth form w4 [64, 4, 4, 16] bf16 (gdkvm_stem_pack_s2d).
+extern "C" int gdkvm_stem_conv_nchw(const void* x, const void* w4, void* y, int N, int C, int H, int W, int io_dtype, void* stream)
+{
+    if (C <= 0 || C > 4 || H <= 0 || W <= 0 || (H & 1) || (W & 1))
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "stem_conv_nchw: C=%d H=%d W=%d (at most 4 channels, H and W even)", C, H, W);
+    return stem_conv_pool_impl("stem_conv_nchw", nullptr, x, C, w4, nullptr, y, N, H / 2, W / 2, io_dtype, stream, false);
+}
+
+extern "C" int gdkvm_stem_pack_s2d(const float* w7, void* w4, int C, long long sk, long long sc, long long sr, long long ss, void* stream)
+{
+    if (C <= 0 || C > 4) return gdkvm_fail(GDKVM_ERR_SHAPE, "stem_pack_s2d: C=%d (at most 4 input channels)", C);
+    if (!w7 || !w4 || !gdkvm_aligned16(w4)) return gdkvm_fail(GDKVM_ERR_ARG, "stem_pack_s2d: null or unaligned pointer");
+    if (int rc = gdkvm_check_device()) return rc;
+    hipLaunchKernelGGL(stem_pack_s2d_kernel, dim3(64), dim3(256), 0, static_cast<hipStream_t>(stream), w7, static_cast<bf16_t*>(w4), C, sk, sc, sr, ss);
+    GDKVM_LAUNCH_CHECK("stem_pack_s2d_kernel");
+    return GDKVM_OK;
 }

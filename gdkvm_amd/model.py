@@ -148,7 +148,10 @@ class Encoder(nn.Module):
     def forward(self, x):
         s = self.stem
         if len(s) == 4 and isinstance(s[1], nn.BatchNorm2d):                  # training build: conv, fused BN + ReLU, pool
-            x = _bn_act(s[1], s[0](x), True)
+            if torch.is_grad_enabled() and isinstance(s[0], nn.Conv2d) and ops.stem_conv_served(x, s[0]):
+                x = _bn_act(s[1], ops.stem_conv(x, s[0].weight), True)     # the hand-written stem kernel, convolution only (csrc/stem_conv_pool.hip)
+            else:
+                x = _bn_act(s[1], s[0](x), True)
             p = s[3]
             if (x.is_cuda and isinstance(p, nn.MaxPool2d) and (p.kernel_size, p.stride, p.padding, p.dilation, p.ceil_mode) == (3, 2, 1, 1, False)
                     and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0 and x.dtype in (torch.bfloat16, torch.float32)):
@@ -523,8 +526,10 @@ class GDKVM(nn.Module):
         dt = self.key_proj.weight.dtype
         if torch.is_autocast_enabled():
             dt = torch.get_autocast_dtype(x.device.type) if x.is_cuda else x.dtype
-        if x.is_cuda and isinstance(self.encoder.stem[0], FusedConvPool) and getattr(self.encoder.stem[0], "w_s2d", None) is not None:
-            x = x.to(dt)                                                         # (the space-to-depth stem reads NCHW frames itself)
+        stem0 = self.encoder.stem[0]
+        if x.is_cuda and ((isinstance(stem0, FusedConvPool) and getattr(stem0, "w_s2d", None) is not None)
+                          or (torch.is_grad_enabled() and isinstance(stem0, nn.Conv2d) and dt == torch.bfloat16 and ops.stem_conv_served(x, stem0))):
+            x = x.to(dt)                                                         # (the stem kernels read NCHW frames themselves)
         else:
             x = x.to(dtype=dt, memory_format=torch.channels_last)                # cast + NHWC in one pass
         if self.training and x.is_cuda and torch.is_grad_enabled() and dt == torch.bfloat16:

@@ -66,6 +66,8 @@ SIGNATURES = {
     "gdkvm_proj_rows": (_i, [_vp] * 6 + [ctypes.c_longlong] + [_i] * 5 + [_vp]),
     "gdkvm_stem_conv_pool": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
     "gdkvm_stem_conv_pool_nchw": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
+    "gdkvm_stem_conv_nchw": (_i, [_vp] * 3 + [_i] * 5 + [_vp]),
+    "gdkvm_stem_pack_s2d": (_i, [_vp, _vp, _i] + [ctypes.c_longlong] * 4 + [_vp]),
     "gdkvm_gate_logits": (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     "gdkvm_proj_gates": (_i, [_vp] * 13 + [_i] * 7 + [_vp]),
     "gdkvm_conv_bias_act": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
@@ -1020,7 +1022,7 @@ def conv3x3_train_served(x: torch.Tensor, weight: torch.Tensor, stride, padding,
     k, c = weight.shape[:2]
     return (x.is_cuda and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and tuple(padding) == (1, 1)
             and tuple(dilation) == (1, 1) and groups == 1 and c % 64 == 0 and k % 64 == 0 and x.shape[-1] <= 64
-            and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16)))
+            and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)))
 
 
 def conv3x3(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
@@ -1201,6 +1203,49 @@ def stem_conv_pool_nchw(x: torch.Tensor, w_s2d: torch.Tensor, bias: torch.Tensor
         rc = lib.gdkvm_stem_conv_pool_nchw(x.data_ptr(), w_s2d.data_ptr(), bias.data_ptr(), y.data_ptr(), n, c, hh, ww, BF16, _stream(x.device))
     _check(rc, "gdkvm_stem_conv_pool_nchw")
     return y
+
+
+class _StemConvFunction(torch.autograd.Function):
+    """The training stem's convolution (7x7 / stride 2 / pad 3, no bias, <= 4 input channels -> 64) on the hand-written stem kernel in its
+    convolution-only form (gdkvm_stem_pack_s2d + gdkvm_stem_conv_nchw): bf16 NCHW frames in, channels_last bf16 out.  The input is the
+    image (no data gradient); the weight gradient stays the framework's convolution_backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        lib = load()
+        xb = x.detach().to(torch.bfloat16).contiguous()
+        n, c, hh, ww = xb.shape
+        w4 = torch.empty(64 * 256, dtype=torch.bfloat16, device=xb.device)
+        y = torch.empty((n, 64, hh // 2, ww // 2), dtype=torch.bfloat16, device=xb.device, memory_format=torch.channels_last)
+        wd = weight.detach()
+        with torch.cuda.device(xb.device):
+            _check(lib.gdkvm_stem_pack_s2d(wd.data_ptr(), w4.data_ptr(), c, *wd.stride(), _stream(xb.device)), "gdkvm_stem_pack_s2d")
+            _check(lib.gdkvm_stem_conv_nchw(xb.data_ptr(), w4.data_ptr(), y.data_ptr(), n, c, hh, ww, BF16, _stream(xb.device)), "gdkvm_stem_conv_nchw")
+        ctx.save_for_backward(xb, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, weight = ctx.saved_tensors
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dyb = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            dw = torch.ops.aten.convolution_backward(dyb, xb, weight.detach().to(torch.bfloat16), None, (2, 2), (3, 3), (1, 1), False, (0, 0), 1,
+                                                     (False, True, False))[1].to(weight.dtype)
+        return None, dw
+
+
+def stem_conv_served(x: torch.Tensor, conv) -> bool:
+    w = conv.weight
+    return (x.is_cuda and x.dim() == 4 and x.shape[1] <= 4 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and conv.bias is None
+            and tuple(w.shape) == (64, x.shape[1], 7, 7) and w.dtype == torch.float32 and conv.stride == (2, 2) and conv.padding == (3, 3)
+            and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"
+            and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)))
+
+
+def stem_conv(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """conv2d(x, weight, stride=2, padding=3) for the training stem (bf16 out, channels_last), differentiable in the weight."""
+    return _StemConvFunction.apply(x, weight)
 
 
 def upsample_cat_bwd(dout: torch.Tensor, lo_shape, skip_shape) -> Tuple[torch.Tensor, torch.Tensor]:

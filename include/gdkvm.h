@@ -399,6 +399,11 @@ int gdkvm_stem_conv_pool(const void* xs, const void* w, const float* bias, void*
  * gdkvm_stem_s2d followed by gdkvm_stem_conv_pool. */
 int gdkvm_stem_conv_pool_nchw(const void* x, const void* w, const float* bias, void* y, int N, int C, int H, int W,
                               int io_dtype, void* stream);
+/* Training: the stem's raw convolution (7x7 / stride 2 / pad 3, no bias) on the same kernel, y [N, H/2, W/2, 64] bf16 written to memory
+ * (BatchNorm follows), from NCHW frames and the kernel in the space-to-depth form w4 [64, 4, 4, 16] bf16 -- which gdkvm_stem_pack_s2d
+ * builds from the fp32 [64, C, 7, 7] weight (element strides sk, sc, sr, ss) in one small launch per step. */
+int gdkvm_stem_conv_nchw(const void* x, const void* w4, void* y, int N, int C, int H, int W, int io_dtype, void* stream);
+int gdkvm_stem_pack_s2d(const float* w7, void* w4, int C, long long sk, long long sc, long long sr, long long ss, void* stream);
 
 /* Row n1, the training stem: 3x3 / stride 2 / pad 1 max-pool of an NHWC tensor x [N, H, W, C] -> y [N, Ho, Wo, C]
  * (Ho = (H-1)/2+1) recording the winning tap of every output element in idx (one byte each, [N, Ho, Wo, C]: 3*dy + dx in

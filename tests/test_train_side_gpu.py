@@ -389,3 +389,24 @@ def test_training_weight_packs_in_one_launch(hip):
     with torch.no_grad():
         ws[0].mul_(0.5)
     assert ops.conv3x3_train_packs(ws) == 2                        # the rescaled one and the one dropped above
+
+
+@pytest.mark.parametrize("case", [(3, 3, 112, 112), (2, 1, 64, 48), (1, 4, 130, 118), (9, 3, 20, 256)])
+def test_training_stem_convolution_on_the_stem_kernel(hip, case):
+    """ops.stem_conv (gdkvm_stem_pack_s2d + gdkvm_stem_conv_nchw: the inference stem kernel in its convolution-only form) == conv2d(x, w,
+    stride 2, padding 3) in fp64 on the bf16-rounded operands, rounded once to bf16; the weight gradient (the framework's) matches fp64
+    autograd; ragged sizes (tiles of 9 x 57 outputs), 1 .. 4 input channels."""
+    from gdkvm_amd import ops
+    n, c, hh, ww = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(n, c, hh, ww, device="cuda").bfloat16()
+    w = torch.nn.Parameter(torch.randn(64, c, 7, 7, device="cuda") / (49 * c) ** 0.5)
+    y = ops.stem_conv(x, w)
+    w64 = w.detach().bfloat16().double().requires_grad_()
+    ref = F.conv2d(x.double(), w64, None, 2, 3)
+    assert y.shape == ref.shape and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    assert (y.double() - ref).abs().max() <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
+    gy = torch.randn_like(y)
+    (dw,) = torch.autograd.grad(y, w, gy)
+    (dref,) = torch.autograd.grad(ref, w64, gy.double())
+    assert dw.dtype == torch.float32 and (dw.double() - dref).abs().max() <= 2e-2 * max(1.0, dref.abs().max().item())
