@@ -18,6 +18,7 @@
 //     ct_channel (16-byte stores / residual loads);
 //   * the same kernel computes the training-mode data gradient (weights packed flipped and transposed).
 // Arithmetic: fp32 accumulation over the same 9 C products as a library convolution, one rounding after the epilogue.
+#include <stdlib.h>
 #include <atomic>
 #include <type_traits>
 
@@ -33,9 +34,10 @@ constexpr int CT_PIX = CT_PIX_BYTES;              // bytes between LDS pixels: 8
                                          // conflict-free for ds_read_b128: its 16-lane groups mix two lane quarters)
 constexpr int CT_SLOTS = CT_PIX / 16;    // 16-byte LDS slots per pixel
 constexpr int CT_MAXMT = 13;             // 16-pixel tiles per workgroup tile (208 pixels)
-// wave grids <NWN, NTW>: 1 = <4, 1>, 2 = <4, 2>, 3 = <2, 2>; the defaults are the measured picks (tools/conv_probe.py; K = 64: <2, 2> since the
+// wave grids <NWN, NTW>: 1 = <4, 1>, 2 = <4, 2>, 3 = <2, 2> (eight waves, tiles of up to 208 pixels); 4 = <4, 2> on FOUR waves with tiles of up to 112
+// pixels, two workgroups per CU (round 4: 1 - 4 % faster than 2 on every K % 128 == 0 layer, profiles/r04_w_conv_half_tiles.txt); the defaults are the measured picks (tools/conv_probe.py; K = 64: <2, 2> since the
 // weights are packed -- 121 against 129 us on the 192 -> 64 layer: half the LDS operand reads per MFMA, and the fourfold weight fetch is cheap now)
-constexpr int CT_VARIANT_128 = 2, CT_VARIANT_64 = 3;
+constexpr int CT_VARIANT_128 = 4, CT_VARIANT_64 = 3;
 
 __device__ const uint4 g_ct_zero16 = {0, 0, 0, 0};
 
@@ -87,10 +89,13 @@ __host__ __device__ __forceinline__ int ct_channel(int kt, int j, int perm)
 // fragments from LDS and NTW weight fragments from L2 for MTW NTW MFMAs; per workgroup that is 8 MTW KB of LDS reads against
 // 32 MTW NTW cycles of MFMA per SIMD.  <4, 2> (MTW 7): 56 KB / 448 cycles; <2, 2> (MTW 4, the 64-channel layers): 32 KB / 256
 // cycles where <4, 1> had 56 KB / 224 -- the LDS read rate (128 B per cycle) is the co-bound, so the grid follows the channels.
-template <int NWN, int NTW, bool PK>
-__global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
+// NWV = 4, MAXMT = 7 (round 4 experiment, variant 4): FOUR waves per workgroup, each with the SAME work as a wave of <4, 2> (seven pixel
+// tiles x two channel tiles), on a tile of half the pixels (112) -- so that TWO workgroups share a CU and drift apart: one's barrier,
+// first-band wait and epilogue overlap the other's MFMAs (what conv3x3_c64 gains from its two workgroups per CU, profiles/r04_v_...).
+template <int NWN, int NTW, bool PK, int NWV = 8, int MAXMT = CT_MAXMT>
+__global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 2 : 1)) void conv3x3_tile_kernel(ConvTileArgs a)
 {
-    constexpr int MW = 8 / NWN, MTW = (CT_MAXMT + MW - 1) / MW;        // pixel-tile groups, pixel tiles per wave
+    constexpr int MW = NWV / NWN, MTW = (MAXMT + MW - 1) / MW;         // pixel-tile groups, pixel tiles per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char ct_band[];    // [2][npieces * 1024] | 1 KiB dump slot
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wn = w % NWN, wm = w / NWN;
@@ -102,12 +107,12 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
     const int tpix = a.fpt * a.th * W;                     // output pixels of a full tile
     const int co0 = blockIdx.y * (16 * NTW * NWN) + 16 * NTW * wn;     // this wave's output channels co0 .. co0 + 16 NTW - 1
 
-    // DMA piece geometry (tile-invariant): piece j = w + 8u, slot d = 64 j + lane = CT_SLOTS pix + c; c >= 8 is padding
-    constexpr int PP = 7;                                  // pieces per wave: npieces <= 56
+    // DMA piece geometry (tile-invariant): piece j = w + NWV u, slot d = 64 j + lane = CT_SLOTS pix + c; c >= 8 is padding
+    constexpr int PP = NWV == 8 ? 7 : 8;                   // pieces per wave: npieces <= 56 (eight waves) / 32 (four)
     int g_pix[PP], g_yx[PP], g_fr[PP];                     // source pixel offset from the band's (0, 0); band row or -1; frame | 8c << 8
 #pragma unroll
     for (int u = 0; u < PP; ++u) {
-        const int j = w + 8 * u, d = 64 * j + lane, pix = d / CT_SLOTS, c = d - CT_SLOTS * pix;
+        const int j = w + NWV * u, d = 64 * j + lane, pix = d / CT_SLOTS, c = d - CT_SLOTS * pix;
         const int f = ct_div(pix, a.inv_band), r = pix - f * (a.bh * BW), by = ct_div(r, a.inv_bw), bx = r - by * BW;
         g_pix[u] = (f * H + by) * W + bx;
         const bool live = j < a.npieces && c < 8 && pix < a.band_px && bx >= 1 && bx <= W;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(512) void conv3x3_tile_kernel(ConvTileArgs a)
 #endif
 #pragma unroll
         for (int u = 0; u < PP; ++u) {
-            const int j = w + 8 * u;
+            const int j = w + NWV * u;
             const int yy = y0 + g_yx[u];
             const bool ok = g_yx[u] >= 0 && (unsigned)yy < (unsigned)H && (g_fr[u] & 255) < nfr;
             const bf16_t* src = ok ? origin + g_pix[u] * cs + (g_fr[u] >> 8) : reinterpret_cast<const bf16_t*>(&g_ct_zero16);
@@ -447,17 +452,17 @@ extern "C" int gdkvm_conv3x3_pack_weights(const void* w, void* packed, int K, in
 }
 
 namespace {
-template <int NWN, int NTW>
+template <int NWN, int NTW, int NWV = 8, int MAXMT = CT_MAXMT>
 void launch_tile(bool packed, dim3 grid, size_t lds, hipStream_t st, const ConvTileArgs& a)
 {
-    if (packed) hipLaunchKernelGGL((conv3x3_tile_kernel<NWN, NTW, true>), grid, dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((conv3x3_tile_kernel<NWN, NTW, false>), grid, dim3(512), lds, st, a);
+    if (packed) hipLaunchKernelGGL((conv3x3_tile_kernel<NWN, NTW, true, NWV, MAXMT>), grid, dim3(64 * NWV), lds, st, a);
+    else hipLaunchKernelGGL((conv3x3_tile_kernel<NWN, NTW, false, NWV, MAXMT>), grid, dim3(64 * NWV), lds, st, a);
 }
-template <int NWN, int NTW>
+template <int NWN, int NTW, int NWV = 8, int MAXMT = CT_MAXMT>
 bool setattr_tile()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_tile_kernel<NWN, NTW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 113 * 1024) == hipSuccess
-        && hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_tile_kernel<NWN, NTW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 113 * 1024) == hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_tile_kernel<NWN, NTW, true, NWV, MAXMT>), hipFuncAttributeMaxDynamicSharedMemorySize, 113 * 1024) == hipSuccess
+        && hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_tile_kernel<NWN, NTW, false, NWV, MAXMT>), hipFuncAttributeMaxDynamicSharedMemorySize, 113 * 1024) == hipSuccess;
 }
 }  // namespace
 
@@ -468,23 +473,32 @@ extern "C" void gdkvm_ct_diag_buffer(unsigned long long* p) { (void)hipMemcpyToS
 int gdkvm_conv3x3_tile_launch(const void* x, const void* x2, int C1, const void* w, const float* bias, const void* residual, void* y,
                               int N, int C, int H, int W, int K, int relu, int variant, int packed, hipStream_t st)
 {
-    if (C % CT_CK || K % 16 || W > 64 || W < 1 || H < 1 || N < 1 || variant < 0 || variant > 3) return 1;
+    static const bool half_default = [] { const char* e = getenv("GDKVM_CONV_TILE128"); return !(e && e[0] == '2'); }();     // ("2": A/B switch, the eight-wave form)
+    if (variant == 0 && K % 128 == 0 && CT_VARIANT_128 == 4 && half_default) {
+        // by shape: the two-workgroups-per-CU form where the tile's band fits its 32 DMA pieces, else the eight-wave form
+        if (gdkvm_conv3x3_tile_launch(x, x2, C1, w, bias, residual, y, N, C, H, W, K, relu, 4, packed, st) == 0) return 0;
+        variant = 2;
+    }
+    if (C % CT_CK || K % 16 || W > 64 || W < 1 || H < 1 || N < 1 || variant < 0 || variant > 4) return 1;
+    if (variant == 4 && K % 128) return 1;
+    const bool half = variant == 4;                       // four waves, 112-pixel tiles, two workgroups per CU
     if (x2 && (C1 <= 0 || C1 >= C || C1 % CT_CK)) return 1;
     ConvTileArgs a;
     a.x2 = static_cast<const bf16_t*>(x2); a.C1 = x2 ? C1 : C;
     a.x = static_cast<const bf16_t*>(x); a.w = static_cast<const bf16_t*>(w); a.bias = bias;
     a.res = static_cast<const bf16_t*>(residual); a.y = static_cast<bf16_t*>(y);
     a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.relu = relu;
-    const int maxpix = 16 * CT_MAXMT;
+    const int maxpix = half ? 16 * 7 : 16 * CT_MAXMT;
+    const int maxpieces = half ? 32 : 56;
     if (H * W <= maxpix) { a.th = H; a.fpt = maxpix / (H * W); a.tiles_y = 1; if (a.fpt > N) a.fpt = N; }
     else { a.fpt = 1; a.th = maxpix / W; if (a.th < 1) return 1; a.tiles_y = (H + a.th - 1) / a.th; }
     a.bw = W + 2; a.bh = a.th + 2;
     // the halo band of a tile must fit the 56 DMA pieces (8 waves x 7) of a chunk: tiny maps take fewer frames, wide ones fewer rows
     auto pieces = [&]() { a.band_px = a.fpt * a.bh * a.bw; return (a.band_px * CT_SLOTS + 63) / 64; };
-    while (pieces() > 56 && a.fpt > 1) --a.fpt;
-    while (pieces() > 56 && a.th > 1) { --a.th; a.bh = a.th + 2; a.tiles_y = (H + a.th - 1) / a.th; }
+    while (pieces() > maxpieces && a.fpt > 1) --a.fpt;
+    while (pieces() > maxpieces && a.th > 1) { --a.th; a.bh = a.th + 2; a.tiles_y = (H + a.th - 1) / a.th; }
     a.npieces = pieces();
-    if (a.npieces > 56) return 1;
+    if (a.npieces > maxpieces) return 1;
     a.inv_band = 1.0f / (float)(a.bh * a.bw); a.inv_bw = 1.0f / (float)a.bw;
     a.inv_tw = 1.0f / (float)(a.th * W); a.inv_w = 1.0f / (float)W;
     a.perm = K % 32 == 0;
@@ -493,23 +507,24 @@ int gdkvm_conv3x3_tile_launch(const void* x, const void* x2, int C1, const void*
     if (ntiles <= 0 || ntiles > 0x7fffffffLL) return 1;
     a.ntiles = (int)ntiles;
     // wave grid by output channels (variant 0; 1..4 pick one for tuning): 128 per workgroup where K allows, else 64
-    if (variant == 0) variant = K % 128 == 0 ? CT_VARIANT_128 : CT_VARIANT_64;
-    const int kwg = variant == 2 ? 128 : 64;               // output channels per workgroup
+    if (variant == 0) variant = K % 128 == 0 ? 2 : CT_VARIANT_64;
+    const int kwg = (variant == 2 || variant == 4) ? 128 : 64;   // output channels per workgroup
     const int gy = (K + kwg - 1) / kwg;
     const size_t lds = (size_t)2 * a.npieces * 1024 + 1024;
-    int per = 256 / gy; if (per < 1) per = 1;
+    int per = (half ? 512 : 256) / gy; if (per < 1) per = 1;
     const int gx = (int)(ntiles < per ? ntiles : per);     // persistent: one workgroup per CU
     static std::atomic<unsigned long long> done_mask{0};   // per device; a lost race only repeats the idempotent call
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 1;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
-        if (!setattr_tile<4, 1>() || !setattr_tile<4, 2>() || !setattr_tile<2, 2>()) return 1;
+        if (!setattr_tile<4, 1>() || !setattr_tile<4, 2>() || !setattr_tile<2, 2>() || !setattr_tile<4, 2, 4, 7>()) return 1;
         done_mask.fetch_or(bit, std::memory_order_relaxed);
     }
     switch (variant) {
         case 1: launch_tile<4, 1>(packed, dim3(gx, gy), lds, st, a); break;
         case 2: launch_tile<4, 2>(packed, dim3(gx, gy), lds, st, a); break;
+        case 4: launch_tile<4, 2, 4, 7>(packed, dim3(gx, gy), lds, st, a); break;
         default: launch_tile<2, 2>(packed, dim3(gx, gy), lds, st, a); break;
     }
     return 0;

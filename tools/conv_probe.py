@@ -49,7 +49,7 @@ def main():
                 z = torch.nn.functional.conv2d(x, w, None, st, pad)
                 return ops.bias_act_(z, b, r, True)
             line = f"{name:24s} {'+res' if res else '    '} miopen+epilogue {ev(mi):6.1f} us (conv {ev(lambda: torch.nn.functional.conv2d(x, w, None, st, pad)):6.1f}) | hand-written:"
-            for t in (4, 5, 6, 7, 8):
+            for t in ():
                 try:
                     y = ops.conv_bias_act(x, w, b, r, st, pad, True, t)
                     err = (y.float() - ref).abs().max().item() / ref.abs().max().item()
@@ -58,7 +58,9 @@ def main():
                     line += f" k{t}   n/a "
             if R == 3 and st == 1 and C % 64 == 0:
                 pk = ops.conv3x3_pack_weights(w)
-                for t in ((4, 5) if C == 64 and K == 64 else (5, 6, 7, 8)):
+                for t in ((4, 5) if C == 64 and K == 64 else (5, 7, 8, 10)):
+                    if t in (7, 10) and K % 128:
+                        continue
                     y = ops.conv_bias_act(x, w, b, r, st, pad, True, t, pk)
                     err = (y.float() - ref).abs().max().item() / ref.abs().max().item()
                     line += f" | k{t} packed {ev(lambda: ops.conv_bias_act(x, w, b, r, st, pad, True, t, pk)):6.1f}" + ("" if err < 1e-2 else f"(ERR {err:.1e})")
