@@ -35,7 +35,8 @@ constexpr int CT_PIX = CT_PIX_BYTES;              // bytes between LDS pixels: 8
 constexpr int CT_SLOTS = CT_PIX / 16;    // 16-byte LDS slots per pixel
 constexpr int CT_MAXMT = 13;             // 16-pixel tiles per workgroup tile (208 pixels)
 // wave grids <NWN, NTW>: 1 = <4, 1>, 2 = <4, 2>, 3 = <2, 2> (eight waves, tiles of up to 208 pixels); 4 = <4, 2> on FOUR waves with tiles of up to 112
-// pixels, two workgroups per CU (round 4: 1 - 4 % faster than 2 on every K % 128 == 0 layer, profiles/r04_w_conv_half_tiles.txt); the defaults are the measured picks (tools/conv_probe.py; K = 64: <2, 2> since the
+// pixels, two workgroups per CU (round 4: 1 - 4 % faster than 2 on every K % 128 == 0 layer, profiles/r04_w_conv_half_tiles.txt), 5 = <2, 2> likewise
+// (64 channels per workgroup); the defaults are the measured picks (tools/conv_probe.py; K = 64: <2, 2> since the
 // weights are packed -- 121 against 129 us on the 192 -> 64 layer: half the LDS operand reads per MFMA, and the fourfold weight fetch is cheap now)
 constexpr int CT_VARIANT_128 = 4, CT_VARIANT_64 = 3;
 
@@ -479,9 +480,14 @@ int gdkvm_conv3x3_tile_launch(const void* x, const void* x2, int C1, const void*
         if (gdkvm_conv3x3_tile_launch(x, x2, C1, w, bias, residual, y, N, C, H, W, K, relu, 4, packed, st) == 0) return 0;
         variant = 2;
     }
-    if (C % CT_CK || K % 16 || W > 64 || W < 1 || H < 1 || N < 1 || variant < 0 || variant > 4) return 1;
+    static const bool half64 = [] { const char* e = getenv("GDKVM_CONV_TILE64"); return !(e && e[0] == '3'); }();   // ("3": A/B switch, the eight-wave form)
+    if (variant == 0 && K % 128 != 0 && half64) {
+        if (gdkvm_conv3x3_tile_launch(x, x2, C1, w, bias, residual, y, N, C, H, W, K, relu, 5, packed, st) == 0) return 0;
+        variant = 3;
+    }
+    if (C % CT_CK || K % 16 || W > 64 || W < 1 || H < 1 || N < 1 || variant < 0 || variant > 5) return 1;
     if (variant == 4 && K % 128) return 1;
-    const bool half = variant == 4;                       // four waves, 112-pixel tiles, two workgroups per CU
+    const bool half = variant == 4 || variant == 5;       // four waves, 112-pixel tiles, two workgroups per CU
     if (x2 && (C1 <= 0 || C1 >= C || C1 % CT_CK)) return 1;
     ConvTileArgs a;
     a.x2 = static_cast<const bf16_t*>(x2); a.C1 = x2 ? C1 : C;
@@ -518,13 +524,14 @@ int gdkvm_conv3x3_tile_launch(const void* x, const void* x2, int C1, const void*
     if (hipGetDevice(&dev) != hipSuccess) return 1;
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
-        if (!setattr_tile<4, 1>() || !setattr_tile<4, 2>() || !setattr_tile<2, 2>() || !setattr_tile<4, 2, 4, 7>()) return 1;
+        if (!setattr_tile<4, 1>() || !setattr_tile<4, 2>() || !setattr_tile<2, 2>() || !setattr_tile<4, 2, 4, 7>() || !setattr_tile<2, 2, 4, 7>()) return 1;
         done_mask.fetch_or(bit, std::memory_order_relaxed);
     }
     switch (variant) {
         case 1: launch_tile<4, 1>(packed, dim3(gx, gy), lds, st, a); break;
         case 2: launch_tile<4, 2>(packed, dim3(gx, gy), lds, st, a); break;
         case 4: launch_tile<4, 2, 4, 7>(packed, dim3(gx, gy), lds, st, a); break;
+        case 5: launch_tile<2, 2, 4, 7>(packed, dim3(gx, gy), lds, st, a); break;      // 64 channels per workgroup: 2 channel groups x 2 pixel-tile groups
         default: launch_tile<2, 2>(packed, dim3(gx, gy), lds, st, a); break;
     }
     return 0;

@@ -25,7 +25,7 @@ extern "C" int gdkvm_conv_bias_act(const void* x, const void* w, const float* bi
                           N, C, H, W, K, R, S, stride, pad);
     const bool packed = kernel & GDKVM_CONV_PACKED_WEIGHTS;
     kernel &= ~GDKVM_CONV_PACKED_WEIGHTS;
-    if (kernel != 0 && (kernel < 4 || kernel > 10)) return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: kernel=%d (0 = by shape, 4, 5, 6..8, 9, 10)", kernel);
+    if (kernel != 0 && (kernel < 4 || kernel > 11)) return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: kernel=%d (0 = by shape, 4, 5, 6..8, 9, 10, 11)", kernel);
     if (kernel == 9) {
         // the general implicit-GEMM kernel: any R x S / stride / pad, weights as gdkvm_conv_igemm_pack_weights wrote them
         if (!packed) return gdkvm_fail(GDKVM_ERR_ARG, "conv_bias_act: kernel 9 reads the gdkvm_conv_igemm_pack_weights copy of the weights (flag %d)", GDKVM_CONV_PACKED_WEIGHTS);
@@ -60,7 +60,7 @@ extern "C" int gdkvm_conv_bias_act(const void* x, const void* w, const float* bi
         GDKVM_LAUNCH_CHECK("conv3x3_c64_kernel");
         return GDKVM_OK;
     }
-    if (gdkvm_conv3x3_tile_launch(x, nullptr, 0, w, bias, residual, y, N, C, H, W, K, relu, kernel == 10 ? 4 : (kernel >= 6 ? kernel - 5 : 0), packed ? 1 : 0, st))
+    if (gdkvm_conv3x3_tile_launch(x, nullptr, 0, w, bias, residual, y, N, C, H, W, K, relu, kernel >= 10 ? kernel - 6 : (kernel >= 6 ? kernel - 5 : 0), packed ? 1 : 0, st))
         return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_bias_act: C=%d K=%d %dx%d is not served by the hand-written kernels (C a multiple of 64, K of "
                                            "16, rows of at most 64 pixels): use the framework convolution + gdkvm_bias_act", C, K, H, W);
     GDKVM_LAUNCH_CHECK("conv3x3_tile_kernel");
@@ -76,7 +76,7 @@ extern "C" int gdkvm_conv_cat_bias_act(const void* x1, const void* x2, const voi
     if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "conv_cat_bias_act: only bf16 is implemented");
     const bool packed = kernel & GDKVM_CONV_PACKED_WEIGHTS;
     kernel &= ~GDKVM_CONV_PACKED_WEIGHTS;
-    if (kernel != 0 && (kernel < 5 || kernel > 10 || kernel == 9)) return gdkvm_fail(GDKVM_ERR_ARG, "conv_cat_bias_act: kernel=%d (0, 5..8, 10)", kernel);
+    if (kernel != 0 && (kernel < 5 || kernel > 11 || kernel == 9)) return gdkvm_fail(GDKVM_ERR_ARG, "conv_cat_bias_act: kernel=%d (0, 5..8, 10, 11)", kernel);
     if (N < 0 || C1 <= 0 || C2 <= 0 || C1 % 64 || C2 % 64 || H <= 0 || W <= 0 || K <= 0 || K % 16)
         return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_cat_bias_act: N=%d C1=%d C2=%d H=%d W=%d K=%d (C1, C2 multiples of 64, K of 16)", N, C1, C2, H, W, K);
     if (N == 0) return GDKVM_OK;
@@ -86,7 +86,7 @@ extern "C" int gdkvm_conv_cat_bias_act(const void* x1, const void* x2, const voi
     if ((size_t)N * H * W * (C1 + C2) >= (1ull << 31) || (size_t)N * H * W * K >= (1ull << 31))
         return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_cat_bias_act: tensor too large for 32-bit offsets");
     if (int rc = gdkvm_check_device()) return rc;
-    if (gdkvm_conv3x3_tile_launch(x1, x2, C1, w, bias, residual, y, N, C1 + C2, H, W, K, relu, kernel == 10 ? 4 : (kernel >= 6 ? kernel - 5 : 0), packed ? 1 : 0,
+    if (gdkvm_conv3x3_tile_launch(x1, x2, C1, w, bias, residual, y, N, C1 + C2, H, W, K, relu, kernel >= 10 ? kernel - 6 : (kernel >= 6 ? kernel - 5 : 0), packed ? 1 : 0,
                                   static_cast<hipStream_t>(stream)))
         return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_cat_bias_act: %dx%d is not served (rows of at most 64 pixels)", H, W);
     GDKVM_LAUNCH_CHECK("conv3x3_tile_kernel");

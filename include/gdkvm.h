@@ -331,8 +331,9 @@ int gdkvm_proj_gates(const void* x, const void* wpack, const float* bias, void* 
  * y / residual [N, H, W, K], bias fp32 [K]; bf16 only.  The fp32 accumulator is rounded ONCE (after the epilogue).  Both kernels
  * are hand-written: kernel 4 = 64 -> 64 channels (conv3x3_c64.hip: LDS halo band, weights resident in registers), kernel 5 = C a
  * multiple of 64, K of 16, rows of <= 64 pixels (conv3x3_tile.hip: 64-channel LDS chunks, weights streamed); kernel 0 picks by
- * shape; 6, 7, 8 pin kernel 5's wave grid (4 channel groups x 1 tile, 4 x 2, 2 x 2: tuning; 5 picks by K), 10 = the 4 x 2 grid on
- * four waves with half-size pixel tiles, two workgroups per CU (K a multiple of 128: what 0 / 5 pick there; same sums, same bits).
+ * shape; 6, 7, 8 pin kernel 5's wave grid (4 channel groups x 1 tile, 4 x 2, 2 x 2: tuning; 5 picks by K), 10 / 11 = the 4 x 2 / 2 x 2
+ * grids on four waves with half-size pixel tiles, two workgroups per CU (what 0 / 5 pick: 10 for K a multiple of 128, else 11; same
+ * sums, same bits).
  * kernel 9 | GDKVM_CONV_PACKED_WEIGHTS = the general implicit-GEMM kernel (conv_igemm.hip): any R x S, stride and padding, rows of
  * any width -- the strided 3x3 layers, the 1x1 downsamples, 3x3 / 1 / 1 on maps wider than 64 pixels; C a multiple of 32, K of 128,
  * w the gdkvm_conv_igemm_pack_weights copy of the [K, R, S, C] weights.  Shapes none of the three serves (odd channel counts)
@@ -378,7 +379,7 @@ int gdkvm_conv_down_bias_act(const void* x, const void* w, const float* bias, vo
 /* The same 3x3 / 1 / 1 convolution over the channel concatenation [x1 (C1 channels) ; x2 (C2)] of two NHWC tensors, which is
  * never materialised -- the decoder's  conv(cat(upsample(feature), skip))  without the concatenated copy.  C1, C2 multiples of
  * 64, K of 16, rows of <= 64 pixels; w [K, 3, 3, C1 + C2] or its packed copy (kernel | GDKVM_CONV_PACKED_WEIGHTS); kernel 0 or
- * 5..8, 10.  Bit-identical to gdkvm_conv_bias_act on the concatenated tensor. */
+ * 5..8, 10, 11.  Bit-identical to gdkvm_conv_bias_act on the concatenated tensor. */
 int gdkvm_conv_cat_bias_act(const void* x1, const void* x2, const void* w, const float* bias, const void* residual, void* y,
                             int N, int C1, int C2, int H, int W, int K, int relu, int kernel, int io_dtype, void* stream);
 

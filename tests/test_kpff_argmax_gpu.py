@@ -292,7 +292,7 @@ def test_conv_with_fused_epilogue(hip, kernel, case):
         # the wave-grid variants (6..8) and the fragment-ordered weights compute the same sums in the same order: bit-identical
         want = hip.conv_bias_act(x, wt, b, r, stride, 1, True, 5)
         pk = hip.conv3x3_pack_weights(wt)
-        for variant in (5, 6, 7, 8) + ((10,) if k % 128 == 0 else ()):      # (10: four waves on half-size tiles, two workgroups per CU)
+        for variant in (5, 6, 7, 8, 11) + ((10,) if k % 128 == 0 else ()):  # (10, 11: four waves on half-size tiles, two workgroups per CU)
             assert torch.equal(hip.conv_bias_act(x, wt, b, r, stride, 1, True, variant), want)
             assert torch.equal(hip.conv_bias_act(x, wt, b, r, stride, 1, True, variant, pk), want)
         if c64:
