@@ -1179,7 +1179,11 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
         const size_t lds1 = (size_t)KPFF_TM * (Cin + KPFF_PAD16) * sizeof(bf16_t);
         if (lds1 > 160 * 1024) return gdkvm_fail(GDKVM_ERR_SHAPE, "kpff_fwd: Cp+Ck+Cv=%d exceeds the LDS tile", Cin);
         const int total_tiles = BT * tiles;
+#ifdef KPFF_FORCE_NT1                                           // ablation (tools/abl_kpff.py): one 64-token tile per four-wave workgroup, two workgroups per CU
+        const bool pair = false;
+#else
         const bool pair = 2 * lds1 <= 160 * 1024 && total_tiles >= 2;     // two 64-token tiles per 8-wave workgroup
+#endif
         bf16_t* wab = static_cast<bf16_t*>(workspace);
         const size_t na = (size_t)2 * Cp * Cin, nl = (size_t)Cp * Ck;
         if (!g_kpff_skip_pack) {
