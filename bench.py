@@ -176,7 +176,10 @@ def run_train(args, world, rank, dev, steps, warmup):
     torch.manual_seed(3)
     model = GDKVM(cfg).train().to(dev).to(memory_format=torch.channels_last)
     ddp = wrap_ddp(model, dev)
-    opt = torch.optim.AdamW(model.parameters(), lr=1.0e-4)
+    # one process: the step is captured once into a HIP graph and replayed (gdkvm_amd.train.GraphedTrainStep -- the eager loop is bound by the
+    # host's ~420 launches per step, not by the GPU); several ranks: the eager step under DDP.  GDKVM_TRAIN_GRAPH=0 times the eager step.
+    graphed = world == 1 and os.environ.get("GDKVM_TRAIN_GRAPH", "1") != "0"
+    opt = torch.optim.AdamW(model.parameters(), lr=1.0e-4, fused=True, capturable=graphed)
     B, T, S = args.batch, args.frames, args.size
     g = torch.Generator(device="cpu").manual_seed(3000 + rank)
     frames = torch.rand(B, T, 3, S, S, generator=g).to(dev)
@@ -190,12 +193,18 @@ def run_train(args, world, rank, dev, steps, warmup):
 
     first = train_step(ddp, opt, frames, target, torch.bfloat16)     # set-up: MIOpen's solver search (find mode), not a step
     loss = first
+    if graphed:
+        from gdkvm_amd.train import GraphedTrainStep
+        gstep = GraphedTrainStep(ddp, opt, frames, target, torch.bfloat16, warmup=3)      # (three more eager steps, then the capture)
+        step = lambda: gstep(frames, target)
+    else:
+        step = lambda: train_step(ddp, opt, frames, target, torch.bfloat16)
     for _ in range(warmup):
-        loss = train_step(ddp, opt, frames, target, torch.bfloat16)
+        loss = step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = train_step(ddp, opt, frames, target, torch.bfloat16)
+        loss = step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -204,7 +213,7 @@ def run_train(args, world, rank, dev, steps, warmup):
         dt = tt.item()
     return {"frames_per_s": round(world * B * T * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
             "warmup": warmup, "first_loss": round(float(first), 5), "final_loss": round(float(loss), 5),
-            "wrapped": type(ddp).__name__,
+            "wrapped": type(ddp).__name__, "launch": "one hipGraph replay per step" if graphed else "eager (one launch call per kernel)",
             "workload": "BASELINE.json configs[3]: EchoNet-Dynamic training, DDP, 16 clips/GPU (global batch 128 at 8 GPUs), "
                         "bf16 autocast, AdamW lr 1e-4",
             "clips_per_gpu": B, "frames_per_clip": T, "image": f"{S}x{S}",

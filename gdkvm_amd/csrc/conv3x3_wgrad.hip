@@ -163,9 +163,15 @@ __global__ __launch_bounds__(512) void conv3x3_wgrad_reduce_kernel(const float* 
     const int per = (gx + 7) / 8, b0 = ch * per, b1 = min(gx, b0 + per);
     for (size_t base = (size_t)blockIdx.x * 64; base < total; base += (size_t)gridDim.x * 64) {
         const size_t i = base + e;                          // (total is a multiple of 64)
-        float s = 0.f;
-        for (int b = b0; b < b1; ++b) s += part[(size_t)b * total + i];
-        s_sum[ch][e] = s;
+        // eight running sums (partials b0 + j, b0 + j + 8, ...) added up in index order: eight loads in flight per thread instead of a
+        // dependent chain of up to 64 L2 round trips (round 4: 20 -> 8 us per layer; the same fixed order on every run)
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = b0;
+        for (; b + 8 <= b1; b += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s8[j] += part[(size_t)(b + j) * total + i];
+        for (int j = 0; b < b1; ++b, ++j) s8[j] += part[(size_t)b * total + i];
+        s_sum[ch][e] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
         __syncthreads();
         if (ch == 0) {
             float t8 = 0.f;

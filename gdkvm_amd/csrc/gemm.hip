@@ -207,9 +207,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p)
 __global__ void gemm_reduce_kernel(const float* part, float* c, size_t n, int splits)
 {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += part[(size_t)z * n + i];     // fixed order: deterministic
-        c[i] = s;
+        // fixed order (deterministic): eight running sums over splits z = j (mod 8), eight loads in flight instead of a dependent chain
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 8 <= splits; z += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s8[j] += part[(size_t)(z + j) * n + i];
+        for (int j = 0; z < splits; ++z, ++j) s8[j] += part[(size_t)z * n + i];
+        c[i] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     }
 }
 

@@ -243,6 +243,151 @@ __global__ __launch_bounds__(256) void stem_pack_s2d_kernel(const float* w7, bf1
     w4[i] = f32_to_bf16(x);
 }
 
+
+// ---- training: the stem's WEIGHT GRADIENT (round 4), in the space-to-depth form the forward kernels use:
+//   dW4[k][a][b][ch] = sum over output pixels  dy[n, cy, cx, k] * xs[n, cy + a - 2, cx + b - 2, ch]      (64 x 256, fp32)
+// -- a product over the PIXEL axis, the slow axis of both operands, so both MFMA operands are read out of LDS transposed
+// (ds_read_b64_tr_b16, as conv3x3_wgrad.hip does).  A workgroup (4 waves) walks tiles of 4 x 56 output pixels (7 k-steps of 32): the
+// dy tile (64 channels, 144 B per pixel) arrives by LDS-DMA, the 7 x 59 pixel band of the space-to-depth image (32 B per pixel) is built
+// from the NCHW frames through registers exactly like the forward's; wave w owns kernel row a = w: 4 output-channel tiles x 4 kernel
+// columns (the 16 channels of band pixel (py + a, px + b) are one MFMA column tile) = 16 accumulator tiles, kept in registers over all
+// the workgroup's tiles.  Three workgroups per CU cover each other's fetches.  Partials go to the workspace; a second kernel adds them
+// in index order (deterministic, unlike the library's atomically accumulated gradient) and scatters the 7 x 7 taps that exist into the
+// parameter's own layout.  The library kernel took 185 us (+ its casts and zero-fills) of a 7.0 ms training step.
+constexpr int SW_TH = 4, SW_TW = 56;
+constexpr int SW_BR = SW_TH + 3, SW_BC = SW_TW + 3;
+constexpr int SW_BSLOTS = SW_BR * SW_BC * 2;                  // 16-byte slots of the band
+constexpr int SW_BPT = (SW_BSLOTS + 255) / 256;               // slots per thread
+constexpr int SW_BAND_BYTES = (SW_BSLOTS * 16 + 1023) / 1024 * 1024;
+constexpr int SW_YPIX = 144;                                   // bytes between dy pixels in LDS (128 + 16: see conv3x3_wgrad.hip)
+constexpr int SW_YPIECES = (SW_TH * SW_TW * 9 + 63) / 64;      // 1 KiB DMA pieces of the dy tile
+constexpr int SW_KSTEPS = SW_TH * SW_TW / 32;
+static_assert(SW_TH * SW_TW % 32 == 0 && SW_TW % 4 == 0, "tiles are whole k-steps; four consecutive pixels never straddle a row");
+
+struct StemWgradArgs { const bf16_t* xf; const bf16_t* dy; float* part; int N, Cf, Hs, Ws, tiles_x, tiles_y; };
+
+__global__ __launch_bounds__(256, 3) void stem_wgrad_kernel(StemWgradArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_band[SW_BAND_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char s_y[SW_YPIECES * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);                     // wave = kernel row a
+    const int q = li >> 2, p4 = (li & 3) * 4;                                    // transposed-read geometry (conv3x3_wgrad.hip)
+    const int ntiles = a.N * a.tiles_y * a.tiles_x;
+    const int H = 2 * a.Hs, W = 2 * a.Ws;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[kt][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % a.tiles_x, t2 = tile / a.tiles_x, ty = t2 % a.tiles_y, n = t2 / a.tiles_y;
+        const int cy0 = SW_TH * ty, cx0 = SW_TW * tx, y0 = cy0 - 2, x0 = cx0 - 2;
+        // the band's slots from the frames, into registers (slot d = 2 pix + half: channels 2 half, 2 half + 1 x row parity x column pair).
+        // (Requested a whole tile ahead instead -- asm loads with hand-written wait counts -- the kernel took 81 us against 76: the three
+        // workgroups of a CU already cover each other's fetches.)
+        unsigned stage[SW_BPT][4];
+#pragma unroll
+        for (int u = 0; u < SW_BPT; ++u) {
+            const int d = 256 * u + tid, pix = d >> 1, half = d & 1;
+            const int by = pix / SW_BC, bx = pix - by * SW_BC, yy = y0 + by, xx = x0 + bx;
+            const bool ok = d < SW_BSLOTS && yy >= 0 && yy < a.Hs && xx >= 0 && xx < a.Ws;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 2 * half + (e >> 1);
+                const bool live = ok && c < a.Cf;
+                const bf16_t* src = live ? a.xf + ((((size_t)n * a.Cf + c) * H + 2 * yy + (e & 1)) * W + 2 * xx) : reinterpret_cast<const bf16_t*>(&g_stem_zero16);
+                stage[u][e] = *reinterpret_cast<const unsigned*>(src);
+            }
+        }
+        __syncthreads();                                   // everyone is done with the previous tile's buffers
+        for (int j = w; j < SW_YPIECES; j += 4) {           // the dy tile by LDS-DMA (ninth slot of a pixel and pixels outside the image: zeros)
+            const int d = 64 * j + lane, pix = d / 9, c = d - 9 * pix;
+            const int py = pix / SW_TW, px = pix - py * SW_TW, cy = cy0 + py, cx = cx0 + px;
+            const bool ok = c < 8 && pix < SW_TH * SW_TW && cy < a.Hs && cx < a.Ws;
+            const bf16_t* src = ok ? a.dy + ((((size_t)n * a.Hs + cy) * a.Ws + cx) * 64 + c * 8) : reinterpret_cast<const bf16_t*>(&g_stem_zero16);
+            __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(s_y + 1024 * j)), 16, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < SW_BPT; ++u) {
+            const int d = 256 * u + tid;
+            if (d < SW_BSLOTS) *reinterpret_cast<uint4*>(s_band + 16 * d) = make_uint4(stage[u][0], stage[u][1], stage[u][2], stage[u][3]);
+        }
+        __syncthreads();                                   // (vmcnt(0) + barrier: band and dy tile are in LDS)
+#pragma unroll 1
+        for (int s = 0; s < SW_KSTEPS; ++s) {
+            unsigned ya[2], xa[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int pp = 32 * s + 8 * g + 4 * hf + q, py = pp / SW_TW, px = pp - py * SW_TW;
+                ya[hf] = (unsigned)(uintptr_t)(s_y + pp * SW_YPIX + p4 * 2);
+                xa[hf] = (unsigned)(uintptr_t)(s_band + ((py + w) * SW_BC + px) * 32 + p4 * 2);
+            }
+            uint2 fa[4][2], fb[4][2];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=&v"(fa[kt][hf]) : "v"(ya[hf] + 32 * kt) : "memory");
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=&v"(fb[b][hf]) : "v"(xa[hf] + 32 * b) : "memory");
+            // (the fragments are operands of the wait so that no MFMA can be scheduled above it)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]),
+                           "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]), "+v"(fb[3][0]), "+v"(fb[3][1])
+                         :: "memory");
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const bf16x8 bf = __builtin_bit_cast(bf16x8, make_uint4(fb[b][0].x, fb[b][0].y, fb[b][1].x, fb[b][1].y));
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, make_uint4(fa[kt][0].x, fa[kt][0].y, fa[kt][1].x, fa[kt][1].y));
+                    acc[kt][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[kt][b], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // partial block part[blockIdx.x][k 64][a 4][b 4][ch 16]: lane (li, g) holds rows 4g + r (output channel) of column li (channel)
+    float* out = a.part + (size_t)blockIdx.x * (64 * 256);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[((16 * kt + 4 * g + r) * 4 + w) * 64 + 16 * b + li] = acc[kt][b][r];
+}
+
+// dW7[k][c][u][v] (element strides sk, sc, sr, ss) = sum over the gx partial blocks, in index order, of the space-to-depth element that
+// stands for tap (u, v) of channel c: a = (u + 1) / 2, p = (u + 1) % 2 (stem_pack_s2d_kernel's map, inverted); the others are dropped.
+__global__ __launch_bounds__(512) void stem_wgrad_reduce_kernel(const float* part, float* dw, int gx, int C, long long sk, long long sc, long long sr, long long ss)
+{
+    __shared__ float s_sum[8][64];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int per = (gx + 7) / 8, b0 = sl * per, b1 = min(gx, b0 + per);
+    const int i = blockIdx.x * 64 + e;                      // (k, a, b, ch)
+    // eight running sums (partials b0 + j, b0 + j + 8, ...), added up in index order: eight loads in flight instead of a dependent chain
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = b0;
+    for (; b + 8 <= b1; b += 8)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s8[j] += part[(size_t)(b + j) * (64 * 256) + i];
+    for (int j = 0; b < b1; ++b, ++j) s8[j] += part[(size_t)b * (64 * 256) + i];
+    const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    s_sum[sl][e] = s;
+    __syncthreads();
+    if (sl == 0) {
+        float t8 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t8 += s_sum[j][e];
+        const int ch = i & 15, bb = (i >> 4) & 3, aa = (i >> 6) & 3, k = i >> 8;
+        const int c = ch >> 2, p = (ch >> 1) & 1, qq = ch & 1, u = 2 * aa + p - 1, v = 2 * bb + qq - 1;
+        if (c < C && u >= 0 && u <= 6 && v >= 0 && v <= 6) dw[k * sk + c * sc + u * sr + v * ss] = t8;
+    }
+}
+
 }  // namespace
 
 static int stem_conv_pool_impl(const char* who, const void* xs, const void* xf, int Cf, const void* w, const float* bias, void* y,
@@ -319,5 +464,48 @@ extern "C" int gdkvm_stem_pack_s2d(const float* w7, void* w4, int C, long long s
     if (int rc = gdkvm_check_device()) return rc;
     hipLaunchKernelGGL(stem_pack_s2d_kernel, dim3(64), dim3(256), 0, static_cast<hipStream_t>(stream), w7, static_cast<bf16_t*>(w4), C, sk, sc, sr, ss);
     GDKVM_LAUNCH_CHECK("stem_pack_s2d_kernel");
+    return GDKVM_OK;
+}
+
+
+// ---- training: weight gradient of the stem convolution ------------------------------------------------------------------------------
+static int stem_wgrad_grid(int N, int Hs, int Ws, int* tiles_x, int* tiles_y)
+{
+    *tiles_x = (Ws + SW_TW - 1) / SW_TW; *tiles_y = (Hs + SW_TH - 1) / SW_TH;
+    const long long ntiles = (long long)N * *tiles_x * *tiles_y;
+    if (ntiles > 0x7fffffffLL) return -1;
+    return (int)(ntiles < 768 ? ntiles : 768);             // persistent: three workgroups per CU
+}
+
+extern "C" size_t gdkvm_stem_wgrad_workspace_bytes(int N, int H, int W)
+{
+    int tx, ty;
+    if (N <= 0 || H <= 0 || W <= 0) return 16;
+    const int gx = stem_wgrad_grid(N, H / 2, W / 2, &tx, &ty);
+    return gx <= 0 ? 16 : (size_t)gx * 64 * 256 * sizeof(float);
+}
+
+extern "C" int gdkvm_stem_wgrad_nchw(const void* x, const void* dy, float* dw, long long sk, long long sc, long long sr, long long ss,
+                                     void* workspace, size_t workspace_bytes, int N, int C, int H, int W, int io_dtype, void* stream)
+{
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "stem_wgrad_nchw: only bf16 operands are implemented");
+    if (C <= 0 || C > 4 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || N < 0)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "stem_wgrad_nchw: N=%d C=%d H=%d W=%d (at most 4 channels, H and W even)", N, C, H, W);
+    if (N == 0) return GDKVM_OK;
+    if (!x || !dy || !dw || !workspace || !gdkvm_aligned16(x) || !gdkvm_aligned16(dy) || !gdkvm_aligned16(workspace))
+        return gdkvm_fail(GDKVM_ERR_ARG, "stem_wgrad_nchw: null or unaligned pointer");
+    StemWgradArgs a;
+    a.xf = static_cast<const bf16_t*>(x); a.dy = static_cast<const bf16_t*>(dy); a.part = static_cast<float*>(workspace);
+    a.N = N; a.Cf = C; a.Hs = H / 2; a.Ws = W / 2;
+    const int gx = stem_wgrad_grid(N, a.Hs, a.Ws, &a.tiles_x, &a.tiles_y);
+    if (gx <= 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "stem_wgrad_nchw: too many tiles");
+    const size_t need = (size_t)gx * 64 * 256 * sizeof(float);
+    if (workspace_bytes < need) return gdkvm_fail(GDKVM_ERR_WORKSPACE, "stem_wgrad_nchw: workspace %zu < %zu bytes", workspace_bytes, need);
+    if (int rc = gdkvm_check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(stem_wgrad_kernel, dim3(gx), dim3(256), 0, st, a);
+    GDKVM_LAUNCH_CHECK("stem_wgrad_kernel");
+    hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(64 * 256 / 64), dim3(512), 0, st, static_cast<const float*>(workspace), dw, gx, C, sk, sc, sr, ss);
+    GDKVM_LAUNCH_CHECK("stem_wgrad_reduce_kernel");
     return GDKVM_OK;
 }

@@ -68,6 +68,8 @@ SIGNATURES = {
     "gdkvm_stem_conv_pool_nchw": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "gdkvm_stem_conv_nchw": (_i, [_vp] * 3 + [_i] * 5 + [_vp]),
     "gdkvm_stem_pack_s2d": (_i, [_vp, _vp, _i] + [ctypes.c_longlong] * 4 + [_vp]),
+    "gdkvm_stem_wgrad_workspace_bytes": (_sz, [_i] * 3),
+    "gdkvm_stem_wgrad_nchw": (_i, [_vp] * 3 + [ctypes.c_longlong] * 4 + [_vp, _sz] + [_i] * 5 + [_vp]),
     "gdkvm_gate_logits": (_i, [_vp] * 7 + [_i] * 5 + [_vp]),
     "gdkvm_proj_gates": (_i, [_vp] * 13 + [_i] * 7 + [_vp]),
     "gdkvm_conv_bias_act": (_i, [_vp] * 5 + [_i] * 12 + [_vp]),
@@ -1208,7 +1210,7 @@ def stem_conv_pool_nchw(x: torch.Tensor, w_s2d: torch.Tensor, bias: torch.Tensor
 class _StemConvFunction(torch.autograd.Function):
     """The training stem's convolution (7x7 / stride 2 / pad 3, no bias, <= 4 input channels -> 64) on the hand-written stem kernel in its
     convolution-only form (gdkvm_stem_pack_s2d + gdkvm_stem_conv_nchw): bf16 NCHW frames in, channels_last bf16 out.  The input is the
-    image (no data gradient); the weight gradient stays the framework's convolution_backward."""
+    image (no data gradient); the weight gradient is gdkvm_stem_wgrad_nchw (stem_wgrad)."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -1229,10 +1231,28 @@ class _StemConvFunction(torch.autograd.Function):
         xb, weight = ctx.saved_tensors
         dw = None
         if ctx.needs_input_grad[1]:
-            dyb = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-            dw = torch.ops.aten.convolution_backward(dyb, xb, weight.detach().to(torch.bfloat16), None, (2, 2), (3, 3), (1, 1), False, (0, 0), 1,
-                                                     (False, True, False))[1].to(weight.dtype)
+            dw = stem_wgrad(xb, dy, like=weight)
         return None, dw
+
+
+def stem_wgrad(x: torch.Tensor, dy: torch.Tensor, like: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weight gradient [64, C, 7, 7] fp32 of the stem convolution (7x7 / stride 2 / pad 3) for NCHW bf16 frames x [N, C <= 4, H, W] and
+    dy [N, 64, H/2, W/2] (channels_last bf16), on gdkvm_stem_wgrad_nchw: fixed summation order, in the memory format of `like`."""
+    lib = load()
+    xb = x.detach().to(torch.bfloat16).contiguous()
+    dyb = _nhwc(dy.detach(), "stem_wgrad")
+    if dyb.dtype != torch.bfloat16:
+        dyb = dyb.to(torch.bfloat16)
+    n, c, hh, ww = xb.shape
+    if tuple(dyb.shape) != (n, 64, hh // 2, ww // 2):
+        raise GdkvmError(f"stem_wgrad: dy {tuple(dyb.shape)} does not match x {tuple(xb.shape)}")
+    dw = torch.empty_like(like, dtype=torch.float32) if like is not None else torch.empty((64, c, 7, 7), dtype=torch.float32, device=xb.device)
+    need = lib.gdkvm_stem_wgrad_workspace_bytes(n, hh, ww)
+    ws = torch.empty(need, dtype=torch.uint8, device=xb.device)
+    with torch.cuda.device(xb.device):
+        _check(lib.gdkvm_stem_wgrad_nchw(xb.data_ptr(), dyb.data_ptr(), dw.data_ptr(), *dw.stride(), ws.data_ptr(), need, n, c, hh, ww, BF16,
+                                         _stream(xb.device)), "gdkvm_stem_wgrad_nchw")
+    return dw
 
 
 def stem_conv_served(x: torch.Tensor, conv) -> bool:

@@ -96,3 +96,42 @@ def fit_synthetic(model: nn.Module, steps: int, clips: int = 8, frames: int = 8,
         losses.append(float(train_step(model, opt, x, y, autocast_dtype if dev.type == "cuda" else None)))
     model.eval()
     return losses
+
+
+class GraphedTrainStep:
+    """train_step captured ONCE into a HIP graph and replayed: a training step of this model is ~420 kernel launches of 5 - 100 us, and with
+    the step's kernels down to 6.5 ms the eager loop is bound by the HOST (Python autograd + launch calls: 6.5 - 8.6 ms per step depending
+    on the box's CPU, measured round 4) -- the graph replays the same kernels in the same order with no host work in between.
+    Single process only (DDP's bucketed all-reduce is left to the eager step); shapes are fixed at construction; the optimiser must be
+    capturable (torch.optim.AdamW(..., fused=True, capturable=True)).  The first `warmup` steps run eagerly on a side stream (library
+    convolutions pick their solvers, the HIP library sets its kernel attributes, the optimiser creates its state), then one step is
+    captured; every call copies the batch into the graph's input buffers and replays -- same arithmetic, same order, same results as
+    train_step."""
+
+    def __init__(self, model: nn.Module, opt: torch.optim.Optimizer, frames: torch.Tensor, target: torch.Tensor,
+                 autocast_dtype: Optional[torch.dtype] = None, warmup: int = 3):
+        if not frames.is_cuda:
+            raise RuntimeError("GraphedTrainStep needs device tensors")
+        self.model, self.opt, self.autocast_dtype = model, opt, autocast_dtype
+        self.frames, self.target = frames.clone(), target.clone()
+        side = torch.cuda.Stream(device=frames.device)
+        side.wait_stream(torch.cuda.current_stream(frames.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self.loss = train_step(model, opt, self.frames, self.target, autocast_dtype)
+        torch.cuda.current_stream(frames.device).wait_stream(side)
+        torch.cuda.synchronize(frames.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = train_step(model, opt, self.frames, self.target, autocast_dtype)
+        self.eager_steps = max(1, warmup)       # optimiser steps taken before the first replay (the capture itself runs no kernel)
+
+    def __call__(self, frames: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        if frames.shape != self.frames.shape or target.shape != self.target.shape:
+            raise RuntimeError(f"GraphedTrainStep was captured for {tuple(self.frames.shape)} / {tuple(self.target.shape)}")
+        if frames.data_ptr() != self.frames.data_ptr():
+            self.frames.copy_(frames, non_blocking=True)
+        if target.data_ptr() != self.target.data_ptr():
+            self.target.copy_(target, non_blocking=True)
+        self.graph.replay()
+        return self.loss

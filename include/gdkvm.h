@@ -406,6 +406,13 @@ int gdkvm_stem_conv_pool_nchw(const void* x, const void* w, const float* bias, v
  * builds from the fp32 [64, C, 7, 7] weight (element strides sk, sc, sr, ss) in one small launch per step. */
 int gdkvm_stem_conv_nchw(const void* x, const void* w4, void* y, int N, int C, int H, int W, int io_dtype, void* stream);
 int gdkvm_stem_pack_s2d(const float* w7, void* w4, int C, long long sk, long long sc, long long sr, long long ss, void* stream);
+/* Training: the stem convolution's weight gradient dw7 [64, C, 7, 7] fp32 (element strides sk, sc, sr, ss; every element written) from
+ * the NCHW frames x [N, C <= 4, H, W] bf16 and dy [N, H/2, W/2, 64] bf16 (NHWC), as a pixel-axis product in the space-to-depth form with a
+ * fixed-order reduction over workgroup partials held in `workspace` (gdkvm_stem_wgrad_workspace_bytes): deterministic, unlike the framework
+ * convolution's atomically accumulated gradient it replaces. */
+size_t gdkvm_stem_wgrad_workspace_bytes(int N, int H, int W);
+int gdkvm_stem_wgrad_nchw(const void* x, const void* dy, float* dw, long long sk, long long sc, long long sr, long long ss,
+                          void* workspace, size_t workspace_bytes, int N, int C, int H, int W, int io_dtype, void* stream);
 
 /* Row n1, the training stem: 3x3 / stride 2 / pad 1 max-pool of an NHWC tensor x [N, H, W, C] -> y [N, Ho, Wo, C]
  * (Ho = (H-1)/2+1) recording the winning tap of every output element in idx (one byte each, [N, Ho, Wo, C]: 3*dy + dx in

@@ -2,7 +2,7 @@
 """Per-step kernel table of the STEADY STATE of a profiled bench run, from rocprofv3's kernel_trace.csv: MIOpen's find
 mode runs trial and reference kernels (naive_conv, 36 ms each) during warm-up, which swamp the --stats summary; this takes
 the last K forward steps (a step ends with upsample_argmax_dice_kernel) and averages over them.
-usage: python profiles/steady_state.py <kernel_trace.csv> <out.csv> "<command line that was profiled>" [K=10] [end-marker]
+usage: python profiles/steady_state.py <kernel_trace.csv> <out.csv> "<command line that was profiled>" [K=10] [end-marker] [sequence.csv]
 end-marker: substring of the kernel that ends a step (default upsample_argmax_dice; training: multi_tensor = the fused AdamW
 kernels; runs of marker kernels closer than 8 dispatches count as one step end)."""
 import collections
@@ -35,6 +35,15 @@ def main():
             a[0] += 1
             a[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     tot = sum(v[1] for v in agg.values())
+    if len(sys.argv) > 6:                                   # the dispatch sequence of the last step: name, grid, workgroup, duration, gap before it
+        lo, hi = steps[-1]
+        with open(sys.argv[6], "w") as f:
+            f.write(f"# {cmd}\n# dispatch sequence of the last steady-state step: index, microseconds, idle microseconds before it, grid, workgroup, kernel\n")
+            for i in range(lo, hi):
+                r = rows[i]
+                gap = (int(r["Start_Timestamp"]) - int(rows[i - 1]["End_Timestamp"])) / 1e3 if i > lo else 0.0
+                f.write(f"{i - lo},{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:.1f},{gap:.1f},{r.get('Grid_Size_X', '?')},{r.get('Workgroup_Size_X', '?')},"
+                        f"{short(r['Kernel_Name'])}\n")
     with open(dst, "w") as f:
         f.write(f"# {cmd}\n# steady state: mean over the last {len(steps)} forward steps of the kernel trace; "
                 f"sum of kernel durations per step = {tot / len(steps) / 1e6:.3f} ms\n")

@@ -9,7 +9,7 @@ rm -rf "$OUT" && mkdir -p "$OUT"
 CMD="python3 bench.py --mode train --steps 12 --warmup 5"
 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o t -- $CMD > "$OUT/trace.log" 2>&1
 cd profiles
-python3 steady_state.py "$(ls ../$OUT/*kernel_trace.csv | head -1)" ../gpurun_out/${TAG}_train_cfg4_steady_state.csv "rocprofv3 --kernel-trace -- $CMD" 8 multi_tensor
+python3 steady_state.py "$(ls ../$OUT/*kernel_trace.csv | head -1)" ../gpurun_out/${TAG}_train_cfg4_steady_state.csv "rocprofv3 --kernel-trace -- $CMD" 8 multi_tensor ../gpurun_out/${TAG}_train_cfg4_sequence.csv
 cd ..
 head -40 gpurun_out/${TAG}_train_cfg4_steady_state.csv
 tail -3 "$OUT/trace.log"
