@@ -2,13 +2,16 @@
 // (SURVEY.md §8f row n1):   dW[k][ty][tx][c] = sum over pixels  dy[n, y, x, k] * x[n, y + ty - 1, x + tx - 1, c],
 // NHWC bf16 operands, fp32 result.  It is a product over the PIXEL axis, which is the slow axis of both operands in memory, so
 // both MFMA operands are read out of LDS transposed (ds_read_b64_tr_b16 with per-lane addresses):
-//   * a workgroup (4 waves) owns one (64 output channels) x (9 taps x 64 input channels) block of dW and walks pixel tiles
+//   * a workgroup owns one (64 output channels) x (9 taps x 64 input channels) block of dW and walks pixel tiles
 //     (a whole 14x14 frame, four 7x7 frames, a 7-row band of a 28x28 frame: up to 224 pixels = 7 k-steps of 32), keeping
 //     its 36 accumulator tiles per wave (4 output-channel tiles x 9 taps of input-channel tile w) in registers throughout;
 //   * per tile the x halo band ((rows + 2) x (W + 2) pixels, 64 channels, zero borders) and the dy tile (64 channels, padding
 //     pixels zero) arrive by LDS-DMA, pixels 144 B apart; a tap is a shifted window of the band, so a 32-pixel k-step costs a
 //     wave 4 dy fragments + 9 x fragments (26 transposed 8-byte reads) for 36 MFMAs;
-//   * one buffer per workgroup, two workgroups per CU: while one waits for its DMA the other computes;
+//   * (round 4) the workgroup is EIGHT waves, one per CU: waves 4 .. 7 own the same accumulator tiles as waves 0 .. 3, the two halves walk
+//     separate tile streams with their own buffers, in step only with themselves (a barrier of four waves is a counter in LDS), and at the
+//     end the halves' accumulators are added through LDS -- as two independent four-wave workgroups per CU (rounds 2-3) each half wrote a
+//     147 KB partial block: 75 MB written and read back per layer;
 //   * every workgroup writes its partial block (fp32) to the workspace; a second kernel adds the partials in a fixed order
 //     (deterministic) into dW [K][C][3][3].
 #include <atomic>
@@ -38,16 +41,16 @@ struct WgradArgs {
 
 __device__ __forceinline__ int wg_div(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
 
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a)
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_kernel(WgradArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];     // x band [npx KiB] | dy tile [npy KiB] | 1 KiB dump
+    // 2 x (x band [npx KiB] | dy tile [npy KiB]); at the end the same memory carries one wave half's accumulators to the other (144 KiB)
+    extern __shared__ __attribute__((aligned(16))) unsigned char wg_lds[];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);                     // wave = input-channel tile of the block
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = w8 & 3, h = w8 >> 2;                       // wave = input-channel tile w of the block, in wave half h
     const int H = a.H, W = a.W, C = a.C, K = a.K, BW = a.bw;
     const int cb = blockIdx.y % a.cblocks, kb = blockIdx.y / a.cblocks;
-    unsigned char* s_x = wg_lds;
-    unsigned char* s_y = wg_lds + a.npx * 1024;
-    unsigned char* s_dump = s_y + a.npy * 1024;
+    const int bufsz = (a.npx + a.npy) * 1024;
 
     f32x4 acc[4][9];
 #pragma unroll
@@ -58,32 +61,51 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a)
     // transposed-read lane geometry: lane 4q + p of 16-lane group g addresses pixel row (8g + 4 half + q), channels 4p .. 4p+3
     const int q = li >> 2, p4 = (li & 3) * 4;
 
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    // DMA of a tile into this half's buffer: the x band (64 channels cb) and the dy tile (64 channels kb); geometry computed per piece (no tables)
+    unsigned char* s_x = wg_lds + h * bufsz;
+    unsigned char* s_y = s_x + a.npx * 1024;
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
         const int ty = tile % a.tiles_y, fg = tile / a.tiles_y;
         const int y0 = ty * a.th - 1;
         const int nfr = min(a.fpt, a.N - fg * a.fpt);
-        __syncthreads();                                   // everyone is done with the previous tile's buffers
-        // ---- DMA: the x band (64 channels cb) and the dy tile (64 channels kb); geometry computed per piece (no tables)
-        {
-            const bf16_t* xo = a.x + (((long long)fg * a.fpt * H + y0) * W - 1) * C + cb * 64;
-            for (int j = w; j < a.npx; j += 4) {
-                const int d = 64 * j + lane, pix = d / WG_SLOTS, c = d - WG_SLOTS * pix;
-                const int f = wg_div(pix, a.inv_band), r = pix - f * (a.bh * BW), by = wg_div(r, a.inv_bw), bx = r - by * BW;
-                const int yy = y0 + by;
-                const bool ok = c < 8 && pix < a.band_px && bx >= 1 && bx <= W && (unsigned)yy < (unsigned)H && f < nfr;
-                const bf16_t* src = ok ? xo + ((f * H + by) * W + bx) * C + c * 8 : reinterpret_cast<const bf16_t*>(&g_wg_zero16);
-                __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(s_x + 1024 * j)), 16, 0, 0);
-            }
-            const bf16_t* yo = a.dy + (((long long)fg * a.fpt * H + ty * a.th) * W) * K + kb * 64;
-            for (int j = w; j < a.npy; j += 4) {
-                const int d = 64 * j + lane, pix = d / WG_SLOTS, c = d - WG_SLOTS * pix;
-                const int f = wg_div(pix, a.inv_tw), r = pix - f * (a.th * W), py = wg_div(r, a.inv_w);
-                const bool ok = c < 8 && pix < a.tpix && f < nfr && ty * a.th + py < H;
-                const bf16_t* src = ok ? yo + ((f * H + py) * W + (r - py * W)) * K + c * 8 : reinterpret_cast<const bf16_t*>(&g_wg_zero16);
-                __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(s_y + 1024 * j)), 16, 0, 0);
-            }
+        const bf16_t* xo = a.x + (((long long)fg * a.fpt * H + y0) * W - 1) * C + cb * 64;
+        for (int j = w; j < a.npx; j += 4) {
+            const int d = 64 * j + lane, pix = d / WG_SLOTS, c = d - WG_SLOTS * pix;
+            const int f = wg_div(pix, a.inv_band), r = pix - f * (a.bh * BW), by = wg_div(r, a.inv_bw), bx = r - by * BW;
+            const int yy = y0 + by;
+            const bool ok = c < 8 && pix < a.band_px && bx >= 1 && bx <= W && (unsigned)yy < (unsigned)H && f < nfr;
+            const bf16_t* src = ok ? xo + ((f * H + by) * W + bx) * C + c * 8 : reinterpret_cast<const bf16_t*>(&g_wg_zero16);
+            __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(s_x + 1024 * j)), 16, 0, 0);
         }
-        __syncthreads();                                   // (vmcnt(0) + barrier: both tiles have landed)
+        const bf16_t* yo = a.dy + (((long long)fg * a.fpt * H + ty * a.th) * W) * K + kb * 64;
+        for (int j = w; j < a.npy; j += 4) {
+            const int d = 64 * j + lane, pix = d / WG_SLOTS, c = d - WG_SLOTS * pix;
+            const int f = wg_div(pix, a.inv_tw), r = pix - f * (a.th * W), py = wg_div(r, a.inv_w);
+            const bool ok = c < 8 && pix < a.tpix && f < nfr && ty * a.th + py < H;
+            const bf16_t* src = ok ? yo + ((f * H + py) * W + (r - py * W)) * K + c * 8 : reinterpret_cast<const bf16_t*>(&g_wg_zero16);
+            __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(s_y + 1024 * j)), 16, 0, 0);
+        }
+    };
+
+    // The two wave halves are two independent four-wave "workgroups" -- own tile stream, own buffers, in step only with themselves -- as
+    // the two workgroups per CU of rounds 2-3 were (in lockstep behind one s_barrier per tile and with the k-steps split between the
+    // halves the kernel took 59 us per layer against 55: one half's fetch wait has to overlap the other's MFMAs).  A half's barrier is a
+    // counter in LDS: arrive (after the wave's own DMA and LDS operations are done), then poll until all four waves of the round are in.
+    unsigned* ctr = reinterpret_cast<unsigned*>(wg_lds + 2 * bufsz) + 16 * h;
+    if (tid == 0) { reinterpret_cast<unsigned*>(wg_lds + 2 * bufsz)[0] = 0u; reinterpret_cast<unsigned*>(wg_lds + 2 * bufsz)[16] = 0u; }
+    __syncthreads();
+    unsigned round = 0;
+    auto half_barrier = [&]() __attribute__((always_inline)) {
+        round += 4;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < round) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    for (int tile = 2 * blockIdx.x + h; tile < a.ntiles; tile += 2 * gridDim.x) {
+        half_barrier();                                    // the half is done with the previous tile's buffers
+        fetch(tile);
+        half_barrier();                                    // band and dy tile have landed
         // ---- 7 k-steps of 32 pixels: pixel rows 32 s + 8 g + 4 half + q of this lane
 #pragma unroll 1
         for (int s = 0; s < WG_KSTEPS; ++s) {
@@ -91,8 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a)
             unsigned ya[2], xa[2];                         // this lane's LDS byte addresses in the dy tile / the x band (tap 0, 0)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-                const int pix = min(32 * s + 8 * g + 4 * hf + q, a.tpix - 1 + (WG_MAXPIX - a.tpix > 0 ? 0 : 0));
-                const int pp = 32 * s + 8 * g + 4 * hf + q;
+                const int pp = 32 * s + 8 * g + 4 * hf + q, pix = min(pp, a.tpix - 1);
                 ya[hf] = (unsigned)(uintptr_t)(s_y + min(pp, a.npy * 64 / WG_SLOTS - 1) * WG_PIX + p4 * 2);
                 const int f = wg_div(pix, a.inv_tw), r = pix - f * (a.th * W), py = wg_div(r, a.inv_w), px = r - py * W;
                 xa[hf] = (unsigned)(uintptr_t)(s_x + ((f * a.bh + py) * BW + px) * WG_PIX + (16 * w + p4) * 2);
@@ -135,7 +156,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a)
             taps(std::integral_constant<int, 5>{}, std::integral_constant<int, 9>{});
         }
     }
-    (void)s_dump;
+    // ---- the odd wave half hands its accumulators to the even one through LDS ([wave 4][tile 36][lane 64] x 16 B: 144 KiB, the tile buffers
+    //      are free by now), which adds them and writes the workgroup's ONE partial block -- half the partial traffic of two independent
+    //      four-wave workgroups per CU (75 MB written and read back per layer at the training shape)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4* ex = reinterpret_cast<f32x4*>(wg_lds);
+    if (h == 1) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) ex[(w * 36 + kt * 9 + t) * 64 + lane] = acc[kt][t];
+    }
+    __syncthreads();
+    if (h == 1) return;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[kt][t] += ex[(w * 36 + kt * 9 + t) * 64 + lane];
     // ---- partial block: part[blockIdx.x][blockIdx.y][k 64][tap 9][c 64]; lane (li, g) holds rows 4g + r (output channel) of
     //      column li (input channel 16 w + li)
     float* out = a.part + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * (64 * 9 * 64);
@@ -201,7 +239,7 @@ bool wgrad_plan(int N, int C, int H, int W, int K, WgradPlan* p)
         a.bh = a.th + 2; a.band_px = a.fpt * a.bh * a.bw; a.tpix = a.fpt * a.th * W;
         a.npx = (a.band_px * WG_SLOTS + 63) / 64;
         a.npy = (((a.tpix + 31) / 32 * 32) * WG_SLOTS + 63) / 64;
-        return (size_t)(a.npx + a.npy + 1) * 1024 <= 78 * 1024;           // two workgroups per CU
+        return (size_t)(a.npx + a.npy) * 1024 <= 78 * 1024;               // two buffers in 160 KB
     };
     while (!fits() && a.fpt > 1) --a.fpt;
     while (!fits() && a.th > 1) { --a.th; a.tiles_y = (H + a.th - 1) / a.th; }
@@ -213,10 +251,11 @@ bool wgrad_plan(int N, int C, int H, int W, int K, WgradPlan* p)
     a.ntiles = (int)ntiles;
     a.cblocks = C / 64;
     p->gy = (C / 64) * (K / 64);
-    int gx = 512 / p->gy; if (gx < 1) gx = 1;              // two workgroups per CU (more = more partial blocks to add up: 147 KB each)
-    if (gx > ntiles) gx = (int)ntiles;
+    int gx = 256 / p->gy; if (gx < 1) gx = 1;              // one eight-wave workgroup per CU (more = more partial blocks to add up: 147 KB each)
+    if (gx > (ntiles + 1) / 2) gx = (int)((ntiles + 1) / 2);   // (two tile streams per workgroup)
     p->gx = gx;
-    p->lds = (size_t)(a.npx + a.npy + 1) * 1024;
+    p->lds = 2 * (size_t)(a.npx + a.npy) * 1024 + 128;   // two halves' buffers + their barrier counters
+    if (p->lds < 4 * 36 * 64 * sizeof(f32x4)) p->lds = 4 * 36 * 64 * sizeof(f32x4);      // the accumulator exchange at the end
     return true;
 }
 
@@ -249,12 +288,12 @@ static int conv3x3_wgrad_impl(const void* x, const void* dy, float* dw, void* wo
     if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "conv3x3_wgrad: hipGetDevice");
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 78 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "conv3x3_wgrad: LDS attribute: %s", hipGetErrorString(e));
         done_mask.fetch_or(bit, std::memory_order_relaxed);
     }
     p.a.x = static_cast<const bf16_t*>(x); p.a.dy = static_cast<const bf16_t*>(dy); p.a.part = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(p.gx, p.gy), dim3(256), p.lds, st, p.a);
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(p.gx, p.gy), dim3(512), p.lds, st, p.a);
     GDKVM_LAUNCH_CHECK("conv3x3_wgrad_kernel");
     const size_t n = (size_t)K * 9 * C;
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((unsigned)(n / 64 > 4096 ? 4096 : n / 64)), dim3(512), 0, st,
