@@ -108,25 +108,46 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 2 : 1)) void conv3x3_tile_ker
     const int tpix = a.fpt * a.th * W;                     // output pixels of a full tile
     const int co0 = blockIdx.y * (16 * NTW * NWN) + 16 * NTW * wn;     // this wave's output channels co0 .. co0 + 16 NTW - 1
 
+    // bias of this lane's output channels: asm loads, first thing, waited for with the first band (they are older than its pieces).  A load
+    // the compiler sees would be "pending" to it at the bias's first use in EVERY iteration of the tile loop -- it cannot count across the
+    // LDS-DMA in between -- and it drains vmcnt to 0 there: at the top of each tile's epilogue, on the operands just requested for the next tile.
+    f32x4 bias4[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int kt = min(co0 / 16 + nt, K / 16 - 1);     // (a tile past K: the last tile's bias, results never stored)
+        const float* bp = a.bias + ct_channel(kt, 4 * g, a.perm);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bias4[nt]) : "v"(bp) : "memory");
+    }
+
     // DMA piece geometry (tile-invariant): piece j = w + NWV u, slot d = 64 j + lane = CT_SLOTS pix + c; c >= 8 is padding
     constexpr int PP = NWV == 8 ? 7 : 8;                   // pieces per wave: npieces <= 56 (eight waves) / 32 (four)
-    int g_pix[PP], g_yx[PP], g_fr[PP];                     // source pixel offset from the band's (0, 0); band row or -1; frame | 8c << 8
+    int g_pix[PP], g_meta[PP];                             // source pixel offset from the band's (0, 0); band row << 16 | 8c << 8 | frame, or -1
 #pragma unroll
     for (int u = 0; u < PP; ++u) {
         const int j = w + NWV * u, d = 64 * j + lane, pix = d / CT_SLOTS, c = d - CT_SLOTS * pix;
         const int f = ct_div(pix, a.inv_band), r = pix - f * (a.bh * BW), by = ct_div(r, a.inv_bw), bx = r - by * BW;
         g_pix[u] = (f * H + by) * W + bx;
         const bool live = j < a.npieces && c < 8 && pix < a.band_px && bx >= 1 && bx <= W;
-        g_yx[u] = live ? by : -1;
-        g_fr[u] = f | (c * 8) << 8;
+        g_meta[u] = live ? (by << 16 | (c * 8) << 8 | f) : -1;
     }
-    auto fetch = [&](int tile, int chunk, int buf) __attribute__((always_inline)) {
+    // what a tile's band fetches need of the tile, computed ONCE per tile (scalar: the row / frame-group split of the tile index and two
+    // 64-bit origins; recomputed per chunk it was ~85 scalar instructions of the ~2 000 cycles a wave spent issuing a chunk's fetch)
+    struct Geo { const bf16_t* b1; const bf16_t* b2; int y0, nfr; };
+    auto geo_of = [&](int tile) __attribute__((always_inline)) {
         const int ty = tile % a.tiles_y, fg = tile / a.tiles_y;          // row tile, frame group
-        const int y0 = ty * a.th - 1;
+        Geo q;
+        q.y0 = ty * a.th - 1;
+        q.nfr = min(a.fpt, a.N - fg * a.fpt);                           // frames that exist in the last group
+        const long long px0 = ((long long)fg * a.fpt * H + q.y0) * W - 1;       // band pixel (0, 0) of frame 0
+        q.b1 = a.x + px0 * (a.x2 ? a.C1 : C);
+        q.b2 = a.x2 ? a.x2 + px0 * (C - a.C1) - a.C1 : a.x;             // (indexed by the channel of the concatenated input)
+        return q;
+    };
+    auto fetch = [&](const Geo q, int chunk, int buf) __attribute__((always_inline)) {
+        const int y0 = q.y0, nfr = q.nfr;
         const bool second = a.x2 != nullptr && chunk * CT_CK >= a.C1;   // which tensor of a concatenated input holds this chunk
         const int cs = a.x2 ? (second ? C - a.C1 : a.C1) : C;           // its channel count = pixel pitch
-        const bf16_t* origin = (second ? a.x2 : a.x) + (((long long)fg * a.fpt * H + y0) * W - 1) * cs + chunk * CT_CK - (second ? a.C1 : 0);
-        const int nfr = min(a.fpt, a.N - fg * a.fpt);                   // frames that exist in the last group
+        const bf16_t* origin = (second ? q.b2 : q.b1) + chunk * CT_CK;
         // straight-line on purpose (always PP pieces: surplus ones land in a dump slot): a branch would make the compiler's vmcnt
         // counting conservative for the weight fragments in flight around it
 #ifdef CT_ABL_NODMA
@@ -135,13 +156,19 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 2 : 1)) void conv3x3_tile_ker
 #pragma unroll
         for (int u = 0; u < PP; ++u) {
             const int j = w + NWV * u;
-            const int yy = y0 + g_yx[u];
-            const bool ok = g_yx[u] >= 0 && (unsigned)yy < (unsigned)H && (g_fr[u] & 255) < nfr;
-            const bf16_t* src = ok ? origin + g_pix[u] * cs + (g_fr[u] >> 8) : reinterpret_cast<const bf16_t*>(&g_ct_zero16);
+            const int yy = y0 + (g_meta[u] >> 16);
+            const bool ok = g_meta[u] >= 0 && (unsigned)yy < (unsigned)H && (g_meta[u] & 255) < nfr;
+            const bf16_t* src = ok ? origin + g_pix[u] * cs + ((g_meta[u] >> 8) & 255) : reinterpret_cast<const bf16_t*>(&g_ct_zero16);
             unsigned char* dst = j < a.npieces ? ct_band + buf * band_bytes + 1024 * j : ct_band + 2 * band_bytes;
             __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
         }
     };
+
+    // the first band is requested before anything else is set up (it is the longest wait of the prologue: HBM); the bias loads above are
+    // older than its pieces, so the first chunk's band wait covers them too
+    int tile = blockIdx.x;
+    Geo cur = geo_of(min(tile, a.ntiles - 1));
+    if (tile < a.ntiles) fetch(cur, 0, 0);
 
     // this lane's pixel in each of the wave's pixel tiles: LDS byte offset of tap (0, 0), channel chunk g
     unsigned pbase[MTW];
@@ -151,13 +178,10 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 2 : 1)) void conv3x3_tile_ker
         const int f = ct_div(p, a.inv_tw), r = p - f * (a.th * W), py = ct_div(r, a.inv_w), px = r - py * W;
         pbase[m] = (unsigned)(((f * a.bh + py) * BW + px) * CT_PIX + g * 16);
     }
-    f32x4 bias4[NTW];
     const bf16_t* wrow[NTW];                               // weights [K][3][3][C]: A operand rows of output tile nt
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-        bias4[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int kt = min(co0 / 16 + nt, K / 16 - 1);     // (a tile past K: the last tile's weights, results never stored)
-        if (co0 + 16 * nt < K) bias4[nt] = *reinterpret_cast<const f32x4*>(a.bias + ct_channel(kt, 4 * g, a.perm));
+        const int kt = min(co0 / 16 + nt, K / 16 - 1);     // (a tile past K: the last tile's weights and bias, results never stored)
         // PK: the weights were re-laid out by gdkvm_conv3x3_pack_weights as [K / 16][k-step][lane][8], a fragment = 1 KiB contiguous
         // (8 full cache lines per load instruction instead of 16 half-used ones: the vector-memory path is this kernel's bound)
         if constexpr (PK) wrow[nt] = a.w + (size_t)kt * (9 * C * 16) + lane * 8;
@@ -195,8 +219,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 2 : 1)) void conv3x3_tile_ker
         if constexpr (NTW == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(o.f[0]) : "n"(N) : "memory");
         else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(o.f[0]), "+v"(o.f[1]) : "n"(N) : "memory");
     };
-    int tile = blockIdx.x, gc = 0;                          // gc: chunks processed so far; chunk gc lives in LDS buffer gc & 1
-    if (tile < a.ntiles) fetch(tile, 0, 0);
+    int gc = 0;                                             // gc: chunks processed so far; chunk gc lives in LDS buffer gc & 1
     // weight fragments, WD k-steps ahead, in a ring of WD register sets with STATIC indices: k-step r uses set r % WD and refills it
     // for k-step r + WD.  (Rotating named registers -- wf0 = wf1; ...; wf3 = load -- made the compiler copy the freshly loaded
     // fragment at the loop's back edge behind an s_waitcnt vmcnt(0): the whole L2 latency every second k-step, 3x the MFMA time.)
@@ -205,6 +228,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 2 : 1)) void conv3x3_tile_ker
 #pragma unroll
     for (int j = 0; j < WD; ++j) wload(wr[j], j);
     for (; tile < a.ntiles; tile += gridDim.x) {
+        const Geo nxt = geo_of(min(tile + (int)gridDim.x, a.ntiles - 1));      // (past the last tile: one more band of the last tile, into the buffer nobody reads again)
         f32x4 acc[MTW][NTW];
 #pragma unroll
         for (int m = 0; m < MTW; ++m)
@@ -224,8 +248,9 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 2 : 1)) void conv3x3_tile_ker
             // (past the last tile: one more band of the last tile, into the buffer nobody reads again)
             {
                 const bool more = chunk + 1 < nchunk;
-                const int nt_tile = more ? tile : min(tile + (int)gridDim.x, a.ntiles - 1);
-                fetch(nt_tile, more ? chunk + 1 : 0, buf ^ 1);
+                Geo q;                                     // (field by field: a select between the two structs would put them in scratch)
+                q.b1 = more ? cur.b1 : nxt.b1; q.b2 = more ? cur.b2 : nxt.b2; q.y0 = more ? cur.y0 : nxt.y0; q.nfr = more ? cur.nfr : nxt.nfr;
+                fetch(q, more ? chunk + 1 : 0, buf ^ 1);
             }
             const unsigned char* band = ct_band + buf * band_bytes;
             auto load_x = [&](bf16x8 (&xb)[MTW], int r) __attribute__((always_inline)) {
@@ -282,36 +307,88 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 2 : 1)) void conv3x3_tile_ker
             const int ty = tile % a.tiles_y, fg = tile / a.tiles_y;
             auto bf4 = [](uint2 rr) { return f32x4{__uint_as_float(rr.x << 16), __uint_as_float(rr.x & 0xffff0000u), __uint_as_float(rr.y << 16), __uint_as_float(rr.y & 0xffff0000u)}; };
             auto pk4 = [](const f32x4& v) { return make_uint2((unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16), (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16)); };
-            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            const float lo = a.relu ? 0.f : -INFINITY;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));       // packed fp32 pairs: v_pk_add_f32 / v_pk_max_f32
+            if (NTW == 2 && a.perm) {                      // 8 consecutive channels 32G + 8g .. +7 (co0 and K are multiples of 32)
+                if (co0 < K) {
+                    // every pixel tile's output offset first, then ALL the residual loads, then the arithmetic: one wait for the seven
+                    // loads (a load followed by its use per pixel tile was seven dependent round trips per epilogue)
+                    unsigned o[MTW];                       // element offsets (the launcher keeps tensors below 2^31 elements); ~0u = no pixel
 #pragma unroll
-            for (int m = 0; m < MTW; ++m) {
-                const int p = 16 * (wm + MW * m) + li;
-                if (p >= tpix) continue;
-                const int f = ct_div(p, a.inv_tw), r = p - f * (a.th * W), py = ct_div(r, a.inv_w), px = r - py * W;
-                const int n = fg * a.fpt + f, yy = ty * a.th + py;
-                if (n >= a.N || yy >= H) continue;
-                const size_t opix = (((size_t)n * H + yy) * W + px) * K;
-                if (NTW == 2 && a.perm) {                  // 8 consecutive channels 32G + 8g .. +7 (co0 and K are multiples of 32)
-                    if (co0 >= K) continue;
-                    const size_t o = opix + co0 + 8 * g;
-                    f32x4 v0 = acc[m][0] + bias4[0], v1 = acc[m][NTW - 1] + bias4[NTW - 1];
-                    if (a.res) {
-                        const uint4 rr = *reinterpret_cast<const uint4*>(a.res + o);
-                        v0 += bf4(make_uint2(rr.x, rr.y)); v1 += bf4(make_uint2(rr.z, rr.w));
+                    for (int m = 0; m < MTW; ++m) {
+                        const int p = 16 * (wm + MW * m) + li;
+                        const int pc = min(p, tpix - 1);
+                        const int f = ct_div(pc, a.inv_tw), r = pc - f * (a.th * W), py = ct_div(r, a.inv_w), px = r - py * W;
+                        const int n = fg * a.fpt + f, yy = ty * a.th + py;
+                        o[m] = p < tpix && n < a.N && yy < H ? (unsigned)(((n * H + yy) * W + px) * K + co0 + 8 * g) : ~0u;
                     }
-                    if (a.relu) { v0 = __builtin_elementwise_max(v0, zero4); v1 = __builtin_elementwise_max(v1, zero4); }
-                    const uint2 lo = pk4(v0), hi = pk4(v1);
-                    *reinterpret_cast<uint4*>(a.y + o) = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    continue;
-                }
+                    // The epilogue's loads and stores are asm, invisible to the compiler's wait-count pass: while LDS-DMA (the next band) and the
+                    // asm weight fragments are in flight it answers every use of a load it knows of -- and every rewrite of a register such a
+                    // load or store touched -- with s_waitcnt vmcnt(0), i.e. with a wait for the operands just requested for the NEXT tile
+                    // (round 4 stamps: 6 000 cycles per epilogue, a quarter of a tile's time, for ~1 500 cycles of work).  Without a residual
+                    // nothing is waited for at all; with one, the loads go out in groups of four pixel tiles (all seven spill) and each group
+                    // is waited for once (vmcnt(0): a count that relied on how many stores were issued would break when a pixel tile has no
+                    // live lane and its store is branched over).
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    bf16_t* const yout = a.y;
+                    const bf16_t* const resp = a.res;
+                    const unsigned ofallback = (unsigned)(co0 + 8 * g);
+                    auto finish = [&](auto resc) __attribute__((always_inline)) {
+                        constexpr bool RES = decltype(resc)::value;
+                        static_for_ct<0, (MTW + 3) / 4>([&](auto bc) {
+                            constexpr int M0 = 4 * decltype(bc)::value, M1 = M0 + 4 < MTW ? M0 + 4 : MTW;
+                            u32x4 rr[4] = {};
+                            if constexpr (RES) {
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) {
-                    if (co0 + 16 * nt >= K) continue;
-                    const size_t o = opix + ct_channel(co0 / 16 + nt, 4 * g, a.perm);
-                    f32x4 v = acc[m][nt] + bias4[nt];
-                    if (a.res) v += bf4(*reinterpret_cast<const uint2*>(a.res + o));
-                    if (a.relu) v = __builtin_elementwise_max(v, zero4);
-                    *reinterpret_cast<uint2*>(a.y + o) = pk4(v);
+                                for (int m = M0; m < M1; ++m)
+                                {
+                                    const bf16_t* const rp = resp + (o[m] != ~0u ? o[m] : ofallback);
+                                    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(rr[m - M0]) : "v"(rp) : "memory");
+                                }
+                                asm volatile("s_waitcnt vmcnt(0)" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3]) :: "memory");
+                            }
+#pragma unroll
+                            for (int m = M0; m < M1; ++m) {
+                                f32x2 v[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q)
+                                    v[q] = f32x2{acc[m][q >> 1][2 * (q & 1)], acc[m][q >> 1][2 * (q & 1) + 1]} + f32x2{bias4[q >> 1][2 * (q & 1)], bias4[q >> 1][2 * (q & 1) + 1]};
+                                if constexpr (RES) {
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) v[q] += f32x2{__uint_as_float(rr[m - M0][q] << 16), __uint_as_float(rr[m - M0][q] & 0xffff0000u)};
+                                }
+                                u32x4 ow;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    v[q] = __builtin_elementwise_max(v[q], f32x2{lo, lo});
+                                    ow[q] = (unsigned)f32_to_bf16(v[q][0]) | ((unsigned)f32_to_bf16(v[q][1]) << 16);
+                                }
+                                // (s_nop: the hazard recogniser does not see an asm store's data registers being rewritten right behind it)
+                                bf16_t* const yp = yout + o[m];
+                                if (o[m] != ~0u) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(yp), "v"(ow) : "memory");
+                            }
+                        });
+                    };
+                    if (a.res) finish(std::true_type{}); else finish(std::false_type{});
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MTW; ++m) {
+                    const int p = 16 * (wm + MW * m) + li;
+                    if (p >= tpix) continue;
+                    const int f = ct_div(p, a.inv_tw), r = p - f * (a.th * W), py = ct_div(r, a.inv_w), px = r - py * W;
+                    const int n = fg * a.fpt + f, yy = ty * a.th + py;
+                    if (n >= a.N || yy >= H) continue;
+                    const size_t opix = (((size_t)n * H + yy) * W + px) * K;
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) {
+                        if (co0 + 16 * nt >= K) continue;
+                        const size_t o = opix + ct_channel(co0 / 16 + nt, 4 * g, a.perm);
+                        f32x4 v = acc[m][nt] + bias4[nt];
+                        if (a.res) v += bf4(*reinterpret_cast<const uint2*>(a.res + o));
+                        v = __builtin_elementwise_max(v, f32x4{lo, lo, lo, lo});
+                        *reinterpret_cast<uint2*>(a.y + o) = pk4(v);
+                    }
                 }
             }
         }
@@ -319,6 +396,7 @@ __global__ __launch_bounds__(64 * NWV, (NWV == 4 ? 2 : 1)) void conv3x3_tile_ker
 #ifdef CT_DIAG
         { const int gcs = gc; { const int gc = gcs - 1; CT_STAMP(7); } }   // end of the tile's epilogue (slot 7 of its last chunk)
 #endif
+        cur = nxt;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing may land in LDS after the workgroup is gone
 }
