@@ -13,7 +13,8 @@
 
 namespace {
 
-struct GemmArgs { const void* a; const void* b; void* c; float* part; const float* bias; int M, N, K, K1, rows_per_split, splits; };
+struct GemmArgs { const void* a; const void* b; void* c; float* part; const float* bias; int M, N, K, K1, rows_per_split, splits;
+                  float* part_cs; };   // TN: optional partial column sums of A, [splits][K1] (the bias gradient of a token-major product)
 
 // ---- NT: workgroup tile 128 (M) x 64 (N); wave w owns rows 32w .. 32w+31 and all 64 columns: 2 x 4 accumulator tiles.  The
 // product is computed transposed (C^T = B A^T: the weight rows are the A operand) so that a lane ends with four consecutive
@@ -125,6 +126,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p)
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // column sums of A (sum over the rows m of A[m][k1] -- the bias gradient when A = dY): one more MFMA per step against a fragment of
+    // ones, in the workgroups of the first N tile only (the framework's reduction for it was a zero-fill and 10 - 24 us per projection)
+    const bool colsum = p.part_cs != nullptr && blockIdx.y == 0;
+    f32x4 accs = {0.f, 0.f, 0.f, 0.f};
     // staging: thread t moves 16-byte pieces; piece = (row, 16-byte chunk c of the 64-column slab row)
     constexpr int PIECES = TN_ROWS * 64 * ESZ / 16;        // per matrix: 256 (bf16) or 512 (fp32)
     constexpr int PER = (PIECES + 255) / 256, CPR = 64 * ESZ / 16;     // pieces per thread, chunks per row
@@ -173,6 +178,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p)
             };
             const bf16x8 af = frag(&s_slab[buf][0][w * (TN_ROWS * 16 * 2)]);
             __builtin_amdgcn_sched_barrier(0);
+            if (colsum) {
+                const unsigned one2 = 0x3f803f80u;          // bf16 1.0 twice
+                accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, make_uint4(one2, one2, one2, one2)), accs, 0, 0, 0);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bf16x8 bf = frag(&s_slab[buf][1][j * (TN_ROWS * 16 * 2)]);
@@ -184,6 +193,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p)
 #pragma unroll
             for (int s = 0; s < TN_ROWS / 4; ++s) {        // k step: rows 4s + g
                 const float av = sa[(4 * s + g) * 16 + li];
+                if (colsum) accs = mfma4(av, 1.0f, accs);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float bv = reinterpret_cast<const float*>(&s_slab[buf][1][j * (TN_ROWS * 16 * 4)])[(4 * s + g) * 16 + li];
@@ -202,11 +212,27 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p)
             const int kk = k0 + 16 * w + 4 * g + r, n = n0 + 16 * j + li;
             if (kk < K1 && n < N) P[(size_t)kk * N + n] = acc[j][r];
         }
+    if (colsum && li == 0) {                               // every column of accs holds the same sums: column 0 writes them
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = k0 + 16 * w + 4 * g + r;
+            if (kk < K1) p.part_cs[(size_t)z * K1 + kk] = accs[r];
+        }
+    }
 }
 
-__global__ void gemm_reduce_kernel(const float* part, float* c, size_t n, int splits)
+// (n2 > 0: a second, short array -- the partial column sums -- is summed by the same launch: elements n .. n + n2 - 1)
+__global__ void gemm_reduce_kernel(const float* part, float* c, size_t n, int splits, const float* part2 = nullptr, float* c2 = nullptr, size_t n2 = 0)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n + n2; i0 += (size_t)gridDim.x * blockDim.x) {
+        const bool second = i0 >= n;
+        const size_t i = second ? i0 - n : i0;
+        if (second) {
+            float s = 0.f;
+            for (int z = 0; z < splits; ++z) s += part2[(size_t)z * n2 + i];
+            c2[i] = s;
+            continue;
+        }
         // fixed order (deterministic): eight running sums over splits z = j (mod 8), eight loads in flight instead of a dependent chain
         float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int z = 0;
@@ -253,33 +279,53 @@ extern "C" size_t gdkvm_gemm_tn_workspace_bytes(int M, int K1, int N)
     return (size_t)tn_splits(M) * K1 * N * sizeof(float);
 }
 
-extern "C" int gdkvm_gemm_tn(const void* a, const void* b, float* c, void* workspace, size_t workspace_bytes,
-                             int M, int K1, int N, int io_dtype, void* stream)
+static int gemm_tn_impl(const char* who, const void* a, const void* b, float* c, float* colsum, void* workspace, size_t workspace_bytes,
+                        int M, int K1, int N, int io_dtype, void* stream)
 {
-    if (int rc = check_gemm("gemm_tn", M, N, K1, io_dtype)) return rc;
+    if (int rc = check_gemm(who, M, N, K1, io_dtype)) return rc;
     if (K1 == 0 || N == 0) return GDKVM_OK;
     const int eq = io_dtype == GDKVM_BF16 ? 8 : 4;
-    if (K1 % eq || N % eq) return gdkvm_fail(GDKVM_ERR_SHAPE, "gemm_tn: K1=%d and N=%d must be multiples of %d", K1, N, eq);
+    if (K1 % eq || N % eq) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: K1=%d and N=%d must be multiples of %d", who, K1, N, eq);
     if (!c || !gdkvm_aligned16(c) || (M > 0 && (!a || !b || !gdkvm_aligned16(a) || !gdkvm_aligned16(b))))
-        return gdkvm_fail(GDKVM_ERR_ARG, "gemm_tn: null or unaligned pointer");
+        return gdkvm_fail(GDKVM_ERR_ARG, "%s: null or unaligned pointer", who);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (int rc = gdkvm_check_device()) return rc;
     if (M == 0) {
         hipError_t e = hipMemsetAsync(c, 0, (size_t)K1 * N * sizeof(float), st);
-        return e == hipSuccess ? GDKVM_OK : gdkvm_fail(GDKVM_ERR_LAUNCH, "gemm_tn: memset: %s", hipGetErrorString(e));
+        if (e == hipSuccess && colsum) e = hipMemsetAsync(colsum, 0, (size_t)K1 * sizeof(float), st);
+        return e == hipSuccess ? GDKVM_OK : gdkvm_fail(GDKVM_ERR_LAUNCH, "%s: memset: %s", who, hipGetErrorString(e));
     }
-    const size_t need = gdkvm_gemm_tn_workspace_bytes(M, K1, N);
-    if (!workspace || workspace_bytes < need) return gdkvm_fail(GDKVM_ERR_WORKSPACE, "gemm_tn: workspace %zu < %zu bytes", workspace_bytes, need);
+    const size_t need = gdkvm_gemm_tn_workspace_bytes(M, K1, N) + (colsum ? (size_t)tn_splits(M) * K1 * sizeof(float) : 0);
+    if (!workspace || workspace_bytes < need) return gdkvm_fail(GDKVM_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", who, workspace_bytes, need);
     const int splits = tn_splits(M);
     const int rows = ((M + splits - 1) / splits + TN_ROWS - 1) / TN_ROWS * TN_ROWS;
-    GemmArgs ga{a, b, nullptr, static_cast<float*>(workspace), nullptr, M, N, 0, K1, rows, splits};
+    float* part_cs = colsum ? static_cast<float*>(workspace) + (size_t)splits * K1 * N : nullptr;
+    GemmArgs ga{a, b, nullptr, static_cast<float*>(workspace), nullptr, M, N, 0, K1, rows, splits, part_cs};
     const dim3 grid((unsigned)((K1 + 63) / 64), (unsigned)((N + 63) / 64), (unsigned)splits);
     if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gemm_tn_kernel<GDKVM_F32>), grid, dim3(256), 0, st, ga);
     else hipLaunchKernelGGL((gemm_tn_kernel<GDKVM_BF16>), grid, dim3(256), 0, st, ga);
     GDKVM_LAUNCH_CHECK("gemm_tn_kernel");
-    const size_t n = (size_t)K1 * N;
-    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, st,
-                       static_cast<const float*>(workspace), c, n, splits);
+    const size_t n = (size_t)K1 * N, n2 = colsum ? (size_t)K1 : 0;
+    hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((n + n2 + 255) / 256 > 1024 ? 1024 : (n + n2 + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const float*>(workspace), c, n, splits, static_cast<const float*>(part_cs), colsum, n2);
     GDKVM_LAUNCH_CHECK("gemm_reduce_kernel");
     return GDKVM_OK;
+}
+
+extern "C" int gdkvm_gemm_tn(const void* a, const void* b, float* c, void* workspace, size_t workspace_bytes,
+                             int M, int K1, int N, int io_dtype, void* stream)
+{
+    return gemm_tn_impl("gemm_tn", a, b, c, nullptr, workspace, workspace_bytes, M, K1, N, io_dtype, stream);
+}
+
+extern "C" size_t gdkvm_gemm_tn_colsum_workspace_bytes(int M, int K1, int N)
+{
+    return gdkvm_gemm_tn_workspace_bytes(M, K1, N) + (size_t)tn_splits(M) * (K1 > 0 ? K1 : 0) * sizeof(float);
+}
+
+extern "C" int gdkvm_gemm_tn_colsum(const void* a, const void* b, float* c, float* colsum, void* workspace, size_t workspace_bytes,
+                                    int M, int K1, int N, int io_dtype, void* stream)
+{
+    if (!colsum) return gdkvm_fail(GDKVM_ERR_ARG, "gemm_tn_colsum: null pointer");
+    return gemm_tn_impl("gemm_tn_colsum", a, b, c, colsum, workspace, workspace_bytes, M, K1, N, io_dtype, stream);
 }

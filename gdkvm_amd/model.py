@@ -621,8 +621,7 @@ class GDKVM(nn.Module):
             m = F.adaptive_avg_pool2d(mask0.to(v.dtype), (h, w))
             me = self._tokens(self.mask_embed(m))                                # [B,N,Hh*Dv]
             v = torch.cat([v[:, :1] + me.unsqueeze(1), v[:, 1:]], 1)
-        elif torch.is_grad_enabled() and self.mask_embed.weight.requires_grad:
-            v = v + 0.0 * self.mask_embed.weight.sum()            # keep every parameter in the graph (DDP: no unused params)
+        keep_mask_embed = mask0 is None and torch.is_grad_enabled() and self.mask_embed.weight.requires_grad
         v = v.reshape(B, T, N, Hh, Dv)
         v8 = 8 if p_tok.dtype == torch.bfloat16 else 4
         g_lanes = p_tok.shape[-1] // v8
@@ -642,6 +641,10 @@ class GDKVM(nn.Module):
         else:
             beta = proj(self.gate_proj).float().reshape(B, T, N, Hh)
             alpha = self.decay_proj(p_tok.mean(1)).float().reshape(B, T, Hh)
+        if keep_mask_embed:
+            # keep every parameter in the graph (DDP: no unused params) -- through the B*T*Hh decay logits, not through v: a zero added to the
+            # [B*T*N, Hh*Dv] values was a 29 us pass forward and a reduction over their gradient backward (round 4)
+            alpha = alpha + 0.0 * self.mask_embed.weight.sum()
         if norms is not None:
             r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state, norms=norms)
         else:

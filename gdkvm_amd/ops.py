@@ -54,6 +54,8 @@ SIGNATURES = {
     "gdkvm_gemm_nt": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
     "gdkvm_gemm_tn_workspace_bytes": (_sz, [_i] * 3),
     "gdkvm_gemm_tn": (_i, [_vp] * 4 + [_sz] + [_i] * 4 + [_vp]),
+    "gdkvm_gemm_tn_colsum_workspace_bytes": (_sz, [_i] * 3),
+    "gdkvm_gemm_tn_colsum": (_i, [_vp] * 5 + [_sz] + [_i] * 4 + [_vp]),
     "gdkvm_kpff_workspace_bytes": (_sz, [_i] * 4),
     "gdkvm_kpff_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 7 + [_vp]),
     "gdkvm_kpff_fwd_packed": (_i, [_vp] * 9 + [_sz] + [_i] * 7 + [_vp]),
@@ -1446,10 +1448,11 @@ def gemm_nt(a: torch.Tensor, bt: torch.Tensor, bias: Optional[torch.Tensor] = No
     return c
 
 
-def wgrad(dy2d: torch.Tensor, x2d: torch.Tensor) -> torch.Tensor:
+def wgrad(dy2d: torch.Tensor, x2d: torch.Tensor, colsum: bool = False):
     """dW [M,N] (fp32) = dy^T x for token-major operands dy [K,M], x [K,N] with K (the tokens of the batch) >> M, N: the
     reduction over the tokens is split over workgroups into fp32 partial tiles and summed in a fixed order (gdkvm_gemm_tn);
-    the sum never passes through bf16."""
+    the sum never passes through bf16.  colsum=True: (dW, db) with db [M] (fp32) = the column sums of dy -- the bias gradient --
+    from the same launch (gdkvm_gemm_tn_colsum)."""
     lib = load()
     if dy2d.dim() != 2 or x2d.dim() != 2 or dy2d.shape[0] != x2d.shape[0]:
         raise GdkvmError("wgrad: dy [K,M] and x [K,N] with equal K")
@@ -1460,6 +1463,13 @@ def wgrad(dy2d: torch.Tensor, x2d: torch.Tensor) -> torch.Tensor:
     K, M = dy2d.shape
     N = x2d.shape[1]
     c = torch.empty((M, N), dtype=torch.float32, device=dev)
+    if colsum:
+        db = torch.empty(M, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib.gdkvm_gemm_tn_colsum_workspace_bytes(K, M, N)), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.gdkvm_gemm_tn_colsum(_ptr(dy2d), _ptr(x2d), _ptr(c), _ptr(db), ws.data_ptr(), ws.numel(), K, M, N, _io_dtype(dy2d), _stream(dev))
+        _check(rc, "gdkvm_gemm_tn_colsum")
+        return c, db
     ws = torch.empty(int(lib.gdkvm_gemm_tn_workspace_bytes(K, M, N)), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = lib.gdkvm_gemm_tn(_ptr(dy2d), _ptr(x2d), _ptr(c), ws.data_ptr(), ws.numel(), K, M, N, _io_dtype(dy2d), _stream(dev))
@@ -1485,9 +1495,16 @@ class _TokenLinear(torch.autograd.Function):
         x2d, w = ctx.saved_tensors
         dy = dy.contiguous()
         dx = gemm_nt(dy, w.t().contiguous()) if ctx.needs_input_grad[0] else None
-        dw = wgrad(dy, x2d).to(ctx.wdtype) if ctx.needs_input_grad[1] else None
-        # (column sums with fp32 accumulation straight from the rows: .float().sum(0) wrote and re-read an fp32 copy of dy first)
-        db = dy.sum(0, dtype=torch.float32).to(ctx.wdtype) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        dw = db = None
+        if ctx.needs_input_grad[1] and want_b and dy.is_cuda:
+            dw, db = wgrad(dy, x2d, colsum=True)            # the bias gradient rides on the weight gradient's launch (one more MFMA per step)
+            dw, db = dw.to(ctx.wdtype), db.to(ctx.wdtype)
+        else:
+            if ctx.needs_input_grad[1]:
+                dw = wgrad(dy, x2d).to(ctx.wdtype)
+            if want_b:                                      # (column sums with fp32 accumulation straight from the rows)
+                db = dy.sum(0, dtype=torch.float32).to(ctx.wdtype)
         return dx, dw, db
 
 

@@ -222,6 +222,12 @@ int gdkvm_gemm_nt(const void* a, const void* b, const float* bias, void* c, int 
 size_t gdkvm_gemm_tn_workspace_bytes(int M, int K1, int N);
 int gdkvm_gemm_tn(const void* a, const void* b, float* c, void* workspace, size_t workspace_bytes,
                   int M, int K1, int N, int io_dtype, void* stream);
+/* The same product with the column sums of A as a second result: colsum[K1] (fp32) = sum over the M rows of A[m][k1] -- the bias
+ * gradient of y = x W^T + b when A = dY -- from one more MFMA per step against a fragment of ones, summed over the row splits in the same
+ * fixed order (workspace: gdkvm_gemm_tn_colsum_workspace_bytes). */
+size_t gdkvm_gemm_tn_colsum_workspace_bytes(int M, int K1, int N);
+int gdkvm_gemm_tn_colsum(const void* a, const void* b, float* c, float* colsum, void* workspace, size_t workspace_bytes,
+                         int M, int K1, int N, int io_dtype, void* stream);
 
 /* Row a4: Key-Pixel Feature Fusion ("fuses the local key feature, the global key feature with the pixel
  * feature", /root/reference/website/src/content/homepage/en.json:20; "multiple scales", README.md:20).

@@ -184,6 +184,11 @@ def test_token_linear_and_split_k_weight_gradient(hip, dtype):
     assert (xg.grad.double().cpu() - dx_ref).abs().max() <= tol * dx_ref.abs().max().item()
     # token counts that are no multiple of the row split or of the 32-row LDS slab
     assert torch.allclose(hip.wgrad(dy[:1001], x[:1001]), (dy[:1001].float().t() @ x[:1001].float()), rtol=1e-4, atol=1e-3)
+    # the bias gradient from the same launch (gdkvm_gemm_tn_colsum): column sums of dy, fp32 accumulation, the same bits on every run
+    dw2, db2 = hip.wgrad(dy[:1001], x[:1001], colsum=True)
+    assert torch.equal(dw2, hip.wgrad(dy[:1001], x[:1001]))
+    assert (db2.double().cpu() - dy[:1001].double().cpu().sum(0)).abs().max() <= 1e-4 * 1001 ** 0.5
+    assert torch.equal(db2, hip.wgrad(dy[:1001], x[:1001], colsum=True)[1])
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
