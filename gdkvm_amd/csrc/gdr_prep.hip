@@ -1508,6 +1508,7 @@ extern "C" size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk
 {
     if (gdr_narrow_keys(Dk) && B > 0 && T > 0 && Hh > 0 && N > 0 && Dv > 0 && N <= GDKVM_MAX_N)      // (gdkvm_scan_fwd's zero-extended copies)
         return gdr_up256(gdr_workspace_bytes(B, T, Hh, N, GDKVM_DK, Dv)) + gdr_narrow_extra_bytes(B, T, Hh, N, Dv);
+    if (gdr_wide_keys(Dk)) return GDKVM_WS_TAIL;          // (gdr_general.hip keeps its state in LDS)
     return gdr_workspace_bytes(B, T, Hh, N, Dk, Dv);
 }
 

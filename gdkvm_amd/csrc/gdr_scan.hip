@@ -635,6 +635,10 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
 // GDKVM_ERR_RANGE (with the remedy in gdkvm_last_error) or GDKVM_OK.
 extern "C" int gdkvm_scan_status(const void* workspace, size_t workspace_bytes, int B, int T, int Hh, int N, int Dk, int Dv, int flags, void* stream)
 {
+    if (gdr_wide_keys(Dk)) {                               // fp32 recurrence (gdr_general.hip): there is no operand range to leave
+        const hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+        return e == hipSuccess ? GDKVM_OK : gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_status: %s", hipGetErrorString(e));
+    }
     if (gdr_narrow_keys(Dk)) Dk = GDKVM_DK;                // (gdkvm_scan_fwd ran the Dk = 64 kernels on the same base layout)
     if (int rc = check_common("scan_status", B, T, Hh, N, Dk, Dv, GDKVM_F32, flags)) return rc;
     if (B == 0 || T == 0 || N == 0 || (flags & GDKVM_FLAG_WIDE_RANGE)) return GDKVM_OK;        // nothing ran / full-range operands: no bound to break
@@ -748,6 +752,12 @@ extern "C" int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const
                               int B, int T, int Hh, int N, int Dk, int Dv,
                               int io_dtype, int rule, int flags, void* stream)
 {
+    if (gdr_wide_keys(Dk)) {
+        // key widths 72 .. 256: the definitional recurrence, one workgroup per state slice (gdr_general.hip); inference only
+        if (s_hist) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: s_hist (training) needs Dk <= %d", GDKVM_DK);
+        if (int rc = check_ptrs("scan_fwd", {q, k, v, alpha, beta}, {s_in, r_out, s_out})) return rc;
+        return gdr_general_scan_fwd(q, k, v, alpha, beta, s_in, r_out, s_out, B, T, Hh, N, Dk, Dv, io_dtype, rule, flags, static_cast<hipStream_t>(stream));
+    }
     if (gdr_narrow_keys(Dk) && B > 0 && T > 0 && N > 0) {
         // key widths 8 .. 56: the Dk = 64 kernels on zero-extended copies of q, k and the state (gdr_ws.hpp)
         if (s_hist) return gdkvm_fail(GDKVM_ERR_SHAPE, "scan_fwd: s_hist needs Dk=%d (training pads the keys itself)", GDKVM_DK);

@@ -60,6 +60,10 @@ static inline size_t gdr_narrow_extra_bytes(int B, int T, int Hh, int N, int Dv)
 }
 // 16-byte units: block b of nblk copies copy_q units from src + b*src_q to dst + b*dst_q and zero-fills up to fill_q (gdr_train.hip)
 int gdr_block_copy(const void* src, void* dst, size_t nblk, size_t src_q, size_t dst_q, size_t copy_q, size_t fill_q, hipStream_t st);
+// Key widths above 64 (multiples of 8 up to 256): gdkvm_scan_fwd runs the definitional kernel of gdr_general.hip (no workspace)
+bool gdr_wide_keys(int Dk);
+int gdr_general_scan_fwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta, const float* s_in, void* r_out,
+                         float* s_out, int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, hipStream_t st);
 
 static inline int carve(const char* fn, void* workspace, size_t workspace_bytes, int B, int T, int Hh, int N, int Dk, int Dv, WsView* v)
 {

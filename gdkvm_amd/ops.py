@@ -170,7 +170,8 @@ def _stream(dev) -> int:
     return torch.cuda.current_stream(dev).cuda_stream
 
 
-KERNEL_DK = 64                # per-head key dim the kernels are built for (include/gdkvm.h)
+KERNEL_DK = 64                # per-head key dim the fast kernels are built for (include/gdkvm.h; narrower keys run on them through zero
+                              # channels, wider ones -- up to 256 -- on the general kernel of csrc/gdr_general.hip, inference only)
 
 
 def _pad_keys(q, k, state):

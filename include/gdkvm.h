@@ -84,8 +84,11 @@ size_t gdkvm_scan_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv);
  * processed as consecutive calls with the state carried is bit-identical to one call.
  * Names: LKVA / GDR at /root/reference/README.md:20; "state transition matrix" at
  * /root/reference/website/src/content/homepage/en.json:20.
- * Supported: Dk == 64, or 8 <= Dk < 64 in multiples of 8 (gdkvm_scan_fwd only, not with s_hist: the call zero-extends q, k and the
- * state to 64 channels inside the workspace, which is exact); Dv % 16 == 0; 0 <= N <= 4096 (a 1024x1024 frame at stride 16).
+ * Supported: Dk == 64 (the measured kernels); 8 <= Dk < 64 in multiples of 8 (gdkvm_scan_fwd only, not with s_hist: the call zero-extends
+ * q, k and the state to 64 channels inside the workspace, which is exact); 64 < Dk <= 256 in multiples of 8 (gdkvm_scan_fwd only,
+ * inference: the definitional recurrence in fp32 on one workgroup per 16-column slice of the state, csrc/gdr_general.hip -- same
+ * results, same chunk bit-identity, no workspace, far slower than the Dk = 64 path; gdkvm_scan_status has nothing to report for it);
+ * Dv % 16 == 0; 0 <= N <= 4096 (a 1024x1024 frame at stride 16).
  * s_hist (training): if non-NULL, [B,T,Hh,Dk,Dv] fp32 receives the state BEFORE every frame; gdkvm_scan_bwd needs
  * it together with the untouched workspace of this call. */
 int gdkvm_scan_fwd(const void* q, const void* k, const void* v, const float* alpha, const float* beta,

@@ -75,6 +75,47 @@ def test_module_against_the_independent_restatement(hip):
     assert agree >= 0.97, agree
 
 
+def test_module_with_keys_wider_than_64(hip):
+    """key_dim = 128 (one head; KPFF's LDS tile bounds Cp + Hh (Dk + Dv) at the default's 576): the module's inference path on the general scan kernel (csrc/gdr_general.hip) -- fp32 module and fused
+    bf16 build against oracle/model_plain.plain_forward run at the same widths; the state keeps its [B, Hh, 128, Dv] shape across calls."""
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    from oracle.model_plain import plain_forward
+    torch.manual_seed(31)
+    cfg = GDKVMConfig(heads=1, key_dim=128, value_dim=128)
+    model = GDKVM(cfg).eval()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.8, 1.25)
+    frames = torch.rand(2, 3, 3, 112, 112)
+    sd = {k_: v_.detach().clone() for k_, v_ in model.state_dict().items()}
+    lp, _ = plain_forward(sd, frames, heads=1, key_dim=128, value_dim=128)
+    with torch.no_grad():                               # balance the random-init head so that both classes appear
+        model.decoder.head.bias -= lp.flatten(3).median(-1).values.mean((0, 1)).float()
+    sd = {k_: v_.detach().clone() for k_, v_ in model.state_dict().items()}
+    lp, sp = plain_forward(sd, frames, heads=1, key_dim=128, value_dim=128)
+    model = model.cuda().to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        lg, sg = model(frames.cuda(), return_state=True)
+        la, sa = model(frames[:, :2].cuda(), return_state=True)
+        lb2, sb = model(frames[:, 2:].cuda(), state=sa, return_state=True)
+    assert tuple(sg.shape) == (2, 1, 128, 128)
+    assert (lg.cpu().double() - lp).abs().max() <= 1e-3 and (sg.cpu().double() - sp).abs().max() <= 1e-3
+    # the state carried across calls (fp32 module: the library convolutions of the encoder pick algorithms by batch size)
+    assert (sb - sg).abs().max() <= 1e-4 and (torch.cat([la, lb2], 1) - lg).abs().max() <= 1e-4
+    with torch.no_grad():
+        fused = model.fuse_for_inference().to(torch.bfloat16)
+        fb = frames.cuda().bfloat16()
+        lbd, sbd = fused(fb, return_state=True)
+        l1, s1 = fused(fb[:, :2], return_state=True)
+        l2, s2 = fused(fb[:, 2:], state=s1, return_state=True)
+        lb = lbd.float().cpu().double()
+    assert torch.equal(s2, sbd) and torch.equal(torch.cat([l1, l2], 1), lbd)               # fused build: every kernel deterministic -> the same bits
+    err = (lb - lp).abs()
+    rms = lp.pow(2).mean().sqrt().item()
+    assert err.mean() <= 0.05 * rms and err.max() <= 0.3 * rms, (err.max().item() / rms, err.mean().item() / rms)
+    assert (lb.argmax(2) == lp.argmax(2)).float().mean().item() >= 0.95
+
+
 def test_fused_build_on_maps_wider_than_64_pixels(hip):
     """528x528 frames: the stride-8 map is 66 pixels wide, wider than the chunked 3x3 kernel tiles -- those layers and the strided ones
     take the general implicit-GEMM kernel; 33x33 = 1089 tokens per frame.  The fused bf16 build against the independent restatement."""

@@ -195,7 +195,7 @@ def test_scan_empty_and_degenerate(hip):
 
 
 def test_scan_error_codes(hip):
-    q, k, v, a, b = make_scan_inputs(1, 1, 4, 1, 128, 16)          # (Dk below 64 is served through zero channels; above it is not)
+    q, k, v, a, b = make_scan_inputs(1, 1, 4, 1, 264, 16)          # (Dk below 64 through zero channels, 72 .. 256 on the general kernel; beyond: refused)
     with pytest.raises(hip.GdkvmError, match="Dk"):
         _run(hip, q, k, v, a, b)
     q, k, v, a, b = make_scan_inputs(1, 1, 4, 1, 64, 24)
@@ -282,17 +282,17 @@ def test_scan_frames_of_more_than_256_tokens(hip, N, dtype):
 
 
 def test_scan_rejects_what_the_kernels_are_not_built_for(hip):
-    """The limits that remain fail loudly with a message (never a silent fallback): Dk above 64 or no multiple of 8 at the C ABI, Dv
+    """The limits that remain fail loudly with a message (never a silent fallback): Dk above 256 or no multiple of 8 at the C ABI, Dv
     not a multiple of 16, more than 4096 tokens per frame, unknown flags."""
     from gdkvm_amd import ops
     def call(N=8, Dk=64, Dv=16, flags=0):
         lib = ops.load()
-        z = torch.zeros(1 * 1 * max(N, 1) * 1 * max(Dk, Dv, 64) * 4 + 1024, device="cuda")
+        z = torch.zeros(1 * 1 * max(N, 1) * 1 * max(Dk, Dv, 64) * 4 + 1024, device="cuda")      # (also the [Dk, Dv] state out)
         ws = torch.empty(max(ops.scan_workspace_bytes(1, 1, 1, min(N, 4096), 64, 16), 4096), dtype=torch.uint8, device="cuda")
         return lib.gdkvm_scan_fwd(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), None, z.data_ptr(), z.data_ptr(), None,
                                   ws.data_ptr(), ws.numel(), 1, 1, 1, N, Dk, Dv, 0, 2, flags, None)
     assert call() == 0
-    for kw, msg in [(dict(Dk=36), "Dk=36"), (dict(Dk=128), "Dk=128"), (dict(Dv=24), "Dv=24"), (dict(N=4097), "N=4097"), (dict(flags=64), "flags")]:
+    for kw, msg in [(dict(Dk=36), "Dk=36"), (dict(Dk=264), "Dk=264"), (dict(Dk=132), "Dk=132"), (dict(Dv=24), "Dv=24"), (dict(N=4097), "N=4097"), (dict(flags=64), "flags")]:
         assert call(**kw) == -1 and msg in ops.load().gdkvm_last_error().decode(), kw
 
 
@@ -323,6 +323,42 @@ def test_scan_narrow_keys_at_the_c_abi(hip, case, dtype):
     hist = torch.empty(2, 3, 1, Dk, Dv, device="cuda")
     with pytest.raises(hip.GdkvmError, match="s_hist"):
         hip.scan_fwd(*t, st, flags=3, state_hist=hist)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rule", [0, 1, 2])
+@pytest.mark.parametrize("case", [(128, 49, 32, 2), (72, 7, 16, 1), (256, 70, 48, 1)])
+def test_scan_wide_keys_on_the_general_kernel(hip, case, rule, dtype):
+    """gdkvm_scan_fwd with 64 < Dk <= 256 (multiples of 8): the definitional recurrence on the device (csrc/gdr_general.hip, fp32 FMAs in
+    a fixed order) against the oracle at that width -- every rule, both I/O types, several heads, ragged token counts, a state carried in,
+    gates as logits and in-kernel normalisation; a clip cut into calls is bit-identical to one call; without a read-out only the state
+    comes back; s_hist (training) is refused; gdkvm_scan_status has nothing to report."""
+    from gdkvm_amd import ops
+    Dk, N, Dv, Hh = case
+    B, T = 2, 4
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=Dk + N + rule, normalized=False, logits=True, corr=0.4)
+    s0 = (0.2 * np.random.default_rng(Dk).standard_normal((B, Hh, Dk, Dv))).astype(np.float32)
+    t = [_dev(x, dtype) for x in (q, k, v)] + [_dev(a), _dev(b)]
+    st = _dev(s0)
+    assert ops.scan_workspace_bytes(B, T, Hh, N, Dk, Dv) <= 4096
+    R, S = hip.scan_fwd(*t, st, rule=rule, flags=3, check=True)
+    inp = [O.to_bf16_f32(x) for x in (q, k, v)] if dtype == torch.bfloat16 else [q, k, v]
+    Ro, So = c_oracle.scan(*inp, a, b, s0, rule, 3, math="f64")
+    scale = max(1.0, float(np.abs(So).max()))
+    assert np.abs(S.cpu().numpy() - So).max() <= TOL * scale
+    assert np.all(np.abs(R.float().cpu().numpy() - Ro) <= TOL * scale + (np.abs(Ro) * 2.0 ** -8 if dtype == torch.bfloat16 else 0))
+    # two calls with the state carried == one call, bit for bit
+    Ra, Sa = hip.scan_fwd(*(x[:, :3].contiguous() for x in t), st, rule=rule, flags=3)
+    Rb, Sb = hip.scan_fwd(*(x[:, 3:].contiguous() for x in t), Sa, rule=rule, flags=3)
+    assert torch.equal(torch.cat([Ra, Rb], 1), R) and torch.equal(Sb, S)
+    # no read-out: the state alone; no state in: zeros
+    Rn, Sn = hip.scan_fwd(*t, st, rule=rule, flags=3, readout=False)
+    assert Rn is None and torch.equal(Sn, S)
+    _, S3 = hip.scan_fwd(*t, None, rule=rule, flags=3)
+    _, So3 = c_oracle.scan(*inp, a, b, None, rule, 3, math="f64")
+    assert np.abs(S3.cpu().numpy() - So3).max() <= TOL * max(1.0, float(np.abs(So3).max()))
+    with pytest.raises(hip.GdkvmError, match="s_hist"):
+        hip.scan_fwd(*t, st, rule=rule, flags=3, state_hist=torch.empty(B, T, Hh, Dk, Dv, device="cuda"))
 
 
 @pytest.mark.parametrize("Dk", [32, 16, 48, 20])
