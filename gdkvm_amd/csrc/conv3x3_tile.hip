@@ -559,7 +559,9 @@ int gdkvm_conv3x3_tile_launch(const void* x, const void* x2, int C1, const void*
         variant = 2;
     }
     static const bool half64 = [] { const char* e = getenv("GDKVM_CONV_TILE64"); return !(e && e[0] == '3'); }();   // ("3": A/B switch, the eight-wave form)
-    if (variant == 0 && K % 128 != 0 && half64) {
+    // (a half tile must still hold two rows of the map: on 64-pixel rows it would be ONE row under a three-row band -- at 256x256 inputs the
+    //  192 -> 64 layer took 273 us that way and the forward 1.573 ms against 1.515 ms with the eight-wave form, same box, round 4)
+    if (variant == 0 && K % 128 != 0 && half64 && (H * W <= 16 * 7 || 2 * W <= 16 * 7)) {
         if (gdkvm_conv3x3_tile_launch(x, x2, C1, w, bias, residual, y, N, C, H, W, K, relu, 5, packed, st) == 0) return 0;
         variant = 3;
     }
