@@ -74,6 +74,8 @@ _PROJ_GATES = os.environ.get("GDKVM_PROJ_GATES", "1") != "0"
 # The inference stem reading the NCHW frames itself (round 4: ops.stem_conv_pool_nchw), or (GDKVM_STEM_NCHW=0, the A/B switch) the
 # space-to-depth pass followed by the stem kernel; bit-identical.
 _STEM_NCHW = os.environ.get("GDKVM_STEM_NCHW", "1") != "0"
+# training: key / query / value / gate projections as one stacked product (ops.token_projections); "0" = one product each (A/B switch)
+_TRAIN_PROJ_STACKED = os.environ.get("GDKVM_TRAIN_PROJ_STACKED", "1") != "0"
 
 
 def _bn_act(bn: nn.BatchNorm2d, x: torch.Tensor, relu: bool, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -581,7 +583,7 @@ class GDKVM(nn.Module):
             return F.linear(tok2d, w2, conv.bias)
 
         wk, wq, wv = Hh * Dk, Hh * Dk, Hh * Dv
-        norms = beta = alpha = None
+        norms = beta = alpha = beta_stacked = alpha_stacked = None
         cp8 = tok2d.shape[1] // 8
         infer_bf16 = (tok2d.is_cuda and not train_gpu and not torch.is_grad_enabled() and tok2d.dtype == torch.bfloat16
                       and tok2d.shape[1] % 32 == 0 and tok2d.shape[1] <= 512 and wk % 16 == 0 and wv % 16 == 0)
@@ -613,6 +615,14 @@ class GDKVM(nn.Module):
                 self._qkv_pack = cache
             k2d, q2d, v2d = ops.proj_rows(tok2d, cache[1], cache[2], (wk, wq, wv))
             k_tok, q, v = k2d.reshape(B * T, N, wk), q2d.reshape(B, T, N, Hh, Dk), v2d.reshape(B, T, N, wv)
+        elif train_gpu and tok2d.dtype == torch.bfloat16 and _TRAIN_PROJ_STACKED:
+            # training: the four projections of the feature as ONE stacked product forward and two backward (ops.token_projections)
+            # -- and the decay logit with them: W_d mean_n(x) + b_d = mean_n(W_d x + b_d), so the per-frame decay is the token mean of one
+            # more stacked column (the mean taken in fp32 over bf16 per-token values; the separate path rounded the mean itself to bf16)
+            k2d, q2d, v2d, b2d, a2d = ops.token_projections(tok2d, (self.key_proj, self.query_proj, self.value_proj, self.gate_proj, self.decay_proj))
+            k_tok, q, v = k2d.reshape(B * T, N, wk), q2d.reshape(B, T, N, Hh, Dk), v2d.reshape(B, T, N, wv)
+            beta_stacked = b2d.float().reshape(B, T, N, Hh)
+            alpha_stacked = a2d.float().reshape(B * T, N, Hh).mean(1).reshape(B, T, Hh)
         else:
             k_tok = proj(self.key_proj).reshape(B * T, N, Hh * Dk)               # local key feature
             q = proj(self.query_proj).reshape(B, T, N, Hh, Dk)
@@ -639,8 +649,8 @@ class GDKVM(nn.Module):
             beta, alpha = ops.gate_logits(p_tok, *cache[1])
             beta, alpha = beta.reshape(B, T, N, Hh), alpha.reshape(B, T, Hh)
         else:
-            beta = proj(self.gate_proj).float().reshape(B, T, N, Hh)
-            alpha = self.decay_proj(p_tok.mean(1)).float().reshape(B, T, Hh)
+            beta = beta_stacked if beta_stacked is not None else proj(self.gate_proj).float().reshape(B, T, N, Hh)
+            alpha = alpha_stacked if alpha_stacked is not None else self.decay_proj(p_tok.mean(1)).float().reshape(B, T, Hh)
         if keep_mask_embed:
             # keep every parameter in the graph (DDP: no unused params) -- through the B*T*Hh decay logits, not through v: a zero added to the
             # [B*T*N, Hh*Dv] values was a 29 us pass forward and a reduction over their gradient backward (round 4)

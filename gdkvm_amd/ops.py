@@ -1513,6 +1513,75 @@ def token_linear(x2d: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.T
     return _TokenLinear.apply(x2d, weight, bias)
 
 
+class _TokenProjections(torch.autograd.Function):
+    """Several 1x1 projections of the SAME token rows (key, query, value, write gate) as ONE product against their stacked weights, forward
+    and backward: y_i = x W_i^T + b_i.  As four _TokenLinear calls a training step spent ~55 launches on them -- per projection a weight cast, the
+    product, a transposed weight copy, the data-gradient product, an add into the feature's gradient, the split-K weight gradient and its
+    sum, plus zero-padding of the one-row gate projection both ways; stacked it is: cat + cast of the weights, cat of the biases, one
+    gdkvm_gemm_nt, one copy per output (contiguous rows for the scan kernels) -- and backward one cat of the incoming gradients, one
+    transposed weight copy, one gdkvm_gemm_nt for dX and one gdkvm_gemm_tn_colsum for every dW and db (returned as row slices of its result).
+    The stacked width is padded with zero rows to a multiple of 32 (the MFMA's k step in the dX product)."""
+
+    @staticmethod
+    def forward(ctx, x2d, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        x2d = x2d.contiguous()
+        widths = [int(w.shape[0]) for w in ws]
+        total = sum(widths)
+        padded = (total + 31) // 32 * 32
+        cin = x2d.shape[1]
+        parts = [w.detach().reshape(w.shape[0], cin) for w in ws]
+        if padded > total:
+            parts.append(torch.zeros((padded - total, cin), dtype=parts[0].dtype, device=x2d.device))
+        w_all = torch.cat(parts, 0).to(x2d.dtype)
+        b_parts = [(b.detach().float() if b is not None else torch.zeros(n, dtype=torch.float32, device=x2d.device)) for b, n in zip(bs, widths)]
+        if padded > total:
+            b_parts.append(torch.zeros(padded - total, dtype=torch.float32, device=x2d.device))
+        y = gemm_nt(x2d, w_all, torch.cat(b_parts, 0))
+        ctx.save_for_backward(x2d, w_all)
+        ctx.widths, ctx.padded = widths, padded
+        ctx.meta = [(w.dtype, tuple(w.shape), b is not None, None if b is None else b.dtype) for w, b in zip(ws, bs)]
+        outs, o = [], 0
+        for n in widths:
+            outs.append(y[:, o:o + n].contiguous())
+            o += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        x2d, w_all = ctx.saved_tensors
+        widths, padded = ctx.widths, ctx.padded
+        total = sum(widths)
+        parts = [dy.to(x2d.dtype) if dy is not None else torch.zeros((x2d.shape[0], n), dtype=x2d.dtype, device=x2d.device) for dy, n in zip(dys, widths)]
+        if padded > total:
+            parts.append(torch.zeros((x2d.shape[0], padded - total), dtype=x2d.dtype, device=x2d.device))
+        dy_all = torch.cat(parts, 1)
+        dx = gemm_nt(dy_all, w_all.t().contiguous()) if ctx.needs_input_grad[0] else None
+        grads = [dx]
+        need_w = any(ctx.needs_input_grad[1 + 2 * i] for i in range(len(widths)))
+        need_b = any(ctx.needs_input_grad[2 + 2 * i] and ctx.meta[i][2] for i in range(len(widths)))
+        dw_all = db_all = None
+        if need_w or need_b:
+            dw_all, db_all = wgrad(dy_all, x2d, colsum=True)
+        o = 0
+        for i, n in enumerate(widths):
+            wdt, wshape, has_b, bdt = ctx.meta[i]
+            dw = dw_all[o:o + n].reshape(wshape).to(wdt) if ctx.needs_input_grad[1 + 2 * i] else None
+            db = db_all[o:o + n].to(bdt) if (has_b and ctx.needs_input_grad[2 + 2 * i]) else None
+            grads += [dw, db]
+            o += n
+        return tuple(grads)
+
+
+def token_projections(x2d: torch.Tensor, layers) -> Tuple[torch.Tensor, ...]:
+    """[conv(x) for conv in layers] for 1x1 convolutions (or Linear layers) applied to token rows x2d [rows, Cin]: one stacked product
+    forward, two backward (_TokenProjections).  Each result is a contiguous [rows, out_channels] tensor in x2d's dtype."""
+    args = []
+    for m in layers:
+        args += [m.weight, m.bias]
+    return _TokenProjections.apply(x2d, *args)
+
+
 class _SegLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, target, H, W, dice_weight, eps):

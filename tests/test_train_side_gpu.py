@@ -191,6 +191,44 @@ def test_token_linear_and_split_k_weight_gradient(hip, dtype):
     assert torch.equal(db2, hip.wgrad(dy[:1001], x[:1001], colsum=True)[1])
 
 
+def test_stacked_token_projections(hip):
+    """ops.token_projections (key / query / value / gate as ONE stacked product forward, two backward) against the four separate
+    ops.token_linear calls it replaces: the same outputs bit for bit (the same kernel on the same rows of the stacked weight), gradients
+    equal up to the fp32 summation order of the data gradient (one product over the stacked width instead of four added up)."""
+    torch.manual_seed(9)
+    rows, cin = 2 * 3 * 49, 256
+    x = torch.randn(rows, cin, device="cuda").bfloat16()
+    convs = [torch.nn.Conv2d(cin, n, 1).cuda() for n in (64, 64, 256, 1)]
+    gys = [torch.randn(rows, n, device="cuda").bfloat16() for n in (64, 64, 256, 1)]
+
+    def run(stacked):
+        xg = x.clone().requires_grad_(True)
+        for c in convs:
+            c.zero_grad(set_to_none=True)
+        if stacked:
+            ys = hip.token_projections(xg, convs)
+        else:
+            ys = []
+            for c in convs:
+                w2 = c.weight.reshape(c.out_channels, -1)
+                if c.out_channels >= 8:
+                    ys.append(hip.token_linear(xg, w2, c.bias))
+                else:
+                    pad = 16 - c.out_channels
+                    ys.append(hip.token_linear(xg, F.pad(w2, (0, 0, 0, pad)), F.pad(c.bias, (0, pad)))[:, :c.out_channels])
+        torch.autograd.backward(ys, gys)
+        return [y.detach() for y in ys], xg.grad, [c.weight.grad.clone() for c in convs], [c.bias.grad.clone() for c in convs]
+
+    ya, dxa, dwa, dba = run(False)
+    yb, dxb, dwb, dbb = run(True)
+    for a, b in zip(ya, yb):
+        assert b.is_contiguous() and torch.equal(a, b)
+    assert (dxa.float() - dxb.float()).abs().max() <= 2.0 ** -6 * dxa.float().abs().max()
+    for a, b in zip(dwa + dba, dwb + dbb):
+        assert a.shape == b.shape and b.dtype == torch.float32
+        assert (a - b).abs().max() <= 1e-5 * max(1.0, a.abs().max().item())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(25088, 576, 512), (1001, 64, 256), (130, 40, 32), (1, 8, 64), (4097, 256, 256)])
 def test_hand_written_products_of_the_training_backward(hip, dtype, shape):
