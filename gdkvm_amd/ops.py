@@ -606,13 +606,16 @@ class _KpffFunction(torch.autograd.Function):
         L2, P2 = local.reshape(M, Ck), pixel.reshape(M, Cp)
         # the six products of the backward on the hand-written kernels (csrc/gemm.hip): dX-type ones as gdkvm_gemm_nt against
         # the weight with its input index leading (a one-off transpose of a small matrix), dW-type ones as gdkvm_gemm_tn
-        dx = gemm_nt(dz, wa.to(dt).t().contiguous())     # [M, Cin]
-        dl_add = gemm_nt(dlp, wl.to(dt).t().contiguous())   # [M, Ck]
-        dg_add = gemm_nt(dgp, wg.to(dt).t().contiguous())   # [M, Cv]
-        d_wa = torch.cat([wgrad(dz, P2), wgrad(dz, L2), wgrad(dz, gms)], 1)       # K = B*T*N tokens: split over workgroups, fp32 partials
+        def t_of(wt):                                       # cast and transpose in ONE copy kernel
+            return torch.empty((wt.shape[1], wt.shape[0]), dtype=dt, device=dev).copy_(wt.t())
+        dx = gemm_nt(dz, t_of(wa))                          # [M, Cin]
+        dl_add = gemm_nt(dlp, t_of(wl))                     # [M, Ck]
+        dg_add = gemm_nt(dgp, t_of(wg))                     # [M, Cv]
+        # K = B*T*N tokens: split over workgroups, fp32 partials; the bias gradient (column sums of dz) rides on the first product's launch
+        d_wa_p, d_ba = wgrad(dz, P2, colsum=True)
+        d_wa = torch.cat([d_wa_p, wgrad(dz, L2), wgrad(dz, gms)], 1)
         d_wl = wgrad(dlp, L2)
         d_wg = wgrad(dgp, gms)
-        d_ba = dz.sum(0, dtype=torch.float32)               # (fp32 accumulation straight from the bf16 rows: no fp32 copy of dz)
         d_p, d_l, d_g = torch.empty_like(pixel), torch.empty_like(local), torch.empty((BT, N, Cv), dtype=dt, device=dev)
         with torch.cuda.device(dev):
             _check(lib.gdkvm_kpff_bwd_post(_ptr(d_f), _ptr(dx), _ptr(dl_add), _ptr(dg_add), _ptr(d_p), _ptr(d_l), _ptr(d_g),
