@@ -205,14 +205,112 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint4* __restrict__
     for (; v < w.vend; v += w.step) finish(v, x[v], RES ? res[v] : uint4{0, 0, 0, 0});
 }
 
+// ------------------------------------------------------------------------------------- stem: BatchNorm + ReLU + max-pool as one
+// Round 4.  The training stem is conv -> BatchNorm(train) -> ReLU -> 3x3 / stride 2 / pad 1 max-pool on a 205 MB activation (cfg4); as
+// bn_apply + gdkvm_maxpool_fwd the normalised tensor was written and read back, and backward the pre-pool gradient (205 MB) was written by
+// gdkvm_maxpool_bwd and read twice by the BatchNorm backward.  Fused, the normalised activation and its gradient never exist:
+//   forward   bn_stats -> bn_finalize -> bn_pool_fwd: every pooled element evaluates relu(x*scale + shift) of its 3x3 window itself,
+//             rounded to the I/O type exactly as bn_apply would have stored it (same maxima, same winning taps as the two-kernel form);
+//   backward  the gradient of a pre-pool element is GATHERED from its (at most 2 x 2) windows' gradients and winning taps
+//             (maxpool_bwd_kernel's rule, rounded to the I/O type like its output) inside bn_bwd_reduce and bn_bwd_dx (POOLED = true).
+struct PoolGeo { const uint4* dyp; const unsigned char* idx; int H, W, Ho, Wo; float inv_w, inv_hw; };
+
+// the pre-pool gradient of vector v (= pixel m * G + channel group cg) in the bf16 layout, as maxpool_bwd_kernel<bf16> writes it
+__device__ __forceinline__ uint4 pool_gather(const PoolGeo& q, size_t v, int G, int cg)
+{
+    const int m = (int)(v / G);                              // (M < 2^22: the float reciprocals below are exact)
+    const int n = (int)(((float)m + 0.5f) * q.inv_hw), r = m - n * q.H * q.W;
+    const int ih = (int)(((float)r + 0.5f) * q.inv_w), iw = r - ih * q.W;
+    const int oh0 = ih >> 1, ow0 = iw >> 1;
+    uint4 g[4];
+    uint2 bt[4];
+    int tap[4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int oh = oh0 + a, ow = ow0 + b;
+            const bool ok = (a == 0 || ((ih & 1) && oh < q.Ho)) && (b == 0 || ((iw & 1) && ow < q.Wo)) && oh < q.Ho && ow < q.Wo;
+            const size_t o = (((size_t)n * q.Ho + (ok ? oh : oh0 < q.Ho ? oh0 : q.Ho - 1)) * q.Wo + (ok ? ow : ow0 < q.Wo ? ow0 : q.Wo - 1)) * G + cg;
+            g[2 * a + b] = q.dyp[o];
+            bt[2 * a + b] = *reinterpret_cast<const uint2*>(q.idx + o * 8);
+            tap[2 * a + b] = ok ? 3 * (ih - (2 * oh - 1)) + (iw - (2 * ow - 1)) : 255;
+        }
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned w4[4] = {g[k].x, g[k].y, g[k].z, g[k].w};
+        const unsigned tb[2] = {bt[k].x, bt[k].y};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned wt = (tb[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            const float d = (j & 1) ? __uint_as_float(w4[j >> 1] & 0xffff0000u) : __uint_as_float(w4[j >> 1] << 16);
+            acc[j] += (int)wt == tap[k] ? d : 0.f;
+        }
+    }
+    return pack<GDKVM_BF16>(acc);
+}
+
+// pooled y and winning taps from the raw convolution x [N, H, W, C] (bf16): item = (pooled pixel, 8-channel group)
+__global__ __launch_bounds__(256) void bn_pool_fwd_kernel(const uint4* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          uint4* __restrict__ y, unsigned char* __restrict__ idx, int N, int H, int W, int C, int Ho, int Wo)
+{
+    const int G = C / 8;
+    const size_t total = (size_t)N * Ho * Wo * G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cg = (int)(i % G);
+        size_t p = i / G;
+        const int ow = (int)(p % Wo); p /= Wo;
+        const int oh = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float sc[8], sh[8];
+        load_param<8>(scale, cg * 8, sc); load_param<8>(shift, cg * 8, sh);
+        uint4 win[9];
+        bool ok[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ih = 2 * oh - 1 + dy, iw = 2 * ow - 1 + dx;
+                ok[3 * dy + dx] = ih >= 0 && ih < H && iw >= 0 && iw < W;
+                const int hh = ok[3 * dy + dx] ? ih : 2 * oh, ww = ok[3 * dy + dx] ? iw : 2 * ow;
+                win[3 * dy + dx] = x[(((size_t)n * H + hh) * W + ww) * G + cg];
+            }
+        float m[8];
+        unsigned char best[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; best[j] = 4; }
+        bool first = true;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (!ok[t]) continue;
+            float f[8];
+            unpack<GDKVM_BF16>(win[t], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = bf16_to_f32(f32_to_bf16(fmaxf(fmaf(f[j], sc[j], sh[j]), 0.f)));      // what bn_apply would have stored
+                if (first || a > m[j] || a != a) { m[j] = a; best[j] = (unsigned char)t; }
+            }
+            first = false;
+        }
+        y[i] = pack<GDKVM_BF16>(m);
+        uint2 b;
+        b.x = best[0] | (best[1] << 8) | (best[2] << 16) | ((unsigned)best[3] << 24);
+        b.y = best[4] | (best[5] << 8) | (best[6] << 16) | ((unsigned)best[7] << 24);
+        *reinterpret_cast<uint2*>(idx + i * 8) = b;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------ backward
 // g = dy masked by the ReLU;  S1 = sum g,  S2 = sum g (x - mean)  per channel.
 // MASK: 0 = no ReLU, 1 = from the saved output (y > 0), 2 = recomputed from x with the forward's own fma (x*scale + shift > 0:
 // the same expression bn_apply_kernel evaluated, so the same mask) -- the y tensor is then not read at all (no residual case).
-template <int IO, int MASK>
+template <int IO, int MASK, bool POOLED = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restrict__ x, const uint4* __restrict__ y,
                                                             const uint4* __restrict__ dy, const float* __restrict__ stats,
-                                                            float* __restrict__ part, int M, int C, int G, int rows_per_block)
+                                                            float* __restrict__ part, int M, int C, int G, int rows_per_block, PoolGeo pg = PoolGeo{})
 {
     constexpr int V = VecOf<IO>::V, UNR = 4;
     constexpr bool RELU = MASK == 1;
@@ -240,13 +338,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const uint4* __restr
 #pragma unroll
             for (int u = 0; u < UNR; ++u) xa[u] = x[v + u * w.step];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) da[u] = dy[v + u * w.step];
+            for (int u = 0; u < UNR; ++u) {
+                if constexpr (POOLED) da[u] = pool_gather(pg, v + u * w.step, G, w.cg);
+                else da[u] = dy[v + u * w.step];
+            }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) ya[u] = RELU ? y[v + u * w.step] : uint4{0, 0, 0, 0};
 #pragma unroll
             for (int u = 0; u < UNR; ++u) eat(xa[u], ya[u], da[u]);
         }
-        for (; v < w.vend; v += w.step) eat(x[v], RELU ? y[v] : uint4{0, 0, 0, 0}, dy[v]);
+        for (; v < w.vend; v += w.step) {
+            uint4 dd;
+            if constexpr (POOLED) dd = pool_gather(pg, v, G, w.cg); else dd = dy[v];
+            eat(x[v], RELU ? y[v] : uint4{0, 0, 0, 0}, dd);
+        }
     }
     block_reduce_store<V>(s1, s2, part, C, G);
 }
@@ -266,11 +371,11 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     }
 }
 
-template <int IO, int MASK, bool DRES>
+template <int IO, int MASK, bool DRES, bool POOLED = false>
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const uint4* __restrict__ x, const uint4* __restrict__ y,
                                                         const uint4* __restrict__ dy, const float* __restrict__ stats,
                                                         const float* __restrict__ coef, uint4* __restrict__ dx,
-                                                        uint4* __restrict__ dres, int M, int C, int G, int rows_per_block)
+                                                        uint4* __restrict__ dres, int M, int C, int G, int rows_per_block, PoolGeo pg = PoolGeo{})
 {
     constexpr int V = VecOf<IO>::V, UNR = 4;
     constexpr bool RELU = MASK == 1;
@@ -300,13 +405,20 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const uint4* __restrict_
 #pragma unroll
         for (int u = 0; u < UNR; ++u) xa[u] = x[v + u * w.step];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) da[u] = dy[v + u * w.step];
+        for (int u = 0; u < UNR; ++u) {
+            if constexpr (POOLED) da[u] = pool_gather(pg, v + u * w.step, G, w.cg);
+            else da[u] = dy[v + u * w.step];
+        }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) ya[u] = RELU ? y[v + u * w.step] : uint4{0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < UNR; ++u) finish(v + u * w.step, xa[u], ya[u], da[u]);
     }
-    for (; v < w.vend; v += w.step) finish(v, x[v], RELU ? y[v] : uint4{0, 0, 0, 0}, dy[v]);
+    for (; v < w.vend; v += w.step) {
+        uint4 dd;
+        if constexpr (POOLED) dd = pool_gather(pg, v, G, w.cg); else dd = dy[v];
+        finish(v, x[v], RELU ? y[v] : uint4{0, 0, 0, 0}, dd);
+    }
 }
 
 struct BnPlan {
@@ -432,6 +544,72 @@ extern "C" int gdkvm_bn_bwd(const void* x, const void* y, const void* dy, const 
     if (io_dtype == GDKVM_F32) GDKVM_BN_DX_IO(GDKVM_F32); else GDKVM_BN_DX_IO(GDKVM_BF16);
 #undef GDKVM_BN_DX_IO
 #undef GDKVM_BN_DX
+    GDKVM_LAUNCH_CHECK("bn_bwd_dx_kernel");
+    return GDKVM_OK;
+}
+
+
+// ---- the training stem's BatchNorm + ReLU + 3x3 / stride 2 / pad 1 max-pool as one (bf16, NHWC): see the comment at PoolGeo ----------------
+static int bn_pool_check(const char* who, int N, int H, int W, int C, int io)
+{
+    if (io != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "%s: only bf16 is implemented", who);
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || C / 8 > 256 || (long long)N * H * W >= (1ll << 22))
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: N=%d H=%d W=%d C=%d (C a multiple of 8 up to 2048, fewer than 2^22 pixels)", who, N, H, W, C);
+    return GDKVM_OK;
+}
+
+extern "C" int gdkvm_bn_pool_fwd_train(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                       void* y_pool, void* idx, float* save_stats, void* ws, size_t ws_bytes,
+                                       int N, int H, int W, int C, float eps, float momentum, int io_dtype, void* stream)
+{
+    if (int rc = bn_pool_check("bn_pool_fwd_train", N, H, W, C, io_dtype)) return rc;
+    if (!x || !gamma || !beta || !y_pool || !idx || !save_stats || !ws) return gdkvm_fail(GDKVM_ERR_ARG, "bn_pool_fwd_train: null pointer");
+    if (!gdkvm_aligned16(x) || !gdkvm_aligned16(y_pool) || !gdkvm_aligned16(idx) || !gdkvm_aligned16(ws) || !gdkvm_aligned16(save_stats))
+        return gdkvm_fail(GDKVM_ERR_ARG, "bn_pool_fwd_train: pointers must be 16-byte aligned");
+    if (ws_bytes < gdkvm_bn_workspace_bytes(C)) return gdkvm_fail(GDKVM_ERR_ARG, "bn_pool_fwd_train: workspace too small");
+    if (int rc = gdkvm_check_device()) return rc;
+    const int M = N * H * W, Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const BnPlan p = bn_plan(M, C, 8, 8);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(ws);
+    const uint4* xv = static_cast<const uint4*>(x);
+    hipLaunchKernelGGL((bn_stats_kernel<GDKVM_BF16>), dim3(p.nred), dim3(256), 0, st, xv, part, M, C, p.G, p.rpb_red);
+    GDKVM_LAUNCH_CHECK("bn_stats_kernel");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, p.nred, x, io_dtype, gamma, beta,
+                       running_mean, running_var, save_stats, M, C, eps, momentum);
+    GDKVM_LAUNCH_CHECK("bn_finalize_kernel");
+    const size_t items = (size_t)N * Ho * Wo * (C / 8);
+    const size_t blocks = (items + 255) / 256;
+    hipLaunchKernelGGL(bn_pool_fwd_kernel, dim3((unsigned)(blocks > 65536 ? 65536 : blocks)), dim3(256), 0, st, xv, save_stats + 2 * (size_t)C,
+                       save_stats + 3 * (size_t)C, static_cast<uint4*>(y_pool), static_cast<unsigned char*>(idx), N, H, W, C, Ho, Wo);
+    GDKVM_LAUNCH_CHECK("bn_pool_fwd_kernel");
+    return GDKVM_OK;
+}
+
+extern "C" int gdkvm_bn_pool_bwd(const void* x, const void* dy_pool, const void* idx, const float* gamma, const float* save_stats,
+                                 void* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                                 int N, int H, int W, int C, int io_dtype, void* stream)
+{
+    if (int rc = bn_pool_check("bn_pool_bwd", N, H, W, C, io_dtype)) return rc;
+    if (!x || !dy_pool || !idx || !gamma || !save_stats || !dx || !dgamma || !dbeta || !ws) return gdkvm_fail(GDKVM_ERR_ARG, "bn_pool_bwd: null pointer");
+    if (!gdkvm_aligned16(x) || !gdkvm_aligned16(dy_pool) || !gdkvm_aligned16(idx) || !gdkvm_aligned16(dx) || !gdkvm_aligned16(ws) || !gdkvm_aligned16(save_stats))
+        return gdkvm_fail(GDKVM_ERR_ARG, "bn_pool_bwd: pointers must be 16-byte aligned");
+    if (ws_bytes < gdkvm_bn_workspace_bytes(C)) return gdkvm_fail(GDKVM_ERR_ARG, "bn_pool_bwd: workspace too small");
+    if (int rc = gdkvm_check_device()) return rc;
+    const int M = N * H * W;
+    const BnPlan p = bn_plan(M, C, 8, 4);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* part = static_cast<float*>(ws);
+    float* coef = part + (size_t)BN_MAX_PART * 2 * C;
+    PoolGeo pg{static_cast<const uint4*>(dy_pool), static_cast<const unsigned char*>(idx), H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1,
+               1.0f / (float)W, 1.0f / (float)(H * W)};
+    const uint4* xv = static_cast<const uint4*>(x);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<GDKVM_BF16, 2, true>), dim3(p.nred), dim3(256), 0, st, xv, nullptr, nullptr, save_stats, part, M, C, p.G, p.rpb_red, pg);
+    GDKVM_LAUNCH_CHECK("bn_bwd_reduce_kernel");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, p.nred, gamma, save_stats, dgamma, dbeta, coef, M, C);
+    GDKVM_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+    hipLaunchKernelGGL((bn_bwd_dx_kernel<GDKVM_BF16, 2, false, true>), dim3(p.nmap), dim3(256), 0, st, xv, nullptr, nullptr, save_stats, coef,
+                       static_cast<uint4*>(dx), nullptr, M, C, p.G, p.rpb_map, pg);
     GDKVM_LAUNCH_CHECK("bn_bwd_dx_kernel");
     return GDKVM_OK;
 }

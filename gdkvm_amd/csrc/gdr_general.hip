@@ -1,7 +1,7 @@
 // gdr_general.hip -- gdkvm_scan_fwd for per-head key widths ABOVE the 64 the fast kernels are built for (72 .. 256 in multiples of 8;
 // SURVEY.md §8 rows a1-a3, a5; the reference's real key width is unknown -- SURVEY A.7 -- and round 3's ABI returned GDKVM_ERR_SHAPE here).
 //
-// This is the DEFINITION of the recurrence (oracle/gdkvm_oracle.py::scan, form "sequential") on the device, not the affine-map form of
+// This is the DEFINITION of the recurrence (read, then the token loop of the write) on the device, not the affine-map form of
 // gdr_prep.hip / gdr_scan.hip: one workgroup per (clip, head, 16-column slice of the state) keeps its [Dk][16] fp32 slice in LDS and walks
 // the frames; per frame it reads every token against the state BEFORE the frame's write (R_t = Qn S), decays the state, then applies the
 // frame's tokens in raster order -- rule 0: S += b k v^T; rule 2: e = v - S^T k against the state as updated so far, S += b k e^T; rule 1:

@@ -74,6 +74,8 @@ _PROJ_GATES = os.environ.get("GDKVM_PROJ_GATES", "1") != "0"
 # The inference stem reading the NCHW frames itself (round 4: ops.stem_conv_pool_nchw), or (GDKVM_STEM_NCHW=0, the A/B switch) the
 # space-to-depth pass followed by the stem kernel; bit-identical.
 _STEM_NCHW = os.environ.get("GDKVM_STEM_NCHW", "1") != "0"
+# training stem: BatchNorm + ReLU + max-pool as one op in both directions (ops.bn_relu_pool); "0" = bn_act then maxpool3x3s2 (A/B switch)
+_STEM_BN_POOL = os.environ.get("GDKVM_STEM_BN_POOL", "1") != "0"
 # training: key / query / value / gate projections as one stacked product (ops.token_projections); "0" = one product each (A/B switch)
 _TRAIN_PROJ_STACKED = os.environ.get("GDKVM_TRAIN_PROJ_STACKED", "1") != "0"
 
@@ -151,10 +153,25 @@ class Encoder(nn.Module):
         s = self.stem
         if len(s) == 4 and isinstance(s[1], nn.BatchNorm2d):                  # training build: conv, fused BN + ReLU, pool
             if torch.is_grad_enabled() and isinstance(s[0], nn.Conv2d) and ops.stem_conv_served(x, s[0]):
-                x = _bn_act(s[1], ops.stem_conv(x, s[0].weight), True)     # the hand-written stem kernel, convolution only (csrc/stem_conv_pool.hip)
+                x = ops.stem_conv(x, s[0].weight)         # the hand-written stem kernel, convolution only (csrc/stem_conv_pool.hip)
             else:
-                x = _bn_act(s[1], s[0](x), True)
-            p = s[3]
+                x = s[0](x)
+            p, bn = s[3], s[1]
+            pool_ok = isinstance(p, nn.MaxPool2d) and (p.kernel_size, p.stride, p.padding, p.dilation, p.ceil_mode) == (3, 2, 1, 1, False)
+            if (_STEM_BN_POOL and pool_ok and bn.training and bn.affine and bn.weight.dtype == torch.float32 and ops.bn_relu_pool_served(x)):
+                # BatchNorm + ReLU + max-pool as one op both ways: the full-resolution activation and its gradient are never written
+                momentum = bn.momentum
+                if bn.track_running_stats:
+                    if not _BN_COUNTED_BY_MODEL[0]:
+                        bn.num_batches_tracked.add_(1)
+                    if momentum is None:
+                        momentum = 1.0 / float(bn.num_batches_tracked)
+                x = ops.bn_relu_pool(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                                     bn.running_var if bn.track_running_stats else None, momentum or 0.0, bn.eps)
+                f4 = self.layer1(x)
+                f8 = self.layer2(f4)
+                return f4, f8, self.layer3(f8)
+            x = _bn_act(bn, x, True)
             if (x.is_cuda and isinstance(p, nn.MaxPool2d) and (p.kernel_size, p.stride, p.padding, p.dilation, p.ceil_mode) == (3, 2, 1, 1, False)
                     and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0 and x.dtype in (torch.bfloat16, torch.float32)):
                 x = ops.maxpool3x3s2(x)                   # HIP pool + gather backward

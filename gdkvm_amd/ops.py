@@ -98,6 +98,8 @@ SIGNATURES = {
     "gdkvm_bn_workspace_bytes": (_sz, [_i]),
     "gdkvm_bn_fwd_train": (_i, [_vp] * 9 + [_sz, ctypes.c_longlong, _i, ctypes.c_float, ctypes.c_float, _i, _i, _vp]),
     "gdkvm_bn_bwd": (_i, [_vp] * 10 + [_sz, ctypes.c_longlong, _i, _i, _i, _vp]),
+    "gdkvm_bn_pool_fwd_train": (_i, [_vp] * 9 + [_sz] + [_i] * 4 + [ctypes.c_float] * 2 + [_i, _vp]),
+    "gdkvm_bn_pool_bwd": (_i, [_vp] * 9 + [_sz] + [_i] * 5 + [_vp]),
 }
 
 
@@ -1393,6 +1395,60 @@ def bn_act(x, weight, bias, running_mean=None, running_var=None, residual=None, 
            relu: bool = True):
     """Differentiable fused BatchNorm(batch statistics) (+ residual) (+ ReLU); see bn_act_fwd."""
     return _BNActFunction.apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, relu)
+
+
+class _BNReluPoolFunction(torch.autograd.Function):
+    """maxpool3x3s2(relu(BatchNorm_train(x))) as one op in both directions (gdkvm_bn_pool_fwd_train / gdkvm_bn_pool_bwd): the training
+    stem's tail without the full-resolution activation or its gradient ever being written.  Same bits as bn_act + maxpool3x3s2."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        lib = load()
+        x = _nhwc(x, "bn_relu_pool")
+        n, c, hh, ww = x.shape
+        ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+        for t in (weight, bias, running_mean, running_var):
+            if t is not None and (t.dtype != torch.float32 or t.numel() != c or not t.is_contiguous()):
+                raise GdkvmError("bn_relu_pool: weight / bias / running statistics must be contiguous float32 [C]")
+        y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device)
+        stats = torch.empty((4, c), dtype=torch.float32, device=x.device)
+        ws = torch.empty(int(lib.gdkvm_bn_workspace_bytes(c)), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.gdkvm_bn_pool_fwd_train(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(running_mean), _ptr(running_var),
+                                             y.data_ptr(), idx.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws.numel(), n, hh, ww, c,
+                                             float(eps), float(momentum), _io_dtype(x), _stream(x.device))
+        _check(rc, "gdkvm_bn_pool_fwd_train")
+        ctx.save_for_backward(x, idx, weight, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = load()
+        x, idx, weight, stats = ctx.saved_tensors
+        n, c, hh, ww = x.shape
+        dy = _nhwc(dy, "bn_relu_pool backward")
+        if dy.dtype != x.dtype:
+            dy = dy.to(x.dtype)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty_like(dgamma)
+        ws = torch.empty(int(lib.gdkvm_bn_workspace_bytes(c)), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = lib.gdkvm_bn_pool_bwd(x.data_ptr(), dy.data_ptr(), idx.data_ptr(), weight.data_ptr(), stats.data_ptr(), dx.data_ptr(),
+                                       dgamma.data_ptr(), dbeta.data_ptr(), ws.data_ptr(), ws.numel(), n, hh, ww, c, _io_dtype(x), _stream(x.device))
+        _check(rc, "gdkvm_bn_pool_bwd")
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def bn_relu_pool_served(x: torch.Tensor) -> bool:
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and x.shape[1] // 8 <= 256
+            and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 22))
+
+
+def bn_relu_pool(x, weight, bias, running_mean=None, running_var=None, momentum: float = 0.1, eps: float = 1e-5):
+    """maxpool3x3s2(bn_act(x, ..., relu=True)) as one differentiable op (the training stem's tail); bf16 channels_last."""
+    return _BNReluPoolFunction.apply(x, weight, bias, running_mean, running_var, momentum, eps)
 
 
 class _MaxPoolFunction(torch.autograd.Function):

@@ -454,6 +454,18 @@ int gdkvm_bn_fwd_train(const void* x, const void* residual, const float* gamma, 
 int gdkvm_bn_bwd(const void* x, const void* y, const void* dy, const float* gamma, const float* save_stats,
                  void* dx, void* dres, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
                  long long rows, int C, int relu, int io_dtype, void* stream);
+/* The training stem's tail as ONE op: BatchNorm(batch statistics) -> ReLU -> 3x3 / stride 2 / pad 1 max-pool of the raw convolution
+ * x [N, H, W, C] (bf16, NHWC): y_pool [N, Ho, Wo, C] (Ho = (H-1)/2+1) and the winning taps idx (one byte per element, gdkvm_maxpool_fwd's
+ * format and tie rule) -- the normalised full-resolution activation is never written (every pooled element evaluates its window's
+ * relu(x*scale + shift), rounded as gdkvm_bn_fwd_train would have stored it: the same bits as the two ops in sequence).  Backward:
+ * dx, dgamma, dbeta from dy_pool, idx and x -- the pre-pool gradient is gathered inside the two BatchNorm backward passes
+ * (gdkvm_maxpool_bwd's rule and rounding) and never written either.  Fewer than 2^22 pixels per call; bf16 only; deterministic. */
+int gdkvm_bn_pool_fwd_train(const void* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            void* y_pool, void* idx, float* save_stats, void* ws, size_t ws_bytes,
+                            int N, int H, int W, int C, float eps, float momentum, int io_dtype, void* stream);
+int gdkvm_bn_pool_bwd(const void* x, const void* dy_pool, const void* idx, const float* gamma, const float* save_stats,
+                      void* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                      int N, int H, int W, int C, int io_dtype, void* stream);
 
 /* decoder glue, out = concat(bilinear_upsample(lo -> H x W), skip) over
  * NHWC tensors  lo [N,hl,wl,C1], skip [N,H,W,C2], out [N,H,W,C1+C2]; align_corners = false; bf16 only.  skip == NULL with

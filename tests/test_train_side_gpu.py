@@ -157,6 +157,33 @@ def test_maxpool_forward_and_gather_backward(hip, dtype, shape):
     assert (xa.grad.float() - xb.grad).abs().max() <= (2.0 ** -7 if dtype == torch.bfloat16 else 1e-6) * max(1.0, xb.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("shape", [(4, 64, 56, 56), (3, 16, 9, 11), (2, 8, 1, 1), (2, 24, 4, 7), (5, 64, 13, 30)])
+def test_batchnorm_relu_maxpool_as_one_op(hip, shape):
+    """ops.bn_relu_pool (gdkvm_bn_pool_fwd_train / gdkvm_bn_pool_bwd: the training stem's tail without the full-resolution activation or
+    its gradient) == ops.maxpool3x3s2(ops.bn_act(x, relu=True)) bit for bit -- pooled values, running statistics, dx, dgamma, dbeta --
+    on inputs with many ties (coarse values) and odd sizes."""
+    torch.manual_seed(sum(shape))
+    n, c, hh, ww = shape
+    cl = dict(memory_format=torch.channels_last)
+    x = (torch.randn(shape, device="cuda") * 4).round().div(4).bfloat16().contiguous(**cl)            # coarse values: ties in the windows
+    g, b = torch.rand(c, device="cuda") + 0.5, torch.randn(c, device="cuda") * 0.2
+    dy = torch.randn(n, c, (hh - 1) // 2 + 1, (ww - 1) // 2 + 1, device="cuda").bfloat16().contiguous(**cl)
+
+    def run(fused):
+        xa, ga, ba = x.clone(**cl).requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+        if fused:
+            y = hip.bn_relu_pool(xa, ga, ba, rm, rv, 0.1, 1e-5)
+        else:
+            y = hip.maxpool3x3s2(hip.bn_act(xa, ga, ba, rm, rv, None, 0.1, 1e-5, True))
+        y.backward(dy)
+        return y.detach(), xa.grad, ga.grad, ba.grad, rm, rv
+
+    for a_, b_ in zip(run(False), run(True)):
+        assert a_.shape == b_.shape and torch.equal(a_, b_)
+    assert hip.bn_relu_pool_served(x) and not hip.bn_relu_pool_served(x.float())
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_token_linear_and_split_k_weight_gradient(hip, dtype):
     torch.manual_seed(5)
