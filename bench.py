@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # (The inference forward has no library convolution left -- profiles/r02_p_bench_cfg2_steady_state.csv -- so MIOpen's solver
-# search, torch.backends.cudnn.benchmark, is switched on only by the training leg, whose strided / 1x1 / stem layers are MIOpen.)
+# search, torch.backends.cudnn.benchmark, is switched on only by the training leg, whose strided / 1x1 layers are MIOpen.)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_MEASURED_GBS = 6290.0      # same table: what a float4 copy reaches; quoted beside the spec fraction as frac_measured_peak
@@ -169,7 +169,7 @@ def run_train(args, world, rank, dev, steps, warmup):
     import torch.distributed as dist
     from gdkvm_amd.model import GDKVM, GDKVMConfig
     from gdkvm_amd.train import train_step, wrap_ddp
-    # the strided / 1x1 / stem layers of the TRAINING build are MIOpen in both directions: with fixed shapes let it search its
+    # the strided / 1x1 layers of the TRAINING build are MIOpen in both directions: with fixed shapes let it search its
     # solvers once (find mode) instead of taking the immediate-mode pick; the search runs in the untimed set-up step
     torch.backends.cudnn.benchmark = True
     cfg = GDKVMConfig()

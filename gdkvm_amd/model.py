@@ -9,7 +9,8 @@ query_proj.* / value_proj.* / gate_proj.* / kpff.* / decoder.*`` and one ``_KEY_
 The memory path between encoder and decoder -- LKVA read, GDR write, KPFF -- is ``ops.scan_fwd`` / ``ops.kpff_fwd``
 (hand-written HIP behind include/gdkvm.h).  The CNN either side of it is hand-written too in the
 inference build (``fuse_for_inference()``: every convolution runs on csrc/conv3x3_*.hip, conv_igemm.hip, stem_conv_pool.hip
-with its epilogue inside); the training build keeps torch / MIOpen for the strided, 1x1 and stem layers only.  There is no
+with its epilogue inside); the training build keeps torch / MIOpen for the strided 3x3 and the 1x1 layers only (the stem's convolution and weight gradient are
+hand-written since round 4).  There is no
 eager fallback for the memory path: on a CPU tensor or without libgdkvm_hip.so the forward raises.
 """
 from __future__ import annotations
