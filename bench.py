@@ -193,12 +193,16 @@ def run_train(args, world, rank, dev, steps, warmup):
 
     first = train_step(ddp, opt, frames, target, torch.bfloat16)     # set-up: MIOpen's solver search (find mode), not a step
     loss = first
+    step = lambda: train_step(ddp, opt, frames, target, torch.bfloat16)
     if graphed:
         from gdkvm_amd.train import GraphedTrainStep
-        gstep = GraphedTrainStep(ddp, opt, frames, target, torch.bfloat16, warmup=3)      # (three more eager steps, then the capture)
-        step = lambda: gstep(frames, target)
-    else:
-        step = lambda: train_step(ddp, opt, frames, target, torch.bfloat16)
+        try:
+            gstep = GraphedTrainStep(ddp, opt, frames, target, torch.bfloat16, warmup=3)      # (three more eager steps, then the capture)
+            step = lambda: gstep(frames, target)
+        except Exception as e:                              # a capture that fails is reported and the eager step is timed instead
+            print(f"[bench] training step not captured ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            graphed = False
     for _ in range(warmup):
         loss = step()
     barrier()
