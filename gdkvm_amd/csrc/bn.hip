@@ -421,6 +421,86 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const uint4* __restrict_
     }
 }
 
+// The pooled backward on 2 x 2 blocks of pre-pool pixels (round 4): the four pixels of a block share their (at most) 2 x 2 windows, so a
+// thread loads four x vectors, four window gradients and four tap words for four results -- the per-pixel gather of pool_gather reads four
+// windows for EVERY pixel (36 loads per block) and decodes sixteen (pixel, window) pairs where nine exist; the tap a pixel would have in a
+// window is a compile-time constant of its position in the block.  DX = false: partial sums (S1, S2) per workgroup, as bn_bwd_reduce_kernel;
+// DX = true: dx.  Same values per element as the gather form; the sums are added in another order (block-major), so dgamma / dbeta agree
+// with the two-kernel form to fp32 rounding, not bit for bit.  bf16, channel-group counts that divide 256.
+template <bool DX>
+__global__ __launch_bounds__(256) void bn_pool_bwd2x2_kernel(const uint4* __restrict__ x, PoolGeo q, const float* __restrict__ stats,
+                                                             const float* __restrict__ coef, float* __restrict__ part, uint4* __restrict__ dx,
+                                                             int N, int C, int G)
+{
+    const int tid = threadIdx.x, cg = tid % G;
+    const int Hb = (q.H + 1) / 2, Wb = (q.W + 1) / 2;
+    const size_t total = (size_t)N * Hb * Wb * G;
+    float mu[8], sc[8], sh[8], cA[8], c0[8], c1[8], s1[8], s2[8];
+    load_param<8>(stats, cg * 8, mu); load_param<8>(stats + 2 * C, cg * 8, sc); load_param<8>(stats + 3 * C, cg * 8, sh);
+    if constexpr (DX) { load_param<8>(coef, cg * 8, cA); load_param<8>(coef + C, cg * 8, c0); load_param<8>(coef + 2 * C, cg * 8, c1); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total; i += (size_t)gridDim.x * 256) {      // (256 % G == 0: i % G == cg throughout)
+        size_t p = i / G;
+        const int bx = (int)(p % Wb); p /= Wb;
+        const int by = (int)(p % Hb);
+        const int n = (int)(p / Hb);
+        uint4 xv[2][2], gw[2][2];
+        uint2 tw[2][2];
+        bool pok[2][2], wok[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int ih = 2 * by + r, iw = 2 * bx + c, oh = by + r, ow = bx + c;
+                pok[r][c] = ih < q.H && iw < q.W;
+                wok[r][c] = oh < q.Ho && ow < q.Wo;
+                xv[r][c] = x[(((size_t)n * q.H + (pok[r][c] ? ih : 2 * by)) * q.W + (pok[r][c] ? iw : 2 * bx)) * G + cg];
+                const size_t o = (((size_t)n * q.Ho + (wok[r][c] ? oh : by)) * q.Wo + (wok[r][c] ? ow : bx)) * G + cg;      // (window (by, bx) always exists)
+                gw[r][c] = q.dyp[o];
+                tw[r][c] = *reinterpret_cast<const uint2*>(q.idx + o * 8);
+            }
+        float gwf[2][2][8];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) unpack<GDKVM_BF16>(gw[a][b], gwf[a][b]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float g[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = 0.f;
+#pragma unroll
+                for (int a = 0; a <= r; ++a)               // an even row lies in window `by` only, an odd one in `by` and `by + 1`
+#pragma unroll
+                    for (int b = 0; b <= c; ++b) {
+                        const unsigned tap = (unsigned)(3 * (r - 2 * a + 1) + (c - 2 * b + 1));
+                        const unsigned tb[2] = {tw[a][b].x, tw[a][b].y};
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const unsigned wt = (tb[j >> 2] >> (8 * (j & 3))) & 0xffu;
+                            g[j] += (wok[a][b] && wt == tap) ? gwf[a][b][j] : 0.f;
+                        }
+                    }
+                float f[8];
+                unpack<GDKVM_BF16>(xv[r][c], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float gr = bf16_to_f32(f32_to_bf16(g[j]));          // (the gathered gradient as maxpool_bwd_kernel would have stored it)
+                    const float gm = fmaf(f[j], sc[j], sh[j]) > 0.f ? gr : 0.f;
+                    if constexpr (DX) f[j] = fmaf(cA[j], gm, fmaf(c1[j], f[j] - mu[j], c0[j]));
+                    else if (pok[r][c]) { s1[j] += gm; s2[j] = fmaf(gm, f[j] - mu[j], s2[j]); }
+                }
+                if constexpr (DX) {
+                    if (pok[r][c]) dx[(((size_t)n * q.H + 2 * by + r) * q.W + 2 * bx + c) * G + cg] = pack<GDKVM_BF16>(f);
+                }
+            }
+    }
+    if constexpr (!DX) block_reduce_store<8>(s1, s2, part, C, G);
+}
+
 struct BnPlan {
     int G, RP, nred, rpb_red, nmap, rpb_map;
 };
@@ -604,6 +684,19 @@ extern "C" int gdkvm_bn_pool_bwd(const void* x, const void* dy_pool, const void*
     PoolGeo pg{static_cast<const uint4*>(dy_pool), static_cast<const unsigned char*>(idx), H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1,
                1.0f / (float)W, 1.0f / (float)(H * W)};
     const uint4* xv = static_cast<const uint4*>(x);
+    if (256 % p.G == 0) {                                  // 2 x 2 pixel blocks: a third of the gather's loads
+        const size_t items = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * p.G;
+        const size_t blocks = (items + 255) / 256;
+        const int nred = (int)(blocks < (size_t)BN_MAX_PART ? blocks : (size_t)BN_MAX_PART);
+        hipLaunchKernelGGL((bn_pool_bwd2x2_kernel<false>), dim3(nred), dim3(256), 0, st, xv, pg, save_stats, coef, part, static_cast<uint4*>(dx), N, C, p.G);
+        GDKVM_LAUNCH_CHECK("bn_pool_bwd2x2_kernel");
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, nred, gamma, save_stats, dgamma, dbeta, coef, M, C);
+        GDKVM_LAUNCH_CHECK("bn_bwd_finalize_kernel");
+        hipLaunchKernelGGL((bn_pool_bwd2x2_kernel<true>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, xv, pg, save_stats, coef, part,
+                           static_cast<uint4*>(dx), N, C, p.G);
+        GDKVM_LAUNCH_CHECK("bn_pool_bwd2x2_kernel");
+        return GDKVM_OK;
+    }
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<GDKVM_BF16, 2, true>), dim3(p.nred), dim3(256), 0, st, xv, nullptr, nullptr, save_stats, part, M, C, p.G, p.rpb_red, pg);
     GDKVM_LAUNCH_CHECK("bn_bwd_reduce_kernel");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, st, part, p.nred, gamma, save_stats, dgamma, dbeta, coef, M, C);

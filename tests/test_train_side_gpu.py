@@ -160,8 +160,8 @@ def test_maxpool_forward_and_gather_backward(hip, dtype, shape):
 @pytest.mark.parametrize("shape", [(4, 64, 56, 56), (3, 16, 9, 11), (2, 8, 1, 1), (2, 24, 4, 7), (5, 64, 13, 30)])
 def test_batchnorm_relu_maxpool_as_one_op(hip, shape):
     """ops.bn_relu_pool (gdkvm_bn_pool_fwd_train / gdkvm_bn_pool_bwd: the training stem's tail without the full-resolution activation or
-    its gradient) == ops.maxpool3x3s2(ops.bn_act(x, relu=True)) bit for bit -- pooled values, running statistics, dx, dgamma, dbeta --
-    on inputs with many ties (coarse values) and odd sizes."""
+    its gradient) against ops.maxpool3x3s2(ops.bn_act(x, relu=True)): pooled values and running statistics bit for bit, gradients to fp32
+    rounding (bit for bit on the gather form), on inputs with many ties (coarse values) and odd sizes."""
     torch.manual_seed(sum(shape))
     n, c, hh, ww = shape
     cl = dict(memory_format=torch.channels_last)
@@ -179,8 +179,17 @@ def test_batchnorm_relu_maxpool_as_one_op(hip, shape):
         y.backward(dy)
         return y.detach(), xa.grad, ga.grad, ba.grad, rm, rv
 
-    for a_, b_ in zip(run(False), run(True)):
-        assert a_.shape == b_.shape and torch.equal(a_, b_)
+    ya, dxa, dga, dba, rma, rva = run(False)
+    yb, dxb, dgb, dbb, rmb, rvb = run(True)
+    assert torch.equal(ya, yb) and torch.equal(rma, rmb) and torch.equal(rva, rvb)          # forward: the same bits
+    # backward: the same gradient per element; the two sums over the pixels are added block-major on the 2 x 2 form (channel-group counts
+    # that divide 256), so dgamma / dbeta agree to fp32 rounding and dx to a bf16 ulp on the rare element that rounding moves
+    for a_, b_ in ((dga, dgb), (dba, dbb)):
+        assert (a_ - b_).abs().max() <= 1e-5 * max(1.0, a_.abs().max().item())
+    d = (dxa.float() - dxb.float()).abs()
+    assert d.max() <= 2.0 ** -7 * max(1.0, dxa.float().abs().max().item()) and (d > 0).float().mean() <= 1e-2
+    if 256 % (c // 8):
+        assert torch.equal(dxa, dxb) and torch.equal(dga, dgb)                               # (the gather form: bit for bit)
     assert hip.bn_relu_pool_served(x) and not hip.bn_relu_pool_served(x.float())
 
 
