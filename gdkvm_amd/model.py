@@ -77,6 +77,10 @@ _PROJ_GATES = os.environ.get("GDKVM_PROJ_GATES", "1") != "0"
 _STEM_NCHW = os.environ.get("GDKVM_STEM_NCHW", "1") != "0"
 # training stem: BatchNorm + ReLU + max-pool as one op in both directions (ops.bn_relu_pool); "0" = bn_act then maxpool3x3s2 (A/B switch)
 _STEM_BN_POOL = os.environ.get("GDKVM_STEM_BN_POOL", "1") != "0"
+# training: the decoder's 1x1 head on gdkvm_head_logits / gdkvm_head_bwd (deterministic gradients); "0" = the library convolution (A/B switch)
+_TRAIN_HEAD_HIP = os.environ.get("GDKVM_TRAIN_HEAD_HIP", "1") != "0"
+# training: a residual block's input as two outputs of its first convolution's node (ops.conv3x3_fork); "0" = the framework adds the gradients
+_TRAIN_CONV_FORK = os.environ.get("GDKVM_TRAIN_CONV_FORK", "1") != "0"
 # training: key / query / value / gate projections as one stacked product (ops.token_projections); "0" = one product each (A/B switch)
 _TRAIN_PROJ_STACKED = os.environ.get("GDKVM_TRAIN_PROJ_STACKED", "1") != "0"
 
@@ -133,6 +137,14 @@ class BasicBlock(nn.Module):
                 return self.conv2(pair[0], pair[1])
             skip = x if self.down is None else self.down(x)
             return self.conv2(self.conv1(x), skip.contiguous(memory_format=torch.channels_last) if skip.is_cuda else skip)
+        if (self.down is None and _TRAIN_CONV_FORK and torch.is_grad_enabled() and x.requires_grad and self.conv1.bias is None
+                and self.conv1.padding_mode == "zeros"
+                and ops.conv3x3_train_served(x, self.conv1.weight, self.conv1.stride, self.conv1.padding, self.conv1.dilation, self.conv1.groups)):
+            # the block's input feeds the first convolution AND the skip: as two outputs of one node (ops.conv3x3_fork), so that the
+            # skip's gradient is added in the data-gradient kernel's epilogue (a separate add was 23 us per stride-4 block)
+            y1, xs = ops.conv3x3_fork(x, self.conv1.weight)
+            y = _bn_act(self.bn1, y1, True)
+            return _bn_act(self.bn2, _conv(self.conv2, y), True, xs)
         y = _bn_act(self.bn1, _conv(self.conv1, x), True)
         skip = x if self.down is None else _bn_act(self.down[1], self.down[0](x), False)
         return _bn_act(self.bn2, _conv(self.conv2, y), True, skip)
@@ -248,6 +260,10 @@ class Decoder(nn.Module):
             if head_fused and size is None:
                 return HeadFeature(y, cache[1], cache[2])
             x = ops.head_logits(y, cache[1], cache[2])
+        elif _TRAIN_HEAD_HIP and torch.is_grad_enabled() and ops.head_served(y, hd):
+            # training: gdkvm_head_logits forward, gdkvm_head_bwd backward (one pass, fixed summation order) -- the library's bf16 weight
+            # gradient for this layer accumulates atomically and differed by several bf16 ulps from run to run
+            x = ops.head(y, hd.weight, hd.bias)
         else:
             x = hd(y)
         return x if size is None else F.interpolate(x, size=size, mode="bilinear", align_corners=False)

@@ -65,6 +65,8 @@ SIGNATURES = {
     "gdkvm_argmax_dice": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
     "gdkvm_bias_act": (_i, [_vp] * 4 + [_sz] + [_i] * 3 + [_vp]),
     "gdkvm_head_logits": (_i, [_vp] * 4 + [_i] * 6 + [_vp]),
+    "gdkvm_head_bwd_workspace_bytes": (_sz, [_i] * 2),
+    "gdkvm_head_bwd": (_i, [_vp] * 7 + [_sz] + [_i] * 6 + [_vp]),
     "gdkvm_proj_rows": (_i, [_vp] * 6 + [ctypes.c_longlong] + [_i] * 5 + [_vp]),
     "gdkvm_stem_conv_pool": (_i, [_vp] * 4 + [_i] * 4 + [_vp]),
     "gdkvm_stem_conv_pool_nchw": (_i, [_vp] * 4 + [_i] * 5 + [_vp]),
@@ -730,6 +732,53 @@ def head_logits(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> to
     return out
 
 
+class _HeadFunction(torch.autograd.Function):
+    """The decoder's 1x1 head in training: gdkvm_head_logits forward (NCHW class planes for the loss kernel), gdkvm_head_bwd backward
+    (dx, dW, db in one pass over the feature, fixed summation order)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ncls, c = weight.shape[0], weight.shape[1]
+        w2 = weight.detach().reshape(ncls, c).float().contiguous()
+        b2 = bias.detach().float().contiguous()
+        xc = x.contiguous(memory_format=torch.channels_last)
+        ctx.save_for_backward(xc, w2)
+        ctx.meta = (weight.dtype, tuple(weight.shape), bias.dtype)
+        return head_logits(xc, w2, b2)
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = load()
+        xc, w2 = ctx.saved_tensors
+        n, c, hh, ww = xc.shape
+        ncls = w2.shape[0]
+        dz = dz.to(xc.dtype).contiguous()
+        dx = torch.empty_like(xc)
+        dw = torch.empty((ncls, c), dtype=torch.float32, device=xc.device)
+        db = torch.empty(ncls, dtype=torch.float32, device=xc.device)
+        need = int(lib.gdkvm_head_bwd_workspace_bytes(c, ncls))
+        ws = torch.empty(need, dtype=torch.uint8, device=xc.device)
+        with torch.cuda.device(xc.device):
+            rc = lib.gdkvm_head_bwd(xc.data_ptr(), dz.data_ptr(), w2.data_ptr(), dx.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), need,
+                                    n, hh, ww, c, ncls, _io_dtype(xc), _stream(xc.device))
+        _check(rc, "gdkvm_head_bwd")
+        wdt, wshape, bdt = ctx.meta
+        return dx, dw.reshape(wshape).to(wdt), db.to(bdt)
+
+
+def head_served(x: torch.Tensor, conv) -> bool:
+    v = 8 if x.dtype == torch.bfloat16 else 4
+    g = x.shape[1] // v if x.dim() == 4 else 0
+    return (x.is_cuda and x.dim() == 4 and x.dtype in (torch.bfloat16, torch.float32) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.bias is not None and x.shape[1] % v == 0 and 0 < g <= 64 and g & (g - 1) == 0
+            and conv.out_channels <= min(g, 8))
+
+
+def head(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """conv2d(x, weight [classes, C, 1, 1], bias) as contiguous NCHW class planes, differentiable (training): _HeadFunction."""
+    return _HeadFunction.apply(x, weight, bias)
+
+
 def pack_rows_weight(weight: torch.Tensor) -> torch.Tensor:
     """W [Nout, K] (Nout a multiple of 16, K of 32) -> bf16 in the MFMA fragment order gdkvm_proj_rows streams:
     element ((ot * K/32 + ks) * 64 + lane) * 8 + j = W[16 ot + (lane & 15)][32 ks + 8 (lane >> 4) + j]."""
@@ -871,12 +920,13 @@ def conv_down_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor
     return y, yd
 
 
-def _conv3x3_packed(x: torch.Tensor, packed: torch.Tensor, k_out: int, bias: torch.Tensor) -> torch.Tensor:
-    """conv3x3 / stride 1 / pad 1 of channels_last bf16 x with weights given ONLY as a pack (no epilogue beyond the bias)."""
+def _conv3x3_packed(x: torch.Tensor, packed: torch.Tensor, k_out: int, bias: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv3x3 / stride 1 / pad 1 of channels_last bf16 x with weights given ONLY as a pack (no epilogue beyond the bias and an optional
+    residual [N, k_out, H, W] of x's type added in the kernel's epilogue)."""
     n, c, hh, ww = x.shape
     y = torch.empty((n, k_out, hh, ww), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
-        rc = load().gdkvm_conv_bias_act(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), None, y.data_ptr(), n, c, hh, ww, k_out, 3, 3, 1, 1,
+        rc = load().gdkvm_conv_bias_act(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), _ptr(residual), y.data_ptr(), n, c, hh, ww, k_out, 3, 3, 1, 1,
                                         0, CONV_PACKED_WEIGHTS, BF16, _stream(x.device))
     _check(rc, "gdkvm_conv_bias_act")
     return y
@@ -945,10 +995,20 @@ class _Conv3x3Function(torch.autograd.Function):
     (gdkvm_conv3x3_wgrad).  bf16 activations (autocast), fp32 master weights."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, fork=False):
         lib = load()
         xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         k, c = weight.shape[:2]
+        ctx.fork = bool(fork)
+        if fork:
+            # conv3x3_fork: a second output that IS the input (for the residual branch of the block).  Its gradient then arrives HERE, together
+            # with the convolution's, and is added in the data-gradient kernel's epilogue instead of by a separate pass over both tensors
+            y, dummy = _Conv3x3Function._fwd(ctx, lib, x, xb, weight, k, c)
+            return y, xb.view(xb.shape)
+        return _Conv3x3Function._fwd(ctx, lib, x, xb, weight, k, c)[0]
+
+    @staticmethod
+    def _fwd(ctx, lib, x, xb, weight, k, c):
         packs = _train_packs_of(weight)                    # (conv3x3_train_packs ran for this version of the weight: nothing to cast or pack here)
         ctx.kc, ctx.wdtype, ctx.xdtype = (k, c), weight.dtype, x.dtype
         ctx.w_cl = (weight.is_contiguous(memory_format=torch.channels_last) and not weight.is_contiguous()
@@ -959,19 +1019,20 @@ class _Conv3x3Function(torch.autograd.Function):
             ctx.dgrad_pack, ctx.pack_key = packs[1], (weight._version, weight.data_ptr())
             ctx.weight_ref = weight
             ctx.save_for_backward(xb)
-            return _conv3x3_packed(xb, packs[0], k, _zero_bias(k, xb.device))
+            return _conv3x3_packed(xb, packs[0], k, _zero_bias(k, xb.device)), None
         wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         packed = torch.empty(k * 9 * c, dtype=torch.bfloat16, device=xb.device)
         with torch.cuda.device(xb.device):
             _check(lib.gdkvm_conv3x3_pack_weights(wb.data_ptr(), packed.data_ptr(), k, c, BF16, _stream(xb.device)), "gdkvm_conv3x3_pack_weights")
         ctx.dgrad_pack = None
         ctx.save_for_backward(xb, wb)
-        return _conv3x3_packed(xb, packed, k, _zero_bias(k, xb.device))
+        return _conv3x3_packed(xb, packed, k, _zero_bias(k, xb.device)), None
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, d_alias=None):
         k, c = ctx.kc
         dyb = dy.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        res = None if d_alias is None else d_alias.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         dx = dw = None
         if ctx.dgrad_pack is not None:
             (xb,), wb = ctx.saved_tensors, None
@@ -987,13 +1048,15 @@ class _Conv3x3Function(torch.autograd.Function):
                 with torch.cuda.device(dyb.device):
                     _check(load().gdkvm_conv3x3_pack_weights_dgrad(wb.data_ptr(), packed.data_ptr(), k, c, BF16, _stream(dyb.device)),
                            "gdkvm_conv3x3_pack_weights_dgrad")
-            dx = _conv3x3_packed(dyb, packed, c, _zero_bias(c, dyb.device)).to(ctx.xdtype)
+            dx = _conv3x3_packed(dyb, packed, c, _zero_bias(c, dyb.device), res).to(ctx.xdtype)
+        elif res is not None:
+            dx = res.to(ctx.xdtype)
         if ctx.needs_input_grad[1]:
             if os.environ.get("GDKVM_CONV_WGRAD") == "framework":          # (A/B switch for tools: the framework's weight gradient)
                 dw = torch.ops.aten.convolution_backward(dyb, xb, wb, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, (False, True, False))[1].to(ctx.wdtype)
             else:
                 dw = conv3x3_wgrad(xb, dyb, channels_last=ctx.w_cl).to(ctx.wdtype)  # (fp32 sums over all pixels, deterministic; in the weight's own memory order)
-        return dx, dw
+        return dx, dw, None
 
 
 _WGRAD_WS = {}
@@ -1038,6 +1101,13 @@ def conv3x3_train_served(x: torch.Tensor, weight: torch.Tensor, stride, padding,
 def conv3x3(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """conv2d(x, weight, padding=1) for a 3x3 / stride-1 layer with channel counts in multiples of 64, differentiable, bf16."""
     return _Conv3x3Function.apply(x, weight)
+
+
+def conv3x3_fork(x: torch.Tensor, weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(conv3x3(x, weight), x') where x' is x itself (bf16, channels_last) as a second output of the same autograd node: a residual block
+    feeds x' to its skip connection, and the skip's gradient is then added to the convolution's data gradient inside that kernel's
+    epilogue (its residual input) instead of by the framework's add over two full tensors."""
+    return _Conv3x3Function.apply(x, weight, True)
 
 
 def conv_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tensor] = None,

@@ -309,6 +309,12 @@ int gdkvm_bias_act(const void* x, const float* bias, const void* residual, void*
  * gdkvm_upsample_argmax_dice reads; one pass instead of convolution + bias add + layout copy. */
 int gdkvm_head_logits(const void* x, const float* w, const float* b, void* out, int N, int H, int W, int C, int classes,
                       int io_dtype, void* stream);
+/* Training: the head's backward in one pass.  dz [N, classes, H, W] (io dtype, NCHW planes as gdkvm_seg_loss_bwd writes them), x the feature
+ * gdkvm_head_logits read, w fp32 [classes, C] -> dx [N, H, W, C] (io dtype), dw fp32 [classes, C], db fp32 [classes]; per-workgroup partial
+ * sums in `workspace` (gdkvm_head_bwd_workspace_bytes) added in index order: deterministic.  classes <= min(C/8 (C/4 for fp32), 8). */
+size_t gdkvm_head_bwd_workspace_bytes(int C, int ncls);
+int gdkvm_head_bwd(const void* x, const void* dz, const float* w, void* dx, float* dw, float* db, void* workspace, size_t workspace_bytes,
+                   int N, int H, int W, int C, int ncls, int io_dtype, void* stream);
 
 /* Row n4, the key / query / value projections in one pass over the token rows x [rows, K] (bf16):
  *   [out0 | out1 | out2][row, :] = x[row, :] W^T + bias,  W [w0 + w1 + w2, K] -- three contiguous outputs [rows, w0], [rows, w1],

@@ -227,6 +227,36 @@ def test_token_linear_and_split_k_weight_gradient(hip, dtype):
     assert torch.equal(db2, hip.wgrad(dy[:1001], x[:1001], colsum=True)[1])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("case", [(3, 64, 28, 28, 2), (2, 32, 9, 5, 4), (1, 64, 7, 7, 8)])
+def test_head_forward_and_one_pass_backward(hip, case, dtype):
+    """ops.head (gdkvm_head_logits forward, gdkvm_head_bwd backward) against conv2d in fp64 on the same operands: logits, dx, dW, db;
+    the backward is the same bits on every run."""
+    n, c, hh, ww, ncls = case
+    if dtype == torch.float32 and ncls > c // 4:
+        pytest.skip("classes <= C/4 lanes per pixel in fp32")
+    torch.manual_seed(sum(case))
+    x = torch.randn(n, c, hh, ww, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    conv = torch.nn.Conv2d(c, ncls, 1).cuda()
+    gz = torch.randn(n, ncls, hh, ww, device="cuda").to(dtype)
+    z = hip.head(x, conv.weight, conv.bias)
+    assert z.is_contiguous() and z.dtype == dtype
+    z.backward(gz)
+    x64 = x.detach().double().requires_grad_(True)
+    w64, b64 = conv.weight.detach().double().requires_grad_(True), conv.bias.detach().double().requires_grad_(True)
+    z64 = F.conv2d(x64, w64, b64)
+    z64.backward(gz.double())
+    tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-5
+    assert (z.double() - z64).abs().max() <= tol * max(1.0, z64.abs().max().item())
+    assert (x.grad.double() - x64.grad).abs().max() <= tol * max(1.0, x64.grad.abs().max().item())
+    assert conv.weight.grad.dtype == torch.float32 and (conv.weight.grad.double() - w64.grad).abs().max() <= 1e-5 * max(1.0, w64.grad.abs().max().item())
+    assert (conv.bias.grad.double() - b64.grad).abs().max() <= 1e-5 * max(1.0, b64.grad.abs().max().item())
+    g1 = (x.grad.clone(), conv.weight.grad.clone(), conv.bias.grad.clone())
+    x.grad = None; conv.zero_grad(set_to_none=True)
+    hip.head(x, conv.weight, conv.bias).backward(gz)
+    assert all(torch.equal(a, b) for a, b in zip(g1, (x.grad, conv.weight.grad, conv.bias.grad)))
+
+
 def test_stacked_token_projections(hip):
     """ops.token_projections (key / query / value / gate as ONE stacked product forward, two backward) against the four separate
     ops.token_linear calls it replaces: the same outputs bit for bit (the same kernel on the same rows of the stacked weight), gradients
