@@ -7,6 +7,7 @@
 // HBM-bound by construction.
 #include <type_traits>
 
+#include <stdlib.h>
 #include "gdkvm_common.hpp"
 
 namespace {
@@ -332,6 +333,86 @@ __global__ __launch_bounds__(256) void upsample_cat_bf16_kernel(const bf16_t* lo
     }
 }
 
+// Exactly 2x (the decoder's two enlargements): one workgroup iteration per PAIR of output rows 2ip+1, 2ip+2 -- they share the vertical taps
+// ip, ip+1 (weights 1/4 and 3/4) as the column pairs of upsample_cat_bf16_kernel share the horizontal ones -- so a thread's four tap loads
+// feed a 2 x 2 block of outputs (round 4: the row-at-a-time form issued four loads per two outputs and a workgroup iteration moved 7 KB;
+// 49 us for the two enlargements of a cfg2 forward).  The arithmetic per output is that kernel's expression, so the bits are the same.
+__global__ __launch_bounds__(256) void upsample_cat_bf16_2x_kernel(const bf16_t* lo, const bf16_t* skip, bf16_t* out,
+                                                                   int Nimg, int hl, int wl, int C1, int C2, float inv_c1n, float inv_c2n, float inv_hp)
+{
+    auto qdiv = [](int n, float inv) { return (int)(((float)n + 0.5f) * inv); };
+    const int H = 2 * hl, W = 2 * wl, C = C1 + C2, c1n = C1 / 8, c2n = C2 / 8, n2 = W * c2n, tid = threadIdx.x;
+    const int nu = (wl + 1) * c1n, hp = hl + 1;           // column pairs x channel vectors; row pairs per image
+    for (int rp = blockIdx.x; rp < Nimg * hp; rp += gridDim.x) {
+        const int n = qdiv(rp, inv_hp), ip = rp - n * hp - 1;
+        const int r0 = max(ip, 0), r1 = min(ip + 1, hl - 1);
+        const bf16_t* lo0 = lo + ((size_t)n * hl + r0) * wl * C1;
+        const bf16_t* lo1 = lo + ((size_t)n * hl + r1) * wl * C1;
+        // the copy half of both rows, requested first (in flight behind the taps)
+        constexpr int MAXV = 2;
+        uint4 cp[2][MAXV];
+#pragma unroll
+        for (int ey = 0; ey < 2; ++ey) {
+            const int y = min(max(2 * ip + 1 + ey, 0), H - 1);
+            const bf16_t* sk = skip + ((size_t)n * H + y) * W * C2;
+#pragma unroll
+            for (int u = 0; u < MAXV; ++u) cp[ey][u] = n2 ? *reinterpret_cast<const uint4*>(sk + min(u * 256 + tid, n2 - 1) * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        for (int u0 = 0; u0 < nu; u0 += 256) {
+            const int u = min(u0 + tid, nu - 1);
+            const int jq = qdiv(u, inv_c1n), c = (u - jq * c1n) * 8, jp = jq - 1;
+            const int x0 = max(jp, 0), x1 = min(jp + 1, wl - 1);
+            const uint4 t00 = *reinterpret_cast<const uint4*>(lo0 + x0 * C1 + c), t01 = *reinterpret_cast<const uint4*>(lo0 + x1 * C1 + c);
+            const uint4 t10 = *reinterpret_cast<const uint4*>(lo1 + x0 * C1 + c), t11 = *reinterpret_cast<const uint4*>(lo1 + x1 * C1 + c);
+            if (u0 + tid >= nu) continue;
+            float a[8], b[8], cc[8], d[8];
+            unpack8(t00, a); unpack8(t01, b); unpack8(t10, cc); unpack8(t11, d);
+#pragma unroll
+            for (int ey = 0; ey < 2; ++ey) {
+                const int y = 2 * ip + 1 + ey;
+                if (y < 0 || y >= H) continue;
+                // the row-at-a-time kernel's weights: fy = max(y/2 - 1/4, 0), ly = fy - floor(fy): 0 on row 0, 1/4 / 3/4 inside
+                const float fy = fmaxf(0.5f * ((float)y + 0.5f) - 0.5f, 0.f);
+                const float ly = fy - (float)(int)fy, hy = 1.f - ly;
+                bf16_t* orow = out + ((size_t)n * H + y) * W * C;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int x = 2 * jp + 1 + e;
+                    if (x < 0 || x >= W) continue;
+                    const float lx = e ? 0.75f : 0.25f, hx = 1.f - lx;
+                    unsigned r[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v0 = hy * (hx * a[2 * q] + lx * b[2 * q]) + ly * (hx * cc[2 * q] + lx * d[2 * q]);
+                        const float v1 = hy * (hx * a[2 * q + 1] + lx * b[2 * q + 1]) + ly * (hx * cc[2 * q + 1] + lx * d[2 * q + 1]);
+                        r[q] = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
+                    }
+                    *reinterpret_cast<uint4*>(orow + x * C + c) = make_uint4(r[0], r[1], r[2], r[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int ey = 0; ey < 2; ++ey) {
+            const int y = 2 * ip + 1 + ey;
+            if (y < 0 || y >= H) continue;
+            bf16_t* orow = out + ((size_t)n * H + y) * W * C;
+            const bf16_t* sk = skip + ((size_t)n * H + y) * W * C2;
+#pragma unroll
+            for (int u = 0; u < MAXV; ++u) {
+                const int jc = u * 256 + tid;
+                if (jc < n2) {
+                    const int x = qdiv(jc, inv_c2n);
+                    *reinterpret_cast<uint4*>(orow + x * C + C1 + (jc - x * c2n) * 8) = cp[ey][u];
+                }
+            }
+            for (int jc = MAXV * 256 + tid; jc < n2; jc += 256) {
+                const int x = qdiv(jc, inv_c2n);
+                *reinterpret_cast<uint4*>(orow + x * C + C1 + (jc - x * c2n) * 8) = *reinterpret_cast<const uint4*>(sk + jc * 8);
+            }
+        }
+    }
+}
+
 // Training stem: 3x3 / stride 2 / pad 1 max-pool with the winning tap recorded (one byte per output element, 3*dy + dx in
 // window coordinates; first maximum in row-major scan order, as PyTorch), and its backward as a GATHER: an input pixel
 // belongs to at most 2 x 2 windows, so a thread reads their tap bytes and gradients and writes its 16 bytes of dx once
@@ -560,8 +641,20 @@ extern "C" int gdkvm_upsample_cat(const void* lo, const void* skip, void* out,
     // the kernel's float-reciprocal row -> (image, y) split is exact below 2^20 rows: larger batches go as several launches over
     // image ranges (16384 frames x 64 rows used to be refused)
     const int per = (int)(((1u << 20) - 1) / (unsigned)H);
+    const char* env_pairs = getenv("GDKVM_UPSAMPLE_ROW_PAIRS");                     // ("0": A/B switch, the row-at-a-time kernel; read per call: tests toggle it)
+    const bool pairs = !(env_pairs && env_pairs[0] == '0');
     for (int n0 = 0; n0 < Nimg; n0 += per) {
         const int nn = Nimg - n0 < per ? Nimg - n0 : per;
+        if (pairs && H == 2 * hl && W == 2 * wl) {
+            size_t blocks = (size_t)nn * (hl + 1);
+            if (blocks > 256 * 16) blocks = 256 * 16;
+            hipLaunchKernelGGL(upsample_cat_bf16_2x_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                               static_cast<const bf16_t*>(lo) + (size_t)n0 * hl * wl * C1,
+                               skip ? static_cast<const bf16_t*>(skip) + (size_t)n0 * H * W * C2 : nullptr,
+                               static_cast<bf16_t*>(out) + (size_t)n0 * H * W * (C1 + C2),
+                               nn, hl, wl, C1, C2, 8.0f / (float)C1, 8.0f / (float)C2, 1.0f / (float)(hl + 1));
+            continue;
+        }
         size_t blocks = (size_t)nn * H;
         if (blocks > 256 * 16) blocks = 256 * 16;
         hipLaunchKernelGGL(upsample_cat_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),

@@ -188,6 +188,15 @@ def test_upsample_cat(hip, case):
     assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got[:, c1:], sk)
     assert (got[:, :c1].float() - up).abs().max() <= 2.0 ** -7 * up.abs().max()     # one bf16 rounding of an fp32 blend
+    # exactly 2x runs on the row-pair kernel (four tap loads per 2 x 2 outputs); the row-at-a-time kernel gives the same bits
+    import os
+    os.environ["GDKVM_UPSAMPLE_ROW_PAIRS"] = "0"
+    try:
+        assert torch.equal(hip.upsample_cat(lo, sk), got)
+        assert torch.equal(hip.upsample_bilinear(lo, (H, W)), got[:, :c1])
+    finally:
+        del os.environ["GDKVM_UPSAMPLE_ROW_PAIRS"]
+    assert torch.equal(hip.upsample_bilinear(lo, (H, W)), got[:, :c1])
 
 
 def test_upsample_cat_more_than_2_20_output_rows(hip):
