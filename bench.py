@@ -344,7 +344,7 @@ def main():
     frames32 = clips(1000 + rank, B)
     frames = frames32.to(dev).to(torch.bfloat16)            # resident in HBM as bf16 before the timed region
 
-    def step():
+    def eager_step():
         with torch.no_grad():
             return model.segment(frames)[0]
 
@@ -353,7 +353,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    step()                                                  # set-up, not a step: weight packs, library load, first launches
+    ref_mask = eager_step().clone()                         # set-up, not a step: weight packs, library load, first launches
+    # The step is one hipGraph replay of the forward (model.GraphedSegment: the same kernels in the same order; a forward is ~25 launches for
+    # ~0.95 ms of GPU time, so on a slow host the eager loop is bound by the launch calls, not by the GPU); GDKVM_FWD_GRAPH=0 times the eager
+    # calls.  The replayed masks are checked against the eager ones before anything is timed.
+    step, launch = eager_step, "eager (one launch call per kernel)"
+    if os.environ.get("GDKVM_FWD_GRAPH", "1") != "0":
+        try:
+            gseg = model.graphed_segment(frames)
+            if not torch.equal(gseg(frames)[0], ref_mask):
+                raise RuntimeError("the replayed forward's masks differ from the eager ones")
+            step, launch = (lambda: gseg(frames)[0]), "one hipGraph replay per step"
+        except Exception as e:
+            print(f"[bench] forward not captured ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -380,6 +393,7 @@ def main():
                       "clips_per_gpu": B, "frames_per_clip": T, "image": f"{S}x{S}", "tokens_per_frame": (S // 16) ** 2,
                       "heads": cfg.heads, "key_dim": cfg.key_dim, "value_dim": cfg.value_dim, "rule": cfg.rule,
                       "input": "frames resident in HBM as bf16 before the timed region (host-to-device copy and cast untimed)",
+                      "launch": launch,
                       "sharding": f"clips over {world} GPU(s), no data-path collective",
                       "world_size": (dist.get_world_size() if world > 1 else 1), "ranks_seen": ranks_seen,
                       "collective_backend": ("nccl (RCCL)" if world > 1 else None)}}

@@ -782,6 +782,11 @@ class GDKVM(nn.Module):
             counts.append(c)
         return torch.cat(masks, 1), (None if target is None else torch.cat(counts, 1)), state
 
+    def graphed_segment(self, frames, target=None, warmup: int = 2):
+        """segment() for ONE clip shape captured into a hipGraph (GraphedSegment): a serving loop that replays it spends no host time
+        on the ~25 launches of a forward."""
+        return GraphedSegment(self, frames, target, warmup)
+
     # -------------------------------------------------------------------------------------- checkpoints
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         remapped = {}
@@ -793,3 +798,38 @@ class GDKVM(nn.Module):
             remapped[key] = val
         self.invalidate_packed_weights()
         return super().load_state_dict(remapped, strict=strict, **kw)
+
+
+class GraphedSegment:
+    """GDKVM.segment(frames, target) captured ONCE into a hipGraph and replayed (inference build, fixed clip shape): the same kernels in the
+    same order with no host work between them -- a forward is ~25 launches for ~0.95 ms of GPU time, so a slow or busy host (one launch call
+    costing more than ~35 us) would otherwise bound the rate.  Construction runs `warmup` eager calls on a side stream (weight packs, kernel
+    attributes), then captures; a call copies the batch into the graph's input buffers unless it IS those buffers, replays and returns the
+    graph's output tensors (overwritten by the next call): (mask uint8 [B,T,H,W], Dice counts int32 [B,T,ncls,3] | None)."""
+
+    def __init__(self, model: "GDKVM", frames: torch.Tensor, target: Optional[torch.Tensor] = None, warmup: int = 2):
+        if not frames.is_cuda:
+            raise RuntimeError("GraphedSegment needs device tensors")
+        self.model, self.frames, self.target = model, frames, target
+        with torch.no_grad():
+            side = torch.cuda.Stream(device=frames.device)
+            side.wait_stream(torch.cuda.current_stream(frames.device))
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):
+                    model.segment(self.frames, self.target)
+            torch.cuda.current_stream(frames.device).wait_stream(side)
+            torch.cuda.synchronize(frames.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = model.segment(self.frames, self.target)
+
+    def __call__(self, frames: torch.Tensor, target: Optional[torch.Tensor] = None):
+        if frames.shape != self.frames.shape or frames.dtype != self.frames.dtype or (target is None) != (self.target is None):
+            raise RuntimeError(f"GraphedSegment was captured for frames {tuple(self.frames.shape)} {self.frames.dtype}"
+                               f"{'' if self.target is None else ' with a target'}")
+        if frames.data_ptr() != self.frames.data_ptr():
+            self.frames.copy_(frames, non_blocking=True)
+        if target is not None and target.data_ptr() != self.target.data_ptr():
+            self.target.copy_(target, non_blocking=True)
+        self.graph.replay()
+        return self.out

@@ -116,6 +116,26 @@ def test_module_with_keys_wider_than_64(hip):
     assert (lb.argmax(2) == lp.argmax(2)).float().mean().item() >= 0.95
 
 
+def test_segment_captured_in_a_graph(hip):
+    """GDKVM.graphed_segment: segment() of the fused bf16 build captured into a hipGraph and replayed == the eager call, bit for bit (masks
+    and Dice counts), for the captured batch and for fresh batches copied into its input buffers; another shape is refused."""
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    torch.manual_seed(41)
+    model = GDKVM(GDKVMConfig()).eval().fuse_for_inference().cuda().to(torch.bfloat16).to(memory_format=torch.channels_last)
+    frames = [torch.rand(2, 4, 3, 112, 112, device="cuda").bfloat16() for _ in range(3)]
+    target = [(torch.rand(2, 4, 112, 112, device="cuda") > 0.5).to(torch.uint8) for _ in range(3)]
+    with torch.no_grad():
+        want = [tuple(t.clone() for t in model.segment(f, t_)) for f, t_ in zip(frames, target)]
+        g = model.graphed_segment(frames[0].clone(), target[0].clone())
+        for f, t_, (m, c) in zip(frames, target, want):
+            gm, gc = g(f, t_)
+            assert torch.equal(gm, m) and torch.equal(gc, c)
+        g2 = model.graphed_segment(frames[1])                  # without a target: masks only
+        assert g2(frames[2])[1] is None and torch.equal(g2(frames[2])[0], want[2][0])
+    with pytest.raises(RuntimeError):
+        g(frames[0][:, :2], target[0][:, :2])
+
+
 def test_fused_build_on_maps_wider_than_64_pixels(hip):
     """528x528 frames: the stride-8 map is 66 pixels wide, wider than the chunked 3x3 kernel tiles -- those layers and the strided ones
     take the general implicit-GEMM kernel; 33x33 = 1089 tokens per frame.  The fused bf16 build against the independent restatement."""
