@@ -514,7 +514,7 @@ def main():
                 wl = {"configs[2] 8x20x256x256, 4 classes, one call": module_rate(lambda: m3.segment(f3), 160)}
                 del m3, f3, lg3, mask32, mask16
                 f5 = torch.rand(2, 512, 3, 256, 256, device=dev).to(torch.bfloat16)
-                wl["configs[4] 2x512x256x256, 16 chunks of 32 frames, state carried"] = module_rate(lambda: model.segment_clip(f5, 32), 1024)
+                wl["configs[4] 2x512x256x256, 16 chunks of 32 frames, state carried"] = module_rate(lambda: model.segment_clip(f5, 32, graph=True), 1024)
                 model.cfg.scan_segments = 0
                 try:
                     wl["configs[4] 2x512x256x256, one call, scan in 16 time segments"] = module_rate(lambda: model.segment(f5), 1024)

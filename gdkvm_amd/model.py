@@ -764,7 +764,7 @@ class GDKVM(nn.Module):
         return out + (s_out,) if return_state else out
 
     @torch.no_grad()
-    def segment_clip(self, frames, chunk_frames: int, target=None, mask0=None, state=None):
+    def segment_clip(self, frames, chunk_frames: int, target=None, mask0=None, state=None, graph: bool = False):
         """A long clip as consecutive chunks of ``chunk_frames`` frames with the memory state carried from chunk to chunk
         ("GDR memory-state carry across chunks", BASELINE.json configs[4]): activations are held for one chunk at a time, and -- with
         the default ``scan_segments = 1`` -- masks, Dice counts and the final state are those of ONE call over the whole clip, and of
@@ -774,6 +774,24 @@ class GDKVM(nn.Module):
         if chunk_frames <= 0:
             raise ValueError("chunk_frames must be positive")
         masks, counts = [], []
+        if graph and frames.is_cuda and mask0 is None and T % chunk_frames == 0:
+            # every chunk is ONE replay of a hipGraph captured for the chunk's shape (GraphedSegment with the state carried; cached on the
+            # module): the same kernels and the same bits as the loop below, without the host's launch calls between them -- a long clip is
+            # many short forwards, which is where a slow host shows (round 4: 17.5 against 12.0 ms per 1024 frames between two boxes)
+            cfg = self.cfg
+            key = (B, chunk_frames) + tuple(frames.shape[2:]) + (frames.dtype, target is not None, frames.device)
+            cache = self.__dict__.setdefault("_clip_graphs", {})
+            if key not in cache:
+                s0 = torch.zeros((B, cfg.heads, cfg.key_dim, cfg.value_dim), dtype=torch.float32, device=frames.device)
+                cache[key] = GraphedSegment(self, frames[:, :chunk_frames].clone(), None if target is None else target[:, :chunk_frames].clone(), state=s0)
+            g = cache[key]
+            cur = torch.zeros_like(g.state) if state is None else state
+            for t0 in range(0, T, chunk_frames):
+                m, c, s_new = g(frames[:, t0:t0 + chunk_frames], None if target is None else target[:, t0:t0 + chunk_frames], state=cur)
+                masks.append(m.clone())
+                counts.append(None if c is None else c.clone())
+                cur = s_new                                 # (the graph's output buffer: copied into its input buffer by the next call)
+            return torch.cat(masks, 1), (None if target is None else torch.cat(counts, 1)), cur.clone()
         for t0 in range(0, T, chunk_frames):
             t1 = min(T, t0 + chunk_frames)
             m, c, state = self.segment(frames[:, t0:t1], None if target is None else target[:, t0:t1], return_state=True,
@@ -782,10 +800,10 @@ class GDKVM(nn.Module):
             counts.append(c)
         return torch.cat(masks, 1), (None if target is None else torch.cat(counts, 1)), state
 
-    def graphed_segment(self, frames, target=None, warmup: int = 2):
+    def graphed_segment(self, frames, target=None, warmup: int = 2, state=None):
         """segment() for ONE clip shape captured into a hipGraph (GraphedSegment): a serving loop that replays it spends no host time
         on the ~25 launches of a forward."""
-        return GraphedSegment(self, frames, target, warmup)
+        return GraphedSegment(self, frames, target, warmup, state)
 
     # -------------------------------------------------------------------------------------- checkpoints
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -807,29 +825,36 @@ class GraphedSegment:
     attributes), then captures; a call copies the batch into the graph's input buffers unless it IS those buffers, replays and returns the
     graph's output tensors (overwritten by the next call): (mask uint8 [B,T,H,W], Dice counts int32 [B,T,ncls,3] | None)."""
 
-    def __init__(self, model: "GDKVM", frames: torch.Tensor, target: Optional[torch.Tensor] = None, warmup: int = 2):
+    def __init__(self, model: "GDKVM", frames: torch.Tensor, target: Optional[torch.Tensor] = None, warmup: int = 2,
+                 state: Optional[torch.Tensor] = None):
+        """state (fp32 [B,Hh,Dk,Dv]): capture the state-carrying form -- calls then take `state=` (copied into the graph's buffer) and
+        return (mask, counts, state after the last frame), as segment(..., state=, return_state=True) does (GDKVM.segment_clip)."""
         if not frames.is_cuda:
             raise RuntimeError("GraphedSegment needs device tensors")
-        self.model, self.frames, self.target = model, frames, target
+        self.model, self.frames, self.target, self.state = model, frames, target, state
+        kw = {} if state is None else {"state": state, "return_state": True}
         with torch.no_grad():
             side = torch.cuda.Stream(device=frames.device)
             side.wait_stream(torch.cuda.current_stream(frames.device))
             with torch.cuda.stream(side):
                 for _ in range(max(1, warmup)):
-                    model.segment(self.frames, self.target)
+                    model.segment(self.frames, self.target, **kw)
             torch.cuda.current_stream(frames.device).wait_stream(side)
             torch.cuda.synchronize(frames.device)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.out = model.segment(self.frames, self.target)
+                self.out = model.segment(self.frames, self.target, **kw)
 
-    def __call__(self, frames: torch.Tensor, target: Optional[torch.Tensor] = None):
-        if frames.shape != self.frames.shape or frames.dtype != self.frames.dtype or (target is None) != (self.target is None):
+    def __call__(self, frames: torch.Tensor, target: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None):
+        if (frames.shape != self.frames.shape or frames.dtype != self.frames.dtype or (target is None) != (self.target is None)
+                or (state is None) != (self.state is None)):
             raise RuntimeError(f"GraphedSegment was captured for frames {tuple(self.frames.shape)} {self.frames.dtype}"
-                               f"{'' if self.target is None else ' with a target'}")
+                               f"{'' if self.target is None else ' with a target'}{'' if self.state is None else ' with a state'}")
         if frames.data_ptr() != self.frames.data_ptr():
             self.frames.copy_(frames, non_blocking=True)
         if target is not None and target.data_ptr() != self.target.data_ptr():
             self.target.copy_(target, non_blocking=True)
+        if state is not None and state.data_ptr() != self.state.data_ptr():
+            self.state.copy_(state, non_blocking=True)
         self.graph.replay()
         return self.out

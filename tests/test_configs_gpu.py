@@ -294,6 +294,10 @@ def test_cfg5_module_long_clip_in_chunks_with_the_state_carried(hip):
     assert m32.shape == (B, T, S, S) and s32.shape == (B, 1, 64, 256)
     assert torch.equal(m32, m64) and torch.equal(c32, c64) and torch.equal(s32, s64)
     assert torch.isfinite(s32).all() and 0.05 < m32.float().mean().item() < 0.95
+    # every chunk as one replay of a hipGraph with the state carried through its buffers (segment_clip(graph=True)): the same bits, twice
+    for _ in range(2):
+        mg, cg, sg = fused.segment_clip(fr, 32, target=tgt, graph=True)
+        assert torch.equal(mg, m32) and torch.equal(cg, c32) and torch.equal(sg, s32)
     agree = (m32[:1, :2].cpu().long() == lp.argmax(2)).float().mean().item()
     assert agree >= 0.96, agree
     # one call over the whole clip with the time axis cut into concurrent segments: the library's choice for this shape is 16
