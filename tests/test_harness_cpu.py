@@ -51,3 +51,26 @@ def test_offline_run_log(tmp_path):
     lines = open(os.path.join(run.dir, "metrics.jsonl")).read().strip().split("\n")
     assert [json.loads(l)["loss"] for l in lines] == [0.5, 0.25] and "offline-run-" in run.dir
     assert not OfflineRun(str(tmp_path), {}, "disabled").enabled
+
+
+def test_graph_wrappers_and_new_switches_fail_loudly_on_the_cpu():
+    """The graph-capture wrappers (model.GraphedSegment, train.GraphedTrainStep) are device-only and say so; the product has no CPU route
+    for the hand-written operators they replay (ops raise without a device tensor); the configuration carries the long-clip switch."""
+    import pytest
+    import torch
+    from gdkvm_amd import ops
+    from gdkvm_amd.model import GDKVM, GDKVMConfig, GraphedSegment
+    from gdkvm_amd.train import GraphedTrainStep
+    cfg = GDKVMConfig(widths=(16, 32, 64), pixel_dim=64, value_dim=64)
+    assert cfg.scan_segments == 1                          # serial scan (chunk bit-identity) unless asked otherwise
+    model = GDKVM(cfg).eval()
+    frames = torch.rand(1, 2, 3, 32, 32)
+    with pytest.raises(RuntimeError, match="device"):
+        GraphedSegment(model, frames)
+    with pytest.raises(RuntimeError, match="device"):
+        GraphedTrainStep(model, None, frames, torch.zeros(1, 2, 32, 32, dtype=torch.long))
+    x = torch.randn(8, 64)
+    lin = torch.nn.Linear(64, 16)
+    with pytest.raises(Exception):                          # token-major products exist on the device only (no silent CPU fallback)
+        ops.token_projections(x, (lin,))
+    assert not ops.bn_relu_pool_served(torch.zeros(1, 8, 4, 4)) and not ops.head_served(torch.zeros(1, 64, 4, 4), torch.nn.Conv2d(64, 2, 1))
