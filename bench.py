@@ -222,7 +222,7 @@ def run_train(args, world, rank, dev, steps, warmup):
                         "bf16 autocast, AdamW lr 1e-4",
             "clips_per_gpu": B, "frames_per_clip": T, "image": f"{S}x{S}",
             "sharding": f"DDP over {world} GPU(s): one gradient all-reduce per step (RCCL)" if world > 1
-                        else "one GPU: no gradient exchange (the one-rank RCCL path is tests/test_nccl_gpu.py)"}
+                        else "one GPU: no gradient exchange (the one-rank RCCL path is tests/test_zz_nccl_gpu.py)"}
 
 
 def bench_train(args, world, rank, dev):

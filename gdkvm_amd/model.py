@@ -56,11 +56,24 @@ def _bn(c):
     return nn.BatchNorm2d(c)
 
 
+# Bumped by weights_changed(): part of every weight-pack key.  Version counters alone do not see every write -- in-place writes through
+# ``.data`` bump nothing, and neither does torch.optim.AdamW(fused=True) (round 5) -- so whoever steps an optimiser says so here
+# (gdkvm_amd.train.train_step and GraphedTrainStep do).
+_WEIGHTS_EPOCH = [0]
+
+
+def weights_changed() -> None:
+    """Tell every packed-weight cache of the inference paths that parameters were written (an optimiser step): the packs are rebuilt on
+    their next use.  Cheap (a counter); call it after any write the version counters cannot show."""
+    _WEIGHTS_EPOCH[0] += 1
+
+
 def _wkey(*tensors):
-    """Cache key of a weight pack: version counter AND storage address of EVERY source tensor.  In-place writes through
-    ``.data`` (``p.data.copy_()``: EMA swaps, weight surgery) bump neither -- after such a write call
-    ``GDKVM.invalidate_packed_weights()`` (load_state_dict / .to() / train() / fuse_for_inference() do it themselves)."""
-    return tuple((t._version, t.data_ptr()) for t in tensors)
+    """Cache key of a weight pack: the weights epoch (weights_changed), and version counter AND storage address of EVERY source tensor.
+    In-place writes through ``.data`` (``p.data.copy_()``: EMA swaps, weight surgery) and fused optimiser steps bump no counter -- after
+    such a write call ``weights_changed()`` or ``GDKVM.invalidate_packed_weights()`` (load_state_dict / .to() / train() /
+    fuse_for_inference() do the latter themselves; train_step / GraphedTrainStep the former)."""
+    return (_WEIGHTS_EPOCH[0],) + tuple((t._version, t.data_ptr()) for t in tensors)
 
 
 _BN_COUNTED_BY_MODEL = [False]
@@ -494,10 +507,12 @@ class GDKVM(nn.Module):
         optimiser steps, ``load_state_dict`` and re-binding; an in-place write through ``.data`` changes neither, so code that
         does one must call this.  Called by load_state_dict(), _apply() (.to / .cuda / .half ...), train() and
         fuse_for_inference()."""
-        for name in ("_qkv_pack", "_gate_w32", "_kpff_pack"):
+        for name in ("_qkv_pack", "_gate_w32", "_kpff_pack", "_clip_graphs"):
             self.__dict__.pop(name, None)
-        for w in self.__dict__.pop("_train_pack_weights", None) or ():     # (the training step's per-weight packs, ops.conv3x3_train_packs)
-            ops._TRAIN_PACKS.pop(id(w), None)
+        # graphs captured over this module (GraphedSegment, GraphedTrainStep) hold the packs they read and compare this counter: a replay
+        # after the packs were dropped raises instead of convolving with the weights of capture time
+        self.__dict__["_pack_epoch"] = self.__dict__.get("_pack_epoch", 0) + 1
+        ops.drop_train_packs(self.__dict__.pop("_train_pack_weights", None) or ())     # (the training step's per-weight packs, ops.conv3x3_train_packs)
         if "_modules" not in self.__dict__:
             return
         dec = self._modules.get("decoder")
@@ -576,6 +591,7 @@ class GDKVM(nn.Module):
                 ws = self._train_pack_weights = [m.weight for m in self.modules() if isinstance(m, nn.Conv2d) and m.bias is None
                                                  and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and m.groups == 1
                                                  and m.weight.shape[0] % 64 == 0 and m.weight.shape[1] % 64 == 0]
+            # (EVERY training forward re-packs: nothing a cache could key on records a fused optimiser's step -- ops.conv3x3_train_packs)
             ops.conv3x3_train_packs([w for w in ws if w.is_cuda and w.dtype == torch.float32])
         counted = self.training and x.is_cuda
         if counted:                                                              # BatchNorm step counters: one launch, not 19
@@ -588,6 +604,7 @@ class GDKVM(nn.Module):
             return self._after_encoder(f4, f8, f16, mask0, state, return_state, _lowres, (B, T, H, W), _head_fused)
         finally:
             _BN_COUNTED_BY_MODEL[0] = False
+            ops.end_train_packs()
 
     def _after_encoder(self, f4, f8, f16, mask0, state, return_state, _lowres, dims, _head_fused=False):
         cfg = self.cfg
@@ -779,8 +796,13 @@ class GDKVM(nn.Module):
             # module): the same kernels and the same bits as the loop below, without the host's launch calls between them -- a long clip is
             # many short forwards, which is where a slow host shows (round 4: 17.5 against 12.0 ms per 1024 frames between two boxes)
             cfg = self.cfg
-            key = (B, chunk_frames) + tuple(frames.shape[2:]) + (frames.dtype, target is not None, frames.device)
+            # (keyed on everything the captured kernels were chosen by: the shape, the recurrence and its segmenting, and the weight /
+            # pack epochs -- a graph reads the weight packs of capture time; invalidate_packed_weights() drops the whole cache)
+            key = (B, chunk_frames) + tuple(frames.shape[2:]) + (frames.dtype, target is not None, frames.device, cfg.rule, cfg.scan_segments,
+                                                                   _WEIGHTS_EPOCH[0], self.__dict__.get("_pack_epoch", 0))
             cache = self.__dict__.setdefault("_clip_graphs", {})
+            for old in [k_ for k_ in cache if k_[:-2] == key[:-2] and k_ != key]:
+                del cache[old]                              # the same shape under older weights: never replayed again
             if key not in cache:
                 s0 = torch.zeros((B, cfg.heads, cfg.key_dim, cfg.value_dim), dtype=torch.float32, device=frames.device)
                 cache[key] = GraphedSegment(self, frames[:, :chunk_frames].clone(), None if target is None else target[:, :chunk_frames].clone(), state=s0)
@@ -818,6 +840,20 @@ class GDKVM(nn.Module):
         return super().load_state_dict(remapped, strict=strict, **kw)
 
 
+def _packs_held(model: "GDKVM"):
+    """Every packed-weight tensor the module caches hold right now (what a captured graph reads by address)."""
+    held = [model.__dict__.get(n) for n in ("_qkv_pack", "_gate_w32", "_kpff_pack")]
+    dec = model._modules.get("decoder")
+    if dec is not None:
+        held.append(dec.__dict__.get("_head_w32"))
+    for m in model.modules():
+        if isinstance(m, FusedConv):
+            held.append(m.__dict__.get("_wpack"))
+    for p in model.parameters():
+        held.append(p.__dict__.get("_gdkvm_train_packs"))
+    return [h for h in held if h is not None]
+
+
 class GraphedSegment:
     """GDKVM.segment(frames, target) captured ONCE into a hipGraph and replayed (inference build, fixed clip shape): the same kernels in the
     same order with no host work between them -- a forward is ~25 launches for ~0.95 ms of GPU time, so a slow or busy host (one launch call
@@ -844,12 +880,20 @@ class GraphedSegment:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.out = model.segment(self.frames, self.target, **kw)
+        # The graph holds raw addresses of the weight packs the warm-up calls built OUTSIDE its memory pool: keep them alive here (a replay
+        # must never read freed memory), and remember the epochs they belong to -- a replay after the weights or packs changed would segment
+        # with the weights of capture time, so __call__ raises instead.
+        self._held = _packs_held(model)
+        self._epochs = (_WEIGHTS_EPOCH[0], model.__dict__.get("_pack_epoch", 0))
 
     def __call__(self, frames: torch.Tensor, target: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None):
         if (frames.shape != self.frames.shape or frames.dtype != self.frames.dtype or (target is None) != (self.target is None)
                 or (state is None) != (self.state is None)):
             raise RuntimeError(f"GraphedSegment was captured for frames {tuple(self.frames.shape)} {self.frames.dtype}"
                                f"{'' if self.target is None else ' with a target'}{'' if self.state is None else ' with a state'}")
+        if self._epochs != (_WEIGHTS_EPOCH[0], self.model.__dict__.get("_pack_epoch", 0)):
+            raise RuntimeError("GraphedSegment: the model's weights or weight packs changed since the capture (optimiser step, load_state_dict, "
+                               ".to(), train() / eval()): the graph reads the packs of capture time -- capture a new one")
         if frames.data_ptr() != self.frames.data_ptr():
             self.frames.copy_(frames, non_blocking=True)
         if target is not None and target.data_ptr() != self.target.data_ptr():

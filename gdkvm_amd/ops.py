@@ -942,34 +942,40 @@ def _zero_bias(k: int, device) -> torch.Tensor:
     return _ZERO_BIAS[key]
 
 
-_TRAIN_PACKS = {}            # id(weight) -> (key, forward pack, data-gradient pack): filled by conv3x3_train_packs, read by conv3x3
+# The training step's weight packs live ON the parameter (``w._gdkvm_train_packs``), not in a table keyed by id(): they go when the parameter
+# goes, and a new parameter that reuses the id / address of a dead one cannot inherit them.  They are valid only inside the PACK SCOPE they were
+# made for (``train_packs``: one forward of one model) -- NOT "until the version counter changes": torch.optim.AdamW(fused=True) writes the
+# parameters without bumping ``_version`` (round 5: keyed on the counter, the fourteen stride-1 3x3 layers kept convolving with their initial
+# weights under the fused optimiser, and the loss fell ~10x slower than under the default one).
+_PACK_SCOPE = [None]
+_PACK_TOKENS = [0]
 
 
 def conv3x3_train_packs(weights) -> int:
-    """Both packs (forward, data gradient) of every listed fp32 [K,C,3,3] weight in ONE launch (gdkvm_conv3x3_pack_weights_train),
-    kept until the weight changes (version counter / storage) -- call once per training step, before the forward; ops.conv3x3 then finds
-    its layer's packs here instead of casting and packing per layer (three launches per layer and step).  Weights whose packs are current
-    are skipped.  Returns the number of layers packed."""
+    """Both packs (forward, data gradient) of every listed fp32 [K,C,3,3] weight in ONE launch (gdkvm_conv3x3_pack_weights_train), into
+    buffers kept on the parameter; EVERY call re-packs every weight (a fused optimiser step leaves no trace a cache could key on) and opens a
+    new pack scope: ops.conv3x3 uses a weight's packs only while the scope of the call that made them is open (``end_train_packs`` closes it;
+    ``train_packs`` is the context-manager form).  Returns the number of layers packed."""
     lib = load()
     todo = []
+    _PACK_TOKENS[0] += 1
+    token = _PACK_TOKENS[0]
     for w in weights:
         k, c = w.shape[:2]
         if not (w.is_cuda and w.dtype == torch.float32 and w.dim() == 4 and tuple(w.shape[2:]) == (3, 3) and k % 64 == 0 and c % 64 == 0):
             continue
-        key = (w._version, w.data_ptr(), tuple(w.stride()))
-        ent = _TRAIN_PACKS.get(id(w))
-        if ent is None or ent[0] != key:
-            if ent is None or ent[1].numel() != k * 9 * c or ent[1].device != w.device:
-                ent = (None, torch.empty(k * 9 * c, dtype=torch.bfloat16, device=w.device), torch.empty(k * 9 * c, dtype=torch.bfloat16, device=w.device))
-            _TRAIN_PACKS[id(w)] = (key, ent[1], ent[2])
-            todo.append(w)
+        ent = w.__dict__.get("_gdkvm_train_packs")
+        if ent is None or ent[1].numel() != k * 9 * c or ent[1].device != w.device:
+            ent = (None, torch.empty(k * 9 * c, dtype=torch.bfloat16, device=w.device), torch.empty(k * 9 * c, dtype=torch.bfloat16, device=w.device))
+        w.__dict__["_gdkvm_train_packs"] = ((token, w._version, w.data_ptr(), tuple(w.stride())), ent[1], ent[2])
+        todo.append(w)
     for i0 in range(0, len(todo), 24):
         part = todo[i0:i0 + 24]
         n = len(part)
         P = ctypes.c_void_p * n
         wp = P(*[w.data_ptr() for w in part])
-        fp = P(*[_TRAIN_PACKS[id(w)][1].data_ptr() for w in part])
-        dp = P(*[_TRAIN_PACKS[id(w)][2].data_ptr() for w in part])
+        fp = P(*[w.__dict__["_gdkvm_train_packs"][1].data_ptr() for w in part])
+        dp = P(*[w.__dict__["_gdkvm_train_packs"][2].data_ptr() for w in part])
         ks = (ctypes.c_int * n)(*[w.shape[0] for w in part])
         cs = (ctypes.c_int * n)(*[w.shape[1] for w in part])
         st = (ctypes.c_longlong * (4 * n))(*[x for w in part for x in w.stride()])
@@ -979,12 +985,38 @@ def conv3x3_train_packs(weights) -> int:
                                                       ctypes.cast(ks, ctypes.c_void_p), ctypes.cast(cs, ctypes.c_void_p), ctypes.cast(st, ctypes.c_void_p),
                                                       _stream(dev))
         _check(rc, "gdkvm_conv3x3_pack_weights_train")
+    _PACK_SCOPE[0] = token
     return len(todo)
 
 
+def end_train_packs() -> None:
+    """Close the pack scope conv3x3_train_packs opened (the end of the forward it was opened for)."""
+    _PACK_SCOPE[0] = None
+
+
+class train_packs:
+    """``with ops.train_packs(weights): ...`` -- conv3x3_train_packs for the block, the scope closed at its end."""
+
+    def __init__(self, weights):
+        self.weights = list(weights)
+
+    def __enter__(self):
+        self.packed = conv3x3_train_packs(self.weights)
+        return self
+
+    def __exit__(self, *exc):
+        end_train_packs()
+        return False
+
+
+def drop_train_packs(weights) -> None:
+    for w in weights:
+        w.__dict__.pop("_gdkvm_train_packs", None)
+
+
 def _train_packs_of(weight):
-    ent = _TRAIN_PACKS.get(id(weight))
-    if ent is not None and ent[0] == (weight._version, weight.data_ptr(), tuple(weight.stride())):
+    ent = weight.__dict__.get("_gdkvm_train_packs")
+    if ent is not None and _PACK_SCOPE[0] is not None and ent[0] == (_PACK_SCOPE[0], weight._version, weight.data_ptr(), tuple(weight.stride())):
         return ent[1], ent[2]
     return None
 

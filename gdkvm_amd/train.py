@@ -74,6 +74,8 @@ def train_step(model: nn.Module, opt: torch.optim.Optimizer, frames: torch.Tenso
     loss = segmentation_loss_lowres(logits, target) if fused else segmentation_loss(logits, target)
     loss.backward()
     opt.step()
+    from .model import weights_changed
+    weights_changed()          # (fused optimisers write the parameters without bumping their version counters: the pack caches key on this too)
     return loss.detach()
 
 
@@ -106,7 +108,7 @@ class GraphedTrainStep:
     capturable (torch.optim.AdamW(..., fused=True, capturable=True)).  The first `warmup` steps run eagerly on a side stream (library
     convolutions pick their solvers, the HIP library sets its kernel attributes, the optimiser creates its state), then one step is
     captured; every call copies the batch into the graph's input buffers and replays -- same arithmetic, same order, same results as
-    train_step."""
+    train_step (tools/graph_step_diag.py prints both loss sequences side by side; tests/test_train_side_gpu.py asserts them equal)."""
 
     def __init__(self, model: nn.Module, opt: torch.optim.Optimizer, frames: torch.Tensor, target: torch.Tensor,
                  autocast_dtype: Optional[torch.dtype] = None, warmup: int = 3):
@@ -125,6 +127,12 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph):
             self.loss = train_step(model, opt, self.frames, self.target, autocast_dtype)
         self.eager_steps = max(1, warmup)       # optimiser steps taken before the first replay (the capture itself runs no kernel)
+        # the captured kernels address the per-weight packs (re-packed by the graph itself every replay) and other buffers the warm-up steps
+        # allocated outside the graph's pool: held here, so that GDKVM.invalidate_packed_weights() (an eval() / train() toggle between steps)
+        # cannot free what a replay writes
+        from .model import _packs_held
+        inner = getattr(model, "module", model)
+        self._held = _packs_held(inner) if hasattr(inner, "invalidate_packed_weights") else []
 
     def __call__(self, frames: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         if frames.shape != self.frames.shape or target.shape != self.target.shape:
@@ -134,4 +142,6 @@ class GraphedTrainStep:
         if target.data_ptr() != self.target.data_ptr():
             self.target.copy_(target, non_blocking=True)
         self.graph.replay()
-        return self.loss
+        from .model import weights_changed
+        weights_changed()
+        return self.loss.clone()                # (the graph's own output buffer is overwritten by the next replay)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Child process of tests/test_nccl_gpu.py: BASELINE.json configs[3] (DDP training over RCCL) as far as ONE GPU allows.
+"""Child process of tests/test_zz_nccl_gpu.py: BASELINE.json configs[3] (DDP training over RCCL) as far as ONE GPU allows.
 
 A one-rank ``nccl`` process group is legal on one GPU and runs the real RCCL code path: communicator set-up, DDP's reducer
 (bucket views, autograd hooks on the HIP autograd Functions, the all-reduce launch) and all_gather of device tensors.  The

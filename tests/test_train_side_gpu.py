@@ -463,53 +463,130 @@ def test_train_step_uses_the_fused_objective(hip):
         assert (ga[n] - p.grad).abs().max().item() <= 2e-3 * scale, n
 
 
+def _ellipse_batches(n, B, T, S, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    frames, target = [], []
+    for i in range(n):
+        cy, cx = S * (0.45 + 0.02 * i), S * (0.5 - 0.01 * i)
+        m = ((((yy - cy) / (S * 0.3)) ** 2 + ((xx - cx) / (S * 0.2)) ** 2) < 1)
+        tg = m.long().expand(B, T, S, S).contiguous()
+        fr = torch.rand(B, T, 3, S, S, generator=g) * 0.5 + 0.5 * m.float()            # the label is visible in the frames: a learnable batch
+        frames.append(fr.cuda()); target.append(tg.cuda())
+    return frames, target
+
+
 def test_training_step_captured_in_a_graph(hip):
-    """GraphedTrainStep (warm-up steps, one capture, then replays) against the eager train_step from the same start: the losses of the
-    steps and the weights after them agree to the run-to-run spread of the step itself (the strided / 1x1 layers' library gradients
-    accumulate atomically: two EAGER runs differ by as much); fresh batches go through the graph's input buffers."""
+    """GraphedTrainStep (warm-up steps, one capture, then replays) against the eager train_step from the same start, on a batch the model can
+    learn (the label's ellipse is visible in the frames) at lr 1e-3: the loss of EVERY step agrees, the loss falls by a real margin, the
+    weights end where the eager run's end -- and all of it also against the eager step under the DEFAULT (non-fused) AdamW, whose step bumps
+    the parameters' version counters where the fused one does not (round 5: weight packs keyed on the counter stayed at the initial weights
+    under the fused optimiser and the loss fell ~10x slower; with random labels and a bound wider than seven steps' movement the old form of
+    this test could not see it).  Fresh batches go through the graph's input buffers."""
     from gdkvm_amd.model import GDKVM, GDKVMConfig
     from gdkvm_amd.train import GraphedTrainStep, train_step
-    torch.manual_seed(21)
     cfg = GDKVMConfig()
-    frames = [torch.rand(2, 4, 3, 112, 112, device="cuda") for _ in range(6)]
-    target = [(torch.rand(2, 4, 112, 112, device="cuda") > 0.5).long() for _ in range(6)]
+    steps, lr = 8, 1e-3
+    frames, target = _ellipse_batches(steps + 1, 4, 4, 112, 21)
 
-    def run(graphed):
+    def run(kind):
         torch.manual_seed(22)
         model = GDKVM(cfg).cuda().train().to(memory_format=torch.channels_last)
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True, capturable=True)
+        w0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+        kw = {} if kind == "default" else {"fused": True, "capturable": True}
+        opt = torch.optim.AdamW(model.parameters(), lr=lr, **kw)
         losses = []
-        if graphed:
+        if kind == "graph":
             # the warm-up steps and the captured one all see batch 0; replays then take batches 1 ..
             step = GraphedTrainStep(model, opt, frames[0], target[0], torch.bfloat16, warmup=2)
-            for i in range(1, 6):
-                losses.append(step(frames[i], target[i]).item())
+            for i in range(1, steps + 1):
+                losses.append(step(frames[i], target[i]))
+            assert len({l.data_ptr() for l in losses}) == len(losses)        # (each call hands back its own loss tensor, not the graph's buffer)
+            losses = [l.item() for l in losses]
         else:
             for _ in range(2):
                 train_step(model, opt, frames[0], target[0], torch.bfloat16)
-            for i in range(1, 6):
+            for i in range(1, steps + 1):
                 losses.append(train_step(model, opt, frames[i], target[i], torch.bfloat16).item())
-        return losses, {n: p.detach().clone() for n, p in model.named_parameters()}
+        return losses, w0, {n: p.detach().clone() for n, p in model.named_parameters()}
 
-    le, we = run(False)
-    le2, we2 = run(False)
-    lg, wg = run(True)
-    spread = max(max(abs(a - b) for a, b in zip(le, le2)), 1e-4)
-    assert all(abs(a - b) <= 20 * spread + 2e-3 for a, b in zip(le, lg)), (le, lg, spread)
-    assert lg[-1] < lg[0] + 0.05                                  # (it trains: five steps of lr 1e-4 do not blow up)
-    for n in we:
-        d_eager = (we[n] - we2[n]).abs().max().item()
-        assert (we[n] - wg[n]).abs().max().item() <= max(20 * d_eager, 8e-4), n      # seven AdamW steps of lr 1e-4 move a weight by <= 7e-4
+    ld, w0, wd = run("default")
+    lf, _, wf = run("fused")
+    lg, _, wg = run("graph")
+    print("default", ld, "fused", lf, "graph", lg)
+    assert ld[-1] < ld[0] - 0.15, ld                               # it learns: a real margin, not noise
+    # every step's loss agrees to a small fraction of the whole descent (two runs of the SAME kind differ by ~0.008 at this learning rate: the
+    # strided layers' library gradients accumulate atomically; packs stuck at the initial weights left the loss ~0.15 behind by the last step)
+    tol = 0.08 * max(ld[0] - ld[-1], 0.15) + 3e-3
+    for a, b, c in zip(ld, lf, lg):
+        assert abs(a - b) <= tol and abs(a - c) <= tol, (ld, lf, lg)
+    for n in wd:
+        moved = (wd[n] - w0[n]).abs().max().item()
+        if moved < 2e-3:
+            continue                                               # (mask_embed: no gradient to speak of)
+        # ten AdamW steps of lr 1e-3 took this weight from w0 to wd; the other two runs end near it, measured against that journey in the L2
+        # norm (single elements are chaotic under Adam: a tiny gradient that changes sign moves its weight by a full step the other way)
+        journey = (wd[n] - w0[n]).norm().item()
+        assert (wd[n] - wf[n]).norm().item() <= 0.6 * journey, n
+        assert (wd[n] - wg[n]).norm().item() <= 0.6 * journey, n
     with pytest.raises(RuntimeError):
         GraphedTrainStep(GDKVM(cfg).train(), None, torch.rand(1, 2, 3, 112, 112), torch.zeros(1, 2, 112, 112, dtype=torch.long))
+
+
+def test_graphs_survive_or_refuse_a_weight_change(hip):
+    """What a captured graph reads by address stays alive and current: a GraphedSegment replayed after the weights changed raises (it would
+    segment with the packs of capture time); segment_clip(graph=True) captures anew; a GraphedTrainStep replayed after an eval() / train()
+    toggle (which drops the module's pack caches) still trains like the eager step, because it holds the packs it re-packs into."""
+    from gdkvm_amd.model import GDKVM, GDKVMConfig, weights_changed
+    from gdkvm_amd.train import GraphedTrainStep, train_step
+    torch.manual_seed(5)
+    model = GDKVM(GDKVMConfig()).cuda().eval().to(torch.bfloat16).to(memory_format=torch.channels_last).fuse_for_inference()
+    fr = torch.rand(1, 4, 3, 112, 112, device="cuda").bfloat16()
+    gseg = model.graphed_segment(fr)
+    m0 = gseg(fr)[0].clone()
+    assert torch.equal(m0, model.segment(fr)[0])
+    mc0 = model.segment_clip(fr, 2, graph=True)[0]
+    with torch.no_grad():
+        model.decoder.head.bias.mul_(-1.0)                         # (a plain in-place write: the version counter shows it)
+        model.decoder.head.weight.data.mul_(-1.0)                  # (a write through .data: nothing shows it -- say so); logits -> -logits
+    weights_changed()
+    with pytest.raises(RuntimeError, match="changed since the capture"):
+        gseg(fr)
+    m1 = model.segment(fr)[0]
+    mc1 = model.segment_clip(fr, 2, graph=True)[0]                 # captured anew under the new weights
+    assert torch.equal(mc1, m1) and torch.equal(mc0, m0) and not torch.equal(m0, m1)
+    model.eval()                                                   # invalidate_packed_weights(): the old graph still refuses
+    with pytest.raises(RuntimeError, match="changed since the capture"):
+        gseg(fr)
+
+    frames, target = _ellipse_batches(5, 2, 4, 112, 9)
+    def run(graphed):
+        torch.manual_seed(23)
+        tm = GDKVM(GDKVMConfig()).cuda().train().to(memory_format=torch.channels_last)
+        opt = torch.optim.AdamW(tm.parameters(), lr=1e-3, fused=True, capturable=True)
+        step = GraphedTrainStep(tm, opt, frames[0], target[0], torch.bfloat16, warmup=2) if graphed else None
+        if not graphed:
+            for _ in range(2):
+                train_step(tm, opt, frames[0], target[0], torch.bfloat16)
+        out = []
+        for i in range(1, 5):
+            if i == 3:
+                tm.eval(); tm.train()                              # a validation pass between steps: every pack cache of the module is dropped
+                junk = [torch.empty(1 << 22, device="cuda").normal_() for _ in range(8)]       # (and the allocator hands its blocks out again)
+                del junk
+            out.append((step(frames[i], target[i]) if graphed else train_step(tm, opt, frames[i], target[i], torch.bfloat16)).item())
+        return out
+    le, lg = run(False), run(True)
+    print(le, lg)
+    assert all(abs(a - b) <= 0.08 * max(abs(le[0] - le[-1]), 0.15) + 3e-3 for a, b in zip(le, lg)), (le, lg)
 
 
 def test_training_weight_packs_in_one_launch(hip):
     """ops.conv3x3_train_packs: the forward and the data-gradient pack of several layers from their fp32 master weights in ONE launch
     (gdkvm_conv3x3_pack_weights_train) are, bit for bit, what the per-layer sequence produces -- cast to bf16, gdkvm_conv3x3_pack_weights,
     gdkvm_conv3x3_pack_weights_dgrad -- for contiguous and channels_last weights; ops.conv3x3 with the packs in place gives the same output
-    and the same gradients as without them; a changed weight is re-packed, an unchanged one is not."""
-    import ctypes
+    and the same gradients as without them; EVERY call re-packs (a write that bumps no version counter -- a fused optimiser's step, a write
+    through .data -- is picked up), and the packs are used only inside the scope of the call that made them."""
     from gdkvm_amd import ops
     lib = ops.load()
     torch.manual_seed(3)
@@ -518,27 +595,43 @@ def test_training_weight_packs_in_one_launch(hip):
     ws[1] = ws[1].contiguous(memory_format=torch.channels_last)
     ws[3] = ws[3].contiguous(memory_format=torch.channels_last)
     ws = [torch.nn.Parameter(w) for w in ws]
-    assert ops.conv3x3_train_packs(ws) == len(ws) and ops.conv3x3_train_packs(ws) == 0
-    for w in ws:
+
+    def reference_packs(w):
         k, c = w.shape[:2]
         wb = w.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         f0 = torch.empty(k * 9 * c, dtype=torch.bfloat16, device="cuda"); d0 = torch.empty_like(f0)
         assert lib.gdkvm_conv3x3_pack_weights(wb.data_ptr(), f0.data_ptr(), k, c, ops.BF16, None) == 0
         assert lib.gdkvm_conv3x3_pack_weights_dgrad(wb.data_ptr(), d0.data_ptr(), k, c, ops.BF16, None) == 0
+        return f0, d0
+
+    assert ops.conv3x3_train_packs(ws) == len(ws) and ops.conv3x3_train_packs(ws) == len(ws)
+    for w in ws:
+        f0, d0 = reference_packs(w)
         f1, d1 = ops._train_packs_of(w)
         torch.cuda.synchronize()
-        assert torch.equal(f0.view(torch.int16), f1.view(torch.int16)) and torch.equal(d0.view(torch.int16), d1.view(torch.int16)), (k, c)
+        assert torch.equal(f0.view(torch.int16), f1.view(torch.int16)) and torch.equal(d0.view(torch.int16), d1.view(torch.int16)), tuple(w.shape)
+    ops.end_train_packs()
+    assert all(ops._train_packs_of(w) is None for w in ws)         # outside the scope nothing is trusted
     # the differentiable op with and without the packs
     w = ws[1]
     x = torch.randn(4, 64, 14, 14, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_()
     gy = torch.randn(4, 128, 14, 14, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
-    y1 = ops.conv3x3(x, w); g1 = torch.autograd.grad(y1, (x, w), gy)
-    ops._TRAIN_PACKS.pop(id(w))
+    with ops.train_packs(ws):
+        assert ops._train_packs_of(w) is not None
+        y1 = ops.conv3x3(x, w); g1 = torch.autograd.grad(y1, (x, w), gy)
     y0 = ops.conv3x3(x, w); g0 = torch.autograd.grad(y0, (x, w), gy)
     assert torch.equal(y0, y1) and torch.equal(g0[0], g1[0]) and torch.equal(g0[1], g1[1])
-    with torch.no_grad():
-        ws[0].mul_(0.5)
-    assert ops.conv3x3_train_packs(ws) == 2                        # the rescaled one and the one dropped above
+    # a write no version counter records (what torch.optim.AdamW(fused=True) does to every parameter): the next call packs the new values
+    v0 = ws[0]._version
+    ws[0].data.mul_(0.5)
+    assert ws[0]._version == v0
+    with ops.train_packs(ws):
+        f0, d0 = reference_packs(ws[0])
+        f1, d1 = ops._train_packs_of(ws[0])
+        torch.cuda.synchronize()
+        assert torch.equal(f0.view(torch.int16), f1.view(torch.int16)) and torch.equal(d0.view(torch.int16), d1.view(torch.int16))
+    ops.drop_train_packs(ws)
+    assert all("_gdkvm_train_packs" not in w.__dict__ for w in ws)
 
 
 @pytest.mark.parametrize("case", [(3, 3, 112, 112), (2, 1, 64, 48), (1, 4, 130, 118), (9, 3, 20, 256)])
