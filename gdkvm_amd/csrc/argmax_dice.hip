@@ -147,11 +147,13 @@ __global__ __launch_bounds__(256) void upsample_argmax_dice_kernel(UpArgs a)
     // Head fused in: `logits` is the NHWC decoder FEATURE, which the unstaged taps below would read as NCHW class planes (in bounds,
     // wrong values).  The host computes lr_cap with THIS arithmetic for every block of the launch (up_src_host: the same fp32
     // operations) and refuses the call with GDKVM_ERR_SHAPE when a band does not fit the LDS tile, so the condition cannot hold here;
-    // a block that met it anyway writes nothing (GDKVM_DEBUG_TRAPS builds: it faults).
+    // a block that met it anyway fails LOUDLY in its output: every mask byte of its range becomes 255 (no class has that index, so the
+    // mask is visibly wrong and its Dice counts stay zero) instead of whatever torch.empty held (GDKVM_DEBUG_TRAPS builds: it faults).
     if (a.hw_ && !staged) {
 #ifdef GDKVM_DEBUG_TRAPS
         __builtin_trap();
 #endif
+        for (int p = q_lo * PX + (int)threadIdx.x; p < q_hi * PX; p += 256) a.mask[(size_t)f * HW + p] = 255;
         return;
     }
     if (staged && a.hw_) {

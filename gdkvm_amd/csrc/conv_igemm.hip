@@ -23,7 +23,7 @@
 
 namespace {
 
-constexpr int IG_TN = 128;                       // workgroup tile: channels (pixels: the template parameter TM)
+constexpr int IG_TN = 128;                       // workgroup tile: channels (pixels: the template parameter TM); the data-gradient form also 64
 #ifndef IG_WAVES_N
 #define IG_WAVES_N 4
 #endif
@@ -45,6 +45,13 @@ struct IgArgs {
     const bf16_t* w2; const float* bias2; bf16_t* y2; int centre;   // optional second output: the 1x1 convolution (same stride, K channels,
                                                  // bias2 may be NULL) of the window's centre pixel -- tap index `centre` -- with pack w2
     float inv_cps, inv_s;                        // per-k-step index arithmetic without integer division (see conv3x3_tile.hip: ct_div)
+    // ---- data-gradient form (template parameter DG; training, stride 2): x = dy [N, H, W, C] is the gradient of the forward's OUTPUT
+    // (C = the forward's output channels), y = dx [N, OH, OW, K] the gradient of its input.  Input pixel (2a + ph, 2b + pw) receives
+    // the taps whose parity matches: blockIdx.z = 2 ph + pw is that class, a plain stride-1 convolution of dy with (1 + ph)(1 + pw)
+    // taps at (a + r', b + s') -- no products with zeros -- and class (0, 0), whose only tap is the forward window's centre, takes the
+    // 1x1 / stride-2 downsample branch's gradient x2 (same shape as x) as ksteps_all - ksteps_main more k-steps of the same sum.
+    struct Cls { const bf16_t* w; int S, ksteps_main, ksteps_all; float inv_s; } cls[4];
+    const bf16_t* x2; int OH, OW;
 };
 
 __device__ __forceinline__ int ig_div(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }
@@ -61,11 +68,11 @@ __device__ __forceinline__ void ig_static_for(F&& f)
 // TM = pixels per workgroup (128); SUB = 32-deep MFMA k-steps
 // per barrier: with C a multiple of 64 a step gathers 128-byte channel runs (two MFMA k-steps: half the barriers, LDS round trips
 // and index arithmetic per MFMA); SUB = 1 serves channel counts that are only multiples of 32.
-template <int TM, int SUB>
+template <int TM, int SUB, int TN = IG_TN, int WN = IG_WAVES_N, bool DG = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
 {
-    constexpr int WN = IG_WAVES_N;               // waves along the channels (4 / WN along the pixels)
-    constexpr int NTW = IG_TN / 16 / WN;         // 16-channel tiles per wave
+    // WN = waves along the channels (4 / WN along the pixels)
+    constexpr int NTW = TN / 16 / WN;            // 16-channel tiles per wave
     constexpr int MT = TM / 16 / (4 / WN);       // 16-pixel tiles per wave
     constexpr int PITCH = SUB == 2 ? 160 : 80;   // bytes between pixel rows of the LDS tile: 128 + 32 or 64 + 16 (conflict-free ds_read_b128)
     constexpr int PPP = 4 * SUB;                 // 16-byte pieces per pixel and step
@@ -75,8 +82,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
     __shared__ __attribute__((aligned(16))) unsigned char s_a[2][TM * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w / WN, wn = w % WN;
-    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * IG_TN;
-    const int nsteps = a.ksteps / SUB;           // steps of 32 SUB products
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    const int cls = DG ? (int)blockIdx.z : 0;
+    const int S_ = DG ? a.cls[cls].S : a.S;
+    const float inv_s_ = DG ? a.cls[cls].inv_s : a.inv_s;
+    const int nsteps = (DG ? a.cls[cls].ksteps_all : a.ksteps) / SUB;           // steps of 32 SUB products
+    const int main_steps = DG ? a.cls[cls].ksteps_main / SUB : nsteps;          // (DG: the steps after these gather from x2, tap (0, 0))
+    const ptrdiff_t x2_diff = DG && a.x2 ? a.x2 - a.x : 0;
 
     // ---- gather geometry: piece q = 256 u + tid is 16-byte part q % PPP of the channel run of tile pixel q / PPP: PPP lanes share a
     //      run, a wave instruction touches 64 / PPP runs ----------------------------------------------------------------------------
@@ -100,7 +112,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
     const int spt = a.cps / SUB;                 // steps per tap
     const float inv_spt = a.inv_cps * (float)SUB;
     auto gather = [&](int st, uint4 (&d)[GP], unsigned& okm) __attribute__((always_inline)) {
-        const int tap = ig_div(st, inv_spt), c0 = (st - tap * spt) * 32 * SUB, r = ig_div(tap, a.inv_s), s = tap - r * a.S;
+        const bool second = DG && st >= main_steps;
+        const int stm = second ? st - main_steps : st;
+        const int tap = ig_div(stm, inv_spt), c0 = (stm - tap * spt) * 32 * SUB, r = ig_div(tap, inv_s_), s = tap - r * S_;
+        const ptrdiff_t src = second ? x2_diff : 0;
         okm = 0;
 #pragma unroll
         for (int u = 0; u < GP; ++u) {
@@ -110,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
 #ifdef IG_ABL_SAMEPIX                                          // ablation: every gather from one (cached) address
             d[u] = *reinterpret_cast<const uint4*>(a.x + 8 * (tid & 7));
 #else
-            d[u] = *reinterpret_cast<const uint4*>(g_base[u] + ((size_t)(ok ? iy : 0) * a.W + (ok ? ix : 0)) * a.C + c0);
+            d[u] = *reinterpret_cast<const uint4*>(g_base[u] + src + ((size_t)(ok ? iy : 0) * a.W + (ok ? ix : 0)) * a.C + c0);
 #endif
         }
     };
@@ -200,7 +215,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
                 const int p = m0 + 16 * MT * wm + 16 * mt + li;
                 if (p >= a.M) continue;
                 f32x4 v = acc[mt][nt] + b4;
-                const size_t o = (size_t)p * a.K + ch;
+                size_t o = (size_t)p * a.K + ch;
+                if constexpr (DG) {                        // pixel (n, ya, xb) of the dy grid -> input pixel (2 ya + ph, 2 xb + pw)
+                    const int pn = p / (a.Ho * a.Wo), prem = p - pn * a.Ho * a.Wo, ya = prem / a.Wo, xb = prem - ya * a.Wo;
+                    const int oy = 2 * ya + (cls >> 1), ox = 2 * xb + (cls & 1);
+                    if (oy >= a.OH || ox >= a.OW) continue; // (odd sizes: the last row / column of a class may not exist)
+                    o = (((size_t)pn * a.OH + oy) * a.OW + ox) * a.K + ch;
+                }
                 if (res) {
                     const uint2 rr = *reinterpret_cast<const uint2*>(res + o);
                     v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
@@ -213,9 +234,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
             }
         }
     };
-    run_pass(a.w, 0, nsteps, a.bias, a.res, a.y, a.relu);
-    IG_STAMP(15, 3);
-    if (a.w2) run_pass(a.w2, a.centre * spt, spt, a.bias2, nullptr, a.y2, 0);
+    if constexpr (DG) {
+        run_pass(a.cls[cls].w, 0, nsteps, nullptr, nullptr, a.y, 0);
+    } else {
+        run_pass(a.w, 0, nsteps, a.bias, a.res, a.y, a.relu);
+        IG_STAMP(15, 3);
+        if (a.w2) run_pass(a.w2, a.centre * spt, spt, a.bias2, nullptr, a.y2, 0);
+    }
 }
 
 // weights [K][R][S][C] (= [K][Kd]) -> [K / 16][Kd / 32][lane = 16 g + li][8]:  w[16 nt + li][32 ks + 8 g ..]
@@ -263,7 +288,7 @@ int gdkvm_conv_igemm_launch(const void* x, const void* wpacked, const float* bia
     if (Ho < 1 || Wo < 1) return 1;
     const long long M = (long long)N * Ho * Wo;
     if (M * (long long)(K > C ? K : C) > 0x7fffffffLL || (long long)N * H * W * C > 0x7fffffffLL || (long long)R * S * C / 32 > 65535) return 1;
-    IgArgs a;
+    IgArgs a{};
     a.x = static_cast<const bf16_t*>(x); a.w = static_cast<const bf16_t*>(wpacked); a.bias = bias;
     a.res = static_cast<const bf16_t*>(residual); a.y = static_cast<bf16_t*>(y);
     a.w2 = static_cast<const bf16_t*>(w2packed); a.bias2 = bias2; a.y2 = static_cast<bf16_t*>(y2); a.centre = (R / 2) * S + S / 2;
@@ -273,5 +298,40 @@ int gdkvm_conv_igemm_launch(const void* x, const void* wpacked, const float* bia
     const dim3 grid((unsigned)((M + 127) / 128), (unsigned)(K / IG_TN));
     if (C % 64 == 0) hipLaunchKernelGGL((conv_igemm_kernel<128, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<128, 1>), grid, dim3(256), 0, st, a);
+    return 0;
+}
+
+// internal entry used by gdkvm_conv_s2_dgrad (conv_s2_train.hip): the data gradient of a 3x3 / stride-2 / pad-1 convolution (+ the 1x1 /
+// stride-2 branch's, dy2 may be NULL) as the kernel's DG form.  dy, dy2 [N, Ho, Wo, Kf] bf16; dx [N, H, W, Cf]; packs: the four class packs
+// of gdkvm_conv_s2_pack_train, consecutive.  0 = launched, 1 = shape not covered.
+int gdkvm_conv_igemm_dgrad_launch(const void* dy, const void* dy2, const void* packs, void* dx, int N, int Cf, int H, int W, int Kf, hipStream_t st)
+{
+    if (Cf % 64 || Kf % 64 || N < 1 || H < 1 || W < 1) return 1;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long M = (long long)N * Ho * Wo;
+    if (M * Kf > 0x7fffffffLL || (long long)N * H * W * Cf > 0x7fffffffLL || 5LL * Kf / 32 > 65535) return 1;
+    IgArgs a{};
+    a.x = static_cast<const bf16_t*>(dy); a.x2 = static_cast<const bf16_t*>(dy2); a.y = static_cast<bf16_t*>(dx);
+    a.N = N; a.H = Ho; a.W = Wo; a.C = Kf; a.K = Cf; a.R = 1; a.S = 1; a.stride = 1; a.pad = 0; a.Ho = Ho; a.Wo = Wo; a.relu = 0;
+    a.OH = H; a.OW = W;
+    a.M = (int)M; a.cps = Kf / 32; a.ksteps = a.cps;
+    a.inv_cps = 1.0f / (float)a.cps; a.inv_s = 1.0f;
+    const bf16_t* wp = static_cast<const bf16_t*>(packs);
+    for (int c = 0; c < 4; ++c) {
+        const int ph = c >> 1, pw = c & 1, taps = (1 + ph) * (1 + pw);
+        a.cls[c].w = wp;
+        a.cls[c].S = 1 + pw;
+        a.cls[c].inv_s = 1.0f / (float)(1 + pw);
+        a.cls[c].ksteps_main = taps * a.cps;
+        a.cls[c].ksteps_all = (taps + (c == 0 && dy2 ? 1 : 0)) * a.cps;
+        wp += gdkvm_conv_s2_dgrad_pack_elems(Cf, Kf, c, dy2 != nullptr);
+    }
+    if (Cf % 128 == 0) {
+        const dim3 grid((unsigned)((M + 127) / 128), (unsigned)(Cf / 128), 4);
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 2, 128, 4, true>), grid, dim3(256), 0, st, a);
+    } else {
+        const dim3 grid((unsigned)((M + 127) / 128), (unsigned)(Cf / 64), 4);
+        hipLaunchKernelGGL((conv_igemm_kernel<128, 2, 64, 2, true>), grid, dim3(256), 0, st, a);
+    }
     return 0;
 }

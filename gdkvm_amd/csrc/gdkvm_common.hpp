@@ -24,6 +24,14 @@ static inline bool gdkvm_aligned16(const void* p) { return (reinterpret_cast<uin
         if (e__ != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
     } while (0)
 
+// elements of the data-gradient weight pack of parity class cls = 2 ph + pw of a 3x3 / stride-2 layer (conv_s2_train.hip): (1 + ph)(1 + pw)
+// taps of Kf x Cf weights, class 0 one more when the block's 1x1 downsample branch rides along
+__host__ __device__ static inline size_t gdkvm_conv_s2_dgrad_pack_elems(int Cf, int Kf, int cls, int with_down)
+{
+    const int taps = (1 + (cls >> 1)) * (1 + (cls & 1)) + (cls == 0 && with_down ? 1 : 0);
+    return (size_t)taps * Kf * Cf;
+}
+
 // ---- device side -----------------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t u) { return __uint_as_float(((unsigned)u) << 16); }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f)

@@ -14,7 +14,11 @@
 namespace {
 
 struct GemmArgs { const void* a; const void* b; void* c; float* part; const float* bias; int M, N, K, K1, rows_per_split, splits;
-                  float* part_cs; };   // TN: optional partial column sums of A, [splits][K1] (the bias gradient of a token-major product)
+                  float* part_cs;      // TN: optional partial column sums of A, [splits][K1] (the bias gradient of a token-major product)
+                  // TN, CONV form (the weight gradient of a strided convolution): row m of B is not stored -- it is pixel
+                  // (n, yo * stride - pad + r, xo * stride - pad + s) of the NHWC tensor b [cN, cH, cW, cC] for m = (n, yo, xo) on the
+                  // cHo x cWo output grid and column tile n0 = tap * cC + c0 (zeros outside the image): C = dy^T im2col(x) with no im2col
+                  int cH, cW, cC, cHo, cWo, cS, cstride, cpad; };
 
 // ---- NT: workgroup tile 128 (M) x 64 (N); wave w owns rows 32w .. 32w+31 and all 64 columns: 2 x 4 accumulator tiles.  The
 // product is computed transposed (C^T = B A^T: the weight rows are the A operand) so that a lane ends with four consecutive
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p)
 // back through ds_read_b64_tr_b16 with the row index as the MFMA k index.  fp32: 16-row steps, plain LDS reads, exact MFMA.
 constexpr int TN_ROWS = 32;
 
-template <int IO>
+template <int IO, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p)
 {
     constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
@@ -135,6 +139,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p)
     constexpr int PER = (PIECES + 255) / 256, CPR = 64 * ESZ / 16;     // pieces per thread, chunks per row
     constexpr int EPC = 16 / ESZ;                          // elements per chunk
     uint4 ra[PER], rb[PER];
+    // CONV: this tile's tap (r, s) and first channel -- N = taps * cC and cC is a multiple of 64, so a 64-column tile lies in one tap
+    const int tap = CONV ? n0 / p.cC : 0, tap_r = CONV ? tap / p.cS : 0, tap_s = CONV ? tap - tap_r * p.cS : 0, cc0 = CONV ? n0 - tap * p.cC : 0;
     auto fetch = [&](int r0) {
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
@@ -144,7 +150,15 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p)
             if (pc < PIECES && m < r_hi) {
                 const int ka = k0 + c * EPC, nb = n0 + c * EPC;
                 if (ka + EPC <= K1) ra[u] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.a) + ((size_t)m * K1 + ka) * ESZ);
-                if (nb + EPC <= N) rb[u] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.b) + ((size_t)m * N + nb) * ESZ);
+                if constexpr (CONV) {
+                    const int hw = p.cHo * p.cWo, gn = m / hw, rem = m - gn * hw, yo = rem / p.cWo, xo = rem - yo * p.cWo;
+                    const int iy = yo * p.cstride - p.cpad + tap_r, ix = xo * p.cstride - p.cpad + tap_s;
+                    if ((unsigned)iy < (unsigned)p.cH && (unsigned)ix < (unsigned)p.cW)
+                        rb[u] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.b) +
+                                                                ((((size_t)gn * p.cH + iy) * p.cW + ix) * p.cC + cc0 + c * EPC) * ESZ);
+                } else {
+                    if (nb + EPC <= N) rb[u] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.b) + ((size_t)m * N + nb) * ESZ);
+                }
             }
         }
     };
@@ -244,6 +258,25 @@ __global__ void gemm_reduce_kernel(const float* part, float* c, size_t n, int sp
     }
 }
 
+// The split sums of the CONV form, written where the parameter's gradient lives: part [splits][K][taps][C] -> dw[k sk + c sc + tap_r sr + tap_s ss]
+// (element strides: any memory format of a [K, C, R, S] parameter), same fixed summation order as gemm_reduce_kernel.
+__global__ void conv_wgrad_reduce_kernel(const float* part, float* dw, int K, int C, int R, int S, int splits,
+                                         long long sk, long long sc, long long sr, long long ss)
+{
+    const size_t n = (size_t)K * R * S * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 8 <= splits; z += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s8[j] += part[(size_t)(z + j) * n + i];
+        for (int j = 0; z < splits; ++z, ++j) s8[j] += part[(size_t)z * n + i];
+        const int c = (int)(i % C), tap = (int)((i / C) % (R * S)), k = (int)(i / ((size_t)C * R * S));
+        dw[(long long)k * sk + (long long)c * sc + (long long)(tap / S) * sr + (long long)(tap % S) * ss] =
+            ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    }
+}
+
 int check_gemm(const char* fn, int M, int N, int K, int io_dtype)
 {
     if (M < 0 || N < 0 || K < 0) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: negative dimension (M=%d N=%d K=%d)", fn, M, N, K);
@@ -328,4 +361,53 @@ extern "C" int gdkvm_gemm_tn_colsum(const void* a, const void* b, float* c, floa
 {
     if (!colsum) return gdkvm_fail(GDKVM_ERR_ARG, "gemm_tn_colsum: null pointer");
     return gemm_tn_impl("gemm_tn_colsum", a, b, c, colsum, workspace, workspace_bytes, M, K1, N, io_dtype, stream);
+}
+
+// ---- weight gradient of a strided convolution (training; SURVEY.md §8 row a7's neighbours: the two 3x3 / stride-2 layers and the two
+// 1x1 / stride-2 downsample branches of the encoder, the last layers whose gradients were library kernels with atomic sums):
+//   dw[k][c][r][s] = sum over (n, yo, xo) dy[n, yo, xo, k] * x[n, yo stride - pad + r, xo stride - pad + s, c]
+// as gemm_tn's CONV form: the rows of the batch are split over workgroups (2048 per split) into fp32 partial tiles, summed in a fixed order.
+static int cw_splits(long long M) { const long long s = (M + 2047) / 2048; return (int)(s < 1 ? 1 : s); }
+
+extern "C" size_t gdkvm_conv_wgrad_strided_workspace_bytes(int N, int C, int H, int W, int K, int R, int S, int stride, int pad)
+{
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return 16;
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    if (Ho < 1 || Wo < 1) return 16;
+    return (size_t)cw_splits((long long)N * Ho * Wo) * K * R * S * C * sizeof(float);
+}
+
+extern "C" int gdkvm_conv_wgrad_strided(const void* x, const void* dy, float* dw, long long sk, long long sc, long long sr, long long ss,
+                                        void* workspace, size_t workspace_bytes,
+                                        int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int io_dtype, void* stream)
+{
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "conv_wgrad_strided: only bf16 is implemented");
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0 || C % 64 || K % 8)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_wgrad_strided: N=%d C=%d H=%d W=%d K=%d %dx%d stride %d pad %d (C a multiple of 64, K of 8)",
+                          N, C, H, W, K, R, S, stride, pad);
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    if (Ho < 1 || Wo < 1) return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_wgrad_strided: empty output grid");
+    const long long M = (long long)N * Ho * Wo;
+    if (M > 0x7fffffffLL || (long long)N * H * W * C > 0x7fffffffLL || M * K > 0x7fffffffLL)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_wgrad_strided: tensor too large for 32-bit offsets");
+    if (!dw || (N > 0 && (!x || !dy || !gdkvm_aligned16(x) || !gdkvm_aligned16(dy)))) return gdkvm_fail(GDKVM_ERR_ARG, "conv_wgrad_strided: null or unaligned pointer");
+    if (int rc = gdkvm_check_device()) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int taps = R * S;
+    const size_t n = (size_t)K * taps * C;
+    const int splits = N == 0 ? 0 : cw_splits(M);
+    if (N > 0) {
+        const size_t need = (size_t)splits * n * sizeof(float);
+        if (!workspace || !gdkvm_aligned16(workspace) || workspace_bytes < need)
+            return gdkvm_fail(GDKVM_ERR_WORKSPACE, "conv_wgrad_strided: workspace %zu < %zu bytes", workspace_bytes, need);
+        const int rows = (int)(((M + splits - 1) / splits + TN_ROWS - 1) / TN_ROWS * TN_ROWS);
+        GemmArgs ga{dy, x, nullptr, static_cast<float*>(workspace), nullptr, (int)M, taps * C, 0, K, rows, splits, nullptr, H, W, C, Ho, Wo, S, stride, pad};
+        const dim3 grid((unsigned)((K + 63) / 64), (unsigned)(taps * C / 64), (unsigned)splits);
+        hipLaunchKernelGGL((gemm_tn_kernel<GDKVM_BF16, true>), grid, dim3(256), 0, st, ga);
+        GDKVM_LAUNCH_CHECK("gemm_tn_kernel<conv>");
+    }
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const float*>(workspace), dw, K, C, R, S, splits, sk, sc, sr, ss);
+    GDKVM_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
+    return GDKVM_OK;
 }

@@ -9,8 +9,8 @@ query_proj.* / value_proj.* / gate_proj.* / kpff.* / decoder.*`` and one ``_KEY_
 The memory path between encoder and decoder -- LKVA read, GDR write, KPFF -- is ``ops.scan_fwd`` / ``ops.kpff_fwd``
 (hand-written HIP behind include/gdkvm.h).  The CNN either side of it is hand-written too in the
 inference build (``fuse_for_inference()``: every convolution runs on csrc/conv3x3_*.hip, conv_igemm.hip, stem_conv_pool.hip
-with its epilogue inside); the training build keeps torch / MIOpen for the strided 3x3 and the 1x1 layers only (the stem's convolution and weight gradient are
-hand-written since round 4).  There is no
+with its epilogue inside); the training build runs every convolution of the default model on hand-written kernels too since round 5 (the
+stem since round 4; the two strided blocks on csrc/conv_s2_train.hip), forward and backward, deterministically.  There is no
 eager fallback for the memory path: on a CPU tensor or without libgdkvm_hip.so the forward raises.
 """
 from __future__ import annotations
@@ -94,6 +94,8 @@ _STEM_BN_POOL = os.environ.get("GDKVM_STEM_BN_POOL", "1") != "0"
 _TRAIN_HEAD_HIP = os.environ.get("GDKVM_TRAIN_HEAD_HIP", "1") != "0"
 # training: a residual block's input as two outputs of its first convolution's node (ops.conv3x3_fork); "0" = the framework adds the gradients
 _TRAIN_CONV_FORK = os.environ.get("GDKVM_TRAIN_CONV_FORK", "1") != "0"
+# training: a strided block's 3x3 / stride-2 convolution + 1x1 branch on csrc/conv_s2_train.hip (deterministic); "0" = the library convolutions (A/B switch)
+_TRAIN_CONV_S2 = os.environ.get("GDKVM_TRAIN_CONV_S2", "1") != "0"
 # training: key / query / value / gate projections as one stacked product (ops.token_projections); "0" = one product each (A/B switch)
 _TRAIN_PROJ_STACKED = os.environ.get("GDKVM_TRAIN_PROJ_STACKED", "1") != "0"
 
@@ -158,6 +160,13 @@ class BasicBlock(nn.Module):
             y1, xs = ops.conv3x3_fork(x, self.conv1.weight)
             y = _bn_act(self.bn1, y1, True)
             return _bn_act(self.bn2, _conv(self.conv2, y), True, xs)
+        if (self.down is not None and _TRAIN_CONV_S2 and torch.is_grad_enabled() and isinstance(self.conv1, nn.Conv2d)
+                and isinstance(self.down[0], nn.Conv2d) and ops.conv_s2_block_served(x, self.conv1, self.down[0])):
+            # the strided convolution and the downsample branch as one node on the hand-written kernels (ops.conv_s2_block): one forward launch,
+            # one data-gradient launch for both branches, deterministic weight gradients
+            y1, yd = ops.conv_s2_block(x, self.conv1.weight, self.down[0].weight)
+            y = _bn_act(self.bn1, y1, True)
+            return _bn_act(self.bn2, _conv(self.conv2, y), True, _bn_act(self.down[1], yd, False))
         y = _bn_act(self.bn1, _conv(self.conv1, x), True)
         skip = x if self.down is None else _bn_act(self.down[1], self.down[0](x), False)
         return _bn_act(self.bn2, _conv(self.conv2, y), True, skip)

@@ -81,6 +81,11 @@ SIGNATURES = {
     "gdkvm_conv_igemm_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gdkvm_conv_down_bias_act": (_i, [_vp] * 4 + [_i] + [_vp] * 3 + [_i] * 10 + [_vp]),
     "gdkvm_conv_cat_bias_act": (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
+    "gdkvm_conv_s2_dgrad_pack_bytes": (_sz, [_i] * 3),
+    "gdkvm_conv_s2_pack_train": (_i, [_vp] * 7 + [_i, _i, _vp]),
+    "gdkvm_conv_s2_dgrad": (_i, [_vp] * 4 + [_i] * 6 + [_vp]),
+    "gdkvm_conv_wgrad_strided_workspace_bytes": (_sz, [_i] * 9),
+    "gdkvm_conv_wgrad_strided": (_i, [_vp] * 3 + [ctypes.c_longlong] * 4 + [_vp, _sz] + [_i] * 10 + [_vp]),
     "gdkvm_conv3x3_pack_weights_dgrad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "gdkvm_conv3x3_pack_weights_train": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gdkvm_conv3x3_wgrad_workspace_bytes": (_sz, [_i] * 5),
@@ -211,7 +216,7 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
         raise GdkvmError(f"bad shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
     if q.shape[-1] < KERNEL_DK and state_hist is None and q.shape[-1] % 8:      # key widths that are no multiple of 8: padded here
         qp, kp, sp = _pad_keys(q, k, state)                # (multiples of 8 below 64: gdkvm_scan_fwd zero-extends them itself)
-        r, s = scan_fwd(qp, kp, v, alpha, beta, sp, rule, flags, workspace, out, None, None, readout)
+        r, s = scan_fwd(qp, kp, v, alpha, beta, sp, rule, flags, workspace, out, None, None, readout, None, check)
         s = s[:, :, :q.shape[-1]].contiguous()
         if state_out is not None:
             state_out.copy_(s)
@@ -1140,6 +1145,122 @@ def conv3x3_fork(x: torch.Tensor, weight: torch.Tensor) -> Tuple[torch.Tensor, t
     feeds x' to its skip connection, and the skip's gradient is then added to the convolution's data gradient inside that kernel's
     epilogue (its residual input) instead of by the framework's add over two full tensors."""
     return _Conv3x3Function.apply(x, weight, True)
+
+
+_S2_WS = {}
+
+
+def conv_wgrad_strided(x: torch.Tensor, dy: torch.Tensor, weight_like: torch.Tensor, stride: int, pad: int) -> torch.Tensor:
+    """dW (fp32, in `weight_like`'s shape [K,C,R,S] AND memory format) of conv2d(x, w, stride, pad) from channels_last bf16 x [N,C,H,W] and
+    dy [N,K,Ho,Wo] (gdkvm_conv_wgrad_strided): any window / stride / pad, C a multiple of 64, K of 8; fixed-order sums -- the same bits on
+    every run."""
+    lib = load()
+    for t in (x, dy):
+        if t.dim() != 4 or not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous(memory_format=torch.channels_last):
+            raise GdkvmError("conv_wgrad_strided needs channels_last bf16 [N,C,H,W] device tensors (no CPU path)")
+    n, c, hh, ww = x.shape
+    k, c2, r, s_ = weight_like.shape
+    ho, wo = (hh + 2 * pad - r) // stride + 1, (ww + 2 * pad - s_) // stride + 1
+    if c2 != c or tuple(dy.shape) != (n, k, ho, wo):
+        raise GdkvmError(f"conv_wgrad_strided: x {tuple(x.shape)}, dy {tuple(dy.shape)} and weight {tuple(weight_like.shape)} do not fit stride {stride} pad {pad}")
+    dw = torch.empty_strided(tuple(weight_like.shape), tuple(weight_like.stride()), dtype=torch.float32, device=x.device)
+    need = max(16, int(lib.gdkvm_conv_wgrad_strided_workspace_bytes(n, c, hh, ww, k, r, s_, stride, pad)))
+    key = (x.device, _stream(x.device))
+    ws = _S2_WS.get(key)
+    if ws is None or ws.numel() < need:                     # one workspace per device and stream, grown to the largest layer (~30 MB)
+        ws = _S2_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
+    sk, sc, sr, ss = dw.stride()
+    with torch.cuda.device(x.device):
+        rc = lib.gdkvm_conv_wgrad_strided(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), sk, sc, sr, ss, ws.data_ptr(), ws.numel(),
+                                          n, c, hh, ww, k, r, s_, stride, pad, BF16, _stream(x.device))
+    _check(rc, "gdkvm_conv_wgrad_strided")
+    return dw
+
+
+def conv_s2_packs(weight: torch.Tensor, down_weight: Optional[torch.Tensor]):
+    """(forward pack, forward pack of the 1x1 branch | None, data-gradient pack) of a [K,C,3,3] fp32 weight and its block's [K,C,1,1] branch,
+    ONE launch from the master weights in whatever memory format they have (gdkvm_conv_s2_pack_train)."""
+    lib = load()
+    k, c = weight.shape[:2]
+    if weight.dtype != torch.float32 or tuple(weight.shape[2:]) != (3, 3) or not weight.is_cuda:
+        raise GdkvmError("conv_s2_packs: fp32 [K,C,3,3] device weight")
+    if down_weight is not None and (tuple(down_weight.shape) != (k, c, 1, 1) or down_weight.dtype != torch.float32 or down_weight.device != weight.device):
+        raise GdkvmError("conv_s2_packs: the branch weight must be fp32 [K,C,1,1] on the same device")
+    dev = weight.device
+    fwd = torch.empty(k * 9 * c, dtype=torch.bfloat16, device=dev)
+    fwd_d = None if down_weight is None else torch.empty(k * c, dtype=torch.bfloat16, device=dev)
+    dg = torch.empty(int(lib.gdkvm_conv_s2_dgrad_pack_bytes(c, k, int(down_weight is not None))) // 2, dtype=torch.bfloat16, device=dev)
+    st = (ctypes.c_longlong * 4)(*weight.stride())
+    sd = None if down_weight is None else (ctypes.c_longlong * 2)(*down_weight.stride()[:2])
+    with torch.cuda.device(dev):
+        rc = lib.gdkvm_conv_s2_pack_train(weight.data_ptr(), ctypes.cast(st, ctypes.c_void_p), _ptr(down_weight),
+                                          None if sd is None else ctypes.cast(sd, ctypes.c_void_p), fwd.data_ptr(), _ptr(fwd_d), dg.data_ptr(),
+                                          k, c, _stream(dev))
+    _check(rc, "gdkvm_conv_s2_pack_train")
+    return fwd, fwd_d, dg
+
+
+class _ConvS2BlockFunction(torch.autograd.Function):
+    """A residual block's 3x3 / stride-2 / pad-1 convolution and its 1x1 / stride-2 downsample branch as ONE autograd node on the hand-written
+    kernels (csrc/conv_s2_train.hip): (y, y_down) forward from one launch, one data-gradient launch for both branches (the framework would add
+    two full-size gradients of the block's input), two deterministic weight gradients.  bf16 activations, fp32 master weights."""
+
+    @staticmethod
+    def forward(ctx, x, weight, down_weight):
+        lib = load()
+        xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        n, c, hh, ww = xb.shape
+        k = weight.shape[0]
+        fwd, fwd_d, dg = conv_s2_packs(weight.detach(), down_weight.detach())
+        ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+        y = torch.empty((n, k, ho, wo), dtype=torch.bfloat16, device=xb.device, memory_format=torch.channels_last)
+        yd = torch.empty_like(y)
+        with torch.cuda.device(xb.device):
+            rc = lib.gdkvm_conv_down_bias_act(xb.data_ptr(), fwd.data_ptr(), _zero_bias(k, xb.device).data_ptr(), y.data_ptr(), 0, fwd_d.data_ptr(),
+                                              None, yd.data_ptr(), n, c, hh, ww, k, 3, 3, 2, 1, BF16, _stream(xb.device))
+        _check(rc, "gdkvm_conv_down_bias_act")
+        ctx.save_for_backward(xb, dg, weight, down_weight)
+        ctx.xdtype = x.dtype
+        return y, yd
+
+    @staticmethod
+    def backward(ctx, dy, dyd):
+        lib = load()
+        xb, dg, weight, down_weight = ctx.saved_tensors
+        n, c, hh, ww = xb.shape
+        k = weight.shape[0]
+        cl = torch.channels_last
+        dyb = dy.to(torch.bfloat16).contiguous(memory_format=cl)
+        dydb = dyd.to(torch.bfloat16).contiguous(memory_format=cl)
+        dx = dw = dwd = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(xb)
+            with torch.cuda.device(xb.device):
+                rc = lib.gdkvm_conv_s2_dgrad(dyb.data_ptr(), dydb.data_ptr(), dg.data_ptr(), dx.data_ptr(), n, c, hh, ww, k, BF16, _stream(xb.device))
+            _check(rc, "gdkvm_conv_s2_dgrad")
+            dx = dx.to(ctx.xdtype)
+        if ctx.needs_input_grad[1]:
+            dw = conv_wgrad_strided(xb, dyb, weight, 2, 1).to(weight.dtype)
+        if ctx.needs_input_grad[2]:
+            dwd = conv_wgrad_strided(xb, dydb, down_weight, 2, 0).to(down_weight.dtype)
+        return dx, dw, dwd
+
+
+def conv_s2_block_served(x: torch.Tensor, conv, down) -> bool:
+    """Does conv_s2_block serve this residual block's (3x3 / stride-2 convolution, 1x1 / stride-2 branch) pair on this input?"""
+    w = conv.weight
+    k, c = w.shape[:2]
+    return (x.is_cuda and x.dim() == 4 and conv.bias is None and down.bias is None and tuple(w.shape[2:]) == (3, 3)
+            and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
+            and conv.padding_mode == "zeros" and tuple(down.weight.shape) == (k, c, 1, 1) and tuple(down.stride) == (2, 2)
+            and tuple(down.padding) == (0, 0) and down.groups == 1 and c % 64 == 0 and k % 128 == 0
+            and w.dtype == torch.float32 and down.weight.dtype == torch.float32
+            and (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)))
+
+
+def conv_s2_block(x: torch.Tensor, weight: torch.Tensor, down_weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(conv2d(x, weight, stride 2, padding 1), conv2d(x, down_weight, stride 2)) in bf16, differentiable, deterministic."""
+    return _ConvS2BlockFunction.apply(x, weight, down_weight)
 
 
 def conv_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, residual: Optional[torch.Tensor] = None,

@@ -391,6 +391,29 @@ int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const v
 int gdkvm_conv_down_bias_act(const void* x, const void* w, const float* bias, void* y, int relu,
                              const void* w_down, const float* bias_down, void* y_down,
                              int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int io_dtype, void* stream);
+/* Training form of the same pair (a residual block's 3x3 / stride-2 / pad-1 convolution w [K, C, 3, 3] and its 1x1 / stride-2 branch
+ * w_down [K, C, 1, 1], both without bias), forward and backward on hand-written kernels, deterministic:
+ *   gdkvm_conv_s2_pack_train   ONE launch from the fp32 master weights (element strides (k, c, r, s) resp. (k, c): any memory format) to
+ *                              packed_fwd / packed_fwd_down (what gdkvm_conv_igemm_pack_weights makes of the bf16-rounded weights: feed
+ *                              them to gdkvm_conv_down_bias_act, stride 2, pad 1) and packed_dgrad (gdkvm_conv_s2_dgrad_pack_bytes).
+ *                              w_down may be NULL (no branch).  K a multiple of 128, C of 64.
+ *   gdkvm_conv_s2_dgrad        dx [N, H, W, C] = the gradient of x from dy [N, Ho, Wo, K] (and dy_down, same shape, or NULL), Ho = (H-1)/2+1:
+ *                              every input pixel sums exactly the taps that reach it (four parity classes, no products with zeros), the
+ *                              branch's gradient inside the same accumulation, one rounding to bf16.
+ *   gdkvm_conv_wgrad_strided   dw[k sk + c sc + r sr + s ss] (fp32, element strides: the parameter's own memory format) =
+ *                              sum_{n, yo, xo} dy[n, yo, xo, k] x[n, yo stride - pad + r, xo stride - pad + s, c]  for ANY R x S / stride /
+ *                              pad; C a multiple of 64, K of 8; the rows of the batch are summed in fixed-order splits (no atomics).
+ * (The reference's own recipe is a multi-process DDP launch, /root/reference/website/src/pages/[lang]/reprod/index.astro:238-249: with
+ * every gradient of the step deterministic, the DDP-wrapped step at world size 1 is bit-equal to the bare one.) */
+size_t gdkvm_conv_s2_dgrad_pack_bytes(int C, int K, int with_down);
+int gdkvm_conv_s2_pack_train(const float* w, const long long* w_strides, const float* w_down, const long long* w_down_strides,
+                             void* packed_fwd, void* packed_fwd_down, void* packed_dgrad, int K, int C, void* stream);
+int gdkvm_conv_s2_dgrad(const void* dy, const void* dy_down, const void* packed_dgrad, void* dx,
+                        int N, int C, int H, int W, int K, int io_dtype, void* stream);
+size_t gdkvm_conv_wgrad_strided_workspace_bytes(int N, int C, int H, int W, int K, int R, int S, int stride, int pad);
+int gdkvm_conv_wgrad_strided(const void* x, const void* dy, float* dw, long long sk, long long sc, long long sr, long long ss,
+                             void* workspace, size_t workspace_bytes,
+                             int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int io_dtype, void* stream);
 /* The same 3x3 / 1 / 1 convolution over the channel concatenation [x1 (C1 channels) ; x2 (C2)] of two NHWC tensors, which is
  * never materialised -- the decoder's  conv(cat(upsample(feature), skip))  without the concatenated copy.  C1, C2 multiples of
  * 64, K of 16, rows of <= 64 pixels; w [K, 3, 3, C1 + C2] or its packed copy (kernel | GDKVM_CONV_PACKED_WEIGHTS); kernel 0 or

@@ -662,3 +662,81 @@ def test_training_stem_convolution_on_the_stem_kernel(hip, case):
     wcl = torch.nn.Parameter(w.detach().clone().contiguous(memory_format=torch.channels_last))      # the gradient takes the parameter's memory format
     (dw3,) = torch.autograd.grad(ops.stem_conv(x, wcl), wcl, gy)
     assert dw3.stride() == wcl.stride() and torch.equal(dw3, dw)
+
+
+@pytest.mark.parametrize("case", [(3, 64, 128, 28, 28), (2, 128, 256, 14, 14), (2, 64, 128, 15, 13), (1, 128, 128, 7, 9), (5, 64, 256, 2, 2)])
+def test_strided_block_convolutions_forward_and_backward(hip, case):
+    """ops.conv_s2_block (csrc/conv_s2_train.hip): a residual block's 3x3 / stride-2 / pad-1 convolution and its 1x1 / stride-2 branch -- both
+    outputs, the gradient of the input (both branches in one accumulation, four parity classes) and both weight gradients against fp64 autograd
+    on the bf16-rounded operands; even and odd sizes; contiguous and channels_last parameters; the same bits on a second run."""
+    from gdkvm_amd import ops
+    n, c, k, hh, ww = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(n, c, hh, ww, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last).requires_grad_()
+    w = torch.nn.Parameter((torch.randn(k, c, 3, 3, device="cuda") / (9 * c) ** 0.5).contiguous(memory_format=torch.channels_last))
+    wd = torch.nn.Parameter(torch.randn(k, c, 1, 1, device="cuda") / c ** 0.5)
+    y, yd = ops.conv_s2_block(x, w, wd)
+    x64 = x.detach().double().requires_grad_()
+    w64, wd64 = w.detach().bfloat16().double().requires_grad_(), wd.detach().bfloat16().double().requires_grad_()
+    ry, ryd = F.conv2d(x64, w64, None, 2, 1), F.conv2d(x64, wd64, None, 2, 0)
+    assert y.shape == ry.shape and yd.shape == ryd.shape and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    for a, b in ((y, ry), (yd, ryd)):
+        assert (a.double() - b).abs().max() <= 2.0 ** -8 * max(1.0, b.abs().max().item())
+    gy, gyd = torch.randn_like(y), torch.randn_like(yd)
+    dx, dw, dwd = torch.autograd.grad((y, yd), (x, w, wd), (gy, gyd))
+    rdx, rdw, rdwd = torch.autograd.grad((ry, ryd), (x64, w64, wd64), (gy.double(), gyd.double()))
+    assert dx.dtype == torch.bfloat16 and dx.shape == x.shape
+    assert (dx.double() - rdx).abs().max() <= 2.0 ** -8 * max(1.0, rdx.abs().max().item())
+    rows = n * y.shape[2] * y.shape[3]
+    for a, b, p in ((dw, rdw, w), (dwd, rdwd, wd)):
+        assert a.dtype == torch.float32 and a.shape == p.shape and a.stride() == p.stride()       # the parameter's own memory format
+        assert (a.double() - b).abs().max() <= 2e-5 * max(1.0, b.abs().max().item()) * max(1.0, rows ** 0.5 / 64)
+    y2, yd2 = ops.conv_s2_block(x, w, wd)
+    g2 = torch.autograd.grad((y2, yd2), (x, w, wd), (gy, gyd))
+    assert torch.equal(y, y2) and torch.equal(yd, yd2) and all(torch.equal(a, b) for a, b in zip((dx, dw, dwd), g2))
+    # a contiguous (KCRS) parameter: the same numbers in its layout
+    wc = torch.nn.Parameter(w.detach().contiguous())
+    y3, yd3 = ops.conv_s2_block(x, wc, wd)
+    g3 = torch.autograd.grad((y3, yd3), (x, wc, wd), (gy, gyd))
+    assert torch.equal(y, y3) and torch.equal(g3[0], dx) and g3[1].stride() == wc.stride() and torch.equal(g3[1], dw)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 12, 10, 3, 1, 1), (3, 128, 40, 9, 9, 1, 2, 0), (1, 64, 72, 16, 16, 5, 2, 2), (2, 64, 64, 8, 8, 3, 3, 0)])
+def test_strided_weight_gradient_any_window(hip, case):
+    """ops.conv_wgrad_strided (gdkvm_conv_wgrad_strided) for windows / strides / paddings beyond the block's: against fp64 autograd."""
+    from gdkvm_amd import ops
+    n, c, k, hh, ww, r, stride, pad = case
+    torch.manual_seed(sum(case))
+    x = torch.randn(n, c, hh, ww, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    w64 = torch.randn(k, c, r, r, device="cuda", dtype=torch.float64, requires_grad=True)
+    ry = F.conv2d(x.double(), w64, None, stride, pad)
+    gy = torch.randn(ry.shape, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    (rdw,) = torch.autograd.grad(ry, w64, gy.double())
+    for like in (torch.empty(k, c, r, r, device="cuda"), torch.empty(k, c, r, r, device="cuda").contiguous(memory_format=torch.channels_last)):
+        dw = ops.conv_wgrad_strided(x, gy, like, stride, pad)
+        assert dw.stride() == like.stride()
+        assert (dw.double() - rdw).abs().max() <= 2e-5 * max(1.0, rdw.abs().max().item())
+
+
+def test_training_step_is_deterministic(hip):
+    """With the strided layers on the hand-written kernels no gradient of a training step accumulates atomically any more: two runs of the
+    same steps from the same start give the same losses and the same weights, bit for bit (what makes a DDP-wrapped step at world size 1
+    equal to the bare one: tests/test_zz_nccl_gpu.py)."""
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    from gdkvm_amd.train import train_step
+    frames, target = _ellipse_batches(3, 2, 4, 112, 33)
+
+    def run():
+        torch.manual_seed(34)
+        model = GDKVM(GDKVMConfig()).cuda().train().to(memory_format=torch.channels_last)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+        losses = [train_step(model, opt, frames[i], target[i], torch.bfloat16).item() for i in range(3)]
+        grads = {n_: p.grad.detach().clone() for n_, p in model.named_parameters()}
+        return losses, grads, {n_: p.detach().clone() for n_, p in model.named_parameters()}
+
+    l1, g1, w1 = run()
+    l2, g2, w2 = run()
+    assert l1 == l2, (l1, l2)
+    diff = [n_ for n_ in g1 if not torch.equal(g1[n_], g2[n_])]
+    assert not diff, diff
+    assert all(torch.equal(w1[n_], w2[n_]) for n_ in w1)
