@@ -169,16 +169,32 @@ def run_train(args, world, rank, dev, steps, warmup):
     import torch.distributed as dist
     from gdkvm_amd.model import GDKVM, GDKVMConfig
     from gdkvm_amd.train import train_step, wrap_ddp
-    # the strided / 1x1 layers of the TRAINING build are MIOpen in both directions: with fixed shapes let it search its
-    # solvers once (find mode) instead of taking the immediate-mode pick; the search runs in the untimed set-up step
-    torch.backends.cudnn.benchmark = True
+    # (no library convolution is left in the training build since round 5: nothing to let MIOpen search for)
     cfg = GDKVMConfig()
     torch.manual_seed(3)
     model = GDKVM(cfg).train().to(dev).to(memory_format=torch.channels_last)
-    ddp = wrap_ddp(model, dev)
-    # one process: the step is captured once into a HIP graph and replayed (gdkvm_amd.train.GraphedTrainStep -- the eager loop is bound by the
-    # host's ~420 launches per step, not by the GPU); several ranks: the eager step under DDP.  GDKVM_TRAIN_GRAPH=0 times the eager step.
-    graphed = world == 1 and os.environ.get("GDKVM_TRAIN_GRAPH", "1") != "0"
+    # The step is captured once into a HIP graph and replayed (gdkvm_amd.train.GraphedTrainStep -- the eager loop is bound by the host's
+    # ~420 launches per step, not by the GPU).  Several ranks: the BARE module with FlatGradSync -- the gradient all-reduce (RCCL) is one
+    # collective node of the same graph, so the per-GPU step at N > 1 is the 1-GPU step plus that node.  GDKVM_TRAIN_GRAPH=0 times the eager
+    # step instead (DistributedDataParallel's bucketed all-reduce at N > 1).
+    graphed = os.environ.get("GDKVM_TRAIN_GRAPH", "1") != "0"
+    sync = None
+    ddp = model
+    force_sync = world == 1 and os.environ.get("GDKVM_TRAIN_FORCE_SYNC") == "1"
+    if force_sync and not dist.is_initialized():
+        # one GPU, but the N > 1 form of the step: a ONE-rank RCCL group, so the captured graph contains the all-reduce node (what a
+        # one-GPU box can show of configs[3]'s exchange; `train_step.gradient_exchange` says so)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    if (world > 1 or force_sync) and graphed:
+        from gdkvm_amd.train import FlatGradSync
+        sync = FlatGradSync(model)
+        sync.broadcast_parameters()
+    elif world > 1:
+        ddp = wrap_ddp(model, dev)
     opt = torch.optim.AdamW(model.parameters(), lr=1.0e-4, fused=True, capturable=graphed)
     B, T, S = args.batch, args.frames, args.size
     g = torch.Generator(device="cpu").manual_seed(3000 + rank)
@@ -191,14 +207,16 @@ def run_train(args, world, rank, dev, steps, warmup):
             dist.barrier()
         torch.cuda.synchronize()
 
-    first = train_step(ddp, opt, frames, target, torch.bfloat16)     # set-up: MIOpen's solver search (find mode), not a step
+    first = train_step(ddp, opt, frames, target, torch.bfloat16, sync)     # set-up step (kernel attributes, allocator, communicator): not timed
     loss = first
-    step = lambda: train_step(ddp, opt, frames, target, torch.bfloat16)
+    step = lambda: train_step(ddp, opt, frames, target, torch.bfloat16, sync)
+    eager_steps = 1
     if graphed:
         from gdkvm_amd.train import GraphedTrainStep
         try:
-            gstep = GraphedTrainStep(ddp, opt, frames, target, torch.bfloat16, warmup=3)      # (three more eager steps, then the capture)
+            gstep = GraphedTrainStep(model, opt, frames, target, torch.bfloat16, warmup=3, grad_sync=sync)      # (three more eager steps, then the capture)
             step = lambda: gstep(frames, target)
+            eager_steps += gstep.eager_steps
         except Exception as e:                              # a capture that fails is reported and the eager step is timed instead
             print(f"[bench] training step not captured ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr, flush=True)
             torch.cuda.synchronize()
@@ -217,7 +235,11 @@ def run_train(args, world, rank, dev, steps, warmup):
         dt = tt.item()
     return {"frames_per_s": round(world * B * T * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
             "warmup": warmup, "first_loss": round(float(first), 5), "final_loss": round(float(loss), 5),
+            "optimizer_steps": eager_steps + warmup + steps,     # (what final_loss is the loss of: set-up + capture warm-up + warmup + steps)
             "wrapped": type(ddp).__name__, "launch": "one hipGraph replay per step" if graphed else "eager (one launch call per kernel)",
+            "gradient_exchange": ("none (one rank)" if world == 1 and sync is None else
+                                  "FlatGradSync: one flat-bucket RCCL all-reduce, a node of the step's graph" if sync is not None else
+                                  "DistributedDataParallel (bucketed all-reduce overlapped with the backward)"),
             "workload": "BASELINE.json configs[3]: EchoNet-Dynamic training, DDP, 16 clips/GPU (global batch 128 at 8 GPUs), "
                         "bf16 autocast, AdamW lr 1e-4",
             "clips_per_gpu": B, "frames_per_clip": T, "image": f"{S}x{S}",
@@ -237,8 +259,9 @@ def bench_train(args, world, rank, dev):
                           "config": {"workload": res["workload"], "clips_per_gpu": res["clips_per_gpu"],
                                      "frames_per_clip": res["frames_per_clip"], "image": res["image"], "sharding": res["sharding"]},
                           "final_loss": res["final_loss"]}), flush=True)
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

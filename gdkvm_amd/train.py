@@ -60,9 +60,66 @@ def wrap_ddp(model: nn.Module, device: Optional[torch.device] = None, bucket_cap
                                                gradient_as_bucket_view=True)
 
 
+class FlatGradSync:
+    """The step's ONE exchange as ONE collective on the stream the step runs on: after the backward every gradient is copied into its slice
+    of one flat fp32 bucket (a few multi-tensor copy launches), the bucket is all-reduced to the mean over the ranks (RCCL over xGMI on the GPU
+    box, gloo in CPU tests), and the parameters' ``.grad`` become views of it (same shape AND strides as the parameter: the fused optimiser
+    pairs elements by address) -- what DistributedDataParallel does with its reducer, hooks and bucket views, in a form a HIP graph can hold:
+    no autograd hooks, no host-side bucket bookkeeping, one communication node.  The whole model is ~16 MB of fp32 gradients: one ring
+    all-reduce of 2 (P-1)/P x 16 MB over 7 x 153 GB/s links is ~0.1 - 0.2 ms against a 5.7 ms step, so it is not overlapped with the backward.
+    Use with the BARE module (not wrapped): ``sync = FlatGradSync(model); sync.broadcast_parameters(); train_step(..., grad_sync=sync)``.
+    The reference's own recipe is a multi-process launch (/root/reference/website/src/pages/[lang]/reprod/index.astro:238-249)."""
+
+    def __init__(self, model: nn.Module, group=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("FlatGradSync needs an initialised process group")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.buffers = list(model.buffers())
+        if not self.params:
+            raise RuntimeError("FlatGradSync: the model has no trainable parameter")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        if any(p.device != dev or p.dtype != dt for p in self.params):
+            raise RuntimeError("FlatGradSync: parameters must share one device and dtype")
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            n = p.numel()
+            dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+            self.views.append(self.flat[off:off + n].as_strided(p.shape, p.stride()) if dense else self.flat[off:off + n].view(p.shape))
+            off += n
+        # gloo has no AVG: SUM then a scale (CPU tests); RCCL averages inside the collective
+        self._avg = dev.type == "cuda"
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        """Every rank starts from rank `src`'s weights and buffers (what DistributedDataParallel does at construction)."""
+        import torch.distributed as dist
+        for t in list(self.params) + self.buffers:
+            dist.broadcast(t.data, src, group=self.group)
+
+    def __call__(self) -> None:
+        import torch.distributed as dist
+        missing = [v for p, v in zip(self.params, self.views) if p.grad is None]
+        if missing:
+            torch._foreach_zero_(missing)                    # (a parameter outside this step's graph contributes zero, as under DDP)
+        have = [(v, p.grad) for p, v in zip(self.params, self.views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        if self._avg:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(self.world)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+
 def train_step(model: nn.Module, opt: torch.optim.Optimizer, frames: torch.Tensor, target: torch.Tensor,
-               autocast_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """forward -> loss -> backward (HIP backward kernels; DDP all-reduce if wrapped) -> optimiser step."""
+               autocast_dtype: Optional[torch.dtype] = None, grad_sync=None) -> torch.Tensor:
+    """forward -> loss -> backward (HIP backward kernels; DDP all-reduce if wrapped) -> [grad_sync(): FlatGradSync on a bare module] ->
+    optimiser step."""
     opt.zero_grad(set_to_none=True)
     fused = frames.is_cuda                      # GPU: the objective is evaluated on the stride-4 logits by the HIP loss kernels
     kw = {"_lowres": True} if fused else {}
@@ -73,6 +130,8 @@ def train_step(model: nn.Module, opt: torch.optim.Optimizer, frames: torch.Tenso
         logits = model(frames, **kw)
     loss = segmentation_loss_lowres(logits, target) if fused else segmentation_loss(logits, target)
     loss.backward()
+    if grad_sync is not None:
+        grad_sync()
     opt.step()
     from .model import weights_changed
     weights_changed()          # (fused optimisers write the parameters without bumping their version counters: the pack caches key on this too)
@@ -104,28 +163,35 @@ class GraphedTrainStep:
     """train_step captured ONCE into a HIP graph and replayed: a training step of this model is ~420 kernel launches of 5 - 100 us, and with
     the step's kernels down to 6.5 ms the eager loop is bound by the HOST (Python autograd + launch calls: 6.5 - 8.6 ms per step depending
     on the box's CPU, measured round 4) -- the graph replays the same kernels in the same order with no host work in between.
-    Single process only (DDP's bucketed all-reduce is left to the eager step); shapes are fixed at construction; the optimiser must be
+    Several ranks: the bare module with grad_sync=FlatGradSync(model) -- the gradient all-reduce is then ONE collective node of the same graph
+    (a DistributedDataParallel wrapper is refused: its reducer is host logic); shapes are fixed at construction; the optimiser must be
     capturable (torch.optim.AdamW(..., fused=True, capturable=True)).  The first `warmup` steps run eagerly on a side stream (library
     convolutions pick their solvers, the HIP library sets its kernel attributes, the optimiser creates its state), then one step is
     captured; every call copies the batch into the graph's input buffers and replays -- same arithmetic, same order, same results as
     train_step (tools/graph_step_diag.py prints both loss sequences side by side; tests/test_train_side_gpu.py asserts them equal)."""
 
     def __init__(self, model: nn.Module, opt: torch.optim.Optimizer, frames: torch.Tensor, target: torch.Tensor,
-                 autocast_dtype: Optional[torch.dtype] = None, warmup: int = 3):
+                 autocast_dtype: Optional[torch.dtype] = None, warmup: int = 3, grad_sync=None):
         if not frames.is_cuda:
             raise RuntimeError("GraphedTrainStep needs device tensors")
-        self.model, self.opt, self.autocast_dtype = model, opt, autocast_dtype
+        if isinstance(model, nn.parallel.DistributedDataParallel):
+            raise RuntimeError("GraphedTrainStep takes the bare module; several ranks: pass grad_sync=FlatGradSync(model) (one captured all-reduce)")
+        self.model, self.opt, self.autocast_dtype, self.grad_sync = model, opt, autocast_dtype, grad_sync
         self.frames, self.target = frames.clone(), target.clone()
         side = torch.cuda.Stream(device=frames.device)
         side.wait_stream(torch.cuda.current_stream(frames.device))
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
-                self.loss = train_step(model, opt, self.frames, self.target, autocast_dtype)
+                self.loss = train_step(model, opt, self.frames, self.target, autocast_dtype, grad_sync)
         torch.cuda.current_stream(frames.device).wait_stream(side)
         torch.cuda.synchronize(frames.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = train_step(model, opt, self.frames, self.target, autocast_dtype)
+        # (with a collective in the step the process group's watchdog THREAD polls the events of the warm-up steps' all-reduces while this
+        # thread captures; under the default "global" capture mode its hipEventQuery aborts the process with "operation not permitted when
+        # stream is capturing" -- measured round 5 -- so only this thread's calls are policed)
+        mode = {"capture_error_mode": "thread_local"} if grad_sync is not None else {}
+        with torch.cuda.graph(self.graph, **mode):
+            self.loss = train_step(model, opt, self.frames, self.target, autocast_dtype, grad_sync)
         self.eager_steps = max(1, warmup)       # optimiser steps taken before the first replay (the capture itself runs no kernel)
         # the captured kernels address the per-weight packs (re-packed by the graph itself every replay) and other buffers the warm-up steps
         # allocated outside the graph's pool: held here, so that GDKVM.invalidate_packed_weights() (an eval() / train() toggle between steps)

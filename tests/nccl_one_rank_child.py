@@ -6,6 +6,7 @@ A one-rank ``nccl`` process group is legal on one GPU and runs the real RCCL cod
 group is initialised before any other GPU call of this process, which is why this is a child and not a pytest function.
 
     python tests/nccl_one_rank_child.py ddp [B T S]     three train steps, DDP-wrapped (forced) against the bare model
+    python tests/nccl_one_rank_child.py graph [B T S]   the step AND its gradient all-reduce captured in one hipGraph, against the eager step
     python tests/nccl_one_rank_child.py cp              context_parallel_scan's exchange branch against gdkvm_scan_fwd
 Prints ONE JSON line; the parent asserts on it.  (reprod/index.astro:238-249 of the reference's website is the recipe: a
 torch.distributed launcher, one process per GPU.)"""
@@ -75,6 +76,40 @@ def ddp(dev, B, T, S):
             "weight_abs_diff_after_3_steps": wdiff}
 
 
+def graph(dev, B, T, S):
+    """The training step with its gradient exchange as ONE hipGraph (GraphedTrainStep + FlatGradSync) on the one-rank RCCL group, against the
+    eager bare step from the same start: every gradient kernel is deterministic and the mean over one rank is the identity, so the losses
+    and the weights must be EQUAL."""
+    from gdkvm_amd import ops
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    from gdkvm_amd.train import FlatGradSync, GraphedTrainStep, train_step
+    ops.require_native()
+    torch.manual_seed(3)
+    bare = GDKVM(GDKVMConfig()).train().to(dev).to(memory_format=torch.channels_last)
+    twin = copy.deepcopy(bare)
+    g = torch.Generator(device="cpu").manual_seed(3000)
+    frames = [torch.rand(B, T, 3, S, S, generator=g).to(dev) for _ in range(4)]
+    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    target = ((((yy - S / 2) / (S * 0.3)) ** 2 + ((xx - S / 2) / (S * 0.2)) ** 2) < 1).long().expand(B, T, S, S).contiguous().to(dev)
+    opt_b = torch.optim.AdamW(bare.parameters(), lr=1.0e-3, fused=True, capturable=True)
+    opt_t = torch.optim.AdamW(twin.parameters(), lr=1.0e-3, fused=True, capturable=True)
+    sync = FlatGradSync(twin)
+    sync.broadcast_parameters()
+    warm = 2
+    gstep = GraphedTrainStep(twin, opt_t, frames[0], target, torch.bfloat16, warmup=warm, grad_sync=sync)
+    for _ in range(warm):
+        train_step(bare, opt_b, frames[0], target, torch.bfloat16)
+    lb, lg = [], []
+    for i in range(1, 4):
+        lb.append(float(train_step(bare, opt_b, frames[i], target, torch.bfloat16)))
+        lg.append(float(gstep(frames[i], target)))
+    torch.cuda.synchronize()
+    wdiff = max((pb.detach().float() - pw.detach().float()).abs().max().item() for pb, pw in zip(bare.parameters(), twin.parameters()))
+    return {"mode": "graph", "backend": dist.get_backend(), "world": dist.get_world_size(), "shape": [B, T, S, S], "loss_bare": lb,
+            "loss_graph": lg, "weight_abs_diff": wdiff, "bucket_elems": sync.flat.numel(),
+            "grads_are_bucket_views": all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))}
+
+
 def cp(dev):
     from gdkvm_amd import ops
     from gdkvm_amd.distributed import context_parallel_scan
@@ -105,6 +140,9 @@ def main():
         if mode == "ddp":
             B, T, S = (int(x) for x in sys.argv[2:5]) if len(sys.argv) >= 5 else (16, 32, 112)
             res = ddp(dev, B, T, S)
+        elif mode == "graph":
+            B, T, S = (int(x) for x in sys.argv[2:5]) if len(sys.argv) >= 5 else (4, 8, 112)
+            res = graph(dev, B, T, S)
         elif mode == "cp":
             res = cp(dev)
         else:

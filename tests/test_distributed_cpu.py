@@ -129,6 +129,77 @@ def _ddp_worker_frozen(rank, world, port, frames, target, state, out):
     torch.distributed.destroy_process_group()
 
 
+def _flat_sync_worker(rank, world, port, frames, target, state, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    from gdkvm_amd.distributed import init_from_env
+    from gdkvm_amd.model import GDKVMConfig
+    from gdkvm_amd.train import FlatGradSync, train_step
+    from oracle.model_ref import GDKVMRef
+    init_from_env("gloo")
+    torch.manual_seed(100 + rank)                    # every rank builds DIFFERENT weights: broadcast_parameters must make them rank 0's
+    model = GDKVMRef(GDKVMConfig(widths=(16, 32, 64), pixel_dim=64, value_dim=32)).train().to(memory_format=torch.channels_last)
+    if rank == 0:
+        model.load_state_dict(state)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    sync = FlatGradSync(model)
+    sync.broadcast_parameters()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    lo, hi = shard_range(frames.shape[0], world, rank)
+    losses = [float(train_step(model, opt, frames[lo:hi], target[lo:hi], None, grad_sync=sync)) for _ in range(2)]
+    grads_are_views = all(p.grad.data_ptr() == v.data_ptr() and p.grad.stride() == p.stride() for p, v in zip(sync.params, sync.views))
+    out.put((rank, {n: p.detach().numpy().copy() for n, p in model.named_parameters()}, losses, grads_are_views))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_flat_gradient_sync_matches_full_batch_steps():
+    """gdkvm_amd.train.FlatGradSync (the graph-capturable form of the step's one exchange: one flat bucket, one all-reduce, gradients as
+    views of it) on two gloo ranks: after broadcast_parameters and two SGD steps on their shards both ranks hold the SAME weights, equal to
+    a single process stepping on the mean of the two shard gradients; channels_last parameters keep their strides in the bucket views."""
+    from gdkvm_amd.model import GDKVMConfig
+    from gdkvm_amd.train import segmentation_loss
+    from oracle.model_ref import GDKVMRef
+    torch.manual_seed(1)
+    cfg = GDKVMConfig(widths=(16, 32, 64), pixel_dim=64, value_dim=32)
+    model = GDKVMRef(cfg).train().to(memory_format=torch.channels_last)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    frames = torch.rand(2, 2, 3, 32, 32)
+    target = (torch.rand(2, 2, 32, 32) > 0.5).long()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    for _ in range(2):                               # the reference run: mean of the per-shard gradients, one step
+        g_sum = None
+        for lo in (0, 1):
+            model.zero_grad()
+            segmentation_loss(model(frames[lo:lo + 1]), target[lo:lo + 1]).backward()
+            g = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+            g_sum = g if g_sum is None else [a if b is None else (b if a is None else a + b) for a, b in zip(g_sum, g)]
+        for p, gs in zip(model.parameters(), g_sum):
+            p.grad = None if gs is None else gs / 2
+        opt.step()
+    want = {n: p.detach().clone() for n, p in model.named_parameters()}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_flat_sync_worker, args=(r, 2, port, frames, target, state, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict((rk, (w, l, v)) for rk, w, l, v in (out.get(timeout=300) for _ in range(2)))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][2] and got[1][2]
+    for n in want:
+        assert (got[0][0][n] == got[1][0][n]).all(), n                                   # the ranks agree exactly
+        assert torch.allclose(torch.from_numpy(got[0][0][n]), want[n], atol=2e-6, rtol=1e-4), n
+
+
 class _OracleBackend:
     """CPU stand-in for gdkvm_amd.ops in context_parallel_scan: the same three calls, computed with the numpy oracle
     (the transition matrix as the scan of an identity state with zero values)."""

@@ -51,6 +51,18 @@ def test_ddp_wrapped_training_steps_on_a_one_rank_rccl_group(hip):
 
 
 @pytest.mark.gpu
+def test_training_step_with_its_all_reduce_captured_in_one_graph(hip):
+    """The multi-GPU training step in the form bench.py runs at N > 1: bare module + FlatGradSync, captured by GraphedTrainStep -- the
+    RCCL all-reduce is a node of the hipGraph.  On the one-rank group the replays must reproduce the eager bare step exactly."""
+    res = _run("graph", "4", "8", "112")
+    print(res)
+    assert res["backend"] == "nccl" and res["world"] == 1 and res["grads_are_bucket_views"] and res["bucket_elems"] > 1_000_000
+    assert res["loss_graph"] == res["loss_bare"], res
+    assert res["weight_abs_diff"] == 0.0, res
+    assert res["loss_bare"][-1] < res["loss_bare"][0], res
+
+
+@pytest.mark.gpu
 def test_context_parallel_scan_exchange_branch_on_rccl(hip):
     res = _run("cp")
     print(res)
