@@ -17,7 +17,6 @@ sys.path.insert(0, ROOT)
 
 
 def main(argv=None):
-    torch.backends.cudnn.benchmark = True          # fixed shapes: let MIOpen search its conv solvers once
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default=os.path.join(ROOT, "config", "config_gdkvm_01.yaml"))
     ap.add_argument("--weights", default="")
@@ -56,7 +55,10 @@ def main(argv=None):
         frames = torch.stack([x for x, _ in items]).to(dev)
         target = torch.stack([y for _, y in items]).to(dev).to(torch.uint8)
         mask, c = model.segment(frames, target=target)
-        counts += c.sum((0, 1)).long()
+        # only frames that carry labels count (EchoNet-Dynamic: the two traced frames of a clip -- gdkvm_amd.data.IGNORE_LABEL everywhere
+        # else, where a predicted pixel must not enter |A|): a labelled frame has a non-empty target in some class
+        labelled = (c[..., 2].sum(-1, keepdim=True) > 0).unsqueeze(-1)
+        counts += (c * labelled).sum((0, 1)).long()
         if vis_left > 0:
             from PIL import Image
             os.makedirs(os.path.join(cfg.run_dir, "vis"), exist_ok=True)

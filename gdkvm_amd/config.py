@@ -19,7 +19,7 @@ class EvalStage:
 
 @dataclass
 class DataCfg:
-    kind: str = "synthetic"          # synthetic | npy_clips | camus_png
+    kind: str = "synthetic"          # synthetic | npy_clips | echonet_npz | camus_png
     frames: int = 10
     size: int = 256
     num_classes: int = 4

@@ -74,12 +74,13 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const void* z, const 
         float p[C], lg[C];
         const float lse = pixel_softmax<IO, C>(z, (size_t)n * C * h * w, h * w, w, ty, tx, p, lg);
         const int t = target_at<TL>(target, i);
+        const float lab = (unsigned)t < (unsigned)C ? 1.f : 0.f;        // an unlabelled pixel (EchoNet: every untraced frame) adds to NO sum
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float is = t == c ? 1.f : 0.f;
             acc[0] += is * (lse - lg[c]);
             acc[1 + c] += is * p[c];
-            acc[1 + C + c] += p[c];
+            acc[1 + C + c] += lab * p[c];
             acc[1 + 2 * C + c] += is;
         }
     }
@@ -157,9 +158,10 @@ __global__ __launch_bounds__(256) void seg_loss_bwd_kernel(const void* z, const 
         pixel_softmax<IO, C>(z, img, h * w, w, ty, tx, p, lg);
         const int t = target_at<TL>(target, ((size_t)n * H + y) * W + x);
         float u[C], dot = 0.f;
-        const float ce_w = (unsigned)t < (unsigned)C ? inv_n : 0.f;   // unlabelled pixel: no cross-entropy term
+        const bool lab = (unsigned)t < (unsigned)C;
+        const float ce_w = lab ? inv_n : 0.f;                         // unlabelled pixel: no cross-entropy term, and no Dice term either
 #pragma unroll
-        for (int c = 0; c < C; ++c) { u[c] = (t == c ? cI[c] : 0.f) + cP[c]; dot = fmaf(p[c], u[c], dot); }
+        for (int c = 0; c < C; ++c) { u[c] = lab ? (t == c ? cI[c] : 0.f) + cP[c] : 0.f; dot = fmaf(p[c], u[c], dot); }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float dl = (p[c] - (t == c ? 1.f : 0.f)) * ce_w + p[c] * (u[c] - dot);

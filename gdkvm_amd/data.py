@@ -1,11 +1,14 @@
 """Clip datasets for the harness.  No dataset ships with this repository and there is no network,
 so the default is a seeded synthetic echo-like clip generator; two on-disk formats are supported for real data:
 
-  npy_clips   <root>/<split>/<name>.npz with  frames [T,H,W] or [T,H,W,3] uint8  and  masks [T,H,W] uint8
-              (how EchoNet-Dynamic AVIs can be pre-extracted -- video decoding needs cv2, which this image lacks)
-  camus_png   <root>/<split>/<patient>/<view>/frame_XXX.png + mask_XXX.png  (the reference's processed
-              "camus_png256x256_10f" layout is not documented beyond its name -- website reprod/index.astro:217,246 -- so
-              this is the builder's own convention)
+  npy_clips    <root>/<split>/<name>.npz with  frames [T,H,W] or [T,H,W,3] uint8  and  masks [T,H,W] uint8
+  echonet_npz  what tools/convert_echonet.py writes from an EchoNet-Dynamic download (Videos/*.avi, FileList.csv, VolumeTracings.csv --
+               the "raw data" link of the reference's guide, website reprod/index.astro:222): one .npz per video with the WHOLE video and
+               the two traced frames' masks; EchoNetNpz cuts a T-frame clip around the traced frames and marks every other frame
+               UNLABELLED (label 255, which the loss leaves out: gdkvm_amd.train.segmentation_loss, gdkvm_seg_loss_fwd)
+  camus_png    <root>/<split>/<patient>/<view>/frame_XXX.png + mask_XXX.png, view in {2CH, 4CH}, masks 0 bg / 1 LV / 2 myocardium / 3 LA --
+               what tools/convert_camus.py writes from the CAMUS NIfTI release (guide: index.astro:221); the reference's own processed
+               "camus_png256x256_10f" tree is not documented beyond its name (index.astro:217,246), so this layout is the builder's
 """
 from __future__ import annotations
 
@@ -54,6 +57,87 @@ class SyntheticEchoClips(Dataset):
         return torch.from_numpy(frames), torch.from_numpy(masks.astype(np.int64))
 
 
+IGNORE_LABEL = 255             # an unlabelled pixel / frame: outside [0, num_classes), so the loss and the Dice counts skip it
+
+
+def polygon_mask(xs, ys, height: int, width: int) -> np.ndarray:
+    """uint8 [height, width] mask of the closed polygon (xs[i], ys[i]) -- even-odd scanline fill at pixel centres, vertices in pixel
+    coordinates (x to the right, y down), as the EchoNet tracings are given.  Pure numpy: the converter runs without skimage / cv2."""
+    xs, ys = np.asarray(xs, np.float64), np.asarray(ys, np.float64)
+    mask = np.zeros((height, width), np.uint8)
+    n = len(xs)
+    if n < 3:
+        return mask
+    x0, y0, x1, y1 = xs, ys, np.roll(xs, -1), np.roll(ys, -1)
+    cols = np.arange(width) + 0.0
+    for r in range(max(0, int(np.floor(ys.min()))), min(height, int(np.ceil(ys.max())) + 1)):
+        yc = r + 0.0
+        cross = (y0 <= yc) != (y1 <= yc)                     # edges that straddle the scanline (half-open: a vertex counts once)
+        if not cross.any():
+            continue
+        xi = np.sort(x0[cross] + (yc - y0[cross]) * (x1[cross] - x0[cross]) / (y1[cross] - y0[cross]))
+        inside = np.zeros(width, bool)
+        for a, b in zip(xi[0::2], xi[1::2]):
+            inside |= (cols >= a) & (cols <= b)
+        mask[r] = inside
+    return mask
+
+
+def echonet_tracing_polygon(rows):
+    """The polygon of one traced frame from its VolumeTracings.csv rows [(X1, Y1, X2, Y2), ...]: row 0 is the long axis, every
+    following row one chord across the ventricle; the outline runs down the chords' first end points and back up their second ones
+    (the construction EchoNet-Dynamic's own loader uses [LIT])."""
+    r = np.asarray(rows, np.float64)
+    x = np.concatenate([r[1:, 0], r[1:, 2][::-1]])
+    y = np.concatenate([r[1:, 1], r[1:, 3][::-1]])
+    return x, y
+
+
+def clip_indices(n_frames: int, labelled, T: int, pad: int = 2) -> np.ndarray:
+    """T frame indices of a clip that CONTAINS every labelled frame (EchoNet: ED and ES), evenly spread from a little before the first to
+    a little after the last (deterministic); videos shorter than T repeat their last frame."""
+    lab = sorted(int(i) for i in labelled)
+    lo, hi = max(0, lab[0] - pad), min(n_frames - 1, lab[-1] + pad)
+    if hi - lo + 1 < T:                                     # widen the window to T frames where the video allows
+        grow = T - (hi - lo + 1)
+        lo = max(0, lo - grow // 2)
+        hi = min(n_frames - 1, lo + T - 1)
+        lo = max(0, hi - T + 1)
+    idx = np.round(np.linspace(lo, hi, T)).astype(np.int64)
+    taken = set()
+    for f in lab:                                           # every labelled frame sits in the clip, each on its own position
+        order = np.argsort(np.abs(idx - f), kind="stable")
+        j = next(int(o) for o in order if int(o) not in taken)
+        idx[j] = f
+        taken.add(j)
+    return np.sort(idx)
+
+
+class EchoNetNpz(Dataset):
+    """EchoNet-Dynamic as tools/convert_echonet.py leaves it: <root>/<split>/<FileName>.npz with `video` [F,H,W] uint8 (grey),
+    `traced` [2] frame indices and `masks` [2,H,W] uint8 (0 background, 1 left ventricle).  A sample is a T-frame clip around the two
+    traced frames: frames [T,3,H,W] float in [0,1], labels [T,H,W] int64 with IGNORE_LABEL on every untraced frame."""
+
+    def __init__(self, root: str, split: str, frames: int):
+        self.files = sorted(glob.glob(os.path.join(root, split, "*.npz")))
+        if not self.files:
+            raise FileNotFoundError(f"no converted EchoNet videos (.npz) under {os.path.join(root, split)}: run tools/convert_echonet.py")
+        self.T = frames
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, i):
+        z = np.load(self.files[i])
+        video, traced, masks = z["video"], z["traced"], z["masks"]
+        idx = clip_indices(video.shape[0], traced, self.T)
+        x = torch.from_numpy(video[idx].astype(np.float32) / 255.0).unsqueeze(1).expand(-1, 3, -1, -1).contiguous()
+        y = torch.full((self.T,) + video.shape[1:], IGNORE_LABEL, dtype=torch.int64)
+        for f, m in zip(traced, masks):
+            y[int(np.nonzero(idx == int(f))[0][0])] = torch.from_numpy(m.astype(np.int64))
+        return x, y
+
+
 class NpzClips(Dataset):
     def __init__(self, root: str, split: str, frames: int):
         self.files = sorted(glob.glob(os.path.join(root, split, "*.npz")))
@@ -74,23 +158,39 @@ class NpzClips(Dataset):
 
 
 class CamusPng(Dataset):
-    def __init__(self, root: str, split: str, frames: int):
+    """CAMUS sequences as PNG trees (tools/convert_camus.py): <root>/<split>/<patient>/<view>/frame_XXX.png + mask_XXX.png with view in
+    {2CH, 4CH} (both chamber views are samples of their own, BASELINE.json configs[2]); masks hold class indices 0..3; a frame without a
+    mask file is unlabelled (IGNORE_LABEL).  Sequences longer than `frames` are subsampled evenly, shorter ones repeat their last frame."""
+
+    VIEWS = ("2CH", "4CH")
+
+    def __init__(self, root: str, split: str, frames: int, views=VIEWS):
         from PIL import Image                                     # noqa: F401  (fail early if Pillow is missing)
-        self.seqs = sorted(d for d in glob.glob(os.path.join(root, split, "*", "*")) if os.path.isdir(d))
+        self.seqs = sorted(d for d in glob.glob(os.path.join(root, split, "*", "*")) if os.path.isdir(d) and os.path.basename(d) in views)
         if not self.seqs:
-            raise FileNotFoundError(f"no <patient>/<view> folders under {os.path.join(root, split)}")
+            raise FileNotFoundError(f"no <patient>/<{'|'.join(views)}> folders under {os.path.join(root, split)}")
         self.T = frames
 
     def __len__(self):
         return len(self.seqs)
 
+    def view(self, i) -> str:
+        return os.path.basename(self.seqs[i])
+
     def __getitem__(self, i):
         from PIL import Image
-        fr = sorted(glob.glob(os.path.join(self.seqs[i], "frame_*.png")))[: self.T]
-        mk = [f.replace("frame_", "mask_") for f in fr]
-        x = np.stack([np.asarray(Image.open(f).convert("RGB"), np.float32) / 255.0 for f in fr])
-        y = np.stack([np.asarray(Image.open(f), np.int64) for f in mk])
-        return torch.from_numpy(x).permute(0, 3, 1, 2).contiguous(), torch.from_numpy(y)
+        fr = sorted(glob.glob(os.path.join(self.seqs[i], "frame_*.png")))
+        if not fr:
+            raise FileNotFoundError(f"{self.seqs[i]} holds no frame_*.png")
+        pick = np.round(np.linspace(0, len(fr) - 1, self.T)).astype(int) if len(fr) >= self.T else \
+            np.minimum(np.arange(self.T), len(fr) - 1)
+        xs, ys = [], []
+        for j in pick:
+            img = np.asarray(Image.open(fr[j]).convert("RGB"), np.float32) / 255.0
+            mk = fr[j].replace("frame_", "mask_")
+            xs.append(img)
+            ys.append(np.asarray(Image.open(mk), np.int64) if os.path.exists(mk) else np.full(img.shape[:2], IGNORE_LABEL, np.int64))
+        return torch.from_numpy(np.stack(xs)).permute(0, 3, 1, 2).contiguous(), torch.from_numpy(np.stack(ys))
 
 
 def build_dataset(cfg, split: str = "train", n_synthetic: int = 256) -> Dataset:
@@ -100,6 +200,8 @@ def build_dataset(cfg, split: str = "train", n_synthetic: int = 256) -> Dataset:
                                   d.num_classes, seed=cfg.seed + (0 if split == "train" else 7919))
     if d.kind == "npy_clips":
         return NpzClips(cfg.data_path, split, d.frames)
+    if d.kind == "echonet_npz":
+        return EchoNetNpz(cfg.data_path, split, d.frames)
     if d.kind == "camus_png":
         return CamusPng(cfg.data_path, split, d.frames)
     raise ValueError(f"unknown data.kind {d.kind!r}")

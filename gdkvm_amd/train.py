@@ -16,8 +16,8 @@ import torch.nn.functional as F
 
 def segmentation_loss(logits: torch.Tensor, target: torch.Tensor, dice_weight: float = 1.0, eps: float = 1.0) -> torch.Tensor:
     """Cross-entropy + soft Dice over [B,T,ncls,H,W] logits and [B,T,H,W] integer labels (fp32 math).  Labels outside
-    [0, ncls) are unlabelled pixels: left out of the cross-entropy mean and of every class's Dice target (gdkvm_seg_loss_fwd
-    does the same)."""
+    [0, ncls) are unlabelled pixels (EchoNet-Dynamic: every frame but the two traced ones): left out of the cross-entropy mean and of every
+    Dice sum -- intersection, target AND prediction mass (gdkvm_seg_loss_fwd does the same)."""
     B, T, C, H, W = logits.shape
     lg = logits.reshape(B * T, C, H, W).float()
     tg = target.reshape(B * T, H, W).long()
@@ -27,7 +27,7 @@ def segmentation_loss(logits: torch.Tensor, target: torch.Tensor, dice_weight: f
     # device-to-host synchronisation in front of the backward
     ce = F.cross_entropy(lg, torch.where(labelled, tg, torch.full_like(tg, -100)), ignore_index=-100, reduction="sum") \
         / labelled.sum().clamp_min(1)
-    p = lg.softmax(1)
+    p = lg.softmax(1) * labelled.unsqueeze(1)       # an unlabelled pixel adds to no sum at all: not to the prediction mass P_c either
     oh = (F.one_hot(torch.where(labelled, tg, torch.zeros_like(tg)), C) * labelled.unsqueeze(-1)).permute(0, 3, 1, 2).float()
     inter = (p * oh).sum((0, 2, 3))
     dice = 1.0 - ((2 * inter + eps) / (p.sum((0, 2, 3)) + oh.sum((0, 2, 3)) + eps)).mean()

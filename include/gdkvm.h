@@ -510,8 +510,9 @@ int gdkvm_upsample_cat_bwd(const void* dout, void* dlo, void* dskip,
  * target [images, H, W] (target_bytes = 1: uint8, 8: int64), 2 <= C <= 8:
  *   l = bilinear_upsample(z -> H x W, align_corners = false) in fp32;  p = softmax(l);
  *   loss = mean CE(l, target) + dice_weight * (1 - mean_c (2 I_c + eps) / (P_c + O_c + eps)),  sums over the whole batch.
- * A label outside [0, C) marks an unlabelled pixel: the CE mean runs over the labelled pixels only and the pixel counts towards
- * no class's I_c / O_c (it still contributes its softmax to P_c).
+ * A label outside [0, C) marks an unlabelled pixel (EchoNet-Dynamic: every frame but the two traced ones): it adds to no sum at all -- the CE
+ * mean runs over the labelled pixels, and neither I_c, O_c nor P_c see it (round 5; before, its softmax still counted in P_c, which pushed
+ * the predictions on unlabelled frames towards "nothing").
  * fwd: out[0] = loss, out[1] = CE, out[2] = Dice term; ws keeps the per-class coefficients the backward needs.
  * bwd: dz [images, C, h, w] = (*grad_out, or 1 if NULL) * dloss/dz -- a gather per stride-4 pixel, deterministic.
  * Full-resolution logits are never materialised.  ws: gdkvm_seg_loss_workspace_bytes(C), the SAME buffer for fwd and bwd. */

@@ -392,7 +392,8 @@ def test_convolution_weight_gradient(hip, case):
 
 def test_fused_objective_ignores_unlabelled_pixels(hip):
     """Labels outside [0, C) (255 in uint8 annotation masks) carry no class: the cross-entropy averages over the labelled pixels
-    only, as F.cross_entropy(ignore_index=...) does; the Dice sums see them as 'no class'.  The host-side loss agrees."""
+    only, as F.cross_entropy(ignore_index=...) does, and NO Dice sum sees them (not the prediction mass either: a clip with two
+    traced frames out of 32 must not be told to predict nothing on the other 30).  The host-side loss agrees."""
     from gdkvm_amd.train import segmentation_loss
     ni, c, h, w, H, W = 3, 2, 28, 28, 112, 112
     torch.manual_seed(5)
@@ -407,7 +408,7 @@ def test_fused_objective_ignores_unlabelled_pixels(hip):
         up = F.interpolate(zb, size=(H, W), mode="bilinear", align_corners=False)
         t = tgt.cpu()
         ce = F.cross_entropy(up, t, ignore_index=255)
-        p = up.softmax(1)
+        p = up.softmax(1) * (t != 255).unsqueeze(1)
         oh = torch.stack([(t == k) for k in range(c)], 1).double()
         dice = 1.0 - ((2 * (p * oh).sum((0, 2, 3)) + 1.0) / (p.sum((0, 2, 3)) + oh.sum((0, 2, 3)) + 1.0)).mean()
         ref = ce + 0.7 * dice

@@ -20,7 +20,6 @@ sys.path.insert(0, ROOT)
 
 
 def main(argv=None):
-    torch.backends.cudnn.benchmark = True          # fixed shapes: let MIOpen search its conv solvers once
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default=os.path.join(ROOT, "config", "config_gdkvm_01.yaml"))
     ap.add_argument("--resume", default="")
