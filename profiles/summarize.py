@@ -33,6 +33,12 @@ def main():
         rows = kept
         cmd += f"   [rows matching /{sys.argv[4]}/ dropped: {gone / 1e6:.1f} ms]"
     with open(dst, "w") as f:
+        if "hotpath" in dst or "scan_" in dst:               # tie the scan kernels' durations to the sources they were measured on (bench.py quotes them)
+            import os
+            import time
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            from gdkvm_amd.build import source_hash
+            f.write(f"# scan_source_hash: {source_hash()} collected: {time.strftime('%Y-%m-%dT%H:%M:%SZ', time.gmtime())}\n")
         f.write(f"# {cmd}\n")
         f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
         for r in rows:
