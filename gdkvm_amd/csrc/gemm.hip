@@ -9,6 +9,8 @@
 //                                                   order (deterministic: no atomics).  Row-major slabs are staged in LDS and read
 //                                                   back transposed (ds_read_b64_tr_b16) as MFMA fragments.
 // bf16 operands run on v_mfma_f32_16x16x32_bf16, fp32 operands on the exact v_mfma_f32_16x16x4_f32.
+#include <stdlib.h>
+
 #include "gdkvm_common.hpp"
 
 namespace {
@@ -117,39 +119,53 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p)
 // back through ds_read_b64_tr_b16 with the row index as the MFMA k index.  fp32: 16-row steps, plain LDS reads, exact MFMA.
 constexpr int TN_ROWS = 32;
 
-template <int IO, bool CONV = false>
+// KT = 16-row K1 tiles per wave (1: a 64 x 64 workgroup tile; 2, bf16 only: 128 x 64 -- eight MFMAs per six fragment reads instead of four
+// per five: the strided convolutions' weight gradients, whose K1 = output channels is 128 / 256).
+template <int IO, bool CONV = false, int KT = 1>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p)
 {
     constexpr int ESZ = IO == GDKVM_F32 ? 4 : 2;
-    __shared__ __attribute__((aligned(16))) char s_slab[2][2][TN_ROWS * 64 * ESZ];   // [buffer][A | B][sub-tile][row][16]
+    static_assert(KT == 1 || IO == GDKVM_BF16, "the 128-row tile is built for bf16 operands");
+    __shared__ __attribute__((aligned(16))) char s_a[2][TN_ROWS * 64 * KT * ESZ];   // [buffer][sub-tile][row][16]
+    __shared__ __attribute__((aligned(16))) char s_b[2][TN_ROWS * 64 * ESZ];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K1 = p.K1, N = p.N, M = p.M;
-    const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64, z = blockIdx.z;
+    const int k0 = blockIdx.x * 64 * KT, n0 = blockIdx.y * 64, z = blockIdx.z;
     const int r_lo = z * p.rows_per_split, r_hi = min(M, r_lo + p.rows_per_split);
-    f32x4 acc[4];
+    f32x4 acc[KT][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // column sums of A (sum over the rows m of A[m][k1] -- the bias gradient when A = dY): one more MFMA per step against a fragment of
     // ones, in the workgroups of the first N tile only (the framework's reduction for it was a zero-fill and 10 - 24 us per projection)
-    const bool colsum = p.part_cs != nullptr && blockIdx.y == 0;
+    const bool colsum = KT == 1 && p.part_cs != nullptr && blockIdx.y == 0;
     f32x4 accs = {0.f, 0.f, 0.f, 0.f};
-    // staging: thread t moves 16-byte pieces; piece = (row, 16-byte chunk c of the 64-column slab row)
-    constexpr int PIECES = TN_ROWS * 64 * ESZ / 16;        // per matrix: 256 (bf16) or 512 (fp32)
-    constexpr int PER = (PIECES + 255) / 256, CPR = 64 * ESZ / 16;     // pieces per thread, chunks per row
+    // staging: thread t moves 16-byte pieces; piece = (row, 16-byte chunk c of the slab row)
     constexpr int EPC = 16 / ESZ;                          // elements per chunk
-    uint4 ra[PER], rb[PER];
+    constexpr int CPR_B = 64 * ESZ / 16, CPR_A = CPR_B * KT;           // chunks per slab row
+    constexpr int PIECES_B = TN_ROWS * CPR_B, PIECES_A = TN_ROWS * CPR_A;   // B: 256 (bf16) or 512 (fp32)
+    constexpr int PER_B = (PIECES_B + 255) / 256, PER_A = (PIECES_A + 255) / 256;
+    uint4 ra[PER_A], rb[PER_B];
     // CONV: this tile's tap (r, s) and first channel -- N = taps * cC and cC is a multiple of 64, so a 64-column tile lies in one tap
     const int tap = CONV ? n0 / p.cC : 0, tap_r = CONV ? tap / p.cS : 0, tap_s = CONV ? tap - tap_r * p.cS : 0, cc0 = CONV ? n0 - tap * p.cC : 0;
     auto fetch = [&](int r0) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int pc = tid + 256 * u, row = pc / CPR, c = pc % CPR;
+        for (int u = 0; u < PER_A; ++u) {
+            const int pc = tid + 256 * u, row = pc / CPR_A, c = pc % CPR_A;
+            const int m = r0 + row, ka = k0 + c * EPC;
+            ra[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (pc < PIECES_A && m < r_hi && ka + EPC <= K1)
+                ra[u] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.a) + ((size_t)m * K1 + ka) * ESZ);
+        }
+#pragma unroll
+        for (int u = 0; u < PER_B; ++u) {
+            const int pc = tid + 256 * u, row = pc / CPR_B, c = pc % CPR_B;
             const int m = r0 + row;
-            ra[u] = rb[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (pc < PIECES && m < r_hi) {
-                const int ka = k0 + c * EPC, nb = n0 + c * EPC;
-                if (ka + EPC <= K1) ra[u] = *reinterpret_cast<const uint4*>(static_cast<const char*>(p.a) + ((size_t)m * K1 + ka) * ESZ);
+            rb[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (pc < PIECES_B && m < r_hi) {
+                const int nb = n0 + c * EPC;
                 if constexpr (CONV) {
                     const int hw = p.cHo * p.cWo, gn = m / hw, rem = m - gn * hw, yo = rem / p.cWo, xo = rem - yo * p.cWo;
                     const int iy = yo * p.cstride - p.cpad + tap_r, ix = xo * p.cstride - p.cpad + tap_s;
@@ -163,14 +179,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p)
         }
     };
     auto stage = [&](int buf) {
+        // sub-tile = 16 columns: chunk c covers columns c*EPC .. ; sub = column / 16, offset inside the sub-tile row
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int pc = tid + 256 * u, row = pc / CPR, c = pc % CPR;
-            if (pc < PIECES) {
-                // sub-tile = 16 columns: chunk c covers columns c*EPC .. ; sub = column / 16, offset inside the sub-tile row
+        for (int u = 0; u < PER_A; ++u) {
+            const int pc = tid + 256 * u, row = pc / CPR_A, c = pc % CPR_A;
+            if (pc < PIECES_A) {
                 const int col = c * EPC, sub = col >> 4, off = ((row * 16) + (col & 15)) * ESZ + sub * (TN_ROWS * 16 * ESZ);
-                *reinterpret_cast<uint4*>(&s_slab[buf][0][off]) = ra[u];
-                *reinterpret_cast<uint4*>(&s_slab[buf][1][off]) = rb[u];
+                *reinterpret_cast<uint4*>(&s_a[buf][off]) = ra[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PER_B; ++u) {
+            const int pc = tid + 256 * u, row = pc / CPR_B, c = pc % CPR_B;
+            if (pc < PIECES_B) {
+                const int col = c * EPC, sub = col >> 4, off = ((row * 16) + (col & 15)) * ESZ + sub * (TN_ROWS * 16 * ESZ);
+                *reinterpret_cast<uint4*>(&s_b[buf][off]) = rb[u];
             }
         }
     };
@@ -190,42 +213,47 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs p)
                              : "=&v"(x0), "=&v"(x1) : "v"(addr) : "memory");
                 return __builtin_bit_cast(bf16x8, make_uint4(x0.x, x0.y, x1.x, x1.y));
             };
-            const bf16x8 af = frag(&s_slab[buf][0][w * (TN_ROWS * 16 * 2)]);
+            bf16x8 af[KT];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) af[kt] = frag(&s_a[buf][(w * KT + kt) * (TN_ROWS * 16 * 2)]);
             __builtin_amdgcn_sched_barrier(0);
             if (colsum) {
                 const unsigned one2 = 0x3f803f80u;          // bf16 1.0 twice
-                accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, make_uint4(one2, one2, one2, one2)), accs, 0, 0, 0);
+                accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], __builtin_bit_cast(bf16x8, make_uint4(one2, one2, one2, one2)), accs, 0, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const bf16x8 bf = frag(&s_slab[buf][1][j * (TN_ROWS * 16 * 2)]);
+                const bf16x8 bf = frag(&s_b[buf][j * (TN_ROWS * 16 * 2)]);
                 __builtin_amdgcn_sched_barrier(0);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[j], 0, 0, 0);
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) acc[kt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kt], bf, acc[kt][j], 0, 0, 0);
             }
         } else {
-            const float* sa = reinterpret_cast<const float*>(&s_slab[buf][0][w * (TN_ROWS * 16 * 4)]);
+            const float* sa = reinterpret_cast<const float*>(&s_a[buf][w * (TN_ROWS * 16 * 4)]);
 #pragma unroll
             for (int s = 0; s < TN_ROWS / 4; ++s) {        // k step: rows 4s + g
                 const float av = sa[(4 * s + g) * 16 + li];
                 if (colsum) accs = mfma4(av, 1.0f, accs);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float bv = reinterpret_cast<const float*>(&s_slab[buf][1][j * (TN_ROWS * 16 * 4)])[(4 * s + g) * 16 + li];
-                    acc[j] = mfma4(av, bv, acc[j]);
+                    const float bv = reinterpret_cast<const float*>(&s_b[buf][j * (TN_ROWS * 16 * 4)])[(4 * s + g) * 16 + li];
+                    acc[0][j] = mfma4(av, bv, acc[0][j]);
                 }
             }
         }
         buf ^= 1;                                          // (the other buffer was last read two barriers ago)
     }
-    // acc[j][r] = C[k0 + 16w + 4g + r][n0 + 16j + li] of this split
+    // acc[kt][j][r] = C[k0 + 16 (w KT + kt) + 4g + r][n0 + 16j + li] of this split
     float* P = p.part + (size_t)z * K1 * N;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int kk = k0 + 16 * w + 4 * g + r, n = n0 + 16 * j + li;
-            if (kk < K1 && n < N) P[(size_t)kk * N + n] = acc[j][r];
-        }
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = k0 + 16 * (w * KT + kt) + 4 * g + r, n = n0 + 16 * j + li;
+                if (kk < K1 && n < N) P[(size_t)kk * N + n] = acc[kt][j][r];
+            }
     if (colsum && li == 0) {                               // every column of accs holds the same sums: column 0 writes them
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -367,14 +395,26 @@ extern "C" int gdkvm_gemm_tn_colsum(const void* a, const void* b, float* c, floa
 // 1x1 / stride-2 downsample branches of the encoder, the last layers whose gradients were library kernels with atomic sums):
 //   dw[k][c][r][s] = sum over (n, yo, xo) dy[n, yo, xo, k] * x[n, yo stride - pad + r, xo stride - pad + s, c]
 // as gemm_tn's CONV form: the rows of the batch are split over workgroups (2048 per split) into fp32 partial tiles, summed in a fixed order.
-static int cw_splits(long long M) { const long long s = (M + 2047) / 2048; return (int)(s < 1 ? 1 : s); }
+// Row splits: enough workgroups to keep every CU several deep (the kernel is a chain of staged 32-row slabs: latency-bound per workgroup, so
+// what fills the chip is the NUMBER of resident workgroups) without drowning the reduction in partial tiles: ~1024 workgroups in all, at
+// least 256 rows each.  (A 1x1 / stride-2 branch has ONE column tile: at 2048 rows per split it ran on 49 workgroups and took as long as
+// its block's 3x3 layer with nine times the work.)  GDKVM_CW_WGS overrides the target (A/B runs).
+static int cw_splits(long long M, int K, int taps, int C)
+{
+    static const int target = [] { const char* e = getenv("GDKVM_CW_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+    const long long tiles = (long long)((K + 127) / 128) * (taps * C / 64);
+    long long s = (target + tiles - 1) / tiles;
+    const long long smax = (M + 255) / 256;
+    if (s > smax) s = smax;
+    return (int)(s < 1 ? 1 : s);
+}
 
 extern "C" size_t gdkvm_conv_wgrad_strided_workspace_bytes(int N, int C, int H, int W, int K, int R, int S, int stride, int pad)
 {
     if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return 16;
     const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
     if (Ho < 1 || Wo < 1) return 16;
-    return (size_t)cw_splits((long long)N * Ho * Wo) * K * R * S * C * sizeof(float);
+    return (size_t)cw_splits((long long)N * Ho * Wo, K, R * S, C) * K * R * S * C * sizeof(float);
 }
 
 extern "C" int gdkvm_conv_wgrad_strided(const void* x, const void* dy, float* dw, long long sk, long long sc, long long sr, long long ss,
@@ -395,15 +435,20 @@ extern "C" int gdkvm_conv_wgrad_strided(const void* x, const void* dy, float* dw
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int taps = R * S;
     const size_t n = (size_t)K * taps * C;
-    const int splits = N == 0 ? 0 : cw_splits(M);
+    const int splits = N == 0 ? 0 : cw_splits(M, K, taps, C);
     if (N > 0) {
         const size_t need = (size_t)splits * n * sizeof(float);
         if (!workspace || !gdkvm_aligned16(workspace) || workspace_bytes < need)
             return gdkvm_fail(GDKVM_ERR_WORKSPACE, "conv_wgrad_strided: workspace %zu < %zu bytes", workspace_bytes, need);
         const int rows = (int)(((M + splits - 1) / splits + TN_ROWS - 1) / TN_ROWS * TN_ROWS);
         GemmArgs ga{dy, x, nullptr, static_cast<float*>(workspace), nullptr, (int)M, taps * C, 0, K, rows, splits, nullptr, H, W, C, Ho, Wo, S, stride, pad};
-        const dim3 grid((unsigned)((K + 63) / 64), (unsigned)(taps * C / 64), (unsigned)splits);
-        hipLaunchKernelGGL((gemm_tn_kernel<GDKVM_BF16, true>), grid, dim3(256), 0, st, ga);
+        if (K % 128 == 0) {                                 // 128 x 64 workgroup tiles: twice the MFMAs per staged row slab
+            const dim3 grid((unsigned)(K / 128), (unsigned)(taps * C / 64), (unsigned)splits);
+            hipLaunchKernelGGL((gemm_tn_kernel<GDKVM_BF16, true, 2>), grid, dim3(256), 0, st, ga);
+        } else {
+            const dim3 grid((unsigned)((K + 63) / 64), (unsigned)(taps * C / 64), (unsigned)splits);
+            hipLaunchKernelGGL((gemm_tn_kernel<GDKVM_BF16, true>), grid, dim3(256), 0, st, ga);
+        }
         GDKVM_LAUNCH_CHECK("gemm_tn_kernel<conv>");
     }
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, st,
