@@ -254,6 +254,43 @@ def test_module_gradients_match_cpu_reference(hip):
     assert worst > 0
 
 
+def test_module_gradients_match_the_independent_restatement(hip):
+    """The same step against oracle.model_plain.plain_loss_and_grads -- architecture, objective and ignore-label rule written a second
+    time in float64 from the state_dict alone, nothing shared with gdkvm_amd -- for the host loss on full-resolution logits AND for the
+    fused objective of train_step (stride-4 logits into gdkvm_seg_loss_fwd / _bwd), with unlabelled pixels in the batch."""
+    from gdkvm_amd.model import GDKVMConfig
+    from gdkvm_amd.train import segmentation_loss, segmentation_loss_lowres
+    from oracle.model_plain import plain_loss_and_grads
+    cfg = GDKVMConfig(widths=(16, 32, 64), pixel_dim=64, value_dim=64)
+    _, model = _pair(cfg, seed=4)
+    model.train()
+    g = torch.Generator().manual_seed(12)
+    frames = torch.rand(2, 3, 3, 64, 64, generator=g)
+    target = (torch.rand(2, 3, 64, 64, generator=g) > 0.5).long()
+    target[:, 2] = 255                                                          # a whole unlabelled frame (EchoNet clips: most of them)
+    target[0, 0, :9] = 255
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    lp, gp = plain_loss_and_grads(sd, frames, target, value_dim=64)
+    for fused in (False, True):
+        model.zero_grad(set_to_none=True)
+        if fused:
+            loss = segmentation_loss_lowres(model(frames.cuda(), _lowres=True), target.cuda())
+        else:
+            loss = segmentation_loss(model(frames.cuda()), target.cuda())
+        loss.backward()
+        assert abs(loss.item() - lp.item()) <= 2e-4 * max(1.0, abs(lp.item())), (fused, loss.item(), lp.item())
+        seen = 0
+        for n, p in model.named_parameters():
+            if n not in gp:
+                assert p.grad is None or p.grad.abs().max() == 0, n
+                continue
+            scale = max(gp[n].abs().max().item(), 1e-6)
+            err = (p.grad.double().cpu() - gp[n]).abs().max().item() / scale
+            assert err <= 2e-3, (fused, n, err, scale)
+            seen += 1
+        assert seen >= 60
+
+
 def test_train_and_eval_entry_points(hip, tmp_path):
     """Row n2 smoke: a few optimisation steps through train.py (HIP forward + backward kernels), a checkpoint, then eval.py
     on it; the loss must drop and the evaluation must print per-class Dice."""

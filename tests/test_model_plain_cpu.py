@@ -60,3 +60,35 @@ def test_the_plain_restatement_notices_a_rewired_skip():
     bad["encoder.layer1.1.bn2.bias"] = sd["encoder.layer1.1.bn2.bias"] + 0.5         # f4 reaches the output only through decoder.up4's skip
     other, _ = plain_forward(bad, frames, value_dim=16)
     assert (other - base).abs().max().item() > 1e-3
+
+
+@pytest.mark.parametrize("case", [dict(widths=(16, 32, 64), pixel_dim=64, value_dim=32, rule="delta_sequential", num_classes=2),
+                                  dict(widths=(16, 16, 32), pixel_dim=32, value_dim=16, heads=2, rule="gated_linear", num_classes=3)])
+def test_reference_gradients_equal_the_plain_restatement(case):
+    """The gradient oracle is independent too: one training step's loss and gradients from the reference module (the product's wiring,
+    torch autograd, train-mode BatchNorm, gdkvm_amd.train.segmentation_loss) against oracle.model_plain.plain_loss_and_grads (the
+    architecture, the objective and its ignore-label rule written a second time in float64, sharing nothing with gdkvm_amd).  The GPU
+    tests compare the product's HIP backward with the reference module; this ties that module to an independent derivation -- with
+    unlabelled pixels (label 255) in the batch, which both sides must leave out of every sum."""
+    from gdkvm_amd.model import GDKVMConfig
+    from gdkvm_amd.train import segmentation_loss
+    from oracle.model_plain import plain_loss_and_grads
+    cfg = GDKVMConfig(**case)
+    ref = _ref(cfg, seed=7).train()
+    g = torch.Generator().manual_seed(11)
+    frames = torch.rand(2, 2, 3, 64, 64, generator=g)
+    target = torch.randint(0, cfg.num_classes, (2, 2, 64, 64), generator=g)
+    target[:, 1, :20] = 255                                                    # unlabelled rows of the second frame
+    loss = segmentation_loss(ref(frames), target)
+    loss.backward()
+    lp, gp = plain_loss_and_grads(ref.state_dict(), frames, target, heads=cfg.heads, key_dim=cfg.key_dim, value_dim=cfg.value_dim, rule=cfg.rule)
+    assert abs(loss.item() - lp.item()) <= 2e-5 * max(1.0, abs(lp.item()))
+    seen = 0
+    for n, p in ref.named_parameters():
+        if p.grad is None or n not in gp:
+            assert (p.grad is None or p.grad.abs().max() == 0) and (n not in gp or gp[n].abs().max() == 0), n
+            continue
+        scale = max(gp[n].abs().max().item(), 1e-7)
+        assert (p.grad.double() - gp[n]).abs().max().item() <= 2e-3 * scale, (n, (p.grad.double() - gp[n]).abs().max().item(), scale)
+        seen += 1
+    assert seen >= 60                                                          # every layer of the model took part
