@@ -1054,8 +1054,7 @@ class _Conv3x3Function(torch.autograd.Function):
             # the data-gradient pack belongs to THIS version of the weight: a copy would cost what the pre-pack saves, so the backward
             # checks that the weight has not been written since (an optimiser step between forward and backward is not a thing)
             ctx.dgrad_pack, ctx.pack_key = packs[1], (weight._version, weight.data_ptr())
-            ctx.weight_ref = weight
-            ctx.save_for_backward(xb)
+            ctx.save_for_backward(xb, weight)              # (the weight rides along only to be checked in the backward: autograd tracks it)
             return _conv3x3_packed(xb, packs[0], k, _zero_bias(k, xb.device)), None
         wb = weight.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         packed = torch.empty(k * 9 * c, dtype=torch.bfloat16, device=xb.device)
@@ -1072,8 +1071,7 @@ class _Conv3x3Function(torch.autograd.Function):
         res = None if d_alias is None else d_alias.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
         dx = dw = None
         if ctx.dgrad_pack is not None:
-            (xb,), wb = ctx.saved_tensors, None
-            w = ctx.weight_ref
+            (xb, w), wb = ctx.saved_tensors, None           # (an in-place write of the weight since the forward makes saved_tensors itself raise)
             if (w._version, w.data_ptr()) != ctx.pack_key:
                 raise RuntimeError("conv3x3: the weight was modified between forward and backward (its pre-packed data-gradient copy is stale)")
         else:
