@@ -2,6 +2,8 @@
 // integer Dice counts.  HBM-bound: every logit is read once with 8/16-byte loads, the mask is written
 // once; counts are reduced wave-wide with ballots, per block in LDS, then one integer atomic per
 // (block, class, kind) -- integer adds commute, so the result is bit-reproducible.
+#include <stdlib.h>
+
 #include "gdkvm_common.hpp"
 
 namespace {
@@ -371,8 +373,14 @@ static int upsample_launch(const char* who, const void* src, const float* head_w
     }
     const int nq = (W % 4 == 0) ? H * W / 4 : H * W;       // work items per frame (pixel quads when rows allow)
     int gx = (nq + 255) / 256;
-    const int cap = BT >= 1024 ? 2 : (BT >= 256 ? 4 : 16);  // enough blocks to fill the chip, few enough that launch and the
-    if (gx > cap) gx = cap;                                //   per-block count reduction do not dominate
+    static const int cap_env = [] { const char* e = getenv("GDKVM_ARGMAX_BLOCKS"); return e ? atoi(e) : 0; }();   // (A/B runs)
+    // enough blocks to fill the chip, few enough that launch and the per-block count reduction do not dominate.  256 .. 1023 frames: THREE
+    // (round 5, 512 frames of 112 x 112: 20.7 us against 23.8 with four, 22.0 with two; the ranges are multiples of 256 quads, so three
+    // blocks own 1280 / 1280 / 576 of a frame's 3136 -- four owned 1024 / 1024 / 1024 / 64, the last staging a band for 64 quads -- and
+    // blocks of unequal length fall out of step: one's memory-bound band phase overlaps another's arithmetic; evenly split ranges
+    // measured 21.3 - 22.3)
+    const int cap = cap_env > 0 ? cap_env : BT >= 1024 ? 2 : (BT >= 256 ? 3 : 16);
+    if (gx > cap) gx = cap;
     // low-resolution rows a block's contiguous output range touches: the kernel's own arithmetic (band of block bx = rows
     // up_src(q_lo) .. up_src(q_hi - 1) + 1), evaluated here for every block of the launch -- lr_cap is the largest band, exactly
     const int per = (((nq + gx - 1) / gx + 255) / 256) * 256, PX = (W % 4 == 0) ? 4 : 1;
