@@ -248,9 +248,25 @@ def run_train(args, world, rank, dev, steps, warmup):
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
+    n_opt = eager_steps + warmup + steps
+    # cross-check AFTER the timed region, one rank only: the same number of optimiser steps from the same start with the plain eager
+    # train_step under the DEFAULT (non-fused) AdamW -- the launch form and the optimiser implementation must not change what is learned
+    # (round 4's graphed line reported a loss ~10x behind the eager one: weight packs keyed on version counters the fused optimiser does
+    # not bump; round 5: every kernel of the step is deterministic, so the two agree to the optimisers' own rounding)
+    final_eager = None
+    if world == 1 and sync is None and n_opt <= 64:
+        torch.manual_seed(3)
+        twin = GDKVM(cfg).train().to(dev).to(memory_format=torch.channels_last)
+        opt2 = torch.optim.AdamW(twin.parameters(), lr=1.0e-4)
+        le = None
+        for _ in range(n_opt):
+            le = train_step(twin, opt2, frames, target, torch.bfloat16)
+        final_eager = round(float(le), 5)
+        del twin, opt2
     return {"frames_per_s": round(world * B * T * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
             "warmup": warmup, "first_loss": round(float(first), 5), "final_loss": round(float(loss), 5),
-            "optimizer_steps": eager_steps + warmup + steps,     # (what final_loss is the loss of: set-up + capture warm-up + warmup + steps)
+            "optimizer_steps": n_opt,                    # (what final_loss is the loss of: set-up + capture warm-up + warmup + steps)
+            "final_loss_eager_default_adamw": final_eager,
             "wrapped": type(ddp).__name__, "launch": "one hipGraph replay per step" if graphed else "eager (one launch call per kernel)",
             "gradient_exchange": ("none (one rank)" if world == 1 and sync is None else
                                   "FlatGradSync: one flat-bucket RCCL all-reduce, a node of the step's graph" if sync is not None else
