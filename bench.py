@@ -417,7 +417,9 @@ def main():
             gseg = model.graphed_segment(frames)
             if not torch.equal(gseg(frames)[0], ref_mask):
                 raise RuntimeError("the replayed forward's masks differ from the eager ones")
-            step, launch = (lambda: gseg(frames)[0]), "one hipGraph replay per step"
+            step, launch = (lambda: gseg(frames)[0]), "one hipGraph replay per step" + (
+                "" if gseg.streams == 1 else f" ({gseg.streams} groups of {B // gseg.streams} clips on {gseg.streams} streams inside the graph; "
+                                             "masks checked bit-equal to the eager forward over the whole batch)")
         except Exception as e:
             print(f"[bench] forward not captured ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr, flush=True)
             torch.cuda.synchronize()

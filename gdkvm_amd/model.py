@@ -770,22 +770,25 @@ class GDKVM(nn.Module):
         return self
 
     @torch.no_grad()
-    def segment(self, frames, target=None, return_state: bool = False, **kw):
+    def segment(self, frames, target=None, return_state: bool = False, _mask_out=None, _counts_out=None, **kw):
         """logits -> (mask uint8 [B,T,H,W], Dice counts int32 [B,T,ncls,3] | None) with the HIP argmax kernel
-        (return_state: plus the memory state after the last frame, [B,Hh,Dk,Dv] fp32)."""
+        (return_state: plus the memory state after the last frame, [B,Hh,Dk,Dv] fp32).  _mask_out / _counts_out: caller-owned contiguous
+        outputs of those shapes (GraphedSegment: slices of ONE result for the parts of a batch it runs on several streams)."""
         B, T, _, H, W = frames.shape
         tgt = None if target is None else target.reshape(B * T, H, W).contiguous()
+        mo = None if _mask_out is None else _mask_out.view(B * T, H, W)
+        co = None if _counts_out is None else _counts_out.view(B * T, -1, 3)
         lowres = self.forward(frames, _lowres=True, _head_fused=True, return_state=return_state, **kw)   # [B,T,ncls,H/4,W/4], or the feature under the head
         s_out = None
         if return_state:
             lowres, s_out = lowres
         if isinstance(lowres, HeadFeature):
             # head + upsample + argmax + Dice in one kernel: the class planes never reach memory (bit-identical to the two-kernel form)
-            mask, counts = ops.head_upsample_argmax_dice(lowres.feature, lowres.weight, lowres.bias, H, W, tgt)
+            mask, counts = ops.head_upsample_argmax_dice(lowres.feature, lowres.weight, lowres.bias, H, W, tgt, mo, co)
             ncls = lowres.weight.shape[0]
         else:
             ncls, hl, wl = lowres.shape[2:]
-            mask, counts = ops.upsample_argmax_dice(lowres.reshape(B * T, ncls, hl, wl).contiguous(), H, W, tgt)
+            mask, counts = ops.upsample_argmax_dice(lowres.reshape(B * T, ncls, hl, wl).contiguous(), H, W, tgt, mo, co)
         out = (mask.reshape(B, T, H, W), (None if counts is None else counts.reshape(B, T, ncls, 3)))
         return out + (s_out,) if return_state else out
 
@@ -831,10 +834,10 @@ class GDKVM(nn.Module):
             counts.append(c)
         return torch.cat(masks, 1), (None if target is None else torch.cat(counts, 1)), state
 
-    def graphed_segment(self, frames, target=None, warmup: int = 2, state=None):
+    def graphed_segment(self, frames, target=None, warmup: int = 2, state=None, streams=None):
         """segment() for ONE clip shape captured into a hipGraph (GraphedSegment): a serving loop that replays it spends no host time
-        on the ~25 launches of a forward."""
-        return GraphedSegment(self, frames, target, warmup, state)
+        on the ~25 launches of a forward; `streams`: see GraphedSegment."""
+        return GraphedSegment(self, frames, target, warmup, state, streams)
 
     # -------------------------------------------------------------------------------------- checkpoints
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -871,12 +874,24 @@ class GraphedSegment:
     graph's output tensors (overwritten by the next call): (mask uint8 [B,T,H,W], Dice counts int32 [B,T,ncls,3] | None)."""
 
     def __init__(self, model: "GDKVM", frames: torch.Tensor, target: Optional[torch.Tensor] = None, warmup: int = 2,
-                 state: Optional[torch.Tensor] = None):
+                 state: Optional[torch.Tensor] = None, streams: Optional[int] = None):
         """state (fp32 [B,Hh,Dk,Dv]): capture the state-carrying form -- calls then take `state=` (copied into the graph's buffer) and
-        return (mask, counts, state after the last frame), as segment(..., state=, return_state=True) does (GDKVM.segment_clip)."""
+        return (mask, counts, state after the last frame), as segment(..., state=, return_state=True) does (GDKVM.segment_clip).
+        streams: the batch is cut into that many equal groups of clips whose forwards run on their own streams INSIDE the one graph (fork at
+        the start, join at the end, every group writing its slice of the one result).  Clips never interact, so the masks are the same
+        bits; what changes is the schedule: every kernel of a forward fills the chip, drains with a tail and runs its phases in lockstep,
+        and a second, independent stream fills those gaps -- cfg2: 0.898 against 0.940 ms per 16 x 32 frames with two groups of eight,
+        although each half-batch kernel alone is less efficient (the halves one after the other: 1.085 ms); three or four groups and
+        unequal ones lose (profiles/r05_n_two_streams_in_one_graph.txt).  None = 2 for stateless batches of at least 8 clips that halve, else 1."""
         if not frames.is_cuda:
             raise RuntimeError("GraphedSegment needs device tensors")
         self.model, self.frames, self.target, self.state = model, frames, target, state
+        B = frames.shape[0]
+        if streams is None:
+            streams = 2 if (state is None and B >= 8 and B % 2 == 0 and os.environ.get("GDKVM_SEGMENT_STREAMS", "2") != "1") else 1
+        if streams < 1 or B % streams or (streams > 1 and state is not None):
+            raise ValueError(f"GraphedSegment: streams={streams} must divide the {B} clips (and the state-carrying form runs on one)")
+        self.streams = streams
         kw = {} if state is None else {"state": state, "return_state": True}
         with torch.no_grad():
             side = torch.cuda.Stream(device=frames.device)
@@ -884,11 +899,32 @@ class GraphedSegment:
             with torch.cuda.stream(side):
                 for _ in range(max(1, warmup)):
                     model.segment(self.frames, self.target, **kw)
+                    if streams > 1:                        # (the groups' shapes too: nothing may be built or sized inside the capture)
+                        model.segment(self.frames[: B // streams], None if target is None else self.target[: B // streams])
             torch.cuda.current_stream(frames.device).wait_stream(side)
             torch.cuda.synchronize(frames.device)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self.out = model.segment(self.frames, self.target, **kw)
+            if streams == 1:
+                with torch.cuda.graph(self.graph):
+                    self.out = model.segment(self.frames, self.target, **kw)
+            else:
+                T, H, W = frames.shape[1], frames.shape[3], frames.shape[4]
+                mask = torch.empty((B, T, H, W), dtype=torch.uint8, device=frames.device)
+                counts = None if target is None else torch.empty((B, T, model.cfg.num_classes, 3), dtype=torch.int32, device=frames.device)
+                self._side = [torch.cuda.Stream(device=frames.device) for _ in range(streams)]
+                per = B // streams
+                with torch.cuda.graph(self.graph):
+                    cur = torch.cuda.current_stream(frames.device)
+                    for s_ in self._side:
+                        s_.wait_stream(cur)
+                    for i, s_ in enumerate(self._side):
+                        with torch.cuda.stream(s_):
+                            lo, hi = i * per, (i + 1) * per
+                            model.segment(self.frames[lo:hi], None if target is None else self.target[lo:hi], _mask_out=mask[lo:hi],
+                                          _counts_out=None if counts is None else counts[lo:hi])
+                    for s_ in self._side:
+                        cur.wait_stream(s_)
+                self.out = (mask, counts)
         # The graph holds raw addresses of the weight packs the warm-up calls built OUTSIDE its memory pool: keep them alive here (a replay
         # must never read freed memory), and remember the epochs they belong to -- a replay after the weights or packs changed would segment
         # with the weights of capture time, so __call__ raises instead.

@@ -654,16 +654,17 @@ def argmax_dice(logits: torch.Tensor, target: Optional[torch.Tensor] = None):
     return mask, counts
 
 
-def upsample_argmax_dice(logits: torch.Tensor, H: int, W: int, target: Optional[torch.Tensor] = None):
+def upsample_argmax_dice(logits: torch.Tensor, H: int, W: int, target: Optional[torch.Tensor] = None,
+                         mask_out: Optional[torch.Tensor] = None, counts_out: Optional[torch.Tensor] = None):
     """Fused bilinear upsample (align_corners=False) + argmax + Dice counts (gdkvm_upsample_argmax_dice).
-    logits [BT,ncls,hl,wl] low-resolution; returns (mask u8 [BT,H,W], counts i32 [BT,ncls,3] | None)."""
+    logits [BT,ncls,hl,wl] low-resolution; returns (mask u8 [BT,H,W], counts i32 [BT,ncls,3] | None); mask_out / counts_out: write there."""
     lib = load()
     BT, ncls, hl, wl = logits.shape
     dev = _dev(logits, target)
     if target is not None and (target.dtype != torch.uint8 or tuple(target.shape) != (BT, H, W)):
         raise GdkvmError("target must be uint8 [BT,H,W]")
-    mask = torch.empty((BT, H, W), dtype=torch.uint8, device=dev)
-    counts = torch.empty((BT, ncls, 3), dtype=torch.int32, device=dev) if target is not None else None
+    mask = _out_like(mask_out, (BT, H, W), torch.uint8, dev, "mask_out")
+    counts = _out_like(counts_out, (BT, ncls, 3), torch.int32, dev, "counts_out") if target is not None else None
     with torch.cuda.device(dev):
         rc = lib.gdkvm_upsample_argmax_dice(_ptr(logits), _ptr(target), _ptr(mask), _ptr(counts), BT, ncls, hl, wl, H, W,
                                             _io_dtype(logits), _stream(dev))
@@ -671,8 +672,19 @@ def upsample_argmax_dice(logits: torch.Tensor, H: int, W: int, target: Optional[
     return mask, counts
 
 
+def _out_like(out, shape, dtype, dev, what):
+    """A caller-owned output (e.g. a slice of a larger result, so that parts of a batch computed on different streams land in ONE tensor
+    without a concatenation pass) or a fresh tensor."""
+    if out is None:
+        return torch.empty(shape, dtype=dtype, device=dev)
+    if tuple(out.shape) != tuple(shape) or out.dtype != dtype or out.device != dev or not out.is_contiguous():
+        raise GdkvmError(f"{what} must be a contiguous {dtype} tensor of shape {tuple(shape)} on the inputs' device")
+    return out
+
+
 def head_upsample_argmax_dice(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, H: int, W: int,
-                              target: Optional[torch.Tensor] = None):
+                              target: Optional[torch.Tensor] = None, mask_out: Optional[torch.Tensor] = None,
+                              counts_out: Optional[torch.Tensor] = None):
     """The decoder's 1x1 head + bilinear upsample + argmax + Dice counts in one kernel (gdkvm_head_upsample_argmax_dice): x is the
     channels_last stride-4 feature [BT,C,hl,wl], weight fp32 [classes, C], bias fp32 [classes]; the class planes never reach memory.
     Bit-identical to head_logits followed by upsample_argmax_dice.  Returns (mask u8 [BT,H,W], counts i32 [BT,classes,3] | None)."""
@@ -689,8 +701,8 @@ def head_upsample_argmax_dice(x: torch.Tensor, weight: torch.Tensor, bias: torch
         raise GdkvmError("all tensors must live on one device")
     if target is not None and (target.dtype != torch.uint8 or tuple(target.shape) != (BT, H, W)):
         raise GdkvmError("target must be uint8 [BT,H,W]")
-    mask = torch.empty((BT, H, W), dtype=torch.uint8, device=dev)
-    counts = torch.empty((BT, ncls, 3), dtype=torch.int32, device=dev) if target is not None else None
+    mask = _out_like(mask_out, (BT, H, W), torch.uint8, dev, "mask_out")
+    counts = _out_like(counts_out, (BT, ncls, 3), torch.int32, dev, "counts_out") if target is not None else None
     with torch.cuda.device(dev):
         rc = lib.gdkvm_head_upsample_argmax_dice(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), _ptr(target), _ptr(mask), _ptr(counts),
                                                  BT, C, ncls, hl, wl, H, W, _io_dtype(x), _stream(dev))

@@ -136,6 +136,34 @@ def test_segment_captured_in_a_graph(hip):
         g(frames[0][:, :2], target[0][:, :2])
 
 
+def test_segment_graph_with_the_batch_on_several_streams(hip):
+    """GraphedSegment(streams=n): the batch as n equal groups of clips on n streams of ONE hipGraph, every group writing its slice of the one
+    result -- the same masks and Dice counts as the eager call over the whole batch, bit for bit (clips never interact); 8 clips default to
+    two streams; fresh batches go through the input buffers; groups that do not divide the batch and the state-carrying form are refused."""
+    from gdkvm_amd.model import GDKVM, GDKVMConfig, GraphedSegment
+    torch.manual_seed(43)
+    model = GDKVM(GDKVMConfig()).eval().fuse_for_inference().cuda().to(torch.bfloat16).to(memory_format=torch.channels_last)
+    frames = [torch.rand(8, 3, 3, 112, 112, device="cuda").bfloat16() for _ in range(2)]
+    target = [(torch.rand(8, 3, 112, 112, device="cuda") > 0.5).to(torch.uint8) for _ in range(2)]
+    with torch.no_grad():
+        want = [tuple(t.clone() for t in model.segment(f, t_)) for f, t_ in zip(frames, target)]
+        g = model.graphed_segment(frames[0].clone(), target[0].clone())
+        assert g.streams == 2
+        for n in (2, 4):
+            gn = GraphedSegment(model, frames[0].clone(), target[0].clone(), streams=n)
+            for f, t_, (m, c) in zip(frames, target, want):
+                gm, gc = gn(f, t_)
+                assert gm.shape == m.shape and torch.equal(gm, m) and torch.equal(gc, c), n
+        gm, gc = g(frames[1], target[1])
+        assert torch.equal(gm, want[1][0]) and torch.equal(gc, want[1][1])
+        g1 = GraphedSegment(model, frames[0].clone(), streams=2)                 # without a target: masks only
+        assert g1(frames[1])[1] is None and torch.equal(g1(frames[1])[0], want[1][0])
+        with pytest.raises(ValueError):
+            GraphedSegment(model, frames[0].clone(), streams=3)
+        with pytest.raises(ValueError):
+            GraphedSegment(model, frames[0].clone(), state=torch.zeros(8, 1, 64, 256, device="cuda"), streams=2)
+
+
 def test_fused_build_on_maps_wider_than_64_pixels(hip):
     """528x528 frames: the stride-8 map is 66 pixels wide, wider than the chunked 3x3 kernel tiles -- those layers and the strided ones
     take the general implicit-GEMM kernel; 33x33 = 1089 tokens per frame.  The fused bf16 build against the independent restatement."""
