@@ -51,6 +51,8 @@ with torch.no_grad():
             s.wait_stream(cur)
         for i, (s, c) in enumerate(zip(streams, chunks)):
             with torch.cuda.stream(s):
+                if i and os.environ.get("PROBE_DELAY_US"):             # experiment: the later streams start late (phases out of step)
+                    torch.cuda._sleep(int(float(os.environ["PROBE_DELAY_US"]) * 2100 * i))
                 outs[i] = model.segment(c)[0]
         for s in streams:
             cur.wait_stream(s)
