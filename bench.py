@@ -573,6 +573,15 @@ def main():
                     ms = e0.elapsed_time(e1) / iters
                     return {"ms_per_call": round(ms, 3), "frames_per_s": round(nframes / (ms * 1e-3), 1)}
                 wl = {"configs[2] 8x20x256x256, 4 classes, one call": module_rate(lambda: m3.segment(f3), 160)}
+                try:                                            # the same call as one hipGraph replay (two groups of clips on two streams inside)
+                    f3b = f3.to(torch.bfloat16)
+                    g3 = m3.graphed_segment(f3b)
+                    if not torch.equal(g3(f3b)[0], mask16):
+                        raise RuntimeError("replayed masks differ from the eager ones")
+                    wl[f"configs[2] 8x20x256x256, 4 classes, one hipGraph replay ({g3.streams} streams inside)"] = module_rate(lambda: g3(f3b), 160, 6)
+                    del g3, f3b
+                except Exception as e:                          # noqa: BLE001 -- informational
+                    wl["configs[2] graph"] = {"error": f"{type(e).__name__}: {e}"[:200]}
                 del m3, f3, lg3, mask32, mask16
                 f5 = torch.rand(2, 512, 3, 256, 256, device=dev).to(torch.bfloat16)
                 wl["configs[4] 2x512x256x256, 16 chunks of 32 frames, state carried"] = module_rate(lambda: model.segment_clip(f5, 32, graph=True), 1024)
