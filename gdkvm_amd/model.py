@@ -882,15 +882,16 @@ class GraphedSegment:
         bits; what changes is the schedule: every kernel of a forward fills the chip, drains with a tail and runs its phases in lockstep,
         and a second, independent stream fills those gaps -- cfg2: 0.898 against 0.940 ms per 16 x 32 frames with two groups of eight,
         although each half-batch kernel alone is less efficient (the halves one after the other: 1.085 ms); three or four groups and
-        unequal ones lose (profiles/r05_n_two_streams_in_one_graph.txt).  None = 2 for stateless batches of at least 8 clips that halve, else 1."""
+        unequal ones lose (profiles/r05_n_two_streams_in_one_graph.txt).  None = 2 for batches of at least 8 clips that halve, else 1 (GDKVM_SEGMENT_STREAMS overrides where it divides the batch)."""
         if not frames.is_cuda:
             raise RuntimeError("GraphedSegment needs device tensors")
         self.model, self.frames, self.target, self.state = model, frames, target, state
         B = frames.shape[0]
         if streams is None:
-            streams = 2 if (state is None and B >= 8 and B % 2 == 0 and os.environ.get("GDKVM_SEGMENT_STREAMS", "2") != "1") else 1
-        if streams < 1 or B % streams or (streams > 1 and state is not None):
-            raise ValueError(f"GraphedSegment: streams={streams} must divide the {B} clips (and the state-carrying form runs on one)")
+            env = os.environ.get("GDKVM_SEGMENT_STREAMS", "")
+            streams = int(env) if env.isdigit() and int(env) >= 1 and B % int(env) == 0 else (2 if (B >= 8 and B % 2 == 0) else 1)
+        if streams < 1 or B % streams:
+            raise ValueError(f"GraphedSegment: streams={streams} must divide the {B} clips")
         self.streams = streams
         kw = {} if state is None else {"state": state, "return_state": True}
         with torch.no_grad():
@@ -900,7 +901,8 @@ class GraphedSegment:
                 for _ in range(max(1, warmup)):
                     model.segment(self.frames, self.target, **kw)
                     if streams > 1:                        # (the groups' shapes too: nothing may be built or sized inside the capture)
-                        model.segment(self.frames[: B // streams], None if target is None else self.target[: B // streams])
+                        kw_w = {} if state is None else {"state": state[: B // streams], "return_state": True}
+                        model.segment(self.frames[: B // streams], None if target is None else self.target[: B // streams], **kw_w)
             torch.cuda.current_stream(frames.device).wait_stream(side)
             torch.cuda.synchronize(frames.device)
             self.graph = torch.cuda.CUDAGraph()
@@ -917,14 +919,18 @@ class GraphedSegment:
                     cur = torch.cuda.current_stream(frames.device)
                     for s_ in self._side:
                         s_.wait_stream(cur)
+                    states = []
                     for i, s_ in enumerate(self._side):
                         with torch.cuda.stream(s_):
                             lo, hi = i * per, (i + 1) * per
-                            model.segment(self.frames[lo:hi], None if target is None else self.target[lo:hi], _mask_out=mask[lo:hi],
-                                          _counts_out=None if counts is None else counts[lo:hi])
+                            kw_i = {} if state is None else {"state": state[lo:hi], "return_state": True}
+                            res = model.segment(self.frames[lo:hi], None if target is None else self.target[lo:hi], _mask_out=mask[lo:hi],
+                                                _counts_out=None if counts is None else counts[lo:hi], **kw_i)
+                            if state is not None:
+                                states.append(res[2])
                     for s_ in self._side:
                         cur.wait_stream(s_)
-                self.out = (mask, counts)
+                    self.out = (mask, counts) if state is None else (mask, counts, torch.cat(states, 0))     # (the groups' final states: one small copy)
         # The graph holds raw addresses of the weight packs the warm-up calls built OUTSIDE its memory pool: keep them alive here (a replay
         # must never read freed memory), and remember the epochs they belong to -- a replay after the weights or packs changed would segment
         # with the weights of capture time, so __call__ raises instead.

@@ -139,7 +139,7 @@ def test_segment_captured_in_a_graph(hip):
 def test_segment_graph_with_the_batch_on_several_streams(hip):
     """GraphedSegment(streams=n): the batch as n equal groups of clips on n streams of ONE hipGraph, every group writing its slice of the one
     result -- the same masks and Dice counts as the eager call over the whole batch, bit for bit (clips never interact); 8 clips default to
-    two streams; fresh batches go through the input buffers; groups that do not divide the batch and the state-carrying form are refused."""
+    two streams; fresh batches go through the input buffers; groups that do not divide the batch are refused; the state-carrying form splits the state with the clips."""
     from gdkvm_amd.model import GDKVM, GDKVMConfig, GraphedSegment
     torch.manual_seed(43)
     model = GDKVM(GDKVMConfig()).eval().fuse_for_inference().cuda().to(torch.bfloat16).to(memory_format=torch.channels_last)
@@ -160,8 +160,12 @@ def test_segment_graph_with_the_batch_on_several_streams(hip):
         assert g1(frames[1])[1] is None and torch.equal(g1(frames[1])[0], want[1][0])
         with pytest.raises(ValueError):
             GraphedSegment(model, frames[0].clone(), streams=3)
-        with pytest.raises(ValueError):
-            GraphedSegment(model, frames[0].clone(), state=torch.zeros(8, 1, 64, 256, device="cuda"), streams=2)
+        # the state-carrying form on two streams: masks, counts and the final state of segment(..., state=, return_state=True)
+        s0 = 0.3 * torch.randn(8, 1, 64, 256, device="cuda")
+        wm, wc, ws = model.segment(frames[1], target[1], state=s0, return_state=True)
+        gs = GraphedSegment(model, frames[0].clone(), target[0].clone(), state=torch.zeros_like(s0), streams=2)
+        gm, gc, gst = gs(frames[1], target[1], state=s0)
+        assert torch.equal(gm, wm) and torch.equal(gc, wc) and torch.equal(gst, ws)
 
 
 def test_fused_build_on_maps_wider_than_64_pixels(hip):
