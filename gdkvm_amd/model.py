@@ -906,8 +906,13 @@ class GraphedSegment:
             torch.cuda.current_stream(frames.device).wait_stream(side)
             torch.cuda.synchronize(frames.device)
             self.graph = torch.cuda.CUDAGraph()
+            # (with a process group alive its watchdog THREAD may poll events of earlier collectives while this thread captures: under the
+            # default "global" capture mode that aborts the process -- train.GraphedTrainStep met it -- so only this thread is policed)
+            mode = {}
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                mode = {"capture_error_mode": "thread_local"}
             if streams == 1:
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, **mode):
                     self.out = model.segment(self.frames, self.target, **kw)
             else:
                 T, H, W = frames.shape[1], frames.shape[3], frames.shape[4]
@@ -915,7 +920,7 @@ class GraphedSegment:
                 counts = None if target is None else torch.empty((B, T, model.cfg.num_classes, 3), dtype=torch.int32, device=frames.device)
                 self._side = [torch.cuda.Stream(device=frames.device) for _ in range(streams)]
                 per = B // streams
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, **mode):
                     cur = torch.cuda.current_stream(frames.device)
                     for s_ in self._side:
                         s_.wait_stream(cur)

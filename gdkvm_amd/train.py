@@ -189,7 +189,8 @@ class GraphedTrainStep:
         # (with a collective in the step the process group's watchdog THREAD polls the events of the warm-up steps' all-reduces while this
         # thread captures; under the default "global" capture mode its hipEventQuery aborts the process with "operation not permitted when
         # stream is capturing" -- measured round 5 -- so only this thread's calls are policed)
-        mode = {"capture_error_mode": "thread_local"} if grad_sync is not None else {}
+        import torch.distributed as dist
+        mode = {"capture_error_mode": "thread_local"} if (grad_sync is not None or (dist.is_available() and dist.is_initialized())) else {}
         with torch.cuda.graph(self.graph, **mode):
             self.loss = train_step(model, opt, self.frames, self.target, autocast_dtype, grad_sync)
         self.eager_steps = max(1, warmup)       # optimiser steps taken before the first replay (the capture itself runs no kernel)

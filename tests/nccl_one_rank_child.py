@@ -7,6 +7,7 @@ group is initialised before any other GPU call of this process, which is why thi
 
     python tests/nccl_one_rank_child.py ddp [B T S]     three train steps, DDP-wrapped (forced) against the bare model
     python tests/nccl_one_rank_child.py graph [B T S]   the step AND its gradient all-reduce captured in one hipGraph, against the eager step
+    python tests/nccl_one_rank_child.py infer           the inference graph (two streams) captured and replayed between collectives
     python tests/nccl_one_rank_child.py cp              context_parallel_scan's exchange branch against gdkvm_scan_fwd
 Prints ONE JSON line; the parent asserts on it.  (reprod/index.astro:238-249 of the reference's website is the recipe: a
 torch.distributed launcher, one process per GPU.)"""
@@ -110,6 +111,33 @@ def graph(dev, B, T, S):
             "grads_are_bucket_views": all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))}
 
 
+def infer(dev):
+    """What `bench.py --gpus N` does on every rank of an N > 1 run, on the one-rank group: collectives (barrier, all-reduce) around a
+    forward that is captured into a hipGraph -- two groups of clips on two streams -- while the process group's watchdog thread is alive."""
+    from gdkvm_amd import ops
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    ops.require_native()
+    torch.manual_seed(5)
+    model = GDKVM(GDKVMConfig()).eval().fuse_for_inference().to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    frames = torch.rand(8, 4, 3, 112, 112, device=dev).bfloat16()
+    t = torch.ones(4, device=dev)
+    for _ in range(3):
+        dist.all_reduce(t)                                   # outstanding collective work right in front of the capture
+    dist.barrier()
+    with torch.no_grad():
+        want = model.segment(frames)[0].clone()
+        dist.all_reduce(t)
+        g = model.graphed_segment(frames)
+        same = bool(torch.equal(g(frames)[0], want))
+        dist.barrier()
+        for _ in range(5):
+            g(frames)
+        dist.all_reduce(t)
+        same = same and bool(torch.equal(g(frames)[0], want))
+    torch.cuda.synchronize()
+    return {"mode": "infer", "backend": dist.get_backend(), "world": dist.get_world_size(), "streams": g.streams, "masks_equal": same}
+
+
 def cp(dev):
     from gdkvm_amd import ops
     from gdkvm_amd.distributed import context_parallel_scan
@@ -143,6 +171,8 @@ def main():
         elif mode == "graph":
             B, T, S = (int(x) for x in sys.argv[2:5]) if len(sys.argv) >= 5 else (4, 8, 112)
             res = graph(dev, B, T, S)
+        elif mode == "infer":
+            res = infer(dev)
         elif mode == "cp":
             res = cp(dev)
         else:

@@ -63,6 +63,15 @@ def test_training_step_with_its_all_reduce_captured_in_one_graph(hip):
 
 
 @pytest.mark.gpu
+def test_inference_graph_captured_beside_a_live_process_group(hip):
+    """bench.py at N > 1: barriers and an all-reduce around a forward captured into a hipGraph (two streams inside) in a process whose
+    RCCL group -- and its watchdog thread -- is alive; the replays give the eager masks."""
+    res = _run("infer")
+    print(res)
+    assert res["backend"] == "nccl" and res["world"] == 1 and res["streams"] == 2 and res["masks_equal"], res
+
+
+@pytest.mark.gpu
 def test_context_parallel_scan_exchange_branch_on_rccl(hip):
     res = _run("cp")
     print(res)
