@@ -39,7 +39,8 @@ with torch.no_grad():
     print(f"one stream, one graph        {timeit(g1.replay):.4f} ms")
 
     chunks = list(frames.split(split, 0)) if split else list(frames.chunk(parts, 0))
-    streams = [torch.cuda.Stream() for _ in range(parts)]
+    pr = os.environ.get("PROBE_PRIORITIES")                     # e.g. "-1,0": stream priorities (lower = higher priority)
+    streams = [torch.cuda.Stream(priority=int(v)) for v in pr.split(",")] if pr else [torch.cuda.Stream() for _ in range(parts)]
     for c in chunks:                                           # warm every shape (packs, attributes) outside the capture
         model.segment(c)
     torch.cuda.synchronize()
