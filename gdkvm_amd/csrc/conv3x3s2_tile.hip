@@ -1,0 +1,365 @@
+// conv3x3s2_tile.hip -- SURVEY.md §8f row n1: the two STRIDED residual blocks of the encoder (3x3 / stride 2 / pad 1 convolution + the block's
+// 1x1 / stride-2 downsample branch) on a halo-band kernel of their own (round 5).  Until now they ran on the general implicit-GEMM kernel
+// (conv_igemm.hip), which gathers every tap's pixels from memory again -- 9 k-steps per tile against a 7 k-cycle prologue and a 9 k-cycle
+// epilogue, the CU's vector-memory path saturated by gathers + weights: 0.15 of the MFMA rate, the worst layers of the forward per flop.
+//
+// The stride-1 tile kernel (conv3x3_tile.hip) stages a halo band in LDS once per 64-channel chunk and reads the nine taps as nine SHIFTED
+// reads at base + immediate.  With stride 2 the sixteen pixels of an MFMA operand are two input pixels apart, which no LDS pitch serves
+// without bank conflicts -- unless the band is stored SPLIT BY PARITY: the input pixel at band row r = 2 pr + rp, column c = 2 pc + cp goes to
+// plane (rp, cp) at (pr, pc).  Output pixel (py, px) then reads tap (dy, dx) at plane (dy & 1, dx & 1), position (py + (dy >> 1), px + (dx >> 1)):
+// consecutive output pixels are consecutive plane pixels again, every operand address is base + immediate, and the LDS-DMA that fills the band
+// writes linearly whatever the source address is, so the split costs nothing.
+//
+//   * four waves own 112 output pixels (7 rows of a 14-wide map, or whole small frames) x 128 output channels, two workgroups per CU;
+//   * input channels in chunks of 32 (80 B per LDS pixel: 64 + 16, conflict-free ds_read_b128): the four planes of a 15 x 29 pixel band are
+//     36 KB, double-buffered 72 KB;
+//   * per chunk nine k-steps of 32 products (one per tap) and, with the branch, a tenth: the CENTRE tap's pixels (plane (1, 1): exactly the
+//     pixels the 1x1 / stride-2 convolution reads) against the branch's weights into a second accumulator set -- the branch costs one k-step
+//     in ten instead of a launch;
+//   * weights in fragment order (gdkvm_conv3x3s2_pack_weights: [K / 16][chunk][tap .. , branch][lane][8]) streamed from L2 by asm loads with
+//     hand-written wait counts, as in conv3x3_tile.hip (a wave that mixes LDS-DMA and register loads gets vmcnt(0) from the compiler).
+// Arithmetic: fp32 accumulation over the same 9 C (resp. C) products as a library convolution, one rounding after the epilogue.
+#include <stdlib.h>
+#include <atomic>
+#include <type_traits>
+
+#include "gdkvm_common.hpp"
+
+namespace {
+
+constexpr int S2_CK = 32;                // input channels per LDS chunk
+constexpr int S2_PIX = 80;               // bytes between LDS pixels: 4 data slots + 1 padding slot of 16 B
+constexpr int S2_SLOTS = S2_PIX / 16;
+constexpr int S2_MAXMT = 7;              // 16-pixel tiles per workgroup tile (112 pixels; the template parameter MT: 7, or 4 for maps of <= 64 pixels)
+constexpr int S2_PP = 10;                // DMA pieces (1 KiB) per wave and chunk: bands of up to 39 KiB (two workgroups' 2 x 39 + 1 KiB fit a CU's 160)
+constexpr int S2_NTW = 2;                // 16-channel output tiles per wave (4 waves x 32 = 128 channels per workgroup)
+
+__device__ const uint4 g_s2_zero16 = {0, 0, 0, 0};
+
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for_s2(F&& f)
+{
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for_s2<I + 1, E>(f);
+    }
+}
+
+struct S2Args {
+    const bf16_t* x; const bf16_t* w; const float* bias; bf16_t* y; bf16_t* yd;
+    int N, H, W, C, K, Ho, Wo;
+    int fpt, th, tiles_y, ntiles;        // frames per tile, output rows per tile, row tiles per frame, tiles in all
+    int pw, fs, npieces, band_px;        // plane row pitch (Wo + 1), band pixels per frame ((4 th + 2) pw), 1 KiB DMA pieces per chunk, band pixels
+    int pb01, pb10, pb11;                // first pixel of planes (0, 1), (1, 0), (1, 1) inside a frame's band (plane (0, 0) starts at 0)
+    int relu;
+    float inv_fs, inv_pw, inv_tw, inv_wo;   // 1 / fs, 1 / pw, 1 / (th Wo), 1 / Wo
+};
+
+__device__ __forceinline__ int s2_div(int n, float inv) { return (int)(((float)n + 0.5f) * inv); }   // exact for the small indices here
+
+// row j of the 16-channel output tile kt is output channel s2_channel(kt, j): the two tiles of a 32-channel group interleave in fours, so
+// that a lane's accumulator rows 4g .. 4g+3 of BOTH tiles of its wave are 8 consecutive channels (one 16-byte store per pixel)
+__host__ __device__ __forceinline__ int s2_channel(int kt, int j) { return 32 * (kt >> 1) + 8 * (j >> 2) + 4 * (kt & 1) + (j & 3); }
+
+template <bool DOWN, int S2_MT>
+__global__ __launch_bounds__(256, 2) void conv3x3s2_tile_kernel(S2Args a)
+{
+    constexpr int KS = DOWN ? 10 : 9;                      // k-steps per chunk: the nine taps (+ the branch on the centre tap's pixels)
+    constexpr int WD = DOWN ? 2 : 3;                       // weight ring depth (KS a multiple of it: static register indices)
+    extern __shared__ __attribute__((aligned(16))) unsigned char s2_band[];    // [2][npieces * 1024] | 1 KiB dump slot
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H, W = a.W, C = a.C, K = a.K, PW = a.pw;
+    const int band_bytes = a.npieces * 1024, nchunk = C / S2_CK;
+    const int tpix = a.fpt * a.th * a.Wo;
+    const int co0 = blockIdx.y * 128 + 32 * w;             // this wave's output channels co0 .. co0 + 31
+
+    f32x4 bias4[S2_NTW];                                   // (asm loads: see conv3x3_tile.hip on what the compiler does to visible ones)
+#pragma unroll
+    for (int nt = 0; nt < S2_NTW; ++nt) {
+        const float* bp = a.bias + s2_channel(co0 / 16 + nt, 4 * g);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(bias4[nt]) : "v"(bp) : "memory");
+    }
+
+    // DMA piece geometry (tile-invariant): piece j = w + 4 u, slot d = 64 j + lane = 5 pix + c5 (c5 = 4: padding)
+    int g_off[S2_PP], g_meta[S2_PP];                       // source pixel offset from the band's origin; band row << 16 | 8 c5 << 8 | frame, or -1
+#pragma unroll
+    for (int u = 0; u < S2_PP; ++u) {
+        const int j = w + 4 * u, d = 64 * j + lane, pix = d / S2_SLOTS, c5 = d - S2_SLOTS * pix;
+        const int f = s2_div(pix, a.inv_fs);
+        int q = pix - f * a.fs, rp = 0, cp = 0;
+        if (q >= a.pb11) { q -= a.pb11; rp = 1; cp = 1; }
+        else if (q >= a.pb10) { q -= a.pb10; rp = 1; }
+        else if (q >= a.pb01) { q -= a.pb01; cp = 1; }
+        const int pr = s2_div(q, a.inv_pw), pc = q - pr * PW;
+        const int r = 2 * pr + rp, c = 2 * pc + cp;        // band row / column: input pixel (iy0 + r, c - 1)
+        g_off[u] = (f * H + r) * W + c;
+        const bool live = j < a.npieces && c5 < 4 && pix < a.band_px && c >= 1 && c <= W;
+        g_meta[u] = live ? (r << 16 | (c5 * 8) << 8 | f) : -1;
+    }
+    struct Geo { const bf16_t* b; int iy0, nfr; };
+    auto geo_of = [&](int tile) __attribute__((always_inline)) {
+        const int ty = tile % a.tiles_y, fg = tile / a.tiles_y;
+        Geo q;
+        q.iy0 = 2 * ty * a.th - 1;
+        q.nfr = min(a.fpt, a.N - fg * a.fpt);
+        q.b = a.x + (((long long)fg * a.fpt * H + q.iy0) * W - 1) * C;         // band pixel (0, 0) of frame 0 (never dereferenced outside the image)
+        return q;
+    };
+    auto fetch = [&](const Geo q, int chunk, int buf) __attribute__((always_inline)) {
+        const bf16_t* origin = q.b + chunk * S2_CK;
+#pragma unroll
+        for (int u = 0; u < S2_PP; ++u) {                   // (always S2_PP pieces: surplus ones land in the dump slot -- no branch, see conv3x3_tile.hip)
+            const int j = w + 4 * u;
+            const int yy = q.iy0 + (g_meta[u] >> 16);
+            const bool ok = g_meta[u] >= 0 && (unsigned)yy < (unsigned)H && (g_meta[u] & 255) < q.nfr;
+            const bf16_t* src = ok ? origin + (long long)g_off[u] * C + ((g_meta[u] >> 8) & 255) : reinterpret_cast<const bf16_t*>(&g_s2_zero16);
+            unsigned char* dst = j < a.npieces ? s2_band + buf * band_bytes + 1024 * j : s2_band + 2 * band_bytes;
+            __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(reinterpret_cast<uintptr_t>(dst)), 16, 0, 0);
+        }
+    };
+
+    int tile = blockIdx.x;
+    Geo cur = geo_of(min(tile, a.ntiles - 1));
+    if (tile < a.ntiles) fetch(cur, 0, 0);
+
+    // this lane's output pixel in each pixel tile: LDS byte offset of plane (0, 0) position (py, px), channel piece g
+    unsigned pbase[S2_MT];
+#pragma unroll
+    for (int m = 0; m < S2_MT; ++m) {
+        const int p = min(16 * m + li, tpix - 1);
+        const int f = s2_div(p, a.inv_tw), r = p - f * (a.th * a.Wo), py = s2_div(r, a.inv_wo), px = r - py * a.Wo;
+        pbase[m] = (unsigned)((f * a.fs + py * PW + px) * S2_PIX + g * 16);
+    }
+    // tap t = 3 dy + dx reads plane (dy & 1, dx & 1) at (py + (dy >> 1), px + (dx >> 1)); t = 9: the centre tap's pixels again (the branch)
+    auto tap_off = [&](int t) __attribute__((always_inline)) {
+        t = t >= 9 ? 4 : t;
+        const int dy = t / 3, dx = t - 3 * dy;
+        const int pb = (dy & 1) ? ((dx & 1) ? a.pb11 : a.pb10) : ((dx & 1) ? a.pb01 : 0);
+        return (unsigned)((pb + (dy >> 1) * PW + (dx >> 1)) * S2_PIX);
+    };
+
+    const int nks = nchunk * KS;
+    const bf16_t* wrow[S2_NTW];
+#pragma unroll
+    for (int nt = 0; nt < S2_NTW; ++nt) wrow[nt] = a.w + ((size_t)(co0 / 16 + nt) * nks * 64 + lane) * 8;
+    struct WF { bf16x8 f[S2_NTW]; };
+    auto wload = [&](WF& o, int ks) __attribute__((always_inline)) {          // (wraps: a tile's last loads fetch the next tile's first k-steps)
+        ks = ks >= nks ? ks - nks : ks;
+        const size_t off = (size_t)ks * 512;
+#pragma unroll
+        for (int nt = 0; nt < S2_NTW; ++nt) asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(o.f[nt]) : "v"(wrow[nt] + off) : "memory");
+    };
+    auto wwait = [&](WF& o, auto nc) __attribute__((always_inline)) {
+        constexpr int N = decltype(nc)::value;
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(o.f[0]), "+v"(o.f[1]) : "n"(N) : "memory");
+    };
+    WF wr[WD];
+#pragma unroll
+    for (int j = 0; j < WD; ++j) wload(wr[j], j);
+    int gc = 0;                                             // chunks processed so far: chunk gc lives in LDS buffer gc & 1
+
+    for (; tile < a.ntiles; tile += gridDim.x) {
+        const Geo nxt = geo_of(min(tile + (int)gridDim.x, a.ntiles - 1));
+        f32x4 acc[S2_MT][S2_NTW], acc2[DOWN ? S2_MT : 1][S2_NTW];
+#pragma unroll
+        for (int m = 0; m < S2_MT; ++m)
+#pragma unroll
+            for (int nt = 0; nt < S2_NTW; ++nt) {
+                acc[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (DOWN) acc2[m][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        for (int chunk = 0; chunk < nchunk; ++chunk, ++gc) {
+            const int buf = gc & 1;
+            // this chunk's band (requested a chunk ago) has landed once only the WD x NTW weight loads of the last WD k-steps are outstanding
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WD * S2_NTW) : "memory");
+            asm volatile("s_barrier" ::: "memory");
+            {
+                const bool more = chunk + 1 < nchunk;
+                Geo q;
+                q.b = more ? cur.b : nxt.b; q.iy0 = more ? cur.iy0 : nxt.iy0; q.nfr = more ? cur.nfr : nxt.nfr;
+                fetch(q, more ? chunk + 1 : 0, buf ^ 1);
+            }
+            const unsigned char* band = s2_band + buf * band_bytes;
+            auto load_x = [&](bf16x8 (&xb)[S2_MT], int t) __attribute__((always_inline)) {
+                const unsigned off = tap_off(min(t, KS - 1));
+#pragma unroll
+                for (int m = 0; m < S2_MT; ++m) xb[m] = *reinterpret_cast<const bf16x8*>(band + pbase[m] + off);
+            };
+            const int ksb = chunk * KS;
+            if constexpr (DOWN) {
+                // ONE set of pixel fragments, refilled fragment by fragment right behind the MFMAs that consumed it (two sets + two accumulator
+                // sets + the rings spill at 256 registers): fragment m of the next tap is requested 2 (S2_MT - 1 - m) + ... MFMAs before its use
+                bf16x8 xs[S2_MT];
+                load_x(xs, 0);
+                static_for_s2<0, KS>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    wwait(wr[j % WD], std::integral_constant<int, (WD - 1) * S2_NTW + (j < WD ? S2_PP : 0)>{});
+                    const unsigned offn = tap_off(min(j + 1, KS - 1));
+#pragma unroll
+                    for (int m = 0; m < S2_MT; ++m) {
+#pragma unroll
+                        for (int nt = 0; nt < S2_NTW; ++nt) {
+                            if constexpr (j == 9) acc2[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[j % WD].f[nt], xs[m], acc2[m][nt], 0, 0, 0);
+                            else acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[j % WD].f[nt], xs[m], acc[m][nt], 0, 0, 0);
+                        }
+                        xs[m] = *reinterpret_cast<const bf16x8*>(band + pbase[m] + offn);
+                    }
+                    wload(wr[j % WD], ksb + j + WD);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            } else {
+                bf16x8 xa[S2_MT], xb[S2_MT];
+                load_x(xa, 0);
+                static_for_s2<0, KS>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    // younger than the fragments of k-step j when they are used: the loads of the next WD - 1 k-steps and, for the first WD
+                    // k-steps of a chunk, the S2_PP band pieces requested above
+                    wwait(wr[j % WD], std::integral_constant<int, (WD - 1) * S2_NTW + (j < WD ? S2_PP : 0)>{});
+                    bf16x8 (&xc)[S2_MT] = (j % 2 == 0) ? xa : xb;
+                    bf16x8 (&xn)[S2_MT] = (j % 2 == 0) ? xb : xa;
+                    load_x(xn, j + 1);
+#pragma unroll
+                    for (int m = 0; m < S2_MT; ++m)
+#pragma unroll
+                        for (int nt = 0; nt < S2_NTW; ++nt) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[j % WD].f[nt], xc[m], acc[m][nt], 0, 0, 0);
+                    wload(wr[j % WD], ksb + j + WD);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+        }
+        // epilogue: lane (li, g) holds channels co0 + 8g .. +7 of pixel 16 m + li (rows 4g .. 4g+3 of both output tiles of the wave)
+        {
+            const int ty = tile % a.tiles_y, fg = tile / a.tiles_y;
+            const float lo = a.relu ? 0.f : -INFINITY;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int m = 0; m < S2_MT; ++m) {
+                const int p = 16 * m + li, pc = min(p, tpix - 1);
+                const int f = s2_div(pc, a.inv_tw), r = pc - f * (a.th * a.Wo), py = s2_div(r, a.inv_wo), px = r - py * a.Wo;
+                const int n = fg * a.fpt + f, yy = ty * a.th + py;
+                const bool live = p < tpix && n < a.N && yy < a.Ho;
+                const size_t o = (((size_t)n * a.Ho + yy) * a.Wo + px) * K + co0 + 8 * g;
+                u32x4 ow, ow2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x2 v = f32x2{acc[m][q >> 1][2 * (q & 1)], acc[m][q >> 1][2 * (q & 1) + 1]} + f32x2{bias4[q >> 1][2 * (q & 1)], bias4[q >> 1][2 * (q & 1) + 1]};
+                    v = __builtin_elementwise_max(v, f32x2{lo, lo});
+                    ow[q] = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    if (DOWN) ow2[q] = (unsigned)f32_to_bf16(acc2[m][q >> 1][2 * (q & 1)]) | ((unsigned)f32_to_bf16(acc2[m][q >> 1][2 * (q & 1) + 1]) << 16);
+                }
+                // (asm stores: invisible to the compiler's wait-count pass, which would otherwise drain the next tile's operands here; s_nop: the
+                //  hazard recogniser does not see an asm store's data registers being rewritten right behind it)
+                if (live) {
+                    bf16_t* const yp = a.y + o;
+                    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(yp), "v"(ow) : "memory");
+                    if (DOWN) {
+                        bf16_t* const yp2 = a.yd + o;
+                        asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(yp2), "v"(ow2) : "memory");
+                    }
+                }
+            }
+        }
+        cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing may land in LDS after the workgroup is gone
+}
+
+// weights w [K][3][3][C] (bf16, the memory order of a channels_last [K, C, 3, 3] tensor) and the branch's wd [K][C] (or NULL) ->
+// [K / 16][k-step = chunk * KS + t][lane = 16 g + li][8]:  t < 9: w[s2_channel(kt, li)][t][32 chunk + 8 g ..],  t = 9: wd[s2_channel(kt, li)][32 chunk + 8 g ..]
+__global__ __launch_bounds__(256) void conv3x3s2_pack_kernel(const uint4* w, const uint4* wd, uint4* packed, int K, int C)
+{
+    const int KS = wd ? 10 : 9, nks = C / S2_CK * KS;
+    const size_t total = (size_t)(K / 16) * nks * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int lane = (int)(i & 63), li = lane & 15, g = lane >> 4;
+        const size_t f = i >> 6;
+        const int ks = (int)(f % nks), kt = (int)(f / nks);
+        const int chunk = ks / KS, t = ks - KS * chunk, k = s2_channel(kt, li);
+        packed[i] = t < 9 ? w[(((size_t)k * 9 + t) * C + chunk * S2_CK + 8 * g) / 8] : wd[((size_t)k * C + chunk * S2_CK + 8 * g) / 8];
+    }
+}
+
+}  // namespace
+
+extern "C" int gdkvm_conv3x3s2_pack_weights(const void* w, const void* w_down, void* packed, int K, int C, int io_dtype, void* stream)
+{
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "conv3x3s2_pack_weights: only bf16 is implemented");
+    if (K <= 0 || C <= 0 || K % 128 || C % S2_CK) return gdkvm_fail(GDKVM_ERR_SHAPE, "conv3x3s2_pack_weights: K=%d C=%d (K a multiple of 128, C of 32)", K, C);
+    if (!w || !packed || !gdkvm_aligned16(w) || !gdkvm_aligned16(packed) || (w_down && !gdkvm_aligned16(w_down)))
+        return gdkvm_fail(GDKVM_ERR_ARG, "conv3x3s2_pack_weights: null or unaligned pointer");
+    if (int rc = gdkvm_check_device()) return rc;
+    const size_t total = (size_t)(K / 16) * (C / S2_CK * (w_down ? 10 : 9)) * 64;
+    hipLaunchKernelGGL(conv3x3s2_pack_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const uint4*>(w), static_cast<const uint4*>(w_down), static_cast<uint4*>(packed), K, C);
+    GDKVM_LAUNCH_CHECK("conv3x3s2_pack_kernel");
+    return GDKVM_OK;
+}
+
+extern "C" int gdkvm_conv3x3s2_down_bias_act(const void* x, const void* packed, const float* bias, void* y, int relu, void* y_down,
+                                             int N, int C, int H, int W, int K, int io_dtype, void* stream)
+{
+    if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "conv3x3s2_down_bias_act: only bf16 is implemented");
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || C % S2_CK || K % 128)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv3x3s2_down_bias_act: N=%d C=%d H=%d W=%d K=%d (C a multiple of 32, K of 128)", N, C, H, W, K);
+    if (N == 0) return GDKVM_OK;
+    if (!x || !packed || !bias || !y) return gdkvm_fail(GDKVM_ERR_ARG, "conv3x3s2_down_bias_act: null pointer");
+    const void* ptrs[] = {x, packed, bias, y};
+    for (const void* p : ptrs) if (!gdkvm_aligned16(p)) return gdkvm_fail(GDKVM_ERR_ARG, "conv3x3s2_down_bias_act: pointers must be 16-byte aligned");
+    if (y_down && !gdkvm_aligned16(y_down)) return gdkvm_fail(GDKVM_ERR_ARG, "conv3x3s2_down_bias_act: pointers must be 16-byte aligned");
+    S2Args a{};
+    a.x = static_cast<const bf16_t*>(x); a.w = static_cast<const bf16_t*>(packed); a.bias = bias;
+    a.y = static_cast<bf16_t*>(y); a.yd = static_cast<bf16_t*>(y_down);
+    a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.relu = relu;
+    a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
+    if ((long long)N * H * W * C > 0x7fffffffLL || (long long)N * a.Ho * a.Wo * K > 0x7fffffffLL)
+        return gdkvm_fail(GDKVM_ERR_SHAPE, "conv3x3s2_down_bias_act: tensor too large for 32-bit offsets");
+    const int maxpix = 16 * S2_MAXMT, maxpieces = 4 * S2_PP - 1;
+    if (a.Wo > maxpix) return gdkvm_fail(GDKVM_ERR_SHAPE, "conv3x3s2_down_bias_act: output rows of %d pixels exceed the %d-pixel tile", a.Wo, maxpix);
+    if (a.Ho * a.Wo <= maxpix) { a.th = a.Ho; a.fpt = maxpix / (a.Ho * a.Wo); a.tiles_y = 1; if (a.fpt > N) a.fpt = N; }
+    else { a.fpt = 1; a.th = maxpix / a.Wo; a.tiles_y = (a.Ho + a.th - 1) / a.th; }
+    a.pw = a.Wo + 1;
+    auto pieces = [&]() {
+        a.fs = (4 * a.th + 2) * a.pw;                     // planes (0, *): th + 1 rows, planes (1, *): th rows, all pw wide
+        a.band_px = a.fpt * a.fs;
+        return (a.band_px * S2_SLOTS + 63) / 64;
+    };
+    while (pieces() > maxpieces && a.fpt > 1) --a.fpt;
+    while (pieces() > maxpieces && a.th > 1) { --a.th; a.tiles_y = (a.Ho + a.th - 1) / a.th; }
+    a.npieces = pieces();
+    if (a.npieces > maxpieces) return gdkvm_fail(GDKVM_ERR_SHAPE, "conv3x3s2_down_bias_act: a one-row band of %d pixels does not fit the LDS tile", a.Wo);
+    a.pb01 = (a.th + 1) * a.pw; a.pb10 = 2 * (a.th + 1) * a.pw; a.pb11 = a.pb10 + a.th * a.pw;
+    a.inv_fs = 1.0f / (float)a.fs; a.inv_pw = 1.0f / (float)a.pw; a.inv_tw = 1.0f / (float)(a.th * a.Wo); a.inv_wo = 1.0f / (float)a.Wo;
+    const long long ntiles = (long long)((N + a.fpt - 1) / a.fpt) * a.tiles_y;
+    if (ntiles > 0x7fffffffLL) return gdkvm_fail(GDKVM_ERR_SHAPE, "conv3x3s2_down_bias_act: too many tiles");
+    a.ntiles = (int)ntiles;
+    if (int rc = gdkvm_check_device()) return rc;
+    const int gy = K / 128;
+    int per = 512 / gy; if (per < 1) per = 1;
+    const int gx = (int)(ntiles < per ? ntiles : per);     // persistent: two workgroups per CU
+    const size_t lds = (size_t)2 * a.npieces * 1024 + 1024;
+    static std::atomic<unsigned long long> done_mask{0};   // per device; a lost race only repeats the idempotent call
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "conv3x3s2_down_bias_act: hipGetDevice");
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
+        const void* fns[] = {reinterpret_cast<const void*>(conv3x3s2_tile_kernel<true, 7>), reinterpret_cast<const void*>(conv3x3s2_tile_kernel<false, 7>),
+                             reinterpret_cast<const void*>(conv3x3s2_tile_kernel<true, 4>), reinterpret_cast<const void*>(conv3x3s2_tile_kernel<false, 4>)};
+        for (const void* fn : fns)
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+                return gdkvm_fail(GDKVM_ERR_LAUNCH, "conv3x3s2_down_bias_act: LDS attribute");
+        done_mask.fetch_or(bit, std::memory_order_relaxed);
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool small = a.fpt * a.th * a.Wo <= 64;          // four pixel tiles hold the workgroup tile
+    if (y_down) {
+        if (small) hipLaunchKernelGGL((conv3x3s2_tile_kernel<true, 4>), dim3(gx, gy), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((conv3x3s2_tile_kernel<true, 7>), dim3(gx, gy), dim3(256), lds, st, a);
+    } else {
+        if (small) hipLaunchKernelGGL((conv3x3s2_tile_kernel<false, 4>), dim3(gx, gy), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL((conv3x3s2_tile_kernel<false, 7>), dim3(gx, gy), dim3(256), lds, st, a);
+    }
+    GDKVM_LAUNCH_CHECK("conv3x3s2_tile_kernel");
+    return GDKVM_OK;
+}

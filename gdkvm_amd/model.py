@@ -81,6 +81,9 @@ _BN_COUNTED_BY_MODEL = [False]
 # (default), or the library convolution + one epilogue pass (GDKVM_CONV_IGEMM=0).  Measured equal on the EchoNet shapes -- 1.013 /
 # 1.020 ms against 1.021 ms per cfg2 forward -- so the hand-written path is taken: no solver search, one launch.
 _IGEMM_STRIDED = os.environ.get("GDKVM_CONV_IGEMM", "1") != "0"
+# The two strided blocks of the inference build on the stride-2 halo-band kernel (round 5, csrc/conv3x3s2_tile.hip); "0" = the general
+# implicit-GEMM kernel (A/B switch; equal up to fp32 re-association)
+_CONV_S2_TILE = os.environ.get("GDKVM_CONV_S2_TILE", "1") != "0"
 # SURVEY.md §8f row n4 in the inference build: key / query / value projections, both gate logits and the key / query norms in ONE
 # launch over the pixel feature (ops.proj_gates), the scan taking the norms as given -- or (GDKVM_PROJ_GATES=0, the A/B switch
 # behind DESIGN.md §8 n4's numbers) the three-launch form: ops.proj_rows, ops.gate_logits, norms inside gdkvm_scan_prep.
@@ -352,6 +355,14 @@ class FusedConv(nn.Module):
                 and cv.weight.is_contiguous(memory_format=torch.channels_last)
                 and self._tile(cv.in_channels, cv.out_channels, cv.stride[0], False, x.shape[-1]) is None):
             return None
+        if (_CONV_S2_TILE and cv.stride[0] == 2 and ops.conv3x3s2_served(cv.in_channels, cv.out_channels, x.shape[-1])):
+            # the stride-2 halo-band kernel (csrc/conv3x3s2_tile.hip): the band staged once per chunk, split by parity; the branch a tenth k-step
+            key = _wkey(cv.weight, d.conv.weight) + (x.device, "s2")
+            ent = self.__dict__.get("_wpack_s2")
+            if ent is None or ent[0] != key:
+                ent = (key, ops.conv3x3s2_pack_weights(cv.weight, d.conv.weight))
+                self.__dict__["_wpack_s2"] = ent
+            return ops.conv3x3s2_down_bias_act(x.contiguous(memory_format=torch.channels_last), ent[1], self.epi.bias, cv.out_channels, self.relu, True)
         dw = d.conv.weight if d.conv.weight.is_contiguous(memory_format=torch.channels_last) else d.conv.weight.contiguous(memory_format=torch.channels_last)
         return ops.conv_down_bias_act(x.contiguous(memory_format=torch.channels_last), cv.weight, self.epi.bias, self._packed(x.device, igemm=True),
                                       dw, d._packed(x.device, igemm=True), None, cv.stride[0], self.relu)
@@ -530,6 +541,7 @@ class GDKVM(nn.Module):
         for m in self.modules():                            # the fragment-ordered weight copies of the fused convolutions
             if isinstance(m, FusedConv):
                 m.__dict__.pop("_wpack", None)
+                m.__dict__.pop("_wpack_s2", None)
 
     def _apply(self, fn, recurse=True):
         self.invalidate_packed_weights()
@@ -861,6 +873,7 @@ def _packs_held(model: "GDKVM"):
     for m in model.modules():
         if isinstance(m, FusedConv):
             held.append(m.__dict__.get("_wpack"))
+            held.append(m.__dict__.get("_wpack_s2"))
     for p in model.parameters():
         held.append(p.__dict__.get("_gdkvm_train_packs"))
     return [h for h in held if h is not None]

@@ -81,6 +81,8 @@ SIGNATURES = {
     "gdkvm_conv_igemm_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gdkvm_conv_down_bias_act": (_i, [_vp] * 4 + [_i] + [_vp] * 3 + [_i] * 10 + [_vp]),
     "gdkvm_conv_cat_bias_act": (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
+    "gdkvm_conv3x3s2_pack_weights": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "gdkvm_conv3x3s2_down_bias_act": (_i, [_vp] * 4 + [_i] + [_vp] + [_i] * 6 + [_vp]),
     "gdkvm_conv_s2_dgrad_pack_bytes": (_sz, [_i] * 3),
     "gdkvm_conv_s2_pack_train": (_i, [_vp] * 7 + [_i, _i, _vp]),
     "gdkvm_conv_s2_dgrad": (_i, [_vp] * 4 + [_i] * 6 + [_vp]),
@@ -934,6 +936,48 @@ def conv_down_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor
         rc = lib.gdkvm_conv_down_bias_act(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), y.data_ptr(), int(relu), down_packed.data_ptr(),
                                           _ptr(down_bias), yd.data_ptr(), n, c, hh, ww, k, r, s, stride, pad, BF16, _stream(x.device))
     _check(rc, "gdkvm_conv_down_bias_act")
+    return y, yd
+
+
+def conv3x3s2_served(c: int, k: int, w_in: int) -> bool:
+    """Does the stride-2 halo-band kernel (gdkvm_conv3x3s2_down_bias_act) take a 3x3 / stride-2 / pad-1 layer of c -> k channels on rows of w_in pixels?"""
+    return c % 32 == 0 and k % 128 == 0 and (w_in - 1) // 2 + 1 <= 112
+
+
+def conv3x3s2_pack_weights(weight: torch.Tensor, down_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The fragment-ordered pack gdkvm_conv3x3s2_down_bias_act reads: weight bf16 channels_last [K,C,3,3], down_weight bf16 [K,C,1,1] or None."""
+    lib = load()
+    k, c = weight.shape[:2]
+    if weight.dtype != torch.bfloat16 or tuple(weight.shape[2:]) != (3, 3) or not weight.is_cuda or not weight.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("conv3x3s2_pack_weights: channels_last bf16 [K,C,3,3] device weight")
+    if down_weight is not None and (down_weight.dtype != torch.bfloat16 or tuple(down_weight.shape) != (k, c, 1, 1) or down_weight.device != weight.device):
+        raise GdkvmError("conv3x3s2_pack_weights: the branch weight must be bf16 [K,C,1,1] on the same device")
+    dw = None if down_weight is None else down_weight.reshape(k, c).contiguous()
+    packed = torch.empty(k * c * (9 + (dw is not None)), dtype=torch.bfloat16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = lib.gdkvm_conv3x3s2_pack_weights(weight.data_ptr(), _ptr(dw), packed.data_ptr(), k, c, BF16, _stream(weight.device))
+    _check(rc, "gdkvm_conv3x3s2_pack_weights")
+    return packed
+
+
+def conv3x3s2_down_bias_act(x: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, k: int, relu: bool = True, with_down: bool = True):
+    """(act(conv2d(x, w, stride 2, padding 1) + bias), conv2d(x, w_down, stride 2) | None) on the stride-2 halo-band kernel
+    (gdkvm_conv3x3s2_down_bias_act); x channels_last bf16 [N,C,H,W], packed = conv3x3s2_pack_weights(w, w_down or None)."""
+    lib = load()
+    if x.dim() != 4 or not x.is_cuda or x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise GdkvmError("conv3x3s2_down_bias_act needs a channels_last bf16 [N,C,H,W] device tensor (no CPU path)")
+    n, c, hh, ww = x.shape
+    if packed.dtype != torch.bfloat16 or packed.numel() != k * c * (9 + int(with_down)) or packed.device != x.device:
+        raise GdkvmError("conv3x3s2_down_bias_act: packed must be conv3x3s2_pack_weights(w, w_down) for this layer")
+    if bias.dtype != torch.float32 or bias.numel() != k:
+        raise GdkvmError("bias must be float32 [K]")
+    ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+    y = torch.empty((n, k, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    yd = torch.empty_like(y) if with_down else None
+    with torch.cuda.device(x.device):
+        rc = lib.gdkvm_conv3x3s2_down_bias_act(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), y.data_ptr(), int(relu), _ptr(yd),
+                                               n, c, hh, ww, k, BF16, _stream(x.device))
+    _check(rc, "gdkvm_conv3x3s2_down_bias_act")
     return y, yd
 
 

@@ -391,6 +391,16 @@ int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const v
 int gdkvm_conv_down_bias_act(const void* x, const void* w, const float* bias, void* y, int relu,
                              const void* w_down, const float* bias_down, void* y_down,
                              int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int io_dtype, void* stream);
+/* The same pair on a halo-band kernel of its own (round 5; csrc/conv3x3s2_tile.hip): the 3x3 / stride-2 / pad-1 convolution with bias (+ ReLU)
+ * and, when y_down is given, the block's 1x1 / stride-2 branch (no bias) from ONE launch -- the input band is staged in LDS once per 32-channel
+ * chunk, split by row / column parity so that every tap is a base + immediate read, and the branch is a tenth k-step per chunk on the centre
+ * tap's pixels.  packed: gdkvm_conv3x3s2_pack_weights of the bf16 weights w [K, 3, 3, C] (the memory order of a channels_last [K, C, 3, 3]
+ * tensor) and, for the branch, w_down [K, C] -- K (9 + 1) C elements, or K 9 C without a branch; a pack made WITH a branch needs y_down, one
+ * made without needs y_down = NULL.  C a multiple of 32, K of 128, output rows of at most 112 pixels; else GDKVM_ERR_SHAPE (the general
+ * kernel, gdkvm_conv_down_bias_act, serves those).  Same sums as the general kernel in another order: equal up to fp32 re-association. */
+int gdkvm_conv3x3s2_pack_weights(const void* w, const void* w_down, void* packed, int K, int C, int io_dtype, void* stream);
+int gdkvm_conv3x3s2_down_bias_act(const void* x, const void* packed, const float* bias, void* y, int relu, void* y_down,
+                                  int N, int C, int H, int W, int K, int io_dtype, void* stream);
 /* Training form of the same pair (a residual block's 3x3 / stride-2 / pad-1 convolution w [K, C, 3, 3] and its 1x1 / stride-2 branch
  * w_down [K, C, 1, 1], both without bias), forward and backward on hand-written kernels, deterministic:
  *   gdkvm_conv_s2_pack_train   ONE launch from the fp32 master weights (element strides (k, c, r, s) resp. (k, c): any memory format) to
