@@ -81,9 +81,12 @@ _BN_COUNTED_BY_MODEL = [False]
 # (default), or the library convolution + one epilogue pass (GDKVM_CONV_IGEMM=0).  Measured equal on the EchoNet shapes -- 1.013 /
 # 1.020 ms against 1.021 ms per cfg2 forward -- so the hand-written path is taken: no solver search, one launch.
 _IGEMM_STRIDED = os.environ.get("GDKVM_CONV_IGEMM", "1") != "0"
-# The two strided blocks of the inference build on the stride-2 halo-band kernel (round 5, csrc/conv3x3s2_tile.hip); "0" = the general
-# implicit-GEMM kernel (A/B switch; equal up to fp32 re-association)
-_CONV_S2_TILE = os.environ.get("GDKVM_CONV_S2_TILE", "1") != "0"
+# The two strided blocks of the inference build: the general implicit-GEMM kernel (default), or ("1") the stride-2 halo-band kernel of round 5
+# (csrc/conv3x3s2_tile.hip; equal up to fp32 re-association).  Measured both ways: alone the band kernel is 15 % faster per layer (43.5 + 33.6 against
+# 51.1 + 39.0 us, forward 0.908 against 0.914 ms on one stream), but in the shipped two-stream forward it LOSES 2 % (0.894 against 0.873-0.884 ms per
+# step, three alternating bench runs): its two 73 KB workgroups fill a CU's LDS, and what the second stream gains is exactly the room other
+# kernels leave (profiles/r05_m_small_experiments.txt).
+_CONV_S2_TILE = os.environ.get("GDKVM_CONV_S2_TILE", "0") == "1"
 # SURVEY.md §8f row n4 in the inference build: key / query / value projections, both gate logits and the key / query norms in ONE
 # launch over the pixel feature (ops.proj_gates), the scan taking the norms as given -- or (GDKVM_PROJ_GATES=0, the A/B switch
 # behind DESIGN.md §8 n4's numbers) the three-launch form: ops.proj_rows, ops.gate_logits, norms inside gdkvm_scan_prep.
