@@ -46,15 +46,19 @@ def main(argv=None):
         model = model.to(torch.bfloat16)
     model = model.to(memory_format=torch.channels_last)
 
+    from gdkvm_amd.pipeline import DevicePrefetcher, SegmentRunner
     ds = build_dataset(cfg, args.split)
     lo, hi = shard_range(len(ds), world, rank)
     counts = torch.zeros(cfg.data.num_classes, 3, dtype=torch.int64, device=dev)
     vis_left = cfg.eval_stage.num_vis if rank == 0 else 0
-    for i in range(lo, hi, cfg.batch_size):
-        items = [ds[j] for j in range(i, min(i + cfg.batch_size, hi))]
-        frames = torch.stack([x for x, _ in items]).to(dev)
-        target = torch.stack([y for _, y in items]).to(dev).to(torch.uint8)
-        mask, c = model.segment(frames, target=target)
+    # this rank's shard through a prefetching loader (worker processes decode, pinned staging, host-to-device copies on a side stream) into
+    # ONE captured forward per batch shape (SegmentRunner -> GraphedSegment: a hipGraph replay per batch; the short last batch runs eagerly)
+    dl = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, range(lo, hi)), batch_size=cfg.batch_size, shuffle=False, num_workers=2)
+    fdt = torch.bfloat16 if cfg.precision == "bf16" else torch.float32
+    runner = SegmentRunner(model, graph=os.environ.get("GDKVM_FWD_GRAPH", "1") != "0")
+    i = lo
+    for frames, target in DevicePrefetcher(dl, dev, slots=2, frames_dtype=fdt, target_dtype=torch.uint8):
+        mask, c = runner(frames, target)
         # only frames that carry labels count (EchoNet-Dynamic: the two traced frames of a clip -- gdkvm_amd.data.IGNORE_LABEL everywhere
         # else, where a predicted pixel must not enter |A|): a labelled frame has a non-empty target in some class
         labelled = (c[..., 2].sum(-1, keepdim=True) > 0).unsqueeze(-1)
@@ -65,11 +69,13 @@ def main(argv=None):
             scale = 255 // max(cfg.data.num_classes - 1, 1)
             Image.fromarray((mask[0, 0].cpu().numpy() * scale).astype("uint8")).save(os.path.join(cfg.run_dir, "vis", f"mask_{i:05d}.png"))
             vis_left -= 1
+        i += frames.shape[0]
     if world > 1:
         torch.distributed.all_reduce(counts)                      # the only exchange: 3 integers per class
     if rank == 0:
         dice = ops.dice_from_counts(counts).tolist()
-        print(json.dumps({"split": args.split, "clips": len(ds), "dice_per_class": [round(d, 5) for d in dice],
+        print(json.dumps({"split": args.split, "clips": len(ds), "forward": {"graph_replays": runner.replays, "eager_calls": runner.eager_calls},
+                          "dice_per_class": [round(d, 5) for d in dice],
                           "mean_foreground_dice": round(sum(dice[1:]) / max(len(dice) - 1, 1), 5)}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

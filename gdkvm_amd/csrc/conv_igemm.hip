@@ -303,8 +303,10 @@ int gdkvm_conv_igemm_launch(const void* x, const void* wpacked, const float* bia
 
 // internal entry used by gdkvm_conv_s2_dgrad (conv_s2_train.hip): the data gradient of a 3x3 / stride-2 / pad-1 convolution (+ the 1x1 /
 // stride-2 branch's, dy2 may be NULL) as the kernel's DG form.  dy, dy2 [N, Ho, Wo, Kf] bf16; dx [N, H, W, Cf]; packs: the four class packs
-// of gdkvm_conv_s2_pack_train, consecutive.  0 = launched, 1 = shape not covered.
-int gdkvm_conv_igemm_dgrad_launch(const void* dy, const void* dy2, const void* packs, void* dx, int N, int Cf, int H, int W, int Kf, hipStream_t st)
+// of gdkvm_conv_s2_pack_train, consecutive.  with_down says how the PACK was built (class 0 carries one more tap when the branch rode
+// along): the class offsets follow it, not dy2 -- dy2 == NULL on a pack with the branch is a zero branch gradient (the extra k-steps
+// are skipped, the offsets stay).  0 = launched, 1 = shape not covered.
+int gdkvm_conv_igemm_dgrad_launch(const void* dy, const void* dy2, const void* packs, int with_down, void* dx, int N, int Cf, int H, int W, int Kf, hipStream_t st)
 {
     if (Cf % 64 || Kf % 64 || N < 1 || H < 1 || W < 1) return 1;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -323,8 +325,8 @@ int gdkvm_conv_igemm_dgrad_launch(const void* dy, const void* dy2, const void* p
         a.cls[c].S = 1 + pw;
         a.cls[c].inv_s = 1.0f / (float)(1 + pw);
         a.cls[c].ksteps_main = taps * a.cps;
-        a.cls[c].ksteps_all = (taps + (c == 0 && dy2 ? 1 : 0)) * a.cps;
-        wp += gdkvm_conv_s2_dgrad_pack_elems(Cf, Kf, c, dy2 != nullptr);
+        a.cls[c].ksteps_all = (taps + (c == 0 && dy2 && with_down ? 1 : 0)) * a.cps;
+        wp += gdkvm_conv_s2_dgrad_pack_elems(Cf, Kf, c, with_down);
     }
     if (Cf % 128 == 0) {
         const dim3 grid((unsigned)((M + 127) / 128), (unsigned)(Cf / 128), 4);

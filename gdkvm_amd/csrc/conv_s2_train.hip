@@ -11,7 +11,7 @@
 // Everything is deterministic: same inputs, same bits.
 #include "gdkvm_common.hpp"
 
-int gdkvm_conv_igemm_dgrad_launch(const void* dy, const void* dy2, const void* packs, void* dx, int N, int Cf, int H, int W, int Kf, hipStream_t st);
+int gdkvm_conv_igemm_dgrad_launch(const void* dy, const void* dy2, const void* packs, int with_down, void* dx, int N, int Cf, int H, int W, int Kf, hipStream_t st);
 
 namespace {
 
@@ -106,9 +106,10 @@ extern "C" int gdkvm_conv_s2_pack_train(const float* w, const long long* w_strid
 }
 
 extern "C" int gdkvm_conv_s2_dgrad(const void* dy, const void* dy_down, const void* packed_dgrad, void* dx,
-                                   int N, int C, int H, int W, int K, int io_dtype, void* stream)
+                                   int N, int C, int H, int W, int K, int with_down, int io_dtype, void* stream)
 {
     if (io_dtype != GDKVM_BF16) return gdkvm_fail(GDKVM_ERR_DTYPE, "conv_s2_dgrad: only bf16 is implemented");
+    if (dy_down && !with_down) return gdkvm_fail(GDKVM_ERR_ARG, "conv_s2_dgrad: dy_down given for a pack made without the 1x1 branch (with_down = 0)");
     if (N < 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || C % 64 || K % 64)
         return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_s2_dgrad: N=%d C=%d H=%d W=%d K=%d (C, K multiples of 64)", N, C, H, W, K);
     if (N == 0) return GDKVM_OK;
@@ -116,7 +117,7 @@ extern "C" int gdkvm_conv_s2_dgrad(const void* dy, const void* dy_down, const vo
     if (!gdkvm_aligned16(dy) || !gdkvm_aligned16(packed_dgrad) || !gdkvm_aligned16(dx) || (dy_down && !gdkvm_aligned16(dy_down)))
         return gdkvm_fail(GDKVM_ERR_ARG, "conv_s2_dgrad: pointers must be 16-byte aligned");
     if (int rc = gdkvm_check_device()) return rc;
-    if (gdkvm_conv_igemm_dgrad_launch(dy, dy_down, packed_dgrad, dx, N, C, H, W, K, static_cast<hipStream_t>(stream)))
+    if (gdkvm_conv_igemm_dgrad_launch(dy, dy_down, packed_dgrad, with_down != 0, dx, N, C, H, W, K, static_cast<hipStream_t>(stream)))
         return gdkvm_fail(GDKVM_ERR_SHAPE, "conv_s2_dgrad: tensor too large for 32-bit offsets");
     GDKVM_LAUNCH_CHECK("conv_igemm_kernel<dgrad>");
     return GDKVM_OK;

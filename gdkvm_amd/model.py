@@ -50,6 +50,15 @@ class GDKVMConfig:
     #                leaves more than half the CUs idle -- 2 clips x 512 frames: 16 -- else the serial scan); n > 1: that many.
     #                Equal to the serial scan up to fp32 re-association through the segments' transition matrices, NOT bit for bit.
     scan_segments: int = 1
+    # SURVEY.md A.1 flag: carry z [B,Hh,Dk] ("the same recurrence on v == 1") beside S and divide the read-out by |q . z| + normalizer_eps.
+    # Inference only.  The module's `state` is then [B,Hh,Dk,Dv+1]: S with z as one more column.
+    normalizer: bool = False
+    normalizer_eps: float = 1e-6
+    # per-frame `step` mode -- the value written for frame t carries the embedding (mask_embed) of the mask
+    # PREDICTED for frame t (of mask0 for frame 0 when it is given), XMem-style: read -> KPFF -> decoder -> mask -> write, frame by frame.
+    # Inference only; the time loop is then ~12 launches per frame instead of one scan launch per chunk (GDKVM.segment captures it in
+    # one hipGraph all the same: GraphedSegment).
+    mask_feedback: bool = False
 
 
 def _bn(c):
@@ -62,18 +71,58 @@ def _bn(c):
 _WEIGHTS_EPOCH = [0]
 
 
-def weights_changed() -> None:
-    """Tell every packed-weight cache of the inference paths that parameters were written (an optimiser step): the packs are rebuilt on
-    their next use.  Cheap (a counter); call it after any write the version counters cannot show."""
-    _WEIGHTS_EPOCH[0] += 1
+def weights_changed(model: Optional[nn.Module] = None) -> None:
+    """Tell the packed-weight caches of the inference paths that parameters were written (an optimiser step): the packs are rebuilt on
+    their next use.  Cheap (a counter); call it after any write the version counters cannot show.  With `model` (a GDKVM, or a wrapper
+    holding one as ``.module``) only THAT model's caches and graphs are told -- a frozen teacher / EMA copy in the same process keeps its
+    packs and its captured GraphedSegment (train_step / GraphedTrainStep pass the model they stepped); without an argument every model
+    in the process is told (the process-wide epoch)."""
+    inner = getattr(model, "module", model)
+    cell = None if inner is None else inner.__dict__.get("_epoch_cell")
+    if cell is None:
+        _WEIGHTS_EPOCH[0] += 1
+    else:
+        cell[0] += 1
 
 
-def _wkey(*tensors):
-    """Cache key of a weight pack: the weights epoch (weights_changed), and version counter AND storage address of EVERY source tensor.
+def _epoch_of(owner) -> Tuple[int, int]:
+    """(process-wide epoch, the owning model's epoch): GDKVM hands its ``_epoch_cell`` to the sub-modules that cache packs."""
+    cell = None if owner is None else owner.__dict__.get("_epoch_cell")
+    return (_WEIGHTS_EPOCH[0], 0 if cell is None else cell[0])
+
+
+def _wkey(owner, *tensors):
+    """Cache key of a weight pack: the weights epochs (weights_changed: process-wide and the owning model's), and version counter AND
+    storage address of EVERY source tensor.
     In-place writes through ``.data`` (``p.data.copy_()``: EMA swaps, weight surgery) and fused optimiser steps bump no counter -- after
-    such a write call ``weights_changed()`` or ``GDKVM.invalidate_packed_weights()`` (load_state_dict / .to() / train() /
-    fuse_for_inference() do the latter themselves; train_step / GraphedTrainStep the former)."""
-    return (_WEIGHTS_EPOCH[0],) + tuple((t._version, t.data_ptr()) for t in tensors)
+    such a write call ``weights_changed(model)`` or ``GDKVM.invalidate_packed_weights()`` (load_state_dict / .to() / a train() / eval()
+    mode CHANGE / fuse_for_inference() do the latter themselves; train_step / GraphedTrainStep the former)."""
+    return _epoch_of(owner) + tuple((t._version, t.data_ptr()) for t in tensors)
+
+
+# Convolutions the hand-written kernels do not serve (other `widths`, odd sizes, fp32 inference) run on the framework's library: allowed
+# (BASELINE.json north_star keeps the CNN on PyTorch-ROCm), but never silently on a GPU tensor -- one warning per layer and reason, and
+# GDKVM_STRICT=1 turns it into an error (CI / benchmark runs: the measured path must be the hand-written one).
+_STRICT = os.environ.get("GDKVM_STRICT", "0") == "1"
+_FALLBACKS_SEEN: set = set()
+
+
+def _library_fallback(x: torch.Tensor, layer: str, why: str) -> None:
+    """Called right before a GPU convolution leaves the hand-written path."""
+    if not x.is_cuda:
+        return                                              # (the CPU reference module is plain torch by design)
+    msg = f"gdkvm_amd: {layer} runs on the framework's library kernel, not on csrc/*.hip ({why})"
+    if _STRICT:
+        raise RuntimeError(msg + " [GDKVM_STRICT=1]")
+    if (layer, why) not in _FALLBACKS_SEEN:
+        _FALLBACKS_SEEN.add((layer, why))
+        import warnings
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
+def _describe(conv: nn.Conv2d, x: torch.Tensor) -> str:
+    return (f"Conv2d({conv.in_channels}->{conv.out_channels}, k={tuple(conv.kernel_size)}, s={tuple(conv.stride)}) on "
+            f"{tuple(x.shape)} {str(x.dtype).replace('torch.', '')}")
 
 
 _BN_COUNTED_BY_MODEL = [False]
@@ -81,12 +130,6 @@ _BN_COUNTED_BY_MODEL = [False]
 # (default), or the library convolution + one epilogue pass (GDKVM_CONV_IGEMM=0).  Measured equal on the EchoNet shapes -- 1.013 /
 # 1.020 ms against 1.021 ms per cfg2 forward -- so the hand-written path is taken: no solver search, one launch.
 _IGEMM_STRIDED = os.environ.get("GDKVM_CONV_IGEMM", "1") != "0"
-# The two strided blocks of the inference build: the general implicit-GEMM kernel (default), or ("1") the stride-2 halo-band kernel of round 5
-# (csrc/conv3x3s2_tile.hip; equal up to fp32 re-association).  Measured both ways: alone the band kernel is 15 % faster per layer (43.5 + 33.6 against
-# 51.1 + 39.0 us, forward 0.908 against 0.914 ms on one stream), but in the shipped two-stream forward it LOSES 2 % (0.894 against 0.873-0.884 ms per
-# step, three alternating bench runs): its two 73 KB workgroups fill a CU's LDS, and what the second stream gains is exactly the room other
-# kernels leave (profiles/r05_m_small_experiments.txt).
-_CONV_S2_TILE = os.environ.get("GDKVM_CONV_S2_TILE", "0") == "1"
 # SURVEY.md §8f row n4 in the inference build: key / query / value projections, both gate logits and the key / query norms in ONE
 # launch over the pixel feature (ops.proj_gates), the scan taking the norms as given -- or (GDKVM_PROJ_GATES=0, the A/B switch
 # behind DESIGN.md §8 n4's numbers) the three-launch form: ops.proj_rows, ops.gate_logits, norms inside gdkvm_scan_prep.
@@ -137,6 +180,9 @@ def _conv(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     if (torch.is_grad_enabled() and isinstance(conv, nn.Conv2d) and conv.bias is None and conv.padding_mode == "zeros"
             and ops.conv3x3_train_served(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)):
         return ops.conv3x3(x, conv.weight)
+    if torch.is_grad_enabled():
+        _library_fallback(x, _describe(conv, x), "training build: only stride-1 3x3 layers with channel counts in multiples of 64, "
+                          "the stem and the strided blocks of the default widths are hand-written")
     return conv(x)
 
 
@@ -196,6 +242,8 @@ class Encoder(nn.Module):
             if torch.is_grad_enabled() and isinstance(s[0], nn.Conv2d) and ops.stem_conv_served(x, s[0]):
                 x = ops.stem_conv(x, s[0].weight)         # the hand-written stem kernel, convolution only (csrc/stem_conv_pool.hip)
             else:
+                if torch.is_grad_enabled():
+                    _library_fallback(x, "encoder.stem: " + _describe(s[0], x), "training stem kernel serves 7x7 / stride 2 / <= 4 input channels / 64 outputs in bf16")
                 x = s[0](x)
             p, bn = s[3], s[1]
             pool_ok = isinstance(p, nn.MaxPool2d) and (p.kernel_size, p.stride, p.padding, p.dilation, p.ceil_mode) == (3, 2, 1, 1, False)
@@ -280,7 +328,7 @@ class Decoder(nn.Module):
                 and hd.stride == (1, 1) and hd.padding == (0, 0) and hd.groups == 1 and hd.bias is not None and y.shape[1] % v == 0
                 and g <= 64 and g & (g - 1) == 0 and hd.out_channels <= g and y.is_contiguous(memory_format=torch.channels_last)):
             # 1x1 convolution + bias straight into the NCHW planes the argmax / loss kernels read (ops.head_logits): one pass
-            key = _wkey(hd.weight, hd.bias) + (y.device,)
+            key = _wkey(self, hd.weight, hd.bias) + (y.device,)
             cache = getattr(self, "_head_w32", None)
             if cache is None or cache[0] != key:
                 cache = (key, hd.weight.detach().reshape(hd.out_channels, -1).float().contiguous(), hd.bias.detach().float().contiguous())
@@ -293,6 +341,7 @@ class Decoder(nn.Module):
             # gradient for this layer accumulates atomically and differed by several bf16 ulps from run to run
             x = ops.head(y, hd.weight, hd.bias)
         else:
+            _library_fallback(y, "decoder.head: " + _describe(hd, y), "head kernels serve a 1x1 convolution with bias on a channels_last bf16 / fp32 feature of 8 ... 512 channels")
             x = hd(y)
         return x if size is None else F.interpolate(x, size=size, mode="bilinear", align_corners=False)
 
@@ -336,7 +385,7 @@ class FusedConv(nn.Module):
     def _packed(self, device, igemm: bool = False):
         """The fragment-ordered copy of the weights (ops.conv3x3_pack_weights, or ops.conv_igemm_pack_weights for the general
         kernel), kept until the weights change (_wkey)."""
-        key = _wkey(self.conv.weight) + (device, igemm)
+        key = _wkey(self, self.conv.weight) + (device, igemm)
         ent = self.__dict__.get("_wpack")
         if ent is None or ent[0] != key:
             ent = (key, (ops.conv_igemm_pack_weights if igemm else ops.conv3x3_pack_weights)(self.conv.weight))
@@ -358,14 +407,6 @@ class FusedConv(nn.Module):
                 and cv.weight.is_contiguous(memory_format=torch.channels_last)
                 and self._tile(cv.in_channels, cv.out_channels, cv.stride[0], False, x.shape[-1]) is None):
             return None
-        if (_CONV_S2_TILE and cv.stride[0] == 2 and ops.conv3x3s2_served(cv.in_channels, cv.out_channels, x.shape[-1])):
-            # the stride-2 halo-band kernel (csrc/conv3x3s2_tile.hip): the band staged once per chunk, split by parity; the branch a tenth k-step
-            key = _wkey(cv.weight, d.conv.weight) + (x.device, "s2")
-            ent = self.__dict__.get("_wpack_s2")
-            if ent is None or ent[0] != key:
-                ent = (key, ops.conv3x3s2_pack_weights(cv.weight, d.conv.weight))
-                self.__dict__["_wpack_s2"] = ent
-            return ops.conv3x3s2_down_bias_act(x.contiguous(memory_format=torch.channels_last), ent[1], self.epi.bias, cv.out_channels, self.relu, True)
         dw = d.conv.weight if d.conv.weight.is_contiguous(memory_format=torch.channels_last) else d.conv.weight.contiguous(memory_format=torch.channels_last)
         return ops.conv_down_bias_act(x.contiguous(memory_format=torch.channels_last), cv.weight, self.epi.bias, self._packed(x.device, igemm=True),
                                       dw, d._packed(x.device, igemm=True), None, cv.stride[0], self.relu)
@@ -400,6 +441,8 @@ class FusedConv(nn.Module):
                 # implicit-GEMM kernel, epilogue included (A/B switch: see _IGEMM_STRIDED)
                 return ops.conv_bias_act(x.contiguous(memory_format=torch.channels_last), cv.weight, self.epi.bias, residual,
                                          cv.stride[0], 1, self.relu, ops.CONV_KERNEL_IGEMM, self._packed(x.device, igemm=True))
+        _library_fallback(x, _describe(cv, x), "inference build: the hand-written kernels take bf16 channels_last 3x3 / pad 1 layers with channel counts "
+                          "in multiples of 8 (strided: 32 in, 128 out) and the 1x1 branch fused into a strided block")
         y = self.conv(x)
         if folded:                                          # the bias was added to the consumer's epilogue bias: nothing to do here
             return y
@@ -452,6 +495,7 @@ class FusedConvPool(FusedConv):
             y = F.conv2d(xs, self.w_s2d, None, 1, 2)                             # [N, Cout, H/2 + 1, W/2 + 1]: last row/col unused
             return ops.bias_relu_maxpool(y.contiguous(memory_format=torch.channels_last)[:, :, :x.shape[2] // 2, :x.shape[3] // 2],
                                          self.epi.bias)
+        _library_fallback(x, "encoder.stem: " + _describe(self.conv, x), "inference stem kernel serves 7x7 / stride 2 / pad 3, <= 4 input channels, 64 outputs, bf16, even sizes")
         y = self.conv(x)
         if not y.is_cuda:
             return F.max_pool2d(F.relu(y + self.epi.bias.to(y.dtype).reshape(1, -1, 1, 1)), 3, 2, 1)
@@ -512,6 +556,10 @@ class GDKVM(nn.Module):
         Hh, Dk, Dv, Cp = cfg.heads, cfg.key_dim, cfg.value_dim, cfg.pixel_dim
         if cfg.widths[2] != Cp:
             raise ValueError("pixel_dim must equal the stride-16 encoder width")
+        if cfg.normalizer and (cfg.mask_feedback or cfg.scan_segments != 1):
+            raise ValueError("normalizer=True runs on the serial scan only (no mask_feedback, scan_segments=1)")
+        if cfg.normalizer and not 0.0 < cfg.normalizer_eps < 1.0:
+            raise ValueError("normalizer_eps must lie in (0, 1)")
         self.encoder = Encoder(cfg.in_channels, cfg.widths)
         self.key_proj = nn.Conv2d(Cp, Hh * Dk, 1)
         self.query_proj = nn.Conv2d(Cp, Hh * Dk, 1)
@@ -522,6 +570,15 @@ class GDKVM(nn.Module):
         nn.init.constant_(self.decay_proj.bias, 2.0)                     # sigmoid(2) ~ 0.88: remember by default
         self.kpff = KPFFParams(Hh * Dk, Hh * Dv, Cp)
         self.decoder = Decoder(Cp, cfg.widths, cfg.num_classes)
+        # this model's weights epoch (weights_changed(model)), shared with every sub-module that caches a weight pack
+        self.__dict__["_epoch_cell"] = [0]
+        self._share_epoch_cell()
+
+    def _share_epoch_cell(self):
+        cell = self.__dict__["_epoch_cell"]
+        for m in self.modules():
+            if isinstance(m, (Decoder, FusedConv)):
+                m.__dict__["_epoch_cell"] = cell
 
     # ------------------------------------------------------------------ packed-weight caches of the inference build
     def invalidate_packed_weights(self):
@@ -530,7 +587,7 @@ class GDKVM(nn.Module):
         optimiser steps, ``load_state_dict`` and re-binding; an in-place write through ``.data`` changes neither, so code that
         does one must call this.  Called by load_state_dict(), _apply() (.to / .cuda / .half ...), train() and
         fuse_for_inference()."""
-        for name in ("_qkv_pack", "_gate_w32", "_kpff_pack", "_clip_graphs"):
+        for name in ("_qkv_pack", "_gate_w32", "_kpff_pack", "_clip_graphs", "_mask_w32"):
             self.__dict__.pop(name, None)
         # graphs captured over this module (GraphedSegment, GraphedTrainStep) hold the packs they read and compare this counter: a replay
         # after the packs were dropped raises instead of convolving with the weights of capture time
@@ -544,21 +601,30 @@ class GDKVM(nn.Module):
         for m in self.modules():                            # the fragment-ordered weight copies of the fused convolutions
             if isinstance(m, FusedConv):
                 m.__dict__.pop("_wpack", None)
-                m.__dict__.pop("_wpack_s2", None)
 
     def _apply(self, fn, recurse=True):
         self.invalidate_packed_weights()
         return super()._apply(fn, recurse)
 
     def train(self, mode: bool = True):
-        self.invalidate_packed_weights()
+        if mode != self.training:                           # (a defensive model.eval() on an eval-mode model changes nothing: graphs captured over it stay valid)
+            self.invalidate_packed_weights()
         return super().train(mode)
 
     # ------------------------------------------------------------------ memory path (HIP; overridable hooks)
-    def _memory_scan(self, q, k, v, alpha_logit, beta_logit, state, norms=None):
+    def _memory_scan(self, q, k, v, alpha_logit, beta_logit, state, norms=None, readout=True):
         """q,k [B,T,N,Hh,Dk] v [B,T,N,Hh,Dv] alpha [B,T,Hh] beta [B,T,N,Hh] -> (R [B,T,N,Hh,Dv], S_T).  norms (inference): the
-        inverse key / query norms ops.proj_gates produced with the projections."""
+        inverse key / query norms ops.proj_gates produced with the projections.  readout=False (the write half of a per-frame step):
+        R is not produced (None)."""
         flags = ops.FLAG_NORMALIZE_QK | ops.FLAG_GATE_LOGITS
+        if self.cfg.normalizer:
+            if torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v, alpha_logit, beta_logit)):
+                raise NotImplementedError("GDKVMConfig(normalizer=True) is an inference flag: no backward through the normalised read-out")
+            Dv = v.shape[-1]                                  # module state = [S | z]: [B,Hh,Dk,Dv+1]
+            s0 = None if state is None else state[..., :Dv].contiguous()
+            z0 = None if state is None else state[..., Dv].contiguous()
+            r, s_out, z_out = ops.scan_fwd_normalizer(q, k, v, alpha_logit, beta_logit, s0, z0, _RULES[self.cfg.rule], flags, self.cfg.normalizer_eps)
+            return r, torch.cat([s_out, z_out.unsqueeze(-1)], -1)
         if torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v, alpha_logit, beta_logit)):
             return ops.scan(q, k, v, alpha_logit, beta_logit, state, _RULES[self.cfg.rule], flags)   # saves history
         seg = self.cfg.scan_segments
@@ -568,14 +634,31 @@ class GDKVM(nn.Module):
             if seg > 1 and q.shape[1] % seg:
                 raise ValueError(f"scan_segments={seg} must divide the call's {q.shape[1]} frames")
             return ops.scan_fwd_segmented(q, k, v, alpha_logit, beta_logit, state, segments=seg, rule=_RULES[self.cfg.rule], flags=flags)
-        return ops.scan_fwd(q, k, v, alpha_logit, beta_logit, state, rule=_RULES[self.cfg.rule], flags=flags, norms=norms)
+        return ops.scan_fwd(q, k, v, alpha_logit, beta_logit, state, rule=_RULES[self.cfg.rule], flags=flags, norms=norms, readout=readout)
+
+    def _mask_from_lowres(self, lowres, H, W, target=None, mask_out=None, counts_out=None):
+        """stride-4 logits [F,ncls,hl,wl] -> (mask uint8 [F,H,W], Dice counts | None): bilinear x4 + argmax (ties -> lowest class)."""
+        return ops.upsample_argmax_dice(lowres.contiguous(), H, W, target, mask_out, counts_out)
+
+    def _memory_read(self, q, state, norms=None):
+        """The read half of a per-frame step (mask_feedback): q [B,N,Hh,Dk], state [B,Hh,Dk,Dv] fp32 -> R [B,N,Hh,Dv] = Qn S."""
+        return ops.lkva_read(q, state, ops.FLAG_NORMALIZE_QK, norms)
+
+    def _embed_mask_(self, v, mask, h, w):
+        """v [B,N,Hh*Dv] += mask_embed(adaptive_avg_pool(mask != 0)) in place; mask uint8 [B,H,W] (a predicted mask)."""
+        key = _wkey(self, self.mask_embed.weight) + (v.device,)
+        cache = self.__dict__.get("_mask_w32")
+        if cache is None or cache[0] != key:
+            cache = (key, self.mask_embed.weight.detach().reshape(-1).float().contiguous())
+            self.__dict__["_mask_w32"] = cache
+        return ops.mask_embed_add_(v, mask, cache[1], h, w)
 
     def _fuse(self, local, glob, pixel, h, w):
         p = self.kpff
         if torch.is_grad_enabled() and (pixel.requires_grad or p.wa.requires_grad):
             return ops.kpff(local, glob, pixel, p.wa, p.ba, p.wl, p.wg, h, w)
         # inference: keep the bf16 weight pack of the previous call while the weight tensors are unchanged
-        key = _wkey(p.wa, p.ba, p.wl, p.wg) + (local.dtype, local.device)
+        key = _wkey(self, p.wa, p.ba, p.wl, p.wg) + (local.dtype, local.device)
         cache = getattr(self, "_kpff_pack", None)
         hit = cache is not None and cache[0] == key
         ws = cache[1] if hit else torch.empty(ops.load().gdkvm_kpff_workspace_bytes(local.shape[-1], glob.shape[-1], pixel.shape[-1],
@@ -597,6 +680,9 @@ class GDKVM(nn.Module):
         cfg = self.cfg
         B, T, C, H, W = frames.shape
         Hh, Dk, Dv = cfg.heads, cfg.key_dim, cfg.value_dim
+        if cfg.mask_feedback:
+            logits, _, _, s_out = self._forward_feedback(frames, mask0, state, lowres=_lowres)
+            return (logits, s_out) if return_state else logits
         x = frames.reshape(B * T, C, H, W)
         dt = self.key_proj.weight.dtype
         if torch.is_autocast_enabled():
@@ -630,9 +716,118 @@ class GDKVM(nn.Module):
             _BN_COUNTED_BY_MODEL[0] = False
             ops.end_train_packs()
 
+    def _forward_feedback(self, frames, mask0=None, state=None, lowres=False, target=None, masks_only=False, mask_out=None, counts_out=None):
+        """The per-frame step mode (cfg.mask_feedback).  Encoder and projections run once for all frames (they do
+        not depend on the state), then frame by frame, every clip's frame t together:
+            R_t = Qn_t S_{t-1}                         (_memory_read: gdkvm_lkva_read)
+            F_t = KPFF(K_t, R_t, P_t); decoder; mask_t = argmax(upsample(logits_t))
+            v_t = value_proj(f_t) + mask_embed(pool(mask_t != 0))      (mask0 instead of mask_0 when given)
+            S_t = GDR(S_{t-1}, K_t, v_t)               (_memory_scan with T = 1, no read-out)
+        The batch is laid out TIME-MAJOR ([T*B, ...]: one transposed copy of the frames) so that every per-frame operand is a contiguous
+        block.  Returns (logits [B,T,ncls,.,.] | None when masks_only, mask uint8 [B,T,H,W], Dice counts [B,T,ncls,3] | None, S_T)."""
+        cfg = self.cfg
+        if torch.is_grad_enabled() and self.training:
+            raise NotImplementedError("GDKVMConfig(mask_feedback=True) is an inference mode (the predicted mask is an argmax): eval() / torch.no_grad()")
+        B, T, C, H, W = frames.shape
+        Hh, Dk, Dv = cfg.heads, cfg.key_dim, cfg.value_dim
+        with torch.no_grad():
+            x = frames.transpose(0, 1).reshape(T * B, C, H, W)                   # time-major copy
+            dt = self.key_proj.weight.dtype
+            stem0 = self.encoder.stem[0]
+            if x.is_cuda and isinstance(stem0, FusedConvPool) and getattr(stem0, "w_s2d", None) is not None:
+                x = x.to(dt)
+            else:
+                x = x.to(dtype=dt, memory_format=torch.channels_last)
+            f4, f8, f16 = self.encoder(x)
+            h, w = f16.shape[-2:]
+            N = h * w
+            p_tok, k_tok, q, v, alpha, beta, norms = self._project(f16, T, B, None)      # q [T,B,N,Hh,Dk], alpha [T,B,Hh], ...
+            v = v.reshape(T, B, N, Hh * Dv)
+            k5 = k_tok.reshape(T, B, N, Hh, Dk)
+            nrm = None if norms is None else norms.reshape(T, B * N, Hh, 2)
+            S = torch.zeros((B, Hh, Dk, Dv), dtype=torch.float32, device=frames.device) if state is None else state.to(torch.float32)
+            tgt = None if target is None else target.transpose(0, 1).contiguous()          # [T,B,H,W]
+            mask_tm = torch.empty((T, B, H, W), dtype=torch.uint8, device=frames.device)
+            counts_tm = None if target is None else torch.empty((T, B, cfg.num_classes, 3), dtype=torch.int32, device=frames.device)
+            lows = []
+            for t in range(T):
+                sl = slice(t * B, (t + 1) * B)
+                r_t = self._memory_read(q[t], S, None if nrm is None else nrm[t])
+                fused = self._fuse(k_tok[sl], r_t.reshape(B, N, Hh * Dv), p_tok[sl], h, w)
+                fmap = fused.reshape(B, h, w, -1).permute(0, 3, 1, 2)
+                out = self.decoder(fmap, f8[sl], f4[sl], None, head_fused=masks_only)
+                tg_t = None if tgt is None else tgt[t]
+                co_t = None if counts_tm is None else counts_tm[t]
+                # (the mask kernel wants 16-byte aligned outputs: frame t's slab of the time-major result is, for the usual shapes)
+                slab_ok = (B * H * W) % 16 == 0 and (co_t is None or (B * cfg.num_classes * 12) % 16 == 0)
+                if isinstance(out, HeadFeature) and slab_ok:   # fused inference build: head + upsample + argmax (+ Dice) in one kernel
+                    ops.head_upsample_argmax_dice(out.feature, out.weight, out.bias, H, W, tg_t, mask_tm[t], co_t)
+                elif isinstance(out, HeadFeature):
+                    m_t, c_t = ops.head_upsample_argmax_dice(out.feature, out.weight, out.bias, H, W, tg_t)
+                    mask_tm[t].copy_(m_t)
+                    if co_t is not None:
+                        co_t.copy_(c_t)
+                else:
+                    if not masks_only:
+                        lows.append(out)
+                    m_t, c_t = self._mask_from_lowres(out, H, W, tg_t)
+                    mask_tm[t].copy_(m_t)
+                    if co_t is not None:
+                        co_t.copy_(c_t)
+                v_t = v[t]
+                if t == 0 and mask0 is not None:
+                    m0 = F.adaptive_avg_pool2d(mask0.to(v_t.dtype), (h, w))
+                    v_t = v_t + self._tokens(self.mask_embed(m0))
+                else:
+                    v_t = self._embed_mask_(v_t, mask_tm[t], h, w)
+                kw = {} if nrm is None else {"norms": nrm[t]}
+                _, S = self._memory_scan(q[t].unsqueeze(1), k5[t].unsqueeze(1), v_t.reshape(B, 1, N, Hh, Dv), alpha[t].unsqueeze(1),
+                                         beta[t].unsqueeze(1), S, readout=False, **kw)
+            mask = mask_tm.transpose(0, 1)
+            if mask_out is not None:
+                mask_out.view(B, T, H, W).copy_(mask)
+                mask = mask_out.view(B, T, H, W)
+            else:
+                mask = mask.contiguous()
+            counts = None
+            if counts_tm is not None:
+                counts = counts_tm.transpose(0, 1)
+                if counts_out is not None:
+                    counts_out.view(B, T, cfg.num_classes, 3).copy_(counts)
+                    counts = counts_out.view(B, T, cfg.num_classes, 3)
+                else:
+                    counts = counts.contiguous()
+            logits = None
+            if not masks_only:
+                low = torch.stack(lows, 1)                                        # [B,T,ncls,hl,wl]
+                logits = low if lowres else F.interpolate(low.reshape(B * T, *low.shape[2:]), size=(H, W), mode="bilinear",
+                                                           align_corners=False).reshape(B, T, -1, H, W)
+            return logits, mask, counts, S
+
     def _after_encoder(self, f4, f8, f16, mask0, state, return_state, _lowres, dims, _head_fused=False):
         cfg = self.cfg
         B, T, H, W = dims
+        Hh, Dk, Dv = cfg.heads, cfg.key_dim, cfg.value_dim
+        h, w = f16.shape[-2:]
+        N = h * w
+        p_tok, k_tok, q, v, alpha, beta, norms = self._project(f16, B, T, mask0)
+        if norms is not None and not cfg.normalizer:
+            r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state, norms=norms)
+        else:
+            r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state)
+        fused = self._fuse(k_tok, r.reshape(B * T, N, Hh * Dv), p_tok, h, w)       # [BT,N,Cp]
+        fmap = fused.reshape(B * T, h, w, -1).permute(0, 3, 1, 2)                  # channels_last view, no copy
+        logits = self.decoder(fmap, f8, f4, None if _lowres else (H, W), head_fused=_head_fused and _lowres)
+        if isinstance(logits, HeadFeature):
+            return (logits, s_out) if return_state else logits
+        logits = logits.reshape(B, T, cfg.num_classes, *logits.shape[-2:])
+        return (logits, s_out) if return_state else logits
+
+    def _project(self, f16, B, T, mask0=None):
+        """Everything derived from the stride-16 feature per token: (p_tok [BT,N,Cp], k_tok [BT,N,Hh*Dk], q [B,T,N,Hh,Dk], v [B,T,N,Hh,Dv],
+        alpha logits [B,T,Hh], beta logits [B,T,N,Hh], inverse key / query norms | None).  (B, T) only shape the views: the per-frame
+        step mode passes (T, B) for its time-major batch."""
+        cfg = self.cfg
         Hh, Dk, Dv = cfg.heads, cfg.key_dim, cfg.value_dim
         h, w = f16.shape[-2:]
         N = h * w
@@ -666,7 +861,7 @@ class GDKVM(nn.Module):
             # ONE launch for everything derived from the pixel feature: K / Q / V, both gate logits, the key / query norms
             projs = (self.key_proj, self.query_proj, self.value_proj)
             gp, dp = self.gate_proj, self.decay_proj
-            key = _wkey(*(t for c in projs for t in (c.weight, c.bias)), gp.weight, gp.bias, dp.weight, dp.bias) + (tok2d.device,)
+            key = _wkey(self, *(t for c in projs for t in (c.weight, c.bias)), gp.weight, gp.bias, dp.weight, dp.bias) + (tok2d.device,)
             cache = getattr(self, "_qkv_pack", None)
             if cache is None or cache[0] != key:
                 w_all = torch.cat([c.weight.detach().reshape(c.out_channels, -1).float() for c in projs], 0)
@@ -681,7 +876,7 @@ class GDKVM(nn.Module):
             # the three projections in ONE pass over the tokens (ops.proj_rows: token tile in LDS, weights streamed in MFMA
             # fragment order); the packed weight is rebuilt only when a projection's parameters change
             projs = (self.key_proj, self.query_proj, self.value_proj)
-            key = _wkey(*(t for c in projs for t in (c.weight, c.bias))) + (tok2d.device,)
+            key = _wkey(self, *(t for c in projs for t in (c.weight, c.bias))) + (tok2d.device,)
             cache = getattr(self, "_qkv_pack", None)
             if cache is None or cache[0] != key:
                 w_all = torch.cat([c.weight.detach().reshape(c.out_channels, -1).float() for c in projs], 0)
@@ -716,7 +911,7 @@ class GDKVM(nn.Module):
                 and p_tok.shape[-1] % v8 == 0 and g_lanes <= 64 and g_lanes & (g_lanes - 1) == 0):
             # both gate logits in one pass over the feature (token mean + two N = 1 projections + casts as framework ops: 6 launches)
             gp, dp = self.gate_proj, self.decay_proj
-            key = _wkey(gp.weight, gp.bias, dp.weight, dp.bias) + (p_tok.device,)
+            key = _wkey(self, gp.weight, gp.bias, dp.weight, dp.bias) + (p_tok.device,)
             cache = getattr(self, "_gate_w32", None)
             if cache is None or cache[0] != key:
                 cache = (key, tuple(t.detach().float().contiguous() for t in (gp.weight.reshape(Hh, -1), gp.bias, dp.weight, dp.bias)))
@@ -730,17 +925,7 @@ class GDKVM(nn.Module):
             # keep every parameter in the graph (DDP: no unused params) -- through the B*T*Hh decay logits, not through v: a zero added to the
             # [B*T*N, Hh*Dv] values was a 29 us pass forward and a reduction over their gradient backward (round 4)
             alpha = alpha + 0.0 * self.mask_embed.weight.sum()
-        if norms is not None:
-            r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state, norms=norms)
-        else:
-            r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state)
-        fused = self._fuse(k_tok, r.reshape(B * T, N, Hh * Dv), p_tok, h, w)       # [BT,N,Cp]
-        fmap = fused.reshape(B * T, h, w, -1).permute(0, 3, 1, 2)                  # channels_last view, no copy
-        logits = self.decoder(fmap, f8, f4, None if _lowres else (H, W), head_fused=_head_fused and _lowres)
-        if isinstance(logits, HeadFeature):
-            return (logits, s_out) if return_state else logits
-        logits = logits.reshape(B, T, cfg.num_classes, *logits.shape[-2:])
-        return (logits, s_out) if return_state else logits
+        return p_tok, k_tok, q, v, alpha, beta, norms
 
     @torch.no_grad()
     def fuse_for_inference(self):
@@ -782,6 +967,7 @@ class GDKVM(nn.Module):
             fused.conv, fused.epi, fused.relu = stem[0].conv, stem[0].epi, True
             stem = nn.Sequential(fused.enable_s2d())
         self.encoder.stem = stem
+        self._share_epoch_cell()
         return self
 
     @torch.no_grad()
@@ -790,6 +976,10 @@ class GDKVM(nn.Module):
         (return_state: plus the memory state after the last frame, [B,Hh,Dk,Dv] fp32).  _mask_out / _counts_out: caller-owned contiguous
         outputs of those shapes (GraphedSegment: slices of ONE result for the parts of a batch it runs on several streams)."""
         B, T, _, H, W = frames.shape
+        if self.cfg.mask_feedback:
+            _, mask, counts, s_out = self._forward_feedback(frames, kw.get("mask0"), kw.get("state"), target=target, masks_only=True,
+                                                            mask_out=_mask_out, counts_out=_counts_out)
+            return (mask, counts, s_out) if return_state else (mask, counts)
         tgt = None if target is None else target.reshape(B * T, H, W).contiguous()
         mo = None if _mask_out is None else _mask_out.view(B * T, H, W)
         co = None if _counts_out is None else _counts_out.view(B * T, -1, 3)
@@ -826,7 +1016,7 @@ class GDKVM(nn.Module):
             # (keyed on everything the captured kernels were chosen by: the shape, the recurrence and its segmenting, and the weight /
             # pack epochs -- a graph reads the weight packs of capture time; invalidate_packed_weights() drops the whole cache)
             key = (B, chunk_frames) + tuple(frames.shape[2:]) + (frames.dtype, target is not None, frames.device, cfg.rule, cfg.scan_segments,
-                                                                   _WEIGHTS_EPOCH[0], self.__dict__.get("_pack_epoch", 0))
+                                                                   _epoch_of(self), self.__dict__.get("_pack_epoch", 0))
             cache = self.__dict__.setdefault("_clip_graphs", {})
             for old in [k_ for k_ in cache if k_[:-2] == key[:-2] and k_ != key]:
                 del cache[old]                              # the same shape under older weights: never replayed again
@@ -869,14 +1059,13 @@ class GDKVM(nn.Module):
 
 def _packs_held(model: "GDKVM"):
     """Every packed-weight tensor the module caches hold right now (what a captured graph reads by address)."""
-    held = [model.__dict__.get(n) for n in ("_qkv_pack", "_gate_w32", "_kpff_pack")]
+    held = [model.__dict__.get(n) for n in ("_qkv_pack", "_gate_w32", "_kpff_pack", "_mask_w32")]
     dec = model._modules.get("decoder")
     if dec is not None:
         held.append(dec.__dict__.get("_head_w32"))
     for m in model.modules():
         if isinstance(m, FusedConv):
             held.append(m.__dict__.get("_wpack"))
-            held.append(m.__dict__.get("_wpack_s2"))
     for p in model.parameters():
         held.append(p.__dict__.get("_gdkvm_train_packs"))
     return [h for h in held if h is not None]
@@ -903,11 +1092,22 @@ class GraphedSegment:
             raise RuntimeError("GraphedSegment needs device tensors")
         self.model, self.frames, self.target, self.state = model, frames, target, state
         B = frames.shape[0]
+        def aligned(n):
+            """Every group writes its slice of the ONE mask / counts result, and the mask kernel wants 16-byte aligned outputs: the
+            per-group byte offsets (per x T x H x W mask bytes, per x T x ncls x 12 count bytes) must be multiples of 16."""
+            per_ = B // n
+            return n == 1 or ((per_ * frames.shape[1] * frames.shape[3] * frames.shape[4]) % 16 == 0
+                              and (target is None or (per_ * frames.shape[1] * model.cfg.num_classes * 12) % 16 == 0))
         if streams is None:
             env = os.environ.get("GDKVM_SEGMENT_STREAMS", "")
             streams = int(env) if env.isdigit() and int(env) >= 1 and B % int(env) == 0 else (2 if (B >= 8 and B % 2 == 0) else 1)
+            if not aligned(streams):
+                streams = 1                                 # (e.g. 10 clips x 3 frames x 2 classes: 360-byte count slabs)
         if streams < 1 or B % streams:
             raise ValueError(f"GraphedSegment: streams={streams} must divide the {B} clips")
+        if not aligned(streams):
+            raise ValueError(f"GraphedSegment: with streams={streams} a group's slice of the mask / Dice-count result does not start on a 16-byte "
+                             f"boundary for {B} clips x {frames.shape[1]} frames ({model.cfg.num_classes} classes); use streams=1")
         self.streams = streams
         kw = {} if state is None else {"state": state, "return_state": True}
         with torch.no_grad():
@@ -956,14 +1156,14 @@ class GraphedSegment:
         # must never read freed memory), and remember the epochs they belong to -- a replay after the weights or packs changed would segment
         # with the weights of capture time, so __call__ raises instead.
         self._held = _packs_held(model)
-        self._epochs = (_WEIGHTS_EPOCH[0], model.__dict__.get("_pack_epoch", 0))
+        self._epochs = (_epoch_of(model), model.__dict__.get("_pack_epoch", 0))
 
     def __call__(self, frames: torch.Tensor, target: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None):
         if (frames.shape != self.frames.shape or frames.dtype != self.frames.dtype or (target is None) != (self.target is None)
                 or (state is None) != (self.state is None)):
             raise RuntimeError(f"GraphedSegment was captured for frames {tuple(self.frames.shape)} {self.frames.dtype}"
                                f"{'' if self.target is None else ' with a target'}{'' if self.state is None else ' with a state'}")
-        if self._epochs != (_WEIGHTS_EPOCH[0], self.model.__dict__.get("_pack_epoch", 0)):
+        if self._epochs != (_epoch_of(self.model), self.model.__dict__.get("_pack_epoch", 0)):
             raise RuntimeError("GraphedSegment: the model's weights or weight packs changed since the capture (optimiser step, load_state_dict, "
                                ".to(), train() / eval()): the graph reads the packs of capture time -- capture a new one")
         if frames.data_ptr() != self.frames.data_ptr():

@@ -46,6 +46,10 @@ SIGNATURES = {
     "gdkvm_scan_segments": (_i, [_i] * 5),
     "gdkvm_scan_segmented_workspace_bytes": (_sz, [_i] * 7),
     "gdkvm_scan_fwd_segmented": (_i, [_vp] * 9 + [_sz] + [_i] * 10 + [_vp]),
+    "gdkvm_scan_normalizer_workspace_bytes": (_sz, [_i] * 7),
+    "gdkvm_scan_fwd_normalizer": (_i, [_vp] * 11 + [_sz] + [_i] * 9 + [ctypes.c_float, _vp]),
+    "gdkvm_lkva_read": (_i, [_vp] * 4 + [_i] * 7 + [_vp]),
+    "gdkvm_mask_embed_add": (_i, [_vp] * 3 + [_i] * 7 + [_vp]),
     "gdkvm_scan_train_workspace_bytes": (_sz, [_i] * 7),
     "gdkvm_scan_train_fwd": (_i, [_vp] * 9 + [_sz] + [_i] * 9 + [_vp]),
     "gdkvm_scan_train_bwd": (_i, [_vp] * 14 + [_sz] + [_i] * 9 + [_vp]),
@@ -81,11 +85,9 @@ SIGNATURES = {
     "gdkvm_conv_igemm_pack_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "gdkvm_conv_down_bias_act": (_i, [_vp] * 4 + [_i] + [_vp] * 3 + [_i] * 10 + [_vp]),
     "gdkvm_conv_cat_bias_act": (_i, [_vp] * 6 + [_i] * 9 + [_vp]),
-    "gdkvm_conv3x3s2_pack_weights": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
-    "gdkvm_conv3x3s2_down_bias_act": (_i, [_vp] * 4 + [_i] + [_vp] + [_i] * 6 + [_vp]),
     "gdkvm_conv_s2_dgrad_pack_bytes": (_sz, [_i] * 3),
     "gdkvm_conv_s2_pack_train": (_i, [_vp] * 7 + [_i, _i, _vp]),
-    "gdkvm_conv_s2_dgrad": (_i, [_vp] * 4 + [_i] * 6 + [_vp]),
+    "gdkvm_conv_s2_dgrad": (_i, [_vp] * 4 + [_i] * 7 + [_vp]),
     "gdkvm_conv_wgrad_strided_workspace_bytes": (_sz, [_i] * 9),
     "gdkvm_conv_wgrad_strided": (_i, [_vp] * 3 + [ctypes.c_longlong] * 4 + [_vp, _sz] + [_i] * 10 + [_vp]),
     "gdkvm_conv3x3_pack_weights_dgrad": (_i, [_vp, _vp, _i, _i, _i, _vp]),
@@ -261,6 +263,73 @@ def scan_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Ten
     if check:
         scan_status(workspace, B, T, Hh, N, Dk, Dv, flags | (FLAG_WIDE_RANGE if rule == RULE_DELTA_PARALLEL else 0))
     return r, s
+
+
+def scan_fwd_normalizer(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, alpha: torch.Tensor, beta: torch.Tensor,
+                        state: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None, rule: int = RULE_DELTA_SEQUENTIAL,
+                        flags: int = 0, eps: float = 1e-6):
+    """gdkvm_scan_fwd_normalizer (SURVEY.md A.1's `normalizer` flag): the scan with z [B,Hh,Dk] carried beside S and the read-out divided
+    by |q . z| + eps.  Returns (R [B,T,N,Hh,Dv], S_T [B,Hh,Dk,Dv] fp32, z_T [B,Hh,Dk] fp32).  Inference only; Dk = 64."""
+    lib = load()
+    if q.dim() != 5 or k.shape != q.shape or v.dim() != 5 or v.shape[:4] != q.shape[:4]:
+        raise GdkvmError(f"bad shapes q{tuple(q.shape)} k{tuple(k.shape)} v{tuple(v.shape)}")
+    B, T, N, Hh, Dk = q.shape
+    Dv = v.shape[-1]
+    if tuple(alpha.shape) != (B, T, Hh) or tuple(beta.shape) != (B, T, N, Hh) or alpha.dtype != torch.float32 or beta.dtype != torch.float32:
+        raise GdkvmError(f"bad gates alpha{tuple(alpha.shape)} beta{tuple(beta.shape)} (float32)")
+    if k.dtype != q.dtype or v.dtype != q.dtype:
+        raise GdkvmError("q, k, v must share one dtype")
+    if state is not None and (tuple(state.shape) != (B, Hh, Dk, Dv) or state.dtype != torch.float32):
+        raise GdkvmError("state must be float32 [B,Hh,Dk,Dv]")
+    if z is not None and (tuple(z.shape) != (B, Hh, Dk) or z.dtype != torch.float32):
+        raise GdkvmError("z must be float32 [B,Hh,Dk]")
+    dev = _dev(q, k, v, alpha, beta, state, z)
+    io = _io_dtype(q)
+    ws = torch.empty(int(lib.gdkvm_scan_normalizer_workspace_bytes(B, T, Hh, N, Dk, Dv, io)), dtype=torch.uint8, device=dev)
+    r = torch.empty((B, T, N, Hh, Dv), dtype=q.dtype, device=dev)
+    s = torch.empty((B, Hh, Dk, Dv), dtype=torch.float32, device=dev)
+    zo = torch.empty((B, Hh, Dk), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gdkvm_scan_fwd_normalizer(_ptr(q), _ptr(k), _ptr(v), _ptr(alpha), _ptr(beta), _ptr(state), _ptr(z), _ptr(r), _ptr(s), _ptr(zo),
+                                           ws.data_ptr(), ws.numel(), B, T, Hh, N, Dk, Dv, io, rule, flags, float(eps), _stream(dev))
+    _check(rc, "gdkvm_scan_fwd_normalizer")
+    return r, s, zo
+
+
+def lkva_read(q: torch.Tensor, state: torch.Tensor, flags: int = 0, norms: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """gdkvm_lkva_read: R [B,N,Hh,Dv] = Qn S for ONE frame per clip (the read half of a per-frame step).  q [B,N,Hh,Dk] f32|bf16,
+    state [B,Hh,Dk,Dv] fp32, norms [B*N,Hh,2] fp32 from ops.proj_gates or None."""
+    lib = load()
+    if q.dim() != 4 or state.dim() != 4 or state.shape[0] != q.shape[0] or state.shape[1] != q.shape[2] or state.shape[2] != q.shape[3]:
+        raise GdkvmError(f"lkva_read: bad shapes q{tuple(q.shape)} state{tuple(state.shape)}")
+    if state.dtype != torch.float32:
+        raise GdkvmError("lkva_read: state must be float32")
+    B, N, Hh, Dk = q.shape
+    Dv = state.shape[-1]
+    dev = _dev(q, state, norms, out)
+    if norms is not None and (norms.dtype != torch.float32 or norms.numel() != B * N * Hh * 2):
+        raise GdkvmError("lkva_read: norms must be float32 [B*N, Hh, 2]")
+    r = _out_like(out, (B, N, Hh, Dv), q.dtype, dev, "lkva_read") if out is not None else torch.empty((B, N, Hh, Dv), dtype=q.dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.gdkvm_lkva_read(_ptr(q), _ptr(norms), _ptr(state), _ptr(r), B, N, Hh, Dk, Dv, _io_dtype(q), flags, _stream(dev))
+    _check(rc, "gdkvm_lkva_read")
+    return r
+
+
+def mask_embed_add_(v: torch.Tensor, mask: torch.Tensor, w_embed: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """gdkvm_mask_embed_add, in place: v [BT, h*w, C] += w_embed[c] * adaptive_avg_pool(mask != 0) per token.  mask uint8 [BT,H,W],
+    w_embed fp32 [C]."""
+    lib = load()
+    if v.dim() != 3 or mask.dim() != 3 or mask.dtype != torch.uint8 or mask.shape[0] != v.shape[0] or v.shape[1] != h * w:
+        raise GdkvmError(f"mask_embed_add_: bad shapes v{tuple(v.shape)} mask{tuple(mask.shape)} {mask.dtype} tokens {h}x{w}")
+    if w_embed.dtype != torch.float32 or w_embed.numel() != v.shape[2]:
+        raise GdkvmError("mask_embed_add_: w_embed must be float32 [C]")
+    dev = _dev(v, mask, w_embed)
+    with torch.cuda.device(dev):
+        rc = lib.gdkvm_mask_embed_add(_ptr(mask), _ptr(w_embed), _ptr(v), v.shape[0], mask.shape[1], mask.shape[2], h, w, v.shape[2],
+                                      _io_dtype(v), _stream(dev))
+    _check(rc, "gdkvm_mask_embed_add")
+    return v
 
 
 def scan_status(workspace: torch.Tensor, B: int, T: int, Hh: int, N: int, Dk: int, Dv: int, flags: int = 0) -> None:
@@ -939,48 +1008,6 @@ def conv_down_bias_act(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor
     return y, yd
 
 
-def conv3x3s2_served(c: int, k: int, w_in: int) -> bool:
-    """Does the stride-2 halo-band kernel (gdkvm_conv3x3s2_down_bias_act) take a 3x3 / stride-2 / pad-1 layer of c -> k channels on rows of w_in pixels?"""
-    return c % 32 == 0 and k % 128 == 0 and (w_in - 1) // 2 + 1 <= 112
-
-
-def conv3x3s2_pack_weights(weight: torch.Tensor, down_weight: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """The fragment-ordered pack gdkvm_conv3x3s2_down_bias_act reads: weight bf16 channels_last [K,C,3,3], down_weight bf16 [K,C,1,1] or None."""
-    lib = load()
-    k, c = weight.shape[:2]
-    if weight.dtype != torch.bfloat16 or tuple(weight.shape[2:]) != (3, 3) or not weight.is_cuda or not weight.is_contiguous(memory_format=torch.channels_last):
-        raise GdkvmError("conv3x3s2_pack_weights: channels_last bf16 [K,C,3,3] device weight")
-    if down_weight is not None and (down_weight.dtype != torch.bfloat16 or tuple(down_weight.shape) != (k, c, 1, 1) or down_weight.device != weight.device):
-        raise GdkvmError("conv3x3s2_pack_weights: the branch weight must be bf16 [K,C,1,1] on the same device")
-    dw = None if down_weight is None else down_weight.reshape(k, c).contiguous()
-    packed = torch.empty(k * c * (9 + (dw is not None)), dtype=torch.bfloat16, device=weight.device)
-    with torch.cuda.device(weight.device):
-        rc = lib.gdkvm_conv3x3s2_pack_weights(weight.data_ptr(), _ptr(dw), packed.data_ptr(), k, c, BF16, _stream(weight.device))
-    _check(rc, "gdkvm_conv3x3s2_pack_weights")
-    return packed
-
-
-def conv3x3s2_down_bias_act(x: torch.Tensor, packed: torch.Tensor, bias: torch.Tensor, k: int, relu: bool = True, with_down: bool = True):
-    """(act(conv2d(x, w, stride 2, padding 1) + bias), conv2d(x, w_down, stride 2) | None) on the stride-2 halo-band kernel
-    (gdkvm_conv3x3s2_down_bias_act); x channels_last bf16 [N,C,H,W], packed = conv3x3s2_pack_weights(w, w_down or None)."""
-    lib = load()
-    if x.dim() != 4 or not x.is_cuda or x.dtype != torch.bfloat16 or not x.is_contiguous(memory_format=torch.channels_last):
-        raise GdkvmError("conv3x3s2_down_bias_act needs a channels_last bf16 [N,C,H,W] device tensor (no CPU path)")
-    n, c, hh, ww = x.shape
-    if packed.dtype != torch.bfloat16 or packed.numel() != k * c * (9 + int(with_down)) or packed.device != x.device:
-        raise GdkvmError("conv3x3s2_down_bias_act: packed must be conv3x3s2_pack_weights(w, w_down) for this layer")
-    if bias.dtype != torch.float32 or bias.numel() != k:
-        raise GdkvmError("bias must be float32 [K]")
-    ho, wo = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
-    y = torch.empty((n, k, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-    yd = torch.empty_like(y) if with_down else None
-    with torch.cuda.device(x.device):
-        rc = lib.gdkvm_conv3x3s2_down_bias_act(x.data_ptr(), packed.data_ptr(), bias.data_ptr(), y.data_ptr(), int(relu), _ptr(yd),
-                                               n, c, hh, ww, k, BF16, _stream(x.device))
-    _check(rc, "gdkvm_conv3x3s2_down_bias_act")
-    return y, yd
-
-
 def _conv3x3_packed(x: torch.Tensor, packed: torch.Tensor, k_out: int, bias: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """conv3x3 / stride 1 / pad 1 of channels_last bf16 x with weights given ONLY as a pack (no epilogue beyond the bias and an optional
     residual [N, k_out, H, W] of x's type added in the kernel's epilogue)."""
@@ -1290,7 +1317,7 @@ class _ConvS2BlockFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(xb)
             with torch.cuda.device(xb.device):
-                rc = lib.gdkvm_conv_s2_dgrad(dyb.data_ptr(), dydb.data_ptr(), dg.data_ptr(), dx.data_ptr(), n, c, hh, ww, k, BF16, _stream(xb.device))
+                rc = lib.gdkvm_conv_s2_dgrad(dyb.data_ptr(), dydb.data_ptr(), dg.data_ptr(), dx.data_ptr(), n, c, hh, ww, k, 1, BF16, _stream(xb.device))
             _check(rc, "gdkvm_conv_s2_dgrad")
             dx = dx.to(ctx.xdtype)
         if ctx.needs_input_grad[1]:

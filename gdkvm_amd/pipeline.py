@@ -1,0 +1,158 @@
+"""The paths a USER runs (train.py / eval.py) on the fast forms the benchmark measures: host batches staged through pinned memory and
+copied to the device on a side stream while the previous batch computes (DevicePrefetcher), the inference forward as one hipGraph
+replay per batch shape (SegmentRunner -> GraphedSegment), the training step as one hipGraph replay with the gradient exchange as a node
+of it (make_train_step -> GraphedTrainStep + FlatGradSync + fused AdamW), each with a LOUD eager fallback.
+
+The reference's recipe these serve: /root/reference/website/src/pages/[lang]/reprod/index.astro:238-264 (two GPUs under a
+torch.distributed launcher, batch_size 8, learning_rate 1e-4, num_iterations 3000).  Host plumbing only -- no arithmetic of the memory
+path lives here; the one computation is the uint8 -> [0, 1] cast of frames a loader delivers as bytes (done on the GPU: a quarter of
+the float32 bytes cross PCIe)."""
+from __future__ import annotations
+
+import sys
+import warnings
+from typing import Iterable, Iterator, Optional, Tuple
+
+import torch
+
+
+class DevicePrefetcher:
+    """Iterate a loader of (frames, target) HOST batches as device tensors, `slots` batches deep: batch i+1 is staged into pinned memory
+    and copied host-to-device on a side stream while batch i computes; the consumer's stream waits only for its own batch's copy event,
+    and a slot's device buffers are not overwritten before the consumer of their previous batch has been passed (an event recorded on the
+    consumer's stream when it asks for the next batch).  uint8 frames are cast to `frames_dtype` and scaled to [0, 1] on the device;
+    float frames are cast; targets keep their dtype unless `target_dtype` is given.  Yields (frames, target) device tensors that stay
+    valid until the NEXT next()."""
+
+    def __init__(self, loader: Iterable, device: torch.device, slots: int = 2, frames_dtype: Optional[torch.dtype] = None,
+                 target_dtype: Optional[torch.dtype] = None):
+        if slots < 2:
+            raise ValueError("DevicePrefetcher needs at least two slots")
+        self.loader, self.device, self.slots = loader, device, slots
+        self.frames_dtype, self.target_dtype = frames_dtype, target_dtype
+        self.stream = torch.cuda.Stream(device=device)
+        self._pinned = [None] * slots           # per slot: (frames, target) pinned host staging, re-used while the shape holds
+        self._dev = [None] * slots
+        self._free = [None] * slots             # event: the consumer is done with this slot's device buffers
+        self._copied = [None] * slots           # event: the slot's last host-to-device copy
+        self.h2d_bytes = 0
+
+    def _stage(self, slot: int, batch) -> Tuple[torch.Tensor, torch.Tensor, torch.cuda.Event]:
+        frames, target = batch
+        pin, dev = self._pinned[slot], self._dev[slot]
+        if pin is None or pin[0].shape != frames.shape or pin[0].dtype != frames.dtype or pin[1].shape != target.shape or pin[1].dtype != target.dtype:
+            pin = (torch.empty(frames.shape, dtype=frames.dtype, pin_memory=True), torch.empty(target.shape, dtype=target.dtype, pin_memory=True))
+            dev = (torch.empty(frames.shape, dtype=frames.dtype, device=self.device), torch.empty(target.shape, dtype=target.dtype, device=self.device))
+            self._pinned[slot], self._dev[slot] = pin, dev
+        if self._copied[slot] is not None:
+            self._copied[slot].synchronize()    # (the slot's previous host-to-device copy has left the pinned buffers)
+        pin[0].copy_(frames)                    # (host memcpy into page-locked memory: what makes the H2D copy asynchronous)
+        pin[1].copy_(target)
+        with torch.cuda.stream(self.stream):
+            if self._free[slot] is not None:
+                self.stream.wait_event(self._free[slot])
+            dev[0].copy_(pin[0], non_blocking=True)
+            dev[1].copy_(pin[1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._copied[slot] = ev
+        self.h2d_bytes += frames.numel() * frames.element_size() + target.numel() * target.element_size()
+        return dev[0], dev[1], ev
+
+    def _finish(self, frames: torch.Tensor, target: torch.Tensor):
+        if frames.dtype == torch.uint8:
+            frames = frames.to(self.frames_dtype or torch.float32).mul_(1.0 / 255.0)
+        elif self.frames_dtype is not None and frames.dtype != self.frames_dtype:
+            frames = frames.to(self.frames_dtype)
+        if self.target_dtype is not None and target.dtype != self.target_dtype:
+            target = target.to(self.target_dtype)
+        return frames, target
+
+    def _hand_out(self, queue):
+        s, f, t, ev = queue.pop(0)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)                       # the consumer's stream waits for ITS batch's copy only
+        yield self._finish(f, t)
+        done = torch.cuda.Event()                # (the consumer came back for the next batch: everything it launched on slot s is in its stream)
+        done.record(torch.cuda.current_stream(self.device))
+        self._free[s] = done
+
+    def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        queue = []                               # staged batches, oldest first: (slot, frames, target, copy event)
+        slot = 0
+        for batch in self.loader:
+            queue.append((slot,) + self._stage(slot, batch))
+            slot = (slot + 1) % self.slots
+            if len(queue) < self.slots:
+                continue                         # slots - 1 copies stay in flight behind the batch being computed
+            yield from self._hand_out(queue)
+        while queue:
+            yield from self._hand_out(queue)
+
+
+class SegmentRunner:
+    """model.segment(frames, target) for a stream of batches: ONE captured GraphedSegment per batch shape (the full batches of a split),
+    an eager call -- said once, on stderr -- for shapes that occur once (the last, short batch) or when a capture fails."""
+
+    def __init__(self, model, graph: bool = True, min_repeats: int = 2):
+        self.model, self.graph, self.min_repeats = model, graph, min_repeats
+        self._graphs, self._seen = {}, {}
+        self.replays = self.eager_calls = 0
+        self._told = False
+
+    def __call__(self, frames: torch.Tensor, target: Optional[torch.Tensor] = None):
+        key = (tuple(frames.shape), frames.dtype, None if target is None else target.dtype)
+        self._seen[key] = self._seen.get(key, 0) + 1
+        g = self._graphs.get(key)
+        if g is None and self.graph and self._seen[key] >= self.min_repeats:
+            try:
+                from .model import GraphedSegment
+                g = GraphedSegment(self.model, frames.clone(), None if target is None else target.clone())
+            except Exception as e:              # noqa: BLE001 -- a failed capture must not end an evaluation: say so, run eagerly
+                print(f"[gdkvm] forward not captured for {key[0]} ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
+                torch.cuda.synchronize()
+                g = False
+            self._graphs[key] = g
+        if g:
+            self.replays += 1
+            out = g(frames, target)
+            return out[0].clone(), (None if out[1] is None else out[1].clone())
+        self.eager_calls += 1
+        with torch.no_grad():
+            return self.model.segment(frames, target=target)
+
+
+def make_train_step(model, opt_factory, frames: torch.Tensor, target: torch.Tensor, autocast_dtype, world: int, device,
+                    graph: bool = True, opt_state: Optional[dict] = None):
+    """The training step train.py runs, in the form bench.py measures: ONE hipGraph replay per step (GraphedTrainStep) over the bare module,
+    the gradient all-reduce a node of the graph (FlatGradSync) when world > 1, fused capturable AdamW -- or, loudly, the eager step
+    (DistributedDataParallel + the default AdamW) when the capture fails or graph=False.  opt_factory(params, fused: bool, capturable: bool)
+    -> optimiser (opt_state: a checkpoint's optimiser state, loaded before the capture).  Returns (step(frames, target) -> loss, optimiser,
+    description dict); the shapes are those of `frames` / `target`.  The capture's warm-up runs info["warmup_steps"] REAL optimiser steps on
+    the batch given here: the caller counts them as iterations."""
+    from .train import FlatGradSync, GraphedTrainStep, train_step, wrap_ddp
+    info = {"launch": "eager", "grad_sync": "none", "optimizer": "AdamW"}
+    if graph:
+        sync = None
+        try:
+            if world > 1:
+                sync = FlatGradSync(model)
+                sync.broadcast_parameters()
+            opt = opt_factory(model.parameters(), True, True)
+            if opt_state is not None:
+                opt.load_state_dict(opt_state)
+            gstep = GraphedTrainStep(model, opt, frames, target, autocast_dtype, warmup=2, grad_sync=sync)
+            info.update(launch="one hipGraph replay per step (GraphedTrainStep)", optimizer="AdamW(fused, capturable)", warmup_steps=gstep.eager_steps,
+                        grad_sync="FlatGradSync: one flat-bucket all-reduce, a node of the graph" if sync is not None else "none (one rank)")
+            return (lambda f, t: gstep(f, t)), opt, info
+        except Exception as e:                  # noqa: BLE001
+            warnings.warn(f"gdkvm_amd: the training step was not captured ({type(e).__name__}: {e}); falling back to the EAGER step "
+                          "(DistributedDataParallel, ~1.6x slower per step on this model)", RuntimeWarning)
+            print(f"[gdkvm] training step not captured ({type(e).__name__}: {e}); running the eager step", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+    ddp = wrap_ddp(model, device)
+    opt = opt_factory(model.parameters(), False, False)
+    if opt_state is not None:
+        opt.load_state_dict(opt_state)
+    info.update(grad_sync="DistributedDataParallel" if ddp is not model else "none (one rank)")
+    return (lambda f, t: train_step(ddp, opt, f, t, autocast_dtype)), opt, info

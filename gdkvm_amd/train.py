@@ -68,13 +68,23 @@ class FlatGradSync:
     no autograd hooks, no host-side bucket bookkeeping, one communication node.  The whole model is ~16 MB of fp32 gradients: one ring
     all-reduce of 2 (P-1)/P x 16 MB over 7 x 153 GB/s links is ~0.1 - 0.2 ms against a 5.7 ms step, so it is not overlapped with the backward.
     Use with the BARE module (not wrapped): ``sync = FlatGradSync(model); sync.broadcast_parameters(); train_step(..., grad_sync=sync)``.
-    The reference's own recipe is a multi-process launch (/root/reference/website/src/pages/[lang]/reprod/index.astro:238-249)."""
+    The reference's own recipe is a multi-process launch (/root/reference/website/src/pages/[lang]/reprod/index.astro:238-249).
 
-    def __init__(self, model: nn.Module, group=None):
+    Two differences from DistributedDataParallel, both deliberate: (i) a trainable parameter that received NO gradient in a step raises
+    (as DDP does on its next iteration without find_unused_parameters) -- zero-filling it would let the optimiser decay weights and
+    moments of a parameter that took no part in the step, which a one-process step never does; ``allow_unused=True`` asks for exactly
+    that zero-fill (the gradient is then a true zero on every rank).  (ii) buffers (BatchNorm running statistics) are broadcast once, by
+    ``broadcast_parameters()``; DDP re-broadcasts rank 0's buffers before every forward.  Every rank's running statistics then follow its
+    own shard (the trained weights are identical on all ranks regardless); call ``broadcast_buffers()`` before saving a checkpoint or
+    evaluating if rank 0's statistics are wanted everywhere."""
+
+    def __init__(self, model: nn.Module, group=None, allow_unused: bool = False):
         import torch.distributed as dist
         if not dist.is_initialized():
             raise RuntimeError("FlatGradSync needs an initialised process group")
         self.group = group
+        self.allow_unused = allow_unused
+        self.names = {id(p): n for n, p in model.named_parameters()}
         self.world = dist.get_world_size(group)
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.buffers = list(model.buffers())
@@ -99,11 +109,22 @@ class FlatGradSync:
         for t in list(self.params) + self.buffers:
             dist.broadcast(t.data, src, group=self.group)
 
+    def broadcast_buffers(self, src: int = 0) -> None:
+        """Rank `src`'s buffers (BatchNorm running statistics, step counters) to every rank: DDP does this before each forward, this class
+        only on request (checkpoints, evaluation)."""
+        import torch.distributed as dist
+        for t in self.buffers:
+            dist.broadcast(t.data, src, group=self.group)
+
     def __call__(self) -> None:
         import torch.distributed as dist
         missing = [v for p, v in zip(self.params, self.views) if p.grad is None]
         if missing:
-            torch._foreach_zero_(missing)                    # (a parameter outside this step's graph contributes zero, as under DDP)
+            if not self.allow_unused:
+                names = [self.names.get(id(p), "?") for p in self.params if p.grad is None]
+                raise RuntimeError(f"FlatGradSync: no gradient for {names[:4]}{' ...' if len(names) > 4 else ''} in this step; keep every trainable "
+                                   "parameter in the graph (as DistributedDataParallel requires), freeze it, or pass allow_unused=True")
+            torch._foreach_zero_(missing)                    # (allow_unused: a parameter outside this step's graph contributes zero on every rank)
         have = [(v, p.grad) for p, v in zip(self.params, self.views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
@@ -134,7 +155,7 @@ def train_step(model: nn.Module, opt: torch.optim.Optimizer, frames: torch.Tenso
         grad_sync()
     opt.step()
     from .model import weights_changed
-    weights_changed()          # (fused optimisers write the parameters without bumping their version counters: the pack caches key on this too)
+    weights_changed(model)     # (fused optimisers write the parameters without bumping their version counters: THIS model's pack caches key on it)
     return loss.detach()
 
 
@@ -210,5 +231,5 @@ class GraphedTrainStep:
             self.target.copy_(target, non_blocking=True)
         self.graph.replay()
         from .model import weights_changed
-        weights_changed()
+        weights_changed(self.model)
         return self.loss.clone()                # (the graph's own output buffer is overwritten by the next replay)

@@ -160,6 +160,34 @@ int gdkvm_scan_fwd_segmented(const void* q, const void* k, const void* v, const 
                              int B, int T, int Hh, int N, int Dk, int Dv, int segments,
                              int io_dtype, int rule, int flags, void* stream);
 
+/* SURVEY.md A.1, the `normalizer` flag of the LKVA read: besides S the memory carries z [B, Hh, Dk] (fp32) -- "the same recurrence on
+ * v == 1", i.e. the state column of a value channel that is 1 for every token -- and the read-out of token n of frame t is
+ *     R_t[n, :] = (Qn_t[n] S_{t-1}) / (|Qn_t[n] . z_{t-1}| + eps).
+ * Everything else as gdkvm_scan_fwd (Dk == 64, inference only: no s_hist): z_in / s_in may be NULL (zeros), z_out / s_out may be NULL;
+ * a clip processed as consecutive calls with (S, z) carried is bit-identical to one call.  Implemented as the library's own scan on
+ * Dv + 16 value channels (channel Dv holds the ones) with the division on the way out: csrc/gdr_normalizer.hip.  0 < eps < 1
+ * (SPEC-v0 default 1e-6).  Names: "Linear Key-Value Association" at /root/reference/README.md:20. */
+size_t gdkvm_scan_normalizer_workspace_bytes(int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype);
+int gdkvm_scan_fwd_normalizer(const void* q, const void* k, const void* v, const float* alpha, const float* beta,
+                              const float* s_in, const float* z_in, void* r_out, float* s_out, float* z_out,
+                              void* workspace, size_t workspace_bytes,
+                              int B, int T, int Hh, int N, int Dk, int Dv, int io_dtype, int rule, int flags, float eps, void* stream);
+
+/* The per-frame `step` mode with mask feedback: when the value written for frame t depends on the mask
+ * predicted for frame t, the frame loop is read -> KPFF -> decoder -> mask -> write, one frame of every clip at a time.
+ *   gdkvm_lkva_read       row a1 on its own: r_out [B, N, Hh, Dv] = Qn S for ONE frame per clip, q [B, N, Hh, Dk] (io_dtype), the state
+ *                         s [B, Hh, Dk, Dv] fp32 given as a tensor.  flags: GDKVM_FLAG_NORMALIZE_QK as in gdkvm_scan_fwd; norms
+ *                         (may be NULL) = gdkvm_proj_gates' [B*N, Hh, 2] inverse norms (entry 1 is the query's).  Plain fp32 fmaf
+ *                         chains in key-channel order: deterministic.  Dk == 64.
+ *   gdkvm_mask_embed_add  v [BT, h*w, C] (io_dtype) += w_embed[c] * m, m = the mean over the token's adaptive-average-pool cell
+ *                         (PyTorch's adaptive_avg_pool2d cells) of the foreground indicator of mask [BT, H, W] (uint8: class != 0;
+ *                         255 = unlabelled counts as background): the first-frame-mask embedding of the module applied to a predicted
+ *                         mask.  The write itself is gdkvm_scan_fwd with T == 1. */
+int gdkvm_lkva_read(const void* q, const float* norms, const float* s, void* r_out,
+                    int B, int N, int Hh, int Dk, int Dv, int io_dtype, int flags, void* stream);
+int gdkvm_mask_embed_add(const uint8_t* mask, const float* w_embed, void* v, int BT, int H, int W, int h, int w, int C,
+                         int io_dtype, void* stream);
+
 /* Row a7: backward of gdkvm_scan_fwd.  Inputs: the forward's inputs, its s_hist, its workspace exactly as the
  * forward left it, the gradients d_r [B,T,N,Hh,Dv] (io_dtype) and d_s_out [B,Hh,Dk,Dv] (fp32, may be NULL = 0).
  * Outputs: d_q, d_k [B,T,N,Hh,Dk], d_v [B,T,N,Hh,Dv] (io_dtype), d_alpha [B,T,Hh], d_beta [B,T,N,Hh] (fp32; with
@@ -391,16 +419,6 @@ int gdkvm_conv_bias_act(const void* x, const void* w, const float* bias, const v
 int gdkvm_conv_down_bias_act(const void* x, const void* w, const float* bias, void* y, int relu,
                              const void* w_down, const float* bias_down, void* y_down,
                              int N, int C, int H, int W, int K, int R, int S, int stride, int pad, int io_dtype, void* stream);
-/* The same pair on a halo-band kernel of its own (round 5; csrc/conv3x3s2_tile.hip): the 3x3 / stride-2 / pad-1 convolution with bias (+ ReLU)
- * and, when y_down is given, the block's 1x1 / stride-2 branch (no bias) from ONE launch -- the input band is staged in LDS once per 32-channel
- * chunk, split by row / column parity so that every tap is a base + immediate read, and the branch is a tenth k-step per chunk on the centre
- * tap's pixels.  packed: gdkvm_conv3x3s2_pack_weights of the bf16 weights w [K, 3, 3, C] (the memory order of a channels_last [K, C, 3, 3]
- * tensor) and, for the branch, w_down [K, C] -- K (9 + 1) C elements, or K 9 C without a branch; a pack made WITH a branch needs y_down, one
- * made without needs y_down = NULL.  C a multiple of 32, K of 128, output rows of at most 112 pixels; else GDKVM_ERR_SHAPE (the general
- * kernel, gdkvm_conv_down_bias_act, serves those).  Same sums as the general kernel in another order: equal up to fp32 re-association. */
-int gdkvm_conv3x3s2_pack_weights(const void* w, const void* w_down, void* packed, int K, int C, int io_dtype, void* stream);
-int gdkvm_conv3x3s2_down_bias_act(const void* x, const void* packed, const float* bias, void* y, int relu, void* y_down,
-                                  int N, int C, int H, int W, int K, int io_dtype, void* stream);
 /* Training form of the same pair (a residual block's 3x3 / stride-2 / pad-1 convolution w [K, C, 3, 3] and its 1x1 / stride-2 branch
  * w_down [K, C, 1, 1], both without bias), forward and backward on hand-written kernels, deterministic:
  *   gdkvm_conv_s2_pack_train   ONE launch from the fp32 master weights (element strides (k, c, r, s) resp. (k, c): any memory format) to
@@ -409,7 +427,10 @@ int gdkvm_conv3x3s2_down_bias_act(const void* x, const void* packed, const float
  *                              w_down may be NULL (no branch).  K a multiple of 128, C of 64.
  *   gdkvm_conv_s2_dgrad        dx [N, H, W, C] = the gradient of x from dy [N, Ho, Wo, K] (and dy_down, same shape, or NULL), Ho = (H-1)/2+1:
  *                              every input pixel sums exactly the taps that reach it (four parity classes, no products with zeros), the
- *                              branch's gradient inside the same accumulation, one rounding to bf16.
+ *                              branch's gradient inside the same accumulation, one rounding to bf16.  with_down: was packed_dgrad made WITH the
+ *                              1x1 branch (gdkvm_conv_s2_pack_train with w_down != NULL)?  The class offsets inside the pack follow
+ *                              this, not dy_down: with_down = 1 and dy_down = NULL is a zero branch gradient; dy_down with
+ *                              with_down = 0 is GDKVM_ERR_ARG.
  *   gdkvm_conv_wgrad_strided   dw[k sk + c sc + r sr + s ss] (fp32, element strides: the parameter's own memory format) =
  *                              sum_{n, yo, xo} dy[n, yo, xo, k] x[n, yo stride - pad + r, xo stride - pad + s, c]  for ANY R x S / stride /
  *                              pad; C a multiple of 64, K of 8; the rows of the batch are summed in fixed-order splits (no atomics).
@@ -419,7 +440,7 @@ size_t gdkvm_conv_s2_dgrad_pack_bytes(int C, int K, int with_down);
 int gdkvm_conv_s2_pack_train(const float* w, const long long* w_strides, const float* w_down, const long long* w_down_strides,
                              void* packed_fwd, void* packed_fwd_down, void* packed_dgrad, int K, int C, void* stream);
 int gdkvm_conv_s2_dgrad(const void* dy, const void* dy_down, const void* packed_dgrad, void* dx,
-                        int N, int C, int H, int W, int K, int io_dtype, void* stream);
+                        int N, int C, int H, int W, int K, int with_down, int io_dtype, void* stream);
 size_t gdkvm_conv_wgrad_strided_workspace_bytes(int N, int C, int H, int W, int K, int R, int S, int stride, int pad);
 int gdkvm_conv_wgrad_strided(const void* x, const void* dy, float* dw, long long sk, long long sc, long long sr, long long ss,
                              void* workspace, size_t workspace_bytes,

@@ -36,6 +36,9 @@ def lib():
             fn = getattr(_lib, "gdkvm_oracle_kpff" + suf)
             fn.restype = ctypes.c_int
             fn.argtypes = [_f] * 7 + [_f] + [ctypes.c_int] * 6
+            fn = getattr(_lib, "gdkvm_oracle_scan_normalizer" + suf)
+            fn.restype = ctypes.c_int
+            fn.argtypes = [_f] * 7 + [_f] * 3 + [ctypes.c_int] * 8 + [ctypes.c_double]
         _lib.gdkvm_oracle_argmax_dice.restype = ctypes.c_int
         _lib.gdkvm_oracle_argmax_dice.argtypes = [_f, _u8, _u8, _i32] + [ctypes.c_int] * 4
         _lib.gdkvm_oracle_upsample_argmax_dice.restype = ctypes.c_int
@@ -64,6 +67,22 @@ def scan(q, k, v, alpha, beta, s0=None, rule=2, flags=0, math="f64"):
     if rc != 0:
         raise RuntimeError(f"gdkvm_oracle_scan failed: {rc}")
     return r, s
+
+
+def scan_normalizer(q, k, v, alpha, beta, s0=None, z0=None, rule=2, flags=0, eps=1e-6, math="f64"):
+    """The scan with the `normalizer` flag: z [B,Hh,Dk] carried beside S, read-out divided by |q . z| + eps.
+    -> (R fp32, S_T fp32, z_T fp32)."""
+    q, k, v, alpha, beta, s0, z0 = map(_c32, (q, k, v, alpha, beta, s0, z0))
+    B, T, N, Hh, Dk = q.shape
+    Dv = v.shape[-1]
+    r = np.empty((B, T, N, Hh, Dv), dtype=np.float32)
+    s = np.empty((B, Hh, Dk, Dv), dtype=np.float32)
+    z = np.empty((B, Hh, Dk), dtype=np.float32)
+    rc = getattr(lib(), "gdkvm_oracle_scan_normalizer_" + math)(_fp(q), _fp(k), _fp(v), _fp(alpha), _fp(beta), _fp(s0), _fp(z0),
+                                                                _fp(r), _fp(s), _fp(z), B, T, N, Hh, Dk, Dv, rule, flags, float(eps))
+    if rc != 0:
+        raise RuntimeError(f"gdkvm_oracle_scan_normalizer failed: {rc}")
+    return r, s, z
 
 
 def kpff(L, G, P, Wa, ba, Wl, Wg, h, w, math="f64"):

@@ -130,6 +130,44 @@ def scan(q, k, v, alpha, beta, s0=None, rule=RULE_DELTA_SEQUENTIAL, flags=0, for
     return R, S
 
 
+NORMALIZER_EPS = 1e-6          # SPEC-v0 default of the `normalizer` flag (SURVEY A.1 names the flag, not the value)
+
+
+def scan_normalizer(q, k, v, alpha, beta, s0=None, z0=None, rule=RULE_DELTA_SEQUENTIAL, flags=0, eps=NORMALIZER_EPS, form="sequential",
+                    dtype=np.float64):
+    """SURVEY A.1 with the `normalizer` flag: z [B,Hh,Dk] is carried with "the same recurrence on v == 1" and the read-out is
+    R_t / (|Q_t z_{t-1}| + eps).  Restated literally: one more value channel that is 1 for every token rides through ``scan``; its
+    state column is z, its read-out is Q_t z_{t-1}.  (The scalar C oracle carries z explicitly: the two check each other.)
+    Returns (R [B,T,N,Hh,Dv], S_T, z_T)."""
+    v = np.asarray(v, dtype=dtype)
+    B, T, N, Hh, Dv = v.shape
+    Dk = np.asarray(q).shape[-1]
+    v1 = np.concatenate([v, np.ones((B, T, N, Hh, 1), dtype=dtype)], axis=-1)
+    s_aug = None
+    if s0 is not None or z0 is not None:
+        s_aug = np.zeros((B, Hh, Dk, Dv + 1), dtype=dtype)
+        if s0 is not None:
+            s_aug[..., :Dv] = s0
+        if z0 is not None:
+            s_aug[..., Dv] = z0
+    R1, S1 = scan(q, k, v1, alpha, beta, s_aug, rule, flags, form, dtype)
+    return R1[..., :Dv] / (np.abs(R1[..., Dv:]) + eps), S1[..., :Dv].copy(), S1[..., Dv].copy()
+
+
+def mask_cell_mean(mask_fg, h, w):
+    """adaptive_avg_pool2d of a foreground indicator [F, H, W] (bool / 0-1) to h x w cells: rows [floor(i H / h), ceil((i + 1) H / h)),
+    columns likewise -> [F, h*w] float64 (the pooled first-frame / fed-back mask of the module's mask embedding)."""
+    m = np.asarray(mask_fg, dtype=np.float64)
+    F_, H, W = m.shape
+    out = np.empty((F_, h, w), dtype=np.float64)
+    for i in range(h):
+        y0, y1 = (i * H) // h, -((-(i + 1) * H) // h)
+        for j in range(w):
+            x0, x1 = (j * W) // w, -((-(j + 1) * W) // w)
+            out[:, i, j] = m[:, y0:y1, x0:x1].mean(axis=(1, 2))
+    return out.reshape(F_, h * w)
+
+
 # ----------------------------------------------------------------------------------------------- KPFF
 KPFF_SCALES = (1, 2, 4)
 

@@ -10,9 +10,11 @@ static REAL FN(sigm)(REAL x) { return (REAL)1 / ((REAL)1 + (REAL)exp(-(double)x)
 
 /* Row a3 = a1 + a2 (+ a5 prologue), definitional token-sequential form.
  * q,k [B,T,N,Hh,Dk]  v,r [B,T,N,Hh,Dv]  alpha [B,T,Hh]  beta [B,T,N,Hh]  s [B,Hh,Dk,Dv]. */
-int FN(gdkvm_oracle_scan)(const float* q, const float* k, const float* v, const float* alpha,
-                          const float* beta, const float* s_in, float* r_out, float* s_out,
-                          int B, int T, int N, int Hh, int Dk, int Dv, int rule, int flags)
+/* normalizer (SURVEY.md A.1 flag): z [B,Hh,Dk] is the state column of a value channel that is 1 for every token -- it follows the
+ * SAME write rule as every column of S -- and the read-out of token n becomes R_t[n,:] / (|q_n . z_{t-1}| + eps).  z_in NULL = zeros. */
+static int FN(scan_core)(const float* q, const float* k, const float* v, const float* alpha,
+                         const float* beta, const float* s_in, const float* z_in, float* r_out, float* s_out, float* z_out,
+                         int B, int T, int N, int Hh, int Dk, int Dv, int rule, int flags, int normalizer, double eps)
 {
     if (B < 0 || T < 0 || N < 0 || Hh <= 0 || Dk <= 0 || Dv <= 0 || rule < 0 || rule > 2) return -1;
     int status = 0;
@@ -23,9 +25,12 @@ int FN(gdkvm_oracle_scan)(const float* q, const float* k, const float* v, const 
             REAL* kn = (REAL*)malloc(sizeof(REAL) * (size_t)(N > 0 ? N : 1) * Dk);
             REAL* qn = (REAL*)malloc(sizeof(REAL) * (size_t)Dk);
             REAL* e = (REAL*)malloc(sizeof(REAL) * (size_t)(N > 0 ? N : 1) * Dv);
-            if (!S || !kn || !qn || !e) { status = -5; free(S); free(kn); free(qn); free(e); continue; }
+            REAL* z = (REAL*)malloc(sizeof(REAL) * (size_t)Dk);
+            REAL* ez = (REAL*)malloc(sizeof(REAL) * (size_t)(N > 0 ? N : 1));
+            if (!S || !kn || !qn || !e || !z || !ez) { status = -5; free(S); free(kn); free(qn); free(e); free(z); free(ez); continue; }
             for (int i = 0; i < Dk * Dv; ++i)
                 S[i] = s_in ? (REAL)s_in[((size_t)b * Hh + h) * Dk * Dv + i] : (REAL)0;
+            for (int d = 0; d < Dk; ++d) z[d] = (normalizer && z_in) ? (REAL)z_in[((size_t)b * Hh + h) * Dk + d] : (REAL)0;
             for (int t = 0; t < T; ++t) {
                 const size_t bt = (size_t)b * T + t;
                 REAL a = (REAL)alpha[bt * Hh + h];
@@ -41,10 +46,16 @@ int FN(gdkvm_oracle_scan)(const float* q, const float* k, const float* v, const 
                     }
                     for (int d = 0; d < Dk; ++d) qn[d] = (REAL)qp[d] * inv;
                     float* rp = r_out + ((bt * N + n) * Hh + h) * Dv;
+                    REAL den = 1;
+                    if (normalizer) {
+                        REAL qz = 0;
+                        for (int d = 0; d < Dk; ++d) qz += qn[d] * z[d];
+                        den = (REAL)fabs((double)qz) + (REAL)eps;
+                    }
                     for (int c = 0; c < Dv; ++c) {
                         REAL acc = 0;
                         for (int d = 0; d < Dk; ++d) acc += qn[d] * S[(size_t)d * Dv + c];
-                        rp[c] = (float)acc;
+                        rp[c] = (float)(normalizer ? acc / den : acc);
                     }
                 }
                 /* a5: key normalisation */
@@ -60,6 +71,7 @@ int FN(gdkvm_oracle_scan)(const float* q, const float* k, const float* v, const 
                 }
                 /* a2: GDR write */
                 for (int i = 0; i < Dk * Dv; ++i) S[i] *= a;
+                for (int d = 0; d < Dk; ++d) z[d] *= a;
                 if (rule == 1) /* parallel: every token's error against the decayed state */
                     for (int n = 0; n < N; ++n) {
                         const float* vp = v + ((bt * N + n) * Hh + h) * Dv;
@@ -68,31 +80,57 @@ int FN(gdkvm_oracle_scan)(const float* q, const float* k, const float* v, const 
                             for (int d = 0; d < Dk; ++d) acc += kn[(size_t)n * Dk + d] * S[(size_t)d * Dv + c];
                             e[(size_t)n * Dv + c] = (REAL)vp[c] - acc;
                         }
+                        REAL accz = 0;
+                        for (int d = 0; d < Dk; ++d) accz += kn[(size_t)n * Dk + d] * z[d];
+                        ez[n] = (REAL)1 - accz;
                     }
                 for (int n = 0; n < N; ++n) {
                     const float* vp = v + ((bt * N + n) * Hh + h) * Dv;
                     REAL bt_n = (REAL)beta[(bt * N + n) * Hh + h];
                     if (flags & 2) bt_n = FN(sigm)(bt_n);
                     const REAL* kr = kn + (size_t)n * Dk;
-                    if (rule == 2)
+                    if (rule == 2) {
                         for (int c = 0; c < Dv; ++c) {
                             REAL acc = 0;
                             for (int d = 0; d < Dk; ++d) acc += kr[d] * S[(size_t)d * Dv + c];
                             e[(size_t)n * Dv + c] = (REAL)vp[c] - acc;
                         }
-                    else if (rule == 0)
+                        REAL accz = 0;
+                        for (int d = 0; d < Dk; ++d) accz += kr[d] * z[d];
+                        ez[n] = (REAL)1 - accz;
+                    } else if (rule == 0) {
                         for (int c = 0; c < Dv; ++c) e[(size_t)n * Dv + c] = (REAL)vp[c];
+                        ez[n] = (REAL)1;
+                    }
                     for (int d = 0; d < Dk; ++d) {
                         const REAL bk = bt_n * kr[d];
                         for (int c = 0; c < Dv; ++c) S[(size_t)d * Dv + c] += bk * e[(size_t)n * Dv + c];
+                        z[d] += bk * ez[n];
                     }
                 }
             }
             if (s_out)
                 for (int i = 0; i < Dk * Dv; ++i) s_out[((size_t)b * Hh + h) * Dk * Dv + i] = (float)S[i];
-            free(S); free(kn); free(qn); free(e);
+            if (normalizer && z_out)
+                for (int d = 0; d < Dk; ++d) z_out[((size_t)b * Hh + h) * Dk + d] = (float)z[d];
+            free(S); free(kn); free(qn); free(e); free(z); free(ez);
         }
     return status;
+}
+
+int FN(gdkvm_oracle_scan)(const float* q, const float* k, const float* v, const float* alpha,
+                          const float* beta, const float* s_in, float* r_out, float* s_out,
+                          int B, int T, int N, int Hh, int Dk, int Dv, int rule, int flags)
+{
+    return FN(scan_core)(q, k, v, alpha, beta, s_in, NULL, r_out, s_out, NULL, B, T, N, Hh, Dk, Dv, rule, flags, 0, 0.0);
+}
+
+/* Row a1 with the normalizer flag of SURVEY.md A.1: as gdkvm_oracle_scan, with z [B,Hh,Dk] carried in / out (either may be NULL). */
+int FN(gdkvm_oracle_scan_normalizer)(const float* q, const float* k, const float* v, const float* alpha,
+                                     const float* beta, const float* s_in, const float* z_in, float* r_out, float* s_out, float* z_out,
+                                     int B, int T, int N, int Hh, int Dk, int Dv, int rule, int flags, double eps)
+{
+    return FN(scan_core)(q, k, v, alpha, beta, s_in, z_in, r_out, s_out, z_out, B, T, N, Hh, Dk, Dv, rule, flags, 1, eps);
 }
 
 /* Row a4, KPFF.  L [BT,N,Ck] G [BT,N,Cv] P [BT,N,Cp], N = h*w; Wa [2Cp, Cp+Ck+Cv],

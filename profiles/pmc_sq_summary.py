@@ -24,7 +24,7 @@ def stamp() -> str:
     return f"# scan_source_hash: {source_hash()} collected: {time.strftime('%Y-%m-%dT%H:%M:%SZ', time.gmtime())}\n"
 
 # kernels kept in the summary: the product's own (hot path, epilogues, convolutions) -- MIOpen's find-mode trial kernels are dropped
-KEEP = r"gdr_|kpff|proj_|argmax|conv3x3_c64|grouped_conv|upsample_cat|bias_|stem_|gate_logits|maxpool|bn_|seg_loss"
+KEEP = r"gdr_|kpff|proj_|argmax|conv3x3_|conv_igemm|grouped_conv|upsample|bias_|stem_|gate_logits|maxpool|bn_|seg_loss|head_|block_"
 
 
 def main():

@@ -517,41 +517,3 @@ def test_head_logits_planes(hip, dtype, case):
     assert got.shape == want.shape and got.is_contiguous() and got.dtype == dtype
     tol = 2.0 ** -7 if dtype == torch.bfloat16 else 1e-5
     assert (got.double() - want).abs().max() <= tol * max(1.0, want.abs().max().item())
-
-
-@pytest.mark.parametrize("case", [(512, 64, 128, 28, 28), (6, 128, 256, 14, 14), (3, 64, 128, 15, 13), (5, 32, 128, 8, 8), (2, 64, 256, 30, 58),
-                                  (1, 96, 128, 7, 7), (9, 64, 128, 2, 2)])
-@pytest.mark.parametrize("with_down", [True, False])
-def test_strided_convolution_on_the_parity_split_band_kernel(hip, case, with_down):
-    """gdkvm_conv3x3s2_down_bias_act (csrc/conv3x3s2_tile.hip): a 3x3 / stride-2 / pad-1 convolution + bias + ReLU and the block's 1x1 / stride-2
-    branch from one launch, on a halo band stored split by row / column parity -- against fp64 convolutions on the bf16-rounded operands, rounded
-    once to bf16, and against the general implicit-GEMM kernel (equal up to fp32 re-association); even, odd and tiny maps, several frames
-    per tile, a last tile with fewer frames, with and without the branch; the same bits on a second call."""
-    import torch.nn.functional as F
-    n, c, k, hh, ww = case
-    torch.manual_seed(sum(case) + with_down)
-    cl = torch.channels_last
-    x = torch.randn(n, c, hh, ww, device="cuda").bfloat16().contiguous(memory_format=cl)
-    w = (torch.randn(k, c, 3, 3, device="cuda") / (9 * c) ** 0.5).bfloat16().contiguous(memory_format=cl)
-    wd = (torch.randn(k, c, 1, 1, device="cuda") / c ** 0.5).bfloat16().contiguous(memory_format=cl)
-    b = torch.randn(k, device="cuda")
-    assert hip.conv3x3s2_served(c, k, ww)
-    packed = hip.conv3x3s2_pack_weights(w, wd if with_down else None)
-    y, yd = hip.conv3x3s2_down_bias_act(x, packed, b, k, relu=True, with_down=with_down)
-    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), 2, 1))
-    assert y.shape == ref.shape and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=cl)
-    assert (y.double() - ref).abs().max() <= 2.0 ** -8 * max(1.0, ref.abs().max().item())
-    if with_down:
-        refd = F.conv2d(x.double(), wd.double(), None, 2, 0)
-        assert yd.shape == refd.shape and (yd.double() - refd).abs().max() <= 2.0 ** -8 * max(1.0, refd.abs().max().item())
-        # the general kernel on the same operands: the same sums in another order
-        yg, ygd = hip.conv_down_bias_act(x, w, b, hip.conv_igemm_pack_weights(w), wd, hip.conv_igemm_pack_weights(wd), None, 2, True)
-        assert (y.float() - yg.float()).abs().max() <= 2.0 ** -7 * max(1.0, ref.abs().max().item())
-        assert (yd.float() - ygd.float()).abs().max() <= 2.0 ** -7 * max(1.0, refd.abs().max().item())
-    else:
-        assert yd is None
-    y2, yd2 = hip.conv3x3s2_down_bias_act(x, packed, b, k, relu=True, with_down=with_down)
-    assert torch.equal(y, y2) and (not with_down or torch.equal(yd, yd2))
-    y3, _ = hip.conv3x3s2_down_bias_act(x, packed, b, k, relu=False, with_down=with_down)          # no ReLU: negative values survive
-    ref3 = F.conv2d(x.double(), w.double(), b.double(), 2, 1)
-    assert (y3.double() - ref3).abs().max() <= 2.0 ** -8 * max(1.0, ref3.abs().max().item()) and (y3 < 0).any()

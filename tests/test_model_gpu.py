@@ -338,6 +338,10 @@ def test_train_and_eval_entry_points(hip, tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     losses = [float(l.split("loss")[1].split()[0]) for l in out.stdout.splitlines() if l.startswith("step")]
     assert len(losses) == 6 and losses[-1] < losses[0], losses
+    # the entry point runs the step in the form the benchmark measures: one hipGraph replay (GraphedTrainStep, fused AdamW), not the eager loop
+    how = [l for l in out.stdout.splitlines() if l.startswith("train step:")]
+    assert how and "GraphedTrainStep" in how[0] and "fused" in how[0], out.stdout[-1500:]
+    assert "not captured" not in out.stderr
     ck = os.path.join(tmp_path, "gdkvm_step30.pth")
     assert os.path.exists(ck)
     ev = subprocess.run([sys.executable, os.path.join(root, "eval.py"), "--weights", ck, "eval_stage.num_vis=1"] + common,
@@ -345,6 +349,14 @@ def test_train_and_eval_entry_points(hip, tmp_path):
     assert ev.returncode == 0, ev.stderr[-2000:]
     res = json.loads(ev.stdout.strip().splitlines()[-1])
     assert len(res["dice_per_class"]) == 2 and 0.0 <= res["mean_foreground_dice"] <= 1.0
+    assert res["forward"]["graph_replays"] >= 6 and res["forward"]["eager_calls"] <= 2, res     # GraphedSegment per batch shape (first sight: eager)
+    assert "not captured" not in ev.stderr
+    # the eager forms stay reachable and agree: same Dice from the un-captured forward
+    ev2 = subprocess.run([sys.executable, os.path.join(root, "eval.py"), "--weights", ck] + common, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, GDKVM_FWD_GRAPH="0"))
+    assert ev2.returncode == 0, ev2.stderr[-2000:]
+    res2 = json.loads(ev2.stdout.strip().splitlines()[-1])
+    assert res2["dice_per_class"] == res["dice_per_class"] and res2["forward"]["graph_replays"] == 0
     assert os.listdir(os.path.join(tmp_path, "vis"))
 
 

@@ -238,3 +238,80 @@ def test_upsample_argmax_oracle_matches_torch_interpolate():
     assert (up.argmax(1).numpy() != m).mean() <= 1e-4          # same formula; only FMA-contraction-level near-ties may differ
     same, _ = c_oracle.upsample_argmax_dice(logits, 28, 28)     # identity scale == plain argmax
     assert np.array_equal(same, O.argmax_mask(logits))
+
+
+# ---------------------------------------------------------------------------------------- the `normalizer` flag of SURVEY A.1 (round 6)
+def test_k12_normalizer_known_answers():
+    """K12: z carries "the same recurrence on v == 1", the read-out is R / (|q . z| + eps).  Orthonormal keys, alpha = beta = 1:
+    z = the sum of the written keys; reading with one of them leaves the value unchanged (q . z = 1), reading with the normalised sum
+    of two of them returns the MEAN of their values (the un-normalised read-out is (v1 + v2) / sqrt 2, q . z = sqrt 2): the normaliser
+    turns the read into a convex combination.  Both restatements (numpy: one more value channel; C: z carried explicitly)."""
+    Dk, Dv = 8, 4
+    k0 = np.stack([_unit(Dk, 1), _unit(Dk, 4)])                       # frame 0 writes e1 -> v1, e4 -> v2
+    v0 = np.stack([np.arange(1.0, Dv + 1), 10 * np.arange(1.0, Dv + 1)])
+    q1 = np.stack([_unit(Dk, 1), (_unit(Dk, 1) + _unit(Dk, 4)) / np.sqrt(2)])
+    k = np.stack([k0, np.stack([_unit(Dk, 6), _unit(Dk, 7)])])
+    q = np.stack([np.zeros((2, Dk)), q1])
+    v = np.stack([v0, np.zeros((2, Dv))])
+    args = (q[None, :, :, None], k[None, :, :, None], v[None, :, :, None], np.ones((1, 2, 1)), np.ones((1, 2, 2, 1)))
+    for rule in (O.RULE_GATED_LINEAR, O.RULE_DELTA_SEQUENTIAL):
+        R, S, z = O.scan_normalizer(*args, rule=rule, eps=1e-6)
+        np.testing.assert_allclose(R[0, 1, 0, 0], v0[0] / (1 + 1e-6), rtol=1e-12)
+        np.testing.assert_allclose(R[0, 1, 1, 0], 0.5 * (v0[0] + v0[1]), rtol=1e-6)
+        assert np.array_equal(R[0, 0], np.zeros((2, 1, Dv)))              # empty memory: 0 / (0 + eps)
+        assert np.array_equal(z[0, 0], _unit(Dk, 1) + _unit(Dk, 4) + _unit(Dk, 6) + _unit(Dk, 7))
+        Rc, Sc, zc = c_oracle.scan_normalizer(*args, None, None, rule, 0, 1e-6, math="f64")
+        np.testing.assert_allclose(Rc, R, atol=1e-6)
+        np.testing.assert_allclose(zc, z, atol=0)
+        np.testing.assert_allclose(Sc, S, atol=1e-6)
+
+
+@pytest.mark.parametrize("rule", RULES)
+def test_normalizer_restatements_agree_and_carry(rule):
+    """numpy (augmented value channel) == C (explicit z) on random positive keys / queries (|q . z| away from 0), fp64 and fp32 arithmetic;
+    chunked calls with (S, z) carried equal one call; the plain scan is untouched by the refactoring (S equals the normalizer-free S)."""
+    rng = np.random.default_rng(7 + rule)
+    B, T, N, Hh, Dk, Dv = 2, 5, 6, 2, 8, 5
+    q = np.abs(rng.standard_normal((B, T, N, Hh, Dk))).astype(np.float32)
+    k = np.abs(rng.standard_normal((B, T, N, Hh, Dk))).astype(np.float32)
+    v = rng.standard_normal((B, T, N, Hh, Dv)).astype(np.float32)
+    a = rng.normal(2, 1, (B, T, Hh)).astype(np.float32)
+    b = rng.standard_normal((B, T, N, Hh)).astype(np.float32)
+    R, S, z = O.scan_normalizer(q, k, v, a, b, None, None, rule, 3)
+    Rc, Sc, zc = c_oracle.scan_normalizer(q, k, v, a, b, None, None, rule, 3, math="f64")
+    assert np.abs(R - Rc).max() <= 1e-5 * max(1.0, np.abs(R).max()) and np.abs(S - Sc).max() <= 1e-6 and np.abs(z - zc).max() <= 1e-6
+    Rf, Sf, zf = c_oracle.scan_normalizer(q, k, v, a, b, None, None, rule, 3, math="f32")
+    assert np.abs(Rf - Rc).max() <= 1e-3 * max(1.0, np.abs(Rc).max()) and np.abs(Sf - Sc).max() <= 1e-4
+    _, S_plain = c_oracle.scan(q, k, v, a, b, None, rule, 3, math="f64")
+    assert np.array_equal(S_plain, Sc)
+    R1, S1, z1 = c_oracle.scan_normalizer(q[:, :2], k[:, :2], v[:, :2], a[:, :2], b[:, :2], None, None, rule, 3)
+    R2, S2, z2 = c_oracle.scan_normalizer(q[:, 2:], k[:, 2:], v[:, 2:], a[:, 2:], b[:, 2:], S1, z1, rule, 3)
+    # (the carried S and z are rounded to fp32 on the way: where |q . z| is small the quotient amplifies that rounding)
+    assert np.abs(np.concatenate([R1, R2], 1) - Rc).max() <= 1e-4 * max(1.0, np.abs(Rc).max()) and np.abs(S2 - Sc).max() <= 1e-6 and np.abs(z2 - zc).max() <= 1e-6
+
+
+def test_mask_cell_mean_is_adaptive_avg_pool():
+    """oracle.mask_cell_mean (the pooled foreground indicator the module's mask embedding multiplies) == torch's adaptive_avg_pool2d, on
+    sizes that divide and sizes that do not."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(3)
+    for (H, W, h, w) in [(112, 112, 7, 7), (256, 256, 16, 16), (30, 58, 4, 7), (15, 13, 2, 3)]:
+        m = rng.random((3, H, W)) > 0.6
+        got = O.mask_cell_mean(m, h, w)
+        want = F.adaptive_avg_pool2d(torch.from_numpy(m.astype(np.float64))[:, None], (h, w)).reshape(3, h * w).numpy()
+        np.testing.assert_allclose(got, want, atol=1e-15)
+
+
+def test_c_oracle_is_clean_under_address_and_ub_sanitizers():
+    """make -C oracle SAN=1 builds the scalar C oracle with -fsanitize=address,undefined together with oracle_selftest.c, which walks every
+    entry point over ragged, exactly sized heap buffers (zero frames, zero tokens, carried states, every rule, the normalizer) and checks
+    K1 / K12: a clean exit means no out-of-bounds access, no use of uninitialised scratch the sanitizers can see, no undefined arithmetic.
+    (CPU only: GPU sanitizers are not available on this pool)"""
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    subprocess.check_call(["make", "-C", here, "-s", "SAN=1"])
+    out = subprocess.run([os.path.join(here, "_build", "oracle_selftest_san")], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1"))
+    assert out.returncode == 0 and "oracle_selftest: ok" in out.stdout, out.stdout + out.stderr

@@ -4,7 +4,7 @@ the 1x1 / stride-2 branch in the same launch)."""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
 from gdkvm_amd import ops  # noqa: E402

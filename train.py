@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Training entry point: one process per GPU under torchrun, DDP gradient all-reduce over RCCL.
+"""Training entry point: one process per GPU under torchrun, ONE gradient all-reduce per step over RCCL.
+The step runs in the form bench.py measures -- one hipGraph replay: forward, backward, the flat-bucket all-reduce as a node of the graph,
+fused AdamW (gdkvm_amd.pipeline.make_train_step; GDKVM_TRAIN_GRAPH=0 or a failed capture: the eager DistributedDataParallel step, said
+loudly) -- on batches prefetched through pinned memory on a side stream (gdkvm_amd.pipeline.DevicePrefetcher).
 
     python train.py --config config/config_gdkvm_01.yaml [key=value ...]                       # one GPU
     torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 train.py --config ... # one node
@@ -31,8 +34,8 @@ def main(argv=None):
     from gdkvm_amd.data import build_dataset
     from gdkvm_amd.distributed import init_from_env
     from gdkvm_amd.model import GDKVM, GDKVMConfig
+    from gdkvm_amd.pipeline import DevicePrefetcher, make_train_step
     from gdkvm_amd.runlog import OfflineRun
-    from gdkvm_amd.train import train_step, wrap_ddp
 
     cfg = load_config(args.config, args.overrides)
     ops.require_native()
@@ -43,13 +46,11 @@ def main(argv=None):
 
     mcfg = GDKVMConfig(num_classes=cfg.data.num_classes, heads=cfg.model.heads, value_dim=cfg.model.value_dim, rule=cfg.model.rule)
     model = GDKVM(mcfg).train().to(dev).to(memory_format=torch.channels_last)
-    opt = torch.optim.AdamW(model.parameters(), lr=cfg.learning_rate)
-    step0, epoch0 = 0, None
+    step0, epoch0, opt_state = 0, None, None
     if args.resume:
         ck = torch.load(args.resume, map_location=dev)
-        model.load_state_dict(ck["model"]); opt.load_state_dict(ck["optimizer"]); step0 = ck["step"]
+        model.load_state_dict(ck["model"]); opt_state = ck["optimizer"]; step0 = ck["step"]
         epoch0 = ck.get("epoch")
-    ddp = wrap_ddp(model, dev)
 
     ds = build_dataset(cfg, "train")
     sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=True, seed=cfg.seed) if world > 1 else None
@@ -64,11 +65,22 @@ def main(argv=None):
     # a resumed run continues the shuffle sequence where the checkpoint left it (older checkpoints: derived from the step count)
     epoch = epoch0 if epoch0 is not None else step0 // len(dl)
     step, t_log = step0, time.perf_counter()
+    train_one = opt = None                                        # built on the first batch (the graph is captured for its shape)
+    use_graph = os.environ.get("GDKVM_TRAIN_GRAPH", "1") != "0"
+    adamw = lambda params, fused, capturable: torch.optim.AdamW(params, lr=cfg.learning_rate, **({"fused": True, "capturable": capturable} if fused else {}))
     while step < cfg.num_iterations:
         if sampler is not None:
             sampler.set_epoch(epoch)
-        for frames, target in dl:
-            loss = train_step(ddp, opt, frames.to(dev, non_blocking=True), target.to(dev, non_blocking=True), amp)
+        # host batches staged through pinned memory and copied on a side stream while the previous step computes (DevicePrefetcher)
+        for frames, target in DevicePrefetcher(dl, dev, slots=2):
+            if train_one is None:
+                # the step in the form bench.py measures: one hipGraph replay (forward + backward + gradient all-reduce node + fused AdamW);
+                # a capture that fails falls back to the eager DistributedDataParallel step, loudly
+                train_one, opt, how = make_train_step(model, adamw, frames, target, amp, world, dev, graph=use_graph, opt_state=opt_state)
+                if rank == 0:
+                    print(f"train step: {how['launch']}; gradient exchange: {how['grad_sync']}; optimiser: {how['optimizer']}", flush=True)
+                step += how.get("warmup_steps", 0)                # (the capture's warm-up steps are real optimiser steps on this batch)
+            loss = train_one(frames, target)
             step += 1
             if step % cfg.log_every == 0 and rank == 0:
                 torch.cuda.synchronize()
@@ -76,10 +88,10 @@ def main(argv=None):
                 fps = world * cfg.batch_size * cfg.data.frames * cfg.log_every / dt
                 run.log(step, loss=float(loss), frames_per_s=fps)
                 print(f"step {step:6d}  loss {float(loss):.4f}  {fps:9.0f} frames/s", flush=True)
-            if (step % cfg.save_every == 0 or step == cfg.num_iterations) and rank == 0:
+            if (step % cfg.save_every == 0 or step >= cfg.num_iterations) and rank == 0:
                 os.makedirs(cfg.run_dir, exist_ok=True)
                 torch.save({"model": model.state_dict(), "optimizer": opt.state_dict(), "step": step, "epoch": epoch, "config": cfg.to_dict()},
-                           os.path.join(cfg.run_dir, f"gdkvm_step{step}.pth"))
+                           os.path.join(cfg.run_dir, f"gdkvm_step{min(step, cfg.num_iterations)}.pth"))
             if step >= cfg.num_iterations:
                 break
         epoch += 1
