@@ -53,7 +53,7 @@ def main(argv=None):
     vis_left = cfg.eval_stage.num_vis if rank == 0 else 0
     # this rank's shard through a prefetching loader (worker processes decode, pinned staging, host-to-device copies on a side stream) into
     # ONE captured forward per batch shape (SegmentRunner -> GraphedSegment: a hipGraph replay per batch; the short last batch runs eagerly)
-    dl = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, range(lo, hi)), batch_size=cfg.batch_size, shuffle=False, num_workers=2)
+    dl = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, range(lo, hi)), batch_size=cfg.batch_size, shuffle=False, num_workers=2, pin_memory=True)
     fdt = torch.bfloat16 if cfg.precision == "bf16" else torch.float32
     runner = SegmentRunner(model, graph=os.environ.get("GDKVM_FWD_GRAPH", "1") != "0")
     i = lo

@@ -50,7 +50,7 @@ struct IgArgs {
     // the taps whose parity matches: blockIdx.z = 2 ph + pw is that class, a plain stride-1 convolution of dy with (1 + ph)(1 + pw)
     // taps at (a + r', b + s') -- no products with zeros -- and class (0, 0), whose only tap is the forward window's centre, takes the
     // 1x1 / stride-2 downsample branch's gradient x2 (same shape as x) as ksteps_all - ksteps_main more k-steps of the same sum.
-    struct Cls { const bf16_t* w; int S, ksteps_main, ksteps_all; float inv_s; } cls[4];
+    struct Cls { const bf16_t* w; int S, ksteps_main, ksteps_all, ksteps_row; float inv_s; } cls[4];   // ksteps_row: k-steps per row tile IN THE PACK (>= ksteps_all: a pack made with the branch read without it)
     const bf16_t* x2; int OH, OW;
 };
 
@@ -142,10 +142,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
     // One convolution over the gathered pixels: `L` steps starting at gather step g0, weights `wpk` packed for exactly those steps.
     // The layer itself is (0, nsteps); a second pass over the CENTRE tap alone with another weight pack is the 1x1 / same-stride
     // convolution of the same input (the residual block's downsample branch), computed here on the pixels' geometry already set up.
-    auto run_pass = [&](const bf16_t* wpk, int g0, int L, const float* bias, const bf16_t* res, bf16_t* y, int relu) __attribute__((always_inline)) {
+    auto run_pass = [&](const bf16_t* wpk, int g0, int L, const float* bias, const bf16_t* res, bf16_t* y, int relu, int Lrow) __attribute__((always_inline)) {
         // weights: fragment (n-tile, k-step) = 1 KiB contiguous; this wave's four n-tiles, SUB k-steps per step
-        const bf16_t* wp = wpk + ((size_t)((n0 + 16 * NTW * wn) / 16) * (L * SUB) * 64 + lane) * 8;
-        const size_t nt_stride = (size_t)(L * SUB) * 512;
+        const bf16_t* wp = wpk + ((size_t)((n0 + 16 * NTW * wn) / 16) * (Lrow * SUB) * 64 + lane) * 8;      // (Lrow: steps per row tile in the pack)
+        const size_t nt_stride = (size_t)(Lrow * SUB) * 512;
         bf16x8 wr[WD][SUB][NTW];
         auto wload = [&](int l, bf16x8 (&d)[SUB][NTW]) __attribute__((always_inline)) {
             const size_t off = (size_t)min(l, L - 1) * (512 * SUB);
@@ -235,11 +235,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(IgArgs a)
         }
     };
     if constexpr (DG) {
-        run_pass(a.cls[cls].w, 0, nsteps, nullptr, nullptr, a.y, 0);
+        run_pass(a.cls[cls].w, 0, nsteps, nullptr, nullptr, a.y, 0, a.cls[cls].ksteps_row / SUB);
     } else {
-        run_pass(a.w, 0, nsteps, a.bias, a.res, a.y, a.relu);
+        run_pass(a.w, 0, nsteps, a.bias, a.res, a.y, a.relu, nsteps);
         IG_STAMP(15, 3);
-        if (a.w2) run_pass(a.w2, a.centre * spt, spt, a.bias2, nullptr, a.y2, 0);
+        if (a.w2) run_pass(a.w2, a.centre * spt, spt, a.bias2, nullptr, a.y2, 0, spt);
     }
 }
 
@@ -326,6 +326,7 @@ int gdkvm_conv_igemm_dgrad_launch(const void* dy, const void* dy2, const void* p
         a.cls[c].inv_s = 1.0f / (float)(1 + pw);
         a.cls[c].ksteps_main = taps * a.cps;
         a.cls[c].ksteps_all = (taps + (c == 0 && dy2 && with_down ? 1 : 0)) * a.cps;
+        a.cls[c].ksteps_row = (taps + (c == 0 && with_down ? 1 : 0)) * a.cps;
         wp += gdkvm_conv_s2_dgrad_pack_elems(Cf, Kf, c, with_down);
     }
     if (Cf % 128 == 0) {

@@ -273,6 +273,20 @@ class Encoder(nn.Module):
         return f4, f8, self.layer3(f8)
 
 
+def _rows_aligned16(x: torch.Tensor) -> torch.Tensor:
+    """x [T, ...] -> the same values with every x[t] starting on a 16-byte boundary (rows padded inside one buffer; x itself when its rows
+    already do).  Each x[t] stays a contiguous block: one copy for all frames instead of one per frame."""
+    row = x[0].numel() * x.element_size()
+    if row % 16 == 0 and x.data_ptr() % 16 == 0 and x.is_contiguous():
+        return x
+    per = 16 // x.element_size()
+    n = x[0].numel()
+    padded = (n + per - 1) // per * per
+    buf = torch.empty((x.shape[0], padded), dtype=x.dtype, device=x.device)
+    buf[:, :n].copy_(x.reshape(x.shape[0], n))
+    return buf[:, :n].unflatten(1, x.shape[1:]) if x.dim() > 2 else buf[:, :n]
+
+
 class UpBlock(nn.Module):
     def __init__(self, cin, cskip, cout):
         super().__init__()
@@ -745,6 +759,9 @@ class GDKVM(nn.Module):
             v = v.reshape(T, B, N, Hh * Dv)
             k5 = k_tok.reshape(T, B, N, Hh, Dk)
             nrm = None if norms is None else norms.reshape(T, B * N, Hh, 2)
+            if frames.is_cuda:                   # (the kernels want 16-byte aligned operands: frame t's gate / norm rows must start on one)
+                alpha, beta = _rows_aligned16(alpha), _rows_aligned16(beta)
+                nrm = None if nrm is None else _rows_aligned16(nrm)
             S = torch.zeros((B, Hh, Dk, Dv), dtype=torch.float32, device=frames.device) if state is None else state.to(torch.float32)
             tgt = None if target is None else target.transpose(0, 1).contiguous()          # [T,B,H,W]
             mask_tm = torch.empty((T, B, H, W), dtype=torch.uint8, device=frames.device)
@@ -1039,10 +1056,10 @@ class GDKVM(nn.Module):
             counts.append(c)
         return torch.cat(masks, 1), (None if target is None else torch.cat(counts, 1)), state
 
-    def graphed_segment(self, frames, target=None, warmup: int = 2, state=None, streams=None):
+    def graphed_segment(self, frames, target=None, warmup: int = 2, state=None, streams=None, pool=None):
         """segment() for ONE clip shape captured into a hipGraph (GraphedSegment): a serving loop that replays it spends no host time
-        on the ~25 launches of a forward; `streams`: see GraphedSegment."""
-        return GraphedSegment(self, frames, target, warmup, state, streams)
+        on the ~25 launches of a forward; `streams`, `pool`: see GraphedSegment."""
+        return GraphedSegment(self, frames, target, warmup, state, streams, pool)
 
     # -------------------------------------------------------------------------------------- checkpoints
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -1079,7 +1096,7 @@ class GraphedSegment:
     graph's output tensors (overwritten by the next call): (mask uint8 [B,T,H,W], Dice counts int32 [B,T,ncls,3] | None)."""
 
     def __init__(self, model: "GDKVM", frames: torch.Tensor, target: Optional[torch.Tensor] = None, warmup: int = 2,
-                 state: Optional[torch.Tensor] = None, streams: Optional[int] = None):
+                 state: Optional[torch.Tensor] = None, streams: Optional[int] = None, pool=None):
         """state (fp32 [B,Hh,Dk,Dv]): capture the state-carrying form -- calls then take `state=` (copied into the graph's buffer) and
         return (mask, counts, state after the last frame), as segment(..., state=, return_state=True) does (GDKVM.segment_clip).
         streams: the batch is cut into that many equal groups of clips whose forwards run on their own streams INSIDE the one graph (fork at
@@ -1087,7 +1104,10 @@ class GraphedSegment:
         bits; what changes is the schedule: every kernel of a forward fills the chip, drains with a tail and runs its phases in lockstep,
         and a second, independent stream fills those gaps -- cfg2: 0.898 against 0.940 ms per 16 x 32 frames with two groups of eight,
         although each half-batch kernel alone is less efficient (the halves one after the other: 1.085 ms); three or four groups and
-        unequal ones lose (profiles/r05_n_two_streams_in_one_graph.txt).  None = 2 for batches of at least 8 clips that halve, else 1 (GDKVM_SEGMENT_STREAMS overrides where it divides the batch)."""
+        unequal ones lose (profiles/r05_n_two_streams_in_one_graph.txt).  None = 2 for batches of at least 8 clips that halve, else 1 (GDKVM_SEGMENT_STREAMS overrides where it divides the batch).
+        pool: another GraphedSegment's ``graph.pool()`` -- graphs of one pool share their activation memory (never replay two of them
+        concurrently; a graph's outputs are valid until another graph of the pool replays): several captures over DIFFERENT input buffers
+        cost one set of activations (bench.py rotates eight input batches this way)."""
         if not frames.is_cuda:
             raise RuntimeError("GraphedSegment needs device tensors")
         self.model, self.frames, self.target, self.state = model, frames, target, state
@@ -1124,9 +1144,9 @@ class GraphedSegment:
             self.graph = torch.cuda.CUDAGraph()
             # (with a process group alive its watchdog THREAD may poll events of earlier collectives while this thread captures: under the
             # default "global" capture mode that aborts the process -- train.GraphedTrainStep met it -- so only this thread is policed)
-            mode = {}
+            mode = {} if pool is None else {"pool": pool}
             if torch.distributed.is_available() and torch.distributed.is_initialized():
-                mode = {"capture_error_mode": "thread_local"}
+                mode["capture_error_mode"] = "thread_local"
             if streams == 1:
                 with torch.cuda.graph(self.graph, **mode):
                     self.out = model.segment(self.frames, self.target, **kw)

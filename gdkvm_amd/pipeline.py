@@ -31,7 +31,8 @@ class DevicePrefetcher:
         self.loader, self.device, self.slots = loader, device, slots
         self.frames_dtype, self.target_dtype = frames_dtype, target_dtype
         self.stream = torch.cuda.Stream(device=device)
-        self._pinned = [None] * slots           # per slot: (frames, target) pinned host staging, re-used while the shape holds
+        self._pinned = [None] * slots           # per slot: the page-locked (frames, target) its copy in flight reads (kept alive)
+        self._stage_buf = [None] * slots        # per slot: this class's own pinned staging buffers, re-used while the shape holds
         self._dev = [None] * slots
         self._free = [None] * slots             # event: the consumer is done with this slot's device buffers
         self._copied = [None] * slots           # event: the slot's last host-to-device copy
@@ -39,15 +40,23 @@ class DevicePrefetcher:
 
     def _stage(self, slot: int, batch) -> Tuple[torch.Tensor, torch.Tensor, torch.cuda.Event]:
         frames, target = batch
-        pin, dev = self._pinned[slot], self._dev[slot]
-        if pin is None or pin[0].shape != frames.shape or pin[0].dtype != frames.dtype or pin[1].shape != target.shape or pin[1].dtype != target.dtype:
-            pin = (torch.empty(frames.shape, dtype=frames.dtype, pin_memory=True), torch.empty(target.shape, dtype=target.dtype, pin_memory=True))
-            dev = (torch.empty(frames.shape, dtype=frames.dtype, device=self.device), torch.empty(target.shape, dtype=target.dtype, device=self.device))
-            self._pinned[slot], self._dev[slot] = pin, dev
+        dev = self._dev[slot]
+        if dev is None or dev[0].shape != frames.shape or dev[0].dtype != frames.dtype or dev[1].shape != target.shape or dev[1].dtype != target.dtype:
+            dev = self._dev[slot] = (torch.empty(frames.shape, dtype=frames.dtype, device=self.device),
+                                     torch.empty(target.shape, dtype=target.dtype, device=self.device))
         if self._copied[slot] is not None:
-            self._copied[slot].synchronize()    # (the slot's previous host-to-device copy has left the pinned buffers)
-        pin[0].copy_(frames)                    # (host memcpy into page-locked memory: what makes the H2D copy asynchronous)
-        pin[1].copy_(target)
+            self._copied[slot].synchronize()    # (the slot's previous host-to-device copy has left its host buffers)
+        if frames.is_pinned() and target.is_pinned():
+            # already page-locked (DataLoader(pin_memory=True) stages in its own thread): copy straight from it, keep it alive until copied
+            pin = (frames, target)
+        else:
+            pin = self._stage_buf[slot]
+            if pin is None or pin[0].shape != frames.shape or pin[0].dtype != frames.dtype or pin[1].shape != target.shape or pin[1].dtype != target.dtype:
+                pin = self._stage_buf[slot] = (torch.empty(frames.shape, dtype=frames.dtype, pin_memory=True),
+                                               torch.empty(target.shape, dtype=target.dtype, pin_memory=True))
+            pin[0].copy_(frames)                # (host memcpy into page-locked memory: what makes the H2D copy asynchronous)
+            pin[1].copy_(target)
+        self._pinned[slot] = pin
         with torch.cuda.stream(self.stream):
             if self._free[slot] is not None:
                 self.stream.wait_event(self._free[slot])

@@ -55,7 +55,7 @@ def main(argv=None):
     ds = build_dataset(cfg, "train")
     sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=True, seed=cfg.seed) if world > 1 else None
     dl = torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, sampler=sampler, shuffle=sampler is None, drop_last=True,
-                                     num_workers=2, persistent_workers=True)
+                                     num_workers=2, persistent_workers=True, pin_memory=True)
     run = OfflineRun(cfg.run_dir, cfg.to_dict(), cfg.eval_stage.wandb_mode, enabled=rank == 0)
     amp = torch.bfloat16 if cfg.precision == "bf16" else None
 
