@@ -31,7 +31,8 @@ constexpr int CB_C = 64, CB_TH = 7, CB_TW = 28, CB_BW = CB_TW + 2, CB_PIX = 160;
 constexpr int CB_XR = CB_TH + 4, CB_YR = CB_TH + 2;
 constexpr int CB_XSLOTS = CB_XR * CB_BW * 10, CB_XPIECES = (CB_XSLOTS + 63) / 64, CB_XBYTES = CB_XPIECES * 1024;     // 52 KiB
 constexpr int CB_YBYTES = ((CB_YR * CB_BW * CB_PIX + 1023) / 1024) * 1024;                                               // 43 KiB
-constexpr int CB_LDS = 2 * CB_XBYTES + CB_YBYTES;
+constexpr int CB_GEO = CB_XPIECES * 64 * 4;                          // the band's slot geometry, one word per 16-byte slot (13 KiB)
+constexpr int CB_LDS = CB_XBYTES + 2 * CB_YBYTES + 16 + CB_GEO;      // (+ the producers' arrival counter, + the geometry table)
 constexpr int CB_M1 = (CB_YR * CB_TW + 15) / 16, CB_M2 = (CB_TH * CB_TW + 15) / 16;                                      // 16, 13 m-tiles
 
 __device__ const uint4 g_cb_zero16 = {0, 0, 0, 0};
@@ -40,7 +41,7 @@ __device__ const uint4 g_cb_zero16 = {0, 0, 0, 0};
 // diagnostic builds (tools/abl_block.py): s_memtime per wave of workgroup 0 at the phase boundaries of its first tiles
 __device__ unsigned long long* g_cb_diag = nullptr;
 #define CB_STAMP(slot) do { if (blockIdx.x == 0 && lane == 0 && nt_done < 8) { unsigned long long t__; \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); g_cb_diag[(nt_done * 4 + w) * 8 + (slot)] = t__; } } while (0)
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); g_cb_diag[(nt_done * 8 + w) * 8 + (slot)] = t__; } } while (0)
 #else
 #define CB_STAMP(slot) do {} while (0)
 #endif
@@ -50,13 +51,23 @@ struct Block64Args {
     int N, H, W, tiles_y, ntiles;
 };
 
-__global__ __launch_bounds__(256, 1) void conv3x3_block64_kernel(Block64Args a)
+// v2 (round 6, second form): EIGHT waves, two per SIMD.  Waves 0-3 are the block's FIRST convolution (their 144 registers of weights are
+// w1's), waves 4-7 the SECOND (w2's), one tile behind: in phase i the producers turn tile i's x band into y1[i & 1] while the consumers turn
+// y1[(i - 1) & 1] into tile i - 1's output.  Wave w and wave w + 4 share a SIMD, so one role's epilogue (VALU, LDS / global stores) runs
+// beside the other role's MFMAs -- what two workgroups per CU give conv3x3_c64_kernel, and what the one-wave-per-SIMD form above lacked.
+//   LDS: x band 52 KiB (single: the residual is read from memory, L2-hot) + y1 band 2 x 43 KiB.
+//   Per phase two s_barriers that all eight waves join (M behind the last MFMA pass, Y behind the epilogues: see the loop).
+//   Each role works in two passes of at most four m-tiles (MFMAs, then that pass's epilogue): 32 accumulator registers, not 64 -- 144 weights
+//   + 32 accumulators + 32 operand staging + addresses fit the 256-register budget of two waves per SIMD.
+__global__ __launch_bounds__(512, 1) void conv3x3_block64_kernel(Block64Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* xband2 = smem;
-    unsigned char* yband = smem + 2 * CB_XBYTES;
+    unsigned char* xband = smem;
+    unsigned char* yband2 = smem + CB_XBYTES;
+    unsigned* arrivals = reinterpret_cast<unsigned*>(smem + CB_XBYTES + 2 * CB_YBYTES);     // producers done with the x band, counted up for ever
+    unsigned* geo = reinterpret_cast<unsigned*>(smem + CB_XBYTES + 2 * CB_YBYTES + 16);
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), role = w >> 2, wr = w & 3, wm = wr >> 1, wn = wr & 1;
 
     // tile order: virtual index v -> (frame, row tile) such that the row tiles of one frame run on ONE XCD (workgroup v lands on XCD
     // v % 8) at about the same time: their shared halo rows are then L2 hits.  Any bijection is correct; this one is the fast one.
@@ -65,177 +76,234 @@ __global__ __launch_bounds__(256, 1) void conv3x3_block64_kernel(Block64Args a)
         n = blk * 8 + (r & 7);
         ty = r >> 3;
     };
-    const int nvirt = ((a.N + 7) / 8) * 8 * a.tiles_y;                  // (frames padded to a multiple of 8: indices past N are skipped)
+    const int nvirt = a.ntiles;                                         // (frames padded to a multiple of 8: indices past N are skipped)
+    auto next_valid = [&](int v, int& n, int& ty) __attribute__((always_inline)) {
+        while (v < nvirt) { tile_of(v, n, ty); if (n < a.N) break; v += gridDim.x; }
+        return v;
+    };
 
-    // x-band fetch by LDS-DMA: piece j = w + 4u (64 consecutive 16-byte slots) is issued by wave w; slot d = 10 pix + c holds channel
-    // chunk c of band pixel pix (c = 8, 9: padding).  The slot geometry does not depend on the tile: kept in registers.
-    // (the slot geometry is recomputed per fetch -- a dozen integer operations per piece, once per tile: the weight fragments leave no
-    // registers to keep it in)
+    // x-band fetch by LDS-DMA (producer waves only): piece j = wr + 4u (64 consecutive 16-byte slots); slot d = 10 pix + c holds channel chunk
+    // c of band pixel pix (c = 8, 9: padding).  The slot geometry does not depend on the tile; it is kept as a table in LDS (one word per slot:
+    // element offset from the band's origin | band row << 16 | 1 << 24 if the slot carries data), built once -- recomputing it costs ~25
+    // integer instructions per piece (4 k cycles per tile at the producers' priority), keeping it in registers costs 13 that do not exist.
     constexpr int PP = (CB_XPIECES + 3) / 4;
-    auto fetch = [&](int n, int ty, int buf) __attribute__((always_inline)) {
+    for (int d = tid; d < CB_XPIECES * 64; d += 512) {
+        const int pix = d / 10, c = d - 10 * pix, by = pix / CB_BW, bx = pix - by * CB_BW;
+        const bool ok = c < 8 && pix < CB_XR * CB_BW && bx >= 1 && bx <= a.W;
+        geo[d] = ok ? (unsigned)((by * a.W + bx) * CB_C + c * 8) | ((unsigned)by << 16) | (1u << 24) : 0u;
+    }
+    auto fetch = [&](int n, int ty) __attribute__((always_inline)) {
         const int y0 = ty * CB_TH - 2;
         const bf16_t* origin = a.x + (((long long)n * a.H + y0) * a.W - 1) * CB_C;
+        unsigned e[PP];
+#pragma unroll
+        for (int u = 0; u < PP; ++u) e[u] = geo[64 * min(wr + 4 * u, CB_XPIECES - 1) + lane];
 #pragma unroll
         for (int u = 0; u < PP; ++u) {
-            const int j = w + 4 * u;
+            const int j = wr + 4 * u;
             if (j >= CB_XPIECES) break;
-            const int d = 64 * j + lane, pix = d / 10, c = d - 10 * pix;
-            const int by = pix / CB_BW, bx = pix - by * CB_BW, yy = y0 + by;
-            const bool ok = c < 8 && pix < CB_XR * CB_BW && bx >= 1 && bx <= a.W && (unsigned)yy < (unsigned)a.H;
-            const bf16_t* src = ok ? origin + ((by * a.W + bx) * CB_C + c * 8) : reinterpret_cast<const bf16_t*>(&g_cb_zero16);
+            const int yy = y0 + (int)((e[u] >> 16) & 0xff);
+            const bool ok = (e[u] >> 24) && (unsigned)yy < (unsigned)a.H;
+            const bf16_t* src = ok ? origin + (e[u] & 0xffff) : reinterpret_cast<const bf16_t*>(&g_cb_zero16);
             __builtin_amdgcn_global_load_lds(src, reinterpret_cast<__attribute__((address_space(3))) void*>(
-                reinterpret_cast<uintptr_t>(xband2 + buf * CB_XBYTES + 1024 * j)), 16, 0, 0);
+                reinterpret_cast<uintptr_t>(xband + 1024 * j)), 16, 0, 0);
         }
     };
+    auto barrier_lds = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto barrier_all = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
-    // first tile of this workgroup (skipping virtual indices past the last frame)
-    int v = blockIdx.x, n = 0, ty = 0;
-    auto advance = [&]() __attribute__((always_inline)) {               // -> the next valid virtual index at or after v, or nvirt
-        while (v < nvirt) { tile_of(v, n, ty); if (n < a.N) break; v += gridDim.x; }
-    };
-    advance();
-    if (v < nvirt) fetch(n, ty, 0);
+    // this workgroup's tiles, in order: the producers are at tile (vP, nP, tyP), the consumers one behind
+    int vP = blockIdx.x, nP = 0, tyP = 0;
+    vP = next_valid(vP, nP, tyP);
+    __syncthreads();                                                    // (the geometry table is complete)
+    if (role == 0 && vP < nvirt) fetch(nP, tyP);
 
-    // y1 band: zero once -- the halo columns (0 and 29) and the alignment tail are never written again
-    for (int i = tid; i < CB_YBYTES / 16; i += 256) reinterpret_cast<uint4*>(yband)[i] = make_uint4(0, 0, 0, 0);
+    // y1 bands: zero once -- the halo columns (0 and 29) and the alignment tails are never written again (and the arrival counter behind them)
+    for (int i = tid; i < (2 * CB_YBYTES + 16) / 16; i += 512) reinterpret_cast<uint4*>(yband2)[i] = make_uint4(0, 0, 0, 0);
 
-    // weights of this wave's 32 output channels, both layers, all 18 k-steps, as A-operand fragments (packed copies: one contiguous KiB per load)
-    bf16x8 wf1[2][18], wf2[2][18];
+    // this wave's layer: weights of its 32 output channels, all 18 k-steps, as A-operand fragments (packed copies: one contiguous KiB per load)
+    const bf16_t* wsrc = role == 0 ? a.w1 : a.w2;
+    const float* bsrc = role == 0 ? a.b1 : a.b2;
+    bf16x8 wf[2][18];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int ks = 0; ks < 18; ++ks) {
-            wf1[nt][ks] = *reinterpret_cast<const bf16x8*>(a.w1 + ((size_t)((2 * wn + nt) * 18 + ks) * 64 + lane) * 8);
-            wf2[nt][ks] = *reinterpret_cast<const bf16x8*>(a.w2 + ((size_t)((2 * wn + nt) * 18 + ks) * 64 + lane) * 8);
-        }
-    float bia1[8], bia2[8];
+        for (int ks = 0; ks < 18; ++ks)
+            wf[nt][ks] = *reinterpret_cast<const bf16x8*>(wsrc + ((size_t)((2 * wn + nt) * 18 + ks) * 64 + lane) * 8);
+    float bia[8];
     {
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(a.b1 + 32 * wn + 8 * g), p1 = *reinterpret_cast<const f32x4*>(a.b1 + 32 * wn + 8 * g + 4);
-        const f32x4 q0 = *reinterpret_cast<const f32x4*>(a.b2 + 32 * wn + 8 * g), q1 = *reinterpret_cast<const f32x4*>(a.b2 + 32 * wn + 8 * g + 4);
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(bsrc + 32 * wn + 8 * g), p1 = *reinterpret_cast<const f32x4*>(bsrc + 32 * wn + 8 * g + 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { bia1[i] = p0[i]; bia1[4 + i] = p1[i]; bia2[i] = q0[i]; bia2[4 + i] = q1[i]; }
+        for (int i = 0; i < 4; ++i) { bia[i] = p0[i]; bia[4 + i] = p1[i]; }
     }
 
     // this lane's pixel in each of the wave's m-tiles: LDS byte offset of tap (0, 0), channel chunk g.
-    // conv1: pixel p of the 9 x 28 y1 patch -> x band pixel (py, px); conv2: pixel q of the 7 x 28 output tile -> y1 band pixel (qy, qx)
-    // (conv1's lane writes its y1 pixel at band pixel (py, px + 1), channel bytes 64wn + 16g: pb1 + one pixel + 64wn)
-    unsigned pb1[8], pb2[7];
+    // producers: pixel p of the 9 x 28 y1 patch -> x band pixel (py, px) (and the lane WRITES y1 band pixel (py, px + 1): pb + one pixel + 64wn);
+    // consumers: pixel q of the 7 x 28 output tile -> y1 band pixel (qy, qx)
+    const int mt0 = role == 0 ? 8 * wm : 7 * wm, npix = role == 0 ? CB_YR * CB_TW : CB_TH * CB_TW;
+    unsigned pb[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-        const int p = min(16 * (8 * wm + m) + li, CB_YR * CB_TW - 1);
+        const int p = min(16 * (mt0 + m) + li, npix - 1);
         const int py = p / CB_TW, px = p - py * CB_TW;
-        pb1[m] = (unsigned)((py * CB_BW + px) * CB_PIX + g * 16);
-    }
-#pragma unroll
-    for (int m = 0; m < 7; ++m) {
-        const int q = min(16 * (7 * wm + m) + li, CB_TH * CB_TW - 1);
-        const int qy = q / CB_TW, qx = q - qy * CB_TW;
-        pb2[m] = (unsigned)((qy * CB_BW + qx) * CB_PIX + g * 16);
+        pb[m] = (unsigned)((py * CB_BW + px) * CB_PIX + g * 16);
     }
 
-    __syncthreads();                                                    // (vmcnt(0) + barrier: the first band has landed, y1 is zero)
-    int cur = 0;
+    f32x4 acc[4][2];
+    // MFMAs of one pass: `cnt` (<= 4) m-tiles starting at the wave's m-tile m0, all 18 k-steps.  B operands in two half buffers (two
+    // m-tiles each), refilled for the next k-step right behind their MFMAs.
+    // `early` runs behind the first half-step's MFMAs: the consumers request their residual rows there, NOT in front of the pass -- the
+    // compiler's wait-count pass cannot tell the roles apart, assumes the producers' LDS-DMA may be pending at every LDS read that follows
+    // a loop back-edge and puts vmcnt(0) on the pass's first ds_read; a global load issued before that read would be waited for in full.
+    auto mfma_pass = [&](const unsigned char* band, int m0, auto cnt_c, auto early) __attribute__((always_inline)) {
+        constexpr int CNT = decltype(cnt_c)::value, NA = CNT < 2 ? CNT : 2, NB = CNT - NA;
+#pragma unroll
+        for (int m = 0; m < CNT; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto load_h = [&](bf16x8 (&o)[2], int ks, int mo, int cnt) __attribute__((always_inline)) {
+            const int tap = ks >> 1, kh = ks & 1, dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                if (m < cnt) o[m] = *reinterpret_cast<const bf16x8*>(band + pb[m0 + mo + m] + (dy * CB_BW + dx) * CB_PIX + kh * 64);
+        };
+        auto mfma_h = [&](const bf16x8 (&o)[2], int ks, int mo, int cnt) __attribute__((always_inline)) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+                if (m < cnt) {
+                    acc[mo + m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ks], o[m], acc[mo + m][0], 0, 0, 0);
+                    acc[mo + m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ks], o[m], acc[mo + m][1], 0, 0, 0);
+                }
+        };
+        bf16x8 P0[2], Q0[2];                                            // (one half-step ahead: the SIMD's other wave covers the rest of the latency)
+        load_h(P0, 0, 0, NA);
+        load_h(Q0, 0, NA, NB);
+#pragma unroll
+        for (int ks = 0; ks < 18; ++ks) {
+            mfma_h(P0, ks, 0, NA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks == 0) { early(); __builtin_amdgcn_sched_barrier(0); }
+            if (ks + 1 < 18) load_h(P0, ks + 1, 0, NA);
+            mfma_h(Q0, ks, NA, NB);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < 18) load_h(Q0, ks + 1, NA, NB);
+        }
+    };
+
+    barrier_all();                                                      // (the first band has landed -- its issuers waited --, y1 is zero)
+    int vC = nvirt, nC = 0, tyC = 0;                                    // the consumers' tile: none yet
     int nt_done = 0;
     (void)nt_done;
-    while (v < nvirt) {
-        CB_STAMP(0);
-        const unsigned char* xb = xband2 + cur * CB_XBYTES;
-        const int y0 = ty * CB_TH;
-        // the tile after this one (this workgroup's next): its band is requested at barrier A
-        int v2 = v + gridDim.x, n2 = 0, ty2 = 0;
-        while (v2 < nvirt) { tile_of(v2, n2, ty2); if (n2 < a.N) break; v2 += gridDim.x; }
-
-        f32x4 acc[8][2];
-        // One wave per SIMD and 288 registers of weights: the B operands are staged in TWO half-step buffers of four m-tiles (32 registers,
-        // not 64).  Half-step h = 2 ks + (0: m-tiles 0..3, 1: m-tiles 4..): buffer P holds the first halves, Q the second; each is
-        // refilled for the next k-step right after its MFMAs have been issued, so a read has the other half's eight MFMAs (128 cycles) to land.
-        auto compute = [&](const unsigned char* band, const unsigned (&pb)[8], const bf16x8 (&wf)[2][18], auto nm_c) __attribute__((always_inline)) {
-            constexpr int NM = decltype(nm_c)::value, NA = NM < 4 ? NM : 4, NB = NM - NA;
+    // ONE barrier per phase that all eight waves join -- Y, behind the epilogues: y1[i & 1] is complete (lgkmcnt(0)), the consumers are done
+    // with y1[(i - 1) & 1], and x(i + 1) has landed (the producers' vmcnt(0)).  The x band being free is the PRODUCERS' business alone (the
+    // consumers never read it): behind their last MFMA pass the four producer waves meet at a counter in LDS (one ds_add each, a short
+    // s_sleep spin -- they run the same work and arrive together) and request the next band at once, ~6 k cycles ahead of Y, instead of
+    // waiting at a full barrier for the slower consumers.  The consumers raise their wave priority for their MFMA passes (their chain --
+    // MFMAs, residual loads, stores -- is the longer one; the producers fill in during the consumers' epilogues).
+    unsigned p_phases = 0;                                               // phases in which the producers were active (the counter's target / 4)
+    for (int phase = 0; vP < nvirt || vC < nvirt; ++phase) {
+        // the producers' NEXT tile (requested behind barrier M)
+        int vN = nvirt, nN = 0, tyN = 0;
+        if (vP < nvirt) vN = next_valid(vP + gridDim.x, nN, tyN);
+        if (role == 0) {
+            // ================= producers: tile (nP, tyP): x band -> y1[phase & 1] =================
+            CB_STAMP(0);
+            if (vP < nvirt) {
+                unsigned char* yb = yband2 + (phase & 1) * CB_YBYTES;
+                const int y0 = tyP * CB_TH;
+                auto epi1 = [&](int m0) __attribute__((always_inline)) {
 #pragma unroll
-            for (int m = 0; m < NM; ++m) acc[m][0] = acc[m][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            auto load_h = [&](bf16x8 (&o)[4], int ks, int m0, int cnt) __attribute__((always_inline)) {
-                const int tap = ks >> 1, kh = ks & 1, dy = tap / 3, dx = tap - 3 * dy;
+                    for (int m = 0; m < 4; ++m) {
+                        const int p = 16 * (mt0 + m0 + m) + li, py = p / CB_TW, px = p - py * CB_TW, yy = y0 - 1 + py;
+                        const bool inside = p < CB_YR * CB_TW && (unsigned)yy < (unsigned)a.H && px < a.W;
+                        unsigned ow[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    if (m < cnt) o[m] = *reinterpret_cast<const bf16x8*>(band + pb[m0 + m] + (dy * CB_BW + dx) * CB_PIX + kh * 64);
-            };
-            auto mfma_h = [&](const bf16x8 (&o)[4], int ks, int m0, int cnt) __attribute__((always_inline)) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    if (m < cnt) {
-                        acc[m0 + m][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][ks], o[m], acc[m0 + m][0], 0, 0, 0);
-                        acc[m0 + m][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][ks], o[m], acc[m0 + m][1], 0, 0, 0);
+                        for (int q = 0; q < 4; ++q) {
+                            const float v0 = fmaxf(acc[m][q >> 1][2 * (q & 1)] + bia[2 * q], 0.f), v1 = fmaxf(acc[m][q >> 1][2 * (q & 1) + 1] + bia[2 * q + 1], 0.f);
+                            ow[q] = inside ? ((unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16)) : 0u;
+                        }
+                        if (p < CB_YR * CB_TW) *reinterpret_cast<uint4*>(yb + pb[m0 + m] + CB_PIX + 64 * wn) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
                     }
-            };
-            bf16x8 P[4], Q[4];
-            load_h(P, 0, 0, NA);
-            load_h(Q, 0, NA, NB);
-#pragma unroll
-            for (int ks = 0; ks < 18; ++ks) {
-                mfma_h(P, ks, 0, NA);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ks + 1 < 18) load_h(P, ks + 1, 0, NA);
-                mfma_h(Q, ks, NA, NB);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ks + 1 < 18) load_h(Q, ks + 1, NA, NB);
+                };
+                auto nothing = [] {};
+                mfma_pass(xband, 0, std::integral_constant<int, 4>{}, nothing);
+                CB_STAMP(1);
+                epi1(0);
+                CB_STAMP(2);
+                mfma_pass(xband, 4, std::integral_constant<int, 4>{}, nothing);
+                CB_STAMP(3);
+                // producers-only meeting: every producer wave has issued its last read of x(i) -- and received it (the MFMAs that used it
+                // are issued) -- before the band is overwritten
+                ++p_phases;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (__hip_atomic_load(arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u * p_phases) __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");
+                if (vN < nvirt) fetch(nN, tyN);                          // lands behind the epilogue and the consumers' remaining work
+                CB_STAMP(4);
+                epi1(4);
+                CB_STAMP(5);
             }
-        };
-
-        // ---- conv1 on the x band -> y1 band (bias, ReLU, zero outside the image, bf16) ----
-        compute(xb, pb1, wf1, std::integral_constant<int, 8>{});
-        CB_STAMP(1);
+            barrier_all();                                               // Y (vmcnt(0): this wave's pieces of the next band have landed)
+            CB_STAMP(6);
+        } else {
+            // ================= consumers: y1[(phase - 1) & 1] -> tile (nC, tyC) =================
+            CB_STAMP(0);
+            if (vC < nvirt) {
+                const unsigned char* yb = yband2 + ((phase - 1) & 1) * CB_YBYTES;
+                const int y0 = tyC * CB_TH;
+                int li_o;                                                // (= li through an asm: pixel offsets are recomputed here, not hoisted and spilled)
+                asm volatile("v_mov_b32 %0, %1" : "=v"(li_o) : "v"(li));
+                // the block's input at this lane's output pixels (the residual): requested BEFORE a pass's MFMAs, used after them -- the
+                // loads are L2 hits (this workgroup fetched the rows a tile ago) but still ~2 k cycles away
+                uint4 rr[4];
+                auto res_load = [&](int m0, int cnt) __attribute__((always_inline)) {
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int p = 16 * (8 * wm + m) + li, py = p / CB_TW, px = p - py * CB_TW, yy = y0 - 1 + py;
-            const bool inside = p < CB_YR * CB_TW && (unsigned)yy < (unsigned)a.H && px < a.W;
-            unsigned ow[4];
+                    for (int m = 0; m < 4; ++m) {
+                        if (m >= cnt) continue;
+                        const int q = min(16 * (mt0 + m0 + m) + li_o, CB_TH * CB_TW - 1), qy = q / CB_TW, qx = min(q - qy * CB_TW, a.W - 1), yy = min(y0 + qy, a.H - 1);
+                        rr[m] = *reinterpret_cast<const uint4*>(a.x + (((size_t)nC * a.H + yy) * a.W + qx) * CB_C + 32 * wn + 8 * g);
+                    }
+                };
+                auto epi2 = [&](int m0, int cnt) __attribute__((always_inline)) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float v0 = fmaxf(acc[m][q >> 1][2 * (q & 1)] + bia1[2 * q], 0.f), v1 = fmaxf(acc[m][q >> 1][2 * (q & 1) + 1] + bia1[2 * q + 1], 0.f);
-                ow[q] = inside ? ((unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16)) : 0u;
+                    for (int m = 0; m < 4; ++m) {
+                        if (m >= cnt) continue;
+                        const int q = 16 * (mt0 + m0 + m) + li_o, qy = q / CB_TW, qx = q - qy * CB_TW, yy = y0 + qy;
+                        if (q >= CB_TH * CB_TW || yy >= a.H || qx >= a.W) continue;
+                        const unsigned rw[4] = {rr[m].x, rr[m].y, rr[m].z, rr[m].w};
+                        unsigned ow[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float v0 = acc[m][k >> 1][2 * (k & 1)] + bia[2 * k] + __uint_as_float(rw[k] << 16);
+                            const float v1 = acc[m][k >> 1][2 * (k & 1) + 1] + bia[2 * k + 1] + __uint_as_float(rw[k] & 0xffff0000u);
+                            ow[k] = (unsigned)f32_to_bf16(fmaxf(v0, 0.f)) | ((unsigned)f32_to_bf16(fmaxf(v1, 0.f)) << 16);
+                        }
+                        *reinterpret_cast<uint4*>(a.y + (((size_t)nC * a.H + yy) * a.W + qx) * CB_C + 32 * wn + 8 * g) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                    }
+                };
+                __builtin_amdgcn_s_setprio(2);
+                mfma_pass(yb, 0, std::integral_constant<int, 4>{}, [&] { res_load(0, 4); });
+                __builtin_amdgcn_s_setprio(0);
+                CB_STAMP(1);
+                epi2(0, 4);
+                CB_STAMP(2);
+                __builtin_amdgcn_s_setprio(2);
+                if (wm == 0) mfma_pass(yb, 4, std::integral_constant<int, 3>{}, [&] { res_load(4, 3); });
+                else mfma_pass(yb, 4, std::integral_constant<int, CB_M2 - 7 - 4>{}, [&] { res_load(4, CB_M2 - 7 - 4); });
+                __builtin_amdgcn_s_setprio(0);
+                CB_STAMP(3);
+                CB_STAMP(4);
+                epi2(4, wm == 0 ? 3 : CB_M2 - 7 - 4);
+                CB_STAMP(5);
             }
-            if (p < CB_YR * CB_TW) *reinterpret_cast<uint4*>(yband + pb1[m] + CB_PIX + 64 * wn) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+            barrier_lds();                                               // Y
+            CB_STAMP(6);
         }
-        CB_STAMP(2);
-        __syncthreads();                                                // barrier A: y1 is complete; everyone has left the other x buffer
-        if (v2 < nvirt) fetch(n2, ty2, cur ^ 1);                        // lands behind conv2
-        CB_STAMP(3);
-
-        // ---- conv2 on the y1 band ----
-        {
-            unsigned pb2w[8];
-#pragma unroll
-            for (int m = 0; m < 7; ++m) pb2w[m] = pb2[m];
-            pb2w[7] = pb2[6];
-            if (wm == 0) compute(yband, pb2w, wf2, std::integral_constant<int, 7>{});
-            else compute(yband, pb2w, wf2, std::integral_constant<int, CB_M2 - 7>{});
-        }
-        CB_STAMP(4);
-        __syncthreads();                                                // barrier B: everyone is done with y1; the next x band has landed
-        CB_STAMP(5);
-
-        // ---- epilogue 2: + bias + the block's input (x band, centre pixel) , ReLU, store ----
-#pragma unroll
-        for (int m = 0; m < 7; ++m) {
-            const int q = 16 * (7 * wm + m) + li;
-            const int qy = q / CB_TW, qx = q - qy * CB_TW, yy = y0 + qy;
-            if ((wm == 1 && m >= CB_M2 - 7) || q >= CB_TH * CB_TW || yy >= a.H || qx >= a.W) continue;
-            const uint4 rr = *reinterpret_cast<const uint4*>(xb + ((qy + 2) * CB_BW + qx + 1) * CB_PIX + 64 * wn + 16 * g);
-            const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
-            unsigned ow[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float v0 = acc[m][k >> 1][2 * (k & 1)] + bia2[2 * k] + __uint_as_float(rw[k] << 16);
-                const float v1 = acc[m][k >> 1][2 * (k & 1) + 1] + bia2[2 * k + 1] + __uint_as_float(rw[k] & 0xffff0000u);
-                ow[k] = (unsigned)f32_to_bf16(fmaxf(v0, 0.f)) | ((unsigned)f32_to_bf16(fmaxf(v1, 0.f)) << 16);
-            }
-            *reinterpret_cast<uint4*>(a.y + (((size_t)n * a.H + yy) * a.W + qx) * CB_C + 32 * wn + 8 * g) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-        }
-        CB_STAMP(6);
 #ifdef CB_DIAG
         ++nt_done;
 #endif
-        v = v2; n = n2; ty = ty2; cur ^= 1;
+        // advance: the consumers take over the producers' tile, the producers move on
+        vC = vP; nC = nP; tyC = tyP;
+        vP = vN; nP = nN; tyP = tyN;
     }
 }
 
@@ -265,7 +333,7 @@ static int conv3x3_block64_launch(const void* x, const void* w1, const float* b1
         if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && c > 0) cus = c;
     }
     const int grid = (int)(nvirt < cus ? nvirt : cus);                  // persistent: one workgroup per CU (it owns the CU's LDS), weights loaded once each
-    hipLaunchKernelGGL(conv3x3_block64_kernel, dim3(grid), dim3(256), CB_LDS, st, a);
+    hipLaunchKernelGGL(conv3x3_block64_kernel, dim3(grid), dim3(512), CB_LDS, st, a);
     return 0;
 }
 
