@@ -429,6 +429,7 @@ def main():
     ap.add_argument("--frames", type=int, default=32)
     ap.add_argument("--size", type=int, default=112)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-user-path-legs", action="store_true", help="skip the `pipeline` (host-fed forward) and `step_mode` legs (profiling runs)")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = BASELINE configs[1] (the headline metric); train = configs[3]: DDP training step")
     ap.add_argument("--kernel-iters", type=int, default=50)
@@ -666,12 +667,21 @@ def main():
         # over; a quarter of the float32 bytes) copied host-to-device on a side stream by gdkvm_amd.pipeline.DevicePrefetcher (eval.py's
         # loader path), cast + scaled to bf16 on the GPU, copied into the graph's input buffer, one replay.  H2D + cast + copy are INSIDE
         # this figure; it never enters `value`.
-        if world == 1:
+        if world == 1 and not args.no_user_path_legs:
             try:
                 from gdkvm_amd.pipeline import DevicePrefetcher
                 nb, warm_p, k_p = 6, 6, 30
                 host = [((clips(5000 + i, B) * 255).to(torch.uint8).pin_memory(), torch.zeros(16, dtype=torch.uint8).pin_memory()) for i in range(nb)]
                 feed = (host[i % nb] for i in range(warm_p + k_p))
+                # the link alone: the same pinned batches copied host-to-device with nothing else running (what bounds the loop below when
+                # the forward is faster than the copy)
+                dst_ = torch.empty_like(host[0][0], device=dev)
+                torch.cuda.synchronize(); tl0 = time.perf_counter()
+                for i in range(2 * nb):
+                    dst_.copy_(host[i % nb][0], non_blocking=True)
+                torch.cuda.synchronize()
+                h2d_alone = 2 * nb * host[0][0].numel() / (time.perf_counter() - tl0) / 1e9
+                del dst_
                 gp = gsegs[0] if launch.startswith("one hipGraph") else None
                 pre = DevicePrefetcher(feed, dev, slots=3, frames_dtype=torch.bfloat16)
                 t_p, n_p = None, 0
@@ -687,6 +697,7 @@ def main():
                 dt_p = time.perf_counter() - t_p
                 out["pipeline"] = {"frames_per_s": round(B * T * k_p / dt_p, 1), "ms_per_step": round(1e3 * dt_p / k_p, 3), "steps": k_p,
                                    "h2d_GBps": round((pre.h2d_bytes - b0) / dt_p / 1e9, 2),
+                                   "h2d_alone_GBps": round(h2d_alone, 2),      # (pinned -> device copies of the same batches, nothing else running)
                                    "what": f"configs[1] forward fed from {nb} pinned host batches of uint8 frames ({host[0][0].numel() / 1e6:.1f} MB each): "
                                            "host-to-device copy on a side stream (DevicePrefetcher, 3 slots), uint8 -> bf16 / 255 on the GPU, copy into the "
                                            "graph's input buffer, one hipGraph replay -- all inside the timed loop",

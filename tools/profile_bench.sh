@@ -6,7 +6,7 @@ TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_${TAG}_bench
 rm -rf "$OUT" && mkdir -p "$OUT"
-CMD="python3 bench.py --steps 20 --warmup 5 --no-other-configs --no-cpu-baseline --train-steps 0 --kernel-iters 3"
+CMD="python3 bench.py --steps 20 --warmup 5 --no-other-configs --no-cpu-baseline --no-user-path-legs --train-steps 0 --kernel-iters 3"
 rocprofv3 --kernel-trace --output-format csv -d "$OUT" -o t -- $CMD > "$OUT/trace.log" 2>&1
 cd profiles
 python3 steady_state.py "$(ls ../$OUT/*kernel_trace.csv | head -1)" ../gpurun_out/${TAG}_bench_cfg2_steady_state.csv "rocprofv3 --kernel-trace -- $CMD" 10 upsample_argmax_dice - ${GDKVM_SEGMENT_STREAMS:-2}
