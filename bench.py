@@ -729,6 +729,18 @@ def main():
                                     "masks_differ_from_scan_mode": bool((m_e != ref_mask).any().item()),
                                     "what": "GDKVMConfig(mask_feedback=True): read -> KPFF -> decoder -> mask -> embed -> write per frame (every clip's frame t "
                                             f"together), {T}-frame loop captured as one hipGraph ({g_fb.streams} streams inside); encoder and projections once for all frames"}
+                # the loop is bound by its ~13 dependent graph nodes per frame, each a small launch: frames per launch -- the clip batch --
+                # is what helps (profiles/r06_n_step_mode_streams.txt); the same graph at 64 clips, informational
+                try:
+                    f64 = torch.cat([batches[i % n_rot] for i in range(4)], 0)[:64]
+                    g64 = mfb.graphed_segment(f64)
+                    for _ in range(3):
+                        g64(f64)
+                    ms64, _ = time_events(lambda: g64(f64), 5)
+                    out["step_mode"]["at_64_clips"] = {"frames_per_s": round(64 * T / (ms64 * 1e-3), 1), "ms_per_step": round(ms64, 3)}
+                    del g64, f64
+                except Exception as e:                          # noqa: BLE001
+                    out["step_mode"]["at_64_clips"] = {"error": f"{type(e).__name__}: {e}"[:200]}
                 del mfb, g_fb
             except Exception as e:                              # noqa: BLE001 -- informational leg
                 out["step_mode"] = {"error": f"{type(e).__name__}: {e}"[:300]}

@@ -400,3 +400,30 @@ def test_dice_parity_on_a_fitted_model(hip):
     assert d_label32 >= 0.8 and d_label16 >= 0.8                  # it learned the cavity
     assert agree_ref >= 0.9995                                    # GPU module == CPU reference module, same weights (measured: 1.00000)
     assert d_16_vs_32 >= 0.998                                    # bf16 inference build against the fp32 module (measured: 0.9997 - 0.9999)
+
+
+def test_device_prefetcher_delivers_every_batch_in_order(hip):
+    """gdkvm_amd.pipeline.DevicePrefetcher (what train.py / eval.py iterate): batches arrive on the device in order and intact -- from plain
+    host tensors (staged through the prefetcher's own pinned buffers) and from already pinned ones (copied straight from them), with two and
+    three slots, uint8 frames scaled to [0, 1] in the requested dtype, integer targets cast; more batches than slots, a short last batch."""
+    from gdkvm_amd.pipeline import DevicePrefetcher
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    batches = [(torch.randint(0, 256, (3 if i < 6 else 2, 4, 3, 16, 16), generator=g, dtype=torch.uint8),
+                torch.randint(0, 4, (3 if i < 6 else 2, 4, 16, 16), generator=g)) for i in range(7)]
+    for pinned in (False, True):
+        for slots in (2, 3):
+            src = [(f.pin_memory(), t.pin_memory()) for f, t in batches] if pinned else batches
+            pre = DevicePrefetcher(iter(src), dev, slots=slots, frames_dtype=torch.bfloat16, target_dtype=torch.uint8)
+            got = []
+            for f, t in pre:
+                assert f.is_cuda and f.dtype == torch.bfloat16 and t.dtype == torch.uint8
+                got.append((f.float().cpu().clone(), t.cpu().clone()))      # (valid until the next next(): copied here)
+                torch.cuda.current_stream().synchronize()
+            assert len(got) == len(batches) and pre.h2d_bytes == sum(f.numel() + 8 * t.numel() for f, t in batches)
+            for (f, t), (f0, t0) in zip(got, batches):
+                assert torch.equal(t, t0.to(torch.uint8))
+                assert torch.equal(f, (f0.to(torch.bfloat16) * (1.0 / 255.0)).float())
+    float_batches = [(torch.rand(2, 2, 3, 8, 8, generator=g), torch.zeros(2, 2, 8, 8, dtype=torch.long)) for _ in range(3)]
+    out = [f.clone() for f, _ in DevicePrefetcher(float_batches, dev)]
+    assert all(o.dtype == torch.float32 and torch.equal(o.cpu(), f) for o, (f, _) in zip(out, float_batches))
