@@ -46,3 +46,17 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f"{fn} imports oracle"
                 assert "gdkvm_oracle" not in txt, f"{fn} references the oracle"
+
+
+def test_host_side_of_the_library_is_clean_under_sanitizers():
+    """The HOST halves of the HIP library -- workspace carving (csrc/gdr_ws.hpp), the segmented scan's and the normalizer's own carves, argument
+    checks and error reporting of gdr_segmented / gdr_normalizer / gdr_step / gdkvm_api -- built with -fsanitize=address,undefined on the CPU
+    (tests/host_san/: device code compiled as usual and never run; the kernel-heavy entry points they call are stubbed) and driven with
+    workspaces malloc'ed at EXACTLY the size the library asks for, every carved region written end to end: a carve that outgrows its own size
+    request is a heap-buffer-overflow report, not a silent overwrite on the GPU box.  Also pins the error codes of ~25 bad-argument calls."""
+    import subprocess
+    here = os.path.join(ROOT, "tests", "host_san")
+    subprocess.check_call(["bash", os.path.join(here, "build.sh")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(here, "_build", "host_san")], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1"))
+    assert out.returncode == 0 and "host_san: ok" in out.stdout, out.stdout + out.stderr
