@@ -21,8 +21,9 @@ class DevicePrefetcher:
     and copied host-to-device on a side stream while batch i computes; the consumer's stream waits only for its own batch's copy event,
     and a slot's device buffers are not overwritten before the consumer of their previous batch has been passed (an event recorded on the
     consumer's stream when it asks for the next batch).  uint8 frames are cast to `frames_dtype` and scaled to [0, 1] on the device;
-    float frames are cast; targets keep their dtype unless `target_dtype` is given.  Yields (frames, target) device tensors that stay
-    valid until the NEXT next()."""
+    float frames are cast; targets keep their dtype unless `target_dtype` is given -- the casts run on the COPY stream, right behind the
+    batch's transfer, into per-slot buffers: the consumer's stream receives finished tensors and spends nothing on them.  Yields
+    (frames, target) device tensors that stay valid until the NEXT next()."""
 
     def __init__(self, loader: Iterable, device: torch.device, slots: int = 2, frames_dtype: Optional[torch.dtype] = None,
                  target_dtype: Optional[torch.dtype] = None):
@@ -36,6 +37,7 @@ class DevicePrefetcher:
         self._dev = [None] * slots
         self._free = [None] * slots             # event: the consumer is done with this slot's device buffers
         self._copied = [None] * slots           # event: the slot's last host-to-device copy
+        self._conv = [None] * slots             # per slot: the cast frames / target (written on the copy stream)
         self.h2d_bytes = 0
 
     def _stage(self, slot: int, batch) -> Tuple[torch.Tensor, torch.Tensor, torch.cuda.Event]:
@@ -62,26 +64,41 @@ class DevicePrefetcher:
                 self.stream.wait_event(self._free[slot])
             dev[0].copy_(pin[0], non_blocking=True)
             dev[1].copy_(pin[1], non_blocking=True)
+            copied = torch.cuda.Event()
+            copied.record(self.stream)            # (the pinned buffers are free again once this has passed)
+            out_f, out_t = self._convert(slot, dev[0], dev[1])
             ev = torch.cuda.Event()
             ev.record(self.stream)
-        self._copied[slot] = ev
+        self._copied[slot] = copied
         self.h2d_bytes += frames.numel() * frames.element_size() + target.numel() * target.element_size()
-        return dev[0], dev[1], ev
+        return out_f, out_t, ev
 
-    def _finish(self, frames: torch.Tensor, target: torch.Tensor):
-        if frames.dtype == torch.uint8:
-            frames = frames.to(self.frames_dtype or torch.float32).mul_(1.0 / 255.0)
-        elif self.frames_dtype is not None and frames.dtype != self.frames_dtype:
-            frames = frames.to(self.frames_dtype)
-        if self.target_dtype is not None and target.dtype != self.target_dtype:
-            target = target.to(self.target_dtype)
-        return frames, target
+    def _convert(self, slot: int, frames: torch.Tensor, target: torch.Tensor):
+        """The batch in the dtypes the consumer wants, in this slot's own buffers (called under the copy stream)."""
+        fdt = (self.frames_dtype or torch.float32) if frames.dtype == torch.uint8 else (self.frames_dtype or frames.dtype)
+        tdt = self.target_dtype or target.dtype
+        if fdt == frames.dtype and tdt == target.dtype:
+            return frames, target
+        conv = self._conv[slot]
+        if conv is None or conv[0].shape != frames.shape or conv[0].dtype != fdt or conv[1].shape != target.shape or conv[1].dtype != tdt:
+            conv = self._conv[slot] = (torch.empty(frames.shape, dtype=fdt, device=self.device) if fdt != frames.dtype else None,
+                                       torch.empty(target.shape, dtype=tdt, device=self.device) if tdt != target.dtype else None)
+        out_f, out_t = frames, target
+        if conv[0] is not None:
+            conv[0].copy_(frames)                 # (the cast)
+            if frames.dtype == torch.uint8:
+                conv[0].mul_(1.0 / 255.0)
+            out_f = conv[0]
+        if conv[1] is not None:
+            conv[1].copy_(target)
+            out_t = conv[1]
+        return out_f, out_t
 
     def _hand_out(self, queue):
         s, f, t, ev = queue.pop(0)
         cur = torch.cuda.current_stream(self.device)
-        cur.wait_event(ev)                       # the consumer's stream waits for ITS batch's copy only
-        yield self._finish(f, t)
+        cur.wait_event(ev)                       # the consumer's stream waits for ITS batch's copy (and casts) only
+        yield f, t
         done = torch.cuda.Event()                # (the consumer came back for the next batch: everything it launched on slot s is in its stream)
         done.record(torch.cuda.current_stream(self.device))
         self._free[s] = done
