@@ -80,7 +80,8 @@ class DevicePrefetcher:
         if fdt == frames.dtype and tdt == target.dtype:
             return frames, target
         conv = self._conv[slot]
-        if conv is None or conv[0].shape != frames.shape or conv[0].dtype != fdt or conv[1].shape != target.shape or conv[1].dtype != tdt:
+        fits = lambda buf, src, dt: (buf is None) == (dt == src.dtype) and (buf is None or (buf.shape == src.shape and buf.dtype == dt))
+        if conv is None or not fits(conv[0], frames, fdt) or not fits(conv[1], target, tdt):
             conv = self._conv[slot] = (torch.empty(frames.shape, dtype=fdt, device=self.device) if fdt != frames.dtype else None,
                                        torch.empty(target.shape, dtype=tdt, device=self.device) if tdt != target.dtype else None)
         out_f, out_t = frames, target

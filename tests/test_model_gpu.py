@@ -424,6 +424,29 @@ def test_device_prefetcher_delivers_every_batch_in_order(hip):
             for (f, t), (f0, t0) in zip(got, batches):
                 assert torch.equal(t, t0.to(torch.uint8))
                 assert torch.equal(f, (f0.to(torch.bfloat16) * (1.0 / 255.0)).float())
+    # only the frames need a cast (the target already has its dtype), over more batches than slots
+    mixed = [(torch.randint(0, 256, (2, 2, 3, 8, 8), generator=g, dtype=torch.uint8), torch.randint(0, 2, (2, 2, 8, 8), generator=g, dtype=torch.uint8)) for _ in range(5)]
+    seen = [(f.float().cpu().clone(), t.cpu().clone()) for f, t in DevicePrefetcher(mixed, dev, slots=2, frames_dtype=torch.bfloat16)]
+    assert all(torch.equal(f, (f0.to(torch.bfloat16) * (1.0 / 255.0)).float()) and torch.equal(t, t0) for (f, t), (f0, t0) in zip(seen, mixed))
     float_batches = [(torch.rand(2, 2, 3, 8, 8, generator=g), torch.zeros(2, 2, 8, 8, dtype=torch.long)) for _ in range(3)]
     out = [f.clone() for f, _ in DevicePrefetcher(float_batches, dev)]
     assert all(o.dtype == torch.float32 and torch.equal(o.cpu(), f) for o, (f, _) in zip(out, float_batches))
+
+
+def test_graphed_segments_sharing_one_memory_pool(hip):
+    """Several GraphedSegment captures over DIFFERENT input buffers in ONE memory pool (bench.py rotates eight input batches this way: the
+    activations of every replay live at the same addresses, nothing is copied in the timed region): replayed in turn, each graph returns
+    the masks of ITS batch, bit-equal to the eager forward; one and two streams inside."""
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    torch.manual_seed(13)
+    model = GDKVM(GDKVMConfig()).cuda().eval().fuse_for_inference().to(torch.bfloat16).to(memory_format=torch.channels_last)
+    batches = [torch.rand(8, 3, 3, 112, 112, device="cuda").bfloat16() for _ in range(3)]
+    want = [model.segment(b)[0].clone() for b in batches]
+    assert not torch.equal(want[0], want[1])
+    for streams in (1, 2):
+        graphs = []
+        for b in batches:
+            graphs.append(model.graphed_segment(b, streams=streams, pool=None if not graphs else graphs[0].graph.pool()))
+        for rnd in range(2):
+            for i in (2, 0, 1):
+                assert torch.equal(graphs[i](batches[i])[0], want[i]), (streams, rnd, i)
