@@ -682,16 +682,16 @@ def main():
                 torch.cuda.synchronize()
                 h2d_alone = 2 * nb * host[0][0].numel() / (time.perf_counter() - tl0) / 1e9
                 del dst_
-                gp = gsegs[0] if launch.startswith("one hipGraph") else None
+                # eval.py's path: SegmentRunner captures one graph over each of the prefetcher's per-slot buffers (one memory pool), so a
+                # batch is copy (side stream) -> cast (side stream) -> replay, with nothing copied on the compute stream
+                from gdkvm_amd.pipeline import SegmentRunner
+                runner = SegmentRunner(model, graph=launch.startswith("one hipGraph"), min_repeats=1)
                 pre = DevicePrefetcher(feed, dev, slots=3, frames_dtype=torch.bfloat16)
                 t_p, n_p = None, 0
                 for f_, _t in pre:
                     if n_p == warm_p:
                         torch.cuda.synchronize(); t_p = time.perf_counter(); b0 = pre.h2d_bytes
-                    if gp is not None:
-                        gp(f_)
-                    else:
-                        model.segment(f_)
+                    runner(f_)
                     n_p += 1
                 torch.cuda.synchronize()
                 dt_p = time.perf_counter() - t_p
@@ -699,10 +699,11 @@ def main():
                                    "h2d_GBps": round((pre.h2d_bytes - b0) / dt_p / 1e9, 2),
                                    "h2d_alone_GBps": round(h2d_alone, 2),      # (pinned -> device copies of the same batches, nothing else running)
                                    "what": f"configs[1] forward fed from {nb} pinned host batches of uint8 frames ({host[0][0].numel() / 1e6:.1f} MB each): "
-                                           "host-to-device copy on a side stream (DevicePrefetcher, 3 slots), uint8 -> bf16 / 255 on the GPU, copy into the "
-                                           "graph's input buffer, one hipGraph replay -- all inside the timed loop",
+                                           "host-to-device copy and uint8 -> bf16 / 255 on a side stream (DevicePrefetcher, 3 slots), one hipGraph replay over "
+                                           "the slot's buffer (SegmentRunner: eval.py's path; " + f"{runner.captures} captures, {runner.replays} replays, "
+                                           f"{runner.eager_calls} eager calls) -- all inside the timed loop",
                                    "vs_resident_inputs": round((B * T * k_p / dt_p) / value, 3)}
-                del host, pre
+                del host, pre, runner
             except Exception as e:                              # noqa: BLE001 -- informational leg
                 out["pipeline"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             # ---- the per-frame STEP mode (GDKVMConfig(mask_feedback=True)): the predicted mask of frame t feeds the

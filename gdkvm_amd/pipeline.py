@@ -118,29 +118,42 @@ class DevicePrefetcher:
 
 
 class SegmentRunner:
-    """model.segment(frames, target) for a stream of batches: ONE captured GraphedSegment per batch shape (the full batches of a split),
-    an eager call -- said once, on stderr -- for shapes that occur once (the last, short batch) or when a capture fails."""
+    """model.segment(frames, target) for a stream of batches: captured GraphedSegments per batch shape (the full batches of a split), an eager
+    call -- said on stderr when a capture fails -- for shapes seen fewer than `min_repeats` times (the last, short batch).
+    zero_copy (default): a graph is captured OVER the tensors it is called with, one per distinct input buffer, all graphs of a shape in one
+    memory pool -- DevicePrefetcher hands out the same few per-slot buffers again and again, so after `slots` captures every batch is a bare
+    replay with no copy into an input buffer (38.5 MB per batch at the EchoNet shape).  Tensors from anywhere else work too (each new
+    address costs a capture, up to `max_graphs` per shape; beyond that the batch is copied into the first graph's buffers)."""
 
-    def __init__(self, model, graph: bool = True, min_repeats: int = 2):
-        self.model, self.graph, self.min_repeats = model, graph, min_repeats
+    def __init__(self, model, graph: bool = True, min_repeats: int = 2, zero_copy: bool = True, max_graphs: int = 4):
+        self.model, self.graph, self.min_repeats, self.zero_copy, self.max_graphs = model, graph, min_repeats, zero_copy, max_graphs
         self._graphs, self._seen = {}, {}
-        self.replays = self.eager_calls = 0
-        self._told = False
+        self.replays = self.eager_calls = self.captures = 0
 
     def __call__(self, frames: torch.Tensor, target: Optional[torch.Tensor] = None):
-        key = (tuple(frames.shape), frames.dtype, None if target is None else target.dtype)
-        self._seen[key] = self._seen.get(key, 0) + 1
-        g = self._graphs.get(key)
-        if g is None and self.graph and self._seen[key] >= self.min_repeats:
-            try:
-                from .model import GraphedSegment
-                g = GraphedSegment(self.model, frames.clone(), None if target is None else target.clone())
-            except Exception as e:              # noqa: BLE001 -- a failed capture must not end an evaluation: say so, run eagerly
-                print(f"[gdkvm] forward not captured for {key[0]} ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
-                torch.cuda.synchronize()
-                g = False
-            self._graphs[key] = g
-        if g:
+        shape_key = (tuple(frames.shape), frames.dtype, None if target is None else target.dtype)
+        self._seen[shape_key] = self._seen.get(shape_key, 0) + 1
+        per_shape = self._graphs.setdefault(shape_key, {})
+        g = None
+        if self.graph and self._seen[shape_key] >= self.min_repeats and per_shape.get("failed") is None:
+            ptr_key = (frames.data_ptr(), None if target is None else target.data_ptr()) if self.zero_copy else "copy"
+            g = per_shape.get(ptr_key)
+            if g is None and len(per_shape) < self.max_graphs:
+                try:
+                    from .model import GraphedSegment
+                    first = next(iter(per_shape.values()), None)
+                    own = (frames, target) if self.zero_copy else (frames.clone(), None if target is None else target.clone())
+                    g = GraphedSegment(self.model, own[0], own[1], pool=None if first is None else first.graph.pool())
+                    per_shape[ptr_key] = g
+                    self.captures += 1
+                except Exception as e:          # noqa: BLE001 -- a failed capture must not end an evaluation: say so, run eagerly
+                    print(f"[gdkvm] forward not captured for {shape_key[0]} ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
+                    torch.cuda.synchronize()
+                    per_shape["failed"] = True
+                    g = None
+            elif g is None:
+                g = next(v for k, v in per_shape.items() if k != "failed")     # (more buffers than graphs: copy into the first graph's)
+        if g is not None:
             self.replays += 1
             out = g(frames, target)
             return out[0].clone(), (None if out[1] is None else out[1].clone())
