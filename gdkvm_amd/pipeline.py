@@ -23,13 +23,17 @@ class DevicePrefetcher:
     consumer's stream when it asks for the next batch).  uint8 frames are cast to `frames_dtype` and scaled to [0, 1] on the device;
     float frames are cast; targets keep their dtype unless `target_dtype` is given -- the casts run on the COPY stream, right behind the
     batch's transfer, into per-slot buffers: the consumer's stream receives finished tensors and spends nothing on them.  Yields
-    (frames, target) device tensors that stay valid until the NEXT next()."""
+    (frames, target) device tensors that stay valid until the NEXT next().
+    threaded (default): the loader is iterated and the batches are staged by a WORKER THREAD (the host side of a batch -- fetching it from the
+    loader, the pinned copy, enqueueing transfer and casts -- is ~0.5 ms at the EchoNet shape, and launching a captured forward is about as much:
+    one after the other on one thread they bound the loop at ~1.1 ms where the GPU needs 0.9; tools/pipeline_probe.py).  A slot goes back to
+    the worker when the consumer asks for the next batch; an exception in the loader or the staging is re-raised in the consumer."""
 
     def __init__(self, loader: Iterable, device: torch.device, slots: int = 2, frames_dtype: Optional[torch.dtype] = None,
-                 target_dtype: Optional[torch.dtype] = None):
+                 target_dtype: Optional[torch.dtype] = None, threaded: bool = True):
         if slots < 2:
             raise ValueError("DevicePrefetcher needs at least two slots")
-        self.loader, self.device, self.slots = loader, device, slots
+        self.loader, self.device, self.slots, self.threaded = loader, device, slots, threaded
         self.frames_dtype, self.target_dtype = frames_dtype, target_dtype
         self.stream = torch.cuda.Stream(device=device)
         self._pinned = [None] * slots           # per slot: the page-locked (frames, target) its copy in flight reads (kept alive)
@@ -105,6 +109,9 @@ class DevicePrefetcher:
         self._free[s] = done
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+        if self.threaded:
+            yield from self._iter_threaded()
+            return
         queue = []                               # staged batches, oldest first: (slot, frames, target, copy event)
         slot = 0
         for batch in self.loader:
@@ -115,6 +122,50 @@ class DevicePrefetcher:
             yield from self._hand_out(queue)
         while queue:
             yield from self._hand_out(queue)
+
+    def _iter_threaded(self):
+        import queue as _q
+        import threading
+        ready: "_q.Queue" = _q.Queue()           # staged batches (slot, frames, target, event) | an exception | None at the end
+        free = threading.Semaphore(self.slots)   # slots the worker may stage into (given back when the consumer moves on)
+        stop = threading.Event()
+        dev = self.device
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                slot = 0
+                for batch in self.loader:
+                    while not free.acquire(timeout=0.1):
+                        if stop.is_set():
+                            return
+                    if stop.is_set():
+                        return
+                    ready.put((slot,) + self._stage(slot, batch))
+                    slot = (slot + 1) % self.slots
+                ready.put(None)
+            except BaseException as e:           # noqa: BLE001 -- handed to the consumer
+                ready.put(e)
+
+        worker = threading.Thread(target=work, name="gdkvm-prefetch", daemon=True)
+        worker.start()
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                s, f, t, ev = item
+                torch.cuda.current_stream(dev).wait_event(ev)
+                yield f, t
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(dev))
+                self._free[s] = done             # (written before the slot is released: the worker reads it after acquiring)
+                free.release()
+        finally:
+            stop.set()
+            worker.join(timeout=5.0)
 
 
 class SegmentRunner:

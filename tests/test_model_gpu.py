@@ -411,10 +411,10 @@ def test_device_prefetcher_delivers_every_batch_in_order(hip):
     g = torch.Generator().manual_seed(3)
     batches = [(torch.randint(0, 256, (3 if i < 6 else 2, 4, 3, 16, 16), generator=g, dtype=torch.uint8),
                 torch.randint(0, 4, (3 if i < 6 else 2, 4, 16, 16), generator=g)) for i in range(7)]
-    for pinned in (False, True):
+    for pinned, threaded in ((False, True), (True, True), (False, False), (True, False)):
         for slots in (2, 3):
             src = [(f.pin_memory(), t.pin_memory()) for f, t in batches] if pinned else batches
-            pre = DevicePrefetcher(iter(src), dev, slots=slots, frames_dtype=torch.bfloat16, target_dtype=torch.uint8)
+            pre = DevicePrefetcher(iter(src), dev, slots=slots, frames_dtype=torch.bfloat16, target_dtype=torch.uint8, threaded=threaded)
             got = []
             for f, t in pre:
                 assert f.is_cuda and f.dtype == torch.bfloat16 and t.dtype == torch.uint8
@@ -429,6 +429,16 @@ def test_device_prefetcher_delivers_every_batch_in_order(hip):
     seen = [(f.float().cpu().clone(), t.cpu().clone()) for f, t in DevicePrefetcher(mixed, dev, slots=2, frames_dtype=torch.bfloat16)]
     assert all(torch.equal(f, (f0.to(torch.bfloat16) * (1.0 / 255.0)).float()) and torch.equal(t, t0) for (f, t), (f0, t0) in zip(seen, mixed))
     float_batches = [(torch.rand(2, 2, 3, 8, 8, generator=g), torch.zeros(2, 2, 8, 8, dtype=torch.long)) for _ in range(3)]
+    def broken():                                             # an exception inside the loader reaches the consumer (threaded: from the worker)
+        yield float_batches[0]
+        raise ValueError("loader broke")
+    for threaded in (True, False):
+        with pytest.raises(ValueError, match="loader broke"):
+            for _ in DevicePrefetcher(broken(), dev, threaded=threaded):
+                pass
+    early = iter(DevicePrefetcher(float_batches, dev))       # a consumer that stops early leaves no worker behind
+    next(early)
+    early.close()
     out = [f.clone() for f, _ in DevicePrefetcher(float_batches, dev)]
     assert all(o.dtype == torch.float32 and torch.equal(o.cpu(), f) for o, (f, _) in zip(out, float_batches))
 
