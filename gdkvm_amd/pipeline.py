@@ -129,11 +129,14 @@ class DevicePrefetcher:
         ready: "_q.Queue" = _q.Queue()           # staged batches (slot, frames, target, event) | an exception | None at the end
         free = threading.Semaphore(self.slots)   # slots the worker may stage into (given back when the consumer moves on)
         stop = threading.Event()
-        dev = self.device
+        dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
 
         def work():
             try:
-                torch.cuda.set_device(dev)
+                if dev.index is not None:
+                    torch.cuda.set_device(dev)     # (the current device is per thread)
                 slot = 0
                 for batch in self.loader:
                     while not free.acquire(timeout=0.1):
