@@ -24,13 +24,14 @@ class DevicePrefetcher:
     float frames are cast; targets keep their dtype unless `target_dtype` is given -- the casts run on the COPY stream, right behind the
     batch's transfer, into per-slot buffers: the consumer's stream receives finished tensors and spends nothing on them.  Yields
     (frames, target) device tensors that stay valid until the NEXT next().
-    threaded (default): the loader is iterated and the batches are staged by a WORKER THREAD (the host side of a batch -- fetching it from the
-    loader, the pinned copy, enqueueing transfer and casts -- is ~0.5 ms at the EchoNet shape, and launching a captured forward is about as much:
-    one after the other on one thread they bound the loop at ~1.1 ms where the GPU needs 0.9; tools/pipeline_probe.py).  A slot goes back to
-    the worker when the consumer asks for the next batch; an exception in the loader or the staging is re-raised in the consumer."""
+    threaded=True: the loader is iterated and the batches are staged by a WORKER THREAD (a slot goes back to the worker when the consumer asks
+    for the next batch; an exception in the loader or the staging is re-raised in the consumer).  Off by default: measured at the EchoNet
+    shape it is SLOWER (1.23 against 1.05 ms per batch, profiles/r06_v_pipeline_probe.txt) -- the loop is not bound by host work (a graph
+    launch is 0.17 ms, the staging calls ~0.1 ms) but by the host-to-device copies themselves, which take 2-3x their stand-alone time
+    beside the forward's kernels; a second thread only adds hand-offs.  Useful when the LOADER is slow (decoding in the main process)."""
 
     def __init__(self, loader: Iterable, device: torch.device, slots: int = 2, frames_dtype: Optional[torch.dtype] = None,
-                 target_dtype: Optional[torch.dtype] = None, threaded: bool = True):
+                 target_dtype: Optional[torch.dtype] = None, threaded: bool = False):
         if slots < 2:
             raise ValueError("DevicePrefetcher needs at least two slots")
         self.loader, self.device, self.slots, self.threaded = loader, device, slots, threaded

@@ -436,7 +436,7 @@ def test_device_prefetcher_delivers_every_batch_in_order(hip):
         with pytest.raises(ValueError, match="loader broke"):
             for _ in DevicePrefetcher(broken(), dev, threaded=threaded):
                 pass
-    early = iter(DevicePrefetcher(float_batches, dev))       # a consumer that stops early leaves no worker behind
+    early = iter(DevicePrefetcher(float_batches, dev, threaded=True))       # a consumer that stops early leaves no worker behind
     next(early)
     early.close()
     out = [f.clone() for f, _ in DevicePrefetcher(float_batches, dev)]
