@@ -220,3 +220,52 @@ def test_feedback_mode_in_the_fused_build_and_as_one_graph(hip):
     plain.load_state_dict(ref.state_dict())
     pm = plain.cuda().fuse_for_inference().to(torch.bfloat16).to(memory_format=torch.channels_last)
     assert not torch.equal(pm.segment(fr)[0], mk)
+
+
+def test_step_mode_without_feedback_weight_is_the_scan_mode(hip):
+    """A property that ties the two time loops together: with a ZERO mask-embedding weight nothing is fed back, and the per-frame step mode
+    (gdkvm_lkva_read + T = 1 writes, frame by frame) must compute what the scan mode (one gdkvm_scan_fwd over all frames) computes -- other
+    kernels, other operation order, same function: fp32 module logits within 1e-3, final state within 1e-4; at the full cfg2 shape in bf16
+    the masks agree on all but the pixels at bf16-size margins."""
+    import dataclasses
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    torch.manual_seed(17)
+    cfg = GDKVMConfig()
+    scan_m = GDKVM(cfg).eval()
+    with torch.no_grad():
+        scan_m.mask_embed.weight.zero_()
+    step_m = GDKVM(dataclasses.replace(cfg, mask_feedback=True)).eval()
+    step_m.load_state_dict(scan_m.state_dict())
+    frames = torch.rand(2, 6, 3, 112, 112, device="cuda")
+    scan_g, step_g = scan_m.cuda().to(memory_format=torch.channels_last), step_m.cuda().to(memory_format=torch.channels_last)
+    with torch.no_grad():
+        l0, s0 = scan_g(frames, return_state=True, _lowres=True)
+        l1, s1 = step_g(frames, return_state=True, _lowres=True)
+    assert (l0 - l1).abs().max().item() <= 1e-3 and (s0 - s1).abs().max().item() <= 1e-4
+    # full cfg2 shape, fused bf16 build, head balanced so that the masks are mixed
+    with torch.no_grad():
+        big = torch.rand(16, 32, 3, 112, 112, device="cuda")
+        lg = scan_g(big[:2, :8], _lowres=True)
+        gap = (lg[:, :, 0] - lg[:, :, 1]).median()
+        scan_g.decoder.head.bias[1] += gap
+        step_g.decoder.head.bias[1] += gap
+    fs = scan_g.fuse_for_inference().to(torch.bfloat16)
+    ft = step_g.fuse_for_inference().to(torch.bfloat16)
+    m0, m1 = fs.segment(big.bfloat16())[0], ft.segment(big.bfloat16())[0]
+    fg = (m0 != 0).float().mean().item()
+    assert 0.1 < fg < 0.9, fg
+    assert (m0 == m1).float().mean().item() >= 0.97
+
+
+def test_normalizer_chunk_identity_at_the_full_cfg2_shape(hip):
+    """gdkvm_scan_fwd_normalizer at BASELINE configs[1]'s size (16 clips x 32 frames x 49 tokens, Dv = 256, bf16): the clip as four calls of
+    eight frames with (S, z) carried is bit-identical to one call -- the size-independent property of the scan, inherited by the normaliser."""
+    q, k, v, a, b = _positive_inputs(16, 32, 49, 1, 64, 256, seed=11)
+    t = [_dev(x, torch.bfloat16) for x in (q, k, v)] + [_dev(a), _dev(b)]
+    R, S, Z = hip.scan_fwd_normalizer(*t, rule=2, flags=3)
+    parts, s, z = [], None, None
+    for c in range(0, 32, 8):
+        r, s, z = hip.scan_fwd_normalizer(*(x[:, c:c + 8].clone() for x in t), s, z, rule=2, flags=3)
+        parts.append(r)
+    assert torch.equal(torch.cat(parts, 1), R) and torch.equal(s, S) and torch.equal(z, Z)
+    assert torch.isfinite(R.float()).all() and float(Z.min()) > 0.0          # positive keys: z stays positive
