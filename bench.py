@@ -277,7 +277,10 @@ def run_train(args, world, rank, dev, steps, warmup):
     opt = torch.optim.AdamW(model.parameters(), lr=1.0e-4, fused=True, capturable=graphed)
     B, T, S = args.batch, args.frames, args.size
     g = torch.Generator(device="cpu").manual_seed(3000 + rank)
-    frames = torch.rand(B, T, 3, S, S, generator=g).to(dev)
+    # (frames on the 8-bit grid a video holds, scaled exactly as the loader path scales them on the GPU -- uint8 -> float32 x (1 / 255) --
+    # so that the host-fed steps below see the same values as the resident-input steps)
+    frames_u8 = (torch.rand(B, T, 3, S, S, generator=g) * 255).round().to(torch.uint8)
+    frames = frames_u8.to(dev).to(torch.float32).mul_(1.0 / 255.0)
     yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
     target = ((((yy - S / 2) / (S * 0.3)) ** 2 + ((xx - S / 2) / (S * 0.2)) ** 2) < 1).long().expand(B, T, S, S).contiguous().to(dev)
 
@@ -324,11 +327,12 @@ def run_train(args, world, rank, dev, steps, warmup):
     if world == 1 and os.environ.get("GDKVM_BENCH_TRAIN_PIPELINE", "1") != "0":
         try:
             from gdkvm_amd.pipeline import DevicePrefetcher
-            hostb = [(frames.cpu().pin_memory(), target.cpu().pin_memory()) for _ in range(2)]
+            # (what train.py's loader delivers since round 6: uint8 frames and uint8 labels, 26 MB per batch instead of 128 MB of fp32 / int64)
+            hostb = [(frames_u8.clone().pin_memory(), target.cpu().to(torch.uint8).pin_memory()) for _ in range(2)]
             step2 = (lambda f, t: gstep(f, t)) if graphed else (lambda f, t: train_step(ddp, opt, f, t, torch.bfloat16, sync))
             kp, wp = max(steps, 5), 2
             n_ = 0
-            for f_, t_ in DevicePrefetcher((hostb[i % 2] for i in range(wp + kp)), dev, slots=2):
+            for f_, t_ in DevicePrefetcher((hostb[i % 2] for i in range(wp + kp)), dev, slots=2, frames_dtype=torch.float32):
                 if n_ == wp:
                     torch.cuda.synchronize(); tp0 = time.perf_counter()
                 loss = step2(f_, t_)
@@ -357,8 +361,8 @@ def run_train(args, world, rank, dev, steps, warmup):
     return {"frames_per_s": round(world * B * T * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
             "warmup": warmup, "first_loss": round(float(first), 5), "final_loss": round(float(loss), 5),
             "optimizer_steps": n_opt,                    # (what final_loss is the loss of: set-up + capture warm-up + warmup + steps + pipeline steps)
-            # the step as train.py runs it: host batches (fp32 frames, int64 labels, pinned) prefetched on a side stream, copied into the graph's
-            # input buffers, one replay
+            # the step as train.py runs it: host batches (uint8 frames and labels, pinned) prefetched and scaled on a side stream, copied into
+            # the graph's input buffers, one replay
             "pipeline_ms_per_step": pipe_ms,
             "final_loss_eager_default_adamw": final_eager,
             "wrapped": type(ddp).__name__, "launch": "one hipGraph replay per step" if graphed else "eager (one launch call per kernel)",

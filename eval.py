@@ -47,7 +47,7 @@ def main(argv=None):
     model = model.to(memory_format=torch.channels_last)
 
     from gdkvm_amd.pipeline import DevicePrefetcher, SegmentRunner
-    ds = build_dataset(cfg, args.split)
+    ds = build_dataset(cfg, args.split, as_uint8=True)            # bytes across PCIe; cast and scaled on the GPU
     lo, hi = shard_range(len(ds), world, rank)
     counts = torch.zeros(cfg.data.num_classes, 3, dtype=torch.int64, device=dev)
     vis_left = cfg.eval_stage.num_vis if rank == 0 else 0

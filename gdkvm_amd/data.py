@@ -25,8 +25,8 @@ class SyntheticEchoClips(Dataset):
     """Speckled clips with a pulsating ellipse ("ventricle") and, for >2 classes, concentric wall / atrium regions.
     Deterministic per index, so ranks and epochs are reproducible."""
 
-    def __init__(self, n_clips: int, frames: int, size: int, num_classes: int = 2, seed: int = 0):
-        self.n, self.T, self.S, self.C, self.seed = n_clips, frames, size, num_classes, seed
+    def __init__(self, n_clips: int, frames: int, size: int, num_classes: int = 2, seed: int = 0, as_uint8: bool = False):
+        self.n, self.T, self.S, self.C, self.seed, self.as_uint8 = n_clips, frames, size, num_classes, seed, as_uint8
 
     def __len__(self):
         return self.n
@@ -54,6 +54,8 @@ class SyntheticEchoClips(Dataset):
             img = np.clip(tissue * speckle * 1.6, 0, 1).astype(np.float32)
             frames[t] = img[None]
             masks[t] = m
+        if self.as_uint8:                                         # bytes, as a video decoder would hand them over (as_uint8: see build_dataset)
+            return torch.from_numpy(np.round(frames * 255.0).astype(np.uint8)), torch.from_numpy(masks)
         return torch.from_numpy(frames), torch.from_numpy(masks.astype(np.int64))
 
 
@@ -118,11 +120,11 @@ class EchoNetNpz(Dataset):
     `traced` [2] frame indices and `masks` [2,H,W] uint8 (0 background, 1 left ventricle).  A sample is a T-frame clip around the two
     traced frames: frames [T,3,H,W] float in [0,1], labels [T,H,W] int64 with IGNORE_LABEL on every untraced frame."""
 
-    def __init__(self, root: str, split: str, frames: int):
+    def __init__(self, root: str, split: str, frames: int, as_uint8: bool = False):
         self.files = sorted(glob.glob(os.path.join(root, split, "*.npz")))
         if not self.files:
             raise FileNotFoundError(f"no converted EchoNet videos (.npz) under {os.path.join(root, split)}: run tools/convert_echonet.py")
-        self.T = frames
+        self.T, self.as_uint8 = frames, as_uint8
 
     def __len__(self):
         return len(self.files)
@@ -131,19 +133,20 @@ class EchoNetNpz(Dataset):
         z = np.load(self.files[i])
         video, traced, masks = z["video"], z["traced"], z["masks"]
         idx = clip_indices(video.shape[0], traced, self.T)
-        x = torch.from_numpy(video[idx].astype(np.float32) / 255.0).unsqueeze(1).expand(-1, 3, -1, -1).contiguous()
-        y = torch.full((self.T,) + video.shape[1:], IGNORE_LABEL, dtype=torch.int64)
+        clip = np.ascontiguousarray(video[idx])
+        x = torch.from_numpy(clip if self.as_uint8 else clip.astype(np.float32) / 255.0).unsqueeze(1).expand(-1, 3, -1, -1).contiguous()
+        y = torch.full((self.T,) + video.shape[1:], IGNORE_LABEL, dtype=torch.uint8 if self.as_uint8 else torch.int64)
         for f, m in zip(traced, masks):
-            y[int(np.nonzero(idx == int(f))[0][0])] = torch.from_numpy(m.astype(np.int64))
+            y[int(np.nonzero(idx == int(f))[0][0])] = torch.from_numpy(m.astype(np.uint8 if self.as_uint8 else np.int64))
         return x, y
 
 
 class NpzClips(Dataset):
-    def __init__(self, root: str, split: str, frames: int):
+    def __init__(self, root: str, split: str, frames: int, as_uint8: bool = False):
         self.files = sorted(glob.glob(os.path.join(root, split, "*.npz")))
         if not self.files:
             raise FileNotFoundError(f"no .npz clips under {os.path.join(root, split)}")
-        self.T = frames
+        self.T, self.as_uint8 = frames, as_uint8
 
     def __len__(self):
         return len(self.files)
@@ -153,6 +156,8 @@ class NpzClips(Dataset):
         fr, mk = z["frames"][: self.T], z["masks"][: self.T]
         if fr.ndim == 3:
             fr = np.repeat(fr[..., None], 3, -1)
+        if self.as_uint8:
+            return torch.from_numpy(np.ascontiguousarray(fr, dtype=np.uint8)).permute(0, 3, 1, 2).contiguous(), torch.from_numpy(mk.astype(np.uint8))
         x = torch.from_numpy(fr.astype(np.float32) / 255.0).permute(0, 3, 1, 2).contiguous()
         return x, torch.from_numpy(mk.astype(np.int64))
 
@@ -164,8 +169,9 @@ class CamusPng(Dataset):
 
     VIEWS = ("2CH", "4CH")
 
-    def __init__(self, root: str, split: str, frames: int, views=VIEWS):
+    def __init__(self, root: str, split: str, frames: int, views=VIEWS, as_uint8: bool = False):
         from PIL import Image                                     # noqa: F401  (fail early if Pillow is missing)
+        self.as_uint8 = as_uint8
         self.seqs = sorted(d for d in glob.glob(os.path.join(root, split, "*", "*")) if os.path.isdir(d) and os.path.basename(d) in views)
         if not self.seqs:
             raise FileNotFoundError(f"no <patient>/<{'|'.join(views)}> folders under {os.path.join(root, split)}")
@@ -186,22 +192,26 @@ class CamusPng(Dataset):
             np.minimum(np.arange(self.T), len(fr) - 1)
         xs, ys = [], []
         for j in pick:
-            img = np.asarray(Image.open(fr[j]).convert("RGB"), np.float32) / 255.0
+            img = np.asarray(Image.open(fr[j]).convert("RGB"), np.uint8) if self.as_uint8 else np.asarray(Image.open(fr[j]).convert("RGB"), np.float32) / 255.0
             mk = fr[j].replace("frame_", "mask_")
+            ldt = np.uint8 if self.as_uint8 else np.int64
             xs.append(img)
-            ys.append(np.asarray(Image.open(mk), np.int64) if os.path.exists(mk) else np.full(img.shape[:2], IGNORE_LABEL, np.int64))
+            ys.append(np.asarray(Image.open(mk), ldt) if os.path.exists(mk) else np.full(img.shape[:2], IGNORE_LABEL, ldt))
         return torch.from_numpy(np.stack(xs)).permute(0, 3, 1, 2).contiguous(), torch.from_numpy(np.stack(ys))
 
 
-def build_dataset(cfg, split: str = "train", n_synthetic: int = 256) -> Dataset:
+def build_dataset(cfg, split: str = "train", n_synthetic: int = 256, as_uint8: bool = False) -> Dataset:
+    """as_uint8: frames as uint8 [T,3,H,W] (0..255: what the files hold) and labels as uint8 (IGNORE_LABEL = 255 fits) instead of float32 in
+    [0,1] and int64 -- a fifth of the bytes per batch across PCIe (EchoNet shape, 16 clips: 26 MB instead of 128 MB); the entry points ask for
+    it and scale on the GPU (gdkvm_amd.pipeline.DevicePrefetcher).  The HIP loss and mask kernels take uint8 labels as they are."""
     d = cfg.data
     if d.kind == "synthetic" or not cfg.data_path:
         return SyntheticEchoClips(n_synthetic if split == "train" else max(8, n_synthetic // 8), d.frames, d.size,
-                                  d.num_classes, seed=cfg.seed + (0 if split == "train" else 7919))
+                                  d.num_classes, seed=cfg.seed + (0 if split == "train" else 7919), as_uint8=as_uint8)
     if d.kind == "npy_clips":
-        return NpzClips(cfg.data_path, split, d.frames)
+        return NpzClips(cfg.data_path, split, d.frames, as_uint8=as_uint8)
     if d.kind == "echonet_npz":
-        return EchoNetNpz(cfg.data_path, split, d.frames)
+        return EchoNetNpz(cfg.data_path, split, d.frames, as_uint8=as_uint8)
     if d.kind == "camus_png":
-        return CamusPng(cfg.data_path, split, d.frames)
+        return CamusPng(cfg.data_path, split, d.frames, as_uint8=as_uint8)
     raise ValueError(f"unknown data.kind {d.kind!r}")

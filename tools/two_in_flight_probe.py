@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Two forwards in flight: the cfg2 forward's captured graphs (two streams inside each) replayed alternately on TWO host streams, so that batch
+i + 1 starts while batch i is still running (separate memory pools), against the same graphs replayed on one stream.
+    python3 tools/two_in_flight_probe.py"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gdkvm_amd.model import GDKVM, GDKVMConfig, GraphedSegment  # noqa: E402
+
+
+def main():
+    torch.manual_seed(0)
+    dev = torch.device("cuda")
+    model = GDKVM(GDKVMConfig()).eval().fuse_for_inference().to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
+    frames = [torch.rand(16, 32, 3, 112, 112, device=dev).bfloat16() for _ in range(4)]
+    for inner in (2, 1):
+        gs = [GraphedSegment(model, f, streams=inner) for f in frames]          # (own pools)
+        ref = [g(f)[0].clone() for g, f in zip(gs, frames)]
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+
+        def run(two, n=80):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                if two:
+                    with torch.cuda.stream(sa if i % 2 == 0 else sb):
+                        gs[i % 4].graph.replay()
+                else:
+                    gs[i % 4].graph.replay()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t0) / n
+        for _ in range(2):
+            run(False, 20); run(True, 20)
+        print(f"streams inside each graph = {inner}: one forward at a time {run(False):.4f} ms/forward   two in flight {run(True):.4f} ms/forward", flush=True)
+        assert all(torch.equal(g.out[0], r) for g, r in zip(gs, ref))
+        del gs
+
+
+if __name__ == "__main__":
+    main()

@@ -52,7 +52,7 @@ def main(argv=None):
         model.load_state_dict(ck["model"]); opt_state = ck["optimizer"]; step0 = ck["step"]
         epoch0 = ck.get("epoch")
 
-    ds = build_dataset(cfg, "train")
+    ds = build_dataset(cfg, "train", as_uint8=True)               # bytes across PCIe (frames AND labels); scaled to [0, 1] on the GPU
     sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=True, seed=cfg.seed) if world > 1 else None
     dl = torch.utils.data.DataLoader(ds, batch_size=cfg.batch_size, sampler=sampler, shuffle=sampler is None, drop_last=True,
                                      num_workers=2, persistent_workers=True, pin_memory=True)
@@ -72,7 +72,7 @@ def main(argv=None):
         if sampler is not None:
             sampler.set_epoch(epoch)
         # host batches staged through pinned memory and copied on a side stream while the previous step computes (DevicePrefetcher)
-        for frames, target in DevicePrefetcher(dl, dev, slots=2):
+        for frames, target in DevicePrefetcher(dl, dev, slots=2, frames_dtype=torch.float32):
             if train_one is None:
                 # the step in the form bench.py measures: one hipGraph replay (forward + backward + gradient all-reduce node + fused AdamW);
                 # a capture that fails falls back to the eager DistributedDataParallel step, loudly
