@@ -20,22 +20,22 @@ def main():
     for inner in (2, 1):
         gs = [GraphedSegment(model, f, streams=inner) for f in frames]          # (own pools)
         ref = [g(f)[0].clone() for g, f in zip(gs, frames)]
-        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        ss = [torch.cuda.Stream() for _ in range(4)]
 
-        def run(two, n=80):
+        def run(k, n=96):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(n):
-                if two:
-                    with torch.cuda.stream(sa if i % 2 == 0 else sb):
+                if k > 1:
+                    with torch.cuda.stream(ss[i % k]):
                         gs[i % 4].graph.replay()
                 else:
                     gs[i % 4].graph.replay()
             torch.cuda.synchronize()
             return 1e3 * (time.perf_counter() - t0) / n
-        for _ in range(2):
-            run(False, 20); run(True, 20)
-        print(f"streams inside each graph = {inner}: one forward at a time {run(False):.4f} ms/forward   two in flight {run(True):.4f} ms/forward", flush=True)
+        for k in (1, 2, 3, 4):
+            run(k, 24)
+        print(f"streams inside each graph = {inner}: " + "   ".join(f"{k} in flight {run(k):.4f}" for k in (1, 2, 3, 4, 1, 2, 3, 4)) + "  ms/forward", flush=True)
         assert all(torch.equal(g.out[0], r) for g, r in zip(gs, ref))
         del gs
 
