@@ -518,22 +518,45 @@ def main():
     # ~0.95 ms of GPU time, so on a slow host the eager loop is bound by the launch calls, not by the GPU); GDKVM_FWD_GRAPH=0 times the eager
     # calls.  The replayed masks are checked against the eager ones before anything is timed.
     step, launch = eager_step, "eager (one launch call per kernel)"
+    gsegs = None
+    in_flight = max(1, int(os.environ.get("GDKVM_BENCH_IN_FLIGHT", "2")))
+    if n_rot % in_flight:
+        in_flight = 1
     if os.environ.get("GDKVM_FWD_GRAPH", "1") != "0":
         try:
-            # one captured graph per input batch, all in ONE memory pool: the activations of every replay live at the same addresses (as in a
-            # serving loop that replays one graph), only the input batch differs -- nothing is copied inside the timed region
-            gsegs = []
-            for i in range(n_rot):
-                gsegs.append(model.graphed_segment(batches[i], pool=None if not gsegs else gsegs[0].graph.pool()))
-                if not torch.equal(gsegs[i](batches[i])[0], ref_mask if i == 0 else eager_step(i)):
-                    raise RuntimeError(f"the replayed forward's masks differ from the eager ones (batch {i})")
-            gseg = gsegs[0]
-            step, launch = (lambda i=0: gsegs[i % n_rot](batches[i % n_rot])[0]), "one hipGraph replay per step" + (
-                "" if gseg.streams == 1 else f" ({gseg.streams} groups of {B // gseg.streams} clips on {gseg.streams} streams inside the graph; "
-                                             "masks checked bit-equal to the eager forward over the whole batch)")
+            if in_flight > 1:
+                # TWO forwards in flight (round 6): one captured graph per input batch (a single stream inside), replayed in turn on two host
+                # streams -- step i + 1 starts while step i is still running; all K steps have finished at the closing barrier.  Whole-batch
+                # kernels, two forwards drifting apart: 0.81-0.83 against 0.89-0.90 ms per forward for the two-groups-inside-one-graph form
+                # (GDKVM_BENCH_IN_FLIGHT=1).  model.InFlightSegments; profiles/r06_y_forwards_in_flight.txt
+                from gdkvm_amd.model import InFlightSegments
+                ring = InFlightSegments(model, batches, in_flight=in_flight)
+                for i in range(n_rot):
+                    m_i = ring.launch(i)[0]
+                    ring.synchronize()
+                    if not torch.equal(m_i, ref_mask if i == 0 else eager_step(i)):
+                        raise RuntimeError(f"the replayed forward's masks differ from the eager ones (batch {i})")
+                gsegs = ring.graphs
+                step = lambda i=0: ring.launch(i)[0]
+                launch = (f"one hipGraph replay per step, {in_flight} steps in flight: the graphs (one stream inside each) are replayed in turn on {in_flight} "
+                          "host streams, step i + 1 starting while step i runs; every step has finished at the closing barrier; masks checked "
+                          "bit-equal to the eager forward for every input batch")
+            else:
+                # one captured graph per input batch, all in ONE memory pool: the activations of every replay live at the same addresses (as in a
+                # serving loop that replays one graph), only the input batch differs -- nothing is copied inside the timed region
+                gsegs = []
+                for i in range(n_rot):
+                    gsegs.append(model.graphed_segment(batches[i], pool=None if not gsegs else gsegs[0].graph.pool()))
+                    if not torch.equal(gsegs[i](batches[i])[0], ref_mask if i == 0 else eager_step(i)):
+                        raise RuntimeError(f"the replayed forward's masks differ from the eager ones (batch {i})")
+                gseg = gsegs[0]
+                step, launch = (lambda i=0: gsegs[i % n_rot](batches[i % n_rot])[0]), "one hipGraph replay per step" + (
+                    "" if gseg.streams == 1 else f" ({gseg.streams} groups of {B // gseg.streams} clips on {gseg.streams} streams inside the graph; "
+                                                 "masks checked bit-equal to the eager forward over the whole batch)")
         except Exception as e:
             print(f"[bench] forward not captured ({type(e).__name__}: {e}); timing the eager step", file=sys.stderr, flush=True)
             torch.cuda.synchronize()
+            step, launch, gsegs = eager_step, "eager (one launch call per kernel)", None
     # Set-up, part two: the GPU leaves the set-up above (model build, weight packs, capture: mostly host work) at idle clocks and needs ~30
     # forwards to settle -- replays 0-4 after an idle gap take 1.10 ms, 5-24 0.94, 25+ 0.88 (tools/replay_ramp_probe.py, round 5).  A fixed
     # number of untimed forwards brings it to the steady state the metric is about; the W warm-up steps and the K timed steps follow as the
@@ -694,21 +717,25 @@ def main():
                 from gdkvm_amd.pipeline import SegmentRunner
                 runner = SegmentRunner(model, graph=launch.startswith("one hipGraph"), min_repeats=1)
                 pre = DevicePrefetcher(feed, dev, slots=3, frames_dtype=torch.bfloat16)
-                t_p, n_p = None, 0
+                t_p, n_p, pend = None, 0, None
                 for f_, _t in pre:
                     if n_p == warm_p:
                         torch.cuda.synchronize(); t_p = time.perf_counter(); b0 = pre.h2d_bytes
-                    runner(f_)
+                    nxt = runner.submit(f_)                  # (two forwards in flight, results collected one batch behind: eval.py's loop)
+                    if pend is not None:
+                        pend.get()
+                    pend = nxt
                     n_p += 1
+                pend.get()
                 torch.cuda.synchronize()
                 dt_p = time.perf_counter() - t_p
                 out["pipeline"] = {"frames_per_s": round(B * T * k_p / dt_p, 1), "ms_per_step": round(1e3 * dt_p / k_p, 3), "steps": k_p,
                                    "h2d_GBps": round((pre.h2d_bytes - b0) / dt_p / 1e9, 2),
                                    "h2d_alone_GBps": round(h2d_alone, 2),      # (pinned -> device copies of the same batches, nothing else running)
                                    "what": f"configs[1] forward fed from {nb} pinned host batches of uint8 frames ({host[0][0].numel() / 1e6:.1f} MB each): "
-                                           "host-to-device copy and uint8 -> bf16 / 255 on a side stream (DevicePrefetcher, 3 slots), one hipGraph replay over "
-                                           "the slot's buffer (SegmentRunner: eval.py's path; " + f"{runner.captures} captures, {runner.replays} replays, "
-                                           f"{runner.eager_calls} eager calls) -- all inside the timed loop",
+                                           "host-to-device copy and uint8 -> bf16 / 255 on a side stream (DevicePrefetcher, 3 slots), copy into the graph's "
+                                           f"input buffer and one hipGraph replay, {runner.in_flight} forwards in flight (SegmentRunner: eval.py's path; "
+                                           f"{runner.captures} captures, {runner.replays} replays, {runner.eager_calls} eager calls) -- all inside the timed loop",
                                    "vs_resident_inputs": round((B * T * k_p / dt_p) / value, 3)}
                 del host, pre, runner
             except Exception as e:                              # noqa: BLE001 -- informational leg
@@ -845,7 +872,9 @@ def main():
                     c0 = time.perf_counter(); cpu_mask, _ = ref.segment(sample); ts.append(time.perf_counter() - c0)
                 cpu_fps = cb * T / sorted(ts)[1]
                 # Dice of the GPU masks (bf16 run) against the CPU reference's masks on the same clips
-                gmask = step()[:cb].cpu()
+                gm_ = step()
+                torch.cuda.synchronize()                     # (with forwards in flight the replay runs on a stream of its own)
+                gmask = gm_[:cb].cpu()
             _, cnt = ops.argmax_dice(torch.nn.functional.one_hot(gmask.reshape(-1, S, S).long(), cfg.num_classes)
                                      .permute(0, 3, 1, 2).float().contiguous().to(dev), cpu_mask.reshape(-1, S, S).to(dev))
             dice = ops.dice_from_counts(cnt.sum(0)).tolist()

@@ -57,8 +57,19 @@ def main(argv=None):
     fdt = torch.bfloat16 if cfg.precision == "bf16" else torch.float32
     runner = SegmentRunner(model, graph=os.environ.get("GDKVM_FWD_GRAPH", "1") != "0")
     i = lo
-    for frames, target in DevicePrefetcher(dl, dev, slots=2, frames_dtype=fdt, target_dtype=torch.uint8):
-        mask, c = runner(frames, target)
+
+    def batches():
+        """(mask, counts) per batch, one batch behind the submissions: two forwards are in flight (SegmentRunner(in_flight=2))"""
+        pending = None
+        for frames, target in DevicePrefetcher(dl, dev, slots=3, frames_dtype=fdt, target_dtype=torch.uint8):
+            nxt = runner.submit(frames, target)
+            if pending is not None:
+                yield pending.get()
+            pending = nxt
+        if pending is not None:
+            yield pending.get()
+
+    for mask, c in batches():
         # only frames that carry labels count (EchoNet-Dynamic: the two traced frames of a clip -- gdkvm_amd.data.IGNORE_LABEL everywhere
         # else, where a predicted pixel must not enter |A|): a labelled frame has a non-empty target in some class
         labelled = (c[..., 2].sum(-1, keepdim=True) > 0).unsqueeze(-1)
@@ -69,7 +80,7 @@ def main(argv=None):
             scale = 255 // max(cfg.data.num_classes - 1, 1)
             Image.fromarray((mask[0, 0].cpu().numpy() * scale).astype("uint8")).save(os.path.join(cfg.run_dir, "vis", f"mask_{i:05d}.png"))
             vis_left -= 1
-        i += frames.shape[0]
+        i += mask.shape[0]
     if world > 1:
         torch.distributed.all_reduce(counts)                      # the only exchange: 3 integers per class
     if rank == 0:

@@ -1194,3 +1194,49 @@ class GraphedSegment:
             self.state.copy_(state, non_blocking=True)
         self.graph.replay()
         return self.out
+
+
+class InFlightSegments:
+    """Several forwards IN FLIGHT (round 6): one captured GraphedSegment (a single stream inside) per resident input batch, replayed round-robin
+    on `in_flight` host streams, so that batch i + 1 starts while batch i is still running.  Whole-batch kernels are more efficient than the
+    half-batch kernels of the two-groups-inside-one-graph form, and two forwards that drift apart overlap DIFFERENT kernels (a memory-bound
+    mask kernel beside an MFMA-bound convolution) instead of the same kernel twice: cfg2 0.81-0.83 ms per forward with two in flight against
+    0.89-0.90 for GraphedSegment(streams=2) one at a time and 0.93 for one stream one at a time; three or four in flight do not add
+    (profiles/r06_y_forwards_in_flight.txt).  Throughput, not latency: a batch's masks are ready when ITS stream has finished.
+    Graph i always runs on stream i % in_flight; the graphs of one stream share a memory pool (they never overlap), graphs of different streams
+    do not.  launch(i) replays graph i on its stream and returns (mask, counts | None, event recorded behind it); wait(i) makes the caller's
+    current stream wait for that replay; synchronize() waits for every stream on the host."""
+
+    def __init__(self, model: "GDKVM", batches, targets=None, in_flight: int = 2):
+        if in_flight < 1 or not batches or len(batches) % in_flight:
+            raise ValueError(f"InFlightSegments: {len(batches)} batches must be a positive multiple of in_flight={in_flight}")
+        dev = batches[0].device
+        self.in_flight = in_flight
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(in_flight)]
+        self.graphs, self.events = [], [None] * len(batches)
+        for i, b in enumerate(batches):
+            pool = None if i < in_flight else self.graphs[i % in_flight].graph.pool()
+            self.graphs.append(GraphedSegment(model, b, None if targets is None else targets[i], streams=1, pool=pool))
+        torch.cuda.synchronize(dev)
+
+    def __len__(self):
+        return len(self.graphs)
+
+    def launch(self, i: int):
+        g = self.graphs[i % len(self.graphs)]
+        s = self.streams[(i % len(self.graphs)) % self.in_flight]
+        with torch.cuda.stream(s):
+            out = g(g.frames, g.target)
+            ev = torch.cuda.Event()
+            ev.record(s)
+        self.events[i % len(self.graphs)] = ev
+        return out[0], out[1], ev
+
+    def wait(self, i: int) -> None:
+        ev = self.events[i % len(self.graphs)]
+        if ev is not None:
+            torch.cuda.current_stream(self.graphs[0].frames.device).wait_event(ev)
+
+    def synchronize(self) -> None:
+        for s in self.streams:
+            s.synchronize()

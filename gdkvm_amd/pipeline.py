@@ -172,49 +172,99 @@ class DevicePrefetcher:
             worker.join(timeout=5.0)
 
 
+class _Pending:
+    """What SegmentRunner.submit returns: the batch's result once get() has made the caller's stream wait for it."""
+
+    def __init__(self, out, event=None, clone=True):
+        self._out, self._event, self._clone = out, event, clone
+
+    def get(self):
+        if self._event is not None:
+            torch.cuda.current_stream(self._out[0].device).wait_event(self._event)
+        mask, counts = self._out[0], self._out[1]
+        return (mask.clone(), None if counts is None else counts.clone()) if self._clone else (mask, counts)
+
+
 class SegmentRunner:
     """model.segment(frames, target) for a stream of batches: captured GraphedSegments per batch shape (the full batches of a split), an eager
     call -- said on stderr when a capture fails -- for shapes seen fewer than `min_repeats` times (the last, short batch).
-    zero_copy (default): a graph is captured OVER the tensors it is called with, one per distinct input buffer, all graphs of a shape in one
-    memory pool -- DevicePrefetcher hands out the same few per-slot buffers again and again, so after `slots` captures every batch is a bare
-    replay with no copy into an input buffer (38.5 MB per batch at the EchoNet shape).  Tensors from anywhere else work too (each new
-    address costs a capture, up to `max_graphs` per shape; beyond that the batch is copied into the first graph's buffers)."""
 
-    def __init__(self, model, graph: bool = True, min_repeats: int = 2, zero_copy: bool = True, max_graphs: int = 4):
+    in_flight = 2 (default): TWO forwards in flight -- `in_flight` captures per shape (a single stream inside each, a memory pool of its own),
+    used in turn, each replayed on a host stream of its own: batch i + 1 starts while batch i is still running (0.81-0.83 against 0.89-0.90 ms
+    per 16 x 32 frames: model.InFlightSegments).  submit() copies the batch into the graph's input buffers on that stream, makes the CALLER's
+    stream wait for that copy only (so the batch's source -- a DevicePrefetcher slot -- is free again as far as the caller's stream is
+    concerned), replays, and returns a handle; get() on the handle makes the caller's stream wait for the result.  Keep one batch of lag
+    between submit and get (eval.py does) or call the runner directly (`runner(frames, target)` = submit().get(): no overlap).
+    in_flight = 1: one forward at a time, two groups of clips on two streams inside the graph; zero_copy then captures a graph OVER each
+    distinct input buffer (a DevicePrefetcher's slots) in one memory pool, so a batch is a bare replay with no copy (up to `max_graphs` per
+    shape; beyond that the batch is copied into the first graph's buffers)."""
+
+    def __init__(self, model, graph: bool = True, min_repeats: int = 2, zero_copy: bool = True, max_graphs: int = 4, in_flight: int = 2):
         self.model, self.graph, self.min_repeats, self.zero_copy, self.max_graphs = model, graph, min_repeats, zero_copy, max_graphs
-        self._graphs, self._seen = {}, {}
+        self.in_flight = max(1, in_flight)
+        self._graphs, self._seen, self._streams, self._turn = {}, {}, None, {}
         self.replays = self.eager_calls = self.captures = 0
 
-    def __call__(self, frames: torch.Tensor, target: Optional[torch.Tensor] = None):
+    def _capture(self, shape_key, per_shape, key, frames, target, **kw):
+        try:
+            from .model import GraphedSegment
+            g = GraphedSegment(self.model, frames, target, **kw)
+            per_shape[key] = g
+            self.captures += 1
+            return g
+        except Exception as e:                  # noqa: BLE001 -- a failed capture must not end an evaluation: say so, run eagerly
+            print(f"[gdkvm] forward not captured for {shape_key[0]} ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            per_shape["failed"] = True
+            return None
+
+    def submit(self, frames: torch.Tensor, target: Optional[torch.Tensor] = None) -> _Pending:
         shape_key = (tuple(frames.shape), frames.dtype, None if target is None else target.dtype)
         self._seen[shape_key] = self._seen.get(shape_key, 0) + 1
         per_shape = self._graphs.setdefault(shape_key, {})
-        g = None
-        if self.graph and self._seen[shape_key] >= self.min_repeats and per_shape.get("failed") is None:
+        usable = self.graph and self._seen[shape_key] >= self.min_repeats and per_shape.get("failed") is None
+        if usable and self.in_flight > 1:
+            dev = frames.device
+            if self._streams is None:
+                self._streams = [torch.cuda.Stream(device=dev) for _ in range(self.in_flight)]
+            turn = self._turn.get(shape_key, 0)
+            self._turn[shape_key] = (turn + 1) % self.in_flight
+            g = per_shape.get(turn)
+            if g is None:
+                g = self._capture(shape_key, per_shape, turn, frames.clone(), None if target is None else target.clone(), streams=1)
+            if g is not None:
+                s, cur = self._streams[turn], torch.cuda.current_stream(dev)
+                s.wait_stream(cur)              # the batch is ready as far as the caller's stream knows
+                with torch.cuda.stream(s):
+                    g.frames.copy_(frames, non_blocking=True)
+                    if target is not None:
+                        g.target.copy_(target, non_blocking=True)
+                    copied = torch.cuda.Event()
+                    copied.record(s)
+                    out = g(g.frames, g.target)
+                    done = torch.cuda.Event()
+                    done.record(s)
+                cur.wait_event(copied)          # (the source buffers are free once this has passed: a prefetcher slot may be refilled)
+                self.replays += 1
+                return _Pending(out, done)
+        elif usable:
             ptr_key = (frames.data_ptr(), None if target is None else target.data_ptr()) if self.zero_copy else "copy"
             g = per_shape.get(ptr_key)
             if g is None and len(per_shape) < self.max_graphs:
-                try:
-                    from .model import GraphedSegment
-                    first = next(iter(per_shape.values()), None)
-                    own = (frames, target) if self.zero_copy else (frames.clone(), None if target is None else target.clone())
-                    g = GraphedSegment(self.model, own[0], own[1], pool=None if first is None else first.graph.pool())
-                    per_shape[ptr_key] = g
-                    self.captures += 1
-                except Exception as e:          # noqa: BLE001 -- a failed capture must not end an evaluation: say so, run eagerly
-                    print(f"[gdkvm] forward not captured for {shape_key[0]} ({type(e).__name__}: {e}); running eagerly", file=sys.stderr, flush=True)
-                    torch.cuda.synchronize()
-                    per_shape["failed"] = True
-                    g = None
+                first = next((v for k, v in per_shape.items() if k != "failed"), None)
+                own = (frames, target) if self.zero_copy else (frames.clone(), None if target is None else target.clone())
+                g = self._capture(shape_key, per_shape, ptr_key, own[0], own[1], pool=None if first is None else first.graph.pool())
             elif g is None:
                 g = next(v for k, v in per_shape.items() if k != "failed")     # (more buffers than graphs: copy into the first graph's)
-        if g is not None:
-            self.replays += 1
-            out = g(frames, target)
-            return out[0].clone(), (None if out[1] is None else out[1].clone())
+            if g is not None:
+                self.replays += 1
+                return _Pending(g(frames, target))
         self.eager_calls += 1
         with torch.no_grad():
-            return self.model.segment(frames, target=target)
+            return _Pending(self.model.segment(frames, target=target), clone=False)
+
+    def __call__(self, frames: torch.Tensor, target: Optional[torch.Tensor] = None):
+        return self.submit(frames, target).get()
 
 
 def make_train_step(model, opt_factory, frames: torch.Tensor, target: torch.Tensor, autocast_dtype, world: int, device,

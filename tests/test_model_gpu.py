@@ -464,3 +464,50 @@ def test_graphed_segments_sharing_one_memory_pool(hip):
         for rnd in range(2):
             for i in (2, 0, 1):
                 assert torch.equal(graphs[i](batches[i])[0], want[i]), (streams, rnd, i)
+
+
+def test_forwards_in_flight_return_every_batch_s_masks(hip):
+    """model.InFlightSegments (bench.py's timed loop: graphs replayed in turn on two host streams, step i + 1 starting while step i runs) and
+    pipeline.SegmentRunner(in_flight=2) with results collected one batch behind (eval.py's loop): every batch's masks and Dice counts are the
+    eager forward's, bit for bit, under back-to-back launches; in_flight = 1 and direct calls give the same."""
+    from gdkvm_amd.model import GDKVM, GDKVMConfig, InFlightSegments
+    from gdkvm_amd.pipeline import SegmentRunner
+    torch.manual_seed(29)
+    model = GDKVM(GDKVMConfig()).cuda().eval().to(memory_format=torch.channels_last)
+    batches = [torch.rand(8, 3, 3, 112, 112, device="cuda").bfloat16() for _ in range(4)]
+    targets = [(torch.rand(8, 3, 112, 112, device="cuda") > 0.5).to(torch.uint8) for _ in range(4)]
+    with torch.no_grad():
+        lg = model(batches[0].float(), _lowres=True)
+        model.decoder.head.bias[1] += (lg[:, :, 0] - lg[:, :, 1]).median()
+    model = model.fuse_for_inference().to(torch.bfloat16)
+    want = [tuple(t.clone() for t in model.segment(b, target=t_)) for b, t_ in zip(batches, targets)]
+    assert not torch.equal(want[0][0], want[1][0])
+    ring = InFlightSegments(model, batches, targets, in_flight=2)
+    outs = []
+    for rnd in range(3):
+        for i in range(4):
+            outs.append((i, ring.launch(i)))                   # no waiting between launches: two forwards overlap
+        ring.synchronize()
+        for i, (m, c, _) in outs[-4:]:
+            assert torch.equal(m, want[i][0]) and torch.equal(c, want[i][1]), (rnd, i)
+    ring.launch(1)
+    ring.wait(1)                                               # the caller's stream waits for that replay only
+    assert torch.equal(ring.graphs[1].out[0].clone(), want[1][0])
+    with pytest.raises(ValueError):
+        InFlightSegments(model, batches[:3], in_flight=2)
+    for in_flight in (2, 1):
+        runner = SegmentRunner(model, min_repeats=1, in_flight=in_flight)
+        got, pending = [], None
+        for rnd in range(2):
+            for b, t_ in zip(batches, targets):
+                nxt = runner.submit(b, t_)
+                if pending is not None:
+                    got.append(pending.get())
+                pending = nxt
+        got.append(pending.get())
+        torch.cuda.synchronize()
+        assert len(got) == 8 and runner.eager_calls == 0
+        for k, (m, c) in enumerate(got):
+            assert torch.equal(m, want[k % 4][0]) and torch.equal(c, want[k % 4][1]), (in_flight, k)
+        m, c = runner(batches[2], targets[2])
+        assert torch.equal(m, want[2][0]) and torch.equal(c, want[2][1])
