@@ -721,7 +721,7 @@ def main():
                 for f_, _t in pre:
                     if n_p == warm_p:
                         torch.cuda.synchronize(); t_p = time.perf_counter(); b0 = pre.h2d_bytes
-                    nxt = runner.submit(f_)                  # (two forwards in flight, results collected one batch behind: eval.py's loop)
+                    nxt = runner.submit(f_)                  # (results collected one batch behind the submissions: eval.py's loop)
                     if pend is not None:
                         pend.get()
                     pend = nxt
@@ -733,8 +733,8 @@ def main():
                                    "h2d_GBps": round((pre.h2d_bytes - b0) / dt_p / 1e9, 2),
                                    "h2d_alone_GBps": round(h2d_alone, 2),      # (pinned -> device copies of the same batches, nothing else running)
                                    "what": f"configs[1] forward fed from {nb} pinned host batches of uint8 frames ({host[0][0].numel() / 1e6:.1f} MB each): "
-                                           "host-to-device copy and uint8 -> bf16 / 255 on a side stream (DevicePrefetcher, 3 slots), copy into the graph's "
-                                           f"input buffer and one hipGraph replay, {runner.in_flight} forwards in flight (SegmentRunner: eval.py's path; "
+                                           "host-to-device copy and uint8 -> bf16 / 255 on a side stream (DevicePrefetcher, 3 slots), then one hipGraph replay captured "
+                                           f"over the slot's buffer (no further copy), {runner.in_flight} forward(s) in flight (SegmentRunner: eval.py's path; "
                                            f"{runner.captures} captures, {runner.replays} replays, {runner.eager_calls} eager calls) -- all inside the timed loop",
                                    "vs_resident_inputs": round((B * T * k_p / dt_p) / value, 3)}
                 del host, pre, runner

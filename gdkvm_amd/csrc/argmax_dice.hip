@@ -309,6 +309,13 @@ __global__ __launch_bounds__(256) void upsample_argmax_dice_kernel(UpArgs a)
 
 }  // namespace
 
+// The Dice counts are accumulated with integer atomics: they start from zero.  Zeroed by a KERNEL (gdkvm_zero_async), not hipMemsetAsync
+// (round 6): as a memset node of a captured graph the 576-byte fill of a counts tensor that lives in the graph's own memory pool ran on the
+// first replay only -- GraphedSegment(streams=1) with a target returned the first replay's counts plus whatever the pool block held
+// afterwards (tests/test_model_gpu.py::test_forwards_in_flight...; the two-stream form, whose counts tensor is allocated outside the capture,
+// was not affected).
+static int zero_counts(int32_t* counts, size_t n, hipStream_t st) { return gdkvm_zero_async(counts, n * sizeof(int32_t), st); }
+
 extern "C" int gdkvm_argmax_dice(const void* logits, const uint8_t* target, uint8_t* mask, int32_t* counts,
                                  int BT, int ncls, int H, int W, int io_dtype, void* stream)
 {
@@ -325,10 +332,7 @@ extern "C" int gdkvm_argmax_dice(const void* logits, const uint8_t* target, uint
     if (int rc = gdkvm_check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int HW = H * W;
-    if (target) {
-        hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)BT * ncls * 3, st);
-        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "argmax_dice: memset: %s", hipGetErrorString(e));
-    }
+    if (target) if (int rc = zero_counts(counts, (size_t)BT * ncls * 3, st)) return rc;
     AdArgs a{logits, target, mask, counts, ncls, HW};
     const bool vec = (HW % 4) == 0;
     const int nvec = vec ? HW / 4 : HW;
@@ -367,10 +371,7 @@ static int upsample_launch(const char* who, const void* src, const float* head_w
     if ((size_t)H * W > 0x7fffffffu / 2) return gdkvm_fail(GDKVM_ERR_SHAPE, "%s: image too large", who);
     if (int rc = gdkvm_check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (target) {
-        hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)BT * ncls * 3, st);
-        if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "%s: memset: %s", who, hipGetErrorString(e));
-    }
+    if (target) if (int rc = zero_counts(counts, (size_t)BT * ncls * 3, st)) return rc;
     const int nq = (W % 4 == 0) ? H * W / 4 : H * W;       // work items per frame (pixel quads when rows allow)
     int gx = (nq + 255) / 256;
     static const int cap_env = [] { const char* e = getenv("GDKVM_ARGMAX_BLOCKS"); return e ? atoi(e) : 0; }();   // (A/B runs)

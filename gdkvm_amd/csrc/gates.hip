@@ -238,9 +238,8 @@ extern "C" int gdkvm_head_bwd(const void* x, const void* dz, const float* w, voi
     if (!dw || !db) return gdkvm_fail(GDKVM_ERR_ARG, "head_bwd: null pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (N == 0) {
-        hipError_t e = hipMemsetAsync(dw, 0, (size_t)ncls * C * sizeof(float), st);
-        if (e == hipSuccess) e = hipMemsetAsync(db, 0, (size_t)ncls * sizeof(float), st);
-        return e == hipSuccess ? GDKVM_OK : gdkvm_fail(GDKVM_ERR_LAUNCH, "head_bwd: memset: %s", hipGetErrorString(e));
+        if (int rc = gdkvm_zero_async(dw, (size_t)ncls * C * sizeof(float), st)) return rc;
+        return gdkvm_zero_async(db, (size_t)ncls * sizeof(float), st);
     }
     if (!x || !dz || !w || !dx || !workspace) return gdkvm_fail(GDKVM_ERR_ARG, "head_bwd: null pointer");
     if (!gdkvm_aligned16(x) || !gdkvm_aligned16(dx) || !gdkvm_aligned16(workspace)) return gdkvm_fail(GDKVM_ERR_ARG, "head_bwd: pointers must be 16-byte aligned");

@@ -16,6 +16,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // ---- host side -------------------------------------------------------------------------------------
 int gdkvm_fail(int code, const char* fmt, ...);      // records the thread-local message, returns `code`
 int gdkvm_check_device(void);                         // GDKVM_OK iff the current device is gfx950
+// Zero `bytes` (a multiple of 4) at p (4-byte aligned) on `st` with a KERNEL.  Not hipMemsetAsync: as a memset node of a captured graph a
+// small fill of memory inside the graph's own pool ran on the first replay only (round 6, argmax_dice.hip); a kernel node has no such mode.
+int gdkvm_zero_async(void* p, size_t bytes, hipStream_t st);
 static inline bool gdkvm_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define GDKVM_LAUNCH_CHECK(name)                                                        \

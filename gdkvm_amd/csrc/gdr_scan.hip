@@ -676,8 +676,7 @@ extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* p
     if (int rc = gdkvm_check_device()) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // the recurrence on Dk columns from S = I with G = 0 and no read-out:  Phi = prod_t a_t P_t
-    hipError_t e = hipMemsetAsync(ws.zero, 0, 64 * 4 * sizeof(float), st);       // the one G tile every frame and slice reads
-    if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_transition: memset: %s", hipGetErrorString(e));
+    if (int rc = gdkvm_zero_async(ws.zero, 64 * 4 * sizeof(float), st)) return rc;       // the one G tile every frame and slice reads
     AffArgs sa{q, alpha, nullptr, ws.pp, ws.zero, ws.qinv, nullptr, phi_out, nullptr, ws.trash, 1, 1, T, Hh, N, GDKVM_DK, flags, B * Hh, 0, nullptr};
     const dim3 grid((unsigned)(B * Hh * (GDKVM_DK / 16)));
     const bool wide = flags & GDKVM_FLAG_WIDE_RANGE;

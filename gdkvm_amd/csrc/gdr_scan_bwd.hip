@@ -407,8 +407,7 @@ static int scan_bwd_impl(const void* q, const void* k, const void* v, const floa
                                d_hist, gb, n_img, Dv);
             GDKVM_LAUNCH_CHECK("gdr_rows_to_img_kernel");
         } else {
-            hipError_t e = hipMemsetAsync(gb, 0, n_img * 16, st);
-            if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_bwd: memset: %s", hipGetErrorString(e));
+            if (int rc = gdkvm_zero_async(gb, n_img * 16, st)) return rc;
         }
     }
     // reverse recurrence on the forward's serial kernel (operands from the training-mode workspace)

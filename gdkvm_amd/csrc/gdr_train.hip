@@ -179,8 +179,7 @@ extern "C" int gdkvm_scan_train_bwd(const void* q, const void* k, const void* v,
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t es = io_dtype == GDKVM_F32 ? 4 : 2, BT = (size_t)B * T;
     // read-out backward: d_q, and the state gradients of the states the frames read (every C-th entry of d_hist; the rest is zero)
-    hipError_t e = hipMemsetAsync(tv.d_hist, 0, (size_t)B * tv.Tc * Hh * Dk * Dv * sizeof(float), st);
-    if (e != hipSuccess) return gdkvm_fail(GDKVM_ERR_LAUNCH, "scan_train_bwd: memset: %s", hipGetErrorString(e));
+    if (int rc = gdkvm_zero_async(tv.d_hist, (size_t)B * tv.Tc * Hh * Dk * Dv * sizeof(float), st)) return rc;
     if (int rc = gdkvm_readout_bwd(q, tv.hist, d_r, d_q, tv.d_hist, B, T, Hh, N, Dk, Dv, tv.C, io_dtype, flags & GDKVM_FLAG_NORMALIZE_QK, stream))
         return rc;
     if (int rc = gdkvm_scan_state_bwd(tv.k_p, tv.v_p, tv.alpha_p, tv.beta_p, tv.hist, tv.fws, tv.fws_bytes, tv.d_hist, d_s_out,

@@ -352,9 +352,8 @@ static int gemm_tn_impl(const char* who, const void* a, const void* b, float* c,
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (int rc = gdkvm_check_device()) return rc;
     if (M == 0) {
-        hipError_t e = hipMemsetAsync(c, 0, (size_t)K1 * N * sizeof(float), st);
-        if (e == hipSuccess && colsum) e = hipMemsetAsync(colsum, 0, (size_t)K1 * sizeof(float), st);
-        return e == hipSuccess ? GDKVM_OK : gdkvm_fail(GDKVM_ERR_LAUNCH, "%s: memset: %s", who, hipGetErrorString(e));
+        if (int rc = gdkvm_zero_async(c, (size_t)K1 * N * sizeof(float), st)) return rc;
+        return colsum ? gdkvm_zero_async(colsum, (size_t)K1 * sizeof(float), st) : GDKVM_OK;
     }
     const size_t need = gdkvm_gemm_tn_workspace_bytes(M, K1, N) + (colsum ? (size_t)tn_splits(M) * K1 * sizeof(float) : 0);
     if (!workspace || workspace_bytes < need) return gdkvm_fail(GDKVM_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", who, workspace_bytes, need);

@@ -189,17 +189,20 @@ class SegmentRunner:
     """model.segment(frames, target) for a stream of batches: captured GraphedSegments per batch shape (the full batches of a split), an eager
     call -- said on stderr when a capture fails -- for shapes seen fewer than `min_repeats` times (the last, short batch).
 
-    in_flight = 2 (default): TWO forwards in flight -- `in_flight` captures per shape (a single stream inside each, a memory pool of its own),
-    used in turn, each replayed on a host stream of its own: batch i + 1 starts while batch i is still running (0.81-0.83 against 0.89-0.90 ms
-    per 16 x 32 frames: model.InFlightSegments).  submit() copies the batch into the graph's input buffers on that stream, makes the CALLER's
-    stream wait for that copy only (so the batch's source -- a DevicePrefetcher slot -- is free again as far as the caller's stream is
-    concerned), replays, and returns a handle; get() on the handle makes the caller's stream wait for the result.  Keep one batch of lag
-    between submit and get (eval.py does) or call the runner directly (`runner(frames, target)` = submit().get(): no overlap).
-    in_flight = 1: one forward at a time, two groups of clips on two streams inside the graph; zero_copy then captures a graph OVER each
+    in_flight = 1 (default): one forward at a time, two groups of clips on two streams inside the graph; zero_copy captures a graph OVER each
     distinct input buffer (a DevicePrefetcher's slots) in one memory pool, so a batch is a bare replay with no copy (up to `max_graphs` per
-    shape; beyond that the batch is copied into the first graph's buffers)."""
+    shape; beyond that the batch is copied into the first graph's buffers).  The faster form when the batches come from HOST memory through
+    a DevicePrefetcher (bench.py's `pipeline` leg: 444-456 k frames/s against 358-390 k with in_flight = 2 -- the H2D copy and the cast
+    already fill the gaps a second forward in flight would use, and that form copies each batch once more).
+    in_flight = 2: TWO forwards in flight -- `in_flight` captures per shape (a single stream inside each, a memory pool of its own), used in
+    turn, each replayed on a host stream of its own: batch i + 1 starts while batch i is still running.  The faster form when the batches are
+    ALREADY in HBM (0.81-0.82 against 0.87-0.88 ms per 16 x 32 frames: model.InFlightSegments, bench.py's timed loop).  submit() copies the
+    batch into the graph's input buffers on that stream, makes the CALLER's stream wait for that copy only (so the batch's source is free
+    again as far as the caller's stream is concerned), replays, and returns a handle; get() on the handle makes the caller's stream wait for
+    the result.  Keep one batch of lag between submit and get (eval.py does) or call the runner directly (`runner(frames, target)` =
+    submit().get(): no overlap)."""
 
-    def __init__(self, model, graph: bool = True, min_repeats: int = 2, zero_copy: bool = True, max_graphs: int = 4, in_flight: int = 2):
+    def __init__(self, model, graph: bool = True, min_repeats: int = 2, zero_copy: bool = True, max_graphs: int = 4, in_flight: int = 1):
         self.model, self.graph, self.min_repeats, self.zero_copy, self.max_graphs = model, graph, min_repeats, zero_copy, max_graphs
         self.in_flight = max(1, in_flight)
         self._graphs, self._seen, self._streams, self._turn = {}, {}, None, {}

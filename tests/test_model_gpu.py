@@ -511,3 +511,37 @@ def test_forwards_in_flight_return_every_batch_s_masks(hip):
             assert torch.equal(m, want[k % 4][0]) and torch.equal(c, want[k % 4][1]), (in_flight, k)
         m, c = runner(batches[2], targets[2])
         assert torch.equal(m, want[2][0]) and torch.equal(c, want[2][1])
+
+
+def test_graph_replays_zero_the_dice_counts_every_time(hip):
+    """The Dice counts are accumulated with integer atomics from zero.  Regression (round 6): their zeroing was a hipMemsetAsync, and as a
+    memset node of a captured graph over a counts tensor inside the graph's own memory pool it ran on the first replay only -- the single-stream
+    GraphedSegment with a target returned wrong counts from the second replay on.  It is a kernel now (csrc/gdkvm_api.hip gdkvm_zero_async):
+    four replays of the one- and the two-stream graph all equal the eager forward's counts; so does the bare entry point captured by itself."""
+    from gdkvm_amd import ops
+    from gdkvm_amd.model import GDKVM, GDKVMConfig, GraphedSegment
+    torch.manual_seed(31)
+    model = GDKVM(GDKVMConfig()).cuda().eval().to(memory_format=torch.channels_last)
+    b = torch.rand(8, 3, 3, 112, 112, device="cuda").bfloat16()
+    t = (torch.rand(8, 3, 112, 112, device="cuda") > 0.5).to(torch.uint8)
+    with torch.no_grad():
+        lg = model(b.float(), _lowres=True)
+        model.decoder.head.bias[1] += (lg[:, :, 0] - lg[:, :, 1]).median()
+    model = model.fuse_for_inference().to(torch.bfloat16)
+    want_m, want_c = (x.clone() for x in model.segment(b, target=t)[:2])
+    assert want_c.sum().item() > 0
+    for streams in (1, 2):
+        g = GraphedSegment(model, b, t, streams=streams)
+        for r in range(4):
+            m, c = g(b, t)[:2]
+            assert torch.equal(m, want_m) and torch.equal(c, want_c), (streams, r)
+    logits = torch.randn(6, 2, 112, 112, device="cuda")
+    target = (torch.rand(6, 112, 112, device="cuda") > 0.5).to(torch.uint8)
+    ref = ops.argmax_dice(logits, target)[1].clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = ops.argmax_dice(logits, target)[1]               # (the counts tensor is allocated INSIDE the capture: the graph's pool)
+    for r in range(4):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), r
