@@ -123,14 +123,21 @@ def committed_rocprof_scan_us():
     return (round(us, 2) if us else None), src
 
 
+def _profile_order(path):
+    """profiles/rNN_<tag>_...: rounds in order, tags a..z then aa, ab, ... (file times do not survive the copy to the GPU box)"""
+    parts = os.path.basename(path).split("_")
+    return (parts[0], len(parts[1]), parts[1])
+
+
 def committed_in_graph_scan():
     """The scan pair's kernel time PER STEP inside the shipped two-stream graph (each kernel runs once per group of clips, overlapped with
     the other group's kernels), from the newest committed steady-state trace of this very command (profiles/*_bench_cfg2_steady_state*.csv,
     tools/profile_bench.sh): the launch shape the timed region actually runs, quoted beside the isolated one-call figure."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[6-9]_*_bench_cfg2_steady_state*.csv")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[6-9]_*_bench_cfg2_steady_state*.csv")), key=_profile_order)
     if not files:
         return None
+    header = open(files[-1]).read().split("\n")[1]
     rows = {}
     with open(files[-1]) as f:
         for ln in f:
@@ -143,8 +150,9 @@ def committed_in_graph_scan():
         return None
     return {"source": os.path.relpath(files[-1], ROOT), "launches_per_step": sum(v[0] for v in pair.values()),
             "kernel_us_per_step": round(sum(v[1] for v in pair.values()), 2),
-            "note": "sum of the pair's kernel durations per replay of the timed graph (2 groups of 8 clips on 2 streams: the kernels of the "
-                    "two groups overlap other kernels, so this is occupancy-shared time, not an isolated launch)"}
+            "form": "forwards in flight (whole-batch graphs on several host streams)" if "per hardware queue" in header else "two groups of clips on two streams inside one graph",
+            "note": "sum of the pair's kernel durations per step of the timed loop, where the pair runs beside the kernels of another forward "
+                    "(or of the other group of clips): occupancy-shared time, not an isolated launch"}
 
 
 def committed_forward_top_kernels(limit=8):
@@ -155,7 +163,7 @@ def committed_forward_top_kernels(limit=8):
     import csv
     import glob
     def newest(pat):
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)), key=os.path.getmtime)
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)), key=_profile_order)
         return files[-1] if files else None
     ks, sq, hbm = newest("r0[6-9]_*_forward_cfg2_kernel_stats.csv"), newest("r0[6-9]_*_forward_cfg2_pmc_sq.csv"), newest("r0[6-9]_*_forward_cfg2_pmc_hbm.csv")
     if not ks:

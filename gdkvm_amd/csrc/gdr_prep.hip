@@ -547,8 +547,12 @@ __attribute__((amdgpu_waves_per_eu(1, (W3 ? 3 : 2)))) void gdr_prepm_kernel(Prep
     // (a uniform base and two 32-bit lane offsets: as 64-bit lane addresses they cost four registers across the G loop, which the
     // three-workgroups-per-CU build of this kernel does not have)
     const bf16_t* vrow = static_cast<const bf16_t*>(a.v) + (bt * Hh + h) * Dv;
+#ifdef GDKVM_ABL_PREP_VSAME                                 // (tools/abl_scan.py prep: every lane pair reads token 0's piece -- one row segment per load)
+    const unsigned voff0 = 8u * (lane & 1), voff1 = 8u * (lane & 1);
+#else
     const unsigned voff0 = (unsigned)min(lane >> 1, N - 1) * (unsigned)(Hh * Dv) + 8u * (lane & 1);
     const unsigned voff1 = (unsigned)min(32 + (lane >> 1), N - 1) * (unsigned)(Hh * Dv) + 8u * (lane & 1);
+#endif
     auto load_vraw = [&](int cV, uint4& d0, uint4& d1) __attribute__((always_inline)) {
         cV = min(cV, nsl - 1);
         const bf16_t* vp = vrow + 16 * cV;

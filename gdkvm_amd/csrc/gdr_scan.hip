@@ -539,7 +539,11 @@ __global__ __launch_bounds__(256, 2) void gdr_readout_kernel(ReadoutArgs a)     
             }
             const f32x4 accR = (acc0 + acc1) * (rscale * sinv[c]);
             const int nr = 16 * tt + li;
+#ifdef GDKVM_ABL_RO_NOSTORE                                 // (tools/abl_scan.py: stores only where a value is NaN -- never, but not provably)
+            if (nr < N && (c == 0 || two) && accR[0] != accR[0]) {
+#else
             if (nr < N && (c == 0 || two)) {
+#endif
                 char* p = rbase + (size_t)nr * rowr + c * 16 * ESZ;
                 if constexpr (IO == GDKVM_F32) *reinterpret_cast<f32x4*>(p) = accR;
                 else *reinterpret_cast<uint2*>(p) = make_uint2(cvt_pk_bf16(accR[0], accR[1]), cvt_pk_bf16(accR[2], accR[3]));
@@ -548,11 +552,145 @@ __global__ __launch_bounds__(256, 2) void gdr_readout_kernel(ReadoutArgs a)     
     };
     QT qa, qb;
     load_q(tt0, qa);
+#ifdef GDKVM_ABL_RO_NOQ                                     // (tools/abl_scan.py: the first two token tiles' q rows for every tile)
+    load_q(tt0 + 1, qb);
+    for (int tt = tt0; tt < ntt; tt += 2) {
+        tile(tt, qa);
+        if (tt + 1 < ntt) tile(tt + 1, qb);
+    }
+#else
     for (int tt = tt0; tt < ntt; tt += 2) {
         load_q(tt + 1, qb);
         tile(tt, qa);
         load_q(tt + 2, qa);
         if (tt + 1 < ntt) tile(tt + 1, qb);
+    }
+#endif
+}
+
+// gdr_readout_rows_kernel -- the same read-out for bf16 I/O with every global access a run of whole rows (round 6).  Ablation of the
+// kernel above at cfg5 (tools/abl_scan.py ro, profiles/r06_ad_readout_ablation.txt): 82 us of which the R stores cost ~80 and the q loads
+// ~25-45 -- not their bytes (134 + 33 MB) but their SHAPE: a wave's store is 16 rows x 32 bytes, its q load 16 rows x 64 bytes, every
+// wave of the frame's workgroups loads the same q rows, and the memory pipeline is paid per row segment.  Here the workgroup moves both
+// through LDS: q rows of TWO token tiles (32 tokens x 128 bytes) arrive as one 16-byte load per thread (a contiguous 4 KB when Hh = 1),
+// requested one pair ahead; the R tiles of the pair (32 tokens x the workgroup's 128 columns) are written to LDS in the accumulator
+// layout and leave as 16 bytes per thread, four full 256-byte row pieces per wave and instruction.  One barrier per pair of token tiles
+// (q and R stage double-buffered: a stage written in iteration p was last read before the barrier of iteration p - 1).  Arithmetic, operand
+// images and operation order are those of gdr_readout_kernel: bit-identical results.
+constexpr int RO_QP = 2 * GDKVM_DK + 16;                  // q stage row pitch, bytes (16 x odd: a b128 read of 16 rows touches every bank once)
+constexpr int RO_RP = 256 + 32;                           // R stage row pitch, bytes (72 dwords = 8 mod 64: b64 writes of 16 rows x 4 groups in two passes)
+constexpr size_t RO_LDS = 2 * 32 * RO_QP + 2 * 32 * RO_RP;
+
+template <int FMT>
+__global__ __launch_bounds__(256, 2) void gdr_readout_rows_kernel(ReadoutArgs a)
+{
+    constexpr bool PAIR = FMT == FMT_PAIR16;
+    extern __shared__ __attribute__((aligned(16))) char ro_smem[];
+    char* s_q = ro_smem;                                   // [2][32][RO_QP]
+    char* s_r = ro_smem + 2 * 32 * RO_QP;                  // [2][32][RO_RP]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t fh = blockIdx.x;
+    const int h = (int)(fh % a.Hh), N = a.N, Dv = a.Dv, nsl = Dv / 16;
+    const size_t bt = fh / a.Hh;
+    const int c0 = (blockIdx.y * 4 + w) * 2;
+    const bool one = c0 < nsl, two = c0 + 1 < nsl;          // (a wave without columns still stages q rows and stores R rows: no early exit)
+    uint4 sb[2][4];                                        // [col tile][term*2 + ks]
+    {
+        const uint4* img = reinterpret_cast<const uint4*>(a.simg) + (fh * nsl + (one ? c0 : 0)) * 4 * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sb[c][i] = img[((c && two) ? 4 * 64 : 0) + i * 64];
+    }
+    const char* qbase = static_cast<const char*>(a.q) + ((bt * N * a.Hh + h) * GDKVM_DK) * 2;
+    const float* qinv = a.qinv + fh * a.NP;
+    const size_t rowq = (size_t)a.Hh * GDKVM_DK * 2, rowr = (size_t)a.Hh * Dv * 2;
+    const int col0 = 128 * (int)blockIdx.y;                 // first column of the workgroup
+    char* rbase = static_cast<char*>(a.r_out) + ((bt * N * a.Hh + h) * (size_t)Dv + col0) * 2;
+    const int nchunks = min(16, (Dv - col0) / 8);           // 16-byte pieces of a row that exist (Dv is a multiple of 16)
+    const int ntt_all = (N + 15) / 16, per_z = (ntt_all + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int tt0 = (int)blockIdx.z * per_z, ntt = min(ntt_all, tt0 + per_z);
+    if (tt0 >= ntt) return;                                 // (whole workgroup)
+    float sinv[2] = {OpFmt<FMT>::STATE_INV, OpFmt<FMT>::STATE_INV};
+    if constexpr (PAIR) {
+        const size_t bh = (fh / ((size_t)a.T * a.Hh)) * a.Hh + h;
+        const float* ep = a.esc + bh * ((nsl + 3) & ~3);
+        sinv[0] = ep[one ? c0 : 0];
+        sinv[1] = ep[two ? c0 + 1 : (one ? c0 : 0)];
+    }
+    // staging roles: thread -> (token of the pair, 16-byte piece of its q row)
+    const int q_tok = tid >> 3, q_pc = tid & 7;
+    auto fetch_q = [&](int tt) __attribute__((always_inline)) {
+        const int nq = min(16 * tt + q_tok, N - 1);
+        return *reinterpret_cast<const uint4*>(qbase + (size_t)nq * rowq + 16 * q_pc);
+    };
+    auto fetch_qi = [&](int tt, int j) __attribute__((always_inline)) { return qinv[min(16 * min(tt + j, ntt_all - 1) + li, a.NP - 1)]; };
+    uint4 qn = fetch_q(tt0);
+    float qi0 = fetch_qi(tt0, 0), qi1 = fetch_qi(tt0, 1);
+    *reinterpret_cast<uint4*>(s_q + q_tok * RO_QP + 16 * q_pc) = qn;
+    __syncthreads();
+    int par = 0;
+    for (int tt = tt0; tt < ntt; tt += 2, par ^= 1) {
+        const bool more = tt + 2 < ntt;
+        float qi_n0 = 0.f, qi_n1 = 0.f;
+        if (more) {
+            qn = fetch_q(tt + 2);
+            qi_n0 = fetch_qi(tt + 2, 0);
+            qi_n1 = fetch_qi(tt + 2, 1);
+        }
+        const char* sq = s_q + par * 32 * RO_QP;
+        char* sr = s_r + par * 32 * RO_RP;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (tt + j >= ntt || !one) continue;
+            const float qi = j ? qi1 : qi0;
+            uint4 qv[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qv[ks] = *reinterpret_cast<const uint4*>(sq + (16 * j + li) * RO_QP + 64 * ks + 16 * g);
+            float rscale = qi;
+            f16x8 qh[2];
+            if constexpr (PAIR) {
+                const float sc = pow2_floor(qi);
+                rscale = qi * pow2_inv(sc);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) qh[ks] = bf16x8_to_f16(__builtin_bit_cast(bf16x8, qv[ks]), sc);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (PAIR) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sb[c][2 + ks]), qh[ks], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, sb[c][ks]), qh[ks], acc1, 0, 0, 0);
+                    }
+                    acc0 *= PAIR_LO_INV;
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, sb[c][2 + ks]), __builtin_bit_cast(bf16x8, qv[ks]), acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, sb[c][ks]), __builtin_bit_cast(bf16x8, qv[ks]), acc1, 0, 0, 0);
+                    }
+                }
+                const f32x4 accR = (acc0 + acc1) * (rscale * sinv[c]);
+                if (c == 0 || two)
+                    *reinterpret_cast<uint2*>(sr + (16 * j + li) * RO_RP + (2 * w + c) * 32 + 8 * g) =
+                        make_uint2(cvt_pk_bf16(accR[0], accR[1]), cvt_pk_bf16(accR[2], accR[3]));
+            }
+        }
+        if (more) *reinterpret_cast<uint4*>(s_q + (par ^ 1) * 32 * RO_QP + q_tok * RO_QP + 16 * q_pc) = qn;
+        __syncthreads();
+        // the pair's R rows: 32 tokens x 16 pieces of 16 bytes; thread -> pieces tid and tid + 256 (a wave: four whole row pieces of 256 bytes)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int id = tid + 256 * r, row = id >> 4, pc = id & 15;
+            const int nr = 16 * tt + row;
+            if (16 * tt + row < 16 * ntt && nr < N && pc < nchunks)
+                *reinterpret_cast<uint4*>(rbase + (size_t)nr * rowr + 16 * pc) = *reinterpret_cast<const uint4*>(sr + row * RO_RP + 16 * pc);
+        }
+        qi0 = qi_n0;
+        qi1 = qi_n1;
     }
 }
 
@@ -619,10 +757,13 @@ extern "C" int gdkvm_scan_apply(const void* q, const float* alpha, const float* 
             while (wg * nz < 2L * cus && 2 * nz <= (unsigned)(ntt / 2)) nz *= 2;       // (at least two token tiles per workgroup)
         }
         const dim3 rgrid((unsigned)(B * T * Hh), ny, nz);
+        static const bool rows_form = !getenv("GDKVM_READOUT_PLAIN");           // (diagnostic: the round-5 kernel for bf16 I/O too)
         if (io_dtype == GDKVM_F32 && wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
         else if (io_dtype == GDKVM_F32) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_F32, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
-        else if (wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
-        else hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
+        else if (!rows_form && wide) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_SPLIT3>), rgrid, dim3(256), 0, st, ra);
+        else if (!rows_form) hipLaunchKernelGGL((gdr_readout_kernel<GDKVM_BF16, FMT_PAIR16>), rgrid, dim3(256), 0, st, ra);
+        else if (wide) hipLaunchKernelGGL((gdr_readout_rows_kernel<FMT_SPLIT3>), rgrid, dim3(256), RO_LDS, st, ra);
+        else hipLaunchKernelGGL((gdr_readout_rows_kernel<FMT_PAIR16>), rgrid, dim3(256), RO_LDS, st, ra);
         GDKVM_LAUNCH_CHECK("gdr_readout_kernel");
     }
     return GDKVM_OK;
