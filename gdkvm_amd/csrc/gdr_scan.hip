@@ -830,6 +830,9 @@ extern "C" int gdkvm_scan_transition(const void* q, const float* alpha, float* p
 // one workgroup per (clip, head, 16-column slice), wave w owning row tile w; exact fp32 MFMA.  The four accumulator tiles are
 // exchanged through LDS as lane-linear images, which ARE the B operand under the k permutation "register r of lane (li, g) of
 // image m is k = 16m + 4g + r" (the same trick as the scan's exact read-out); double-buffered by segment parity: one barrier each.
+// 13.9 us for 16 segments at cfg5 (0.87 us per step).  Not the operands' round trip: requested one segment ahead, or four ahead in a ring of
+// register sets behind a raw LDS-only barrier, the kernel took 13.9 / 14.5 us (round 6) -- a step is 16 dependent fp32 MFMAs (32 cycles
+// each), the image exchange through LDS and four strided stores, on 32 workgroups; left in its simple form.
 __global__ __launch_bounds__(256) void gdr_stitch_kernel(const float* phi, const float* s_loc, const float* s_in, float* starts, float* s_end,
                                                           int S, int Hh, int Dv)
 {
