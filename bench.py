@@ -338,11 +338,11 @@ def run_train(args, world, rank, dev, steps, warmup):
             # (what train.py's loader delivers since round 6: uint8 frames and uint8 labels, 26 MB per batch instead of 128 MB of fp32 / int64)
             hostb = [(frames_u8.clone().pin_memory(), target.cpu().to(torch.uint8).pin_memory()) for _ in range(2)]
             step2 = (lambda f, t: gstep(f, t)) if graphed else (lambda f, t: train_step(ddp, opt, f, t, torch.bfloat16, sync))
-            kp, wp = max(steps, 8), 4
+            kp, wp = max(steps, 20), 4
             passes = []
             for _pass in range(2):                           # two passes, the faster one is reported: a one-off stall (a first allocation on
                 n_ = 0                                       # the copy stream's pool, a page-locking call) is not the loop's rate
-                for f_, t_ in DevicePrefetcher((hostb[i % 2] for i in range(wp + kp)), dev, slots=2, frames_dtype=torch.float32):
+                for f_, t_ in DevicePrefetcher((hostb[i % 2] for i in range(wp + kp)), dev, slots=3, frames_dtype=torch.float32):
                     if n_ == wp:
                         torch.cuda.synchronize(); tp0 = time.perf_counter()
                     loss = step2(f_, t_)
@@ -360,7 +360,7 @@ def run_train(args, world, rank, dev, steps, warmup):
     # (round 4's graphed line reported a loss ~10x behind the eager one: weight packs keyed on version counters the fused optimiser does
     # not bump; round 5: every kernel of the step is deterministic, so the two agree to the optimisers' own rounding)
     final_eager = None
-    if world == 1 and sync is None and n_opt <= 64:
+    if world == 1 and sync is None and n_opt <= 160:
         torch.manual_seed(3)
         twin = GDKVM(cfg).train().to(dev).to(memory_format=torch.channels_last)
         opt2 = torch.optim.AdamW(twin.parameters(), lr=1.0e-4)
@@ -708,7 +708,7 @@ def main():
         if world == 1 and not args.no_user_path_legs:
             try:
                 from gdkvm_amd.pipeline import DevicePrefetcher
-                nb, warm_p, k_p = 6, 6, 30
+                nb, warm_p, k_p = 6, 30, 90            # (30 untimed batches: the two captures, and the clock ramp after the set-up's idle gaps -- config.prewarm)
                 host = [((clips(5000 + i, B) * 255).to(torch.uint8).pin_memory(), torch.zeros(16, dtype=torch.uint8).pin_memory()) for i in range(nb)]
                 feed = (host[i % nb] for i in range(warm_p + k_p))
                 # the link alone: the same pinned batches copied host-to-device with nothing else running (what bounds the loop below when
@@ -720,8 +720,8 @@ def main():
                 torch.cuda.synchronize()
                 h2d_alone = 2 * nb * host[0][0].numel() / (time.perf_counter() - tl0) / 1e9
                 del dst_
-                # eval.py's path: SegmentRunner captures one graph over each of the prefetcher's per-slot buffers (one memory pool), so a
-                # batch is copy (side stream) -> cast (side stream) -> replay, with nothing copied on the compute stream
+                # eval.py's path: SegmentRunner keeps two forwards in flight (two captured graphs used in turn on two streams); a batch is
+                # copy (copy stream) -> cast (cast stream) -> copy into the graph's buffers + replay (that forward's stream)
                 from gdkvm_amd.pipeline import SegmentRunner
                 runner = SegmentRunner(model, graph=launch.startswith("one hipGraph"), min_repeats=1)
                 pre = DevicePrefetcher(feed, dev, slots=3, frames_dtype=torch.bfloat16)
@@ -741,8 +741,9 @@ def main():
                                    "h2d_GBps": round((pre.h2d_bytes - b0) / dt_p / 1e9, 2),
                                    "h2d_alone_GBps": round(h2d_alone, 2),      # (pinned -> device copies of the same batches, nothing else running)
                                    "what": f"configs[1] forward fed from {nb} pinned host batches of uint8 frames ({host[0][0].numel() / 1e6:.1f} MB each): "
-                                           "host-to-device copy and uint8 -> bf16 / 255 on a side stream (DevicePrefetcher, 3 slots), then one hipGraph replay captured "
-                                           f"over the slot's buffer (no further copy), {runner.in_flight} forward(s) in flight (SegmentRunner: eval.py's path; "
+                                           "host-to-device copy on a side stream, uint8 -> bf16 / 255 on another (DevicePrefetcher, 3 slots, one kept free), "
+                                           + ("copy into the graph's input buffers and one hipGraph replay, " if runner.in_flight > 1 else "one hipGraph replay captured over the slot's buffer (no further copy), ")
+                                           + f"{runner.in_flight} forward(s) in flight, results collected one batch behind (SegmentRunner: eval.py's path; "
                                            f"{runner.captures} captures, {runner.replays} replays, {runner.eager_calls} eager calls) -- all inside the timed loop",
                                    "vs_resident_inputs": round((B * T * k_p / dt_p) / value, 3)}
                 del host, pre, runner

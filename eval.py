@@ -55,13 +55,12 @@ def main(argv=None):
     # ONE captured forward per batch shape (SegmentRunner -> GraphedSegment: a hipGraph replay per batch; the short last batch runs eagerly)
     dl = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, range(lo, hi)), batch_size=cfg.batch_size, shuffle=False, num_workers=2, pin_memory=True)
     fdt = torch.bfloat16 if cfg.precision == "bf16" else torch.float32
-    runner = SegmentRunner(model, graph=os.environ.get("GDKVM_FWD_GRAPH", "1") != "0", in_flight=int(os.environ.get("GDKVM_FWD_IN_FLIGHT", "1")))
+    runner = SegmentRunner(model, graph=os.environ.get("GDKVM_FWD_GRAPH", "1") != "0", in_flight=int(os.environ.get("GDKVM_FWD_IN_FLIGHT", "2")))
     i = lo
 
     def batches():
         """(mask, counts) per batch, one batch behind the submissions: the host queues batch i + 1 (copy, cast, replay) before it reads
-        batch i's result.  GDKVM_FWD_IN_FLIGHT=2: two forwards in flight on two streams (SegmentRunner(in_flight=2): faster with the batches
-        already in HBM, slower behind a host-fed prefetcher -- see its docstring)"""
+        batch i's result, and two forwards are in flight (SegmentRunner(in_flight=2); GDKVM_FWD_IN_FLIGHT=1: one at a time)"""
         pending = None
         for frames, target in DevicePrefetcher(dl, dev, slots=3, frames_dtype=fdt, target_dtype=torch.uint8):
             nxt = runner.submit(frames, target)

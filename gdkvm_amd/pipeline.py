@@ -9,6 +9,7 @@ path lives here; the one computation is the uint8 -> [0, 1] cast of frames a loa
 the float32 bytes cross PCIe)."""
 from __future__ import annotations
 
+import os
 import sys
 import warnings
 from typing import Iterable, Iterator, Optional, Tuple
@@ -24,25 +25,34 @@ class DevicePrefetcher:
     float frames are cast; targets keep their dtype unless `target_dtype` is given -- the casts run on the COPY stream, right behind the
     batch's transfer, into per-slot buffers: the consumer's stream receives finished tensors and spends nothing on them.  Yields
     (frames, target) device tensors that stay valid until the NEXT next().
+    ONE slot is kept free: slots - 1 batches are staged ahead, so the slot a new batch is staged into was handed out TWO iterations ago.
+    (Round 6: with every slot staged or in use, the copy into a slot waited for the forward launched a moment earlier; the host sat in that
+    wait -- the runtime resolves a copy's wait on an unfinished event on the HOST -- and launched the next forward only when the previous one
+    had finished: one launch latency of GPU idle time per batch, 1.04 against 0.96 ms.)
     threaded=True: the loader is iterated and the batches are staged by a WORKER THREAD (a slot goes back to the worker when the consumer asks
     for the next batch; an exception in the loader or the staging is re-raised in the consumer).  Off by default: measured at the EchoNet
     shape it is SLOWER (1.23 against 1.05 ms per batch, profiles/r06_v_pipeline_probe.txt) -- the loop is not bound by host work (a graph
     launch is 0.17 ms, the staging calls ~0.1 ms) but by the host-to-device copies themselves, which take 2-3x their stand-alone time
     beside the forward's kernels; a second thread only adds hand-offs.  Useful when the LOADER is slow (decoding in the main process)."""
 
-    def __init__(self, loader: Iterable, device: torch.device, slots: int = 2, frames_dtype: Optional[torch.dtype] = None,
+    def __init__(self, loader: Iterable, device: torch.device, slots: int = 3, frames_dtype: Optional[torch.dtype] = None,
                  target_dtype: Optional[torch.dtype] = None, threaded: bool = False):
         if slots < 2:
             raise ValueError("DevicePrefetcher needs at least two slots")
         self.loader, self.device, self.slots, self.threaded = loader, device, slots, threaded
         self.frames_dtype, self.target_dtype = frames_dtype, target_dtype
         self.stream = torch.cuda.Stream(device=device)
+        # the casts run on a stream of their OWN (round 6): behind the copy on the copy stream, every batch made the DMA engine wait for a
+        # small kernel that itself waits for room beside the forward's kernels -- copy, cast, copy in one queue ran at 0.53 ms per 19 MB batch
+        # with nothing else on the GPU and ~0.75 ms beside the forward, against 0.36 ms for the copies alone
+        self.cast_stream = torch.cuda.Stream(device=device) if os.environ.get("GDKVM_PREFETCH_CAST_STREAM", "1") != "0" else self.stream
         self._pinned = [None] * slots           # per slot: the page-locked (frames, target) its copy in flight reads (kept alive)
         self._stage_buf = [None] * slots        # per slot: this class's own pinned staging buffers, re-used while the shape holds
         self._dev = [None] * slots
         self._free = [None] * slots             # event: the consumer is done with this slot's device buffers
         self._copied = [None] * slots           # event: the slot's last host-to-device copy
-        self._conv = [None] * slots             # per slot: the cast frames / target (written on the copy stream)
+        self._conv = [None] * slots             # per slot: the cast frames / target (written on the cast stream)
+        self._cast_done = [None] * slots        # event: the slot's last cast (reads the raw device buffers the next copy overwrites)
         self.h2d_bytes = 0
 
     def _stage(self, slot: int, batch) -> Tuple[torch.Tensor, torch.Tensor, torch.cuda.Event]:
@@ -67,13 +77,21 @@ class DevicePrefetcher:
         with torch.cuda.stream(self.stream):
             if self._free[slot] is not None:
                 self.stream.wait_event(self._free[slot])
+            if self._cast_done[slot] is not None and self.cast_stream is not self.stream:
+                self.stream.wait_event(self._cast_done[slot])          # (the slot's raw buffers were last read by its previous cast)
             dev[0].copy_(pin[0], non_blocking=True)
             dev[1].copy_(pin[1], non_blocking=True)
             copied = torch.cuda.Event()
             copied.record(self.stream)            # (the pinned buffers are free again once this has passed)
+        with torch.cuda.stream(self.cast_stream):
+            if self.cast_stream is not self.stream:
+                self.cast_stream.wait_event(copied)
+                if self._free[slot] is not None:
+                    self.cast_stream.wait_event(self._free[slot])      # (the cast buffers of the slot are the consumer's inputs)
             out_f, out_t = self._convert(slot, dev[0], dev[1])
             ev = torch.cuda.Event()
-            ev.record(self.stream)
+            ev.record(self.cast_stream)
+            self._cast_done[slot] = ev
         self._copied[slot] = copied
         self.h2d_bytes += frames.numel() * frames.element_size() + target.numel() * target.element_size()
         return out_f, out_t, ev
@@ -91,9 +109,10 @@ class DevicePrefetcher:
                                        torch.empty(target.shape, dtype=tdt, device=self.device) if tdt != target.dtype else None)
         out_f, out_t = frames, target
         if conv[0] is not None:
-            conv[0].copy_(frames)                 # (the cast)
             if frames.dtype == torch.uint8:
-                conv[0].mul_(1.0 / 255.0)
+                torch.mul(frames, 1.0 / 255.0, out=conv[0])    # (ONE pass: fp32(byte) * fp32(1/255), rounded once to the buffer's dtype)
+            else:
+                conv[0].copy_(frames)             # (the cast)
             out_f = conv[0]
         if conv[1] is not None:
             conv[1].copy_(target)
@@ -118,8 +137,8 @@ class DevicePrefetcher:
         for batch in self.loader:
             queue.append((slot,) + self._stage(slot, batch))
             slot = (slot + 1) % self.slots
-            if len(queue) < self.slots:
-                continue                         # slots - 1 copies stay in flight behind the batch being computed
+            if len(queue) < max(self.slots - 1, 1):
+                continue                         # slots - 2 copies stay in flight behind the batch being computed, ONE slot stays free (below)
             yield from self._hand_out(queue)
         while queue:
             yield from self._hand_out(queue)
@@ -189,20 +208,19 @@ class SegmentRunner:
     """model.segment(frames, target) for a stream of batches: captured GraphedSegments per batch shape (the full batches of a split), an eager
     call -- said on stderr when a capture fails -- for shapes seen fewer than `min_repeats` times (the last, short batch).
 
-    in_flight = 1 (default): one forward at a time, two groups of clips on two streams inside the graph; zero_copy captures a graph OVER each
+    in_flight = 2 (default): TWO forwards in flight -- `in_flight` captures per shape (a single stream inside each, a memory pool of its own),
+    used in turn, each replayed on a host stream of its own: batch i + 1 starts while batch i is still running.  submit() copies the batch
+    into the graph's input buffers on that stream, makes the CALLER's stream wait for that copy only (so the batch's source -- a
+    DevicePrefetcher slot -- is free again as soon as the copy has run, not when the forward has), replays, and returns a handle; get() on
+    the handle makes the caller's stream wait for the result.  Keep one batch of lag between submit and get (eval.py does) or call the
+    runner directly (`runner(frames, target)` = submit().get(): no overlap).  Batches already in HBM: 0.81 against 0.875 ms per 16 x 32
+    frames (model.InFlightSegments, bench.py's timed loop); fed from pinned host memory through a DevicePrefetcher: 0.89 against 0.96-0.99
+    (tools/pipeline_trace.py, profiles/r06_aj_pipeline_slack.txt).
+    in_flight = 1: one forward at a time, two groups of clips on two streams inside the graph; zero_copy then captures a graph OVER each
     distinct input buffer (a DevicePrefetcher's slots) in one memory pool, so a batch is a bare replay with no copy (up to `max_graphs` per
-    shape; beyond that the batch is copied into the first graph's buffers).  The faster form when the batches come from HOST memory through
-    a DevicePrefetcher (bench.py's `pipeline` leg: 444-456 k frames/s against 358-390 k with in_flight = 2 -- the H2D copy and the cast
-    already fill the gaps a second forward in flight would use, and that form copies each batch once more).
-    in_flight = 2: TWO forwards in flight -- `in_flight` captures per shape (a single stream inside each, a memory pool of its own), used in
-    turn, each replayed on a host stream of its own: batch i + 1 starts while batch i is still running.  The faster form when the batches are
-    ALREADY in HBM (0.81-0.82 against 0.87-0.88 ms per 16 x 32 frames: model.InFlightSegments, bench.py's timed loop).  submit() copies the
-    batch into the graph's input buffers on that stream, makes the CALLER's stream wait for that copy only (so the batch's source is free
-    again as far as the caller's stream is concerned), replays, and returns a handle; get() on the handle makes the caller's stream wait for
-    the result.  Keep one batch of lag between submit and get (eval.py does) or call the runner directly (`runner(frames, target)` =
-    submit().get(): no overlap)."""
+    shape; beyond that the batch is copied into the first graph's buffers) -- but the slot stays taken until the forward has finished."""
 
-    def __init__(self, model, graph: bool = True, min_repeats: int = 2, zero_copy: bool = True, max_graphs: int = 4, in_flight: int = 1):
+    def __init__(self, model, graph: bool = True, min_repeats: int = 2, zero_copy: bool = True, max_graphs: int = 4, in_flight: int = 2):
         self.model, self.graph, self.min_repeats, self.zero_copy, self.max_graphs = model, graph, min_repeats, zero_copy, max_graphs
         self.in_flight = max(1, in_flight)
         self._graphs, self._seen, self._streams, self._turn = {}, {}, None, {}

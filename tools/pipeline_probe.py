@@ -19,7 +19,7 @@ def main():
     host = [(torch.randint(0, 256, (16, 32, 3, 112, 112), dtype=torch.uint8).pin_memory(), torch.zeros(16, dtype=torch.uint8).pin_memory()) for _ in range(6)]
     for label, body, thr in (("prefetch only", lambda r, f: None, False), ("prefetch + replay", lambda r, f: r(f), False),
                              ("prefetch + replay (worker thread)", lambda r, f: r(f), True)):
-        runner = SegmentRunner(model, min_repeats=1)
+        runner = SegmentRunner(model, min_repeats=1, in_flight=int(os.environ.get("PROBE_IN_FLIGHT", "1")))
         pre = DevicePrefetcher((host[i % 6] for i in range(46)), dev, slots=3, frames_dtype=torch.bfloat16, threaded=thr)
         n, host_s, next_s = 0, 0.0, 0.0
         it = iter(pre)

@@ -32,15 +32,16 @@ def main():
     feeds = {"float32 frames + int64 labels (128 MB)": [(frames.cpu().pin_memory(), target.cpu().pin_memory()) for _ in range(2)],
              "uint8 frames + uint8 labels (26 MB)": [(u8.clone().pin_memory(), target.cpu().to(torch.uint8).pin_memory()) for _ in range(2)]}
     for name, hostb in feeds.items():
-        for slots in (2, 3):
-            n = 0
-            for f, t in DevicePrefetcher((hostb[i % 2] for i in range(14)), dev, slots=slots, frames_dtype=torch.float32):
-                if n == 4:
-                    torch.cuda.synchronize(); t0 = time.perf_counter()
-                g(f, t)
-                n += 1
-            torch.cuda.synchronize()
-            print(f"{name}, {slots} slots: {1e2 * (time.perf_counter() - t0):.3f} ms per step", flush=True)
+        for slots in (2, 3, 4):
+            for rep in range(2):
+                n = 0
+                for f, t in DevicePrefetcher((hostb[i % 2] for i in range(24)), dev, slots=slots, frames_dtype=torch.float32):
+                    if n == 4:
+                        torch.cuda.synchronize(); t0 = time.perf_counter()
+                    g(f, t)
+                    n += 1
+                torch.cuda.synchronize()
+                print(f"{name}, {slots} slots: {1e3 * (time.perf_counter() - t0) / 20:.3f} ms per step", flush=True)
 
 
 if __name__ == "__main__":

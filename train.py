@@ -72,7 +72,7 @@ def main(argv=None):
         if sampler is not None:
             sampler.set_epoch(epoch)
         # host batches staged through pinned memory and copied on a side stream while the previous step computes (DevicePrefetcher)
-        for frames, target in DevicePrefetcher(dl, dev, slots=2, frames_dtype=torch.float32):
+        for frames, target in DevicePrefetcher(dl, dev, slots=3, frames_dtype=torch.float32):
             if train_one is None:
                 # the step in the form bench.py measures: one hipGraph replay (forward + backward + gradient all-reduce node + fused AdamW);
                 # a capture that fails falls back to the eager DistributedDataParallel step, loudly
