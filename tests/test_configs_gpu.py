@@ -309,3 +309,39 @@ def test_cfg5_module_long_clip_in_chunks_with_the_state_carried(hip):
     torch.cuda.synchronize()
     assert (sseg - s32).abs().max().item() <= 1e-3 * max(1.0, s32.abs().max().item())
     assert (mseg == m32).float().mean().item() >= 0.999
+
+
+def test_readout_rows_form_is_bit_identical_to_the_plain_kernel(hip, tmp_path):
+    """Frames of more than 64 tokens, bf16 I/O: the deferred read-out moves q and R through LDS as whole rows (gdr_readout_rows_kernel, round 6);
+    GDKVM_READOUT_PLAIN=1 (read once per process) keeps round 5's kernel.  Same arithmetic, same order: R and the state bit for bit -- on even and
+    odd counts of 16-column tiles (Dv 256 / 272: the last workgroup's waves without columns), a ragged token count, two heads, both operand formats
+    (flags 3 / wide range), and few frames (the token tiles split over several workgroups)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from gdkvm_amd import ops
+out = {}
+for i, (B, T, N, Hh, Dv, flags) in enumerate([(2, 6, 256, 1, 256, 3), (1, 3, 200, 2, 272, 3), (3, 5, 130, 1, 48, 3 | 8), (1, 2, 1024, 1, 256, 3)]):
+    g = torch.Generator(device="cuda").manual_seed(100 + i)
+    q, k = (torch.randn(B, T, N, Hh, 64, device="cuda", generator=g).bfloat16() for _ in range(2))
+    v = torch.randn(B, T, N, Hh, Dv, device="cuda", generator=g).bfloat16()
+    al = 2 + torch.randn(B, T, Hh, device="cuda", generator=g); be = torch.randn(B, T, N, Hh, device="cuda", generator=g)
+    r, s = ops.scan_fwd(q, k, v, al, be, flags=flags)
+    out[i] = (r.cpu(), s.cpu())
+torch.save(out, sys.argv[1])
+''' % root
+    files = {}
+    for form, env in (("rows", {}), ("plain", {"GDKVM_READOUT_PLAIN": "1"})):
+        files[form] = str(tmp_path / f"{form}.pt")
+        e = {k: v for k, v in os.environ.items() if k != "GDKVM_READOUT_PLAIN"}
+        e.update(env)
+        subprocess.run([sys.executable, "-c", script, files[form]], check=True, env=e, timeout=300)
+    rows, plain = torch.load(files["rows"]), torch.load(files["plain"])
+    assert len(rows) == 4
+    for i in rows:
+        assert torch.isfinite(rows[i][0].float()).all()
+        assert torch.equal(rows[i][0], plain[i][0]) and torch.equal(rows[i][1], plain[i][1]), i
