@@ -16,8 +16,10 @@ def main():
     torch.manual_seed(0)
     dev = torch.device("cuda")
     model = GDKVM(GDKVMConfig()).eval().fuse_for_inference().to(dev).to(torch.bfloat16).to(memory_format=torch.channels_last)
-    frames = [torch.rand(16, 32, 3, 112, 112, device=dev).bfloat16() for _ in range(4)]
-    for inner in (2, 1):
+    clips = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    frames = [torch.rand(clips, 32, 3, 112, 112, device=dev).bfloat16() for _ in range(4)]
+    print(f"{clips} clips per forward", flush=True)
+    for inner in ((2, 1) if clips >= 16 else (1,)):
         gs = [GraphedSegment(model, f, streams=inner) for f in frames]          # (own pools)
         ref = [g(f)[0].clone() for g, f in zip(gs, frames)]
         ss = [torch.cuda.Stream() for _ in range(4)]
