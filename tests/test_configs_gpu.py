@@ -345,3 +345,55 @@ torch.save(out, sys.argv[1])
     for i in rows:
         assert torch.isfinite(rows[i][0].float()).all()
         assert torch.equal(rows[i][0], plain[i][0]) and torch.equal(rows[i][1], plain[i][1]), i
+
+
+@pytest.mark.parametrize("name,B,T,N", [("cfg2", 16, 32, 49), ("cfg3", 8, 20, 256), ("cfg5", 2, 512, 256)])
+def test_full_size_linearity_in_values_and_queries(hip, name, B, T, N):
+    """Size-independent properties at BASELINE's FULL sizes, no oracle involved (fp32 I/O, every rule's default delta_sequential): for fixed
+    keys and gates the whole path is LINEAR in the values -- scan(v1 + 2 v2) = scan(v1) + 2 scan(v2) for the read-outs of every frame and the
+    final state -- and, without the query normalisation, the LKVA read is linear in the queries.  A summation order or an operand-format slip
+    that an oracle comparison at small sizes cannot see (the 512-frame clip, the chunked 256-token frames) breaks these at once."""
+    Hh, Dk, Dv = 1, 64, 256
+    q, k, v1, a, b = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=41, normalized=True, logits=False, corr=0.3)
+    v2 = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=42)[2]
+    q2 = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=43, normalized=False)[0]
+    dq, dk, da, db = _dev(q), _dev(k), _dev(a), _dev(b)
+    R1, S1 = hip.scan_fwd(dq, dk, _dev(v1), da, db, flags=0)
+    R2, S2 = hip.scan_fwd(dq, dk, _dev(v2), da, db, flags=0)
+    R12, S12 = hip.scan_fwd(dq, dk, _dev(v1 + 2.0 * v2), da, db, flags=0)
+    scale = max(1.0, float(R12.abs().max()))
+    assert float((R12 - (R1 + 2.0 * R2)).abs().max()) <= 2e-4 * scale, name
+    assert float((S12 - (S1 + 2.0 * S2)).abs().max()) <= 2e-4 * max(1.0, float(S12.abs().max())), name
+    assert float(R12.abs().max()) > 0.1 and torch.isfinite(R12).all()
+    # linear in q (flags = 0: keys and queries used as given): R(q + 3 q2) = R(q) + 3 R(q2); the state does not depend on q at all
+    Rq2, Sq2 = hip.scan_fwd(_dev(q2), dk, _dev(v1), da, db, flags=0)
+    Rsum, Ssum = hip.scan_fwd(_dev(q + 3.0 * q2), dk, _dev(v1), da, db, flags=0)
+    assert float((Rsum - (R1 + 3.0 * Rq2)).abs().max()) <= 2e-4 * max(1.0, float(Rsum.abs().max())), name
+    assert torch.equal(Sq2, S1) and torch.equal(Ssum, S1), name
+
+
+@pytest.mark.parametrize("BT,ncls,H,W", [(512, 2, 112, 112), (160, 4, 256, 256)])
+def test_full_size_mask_kernel_count_identities(hip, BT, ncls, H, W):
+    """The mask kernels at BASELINE's full sizes (configs[1]: 512 frames of 112 x 112, 2 classes; configs[2]: 160 frames of 256 x 256, 4 classes),
+    through identities every correct result obeys -- no oracle: each pixel is predicted exactly once (sum of |A_c| = H W per frame), each
+    in-range label counted once (sum of |B_c| = labelled pixels), |A_c n B_c| <= min(|A_c|, |B_c|), the counts are those of the returned mask
+    recounted with torch, the fused low-resolution form returns the same mask as upsampling first, and a target equal to the mask gives Dice 1."""
+    g = torch.Generator(device="cuda").manual_seed(H + ncls)
+    lo = torch.randn(BT, ncls, H // 4, W // 4, device="cuda", generator=g)
+    target = torch.randint(0, ncls + 1, (BT, H, W), device="cuda", generator=g, dtype=torch.uint8)       # (label ncls = out of range: ignored)
+    mask, counts = hip.upsample_argmax_dice(lo, H, W, target)
+    c = counts.long()
+    assert torch.equal(c[..., 1].sum(1), torch.full((BT,), H * W, device="cuda"))
+    assert torch.equal(c[..., 2].sum(1), (target < ncls).flatten(1).sum(1))
+    assert (c[..., 0] <= torch.minimum(c[..., 1], c[..., 2])).all() and (c >= 0).all()
+    for cl in range(ncls):
+        a, b = mask == cl, target == cl
+        assert torch.equal(c[:, cl, 1], a.flatten(1).sum(1)) and torch.equal(c[:, cl, 2], b.flatten(1).sum(1))
+        assert torch.equal(c[:, cl, 0], (a & b).flatten(1).sum(1))
+    up = torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear", align_corners=False)
+    m2, c2 = hip.argmax_dice(up, target)
+    decided = (up.topk(2, dim=1).values[:, 0] - up.topk(2, dim=1).values[:, 1]) > 1e-5           # (away from ties the two forms must agree)
+    assert torch.equal(m2[decided], mask[decided]) and decided.float().mean() > 0.999
+    m3, c3 = hip.upsample_argmax_dice(lo, H, W, mask)
+    assert torch.equal(m3, mask) and torch.equal(c3[..., 0], c3[..., 1]) and torch.equal(c3[..., 1], c3[..., 2])
+    assert torch.allclose(hip.dice_from_counts(c3.sum(0)), torch.ones(ncls, dtype=torch.float64, device="cuda"))
