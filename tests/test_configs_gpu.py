@@ -6,7 +6,7 @@ import torch
 
 from oracle import c_oracle
 from oracle import gdkvm_oracle as O
-from tests.util import make_scan_inputs
+from tests.util import make_kpff_inputs, make_scan_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -397,3 +397,27 @@ def test_full_size_mask_kernel_count_identities(hip, BT, ncls, H, W):
     m3, c3 = hip.upsample_argmax_dice(lo, H, W, mask)
     assert torch.equal(m3, mask) and torch.equal(c3[..., 0], c3[..., 1]) and torch.equal(c3[..., 1], c3[..., 2])
     assert torch.allclose(hip.dice_from_counts(c3.sum(0)), torch.ones(ncls, dtype=torch.float64, device="cuda"))
+
+
+@pytest.mark.parametrize("BT,h,w", [(512, 7, 7), (160, 16, 16)])
+def test_full_size_kpff_frames_are_independent(hip, BT, h, w):
+    """KPFF at BASELINE's full sizes (configs[1]: 512 frames of 7 x 7 tokens; configs[2]: 160 of 16 x 16; 64 / 256 / 256 channels, bf16): frames
+    never interact, so the call over all frames equals the calls over any split of them bit for bit (the kernel pairs frames per workgroup and
+    walks them persistently: an index slip shows here), three frames of the full call match the oracle on their own inputs, and zero mixing
+    weights return the pixel feature itself."""
+    Ck, Cv, Cp = 64, 256, 256
+    L, G, P, Wa, ba, Wl, Wg = make_kpff_inputs(BT, h, w, Ck, Cv, Cp, seed=BT + h)
+    dl, dg, dp = (_dev(x, torch.bfloat16) for x in (L, G, P))
+    wts = [_dev(x) for x in (Wa, ba, Wl, Wg)]
+    F = hip.kpff_fwd(dl, dg, dp, *wts, h, w)
+    cut = 101                                              # (odd: the second part starts in the middle of a frame pair)
+    Fa = hip.kpff_fwd(dl[:cut].contiguous(), dg[:cut].contiguous(), dp[:cut].contiguous(), *wts, h, w)
+    Fb = hip.kpff_fwd(dl[cut:].contiguous(), dg[cut:].contiguous(), dp[cut:].contiguous(), *wts, h, w)
+    assert torch.equal(F[:cut], Fa) and torch.equal(F[cut:], Fb)
+    for f in (0, BT // 2 + 1, BT - 1):
+        Fo = c_oracle.kpff(O.to_bf16_f32(L[f:f + 1]), O.to_bf16_f32(G[f:f + 1]), O.to_bf16_f32(P[f:f + 1]), O.to_bf16_f32(Wa), ba,
+                           O.to_bf16_f32(Wl), O.to_bf16_f32(Wg), h, w)
+        err = np.abs(F[f:f + 1].float().cpu().numpy() - Fo)
+        assert np.all(err <= 4e-3 + np.abs(Fo) * 2.0 ** -8), (f, err.max())
+    F0 = hip.kpff_fwd(dl, dg, dp, wts[0], wts[1], 0 * wts[2], 0 * wts[3], h, w)
+    assert torch.equal(F0, dp)
