@@ -545,3 +545,26 @@ def test_graph_replays_zero_the_dice_counts_every_time(hip):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, ref), r
+
+
+def test_full_size_forward_clips_are_independent(hip):
+    """configs[1] at its full size (16 clips x 32 frames x 112 x 112, bf16, the fused inference build): clips never interact, so the forward over
+    the whole batch equals the forwards over any split of it BIT FOR BIT -- stride-4 logits and masks -- although the kernels' grids, tile walks
+    and launch forms change with the batch (5 + 1 + 10 clips against 16).  The property the clip sharding over GPUs (distributed.shard_range)
+    and the graph's groups of clips rest on."""
+    from gdkvm_amd.model import GDKVM, GDKVMConfig
+    torch.manual_seed(7)
+    model = GDKVM(GDKVMConfig()).cuda().eval().to(memory_format=torch.channels_last)
+    x = torch.rand(16, 32, 3, 112, 112, device="cuda").bfloat16()
+    with torch.no_grad():
+        lg = model(x[:4].float(), _lowres=True)
+        model.decoder.head.bias[1] += (lg[:, :, 0] - lg[:, :, 1]).median()
+    model = model.fuse_for_inference().to(torch.bfloat16)
+    with torch.no_grad():
+        full = model.segment(x)[0].clone()
+        assert 0.1 < (full != 0).float().mean().item() < 0.9
+        parts = torch.cat([model.segment(x[a:b].contiguous())[0].clone() for a, b in ((0, 5), (5, 6), (6, 16))])
+        assert torch.equal(full, parts)
+        lo = model(x, _lowres=True).clone()
+        lo_parts = torch.cat([model(x[a:b].contiguous(), _lowres=True).clone() for a, b in ((0, 5), (5, 16))])
+        assert torch.equal(lo, lo_parts)
