@@ -421,3 +421,27 @@ def test_full_size_kpff_frames_are_independent(hip, BT, h, w):
         assert np.all(err <= 4e-3 + np.abs(Fo) * 2.0 ** -8), (f, err.max())
     F0 = hip.kpff_fwd(dl, dg, dp, wts[0], wts[1], 0 * wts[2], 0 * wts[3], h, w)
     assert torch.equal(F0, dp)
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+@pytest.mark.parametrize("B,T,N", [(16, 32, 49), (8, 20, 256)])
+def test_full_size_token_order_does_not_matter_for_the_parallel_rules(hip, rule, B, T, N):
+    """Rules gated_linear (0) and delta_parallel (1) write every token of a frame against the SAME incoming state: permuting the tokens inside the
+    frames must leave the final state unchanged (to fp32 re-association) and permute the read-outs with them -- at configs[1] and configs[2] full
+    sizes, where the 256-token frames go through the chunk maps (composed additively for rule 1).  delta_sequential, the default, is order
+    DEPENDENT by definition (raster order) and is checked to be so."""
+    Hh, Dk, Dv = 1, 64, 256
+    q, k, v, a, b = make_scan_inputs(B, T, N, Hh, Dk, Dv, seed=51 + rule, normalized=True, logits=False, corr=0.3)
+    if rule == 1:
+        b = (b * (0.5 / N ** 0.5)).astype(np.float32)     # (the parallel delta rule is not contractive: small write gates keep the 20 / 32 frames bounded)
+    perm = np.random.default_rng(9).permutation(N)
+    R, S = hip.scan_fwd(_dev(q), _dev(k), _dev(v), _dev(a), _dev(b), rule=rule, flags=0)
+    Rp, Sp = hip.scan_fwd(_dev(q[:, :, perm]), _dev(k[:, :, perm]), _dev(v[:, :, perm]), _dev(a), _dev(b[:, :, perm]), rule=rule, flags=0)
+    scale = max(1.0, float(S.abs().max()))
+    assert torch.isfinite(S).all() and float(S.abs().max()) > 1e-2
+    assert float((Sp - S).abs().max()) <= 2e-4 * scale
+    assert float((Rp - R[:, :, torch.from_numpy(perm).cuda()]).abs().max()) <= 2e-4 * max(1.0, float(R.abs().max()))
+    if rule == 0 and N == 49:
+        R2, S2 = hip.scan_fwd(_dev(q), _dev(k), _dev(v), _dev(a), _dev(b), rule=2, flags=0)
+        R2p, S2p = hip.scan_fwd(_dev(q[:, :, perm]), _dev(k[:, :, perm]), _dev(v[:, :, perm]), _dev(a), _dev(b[:, :, perm]), rule=2, flags=0)
+        assert float((S2p - S2).abs().max()) > 1e-3       # (the sequential rule sees the order)
