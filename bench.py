@@ -963,7 +963,7 @@ def main():
         # that run, quoted with its file name, not a measurement of this one
         try:
             import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_train_cfg4_steady_state.csv")), key=os.path.getmtime)
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_train_cfg4_steady_state.csv")), key=_profile_order)
             if files and isinstance(out.get("train_step"), dict) and "error" not in out["train_step"]:
                 with open(files[-1]) as f:
                     lines = f.read().splitlines()
