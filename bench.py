@@ -872,6 +872,7 @@ def main():
                     wl["configs[2] graph"] = {"error": f"{type(e).__name__}: {e}"[:200]}
                 del m3, f3, lg3, mask32, mask16
                 f5 = torch.rand(2, 512, 3, 256, 256, device=dev).to(torch.bfloat16)
+                # (round 6: the next chunk's encoder + projections run beside the current chunk's memory path and decoder -- model.PipelinedClip)
                 wl["configs[4] 2x512x256x256, 16 chunks of 32 frames, state carried"] = module_rate(lambda: model.segment_clip(f5, 32, graph=True), 1024)
                 model.cfg.scan_segments = 0
                 try:

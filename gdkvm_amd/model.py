@@ -145,6 +145,9 @@ _TRAIN_HEAD_HIP = os.environ.get("GDKVM_TRAIN_HEAD_HIP", "1") != "0"
 _TRAIN_CONV_FORK = os.environ.get("GDKVM_TRAIN_CONV_FORK", "1") != "0"
 # training: a strided block's 3x3 / stride-2 convolution + 1x1 branch on csrc/conv_s2_train.hip (deterministic); "0" = the library convolutions (A/B switch)
 _TRAIN_CONV_S2 = os.environ.get("GDKVM_TRAIN_CONV_S2", "1") != "0"
+# segment_clip(graph=True): the next chunk's encoder + projections beside the current chunk's memory path and decoder (PipelinedClip); "0" = one
+# whole-forward graph per chunk, chunks strictly one after the other (A/B switch; same bits)
+_CLIP_PIPELINE = os.environ.get("GDKVM_CLIP_PIPELINE", "1") != "0"
 # training: key / query / value / gate projections as one stacked product (ops.token_projections); "0" = one product each (A/B switch)
 _TRAIN_PROJ_STACKED = os.environ.get("GDKVM_TRAIN_PROJ_STACKED", "1") != "0"
 
@@ -827,7 +830,17 @@ class GDKVM(nn.Module):
         Hh, Dk, Dv = cfg.heads, cfg.key_dim, cfg.value_dim
         h, w = f16.shape[-2:]
         N = h * w
-        p_tok, k_tok, q, v, alpha, beta, norms = self._project(f16, B, T, mask0)
+        return self._after_projection(f4, f8, f16, self._project(f16, B, T, mask0), state, return_state, _lowres, dims, _head_fused)
+
+    def _after_projection(self, f4, f8, f16, projected, state, return_state, _lowres, dims, _head_fused=False):
+        """Everything that depends on the memory state: the scan (read + write), KPFF, the decoder.  Split from _after_encoder so that a long
+        clip's NEXT chunk can run its encoder and projections beside this (PipelinedClip)."""
+        cfg = self.cfg
+        B, T, H, W = dims
+        Hh, Dk, Dv = cfg.heads, cfg.key_dim, cfg.value_dim
+        h, w = f16.shape[-2:]
+        N = h * w
+        p_tok, k_tok, q, v, alpha, beta, norms = projected
         if norms is not None and not cfg.normalizer:
             r, s_out = self._memory_scan(q, k_tok.reshape(B, T, N, Hh, Dk), v, alpha, beta, state, norms=norms)
         else:
@@ -1004,6 +1017,12 @@ class GDKVM(nn.Module):
         s_out = None
         if return_state:
             lowres, s_out = lowres
+        out = self._masks_of(lowres, (B, T, H, W), tgt, mo, co)
+        return out + (s_out,) if return_state else out
+
+    def _masks_of(self, lowres, dims, tgt, mo, co):
+        """The last step of segment(): stride-4 logits (or the feature under the head) -> (mask [B,T,H,W], counts [B,T,ncls,3] | None)."""
+        B, T, H, W = dims
         if isinstance(lowres, HeadFeature):
             # head + upsample + argmax + Dice in one kernel: the class planes never reach memory (bit-identical to the two-kernel form)
             mask, counts = ops.head_upsample_argmax_dice(lowres.feature, lowres.weight, lowres.bias, H, W, tgt, mo, co)
@@ -1011,8 +1030,31 @@ class GDKVM(nn.Module):
         else:
             ncls, hl, wl = lowres.shape[2:]
             mask, counts = ops.upsample_argmax_dice(lowres.reshape(B * T, ncls, hl, wl).contiguous(), H, W, tgt, mo, co)
-        out = (mask.reshape(B, T, H, W), (None if counts is None else counts.reshape(B, T, ncls, 3)))
-        return out + (s_out,) if return_state else out
+        return (mask.reshape(B, T, H, W), (None if counts is None else counts.reshape(B, T, ncls, 3)))
+
+    def _encode_project(self, frames):
+        """The state-INDEPENDENT part of the inference forward of [B,T,C,H,W] frames: encoder and projections (what forward() does up to
+        _after_projection).  Returns (f4, f8, f16, projected)."""
+        if self.training or self.cfg.mask_feedback:
+            raise RuntimeError("_encode_project serves the inference forward in scan mode")
+        B, T, C, H, W = frames.shape
+        x = frames.reshape(B * T, C, H, W)
+        dt = self.key_proj.weight.dtype
+        stem0 = self.encoder.stem[0]
+        if x.is_cuda and isinstance(stem0, FusedConvPool) and getattr(stem0, "w_s2d", None) is not None:
+            x = x.to(dt)                                                         # (as forward(): the stem kernels read NCHW frames themselves)
+        else:
+            x = x.to(dtype=dt, memory_format=torch.channels_last)
+        f4, f8, f16 = self.encoder(x)
+        return f4, f8, f16, self._project(f16, B, T, None)
+
+    def _segment_from_features(self, feats, state, dims, target=None):
+        """segment(..., state=, return_state=True) from _encode_project's result: (mask, counts | None, state after the last frame)."""
+        B, T, H, W = dims
+        f4, f8, f16, projected = feats
+        lowres, s_out = self._after_projection(f4, f8, f16, projected, state, True, True, dims, True)
+        tgt = None if target is None else target.reshape(B * T, H, W).contiguous()
+        return self._masks_of(lowres, dims, tgt, None, None) + (s_out,)
 
     @torch.no_grad()
     def segment_clip(self, frames, chunk_frames: int, target=None, mask0=None, state=None, graph: bool = False):
@@ -1035,12 +1077,20 @@ class GDKVM(nn.Module):
             key = (B, chunk_frames) + tuple(frames.shape[2:]) + (frames.dtype, target is not None, frames.device, cfg.rule, cfg.scan_segments,
                                                                    _epoch_of(self), self.__dict__.get("_pack_epoch", 0))
             cache = self.__dict__.setdefault("_clip_graphs", {})
-            for old in [k_ for k_ in cache if k_[:-2] == key[:-2] and k_ != key]:
+            for old in [k_ for k_ in cache if k_[:-3] == key[:-2] and k_[:-1] != key]:
                 del cache[old]                              # the same shape under older weights: never replayed again
+            pipelined = (_CLIP_PIPELINE and not cfg.mask_feedback and T // chunk_frames >= 2
+                         and (state is None or state.shape[-1] == cfg.value_dim + int(cfg.normalizer)))
+            key = key + (pipelined,)
             if key not in cache:
-                s0 = torch.zeros((B, cfg.heads, cfg.key_dim, cfg.value_dim), dtype=torch.float32, device=frames.device)
-                cache[key] = GraphedSegment(self, frames[:, :chunk_frames].clone(), None if target is None else target[:, :chunk_frames].clone(), state=s0)
+                if pipelined:
+                    cache[key] = PipelinedClip(self, frames[:, :chunk_frames].clone(), None if target is None else target[:, :chunk_frames].clone())
+                else:
+                    s0 = torch.zeros((B, cfg.heads, cfg.key_dim, cfg.value_dim), dtype=torch.float32, device=frames.device)
+                    cache[key] = GraphedSegment(self, frames[:, :chunk_frames].clone(), None if target is None else target[:, :chunk_frames].clone(), state=s0)
             g = cache[key]
+            if pipelined:
+                return g(frames, target, state)
             cur = torch.zeros_like(g.state) if state is None else state
             for t0 in range(0, T, chunk_frames):
                 m, c, s_new = g(frames[:, t0:t0 + chunk_frames], None if target is None else target[:, t0:t0 + chunk_frames], state=cur)
@@ -1194,6 +1244,104 @@ class GraphedSegment:
             self.state.copy_(state, non_blocking=True)
         self.graph.replay()
         return self.out
+
+
+class PipelinedClip:
+    """GDKVM.segment_clip's chunk loop (a long clip as consecutive chunks with the memory state carried: BASELINE.json configs[4]) with the NEXT
+    chunk's encoder and projections running BESIDE the current chunk's memory path, KPFF, decoder and mask kernel (round 6).  Only the second
+    half depends on the state, and a chunk of a long clip is few frames of few clips -- kernels that leave most of the chip idle -- so the two
+    halves of consecutive chunks overlap: configs[4] (2 clips x 512 frames of 256 x 256 in 16 chunks) 12.3 -> 11.2 ms, one 112 x 112 clip of 256
+    frames 2.68 -> 2.07 ms, four 3.45 -> 2.80 (tools/clip_pipeline_probe.py, profiles/r06_at_clip_pipeline.txt; GDKVM_CLIP_PIPELINE=0 = one
+    whole-forward graph per chunk).  Two captured "front" graphs (encoder + projections, double-buffered outputs, a stream of their own) and two
+    "back" graphs (scan with the state carried, KPFF, decoder, masks + Dice counts; the caller's stream), tied by events:
+        front(i + 1) waits for back(i - 1) (which read the buffers front(i + 1) overwrites);  back(i) waits for front(i).
+    The same kernels on the same operands in the same order per chunk: masks, counts and the final state are segment_clip's, bit for bit."""
+
+    def __init__(self, model: "GDKVM", frames: torch.Tensor, target: Optional[torch.Tensor] = None, warmup: int = 2):
+        if not frames.is_cuda:
+            raise RuntimeError("PipelinedClip needs device tensors")
+        cfg, dev = model.cfg, frames.device
+        B, Tc, _, H, W = frames.shape
+        self.model, self.shape, self.dtype, self.has_target = model, tuple(frames.shape), frames.dtype, target is not None
+        self.dims = (B, Tc, H, W)
+        self.state = torch.zeros((B, cfg.heads, cfg.key_dim, cfg.value_dim + int(cfg.normalizer)), dtype=torch.float32, device=dev)
+        self.fin = [frames.clone(), frames.clone()]
+        self.tgt = [None, None] if target is None else [target.clone(), target.clone()]
+        self.front_stream = torch.cuda.Stream(device=dev)
+        mode = {}
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            mode["capture_error_mode"] = "thread_local"
+        with torch.no_grad():
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):          # (weight packs, kernel attributes, workspaces: nothing may be built inside a capture)
+                    model._segment_from_features(model._encode_project(self.fin[0]), self.state, self.dims, self.tgt[0])
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.gfront, self.feats, self.gback, self.out = [], [], [], []
+            for j in range(2):                           # front graphs: a pool EACH -- in a shared pool the second capture places its outputs where
+                g = torch.cuda.CUDAGraph()               # the first keeps scratch, and front(i + 2) would write over what back(i + 1) still reads
+                with torch.cuda.graph(g, **mode):
+                    f = model._encode_project(self.fin[j])
+                self.gfront.append(g)
+                self.feats.append(f)
+            for j in range(2):                           # back graphs: a pool of their own (a back graph runs while a front graph does)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, **(mode if not self.gback else dict(mode, pool=self.gback[0].pool()))):
+                    o = model._segment_from_features(self.feats[j], self.state, self.dims, self.tgt[j])
+                self.gback.append(g)
+                self.out.append(o)
+        self._held = _packs_held(model)
+        self._epochs = (_epoch_of(model), model.__dict__.get("_pack_epoch", 0))
+
+    @torch.no_grad()
+    def __call__(self, frames: torch.Tensor, target: Optional[torch.Tensor] = None, state: Optional[torch.Tensor] = None):
+        """frames [B, n * chunk, C, H, W] -> (mask [B,T,H,W], counts | None, state after the last frame)."""
+        B, Tc = self.shape[:2]
+        if (frames.shape[0] != B or tuple(frames.shape[2:]) != self.shape[2:] or frames.dtype != self.dtype or frames.shape[1] % Tc
+                or (target is None) != (not self.has_target)):
+            raise RuntimeError(f"PipelinedClip was captured for chunks of {self.shape} {self.dtype}{' with a target' if self.has_target else ''}")
+        if self._epochs != (_epoch_of(self.model), self.model.__dict__.get("_pack_epoch", 0)):
+            raise RuntimeError("PipelinedClip: the model's weights or weight packs changed since the capture -- capture a new one")
+        dev = frames.device
+        cur, fs = torch.cuda.current_stream(dev), self.front_stream
+        n = frames.shape[1] // Tc
+        if state is None:
+            self.state.zero_()
+        else:
+            self.state.copy_(state, non_blocking=True)
+        fs.wait_stream(cur)                              # the clip is ready as far as the caller's stream knows
+        front_done, back_done = [None, None], [None, None]
+
+        def launch_front(i):
+            j = i % 2
+            with torch.cuda.stream(fs):
+                if back_done[j] is not None:
+                    fs.wait_event(back_done[j])          # back(i - 2) read the buffers this replay overwrites
+                self.fin[j].copy_(frames[:, i * Tc:(i + 1) * Tc], non_blocking=True)
+                self.gfront[j].replay()
+                front_done[j] = torch.cuda.Event()
+                front_done[j].record(fs)
+
+        masks, counts = [], []
+        launch_front(0)
+        for i in range(n):
+            j = i % 2
+            if i + 1 < n:
+                launch_front(i + 1)                      # queued BEFORE this chunk's second half: it runs beside it
+            cur.wait_event(front_done[j])
+            if target is not None:
+                self.tgt[j].copy_(target[:, i * Tc:(i + 1) * Tc], non_blocking=True)
+            self.gback[j].replay()
+            m, c, s_new = self.out[j]
+            self.state.copy_(s_new, non_blocking=True)   # (the next chunk's back graph reads the one state buffer)
+            masks.append(m.clone())
+            counts.append(None if c is None else c.clone())
+            back_done[j] = torch.cuda.Event()
+            back_done[j].record(cur)
+        cur.wait_stream(fs)
+        return torch.cat(masks, 1), (None if target is None else torch.cat(counts, 1)), self.state.clone()
 
 
 class InFlightSegments:

@@ -298,6 +298,19 @@ def test_cfg5_module_long_clip_in_chunks_with_the_state_carried(hip):
     for _ in range(2):
         mg, cg, sg = fused.segment_clip(fr, 32, target=tgt, graph=True)
         assert torch.equal(mg, m32) and torch.equal(cg, c32) and torch.equal(sg, s32)
+    # (round 6) that form runs the NEXT chunk's encoder and projections beside the current chunk's memory path and decoder (PipelinedClip);
+    # the strictly sequential form (one whole-forward graph per chunk) gives the same bits, and so does a clip continued from a carried state
+    import gdkvm_amd.model as M
+    assert any(isinstance(v_, M.PipelinedClip) for v_ in fused.__dict__["_clip_graphs"].values())
+    M._CLIP_PIPELINE = False
+    try:
+        mq, cq, sq = fused.segment_clip(fr, 32, target=tgt, graph=True)
+    finally:
+        M._CLIP_PIPELINE = True
+    assert torch.equal(mq, m32) and torch.equal(cq, c32) and torch.equal(sq, s32)
+    m_a, _, s_a = fused.segment_clip(fr[:, :256], 32, graph=True)
+    m_b, _, s_b = fused.segment_clip(fr[:, 256:], 32, state=s_a, graph=True)
+    assert torch.equal(torch.cat([m_a, m_b], 1), m32) and torch.equal(s_b, s32)
     agree = (m32[:1, :2].cpu().long() == lp.argmax(2)).float().mean().item()
     assert agree >= 0.96, agree
     # one call over the whole clip with the time axis cut into concurrent segments: the library's choice for this shape is 16
