@@ -788,6 +788,28 @@ def main():
                 del mfb, g_fb
             except Exception as e:                              # noqa: BLE001 -- informational leg
                 out["step_mode"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            # ---- latency of a SMALL request (a serving loop's other figure): one clip, and four, of T frames as one hipGraph replay with the host
+            # waiting for the masks (median of 30; the throughput figures above never wait)
+            try:
+                lat = {}
+                for nc in (1, 4):
+                    fl = frames[:nc].clone()
+                    g_l = model.graphed_segment(fl, streams=1)
+                    for _ in range(5):
+                        g_l(fl)
+                    torch.cuda.synchronize()
+                    ts = []
+                    for _ in range(30):
+                        t_l = time.perf_counter()
+                        g_l(fl)
+                        torch.cuda.synchronize()
+                        ts.append(1e3 * (time.perf_counter() - t_l))
+                    ts.sort()
+                    lat[f"{nc} clip(s) x {T} frames"] = {"ms": round(ts[len(ts) // 2], 3), "frames_per_s": round(nc * T / (ts[len(ts) // 2] * 1e-3), 1)}
+                    del g_l, fl
+                out["request_latency"] = dict(lat, what="segment() of a small request as one hipGraph replay, launch to masks on the host's clock")
+            except Exception as e:                              # noqa: BLE001 -- informational leg
+                out["request_latency"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         # the same fraction for the scan at the other BASELINE.json shapes that fit one GPU (informational, same timing method,
         # a few launches each): configs[2] CAMUS 256x256x20 (N = 256 tokens per frame) and configs[4], the 512-frame 256x256 clip
         # -- as one gdkvm_scan_fwd call, and as gdkvm_scan_fwd_segmented with the segment count it picks for that shape
