@@ -1182,7 +1182,17 @@ extern "C" int gdkvm_kpff_fwd_train(const void* local, const void* global, const
 #ifdef KPFF_FORCE_NT1                                           // ablation (tools/abl_kpff.py): one 64-token tile per four-wave workgroup, two workgroups per CU
         const bool pair = false;
 #else
-        const bool pair = 2 * lds1 <= 160 * 1024 && total_tiles >= 2;     // two 64-token tiles per 8-wave workgroup
+        // Up to one tile per CU (the per-frame step mode runs KPFF on ONE frame per clip; a group of clips of a forward split over streams): the
+        // kernel's time is one workgroup's latency, and a four-wave workgroup with ONE tile is done sooner than an eight-wave one with two --
+        // 24.3 against 25.7 us at 16 frames, 26.8 against 29.2 at 256, 34.1 against 30.2 at 320 (round 6; same bits).
+        // GDKVM_KPFF_SINGLE_BELOW=n: single-tile workgroups for fewer than n tiles (0 = never).
+        static const int single_below = [] {
+            if (const char* e = getenv("GDKVM_KPFF_SINGLE_BELOW")) return atoi(e);
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) return n + 1;
+            return 257;
+        }();
+        const bool pair = 2 * lds1 <= 160 * 1024 && total_tiles >= 2 && total_tiles >= single_below;     // two 64-token tiles per 8-wave workgroup
 #endif
         bf16_t* wab = static_cast<bf16_t*>(workspace);
         const size_t na = (size_t)2 * Cp * Cin, nl = (size_t)Cp * Ck;
